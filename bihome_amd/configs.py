@@ -1,0 +1,58 @@
+"""The kwargs contract of the two shipped biHomE experiments this build covers.
+
+Values (not text) of MODEL.BACKBONE / MODEL.HEAD / SOLVER from the reference's
+config/s-coco/zeng-bihome-lr-1e-3.yaml and config/s-coco/detone-bihome-lr-5e-3.yaml; the reference
+splats them as **kwargs into `Model.__init__` (train.py:679,690).  pds-coco differs only in the
+data transform (photometric max_delta 32 instead of 0).
+"""
+import copy
+
+ZENG_BIHOME = {
+    "MODEL": {
+        "BACKBONE": {
+            "NAME": "Rethinking", "VARIANT": "DoubleLine", "IMAGE_SIZE": 128, "RESNET_BLOCK": "ResNet34",
+            "PRETRAINED_RESNET": False,      # reference: True (ImageNet URL); no network here
+            "IMAGE_KEY": ["image"], "PATCH_KEYS": ["patch_1", "patch_2"],
+            "TARGET_KEYS": ["pf_hat_12", "pf_hat_21"],
+        },
+        "HEAD": {
+            "NAME": "PerceptualHead", "PATCH_SIZE": 128, "PATCH_KEYS": ["patch_1", "patch_2"],
+            "DELTA_HAT_KEYS": [], "PF_KEYS": ["pf_hat_12", "pf_hat_21"],
+            "RANSAC_HYPOTHESIS_NO": 1, "POINTS_PER_HYPOTHESIS": 128,
+            "AUXILIARY_RESNET": "resnet34", "AUXILIARY_RESNET_OUTPUT_LAYER": 1,
+            "TRIPLET_LOSS": "double-line", "TRIPLET_AGGREGATION": "channel-agnostic",
+            "TRIPLET_MARGIN": "inf", "TRIPLET_DISTANCE": "l1", "TRIPLET_MU": 0.01,
+            "MASK_KEYS": [], "SAMPLING_STRATEGY": "downsample-mask",
+        },
+    },
+    "SOLVER": {"OPTIMIZER": "Adam", "MOMENTUM_1": 0.9, "MOMENTUM_2": 0.999, "LR": 0.001,
+               "MILESTONES": [30000, 60000, 90000], "LR_DECAY": 0.1, "LOSS": "biHomE"},
+    "DATA": {"BATCH_SIZE": 64, "RHO": 32, "PATCH_SIZE": 128, "PHOTOMETRIC_MAX_DELTA": 0},
+}
+
+DETONE_BIHOME = {
+    "MODEL": {
+        "BACKBONE": {
+            "NAME": "ResNet34", "VARIANT": "DoubleLine", "PRETRAINED_RESNET": False,
+            "IMAGE_KEY": ["image"], "PATCH_KEYS": ["patch_1", "patch_2"],
+            "TARGET_KEYS": ["delta_hat_12", "delta_hat_21"],
+        },
+        "HEAD": {
+            "NAME": "PerceptualHead", "PATCH_SIZE": 128, "PATCH_KEYS": ["patch_1", "patch_2"],
+            "DELTA_HAT_KEYS": ["delta_hat_12", "delta_hat_21"], "PF_KEYS": [],
+            "RANSAC_HYPOTHESIS_NO": -1, "POINTS_PER_HYPOTHESIS": -1,
+            "AUXILIARY_RESNET": "resnet34", "AUXILIARY_RESNET_OUTPUT_LAYER": 1,
+            "TRIPLET_LOSS": "double-line", "TRIPLET_AGGREGATION": "channel-agnostic",
+            "TRIPLET_MARGIN": "inf", "TRIPLET_DISTANCE": "l1", "TRIPLET_MU": 0.01,
+            "MASK_KEYS": [], "SAMPLING_STRATEGY": "downsample-mask",
+        },
+    },
+    "SOLVER": {"OPTIMIZER": "Adam", "MOMENTUM_1": 0.9, "MOMENTUM_2": 0.999, "LR": 0.005,
+               "MILESTONES": [30000, 60000, 90000], "LR_DECAY": 0.1, "LOSS": "biHomE"},
+    "DATA": {"BATCH_SIZE": 64, "RHO": 32, "PATCH_SIZE": 128, "PHOTOMETRIC_MAX_DELTA": 0},
+}
+
+
+def get(name):
+    cfg = {"zeng-bihome": ZENG_BIHOME, "detone-bihome": DETONE_BIHOME}[name]
+    return copy.deepcopy(cfg)

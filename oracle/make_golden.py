@@ -1,0 +1,262 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own model files in the build container.
+
+TEST INFRASTRUCTURE ONLY.  Runs only where /root/reference exists (never on the GPU box).  The
+reference's src/backbones/{Rethinking,ResNet34,utils}.py, src/heads/{PerceptualHead,ransac_utils}.py
+and src/data/utils.py are imported verbatim from /root/reference after registering three stand-ins
+for third-party packages that are absent offline (oracle/refshim/: kornia 0.5.0 - four functions
+restated from its published algorithm; torchvision.models - resnet18/34 definitions; cv2 - empty,
+the torch path never calls it).  All heavy arithmetic runs in real torch CPU ops.  Weights and
+inputs are pure functions of seeds (bihome_amd/weights.py, bihome_amd/synth.py) so the tests
+regenerate them instead of storing them; only small outputs are stored.
+
+    python oracle/make_golden.py            # writes tests/golden/{zeng_b8,head_b8,dsac_n4,detone_b4}.npz
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("BIHOME_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+
+
+def install_standins():
+    from oracle.refshim import kornia_standin, torchvision_standin
+    sys.modules["kornia"] = kornia_standin
+    tv = types.ModuleType("torchvision")
+    tv.models = torchvision_standin
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.models"] = torchvision_standin
+    sys.modules["cv2"] = types.ModuleType("cv2")
+    # the reference package is `src`; the build's drop-in shims are ALSO `src.*`, so make sure the
+    # reference's is the one imported in this process
+    if REF in sys.path:
+        sys.path.remove(REF)
+    sys.path.insert(0, REF)
+
+
+class RecordMultinomial:
+    """Wrap torch.multinomial to record the sampled indices (ransac_utils.py:54-57)."""
+
+    def __init__(self):
+        self.calls = []
+        self._orig = torch.multinomial
+
+    def __enter__(self):
+        def wrapped(*a, **k):
+            out = self._orig(*a, **k)
+            self.calls.append(out.clone())
+            return out
+        torch.multinomial = wrapped
+        return self
+
+    def __exit__(self, *exc):
+        torch.multinomial = self._orig
+
+
+def t(x, dtype=torch.float32):
+    return torch.from_numpy(np.asarray(x)).to(dtype)
+
+
+def sub(a, step=8):
+    return a[..., ::step, ::step].detach().double().numpy()
+
+
+def csum(a):
+    a = a.detach().double()
+    return np.array([a.sum().item(), a.abs().sum().item(), (a * a).sum().item()])
+
+
+def run_head_scenario(ref_head_cls, cfg, dtype, batch=8, seed=7):
+    """Head only (biHomE double-line) on given pf fields. Returns dict of outputs."""
+    from bihome_amd import synth
+    from bihome_amd.weights import load_synthetic
+    head = ref_head_cls(torch.nn.Identity(), **cfg["MODEL"]["HEAD"]).to(dtype)
+    load_synthetic(head.auxiliary_resnet, seed=0)
+    head.to(dtype).train()
+    d = synth.make_head_inputs(batch, seed)
+    data = {k: t(d[k], dtype) for k in ("patch_1", "patch_2", "delta", "pf_hat_12", "pf_hat_21")}
+    data["pf_hat_12"].requires_grad_(True)
+    data["pf_hat_21"].requires_grad_(True)
+    torch.manual_seed(1234)
+    with RecordMultinomial() as rec:
+        loss, delta_gt, delta_hat = head(data)
+    loss.backward()
+    out = {"choice_12": rec.calls[0].reshape(batch, -1).numpy(), "choice_21": rec.calls[1].reshape(batch, -1).numpy(),
+           "loss": np.float64(loss.item()), "delta_hat_12": delta_hat.detach().double().numpy(),
+           "grad_pf12_csum": csum(data["pf_hat_12"].grad), "grad_pf21_csum": csum(data["pf_hat_21"].grad)}
+    # sparse gradient: store nonzero entries' positions & values compactly (<= 128 per sample per dir)
+    for name in ("pf_hat_12", "pf_hat_21"):
+        g = data[name].grad.detach().double().numpy()
+        out["grad_" + name + "_sub"] = g[:, :, ::4, ::4]
+    # intermediates, recomputed through the reference's own helper methods with the recorded choice
+    import kornia
+    with torch.no_grad():
+        for tag, pfk, ch in (("12", "pf_hat_12", rec.calls[0]), ("21", "pf_hat_21", rec.calls[1])):
+            mf, cf, fp = head.forward_map_field(data[pfk], None, None)
+            choice = ch.reshape(batch, -1, 1).repeat(1, 1, 2)
+            H = kornia.find_homography_dlt(torch.gather(cf, 1, choice), torch.gather(mf, 1, choice))
+            dh = kornia.transform_points(H, fp) - fp
+            out["H_dlt_" + tag] = H.double().numpy()
+            out["delta_hat_" + tag] = dh.double().numpy()
+            src = "patch_1" if tag == "12" else "patch_2"
+            pw, h4 = head._warp(data[src], delta_hat=dh)
+            mw, _ = head._warp(torch.ones_like(data[src]), delta_hat=dh)
+            out["H_4pt_" + tag] = h4.double().numpy()
+            out["warp_sub_" + tag] = sub(pw, 4)
+            out["warp_csum_" + tag] = csum(pw)
+            out["mask_pooled_" + tag] = torch.nn.AvgPool2d(4, 4)(mw).squeeze(1).double().numpy()
+        # features: extractor is in train mode (batch statistics) exactly as in the training step;
+        # calling it here would also move running stats, so use a deep copy
+        import copy
+        aux = copy.deepcopy(head.auxiliary_resnet)
+        out["feat_p1_csum"] = csum(aux(data["patch_1"]))
+    mace = np.mean(np.linalg.norm(delta_gt.numpy().reshape(-1, 2) - delta_hat.detach().numpy().reshape(-1, 2), axis=-1))
+    out["mace"] = np.float64(mace)
+    out["aux_bn1_running_mean"] = head.auxiliary_resnet.resnet.bn1.running_mean.double().numpy()
+    out["aux_bn1_running_var"] = head.auxiliary_resnet.resnet.bn1.running_var.double().numpy()
+    return out
+
+
+def run_zeng_scenario(ref_bb_cls, ref_head_cls, cfg, dtype, batch=8, seed=42, steps=3):
+    """End to end: Rethinking backbone + biHomE head, `steps` Adam steps on one fixed batch."""
+    from bihome_amd import synth
+    from bihome_amd.weights import load_synthetic
+    bb = ref_bb_cls(**cfg["MODEL"]["BACKBONE"])
+    head = ref_head_cls(bb, **cfg["MODEL"]["HEAD"])
+    load_synthetic(bb, seed=0)
+    load_synthetic(head.auxiliary_resnet, seed=0)
+    model = torch.nn.Sequential(bb, head).to(dtype)
+    s = cfg["SOLVER"]
+    opt = torch.optim.Adam(model.parameters(), lr=s["LR"], betas=(s["MOMENTUM_1"], s["MOMENTUM_2"]), weight_decay=0)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=s["MILESTONES"], gamma=s["LR_DECAY"])
+    d = synth.make_pairs(batch, seed=seed)
+    out = {"loss": [], "mace": [], "gnorm": [], "choice_12": [], "choice_21": []}
+    model.train()                                                       # train.py:296
+    for it in range(steps):
+        opt.zero_grad()                                                 # train.py:305
+        data = {k: t(d[k], dtype) for k in ("patch_1", "patch_2", "delta")}
+        torch.manual_seed(1000 + it)
+        with RecordMultinomial() as rec:
+            loss, delta_gt, delta_hat = model(data)                     # train.py:357
+        if it == 0:
+            data["pf_hat_12"].retain_grad()
+        loss.backward()                                                 # train.py:379
+        if it == 0:
+            out["pf_hat_12_sub"] = sub(data["pf_hat_12"], 8)
+            out["pf_hat_21_sub"] = sub(data["pf_hat_21"], 8)
+            out["pf_hat_12_csum"] = csum(data["pf_hat_12"])
+            out["delta_hat_12"] = delta_hat.detach().double().numpy()
+            out["grad_pf12_csum"] = csum(data["pf_hat_12"].grad)
+            for name in ("layer1.0.weight", "layer2.0.upper_branch.0.weight", "layer4.6.upper_branch.0.weight",
+                         "layer8.0.weight", "layer8.3.weight", "layer8.3.bias", "layer1.1.weight", "layer1.1.bias"):
+                p = dict(bb.named_parameters())[name]
+                out["gradnorm/" + name] = np.float64(p.grad.double().norm().item())
+            out["bn_layer1_running_mean"] = bb.layer1[1].running_mean.double().numpy()
+            out["bn_layer1_running_var"] = bb.layer1[1].running_var.double().numpy()
+        gn = sum(p.grad.double().norm().item() ** 2 for p in model.parameters() if p.grad is not None) ** 0.5
+        opt.step()
+        sched.step()                                                    # train.py:386-387
+        mace = np.mean(np.linalg.norm(delta_gt.numpy().reshape(-1, 2) -
+                                      delta_hat.detach().numpy().reshape(-1, 2), axis=-1))   # train.py:402-403
+        out["loss"].append(loss.item()); out["mace"].append(mace); out["gnorm"].append(gn)
+        out["choice_12"].append(rec.calls[0].reshape(batch, -1).numpy())
+        out["choice_21"].append(rec.calls[1].reshape(batch, -1).numpy())
+    # eval-mode prediction after the steps (eval.py:109 path: backbone.predict_homography -> head.predict_homography)
+    model.eval()
+    with torch.no_grad():
+        data = {k: t(d[k], dtype) for k in ("patch_1", "patch_2", "delta")}
+        torch.manual_seed(2000)
+        with RecordMultinomial() as rec:
+            dh, _ = head.predict_homography(bb.predict_homography(data))
+        out["eval_choice"] = rec.calls[0].reshape(batch, -1).numpy()
+        out["eval_delta_hat"] = dh.double().numpy()
+        out["eval_mace"] = np.float64(np.mean(np.linalg.norm(d["delta"].reshape(-1, 2) - dh.numpy().reshape(-1, 2), axis=-1)))
+    for k in ("loss", "mace", "gnorm", "choice_12", "choice_21"):
+        out[k] = np.asarray(out[k])
+    return out
+
+
+def run_dsac_n4(ref_head_cls, cfg, dtype, batch=8, seed=11):
+    """predict_homography with 4 hypotheses: known-answer for the argmin index (PerceptualHead.py:755-757)."""
+    import copy
+    c = copy.deepcopy(cfg)
+    c["MODEL"]["HEAD"]["RANSAC_HYPOTHESIS_NO"] = 4
+    c["MODEL"]["HEAD"]["POINTS_PER_HYPOTHESIS"] = 16
+    head = ref_head_cls(torch.nn.Identity(), **c["MODEL"]["HEAD"]).to(dtype).eval()
+    from bihome_amd import synth
+    d = synth.make_head_inputs(batch, seed, noise=2.0)
+    data = {"pf_hat_12": t(d["pf_hat_12"], dtype)}
+    torch.manual_seed(99)
+    with RecordMultinomial() as rec, torch.no_grad():
+        dh, _ = head.predict_homography(data)
+        mf, cf, fp = head.forward_map_field(data["pf_hat_12"], None, None)
+        torch.manual_seed(99)
+        Hs, scores = head.dsac(cf, mf, hypothesis_no=4, points_per_hypothesis=16)
+    err = -torch.log(scores)   # monotone in reprojection error; store raw errors recomputed below
+    import kornia
+    with torch.no_grad():
+        e = []
+        for j in range(4):
+            pt = kornia.transform_points(Hs[:, j], cf)
+            e.append((pt - mf).abs().sum(-1).sum(-1))
+        e = torch.stack(e, 1)
+    return {"choice": rec.calls[0].reshape(batch, -1).numpy(), "H": Hs.double().numpy(),
+            "repr_error": e.double().numpy(), "scores": scores.double().numpy(),
+            "best": torch.argmax(scores, -1).numpy(), "delta_hat": dh.double().numpy()}
+
+
+def run_detone_scenario(ref_bb_cls, ref_head_cls, cfg, dtype, batch=4, seed=5):
+    from bihome_amd import synth
+    from bihome_amd.weights import load_synthetic
+    bb = ref_bb_cls(**cfg["MODEL"]["BACKBONE"])
+    head = ref_head_cls(bb, **cfg["MODEL"]["HEAD"])
+    load_synthetic(bb, seed=0)
+    load_synthetic(head.auxiliary_resnet, seed=0)
+    # the fc layer's random init gives |delta| ~ 1; scale is irrelevant for parity
+    model = torch.nn.Sequential(bb, head).to(dtype).train()
+    d = synth.make_pairs(batch, seed=seed)
+    data = {k: t(d[k], dtype) for k in ("patch_1", "patch_2", "delta")}
+    loss, delta_gt, delta_hat = model(data)
+    loss.backward()
+    out = {"loss": np.float64(loss.item()), "delta_hat_12": delta_hat.detach().double().numpy(),
+           "delta_hat_21": data["delta_hat_21"].detach().double().numpy()}
+    for name in ("resnet34.conv1.weight", "resnet34.layer2.0.downsample.0.weight", "resnet34.fc.weight", "resnet34.fc.bias"):
+        out["gradnorm/" + name] = np.float64(dict(bb.named_parameters())[name].grad.double().norm().item())
+    return out
+
+
+def main():
+    install_standins()
+    import importlib
+    Rethinking = importlib.import_module("src.backbones.Rethinking")
+    ResNet34 = importlib.import_module("src.backbones.ResNet34")
+    PerceptualHead = importlib.import_module("src.heads.PerceptualHead")
+    assert os.path.realpath(Rethinking.__file__).startswith(os.path.realpath(REF)), Rethinking.__file__
+    from bihome_amd import configs
+    zeng, detone = configs.get("zeng-bihome"), configs.get("detone-bihome")
+    outdir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(outdir, exist_ok=True)
+    torch.set_num_threads(8)
+    import warnings
+    warnings.filterwarnings("ignore")
+    for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        r = run_head_scenario(PerceptualHead.Model, zeng, dtype)
+        np.savez_compressed(os.path.join(outdir, "head_b8_%s.npz" % tag), **r)
+        print("head", tag, "loss", r["loss"], "mace", r["mace"])
+        r = run_dsac_n4(PerceptualHead.Model, zeng, dtype)
+        np.savez_compressed(os.path.join(outdir, "dsac_n4_%s.npz" % tag), **r)
+        print("dsac", tag, "best", r["best"])
+        r = run_zeng_scenario(Rethinking.Model, PerceptualHead.Model, zeng, dtype)
+        np.savez_compressed(os.path.join(outdir, "zeng_b8_%s.npz" % tag), **r)
+        print("zeng", tag, "loss", r["loss"], "mace", r["mace"], "eval_mace", r["eval_mace"])
+        r = run_detone_scenario(ResNet34.Model, PerceptualHead.Model, detone, dtype)
+        np.savez_compressed(os.path.join(outdir, "detone_b4_%s.npz" % tag), **r)
+        print("detone", tag, "loss", r["loss"])
+
+
+if __name__ == "__main__":
+    main()
