@@ -62,7 +62,7 @@ def t(x, dtype=torch.float32):
 
 
 def sub(a, step=8):
-    return a[..., ::step, ::step].detach().double().numpy()
+    return a[..., ::step, ::step].detach().double().numpy().copy()
 
 
 def csum(a):
@@ -86,11 +86,11 @@ def run_head_scenario(ref_head_cls, cfg, dtype, batch=8, seed=7):
         loss, delta_gt, delta_hat = head(data)
     loss.backward()
     out = {"choice_12": rec.calls[0].reshape(batch, -1).numpy(), "choice_21": rec.calls[1].reshape(batch, -1).numpy(),
-           "loss": np.float64(loss.item()), "delta_hat_12": delta_hat.detach().double().numpy(),
+           "loss": np.float64(loss.item()), "delta_hat_12": delta_hat.detach().double().numpy().copy(),
            "grad_pf12_csum": csum(data["pf_hat_12"].grad), "grad_pf21_csum": csum(data["pf_hat_21"].grad)}
     # sparse gradient: store nonzero entries' positions & values compactly (<= 128 per sample per dir)
     for name in ("pf_hat_12", "pf_hat_21"):
-        g = data[name].grad.detach().double().numpy()
+        g = data[name].grad.detach().double().numpy().copy()
         out["grad_" + name + "_sub"] = g[:, :, ::4, ::4]
     # intermediates, recomputed through the reference's own helper methods with the recorded choice
     import kornia
@@ -100,15 +100,15 @@ def run_head_scenario(ref_head_cls, cfg, dtype, batch=8, seed=7):
             choice = ch.reshape(batch, -1, 1).repeat(1, 1, 2)
             H = kornia.find_homography_dlt(torch.gather(cf, 1, choice), torch.gather(mf, 1, choice))
             dh = kornia.transform_points(H, fp) - fp
-            out["H_dlt_" + tag] = H.double().numpy()
-            out["delta_hat_" + tag] = dh.double().numpy()
+            out["H_dlt_" + tag] = H.double().numpy().copy()
+            out["delta_hat_" + tag] = dh.double().numpy().copy()
             src = "patch_1" if tag == "12" else "patch_2"
             pw, h4 = head._warp(data[src], delta_hat=dh)
             mw, _ = head._warp(torch.ones_like(data[src]), delta_hat=dh)
-            out["H_4pt_" + tag] = h4.double().numpy()
+            out["H_4pt_" + tag] = h4.double().numpy().copy()
             out["warp_sub_" + tag] = sub(pw, 4)
             out["warp_csum_" + tag] = csum(pw)
-            out["mask_pooled_" + tag] = torch.nn.AvgPool2d(4, 4)(mw).squeeze(1).double().numpy()
+            out["mask_pooled_" + tag] = torch.nn.AvgPool2d(4, 4)(mw).squeeze(1).double().numpy().copy()
         # features: extractor is in train mode (batch statistics) exactly as in the training step;
         # calling it here would also move running stats, so use a deep copy
         import copy
@@ -116,8 +116,8 @@ def run_head_scenario(ref_head_cls, cfg, dtype, batch=8, seed=7):
         out["feat_p1_csum"] = csum(aux(data["patch_1"]))
     mace = np.mean(np.linalg.norm(delta_gt.numpy().reshape(-1, 2) - delta_hat.detach().numpy().reshape(-1, 2), axis=-1))
     out["mace"] = np.float64(mace)
-    out["aux_bn1_running_mean"] = head.auxiliary_resnet.resnet.bn1.running_mean.double().numpy()
-    out["aux_bn1_running_var"] = head.auxiliary_resnet.resnet.bn1.running_var.double().numpy()
+    out["aux_bn1_running_mean"] = head.auxiliary_resnet.resnet.bn1.running_mean.double().numpy().copy()
+    out["aux_bn1_running_var"] = head.auxiliary_resnet.resnet.bn1.running_var.double().numpy().copy()
     return out
 
 
@@ -149,14 +149,14 @@ def run_zeng_scenario(ref_bb_cls, ref_head_cls, cfg, dtype, batch=8, seed=42, st
             out["pf_hat_12_sub"] = sub(data["pf_hat_12"], 8)
             out["pf_hat_21_sub"] = sub(data["pf_hat_21"], 8)
             out["pf_hat_12_csum"] = csum(data["pf_hat_12"])
-            out["delta_hat_12"] = delta_hat.detach().double().numpy()
+            out["delta_hat_12"] = delta_hat.detach().double().numpy().copy()
             out["grad_pf12_csum"] = csum(data["pf_hat_12"].grad)
             for name in ("layer1.0.weight", "layer2.0.upper_branch.0.weight", "layer4.6.upper_branch.0.weight",
                          "layer8.0.weight", "layer8.3.weight", "layer8.3.bias", "layer1.1.weight", "layer1.1.bias"):
                 p = dict(bb.named_parameters())[name]
                 out["gradnorm/" + name] = np.float64(p.grad.double().norm().item())
-            out["bn_layer1_running_mean"] = bb.layer1[1].running_mean.double().numpy()
-            out["bn_layer1_running_var"] = bb.layer1[1].running_var.double().numpy()
+            out["bn_layer1_running_mean"] = bb.layer1[1].running_mean.double().numpy().copy()
+            out["bn_layer1_running_var"] = bb.layer1[1].running_var.double().numpy().copy()
         gn = sum(p.grad.double().norm().item() ** 2 for p in model.parameters() if p.grad is not None) ** 0.5
         opt.step()
         sched.step()                                                    # train.py:386-387
@@ -173,7 +173,7 @@ def run_zeng_scenario(ref_bb_cls, ref_head_cls, cfg, dtype, batch=8, seed=42, st
         with RecordMultinomial() as rec:
             dh, _ = head.predict_homography(bb.predict_homography(data))
         out["eval_choice"] = rec.calls[0].reshape(batch, -1).numpy()
-        out["eval_delta_hat"] = dh.double().numpy()
+        out["eval_delta_hat"] = dh.double().numpy().copy()
         out["eval_mace"] = np.float64(np.mean(np.linalg.norm(d["delta"].reshape(-1, 2) - dh.numpy().reshape(-1, 2), axis=-1)))
     for k in ("loss", "mace", "gnorm", "choice_12", "choice_21"):
         out[k] = np.asarray(out[k])
@@ -204,9 +204,9 @@ def run_dsac_n4(ref_head_cls, cfg, dtype, batch=8, seed=11):
             pt = kornia.transform_points(Hs[:, j], cf)
             e.append((pt - mf).abs().sum(-1).sum(-1))
         e = torch.stack(e, 1)
-    return {"choice": rec.calls[0].reshape(batch, -1).numpy(), "H": Hs.double().numpy(),
-            "repr_error": e.double().numpy(), "scores": scores.double().numpy(),
-            "best": torch.argmax(scores, -1).numpy(), "delta_hat": dh.double().numpy()}
+    return {"choice": rec.calls[0].reshape(batch, -1).numpy(), "H": Hs.double().numpy().copy(),
+            "repr_error": e.double().numpy().copy(), "scores": scores.double().numpy().copy(),
+            "best": torch.argmax(scores, -1).numpy(), "delta_hat": dh.double().numpy().copy()}
 
 
 def run_detone_scenario(ref_bb_cls, ref_head_cls, cfg, dtype, batch=4, seed=5):
@@ -222,8 +222,8 @@ def run_detone_scenario(ref_bb_cls, ref_head_cls, cfg, dtype, batch=4, seed=5):
     data = {k: t(d[k], dtype) for k in ("patch_1", "patch_2", "delta")}
     loss, delta_gt, delta_hat = model(data)
     loss.backward()
-    out = {"loss": np.float64(loss.item()), "delta_hat_12": delta_hat.detach().double().numpy(),
-           "delta_hat_21": data["delta_hat_21"].detach().double().numpy()}
+    out = {"loss": np.float64(loss.item()), "delta_hat_12": delta_hat.detach().double().numpy().copy(),
+           "delta_hat_21": data["delta_hat_21"].detach().double().numpy().copy()}
     for name in ("resnet34.conv1.weight", "resnet34.layer2.0.downsample.0.weight", "resnet34.fc.weight", "resnet34.fc.bias"):
         out["gradnorm/" + name] = np.float64(dict(bb.named_parameters())[name].grad.double().norm().item())
     return out
