@@ -1,0 +1,75 @@
+"""ctypes binding of libbihome_hip.so (the C ABI declared in include/bihome.h).
+
+The product path has no CPU fallback: if the shared library is missing or does not export a symbol
+the import fails loudly.  `python __graft_entry__.py build` (or `make -C bihome_amd/csrc`) builds it.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbihome_hip.so")
+
+
+class BhConvDesc(Structure):
+    _fields_ = [(n, c_int) for n in ("N", "Hi", "Wi", "Ci", "Ho", "Wo", "Co", "kh", "kw", "stride", "pad",
+                                     "transposed", "in_nchw", "out_nchw")]
+
+
+P = c_void_p
+# name -> argtypes (all return int).  Must list every symbol include/bihome.h declares.
+SIGNATURES = {
+    "bh_version": [],
+    "bh_device_arch": [c_char_p, c_int],
+    "bh_h4pt_fwd": [P, c_int, c_float, c_float, P, P, P],
+    "bh_h4pt_bwd": [P, P, P, c_int, c_float, c_float, P, P],
+    "bh_dlt_fwd": [P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P],
+    "bh_dlt_bwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P],
+    "bh_dsac_score": [P, P, c_int, c_int, c_int, c_int, P, P, P],
+    "bh_warp_fwd": [P, P, c_int, c_int, c_int, c_int, c_int, P, P, P],
+    "bh_warp_bwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P],
+    "bh_triplet_l1_fwd": [P] * 8 + [c_int, c_int, c_int, P, P, P, P],
+    "bh_bihome_loss_fwd": [P, P, P, c_int, c_float, P, P],
+    "bh_bihome_loss_bwd": [P] * 14 + [c_int, c_int, c_int, c_float] + [P] * 6 + [P],
+    "bh_conv_fwd": [P, P, P, P, POINTER(BhConvDesc), P],
+    "bh_conv_dgrad": [P, P, P, POINTER(BhConvDesc), c_int, P],
+    "bh_conv_wgrad": [P, P, P, P, POINTER(BhConvDesc), P],
+    "bh_bn_fwd": [P] * 8 + [c_int, c_int, c_int, c_float, c_float, c_int, c_int, P],
+    "bh_bn_bwd": [P] * 10 + [c_int, c_int, c_int, c_float, c_int, c_int, P, P, P],
+    "bh_maxpool3s2_fwd": [P, P, c_int, c_int, c_int, c_int, P],
+    "bh_maxpool3s2_bwd": [P, P, P, c_int, c_int, c_int, c_int, P],
+    "bh_gap_fwd": [P, P, c_int, c_int, c_int, P],
+    "bh_gap_bwd": [P, P, c_int, c_int, c_int, P],
+    "bh_add": [P, P, P, c_int64, P],
+}
+
+
+class BihomeLibError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise BihomeLibError(
+            "bihome_amd: %s not found - the HIP extension is not built. Run `python __graft_entry__.py build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            if os.environ.get("BIHOME_DEV_PARTIAL") == "1":      # development only: library under construction
+                continue
+            raise BihomeLibError("bihome_amd: %s does not export %s (stale build?)" % (LIB_PATH, name)) from e
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: "BH_E_BADARG", -2: "BH_E_UNSUPPORTED"}.get(rc, "hipError_t %d" % rc)
+        raise BihomeLibError("%s failed: %s" % (what, kind))

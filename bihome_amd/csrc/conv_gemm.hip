@@ -1,0 +1,369 @@
+// Implicit-GEMM convolution on the gfx950 f32-input MFMA (v_mfma_f32_32x32x2_f32: exact fp32
+// products, fp32 accumulate, 64 FLOP/clk/SIMD).
+//
+//   Out[m][n] = sum_{tap t} sum_{c < Kc}  Src[pix(m, t)][c] * Bw[t][c][n]      (+ bias[n])
+//
+// m runs over the output-side pixel grid [N, Ho, Wo]; pix() gathers from an NHWC source tensor with
+// either the forward rule  (iy = oy*s - p + ky)  or the adjoint rule  (iy = (oy + p - ky)/s when
+// divisible).  With the right (Src, Bw strides, epilogue) this one kernel is Conv2d forward, Conv2d
+// dgrad, ConvTranspose2d(k == s) forward (M = input pixels, N = taps*Co, scatter epilogue) and its
+// dgrad.  Feature maps are NHWC so a tap's Kc channels are one contiguous 16 B-vectorisable run.
+//
+// Block = 256 threads (4 waves), tile BM=128 pixels x BN channels x BK=32 (or 16) reduction channels.
+// A and B tiles are staged k-major in LDS ([BK][BM+1]: the transposed ds_write_b32 pattern and the
+// ds_read_b32 fragment reads are both bank-conflict free), global loads for tile i+1 are issued
+// before the MFMAs of tile i (register prefetch), one barrier pair per tile.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+    const float* Src;
+    const float* Bw;
+    const float* bias;
+    float* Out;
+    int M, Nn, Kc, T;
+    int Ho, Wo;            // output-side pixel grid
+    int Hs, Ws, Cs;        // source grid and its channel count
+    int kw, stride, pad;
+    int adjoint;           // 0: forward gather, 1: adjoint (dgrad of a strided conv) gather
+    int src_nchw;          // scalar path, channels are planes
+    long long sBt, sBc, sBn;
+    int b_kcontig;         // 1: sBc == 1, 0: sBn == 1
+    int epi;               // 0: NHWC [M][Nn]; 1: ConvTranspose scatter; 2: NCHW
+    int accumulate;        // Out += result
+    int ek, eC;            // scatter: kernel (== stride) and real channel count (Nn = ek*ek*eC)
+};
+
+#define BM 128
+
+__device__ __forceinline__ bool src_coord(const GemmArgs& a, int oy, int ox, int t, int& iy, int& ix) {
+    const int ky = t / a.kw, kx = t - ky * a.kw;
+    if (!a.adjoint) {
+        iy = oy * a.stride - a.pad + ky;
+        ix = ox * a.stride - a.pad + kx;
+    } else {
+        int ty = oy + a.pad - ky, tx = ox + a.pad - kx;
+        if (ty < 0 || tx < 0) return false;
+        if (a.stride > 1) {
+            if ((ty % a.stride) || (tx % a.stride)) return false;
+            ty /= a.stride; tx /= a.stride;
+        }
+        iy = ty; ix = tx;
+    }
+    return iy >= 0 && iy < a.Hs && ix >= 0 && ix < a.Ws;
+}
+
+template <int BN, int BK, bool VEC>
+__global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
+    constexpr int WN = (BN >= 64) ? 2 : 1;         // waves along N
+    constexpr int WM = 4 / WN;                     // waves along M
+    constexpr int TM = BM / (WM * 32);             // 32x32 MFMA tiles per wave along M
+    constexpr int TN = BN / (WN * 32);
+    constexpr int LDA = BM + 1;
+    constexpr int LDB_K = BN + 1, LDB_N = BN + 4;
+    constexpr int CH = BK / 4;                     // float4 chunks per tile row
+    constexpr int AROWS = 256 / CH;                // rows covered per pass
+    constexpr int AIT = BM / AROWS;
+    constexpr int BIT_K = (BN + AROWS - 1) / AROWS;   // K-contiguous B: rows = n
+    __shared__ float As[BK * LDA];
+    __shared__ float Bs[BK * LDB_N];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+    // ---- per-thread A rows (fixed for the whole K loop) ----
+    const int a_chunk = tid % CH, a_row0 = tid / CH;
+    int a_n[AIT], a_oy[AIT], a_ox[AIT];
+    bool a_ok[AIT];
+#pragma unroll
+    for (int i = 0; i < AIT; ++i) {
+        int m = m0 + a_row0 + i * AROWS;
+        a_ok[i] = m < a.M;
+        int mm = a_ok[i] ? m : 0;
+        int hw = a.Ho * a.Wo;
+        a_n[i] = mm / hw;
+        int r = mm - a_n[i] * hw;
+        a_oy[i] = r / a.Wo;
+        a_ox[i] = r - a_oy[i] * a.Wo;
+    }
+    // ---- B rows ----
+    const int bk_chunk = tid % CH, bk_row0 = tid / CH;                    // K-contiguous orientation
+    constexpr int NCH = BN / 4;                                           // N-contiguous orientation
+    const int bn_chunk = tid % NCH, bn_row0 = tid / NCH;
+    constexpr int BROWS_N = 256 / NCH;
+    constexpr int BIT_N = (BK + BROWS_N - 1) / BROWS_N;
+    constexpr int BIT = (BIT_K > BIT_N) ? BIT_K : BIT_N;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int kchunks = (a.Kc + BK - 1) / BK;
+    const int ktiles = VEC ? a.T * kchunks : (a.T * a.Kc + BK - 1) / BK;   // scalar path: K linear over (t, c)
+
+    float4 ra[AIT], rb[BIT];
+
+    auto load_tile = [&](int kt) {
+        if (VEC) {
+            const int t = kt / kchunks, c0 = (kt - t * kchunks) * BK;
+            const int c = c0 + a_chunk * 4;
+#pragma unroll
+            for (int i = 0; i < AIT; ++i) {
+                int iy, ix;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a_ok[i] && c < a.Kc && src_coord(a, a_oy[i], a_ox[i], t, iy, ix))
+                    v = *reinterpret_cast<const float4*>(a.Src + (((size_t)a_n[i] * a.Hs + iy) * a.Ws + ix) * a.Cs + c);
+                ra[i] = v;
+            }
+            if (a.b_kcontig) {
+                const int cb = c0 + bk_chunk * 4;
+#pragma unroll
+                for (int i = 0; i < BIT_K; ++i) {
+                    int n = n0 + bk_row0 + i * AROWS;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if ((bk_row0 + i * AROWS) < BN && n < a.Nn && cb < a.Kc)
+                        v = *reinterpret_cast<const float4*>(a.Bw + t * a.sBt + (long long)n * a.sBn + cb);
+                    rb[i] = v;
+                }
+            } else {
+                const int n = n0 + bn_chunk * 4;
+#pragma unroll
+                for (int i = 0; i < BIT_N; ++i) {
+                    int kr = bn_row0 + i * BROWS_N;
+                    int c2 = c0 + kr;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (kr < BK && c2 < a.Kc) {
+                        const float* p = a.Bw + t * a.sBt + (long long)c2 * a.sBc + n;
+                        if (n + 3 < a.Nn) v = *reinterpret_cast<const float4*>(p);
+                        else {
+                            if (n < a.Nn) v.x = p[0];
+                            if (n + 1 < a.Nn) v.y = p[1];
+                            if (n + 2 < a.Nn) v.z = p[2];
+                        }
+                    }
+                    rb[i] = v;
+                }
+            }
+        } else {
+            // scalar path (tiny channel counts / NCHW network input): k = t*Kc + c decoded per element
+            const int Ktot = a.T * a.Kc;
+            const int k0 = kt * BK + a_chunk * 4;
+#pragma unroll
+            for (int i = 0; i < AIT; ++i) {
+                float e[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int k = k0 + j;
+                    if (a_ok[i] && k < Ktot) {
+                        int t = k / a.Kc, c = k - t * a.Kc, iy, ix;
+                        if (src_coord(a, a_oy[i], a_ox[i], t, iy, ix)) {
+                            size_t off = a.src_nchw ? ((((size_t)a_n[i] * a.Cs + c) * a.Hs + iy) * a.Ws + ix)
+                                                    : ((((size_t)a_n[i] * a.Hs + iy) * a.Ws + ix) * a.Cs + c);
+                            e[j] = a.Src[off];
+                        }
+                    }
+                }
+                ra[i] = make_float4(e[0], e[1], e[2], e[3]);
+            }
+            const int kb0 = kt * BK + bk_chunk * 4;
+#pragma unroll
+            for (int i = 0; i < BIT_K; ++i) {
+                int n = n0 + bk_row0 + i * AROWS;
+                float e[4] = {0.f, 0.f, 0.f, 0.f};
+                if ((bk_row0 + i * AROWS) < BN && n < a.Nn) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int k = kb0 + j;
+                        if (k < Ktot) {
+                            int t = k / a.Kc, c = k - t * a.Kc;
+                            e[j] = a.Bw[t * a.sBt + (long long)c * a.sBc + (long long)n * a.sBn];
+                        }
+                    }
+                }
+                rb[i] = make_float4(e[0], e[1], e[2], e[3]);
+            }
+        }
+    };
+
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < AIT; ++i) {
+            const int row = a_row0 + i * AROWS;
+            As[(a_chunk * 4 + 0) * LDA + row] = ra[i].x;
+            As[(a_chunk * 4 + 1) * LDA + row] = ra[i].y;
+            As[(a_chunk * 4 + 2) * LDA + row] = ra[i].z;
+            As[(a_chunk * 4 + 3) * LDA + row] = ra[i].w;
+        }
+        if (!VEC || a.b_kcontig) {
+#pragma unroll
+            for (int i = 0; i < BIT_K; ++i) {
+                const int row = bk_row0 + i * AROWS;
+                if (row < BN) {
+                    Bs[(bk_chunk * 4 + 0) * LDB_K + row] = rb[i].x;
+                    Bs[(bk_chunk * 4 + 1) * LDB_K + row] = rb[i].y;
+                    Bs[(bk_chunk * 4 + 2) * LDB_K + row] = rb[i].z;
+                    Bs[(bk_chunk * 4 + 3) * LDB_K + row] = rb[i].w;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < BIT_N; ++i) {
+                const int kr = bn_row0 + i * BROWS_N;
+                if (kr < BK) *reinterpret_cast<float4*>(&Bs[kr * LDB_N + bn_chunk * 4]) = rb[i];
+            }
+        }
+    };
+
+    const int ldb = (!VEC || a.b_kcontig) ? LDB_K : LDB_N;
+    const int kh2 = lane >> 5, l31 = lane & 31;
+
+    load_tile(0);
+    for (int kt = 0; kt < ktiles; ++kt) {
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < ktiles) load_tile(kt + 1);
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            const int k = 2 * kk + kh2;
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = As[k * LDA + (wm * TM + i) * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = Bs[k * ldb + (wn * TN + j) * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m) ----
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + l31;
+        if (n >= a.Nn) continue;
+        int co = n, tap = 0;
+        if (a.epi == 1) { tap = n / a.eC; co = n - tap * a.eC; }
+        const float bv = a.bias ? a.bias[co] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh2;
+                if (m >= a.M) continue;
+                float v = acc[i][j][r] + bv;
+                size_t off;
+                if (a.epi == 0) {
+                    off = (size_t)m * a.Nn + n;
+                } else {
+                    const int hw = a.Ho * a.Wo;
+                    const int nb = m / hw, rr = m - nb * hw, oy = rr / a.Wo, ox = rr - oy * a.Wo;
+                    if (a.epi == 1) {
+                        const int ay = tap / a.ek, ax = tap - ay * a.ek;
+                        off = (((size_t)nb * (a.Ho * a.ek) + (oy * a.ek + ay)) * (a.Wo * a.ek) + (ox * a.ek + ax)) * a.eC + co;
+                    } else {
+                        off = (((size_t)nb * a.Nn + n) * a.Ho + oy) * a.Wo + ox;
+                    }
+                }
+                if (a.accumulate) v += a.Out[off];
+                a.Out[off] = v;
+            }
+        }
+    }
+}
+
+template <int BN, int BK, bool VEC>
+static int launch(const GemmArgs& a, hipStream_t s) {
+    dim3 grid((a.M + BM - 1) / BM, (a.Nn + BN - 1) / BN);
+    hipLaunchKernelGGL((conv_gemm_kernel<BN, BK, VEC>), grid, dim3(256), 0, s, a);
+    BH_LAUNCH_CHECK();
+    return BH_OK;
+}
+
+static int dispatch(const GemmArgs& a, hipStream_t s) {
+    if (a.M <= 0 || a.Nn <= 0) return BH_OK;
+    const bool vec = !a.src_nchw && (a.Kc % 4 == 0) && (a.Cs % 4 == 0) &&
+                     (a.b_kcontig ? true : true);
+    if (!vec) {
+        if (a.Nn > 64) return launch<128, 32, false>(a, s);
+        if (a.Nn > 32) return launch<64, 32, false>(a, s);
+        return launch<32, 32, false>(a, s);
+    }
+    const bool k16 = (a.Kc % 32) != 0 && a.Kc <= 16;
+    if (a.Nn > 64) return k16 ? launch<128, 16, true>(a, s) : launch<128, 32, true>(a, s);
+    if (a.Nn > 32) return k16 ? launch<64, 16, true>(a, s) : launch<64, 32, true>(a, s);
+    return k16 ? launch<32, 16, true>(a, s) : launch<32, 32, true>(a, s);
+}
+
+static int check_desc(const bh_conv_desc* d) {
+    if (!d) return BH_E_BADARG;
+    if (d->transposed) {
+        if (d->kh != d->stride || d->kw != d->stride || d->pad != 0) return BH_E_UNSUPPORTED;
+        if (d->Ho != d->Hi * d->stride || d->Wo != d->Wi * d->stride) return BH_E_BADARG;
+        if (d->in_nchw || d->out_nchw) return BH_E_UNSUPPORTED;
+    } else {
+        if (d->Ho != (d->Hi + 2 * d->pad - d->kh) / d->stride + 1) return BH_E_BADARG;
+        if (d->Wo != (d->Wi + 2 * d->pad - d->kw) / d->stride + 1) return BH_E_BADARG;
+    }
+    return BH_OK;
+}
+
+extern "C" {
+
+int bh_conv_fwd(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!x || !w || !y) return BH_E_BADARG;
+    GemmArgs a = {};
+    a.Src = x; a.Bw = w; a.bias = bias; a.Out = y;
+    a.Hs = d->Hi; a.Ws = d->Wi; a.Cs = d->Ci; a.Kc = d->Ci;
+    if (!d->transposed) {
+        a.M = d->N * d->Ho * d->Wo; a.Nn = d->Co; a.T = d->kh * d->kw;
+        a.Ho = d->Ho; a.Wo = d->Wo; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad;
+        a.src_nchw = d->in_nchw;
+        a.sBt = d->Ci; a.sBc = 1; a.sBn = (long long)a.T * d->Ci; a.b_kcontig = 1;   // W[n][t][c]
+        a.epi = d->out_nchw ? 2 : 0;
+    } else {
+        // M = input pixels, N = taps*Co, scatter epilogue. Wt[ci][tap][co]
+        const int taps = d->kh * d->kw;
+        a.M = d->N * d->Hi * d->Wi; a.Nn = taps * d->Co; a.T = 1;
+        a.Ho = d->Hi; a.Wo = d->Wi; a.kw = 1; a.stride = 1; a.pad = 0;
+        a.sBt = 0; a.sBc = (long long)taps * d->Co; a.sBn = 1; a.b_kcontig = 0;
+        a.epi = 1; a.ek = d->stride; a.eC = d->Co;
+    }
+    return dispatch(a, bh_stream(stream));
+}
+
+int bh_conv_dgrad(const float* gy, const float* w, float* gx, const bh_conv_desc* d, int accumulate, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!gy || !w || !gx) return BH_E_BADARG;
+    if (d->in_nchw || d->out_nchw) return BH_E_UNSUPPORTED;
+    GemmArgs a = {};
+    a.Src = gy; a.Bw = w; a.bias = nullptr; a.Out = gx; a.accumulate = accumulate;
+    a.M = d->N * d->Hi * d->Wi; a.Nn = d->Ci; a.Kc = d->Co; a.T = d->kh * d->kw;
+    a.Ho = d->Hi; a.Wo = d->Wi;               // output-side grid of this GEMM = conv input grid
+    a.Hs = d->Ho; a.Ws = d->Wo; a.Cs = d->Co;  // gathered source = gy grid
+    a.kw = d->kw;
+    if (!d->transposed) {
+        a.adjoint = 1; a.stride = d->stride; a.pad = d->pad;
+        // B[t][k = co][j = ci] = W[co][t][ci]
+        a.sBt = d->Ci; a.sBc = (long long)a.T * d->Ci; a.sBn = 1; a.b_kcontig = 0;
+    } else {
+        // gx[iy][ix][ci] = sum_{a,b,co} gy[2iy+a][2ix+b][co] * Wt[ci][tap][co]: forward gather, stride k, pad 0
+        a.adjoint = 0; a.stride = d->stride; a.pad = 0;
+        a.sBt = d->Co; a.sBc = 1; a.sBn = (long long)a.T * d->Co; a.b_kcontig = 1;
+    }
+    a.epi = 0;
+    return dispatch(a, bh_stream(stream));
+}
+
+}  // extern "C"

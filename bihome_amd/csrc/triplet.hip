@@ -1,0 +1,193 @@
+// biHomE triplet L1 reduction over the perceptual features (NHWC [B, hw, C]) and its adjoint.
+// HBM-bound: forward reads 4 feature maps once (16*C bytes per pixel), backward reads them again
+// and writes the two feature gradients.  float4 per lane along channels (coalesced 16 B/lane),
+// LP = C/4 lanes cooperate on a pixel and reduce with xor-shuffles; 64/LP pixels per wave pass.
+#include "common.h"
+
+#define TRIP_BLOCKS_PER_SAMPLE 8
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float l1_4(float4 a, float4 b) {
+    return fabsf(a.x - b.x) + fabsf(a.y - b.y) + fabsf(a.z - b.z) + fabsf(a.w - b.w);
+}
+__device__ __forceinline__ float sgn(float v) { return (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f); }
+
+// grid (TRIP_BLOCKS_PER_SAMPLE, B), block 256
+__global__ void __launch_bounds__(256) triplet_fwd_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                          const float* __restrict__ f1w, const float* __restrict__ f2w,
+                                                          const float* __restrict__ m1w, const float* __restrict__ m2w,
+                                                          const float* __restrict__ m1, const float* __restrict__ m2,
+                                                          int hw, int C, float* __restrict__ M1, float* __restrict__ M2,
+                                                          double* __restrict__ numden) {
+    __shared__ double part[4][4];
+    const int b = blockIdx.y;
+    const int LP = min(64, C / 4);          // lanes per pixel
+    const int PPW = 64 / LP;                // pixels per wave pass
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LP, cl = lane % LP;
+    const int wave_global = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
+    double a_n1 = 0, a_d1 = 0, a_n2 = 0, a_d2 = 0;
+    for (int p0 = wave_global * PPW; p0 < hw; p0 += nwaves * PPW) {
+        const int p = p0 + sub;
+        float s1 = 0, s2 = 0, s3 = 0;
+        if (p < hw) {
+            const size_t base = ((size_t)b * hw + p) * C;
+            for (int c = cl * 4; c < C; c += LP * 4) {
+                float4 a1 = ld4(f1 + base + c), a2 = ld4(f2 + base + c), a1w = ld4(f1w + base + c), a2w = ld4(f2w + base + c);
+                s1 += l1_4(a1w, a2);
+                s2 += l1_4(a2w, a1);
+                s3 += l1_4(a1, a2);
+            }
+        }
+        for (int off = 1; off < LP; off <<= 1) {
+            s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); s3 += __shfl_xor(s3, off, 64);
+        }
+        if (p < hw && cl == 0) {
+            const size_t q = (size_t)b * hw + p;
+            float mm1 = s1 - s3, mm2 = s2 - s3;
+            M1[q] = mm1; M2[q] = mm2;
+            float wa = m1w[q] * (m2 ? m2[q] : 1.0f), wb = m2w[q] * (m1 ? m1[q] : 1.0f);
+            a_n1 += (double)(wa * mm1); a_d1 += (double)wa;
+            a_n2 += (double)(wb * mm2); a_d2 += (double)wb;
+        }
+    }
+    a_n1 = wave_sum(a_n1); a_d1 = wave_sum(a_d1); a_n2 = wave_sum(a_n2); a_d2 = wave_sum(a_d2);
+    if (lane == 0) { part[wave][0] = a_n1; part[wave][1] = a_d1; part[wave][2] = a_n2; part[wave][3] = a_d2; }
+    __syncthreads();
+    if (threadIdx.x < 4)
+        atomicAdd(numden + (size_t)b * 4 + threadIdx.x,
+                  part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// single block of 256: sums over the batch
+__global__ void __launch_bounds__(256) bihome_loss_kernel(const double* __restrict__ numden, const double* __restrict__ H1,
+                                                          const double* __restrict__ H2, int B, float mu,
+                                                          float* __restrict__ loss4) {
+    __shared__ double part[4][3];
+    double l1 = 0, l2 = 0, l3 = 0;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const double* nd = numden + (size_t)b * 4;
+        // torch.max(den, ones) in float32 like the reference
+        l1 += (double)((float)nd[0] / fmaxf((float)nd[1], 1.0f));
+        l2 += (double)((float)nd[2] / fmaxf((float)nd[3], 1.0f));
+        double P[9];
+        mat3_mul(H1 + (size_t)b * 9, H2 + (size_t)b * 9, P);
+        P[0] -= 1.0; P[4] -= 1.0; P[8] -= 1.0;
+        for (int i = 0; i < 9; ++i) l3 += P[i] * P[i];
+    }
+    l1 = wave_sum(l1); l2 = wave_sum(l2); l3 = wave_sum(l3);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { part[wave][0] = l1; part[wave][1] = l2; part[wave][2] = l3; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = part[0][0] + part[1][0] + part[2][0] + part[3][0];
+        double c = part[0][1] + part[1][1] + part[2][1] + part[3][1];
+        double d = part[0][2] + part[1][2] + part[2][2] + part[3][2];
+        loss4[0] = (float)(a + c + (double)mu * d);
+        loss4[1] = (float)a; loss4[2] = (float)c; loss4[3] = (float)d;
+    }
+}
+
+// grid (TRIP_BLOCKS_PER_SAMPLE, B), block 256
+__global__ void __launch_bounds__(256) triplet_bwd_kernel(const float* __restrict__ g_loss, const float* __restrict__ f1,
+                                                          const float* __restrict__ f2, const float* __restrict__ f1w,
+                                                          const float* __restrict__ f2w, const float* __restrict__ m1w,
+                                                          const float* __restrict__ m2w, const float* __restrict__ m1,
+                                                          const float* __restrict__ m2, const float* __restrict__ M1,
+                                                          const float* __restrict__ M2, const double* __restrict__ numden,
+                                                          const double* __restrict__ H1, const double* __restrict__ H2,
+                                                          int hw, int C, float mu, float* __restrict__ g_f1w,
+                                                          float* __restrict__ g_f2w, float* __restrict__ g_m1w,
+                                                          float* __restrict__ g_m2w, double* __restrict__ gH1,
+                                                          double* __restrict__ gH2) {
+    const int b = blockIdx.y;
+    const float g = g_loss[0];
+    const double* nd = numden + (size_t)b * 4;
+    const float N1 = (float)nd[0], D1 = (float)nd[1], N2 = (float)nd[2], D2 = (float)nd[3];
+    const float den1 = fmaxf(D1, 1.0f), den2 = fmaxf(D2, 1.0f);
+    // d(N/max(D,1))/dD : -N/D^2 when D > 1 else 0
+    const float dd1 = (D1 > 1.0f) ? -N1 / (den1 * den1) : 0.0f, dd2 = (D2 > 1.0f) ? -N2 / (den2 * den2) : 0.0f;
+    if (blockIdx.x == 0 && threadIdx.x < 9) {
+        // ln3 = ||H1 H2 - I||^2 : gP = 2 mu g P ; gH1 = gP H2^T ; gH2 = H1^T gP
+        const double* A = H1 + (size_t)b * 9;
+        const double* Bm = H2 + (size_t)b * 9;
+        double P[9];
+        mat3_mul(A, Bm, P);
+        P[0] -= 1.0; P[4] -= 1.0; P[8] -= 1.0;
+        const double k = 2.0 * (double)mu * (double)g;
+        const int r = threadIdx.x / 3, c = threadIdx.x % 3;
+        double a = 0, d = 0;
+        for (int t = 0; t < 3; ++t) {
+            a += P[r * 3 + t] * Bm[c * 3 + t];      // (P H2^T)[r][c]
+            d += A[t * 3 + r] * P[t * 3 + c];       // (H1^T P)[r][c]
+        }
+        gH1[(size_t)b * 9 + threadIdx.x] = k * a;
+        gH2[(size_t)b * 9 + threadIdx.x] = k * d;
+    }
+    const int LP = min(64, C / 4), PPW = 64 / LP;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LP, cl = lane % LP;
+    const int wave_global = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
+    for (int p0 = wave_global * PPW; p0 < hw; p0 += nwaves * PPW) {
+        const int p = p0 + sub;
+        if (p >= hw) continue;
+        const size_t q = (size_t)b * hw + p;
+        const float mm2 = m2 ? m2[q] : 1.0f, mm1 = m1 ? m1[q] : 1.0f;
+        const float k1 = g * m1w[q] * mm2 / den1, k2 = g * m2w[q] * mm1 / den2;
+        const size_t base = q * C;
+        for (int c = cl * 4; c < C; c += LP * 4) {
+            float4 a1 = ld4(f1 + base + c), a2 = ld4(f2 + base + c), a1w = ld4(f1w + base + c), a2w = ld4(f2w + base + c);
+            float4 o1 = make_float4(k1 * sgn(a1w.x - a2.x), k1 * sgn(a1w.y - a2.y), k1 * sgn(a1w.z - a2.z), k1 * sgn(a1w.w - a2.w));
+            float4 o2 = make_float4(k2 * sgn(a2w.x - a1.x), k2 * sgn(a2w.y - a1.y), k2 * sgn(a2w.z - a1.z), k2 * sgn(a2w.w - a1.w));
+            *reinterpret_cast<float4*>(g_f1w + base + c) = o1;
+            *reinterpret_cast<float4*>(g_f2w + base + c) = o2;
+        }
+        if (cl == 0) {
+            g_m1w[q] = g * mm2 * (M1[q] / den1 + dd1);
+            g_m2w[q] = g * mm1 * (M2[q] / den2 + dd2);
+        }
+    }
+}
+
+extern "C" {
+
+int bh_triplet_l1_fwd(const float* f1, const float* f2, const float* f1w, const float* f2w, const float* m1w,
+                      const float* m2w, const float* m1, const float* m2, int B, int hw, int C, float* M1, float* M2,
+                      double* numden, void* stream) {
+    if (!f1 || !f2 || !f1w || !f2w || !m1w || !m2w || !M1 || !M2 || !numden || B < 0) return BH_E_BADARG;
+    if (C % 4 || C < 4 || (C / 4 < 64 && (64 % (C / 4)))) return BH_E_UNSUPPORTED;
+    if (B == 0) return BH_OK;
+    hipError_t e = hipMemsetAsync(numden, 0, sizeof(double) * 4 * (size_t)B, bh_stream(stream));
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(triplet_fwd_kernel, dim3(TRIP_BLOCKS_PER_SAMPLE, B), dim3(256), 0, bh_stream(stream), f1, f2, f1w,
+                       f2w, m1w, m2w, m1, m2, hw, C, M1, M2, numden);
+    BH_LAUNCH_CHECK();
+    return BH_OK;
+}
+
+int bh_bihome_loss_fwd(const double* numden, const double* H1, const double* H2, int B, float mu, float* loss4,
+                       void* stream) {
+    if (!numden || !H1 || !H2 || !loss4 || B < 0) return BH_E_BADARG;
+    hipLaunchKernelGGL(bihome_loss_kernel, dim3(1), dim3(256), 0, bh_stream(stream), numden, H1, H2, B, mu, loss4);
+    BH_LAUNCH_CHECK();
+    return BH_OK;
+}
+
+int bh_bihome_loss_bwd(const float* g_loss, const float* f1, const float* f2, const float* f1w, const float* f2w,
+                       const float* m1w, const float* m2w, const float* m1, const float* m2, const float* M1,
+                       const float* M2, const double* numden, const double* H1, const double* H2, int B, int hw, int C,
+                       float mu, float* g_f1w, float* g_f2w, float* g_m1w, float* g_m2w, double* gH1, double* gH2,
+                       void* stream) {
+    if (!g_loss || !f1 || !f2 || !f1w || !f2w || !m1w || !m2w || !M1 || !M2 || !numden || !H1 || !H2 || !g_f1w ||
+        !g_f2w || !g_m1w || !g_m2w || !gH1 || !gH2 || B < 0)
+        return BH_E_BADARG;
+    if (C % 4 || C < 4 || (C / 4 < 64 && (64 % (C / 4)))) return BH_E_UNSUPPORTED;
+    if (B == 0) return BH_OK;
+    hipLaunchKernelGGL(triplet_bwd_kernel, dim3(TRIP_BLOCKS_PER_SAMPLE, B), dim3(256), 0, bh_stream(stream), g_loss, f1,
+                       f2, f1w, f2w, m1w, m2w, m1, m2, M1, M2, numden, H1, H2, hw, C, mu, g_f1w, g_f2w, g_m1w, g_m2w,
+                       gH1, gH2);
+    BH_LAUNCH_CHECK();
+    return BH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,143 @@
+"""Thin tensor-level wrappers over the C ABI (include/bihome.h): argument checking, raw device
+pointers and the current HIP stream.  No arithmetic happens here."""
+import ctypes
+
+import torch
+
+from ._lib import BhConvDesc, check, lib
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, dtype=torch.float32):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise RuntimeError("bihome_amd kernels need device tensors (got %s); there is no CPU path" % t.device)
+    if t.dtype != dtype:
+        raise TypeError("expected %s, got %s" % (dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+
+
+# ------------------------------------------------------------------------------------------------
+# geometry
+# ------------------------------------------------------------------------------------------------
+def h4pt_fwd(delta, size):
+    """delta [B,4,2] f32 -> (H64 [B,9] f64, H32 [B,3,3] f32)."""
+    _chk(delta)
+    B = delta.shape[0]
+    H64 = torch.empty(B, 9, dtype=torch.float64, device=delta.device)
+    H32 = torch.empty(B, 3, 3, dtype=torch.float32, device=delta.device)
+    check(lib.bh_h4pt_fwd(_p(delta), B, float(size), float(size), _p(H64), _p(H32), _stream()), "bh_h4pt_fwd")
+    return H64, H32
+
+
+def h4pt_bwd(delta, H64, gH, size):
+    _chk(delta); _chk(H64, torch.float64); _chk(gH, torch.float64)
+    B = delta.shape[0]
+    gd = torch.empty(B, 4, 2, dtype=torch.float32, device=delta.device)
+    check(lib.bh_h4pt_bwd(_p(delta), _p(H64), _p(gH), B, float(size), float(size), _p(gd), _stream()), "bh_h4pt_bwd")
+    return gd
+
+
+def dlt_fwd(pf, choice, n, P):
+    """pf [B,2,h,w] f32, choice [B,n*P] i64 -> Hdlt [B*n,3,3], delta_hat [B*n,4,2], eig [B*n,96] f64."""
+    _chk(pf); _chk(choice, torch.int64)
+    B, _, h, w = pf.shape
+    assert choice.shape == (B, n * P), (choice.shape, B, n, P)
+    Hd = torch.empty(B * n, 3, 3, dtype=torch.float32, device=pf.device)
+    dh = torch.empty(B * n, 4, 2, dtype=torch.float32, device=pf.device)
+    eig = torch.empty(B * n, 96, dtype=torch.float64, device=pf.device)
+    check(lib.bh_dlt_fwd(_p(pf), _p(choice), B, n, P, h, w, _p(Hd), _p(dh), _p(eig), _stream()), "bh_dlt_fwd")
+    return Hd, dh, eig
+
+
+def dlt_bwd(pf, choice, eig, g_delta, n, P):
+    _chk(pf); _chk(choice, torch.int64); _chk(eig, torch.float64); _chk(g_delta)
+    B, _, h, w = pf.shape
+    g_pf = torch.zeros_like(pf)
+    check(lib.bh_dlt_bwd(_p(pf), _p(choice), _p(eig), _p(g_delta), B, n, P, h, w, _p(g_pf), _stream()), "bh_dlt_bwd")
+    return g_pf
+
+
+def dsac_score(pf, Hd, n):
+    _chk(pf); _chk(Hd)
+    B, _, h, w = pf.shape
+    err = torch.empty(B, n, dtype=torch.float32, device=pf.device)
+    best = torch.empty(B, dtype=torch.int64, device=pf.device)
+    check(lib.bh_dsac_score(_p(pf), _p(Hd), B, n, h, w, _p(err), _p(best), _stream()), "bh_dsac_score")
+    return err, best
+
+
+# ------------------------------------------------------------------------------------------------
+# warp
+# ------------------------------------------------------------------------------------------------
+def warp_fwd(img, H64, pool=4, want_cov=True):
+    """img [B,C,h,w], H64 [B,9] -> (out [B,C,h,w], cov [B,h/pool,w/pool] or None)."""
+    _chk(img); _chk(H64, torch.float64)
+    B, C, h, w = img.shape
+    out = torch.empty_like(img)
+    cov = torch.empty(B, h // pool, w // pool, dtype=torch.float32, device=img.device) if want_cov else None
+    check(lib.bh_warp_fwd(_p(img), _p(H64), B, C, h, w, pool, _p(out), _p(cov), _stream()), "bh_warp_fwd")
+    return out, cov
+
+
+def mask_coverage_fwd(H64, h, w, pool=4):
+    _chk(H64, torch.float64)
+    B = H64.shape[0]
+    cov = torch.empty(B, h // pool, w // pool, dtype=torch.float32, device=H64.device)
+    check(lib.bh_warp_fwd(None, _p(H64), B, 1, h, w, pool, None, _p(cov), _stream()), "bh_warp_fwd(cov)")
+    return cov
+
+
+def warp_bwd(img, H64, g_out, g_cov, pool=4, gH=None):
+    _chk(img); _chk(H64, torch.float64); _chk(g_out); _chk(g_cov)
+    B, C, h, w = img.shape
+    if gH is None:
+        gH = torch.zeros(B, 9, dtype=torch.float64, device=img.device)
+    check(lib.bh_warp_bwd(_p(img), _p(H64), _p(g_out), _p(g_cov), B, C, h, w, pool, _p(gH), _stream()), "bh_warp_bwd")
+    return gH
+
+
+# ------------------------------------------------------------------------------------------------
+# triplet
+# ------------------------------------------------------------------------------------------------
+def triplet_l1_fwd(f1, f2, f1w, f2w, m1w, m2w, m1=None, m2=None):
+    """features NHWC [B,hf,wf,C]; masks [B,hf,wf]."""
+    for t in (f1, f2, f1w, f2w, m1w, m2w, m1, m2):
+        _chk(t)
+    B, hf, wf, C = f1.shape
+    M1 = torch.empty(B, hf, wf, dtype=torch.float32, device=f1.device)
+    M2 = torch.empty_like(M1)
+    numden = torch.empty(B, 4, dtype=torch.float64, device=f1.device)
+    check(lib.bh_triplet_l1_fwd(_p(f1), _p(f2), _p(f1w), _p(f2w), _p(m1w), _p(m2w), _p(m1), _p(m2), B, hf * wf, C,
+                                _p(M1), _p(M2), _p(numden), _stream()), "bh_triplet_l1_fwd")
+    return M1, M2, numden
+
+
+def bihome_loss_fwd(numden, H1, H2, mu):
+    _chk(numden, torch.float64); _chk(H1, torch.float64); _chk(H2, torch.float64)
+    loss4 = torch.empty(4, dtype=torch.float32, device=numden.device)
+    check(lib.bh_bihome_loss_fwd(_p(numden), _p(H1), _p(H2), numden.shape[0], float(mu), _p(loss4), _stream()),
+          "bh_bihome_loss_fwd")
+    return loss4
+
+
+def bihome_loss_bwd(g_loss, f1, f2, f1w, f2w, m1w, m2w, m1, m2, M1, M2, numden, H1, H2, mu):
+    _chk(g_loss)
+    B, hf, wf, C = f1.shape
+    g_f1w, g_f2w = torch.empty_like(f1w), torch.empty_like(f2w)
+    g_m1w, g_m2w = torch.empty_like(m1w), torch.empty_like(m2w)
+    gH1 = torch.empty(B, 9, dtype=torch.float64, device=f1.device)
+    gH2 = torch.empty_like(gH1)
+    check(lib.bh_bihome_loss_bwd(_p(g_loss), _p(f1), _p(f2), _p(f1w), _p(f2w), _p(m1w), _p(m2w), _p(m1), _p(m2), _p(M1),
+                                 _p(M2), _p(numden), _p(H1), _p(H2), B, hf * wf, C, float(mu), _p(g_f1w), _p(g_f2w),
+                                 _p(g_m1w), _p(g_m2w), _p(gH1), _p(gH2), _stream()), "bh_bihome_loss_bwd")
+    return g_f1w, g_f2w, g_m1w, g_m2w, gH1, gH2

@@ -1,0 +1,153 @@
+/*
+ * bihome.h - C ABI of libbihome_hip.so: the MI355X (gfx950) kernels behind the biHomE training hot path.
+ *
+ * Boundary contract: plain device pointers + sizes + a hipStream_t passed as void*,
+ * int status return (0 = ok, >0 = hipError_t, <0 = BH_E_*), no allocation, no global state, re-entrant
+ * per stream.  The reference has no FFI of its own (it is pure Python over ATen); each entry point
+ * below names the reference call site (path:line under the upstream repository) whose arithmetic it
+ * replaces.  The host-side mirror of the reference's plugin API (src/backbones/<Name>.Model,
+ * src/heads/<Name>.Model) lives in bihome_amd/ and calls these through ctypes.
+ *
+ * Layouts: images/patches/perspective fields are NCHW float32 exactly as the reference hands them
+ * over; *internal* feature maps of the conv stacks are NHWC float32 ("pixels x channels"), conv
+ * weights are [Cout][kh][kw][Cin] (= a torch channels_last OIHW tensor), transposed-conv weights
+ * [Cin][kh][kw][Cout] (= channels_last IOHW).  Homographies are row-major 3x3.
+ */
+#ifndef BIHOME_H
+#define BIHOME_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BH_OK 0
+#define BH_E_BADARG (-1)
+#define BH_E_UNSUPPORTED (-2)
+
+/* library / device probe: returns ABI version (>0); writes gcnArchName of device 0 if buf != NULL */
+int bh_version(void);
+int bh_device_arch(char* buf, int buflen);
+
+/* ---------------------------------------------------------------------------------------------
+ * Geometry (per-sample small dense algebra, double precision inside)
+ * ------------------------------------------------------------------------------------------- */
+
+/* four_point_to_homography, src/data/utils.py:7-33 (torch branch -> kornia.get_perspective_transform):
+ * corners [[0,0],[W,0],[W,H],[0,H]] (image_shape_to_corners, src/data/utils.py:36-51) + delta[B,4,2]
+ * -> H[B,9] with H22 = 1, 8x8 solve with partial pivoting.  H64 feeds the warp kernels, H32 is the
+ * float copy handed back to the host module. */
+int bh_h4pt_fwd(const float* delta, int B, float W, float H, double* H64, float* H32, void* stream);
+/* adjoint of the above: gH[B,9] (double; entry 8 ignored) -> gdelta[B,8] (overwritten) */
+int bh_h4pt_bwd(const float* delta, const double* H64, const double* gH, int B, float W, float H,
+                float* gdelta, void* stream);
+
+/* DSACSoftmax.__sample_hypotheses, src/heads/ransac_utils.py:47-74, fused with forward_map_field
+ * (src/heads/PerceptualHead.py:125-146) and the corner transform (PerceptualHead.py:175-178):
+ * pf[B,2,h,w] perspective field, choice[B, n*P] int64 sampled indices (row-major idx = y*w + x)
+ * -> Hdlt[B*n,9] (kornia.find_homography_dlt: Hartley normalisation, A^T A, smallest eigenvector,
+ * denormalise, /(H22+1e-8)) and delta_hat[B*n,4,2] = H.corners - corners.
+ * eig[B*n,96] doubles: eigenvectors (81, column i = vector i), eigenvalues (9), index of the
+ * smallest (1), spare - saved for the adjoint. */
+int bh_dlt_fwd(const float* pf, const int64_t* choice, int B, int n, int P, int h, int w,
+               float* Hdlt, float* delta_hat, double* eig, void* stream);
+/* adjoint: g_delta[B*n,4,2] -> g_pf[B,2,h,w] += (scatter-add at the sampled indices; caller zeroes) */
+int bh_dlt_bwd(const float* pf, const int64_t* choice, const double* eig, const float* g_delta,
+               int B, int n, int P, int h, int w, float* g_pf, void* stream);
+
+/* DSACSoftmax.__score_hypotheses ('repr_error'), src/heads/ransac_utils.py:76-128, and the
+ * arg-max of softmax(-err) == arg-min of err at src/heads/PerceptualHead.py:755-757:
+ * err[B,n] = sum over all h*w points of |H.coord - (coord + pf)|_1 ; best[B] int64 (first minimum). */
+int bh_dsac_score(const float* pf, const float* Hdlt, int B, int n, int h, int w,
+                  float* err, int64_t* best, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Homography warp (warp_image, src/data/utils.py:54-59 -> kornia.warp_perspective(bilinear, zeros,
+ * align_corners=True); net map out(x,y) = bilinear img(H.(x,y,1)))  and the warped all-ones mask
+ * + AvgPool2d(k) (src/heads/PerceptualHead.py:380-382,401,447-459) fused into the same pass.
+ * ------------------------------------------------------------------------------------------- */
+/* img[B,C,h,w] (NULL => only the coverage is produced), H64[B,9]; out[B,C,h,w] (may be NULL when
+ * img is NULL); cov[B,h/pool,w/pool] (NULL => skipped). h,w multiples of pool; pool in {1,2,4,8,16}. */
+int bh_warp_fwd(const float* img, const double* H64, int B, int C, int h, int w, int pool,
+                float* out, float* cov, void* stream);
+/* adjoint w.r.t. H only (the image is data): g_out[B,C,h,w] (NULL ok), g_cov[B,h/pool,w/pool]
+ * (NULL ok) -> gH[B,9] += (double, atomics; caller zeroes) */
+int bh_warp_bwd(const float* img, const double* H64, const float* g_out, const float* g_cov,
+                int B, int C, int h, int w, int pool, double* gH, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * biHomE triplet L1 reduction (triplet_resnet_loss, double-line / l1 / channel-agnostic / str margin:
+ * src/heads/PerceptualHead.py:559-561, 609-665).  Features are NHWC [B,hw,C].
+ * ------------------------------------------------------------------------------------------- */
+/* M1[B,hw] = sum_c |f1w-f2| - sum_c |f1-f2| ; M2[B,hw] = sum_c |f2w-f1| - sum_c |f1-f2| ;
+ * numden[B,4] (double) = { sum m1w*m2*M1, sum m1w*m2, sum m2w*m1*M2, sum m2w*m1 } ; m1,m2 NULL => ones. */
+int bh_triplet_l1_fwd(const float* f1, const float* f2, const float* f1w, const float* f2w,
+                      const float* m1w, const float* m2w, const float* m1, const float* m2,
+                      int B, int hw, int C, float* M1, float* M2, double* numden, void* stream);
+/* loss4[4] = { loss, ln1, ln2, ln3 }: ln_k = sum_b num/max(den,1); ln3 = sum_b ||H1 H2 - I||_F^2;
+ * loss = ln1 + ln2 + mu*ln3 (PerceptualHead.py:656-665) */
+int bh_bihome_loss_fwd(const double* numden, const double* H1, const double* H2, int B, float mu,
+                       float* loss4, void* stream);
+/* adjoint of both: g_loss[1] (device scalar) -> g_f1w,g_f2w [B,hw,C] (overwritten), g_m1w,g_m2w
+ * [B,hw] (overwritten), gH1,gH2 [B,9] double (overwritten) */
+int bh_bihome_loss_bwd(const float* g_loss, const float* f1, const float* f2, const float* f1w,
+                       const float* f2w, const float* m1w, const float* m2w, const float* m1,
+                       const float* m2, const float* M1, const float* M2, const double* numden,
+                       const double* H1, const double* H2, int B, int hw, int C, float mu,
+                       float* g_f1w, float* g_f2w, float* g_m1w, float* g_m2w,
+                       double* gH1, double* gH2, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Conv stacks (Rethinking._forward src/backbones/Rethinking.py:284-294 with blocks
+ * src/backbones/utils.py:60-131; ResNet34 src/backbones/ResNet34.py:15-28; AuxiliaryResnet.forward
+ * src/heads/PerceptualHead.py:50-76).  Replace ATen conv2d / conv_transpose2d / batch_norm / relu /
+ * max_pool2d / adaptive_avg_pool2d / linear and their autograd adjoints.  Implicit GEMM on the
+ * f32-input MFMA (v_mfma_f32_32x32x2_f32): exact fp32 products, fp32 accumulate.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int N, Hi, Wi, Ci;      /* input  NHWC */
+    int Ho, Wo, Co;         /* output NHWC */
+    int kh, kw, stride, pad;
+    int transposed;         /* 0: Conv2d ; 1: ConvTranspose2d with kernel == stride, pad 0 */
+    int in_nchw;            /* 1: x is NCHW (only for the network inputs, Ci <= 4) */
+    int out_nchw;           /* 1: y is NCHW (only for the network output, Co <= 4) */
+} bh_conv_desc;
+
+/* y = conv(x, w) (+ bias[Co] if bias != NULL) */
+int bh_conv_fwd(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, void* stream);
+/* gx = conv^T(gy, w)  (overwritten; accumulate != 0: gx += ..., used where gradient branches join) */
+int bh_conv_dgrad(const float* gy, const float* w, float* gx, const bh_conv_desc* d, int accumulate, void* stream);
+/* gw += x^T * gy ; gbias += sum gy  (accumulated: caller zeroes; gbias NULL ok) */
+int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, const bh_conv_desc* d, void* stream);
+
+/* Training-mode BatchNorm2d over `groups` independent sub-batches stacked along N (the reference
+ * runs the backbone once per direction and the extractor once per patch, each call with its own
+ * batch statistics - Rethinking.py:296-313, PerceptualHead.py:358-398 - this build stacks those
+ * calls into one launch and keeps the statistics separate per group).  x,y: [groups*rows, C].
+ *   stats[groups, C, 2] double = {mean, biased var}; running stats are updated group after group
+ *   with `momentum`, unbiased variance, exactly like consecutive nn.BatchNorm2d calls.
+ *   flags: bit0 relu, bit1 residual add (y = act(bn(x) + res)). eval mode: use_running = 1. */
+int bh_bn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+              const float* res, float* y, double* stats, int groups, int rows, int C, float eps, float momentum,
+              int flags, int use_running, void* stream);
+/* adjoint. gy: grad w.r.t. y; y: the forward output (for the relu mask); x: forward input.
+ * -> gx (overwritten), gres (written when non-NULL: = masked gy), ggamma/gbeta += (NULL ok => frozen) */
+int bh_bn_bwd(const float* gy, const float* y, const float* x, const float* gamma, const double* stats,
+              float* gx, float* gres, float* ggamma, float* gbeta, double* scratch /*[groups,C,2]*/,
+              int groups, int rows, int C, float eps, int flags, int use_running,
+              const float* running_mean, const float* running_var, void* stream);
+
+/* MaxPool2d(3, 2, 1) NHWC, and its adjoint (recomputes the arg-max, first max wins like ATen) */
+int bh_maxpool3s2_fwd(const float* x, float* y, int N, int Hi, int Wi, int C, void* stream);
+int bh_maxpool3s2_bwd(const float* x, const float* gy, float* gx, int N, int Hi, int Wi, int C, void* stream);
+/* AdaptiveAvgPool2d(1) NHWC -> [N,C], and adjoint */
+int bh_gap_fwd(const float* x, float* y, int N, int HW, int C, void* stream);
+int bh_gap_bwd(const float* gy, float* gx, int N, int HW, int C, void* stream);
+/* out = a + b (elementwise, used to join gradient branches) */
+int bh_add(const float* a, const float* b, float* out, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,189 @@
+"""Parity of the head kernels (through the C ABI) with the CPU oracle on identical seeded inputs.
+
+Tolerances: the kernels do their per-sample algebra in double, the reference does it in float32;
+float32 outputs therefore agree with the *float64* oracle to float32 rounding of the result
+(rtol 1e-5) and with the float32 oracle to its own conditioning noise (looser, stated per test).
+Integer outputs (arg-min index) must be bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from bihome_amd import synth
+from oracle import bihome_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    from bihome_amd import kernels
+    return kernels
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(a)).to(dtype).cuda().contiguous()
+
+
+def rand_delta(B, seed, amp=32):
+    g = np.random.Generator(np.random.PCG64(seed))
+    return g.uniform(-amp, amp, (B, 4, 2)).astype(np.float32)
+
+
+def test_h4pt_fwd_bwd(K):
+    B = 37
+    d = rand_delta(B, 1)
+    H64, H32 = K.h4pt_fwd(dev(d), 128)
+    dt = torch.tensor(d, dtype=torch.float64, requires_grad=True)
+    corners = torch.tensor([[0, 0], [128, 0], [128, 128], [0, 128]], dtype=torch.float64).repeat(B, 1, 1)
+    Href = O.four_point_to_homography(corners, dt)
+    np.testing.assert_allclose(H64.cpu().numpy().reshape(B, 3, 3), Href.detach().numpy(), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(H32.cpu().numpy(), Href.detach().numpy(), rtol=2e-6, atol=1e-7)
+    # property: H maps corners -> corners + delta
+    mapped = O.transform_points(H64.cpu().reshape(B, 3, 3), corners)
+    np.testing.assert_allclose(mapped.numpy(), corners.numpy() + d, atol=1e-9)
+    g = np.random.Generator(np.random.PCG64(2)).standard_normal((B, 9))
+    g[:, 8] = 0
+    (Href.reshape(B, 9) * torch.tensor(g)).sum().backward()
+    gd = K.h4pt_bwd(dev(d), H64, dev(g, torch.float64), 128)
+    np.testing.assert_allclose(gd.cpu().numpy(), dt.grad.numpy(), rtol=2e-5, atol=1e-7 * np.abs(dt.grad.numpy()).max())
+
+
+@pytest.mark.parametrize("n,P", [(1, 128), (4, 16), (2, 200)])
+def test_dlt_fwd_bwd(K, n, P):
+    B = 6
+    d = synth.make_head_inputs(B, seed=3, noise=0.7)
+    pf = d["pf_hat_12"]
+    choice = O.sample_choice(128 * 128, B * n * P, torch.Generator().manual_seed(5)).reshape(B, n * P)
+    Hd, dh, eig = K.dlt_fwd(dev(pf), choice.cuda(), n, P)
+    # float64 oracle
+    head = O.BiHomEHead(torch.nn.Identity(), PATCH_SIZE=128, PATCH_KEYS=["patch_1", "patch_2"], DELTA_HAT_KEYS=[],
+                        PF_KEYS=["a", "b"], RANSAC_HYPOTHESIS_NO=n, POINTS_PER_HYPOTHESIS=P, TRIPLET_LOSS="double-line",
+                        TRIPLET_DISTANCE="l1", TRIPLET_AGGREGATION="channel-agnostic", TRIPLET_MARGIN="inf",
+                        MASK_KEYS=[], TRIPLET_MU=0.01).double()
+    pft = torch.tensor(pf, dtype=torch.float64, requires_grad=True)
+    dref, Href, _ = head._delta_from_pf(pft, choice)
+    np.testing.assert_allclose(Hd.cpu().numpy().reshape(B, n, 3, 3), Href.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dh.cpu().numpy().reshape(B, n, 4, 2), dref.detach().numpy(), atol=2e-5)
+    # float32 oracle (what the reference computes): conditioning noise of its float32 SVD
+    d32, H32, _ = head.float()._delta_from_pf(torch.tensor(pf), choice)
+    np.testing.assert_allclose(dh.cpu().numpy().reshape(B, n, 4, 2), d32.detach().numpy(), atol=5e-3)
+    # adjoint
+    head.double()
+    gd = np.random.Generator(np.random.PCG64(9)).standard_normal((B * n, 4, 2)).astype(np.float32)
+    (dref.reshape(B * n, 4, 2) * torch.tensor(gd, dtype=torch.float64)).sum().backward()
+    gpf = K.dlt_bwd(dev(pf), choice.cuda(), eig, dev(gd), n, P)
+    ref = pft.grad.numpy()
+    np.testing.assert_allclose(gpf.cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max())
+
+
+def test_dsac_argmin_bit_exact(K, golden):
+    g = golden("dsac_n4_f32")
+    d = synth.make_head_inputs(8, 11, noise=2.0)
+    pf = dev(d["pf_hat_12"])
+    choice = torch.tensor(g["choice"]).cuda()
+    Hd, dh, _ = K.dlt_fwd(pf, choice, 4, 16)
+    err, best = K.dsac_score(pf, Hd.reshape(-1, 9).contiguous(), 4)
+    assert np.array_equal(best.cpu().numpy(), g["best"])                       # integer: bit-exact
+    np.testing.assert_allclose(err.cpu().numpy(), g["repr_error"], rtol=2e-4)
+    sel = dh.reshape(8, 4, 4, 2)[torch.arange(8), best]
+    np.testing.assert_allclose(sel.cpu().numpy(), g["delta_hat"], atol=5e-2)   # f32 SVD noise at P=16, noise=2px
+
+
+@pytest.mark.parametrize("B,C,size,pool", [(5, 1, 128, 4), (2, 3, 64, 4), (3, 1, 32, 8), (2, 2, 48, 1), (1, 1, 256, 16)])
+def test_warp_fwd_bwd(K, B, C, size, pool):
+    rng = np.random.Generator(np.random.PCG64(B * 100 + size))
+    img = rng.standard_normal((B, C, size, size)).astype(np.float32)
+    # smooth the image a little so that bilinear gradients are O(1)
+    img = F.avg_pool2d(torch.tensor(img), 3, 1, 1).numpy()
+    delta = rand_delta(B, size, amp=size / 4.0)
+    H64, _ = K.h4pt_fwd(dev(delta), size)
+    out, cov = K.warp_fwd(dev(img), H64, pool)
+    Ht = H64.cpu().reshape(B, 3, 3).clone().requires_grad_(True)
+    imt = torch.tensor(img, dtype=torch.float64)
+    ref = O.warp_image(imt, Ht)
+    refcov = F.avg_pool2d(O.warp_image(torch.ones(B, 1, size, size, dtype=torch.float64), Ht), pool).squeeze(1)
+    # the kernel evaluates the map in float32 (like grid_sample's float32 grid); coordinate rounding
+    # ~ size * 2^-24 * few -> value error ~ 1e-5 * local gradient
+    np.testing.assert_allclose(out.cpu().numpy(), ref.detach().numpy(), atol=2e-4)
+    np.testing.assert_allclose(cov.cpu().numpy(), refcov.detach().numpy(), atol=2e-5)
+    ref32 = O.warp_image(torch.tensor(img), H64.cpu().reshape(B, 3, 3).float())
+    np.testing.assert_allclose(out.cpu().numpy(), ref32.numpy(), atol=5e-4)     # reference's own float32 chain
+    go = rng.standard_normal(out.shape).astype(np.float32)
+    gc = rng.standard_normal(cov.shape).astype(np.float32)
+    ((ref * torch.tensor(go, dtype=torch.float64)).sum() + (refcov * torch.tensor(gc, dtype=torch.float64)).sum()).backward()
+    gH = K.warp_bwd(dev(img), H64, dev(go), dev(gc), pool)
+    r = Ht.grad.numpy().reshape(B, 9)
+    np.testing.assert_allclose(gH.cpu().numpy(), r, rtol=2e-3, atol=2e-4 * np.abs(r).max())
+    # coverage-only entry
+    cov2 = K.mask_coverage_fwd(H64, size, size, pool)
+    assert torch.equal(cov2, cov)
+
+
+def test_warp_identity_and_consistency(K):
+    """SURVEY 4(iii),(iv): identity H is the identity; delta_hat == delta_gt maps patch_1 onto patch_2."""
+    d = synth.make_pairs(4, seed=21)
+    p1, p2 = dev(d["patch_1"]), dev(d["patch_2"])
+    H0, _ = K.h4pt_fwd(torch.zeros(4, 4, 2, device="cuda"), 128)
+    out, cov = K.warp_fwd(p1, H0, 4)
+    assert torch.equal(out, p1) and torch.all(cov == 1)
+    Hg, _ = K.h4pt_fwd(dev(d["delta"]), 128)
+    out, cov = K.warp_fwd(p1, Hg, 1)
+    inside = cov.reshape(4, 1, 128, 128) == 1
+    err = ((out - p2).abs() * inside).sum() / inside.sum()
+    assert err.item() < 0.02, err.item()        # same convention => sub-interpolation-noise residual
+
+
+@pytest.mark.parametrize("B,hf,C", [(5, 32, 64), (2, 8, 16), (3, 4, 256), (2, 16, 128)])
+def test_triplet_fwd_bwd(K, B, hf, C):
+    rng = np.random.Generator(np.random.PCG64(B + C))
+    f = [rng.standard_normal((B, hf, hf, C)).astype(np.float32) for _ in range(4)]
+    m1w = rng.uniform(0, 1, (B, hf, hf)).astype(np.float32)
+    m2w = rng.uniform(0, 1, (B, hf, hf)).astype(np.float32)
+    m1w[0] *= 1e-4                                   # force the max(den, 1) clamp branch on one sample
+    dl = rand_delta(B, 5, 8)
+    H1, _ = K.h4pt_fwd(dev(dl), 128)
+    H2, _ = K.h4pt_fwd(dev(-dl[::-1].copy()), 128)
+    mu = 0.01
+    M1, M2, nd = K.triplet_l1_fwd(*[dev(a) for a in f], dev(m1w), dev(m2w))
+    loss4 = K.bihome_loss_fwd(nd, H1, H2, mu)
+    T = lambda a: torch.tensor(a, dtype=torch.float64)
+    f1, f2, f1w, f2w = [T(a).requires_grad_(True) for a in f]
+    a1, a2 = T(m1w).requires_grad_(True), T(m2w).requires_grad_(True)
+    h1 = H1.cpu().reshape(B, 3, 3).clone().requires_grad_(True)
+    h2 = H2.cpu().reshape(B, 3, 3).clone().requires_grad_(True)
+    l1, l2, l3 = (f1w - f2).abs().sum(-1), (f2w - f1).abs().sum(-1), (f1 - f2).abs().sum(-1)
+    d1, d2 = a1.sum((-1, -2)), a2.sum((-1, -2))
+    ln1 = ((a1 * (l1 - l3)).sum((-1, -2)) / torch.max(d1, torch.ones_like(d1))).sum()
+    ln2 = ((a2 * (l2 - l3)).sum((-1, -2)) / torch.max(d2, torch.ones_like(d2))).sum()
+    ln3 = ((h1 @ h2 - torch.eye(3, dtype=torch.float64)) ** 2).sum()
+    loss = ln1 + ln2 + mu * ln3
+    np.testing.assert_allclose(loss4.cpu().numpy(), [loss.item(), ln1.item(), ln2.item(), ln3.item()], rtol=2e-5)
+    np.testing.assert_allclose(M1.cpu().numpy(), (l1 - l3).detach().numpy(), rtol=1e-4, atol=1e-4)
+    (loss * 0.7).backward()
+    g = torch.tensor([0.7], device="cuda")
+    gf1w, gf2w, gm1w, gm2w, gH1, gH2 = K.bihome_loss_bwd(g, *[dev(a) for a in f], dev(m1w), dev(m2w), None, None, M1, M2,
+                                                         nd, H1, H2, mu)
+    np.testing.assert_allclose(gf1w.cpu().numpy(), f1w.grad.numpy(), rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(gf2w.cpu().numpy(), f2w.grad.numpy(), rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(gm1w.cpu().numpy(), a1.grad.numpy(), rtol=2e-4, atol=1e-4 * a1.grad.abs().max().item())
+    np.testing.assert_allclose(gm2w.cpu().numpy(), a2.grad.numpy(), rtol=2e-4, atol=1e-4 * a2.grad.abs().max().item())
+    np.testing.assert_allclose(gH1.cpu().numpy().reshape(B, 3, 3), h1.grad.numpy(), rtol=1e-6, atol=1e-10)   # g and mu are float32 scalars
+    np.testing.assert_allclose(gH2.cpu().numpy().reshape(B, 3, 3), h2.grad.numpy(), rtol=1e-6, atol=1e-10)
+
+
+def test_head_chain_against_golden(K, golden):
+    """DLT -> corners -> 4pt -> warp + coverage on the head-only golden scenario (reference outputs)."""
+    g = golden("head_b8_f32")
+    d = synth.make_head_inputs(8, 7)
+    for tag, src in (("12", "patch_1"), ("21", "patch_2")):
+        pf = dev(d["pf_hat_" + tag])
+        choice = torch.tensor(g["choice_" + tag]).cuda()
+        Hd, dh, _ = K.dlt_fwd(pf, choice, 1, 128)
+        np.testing.assert_allclose(dh.cpu().numpy(), g["delta_hat_" + tag], atol=2e-3)
+        H64, H32 = K.h4pt_fwd(dh, 128)
+        np.testing.assert_allclose(H32.cpu().numpy(), g["H_4pt_" + tag], rtol=1e-4, atol=2e-5)
+        out, cov = K.warp_fwd(dev(d[src]), H64, 4)
+        np.testing.assert_allclose(out.cpu().numpy()[..., ::4, ::4], g["warp_sub_" + tag], atol=2e-3)
+        np.testing.assert_allclose(cov.cpu().numpy(), g["mask_pooled_" + tag], atol=2e-4)
