@@ -34,6 +34,7 @@ SIGNATURES = {
     "bh_conv_fwd": [P, P, P, P, POINTER(BhConvDesc), P],
     "bh_conv_dgrad": [P, P, P, POINTER(BhConvDesc), c_int, P],
     "bh_conv_wgrad": [P, P, P, P, POINTER(BhConvDesc), P],
+    "bh_bn_stats_doubles": [c_int, c_int],
     "bh_bn_fwd": [P] * 8 + [c_int, c_int, c_int, c_float, c_float, c_int, c_int, P],
     "bh_bn_bwd": [P] * 10 + [c_int, c_int, c_int, c_float, c_int, c_int, P, P, P],
     "bh_maxpool3s2_fwd": [P, P, c_int, c_int, c_int, c_int, P],

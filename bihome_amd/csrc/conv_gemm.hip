@@ -346,8 +346,9 @@ int bh_conv_dgrad(const float* gy, const float* w, float* gx, const bh_conv_desc
     int rc = check_desc(d);
     if (rc) return rc;
     if (!gy || !w || !gx) return BH_E_BADARG;
-    if (d->in_nchw || d->out_nchw) return BH_E_UNSUPPORTED;
+    if (d->in_nchw) return BH_E_UNSUPPORTED;          // network inputs are data: no dgrad
     GemmArgs a = {};
+    a.src_nchw = d->out_nchw;                         // gradient of the NCHW network output
     a.Src = gy; a.Bw = w; a.bias = nullptr; a.Out = gx; a.accumulate = accumulate;
     a.M = d->N * d->Hi * d->Wi; a.Nn = d->Ci; a.Kc = d->Co; a.T = d->kh * d->kw;
     a.Ho = d->Hi; a.Wo = d->Wi;               // output-side grid of this GEMM = conv input grid

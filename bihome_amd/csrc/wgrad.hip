@@ -1,0 +1,235 @@
+// Weight gradient as a split-K GEMM on the f32 MFMA:
+//   Out[p][t][q] += sum_m  P[m][p] * Q[pix(m, t)][q]
+// P is the plain operand indexed by the pixel m ([M][Np], channels contiguous), Q the operand gathered
+// with the forward rule of the convolution.  Conv2d: P = gy, Q = x.  ConvTranspose2d(k == s): P = x,
+// Q = gy (gathered at 2*iy+a, 2*ix+b).  The reduction runs over pixels, so both LDS tiles are
+// written row = pixel (k), float4 along channels - no transpose needed - and every block owns a
+// pixel range (split-K) whose partial result is added with hardware fp32 atomics.
+// Tile 64 (p) x 64 (q) x 32 pixels, 4 waves as 2x2, one 32x32 accumulator each.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgradArgs {
+    const float* P;
+    const float* Q;
+    float* Out;
+    int M, Np, Nq, T;
+    int Ho, Wo;              // pixel grid of m
+    int Hs, Ws, Cq;          // gathered source grid / channels
+    int kw, stride, pad;
+    int q_nchw, p_nchw;
+    long long sOp, sOt;
+    int joint;               // scalar path: GEMM columns run over (t, c) jointly, T' = 1
+    int rows_per_block;
+};
+
+#define WBK 32
+#define WLD 68
+
+__device__ __forceinline__ bool q_coord(const WgradArgs& a, int oy, int ox, int t, int& iy, int& ix) {
+    const int ky = t / a.kw, kx = t - ky * a.kw;
+    iy = oy * a.stride - a.pad + ky;
+    ix = ox * a.stride - a.pad + kx;
+    return iy >= 0 && iy < a.Hs && ix >= 0 && ix < a.Ws;
+}
+
+// grid: (ptiles*qtiles, T', splitK)
+template <bool VEC>
+__global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
+    __shared__ float As[WBK * WLD];
+    __shared__ float Bs[WBK * WLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ncols = a.joint ? a.T * a.Nq : a.Nq;
+    const int qtiles = (ncols + 63) / 64;
+    const int p0 = (blockIdx.x / qtiles) * 64, q0 = (blockIdx.x % qtiles) * 64;
+    const int t = a.joint ? 0 : blockIdx.y;
+    const int mbeg = blockIdx.z * a.rows_per_block;
+    const int mend = min(a.M, mbeg + a.rows_per_block);
+    if (mbeg >= mend) return;
+
+    const int chunk = tid & 15, prow0 = tid >> 4;     // 16 float4 chunks x 16 rows per pass, 2 passes
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+
+    float4 rp[2], rq[2];
+    const int hw = a.Ho * a.Wo;
+
+    auto load_tile = [&](int mk) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = mk + prow0 + i * 16;
+            float4 vp = make_float4(0.f, 0.f, 0.f, 0.f), vq = vp;
+            if (m < mend) {
+                const int pc = p0 + chunk * 4;
+                const int nb = m / hw, rr = m - nb * hw, oy = rr / a.Wo, ox = rr - oy * a.Wo;
+                if (a.p_nchw) {
+                    const float* pp = a.P + ((size_t)nb * a.Np + pc) * hw + rr;
+                    if (pc < a.Np) vp.x = pp[0];
+                    if (pc + 1 < a.Np) vp.y = pp[(size_t)hw];
+                    if (pc + 2 < a.Np) vp.z = pp[2 * (size_t)hw];
+                    if (pc + 3 < a.Np) vp.w = pp[3 * (size_t)hw];
+                } else {
+                    const float* pp = a.P + (size_t)m * a.Np + pc;
+                    if ((a.Np & 3) == 0 && pc + 3 < a.Np) vp = *reinterpret_cast<const float4*>(pp);
+                    else {
+                        if (pc < a.Np) vp.x = pp[0];
+                        if (pc + 1 < a.Np) vp.y = pp[1];
+                        if (pc + 2 < a.Np) vp.z = pp[2];
+                        if (pc + 3 < a.Np) vp.w = pp[3];
+                    }
+                }
+                const int qc = q0 + chunk * 4;
+                if (VEC) {
+                    int iy, ix;
+                    if (qc < a.Nq && q_coord(a, oy, ox, t, iy, ix))
+                        vq = *reinterpret_cast<const float4*>(a.Q + (((size_t)nb * a.Hs + iy) * a.Ws + ix) * a.Cq + qc);
+                } else {
+                    float e[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int col = qc + j;
+                        if (col < ncols) {
+                            int tt = a.joint ? col / a.Nq : t;
+                            int c = a.joint ? col - tt * a.Nq : col;
+                            int iy, ix;
+                            if (q_coord(a, oy, ox, tt, iy, ix)) {
+                                size_t off = a.q_nchw ? ((((size_t)nb * a.Cq + c) * a.Hs + iy) * a.Ws + ix)
+                                                      : ((((size_t)nb * a.Hs + iy) * a.Ws + ix) * a.Cq + c);
+                                e[j] = a.Q[off];
+                            }
+                        }
+                    }
+                    vq = make_float4(e[0], e[1], e[2], e[3]);
+                }
+            }
+            rp[i] = vp; rq[i] = vq;
+        }
+    };
+
+    const int kh2 = lane >> 5, l31 = lane & 31;
+    load_tile(mbeg);
+    for (int mk = mbeg; mk < mend; mk += WBK) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = prow0 + i * 16;
+            *reinterpret_cast<float4*>(&As[row * WLD + chunk * 4]) = rp[i];
+            *reinterpret_cast<float4*>(&Bs[row * WLD + chunk * 4]) = rq[i];
+        }
+        __syncthreads();
+        if (mk + WBK < mend) load_tile(mk + WBK);
+#pragma unroll
+        for (int kk = 0; kk < WBK / 2; ++kk) {
+            const int k = 2 * kk + kh2;
+            float av = As[k * WLD + wm * 32 + l31];
+            float bv = Bs[k * WLD + wn * 32 + l31];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int q = q0 + wn * 32 + l31;
+    if (q < ncols) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int p = p0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh2;
+            if (p < a.Np) atomicAdd(a.Out + (long long)p * a.sOp + (long long)t * a.sOt + q, acc[r]);
+        }
+    }
+}
+
+// column sums of a [M][C] matrix accumulated into out[C] (bias gradients)
+__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ x, int M, int C, int rows_per_block,
+                                                     float* __restrict__ out) {
+    __shared__ float sm[256];
+    const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+    const int rsub = threadIdx.x >> 6;
+    const int mbeg = blockIdx.x * rows_per_block, mend = min(M, mbeg + rows_per_block);
+    float acc = 0.f;
+    if (c < C)
+        for (int m = mbeg + rsub; m < mend; m += 4) acc += x[(size_t)m * C + c];
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64 && c < C) atomicAdd(out + c, sm[threadIdx.x] + sm[threadIdx.x + 64] + sm[threadIdx.x + 128] + sm[threadIdx.x + 192]);
+}
+
+// sum of channel plane c of an NCHW tensor, accumulated into out[0]
+__global__ void __launch_bounds__(256) plane_sum_kernel(const float* __restrict__ x, int N, int C, int c, int hw,
+                                                        float* __restrict__ out) {
+    __shared__ float sm[4];
+    float acc = 0.f;
+    const size_t total = (size_t)N * hw;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        size_t n = i / hw, r = i - n * hw;
+        acc += x[(n * C + c) * hw + r];
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, sm[0] + sm[1] + sm[2] + sm[3]);
+}
+
+extern "C" {
+
+int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, const bh_conv_desc* d, void* stream) {
+    if (!d || !x || !gy || !gw) return BH_E_BADARG;
+    if (d->out_nchw && (d->Co > 4 || d->transposed)) return BH_E_UNSUPPORTED;
+    hipStream_t s = bh_stream(stream);
+    WgradArgs a = {};
+    a.Out = gw;
+    a.T = d->kh * d->kw; a.kw = d->kw;
+    bool vec;
+    if (!d->transposed) {
+        a.P = gy; a.Q = x;
+        a.M = d->N * d->Ho * d->Wo; a.Np = d->Co; a.Nq = d->Ci;
+        a.Ho = d->Ho; a.Wo = d->Wo; a.Hs = d->Hi; a.Ws = d->Wi; a.Cq = d->Ci;
+        a.stride = d->stride; a.pad = d->pad; a.q_nchw = d->in_nchw;
+        a.sOp = (long long)a.T * d->Ci; a.sOt = d->Ci;
+        vec = !d->in_nchw && (d->Ci % 4 == 0);
+        a.p_nchw = d->out_nchw;
+    } else {
+        if (d->kh != d->stride || d->kw != d->stride || d->pad != 0) return BH_E_UNSUPPORTED;
+        a.P = x; a.Q = gy;
+        a.M = d->N * d->Hi * d->Wi; a.Np = d->Ci; a.Nq = d->Co;
+        a.Ho = d->Hi; a.Wo = d->Wi; a.Hs = d->Ho; a.Ws = d->Wo; a.Cq = d->Co;
+        a.stride = d->stride; a.pad = 0; a.q_nchw = 0;
+        a.sOp = (long long)a.T * d->Co; a.sOt = d->Co;
+        vec = (d->Co % 4 == 0);
+    }
+    a.joint = vec ? 0 : 1;
+    const int ncols = a.joint ? a.T * a.Nq : a.Nq;
+    const int tiles = ((a.Np + 63) / 64) * ((ncols + 63) / 64);
+    const int ty = a.joint ? 1 : a.T;
+    int split = (2048 + tiles * ty - 1) / (tiles * ty);
+    int maxsplit = (a.M + 255) / 256;
+    if (split > maxsplit) split = maxsplit;
+    if (split < 1) split = 1;
+    a.rows_per_block = (((a.M + split - 1) / split) + WBK - 1) / WBK * WBK;
+    split = (a.M + a.rows_per_block - 1) / a.rows_per_block;
+    dim3 grid(tiles, ty, split);
+    if (vec) hipLaunchKernelGGL((wgrad_kernel<true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((wgrad_kernel<false>), grid, dim3(256), 0, s, a);
+    BH_LAUNCH_CHECK();
+    if (gbias) {
+        // bias gradient = column sums of gy over all output pixels
+        const int M = d->N * d->Ho * d->Wo, C = d->Co;
+        int blocks = (M + 1023) / 1024;
+        if (blocks > 1024) blocks = 1024;
+        int rpb = (M + blocks - 1) / blocks;
+        if (d->out_nchw) {
+            // planes: treat each (n, c) plane as a [hw][1] matrix
+            const int hwp = d->Ho * d->Wo;
+            for (int c = 0; c < C; ++c) {
+                hipLaunchKernelGGL(plane_sum_kernel, dim3(64), dim3(256), 0, s, gy, d->N, C, c, hwp, gbias + c);
+                BH_LAUNCH_CHECK();
+            }
+        } else {
+            hipLaunchKernelGGL(colsum_kernel, dim3(blocks, (C + 63) / 64), dim3(256), 0, s, gy, M, C, rpb, gbias);
+            BH_LAUNCH_CHECK();
+        }
+    }
+    return BH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,263 @@
+"""Drop-in for the reference's `src.heads.PerceptualHead.Model` (the biHomE head) on gfx950 kernels.
+
+Contract: `Model(backbone, **cfg['MODEL']['HEAD'])`; `forward(data) -> (loss, delta_gt,
+delta_hat[B,4,2])`; `predict_homography(data) -> (delta_hat[B,4,2], None)`; state-dict keys
+`auxiliary_resnet.resnet.{conv1,bn1,layer1.*}` and `backbone.*` as upstream.  Only the branch the shipped
+biHomE configs select is built (TRIPLET_LOSS 'double-line', TRIPLET_DISTANCE 'l1', TRIPLET_AGGREGATION
+'channel-agnostic', str TRIPLET_MARGIN, SAMPLING_STRATEGY 'downsample-mask', AUXILIARY_RESNET 'resnet34'
+layer 1); anything else raises.  Reference: src/heads/PerceptualHead.py:15-767, src/heads/ransac_utils.py:26-161,
+src/data/utils.py:7-59.
+
+Data flow of one training forward (both directions stacked along the batch axis, "2B"):
+    pf[2B,2,h,w] --bh_dlt_fwd--> delta_hat[2B,4,2] --bh_h4pt_fwd--> H[2B,9]
+    patches[2B,1,h,w], H --bh_warp_fwd--> warped[2B,1,h,w] + pooled coverage[2B,h/4,w/4]
+    extractor(patches) (no grad), extractor(warped) (dgrad only)  -> NHWC features [2B,h/4,w/4,64]
+    bh_triplet_l1_fwd + bh_bihome_loss_fwd -> loss
+and the adjoint chain back to pf in `_BiHomELoss.backward` / `_DltFunction.backward`.
+"""
+import torch
+import torch.nn as nn
+
+from .. import kernels as K
+from .. import net
+
+
+# -----------------------------------------------------------------------------------------------
+# frozen ResNet-34 stem + layer1 (parameter container with torchvision's names)
+# -----------------------------------------------------------------------------------------------
+class _BasicBlock(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv1 = nn.Conv2d(c, c, 3, 1, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(c)
+        self.conv2 = nn.Conv2d(c, c, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(c)
+        self.downsample = None
+
+
+class _ResNetStem(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.layer1 = nn.Sequential(_BasicBlock(64), _BasicBlock(64), _BasicBlock(64))
+
+
+class AuxiliaryResnet(nn.Module):
+    """PerceptualHead.py:15-76 for AUXILIARY_RESNET='resnet34', AUXILIARY_RESNET_OUTPUT_LAYER=1.
+    Output is NHWC [N, h/4, w/4, 64] (the layout the triplet kernel reads)."""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        if kwargs.get('AUXILIARY_RESNET', 'resnet34') != 'resnet34' or kwargs.get('AUXILIARY_RESNET_OUTPUT_LAYER', 1) != 1:
+            raise NotImplementedError("only AUXILIARY_RESNET='resnet34' with OUTPUT_LAYER=1 is built")
+        if kwargs.get('WITH_PROJECTION_HEAD') is not None:
+            raise NotImplementedError("WITH_PROJECTION_HEAD is not used by any shipped config")
+        self.resnet = _ResNetStem()
+        self.freeze = kwargs.get('AUXILIARY_RESNET_FREEZE', True)
+        if not self.freeze:
+            raise NotImplementedError("AUXILIARY_RESNET_FREEZE=False is not used by any shipped config")
+        for p in self.resnet.parameters():          # PerceptualHead.py:36-39
+            p.requires_grad = False
+        net.to_kernel_layout_(self)
+        self._runners = {}
+
+    @staticmethod
+    def _gray_weight(w):
+        # x.repeat(1,3,1,1) then a 3-channel conv (PerceptualHead.py:52-55) == 1-channel conv with summed weights
+        return w.sum(dim=1, keepdim=True)
+
+    def _runner(self, in_ch):
+        if in_ch not in self._runners:
+            r = self.resnet
+            prog = net.Program()
+            # a 1-channel NCHW image is already NHWC; RGB input is read as NCHW by the first conv
+            s = prog.conv(0, r.conv1, in_nchw=(in_ch != 1), weight_fn=self._gray_weight if in_ch == 1 else None)
+            s = prog.bn(s, r.bn1, relu=True)
+            s = prog.maxpool(s)
+            for blk in r.layer1:
+                s = prog.basic_block(s, blk)
+            self._runners[in_ch] = net.Runner(self, prog, trainable=False)
+        return self._runners[in_ch]
+
+    def forward(self, x, groups=1):
+        """x [N,1|3,h,w] NCHW -> NHWC features; BatchNorms follow self.training (batch statistics in
+        training although the weights are frozen - SURVEY.md 7), one statistic set per group."""
+        net.to_kernel_layout_(self)
+        N, C, h, w = x.shape
+        x = x.contiguous()
+        if C == 1:
+            x = x.view(N, h, w, 1)
+        return self._runner(C)(x, groups)
+
+    def state_dict(self, *args, **kwargs):
+        net.flush_counters(self)
+        return super().state_dict(*args, **kwargs)
+
+
+# -----------------------------------------------------------------------------------------------
+# autograd nodes
+# -----------------------------------------------------------------------------------------------
+class _DltFunction(torch.autograd.Function):
+    """pf[N,2,h,w], choice[N,n*P] -> delta_hat[N,n,4,2], Hdlt[N,n,3,3]  (ransac_utils.py:47-74 +
+    PerceptualHead.py:125-146,175-178)."""
+
+    @staticmethod
+    def forward(ctx, pf, choice, n, P):
+        pf = pf.contiguous()
+        Hd, dh, eig = K.dlt_fwd(pf, choice, n, P)
+        ctx.save_for_backward(pf, choice, eig)
+        ctx.n, ctx.P = n, P
+        N = pf.shape[0]
+        ctx.mark_non_differentiable(Hd)
+        return dh.view(N, n, 4, 2), Hd.view(N, n, 3, 3)
+
+    @staticmethod
+    def backward(ctx, g_dh, _g_H):
+        pf, choice, eig = ctx.saved_tensors
+        g = g_dh.contiguous().view(-1, 4, 2)
+        return K.dlt_bwd(pf, choice, eig, g, ctx.n, ctx.P), None, None, None
+
+
+class _BiHomELoss(torch.autograd.Function):
+    """triplet_resnet_loss, double-line branch (PerceptualHead.py:320-714) for stacked directions.
+    patches[2B,1,h,w] = cat(patch_1, patch_2); delta[2B,4,2] = cat(delta_hat_12, delta_hat_21)."""
+
+    @staticmethod
+    def forward(ctx, delta, patches, head):
+        B2, _, h, w = patches.shape
+        B = B2 // 2
+        aux = head.auxiliary_resnet
+        delta = delta.contiguous()
+        with torch.no_grad():
+            feat = aux(patches, groups=2)                       # :358,:367  (patch_1 then patch_2 statistics)
+        H64, H32 = K.h4pt_fwd(delta, h)                          # _warp -> four_point_to_homography :237-243
+        pool = 4
+        warped, cov = K.warp_fwd(patches, H64, pool)             # :371,:382,:392,:401,:447-459
+        with torch.enable_grad():
+            wl = warped.detach().requires_grad_(True)
+            featw = aux(wl, groups=2)                            # :377,:398
+        f1, f2, f1w, f2w = feat[:B], feat[B:], featw.detach()[:B], featw.detach()[B:]
+        m1w, m2w = cov[:B], cov[B:]
+        M1, M2, numden = K.triplet_l1_fwd(f1, f2, f1w, f2w, m1w, m2w)      # :559-561,:609-653
+        loss4 = K.bihome_loss_fwd(numden, H64[:B], H64[B:], head.triplet_mu)   # :656-665
+        ctx.head, ctx.B, ctx.pool = head, B, pool
+        ctx.saved = (delta, patches, H64, feat, featw, wl, cov, M1, M2, numden)
+        head.last = {"loss4": loss4, "H_4pt": H32, "warped": warped, "coverage": cov}
+        return loss4[0]
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        delta, patches, H64, feat, featw, wl, cov, M1, M2, numden = ctx.saved
+        ctx.saved = None
+        B, head = ctx.B, ctx.head
+        h = patches.shape[-1]
+        g = g_loss.reshape(1).to(torch.float32).contiguous()
+        fw = featw.detach()
+        gf1w, gf2w, gm1w, gm2w, gH1, gH2 = K.bihome_loss_bwd(g, feat[:B], feat[B:], fw[:B], fw[B:], cov[:B], cov[B:], None,
+                                                             None, M1, M2, numden, H64[:B], H64[B:], head.triplet_mu)
+        gfeatw = torch.cat([gf1w, gf2w], 0)
+        (gwarp,) = torch.autograd.grad(featw, wl, gfeatw)        # extractor dgrad (one NetFunction node)
+        gcov = torch.cat([gm1w, gm2w], 0)
+        gH = torch.cat([gH1, gH2], 0)
+        K.warp_bwd(patches, H64, gwarp.contiguous(), gcov, ctx.pool, gH=gH)
+        gdelta = K.h4pt_bwd(delta, H64, gH, h)
+        return gdelta, None, None
+
+
+# -----------------------------------------------------------------------------------------------
+class Model(nn.Module):
+
+    def __init__(self, backbone, **kwargs):
+        super().__init__()
+        self.backbone = backbone
+        self.patch_size = kwargs['PATCH_SIZE']
+        self.patch_keys = kwargs['PATCH_KEYS']
+        self.delta_hat_keys = kwargs['DELTA_HAT_KEYS']
+        if len(self.delta_hat_keys):
+            self.hypothesis_no = 1
+        else:
+            self.pf_keys = kwargs['PF_KEYS']
+            self.hypothesis_no = kwargs['RANSAC_HYPOTHESIS_NO']
+            self.point_per_hypothesis = kwargs['POINTS_PER_HYPOTHESIS']
+            if kwargs.get('SCORING_METHOD', 'repr_error') != 'repr_error':
+                raise NotImplementedError("only SCORING_METHOD='repr_error' is built")
+        self.triplet_version = kwargs['TRIPLET_LOSS']
+        ok = ('double-line' in self.triplet_version and 'dual' not in self.triplet_version
+              and kwargs.get('TRIPLET_DISTANCE') == 'l1' and kwargs.get('TRIPLET_AGGREGATION') == 'channel-agnostic'
+              and isinstance(kwargs.get('TRIPLET_MARGIN'), str) and not len(kwargs.get('MASK_KEYS', []))
+              and 'upsample' not in str(kwargs.get('SAMPLING_STRATEGY', '')))
+        if not ok:
+            raise NotImplementedError("only the biHomE configuration (double-line / l1 / channel-agnostic / str margin / "
+                                      "no MASK_KEYS / downsample-mask) is built - see SURVEY.md 2 for what is out of scope")
+        self.triplet_mu = kwargs['TRIPLET_MU']
+        self.auxiliary_resnet = AuxiliaryResnet(**kwargs)
+        self.last = {}
+
+    # ---- DSAC -----------------------------------------------------------------------------------------
+    @staticmethod
+    def sample_choice(n_points, count, device):
+        """ransac_utils.py:54-56: torch.multinomial with weights arange(N) (p(i) ~ i; a reference quirk kept)."""
+        w = torch.arange(0, n_points, dtype=torch.float32, device=device)
+        return torch.multinomial(w, count, replacement=True)
+
+    def _choices(self, data, key, B, N, device):
+        if key in data:                                         # test hook: indices supplied (bit-exact pin)
+            return data[key].to(device=device, dtype=torch.int64).reshape(B, -1).contiguous()
+        n, P = self.hypothesis_no, self.point_per_hypothesis
+        return self.sample_choice(N, B * P * n, device).reshape(B, -1)
+
+    def _stacked_pf(self, data):
+        pf12, pf21 = data[self.pf_keys[0]], data[self.pf_keys[1]]
+        st = data.get('_bh_pf_stacked')
+        B = pf12.shape[0]
+        if (st is not None and st.shape[0] == 2 * B and pf12.data_ptr() == st.data_ptr()
+                and pf21.data_ptr() == st[B:].data_ptr()):
+            return st                                           # produced stacked by this build's backbone
+        return torch.cat([pf12, pf21], 0)
+
+    def forward(self, data):
+        e1, e2 = self.patch_keys
+        p1, p2 = data[e1], data[e2]
+        if not p1.is_cuda:
+            raise RuntimeError("bihome_amd heads run on the MI355X only; no CPU fallback (use oracle/ for CPU checks)")
+        B = p1.shape[0]
+        if not len(self.delta_hat_keys):
+            pf = self._stacked_pf(data)
+            N = pf.shape[-1] * pf.shape[-2]
+            c12 = self._choices(data, 'choice_12', B, N, pf.device)
+            c21 = self._choices(data, 'choice_21', B, N, pf.device)
+            dh, Hd = _DltFunction.apply(pf, torch.cat([c12, c21], 0), self.hypothesis_no, self.point_per_hypothesis)
+            if self.hypothesis_no != 1:
+                raise NotImplementedError("training with RANSAC_HYPOTHESIS_NO > 1 is not used by any shipped config")
+            delta = dh.reshape(2 * B, 4, 2)
+            self.last_dlt = Hd
+        else:
+            delta = torch.cat([data[self.delta_hat_keys[0]].reshape(B, 4, 2), data[self.delta_hat_keys[1]].reshape(B, 4, 2)], 0)
+        patches = torch.cat([p1.reshape(B, -1, self.patch_size, self.patch_size),
+                             p2.reshape(B, -1, self.patch_size, self.patch_size)], 0)
+        loss = _BiHomELoss.apply(delta, patches, self)
+        if 'summary_writer' in data:                            # PerceptualHead.py:678-697 (syncs; log steps only)
+            step = data['summary_writer_step']
+            l4 = self.last["loss4"].tolist()
+            data['summary_writer'].add_scalars('loss_comp', {'ln1': l4[1], 'ln2': l4[2], 'ln3': l4[3]}, step)
+        delta_gt = data['delta'] if 'delta' in data else None
+        return loss, delta_gt, delta[:B]
+
+    def predict_homography(self, data):
+        if len(self.delta_hat_keys):
+            return data[self.delta_hat_keys[0]], None
+        pf = data[self.pf_keys[0]].contiguous()
+        B, _, h, w = pf.shape
+        n, P = self.hypothesis_no, self.point_per_hypothesis
+        choice = self._choices(data, 'choice', B, h * w, pf.device)
+        Hd, dh, _ = K.dlt_fwd(pf, choice, n, P)
+        if n == 1:
+            return dh.view(B, 4, 2), None
+        err, best = K.dsac_score(pf, Hd.view(-1, 9), n)         # argmax softmax(-err) == argmin err (:755-757)
+        self.last.update(best=best, repr_error=err)
+        return dh.view(B, n, 4, 2)[torch.arange(B, device=pf.device), best], None
+
+    def state_dict(self, *args, **kwargs):
+        net.flush_counters(self)
+        return super().state_dict(*args, **kwargs)

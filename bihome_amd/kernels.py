@@ -141,3 +141,114 @@ def bihome_loss_bwd(g_loss, f1, f2, f1w, f2w, m1w, m2w, m1, m2, M1, M2, numden, 
                                  _p(M2), _p(numden), _p(H1), _p(H2), B, hf * wf, C, float(mu), _p(g_f1w), _p(g_f2w),
                                  _p(g_m1w), _p(g_m2w), _p(gH1), _p(gH2), _stream()), "bh_bihome_loss_bwd")
     return g_f1w, g_f2w, g_m1w, g_m2w, gH1, gH2
+
+
+# ------------------------------------------------------------------------------------------------
+# conv stacks
+# ------------------------------------------------------------------------------------------------
+def conv_desc(N, Hi, Wi, Ci, Co, k, stride, pad, transposed=False, in_nchw=False, out_nchw=False):
+    d = BhConvDesc()
+    d.N, d.Hi, d.Wi, d.Ci, d.Co = N, Hi, Wi, Ci, Co
+    d.kh = d.kw = k
+    d.stride, d.pad = stride, pad
+    d.transposed, d.in_nchw, d.out_nchw = int(transposed), int(in_nchw), int(out_nchw)
+    if transposed:
+        d.Ho, d.Wo = Hi * stride, Wi * stride
+    else:
+        d.Ho, d.Wo = (Hi + 2 * pad - k) // stride + 1, (Wi + 2 * pad - k) // stride + 1
+    return d
+
+
+def conv_out_shape(d):
+    return (d.N, d.Co, d.Ho, d.Wo) if d.out_nchw else (d.N, d.Ho, d.Wo, d.Co)
+
+
+def conv_fwd(x, w, bias, d):
+    _chk(x); _chk(w); _chk(bias)
+    y = torch.empty(conv_out_shape(d), dtype=torch.float32, device=x.device)
+    check(lib.bh_conv_fwd(_p(x), _p(w), _p(bias), _p(y), ctypes.byref(d), _stream()), "bh_conv_fwd")
+    return y
+
+
+def conv_dgrad(gy, w, d, out=None):
+    _chk(gy); _chk(w)
+    acc = out is not None
+    if out is None:
+        out = torch.empty((d.N, d.Hi, d.Wi, d.Ci), dtype=torch.float32, device=gy.device)
+    check(lib.bh_conv_dgrad(_p(gy), _p(w), _p(out), ctypes.byref(d), int(acc), _stream()), "bh_conv_dgrad")
+    return out
+
+
+def conv_wgrad(x, gy, gw, gbias, d):
+    _chk(x); _chk(gy); _chk(gw); _chk(gbias)
+    check(lib.bh_conv_wgrad(_p(x), _p(gy), _p(gw), _p(gbias), ctypes.byref(d), _stream()), "bh_conv_wgrad")
+
+
+def bn_stats_buffer(groups, C, device):
+    return torch.empty(lib.bh_bn_stats_doubles(groups, C), dtype=torch.float64, device=device)
+
+
+def bn_fwd(x, gamma, beta, rmean, rvar, res, groups, eps, momentum, relu, training):
+    """x [groups*rows..., C] NHWC (any leading shape); returns (y, stats)."""
+    _chk(x); _chk(res)
+    C = x.shape[-1]
+    rows = x.numel() // C // groups
+    y = torch.empty_like(x)
+    stats = bn_stats_buffer(groups, C, x.device)
+    flags = (1 if relu else 0) | (2 if res is not None else 0)
+    check(lib.bh_bn_fwd(_p(x), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(res), _p(y), _p(stats), groups, rows, C,
+                        float(eps), float(momentum), flags, 0 if training else 1, _stream()), "bh_bn_fwd")
+    return y, stats
+
+
+def bn_bwd(gy, y, x, gamma, stats, rmean, rvar, groups, eps, relu, training, want_gres, ggamma=None, gbeta=None):
+    _chk(gy); _chk(x)
+    C = x.shape[-1]
+    rows = x.numel() // C // groups
+    gx = torch.empty_like(x)
+    gres = torch.empty_like(x) if want_gres else None
+    scratch = bn_stats_buffer(groups, C, x.device)
+    flags = (1 if relu else 0) | (2 if want_gres else 0)
+    check(lib.bh_bn_bwd(_p(gy), _p(y), _p(x), _p(gamma), _p(stats), _p(gx), _p(gres), _p(ggamma), _p(gbeta), _p(scratch),
+                        groups, rows, C, float(eps), flags, 0 if training else 1, _p(rmean), _p(rvar), _stream()),
+          "bh_bn_bwd")
+    return gx, gres
+
+
+def maxpool_fwd(x):
+    _chk(x)
+    N, Hi, Wi, C = x.shape
+    y = torch.empty((N, (Hi - 1) // 2 + 1, (Wi - 1) // 2 + 1, C), dtype=torch.float32, device=x.device)
+    check(lib.bh_maxpool3s2_fwd(_p(x), _p(y), N, Hi, Wi, C, _stream()), "bh_maxpool3s2_fwd")
+    return y
+
+
+def maxpool_bwd(x, gy):
+    _chk(x); _chk(gy)
+    N, Hi, Wi, C = x.shape
+    gx = torch.empty_like(x)
+    check(lib.bh_maxpool3s2_bwd(_p(x), _p(gy), _p(gx), N, Hi, Wi, C, _stream()), "bh_maxpool3s2_bwd")
+    return gx
+
+
+def gap_fwd(x):
+    _chk(x)
+    N, H, W, C = x.shape
+    y = torch.empty((N, 1, 1, C), dtype=torch.float32, device=x.device)
+    check(lib.bh_gap_fwd(_p(x), _p(y), N, H * W, C, _stream()), "bh_gap_fwd")
+    return y
+
+
+def gap_bwd(gy, shape):
+    _chk(gy)
+    N, H, W, C = shape
+    gx = torch.empty(shape, dtype=torch.float32, device=gy.device)
+    check(lib.bh_gap_bwd(_p(gy), _p(gx), N, H * W, C, _stream()), "bh_gap_bwd")
+    return gx
+
+
+def add_(a, b):
+    """a += b (same shape, contiguous)."""
+    _chk(a); _chk(b)
+    check(lib.bh_add(_p(a), _p(b), _p(a), a.numel(), _stream()), "bh_add")
+    return a

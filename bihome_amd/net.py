@@ -1,0 +1,337 @@
+"""Conv-stack executor: runs a module tree of Conv2d / ConvTranspose2d / BatchNorm2d / ReLU /
+MaxPool2d leaves (the reference's `nn.Module` layout, kept only as the parameter container and
+state-dict schema) as a flat program of HIP kernel launches on NHWC feature maps, forward and
+backward, without autograd in between.
+
+MI355X-first choices:
+  * the reference runs the backbone once per direction (Rethinking.py:296-313) and the extractor once
+    per patch (PerceptualHead.py:358-398); here those calls are stacked along the batch axis into ONE
+    pass with `groups` independent BatchNorm statistics - half the launches, twice the GEMM M;
+  * weights live in [Cout][kh][kw][Cin] order (torch channels_last), which is the K-contiguous B operand
+    of the implicit GEMM, so no per-step repacking; gradients are written by the wgrad kernel straight
+    into a flat fp32 buffer whose slices are the parameters' `.grad` views (one contiguous RCCL payload);
+  * every launch goes to the current HIP stream with static shapes, so a whole step can be captured
+    in a HIP graph.
+"""
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+
+
+# -----------------------------------------------------------------------------------------------
+# parameter layout helpers
+# -----------------------------------------------------------------------------------------------
+def to_kernel_layout_(module):
+    """Re-lay every conv weight in place as channels_last (values and state-dict shapes unchanged)."""
+    for m in module.modules():
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+            if not m.weight.data.is_contiguous(memory_format=torch.channels_last):
+                m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+    return module
+
+
+def kview(w):
+    """[O,I,kh,kw] channels_last parameter -> contiguous [O,kh,kw,I] view (no copy)."""
+    if w.dim() == 2:
+        return w
+    v = w.permute(0, 2, 3, 1)
+    if not v.is_contiguous():
+        raise RuntimeError("conv weight is not in kernel (channels_last) layout; call net.to_kernel_layout_(module)")
+    return v
+
+
+class FlatGrads:
+    """One flat fp32 buffer holding every trainable parameter's gradient; `.grad` of each parameter is a
+    view into it laid out like the parameter (so wgrad kernels and the optimizer see the same bytes)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        self.offsets, n = [], 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += (p.numel() + 3) // 4 * 4          # keep every segment 16 B aligned
+        self.numel = n
+        self.flat = None
+        self.views = None
+
+    def ensure(self, device):
+        if self.flat is None or self.flat.device != device:
+            self.flat = torch.zeros(self.numel, dtype=torch.float32, device=device)
+            self.views = []
+            for p, off in zip(self.params, self.offsets):
+                seg = self.flat[off:off + p.numel()]
+                if p.dim() == 4:
+                    O, I, kh, kw = p.shape
+                    v = seg.view(O, kh, kw, I).permute(0, 3, 1, 2)
+                else:
+                    v = seg.view(p.shape)
+                self.views.append(v)
+        return self.flat
+
+    def attach(self, device):
+        """Make sure every parameter's .grad is its view; zero the buffer if any was detached
+        (optimizer.zero_grad(set_to_none=True) detaches them all - train.py:305)."""
+        self.ensure(device)
+        detached = False
+        for p, v in zip(self.params, self.views):
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                detached = True
+                break
+        if detached:
+            self.flat.zero_()
+            for p, v in zip(self.params, self.views):
+                p.grad = v
+        return self.flat
+
+
+# -----------------------------------------------------------------------------------------------
+# program
+# -----------------------------------------------------------------------------------------------
+class Op:
+    __slots__ = ("kind", "src", "dst", "mod", "relu", "res", "extra")
+
+    def __init__(self, kind, src, dst, mod=None, relu=False, res=None, extra=None):
+        self.kind, self.src, self.dst, self.mod, self.relu, self.res, self.extra = kind, src, dst, mod, relu, res, extra
+
+
+class Program:
+    """Flat op list over numbered tensor slots. Slot 0 is the input."""
+
+    def __init__(self):
+        self.ops = []
+        self.nslots = 1
+
+    def _new(self):
+        self.nslots += 1
+        return self.nslots - 1
+
+    def conv(self, src, mod, in_nchw=False, out_nchw=False, weight_fn=None):
+        dst = self._new()
+        self.ops.append(Op("conv", src, dst, mod, extra={"in_nchw": in_nchw, "out_nchw": out_nchw, "weight_fn": weight_fn}))
+        return dst
+
+    def bn(self, src, mod, relu=False, res=None):
+        dst = self._new()
+        self.ops.append(Op("bn", src, dst, mod, relu=relu, res=res))
+        return dst
+
+    def maxpool(self, src):
+        dst = self._new()
+        self.ops.append(Op("maxpool", src, dst))
+        return dst
+
+    def gap(self, src):
+        dst = self._new()
+        self.ops.append(Op("gap", src, dst))
+        return dst
+
+    # ---- builders for the reference's block types -------------------------------------------
+    def sequential(self, src, seq):
+        """nn.Sequential of Conv/ConvT/BN/ReLU/MaxPool leaves and residual blocks (in reference order)."""
+        mods = list(seq)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d, nn.Linear)):
+                src = self.conv(src, m)
+            elif isinstance(m, nn.BatchNorm2d):
+                relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                src = self.bn(src, m, relu=relu)
+                if relu:
+                    i += 1
+            elif isinstance(m, nn.MaxPool2d):
+                src = self.maxpool(src)
+            elif hasattr(m, "upper_branch"):
+                src = self.residual(src, m)
+            else:
+                raise TypeError("unsupported leaf %r" % type(m))
+            i += 1
+        return src
+
+    def residual(self, src, blk):
+        """ReLU(upper_branch(x) + lower_branch(x) | x)  (src/backbones/utils.py:60-131): the last BN of the
+        upper branch takes the lower result as fused residual input and applies the ReLU."""
+        low = src
+        if getattr(blk, "lower_branch", None) is not None and len(list(blk.lower_branch)) > 0:
+            low = self.sequential(src, blk.lower_branch)
+        up = list(blk.upper_branch)
+        assert isinstance(up[-1], nn.BatchNorm2d)
+        mid = self.sequential(src, up[:-1])
+        return self.bn(mid, up[-1], relu=True, res=low)
+
+    def basic_block(self, src, blk):
+        """torchvision BasicBlock(conv1,bn1,relu,conv2,bn2,downsample)."""
+        low = src
+        if blk.downsample is not None:
+            low = self.sequential(src, blk.downsample)
+        t = self.bn(self.conv(src, blk.conv1), blk.bn1, relu=True)
+        return self.bn(self.conv(t, blk.conv2), blk.bn2, relu=True, res=low)
+
+
+class Ctx:
+    """Saved tensors of one forward pass."""
+    __slots__ = ("slots", "stats", "descs", "groups", "training", "weights")
+
+    def __init__(self):
+        self.slots, self.stats, self.descs, self.weights = {}, {}, {}, {}
+
+
+def _conv_geometry(mod, x_shape, in_nchw, out_nchw):
+    if in_nchw:
+        N, Ci, Hi, Wi = x_shape
+    else:
+        N, Hi, Wi, Ci = x_shape
+    if isinstance(mod, nn.Linear):
+        return K.conv_desc(N, Hi, Wi, Ci, mod.out_features, 1, 1, 0)
+    k, s, p = mod.kernel_size[0], mod.stride[0], mod.padding[0]
+    tr = isinstance(mod, nn.ConvTranspose2d)
+    Co = mod.out_channels
+    return K.conv_desc(N, Hi, Wi, Ci, Co, k, s, p, transposed=tr, in_nchw=in_nchw, out_nchw=out_nchw)
+
+
+def run_forward(prog, x, groups, training, save):
+    """x: NHWC (or NCHW when the first conv is flagged in_nchw). Returns (out, ctx|None)."""
+    ctx = Ctx() if save else None
+    slots = {0: x}
+    if save:
+        ctx.groups, ctx.training = groups, training
+    for i, op in enumerate(prog.ops):
+        src = slots[op.src]
+        if op.kind == "conv":
+            e = op.extra
+            d = _conv_geometry(op.mod, src.shape, e["in_nchw"], e["out_nchw"])
+            w = e["weight_fn"](op.mod.weight) if e["weight_fn"] else op.mod.weight
+            wk = kview(w)
+            out = K.conv_fwd(src, wk, op.mod.bias, d)
+            if save:
+                ctx.descs[i], ctx.weights[i] = d, wk
+        elif op.kind == "bn":
+            m = op.mod
+            res = slots[op.res] if op.res is not None else None
+            out, st = K.bn_fwd(src, m.weight, m.bias, m.running_mean, m.running_var, res, groups, m.eps,
+                               m.momentum if m.momentum is not None else 0.1, op.relu, training)
+            if training:        # flushed to the `num_batches_tracked` buffer lazily (flush_counters): no per-layer launch
+                m._bh_pending_batches = getattr(m, "_bh_pending_batches", 0) + groups
+            if save:
+                ctx.stats[i] = st
+        elif op.kind == "maxpool":
+            out = K.maxpool_fwd(src)
+        elif op.kind == "gap":
+            out = K.gap_fwd(src)
+        else:
+            raise RuntimeError(op.kind)
+        slots[op.dst] = out
+    if save:
+        ctx.slots = slots
+    return slots[prog.ops[-1].dst], ctx
+
+
+def run_backward(prog, ctx, gout, want_wgrad, want_input_grad):
+    """Adjoint of run_forward. Parameter gradients are accumulated (+=) into each parameter's `.grad`
+    tensor (which must already exist, see FlatGrads). Returns the input gradient or None."""
+    grads = {prog.ops[-1].dst: gout}
+    slots = ctx.slots
+    consumed_by = {}
+    for op in prog.ops:
+        consumed_by.setdefault(op.src, 0)
+        consumed_by[op.src] += 1
+        if op.res is not None:
+            consumed_by[op.res] = consumed_by.get(op.res, 0) + 1
+
+    def contribute(slot, g):
+        if slot in grads:
+            K.add_(grads[slot], g)
+        else:
+            grads[slot] = g
+
+    for i in range(len(prog.ops) - 1, -1, -1):
+        op = prog.ops[i]
+        g = grads.pop(op.dst, None)
+        if g is None:
+            continue
+        need_src_grad = (op.src != 0) or want_input_grad
+        x = slots[op.src]
+        if op.kind == "conv":
+            d, wk = ctx.descs[i], ctx.weights[i]
+            m = op.mod
+            if want_wgrad and m.weight.requires_grad and op.extra["weight_fn"] is None:
+                gw = m.weight.grad if m.weight.dim() == 2 else kview(m.weight.grad)
+                gb = m.bias.grad if (m.bias is not None and m.bias.requires_grad) else None
+                K.conv_wgrad(x, g, gw, gb, d)
+            if need_src_grad:
+                if op.src in grads:
+                    K.conv_dgrad(g, wk, d, out=grads[op.src])
+                else:
+                    grads[op.src] = K.conv_dgrad(g, wk, d)
+        elif op.kind == "bn":
+            m = op.mod
+            train_w = want_wgrad and m.weight is not None and m.weight.requires_grad
+            gx, gres = K.bn_bwd(g, slots[op.dst], x, m.weight, ctx.stats[i], m.running_mean, m.running_var, ctx.groups,
+                                m.eps, op.relu, ctx.training, op.res is not None and ((op.res != 0) or want_input_grad),
+                                m.weight.grad if train_w else None, m.bias.grad if train_w else None)
+            if need_src_grad:
+                contribute(op.src, gx)
+            if gres is not None:
+                contribute(op.res, gres)
+        elif op.kind == "maxpool":
+            if need_src_grad:
+                contribute(op.src, K.maxpool_bwd(x, g))
+        elif op.kind == "gap":
+            if need_src_grad:
+                contribute(op.src, K.gap_bwd(g, tuple(x.shape)))
+    return grads.get(0)
+
+
+def flush_counters(module):
+    """Write the BatchNorm call counters accumulated on the host into the `num_batches_tracked`
+    buffers (kept for state-dict compatibility with the reference's checkpoints)."""
+    for m in module.modules():
+        n = getattr(m, "_bh_pending_batches", 0)
+        if n and getattr(m, "num_batches_tracked", None) is not None:
+            m.num_batches_tracked += n
+            m._bh_pending_batches = 0
+
+
+class NetFunction(torch.autograd.Function):
+    """One autograd node for a whole conv stack: forward = run_forward, backward = run_backward.
+    `anchor` is any trainable parameter of the stack (or a dummy): it only tells autograd that the
+    node has trainable state; parameter gradients are written by the kernels into `.grad` directly."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, runner, groups):
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        out, saved = run_forward(runner.prog, x, groups, runner.module.training, save=need)
+        ctx.runner, ctx.saved, ctx.want_x = runner, saved, ctx.needs_input_grad[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        r = ctx.runner
+        if r.flat is not None:
+            r.flat.attach(g.device)
+        gin = run_backward(r.prog, ctx.saved, g.contiguous(), want_wgrad=r.flat is not None, want_input_grad=ctx.want_x)
+        ctx.saved = None
+        return gin, None, None, None
+
+
+class Runner:
+    """Binds a Program to its nn.Module (parameter container) and, if trainable, a FlatGrads buffer."""
+
+    def __init__(self, module, prog, trainable):
+        self.module, self.prog = module, prog
+        params = [p for p in module.parameters() if p.requires_grad]
+        self.flat = FlatGrads(params) if (trainable and params) else None
+        self.anchor = params[0] if (trainable and params) else None
+        self._dummy = None
+
+    def __call__(self, x, groups):
+        if not x.is_cuda:
+            raise RuntimeError("bihome_amd runs on the MI355X only (input on %s): there is no CPU fallback; "
+                               "use oracle/ for CPU checks" % x.device)
+        anchor = self.anchor
+        if anchor is None:
+            if self._dummy is None or self._dummy.device != x.device:
+                self._dummy = torch.zeros(1, device=x.device)
+            anchor = self._dummy
+        return NetFunction.apply(x, anchor, self, groups)

@@ -1,0 +1,57 @@
+"""Thin step / eval harness: what the reference's driver does around `model(data)`.
+
+`train_step` is one iteration of train.py:296-387 (model.train(), zero_grad, forward, backward, optional
+clip_grad_norm_, Adam step, per-iteration MultiStepLR step); `mace` is train.py:402-403 / eval.py:133-134;
+`build_model` wires backbone + head + optimizer the way train.py:675-711 does.  Host plumbing only
+(autograd, optimizer): all tensor arithmetic is in the HIP kernels.
+"""
+import importlib
+
+import numpy as np
+import torch
+
+
+def build_model(cfg, device="cuda"):
+    bcfg, hcfg = cfg["MODEL"]["BACKBONE"], cfg["MODEL"]["HEAD"]
+    backbone = importlib.import_module("src.backbones." + bcfg["NAME"]).Model(**bcfg)       # train.py:675-679
+    head = importlib.import_module("src.heads." + hcfg["NAME"]).Model(backbone, **hcfg)     # train.py:686-690
+    model = torch.nn.Sequential(backbone, head).to(device)                                  # train.py:696
+    return model
+
+
+def build_optimizer(model, solver):
+    opt = torch.optim.Adam(model.parameters(), lr=solver["LR"], betas=(solver["MOMENTUM_1"], solver["MOMENTUM_2"]),
+                           weight_decay=float(solver.get("L2_WEIGHT_DECAY", 0)))            # train.py:703-707
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=solver["MILESTONES"], gamma=solver["LR_DECAY"])
+    return opt, sched
+
+
+def train_step(model, data, opt, sched, clip=-1.0, reducer=None):
+    model.train()                                                   # train.py:296
+    opt.zero_grad()                                                 # train.py:305
+    loss, delta_gt, delta_hat = model(data)                         # train.py:357
+    loss.backward()                                                 # train.py:379
+    if reducer is not None:
+        reducer.allreduce()                                         # RCCL SUM over ranks
+    if clip > 0:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), clip)    # train.py:382-383
+    opt.step()
+    sched.step()                                                    # train.py:386-387
+    return loss.detach(), delta_gt, delta_hat.detach()
+
+
+def mace(delta_gt, delta_hat):
+    """Mean average corner error (train.py:402-403)."""
+    a = delta_gt.detach().cpu().numpy().reshape(-1, 2)
+    b = delta_hat.detach().cpu().numpy().reshape(-1, 2)
+    return float(np.mean(np.linalg.norm(a - b, axis=-1)))
+
+
+@torch.no_grad()
+def predict(model, data):
+    """eval.py:21-28,109: chain predict_homography over the Sequential's children."""
+    model.eval()
+    out = data
+    for m in model.children():
+        out = m.predict_homography(out)
+    return out[0]

@@ -128,6 +128,9 @@ int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, cons
  *   stats[groups, C, 2] double = {mean, biased var}; running stats are updated group after group
  *   with `momentum`, unbiased variance, exactly like consecutive nn.BatchNorm2d calls.
  *   flags: bit0 relu, bit1 residual add (y = act(bn(x) + res)). eval mode: use_running = 1. */
+/* number of doubles the `stats` (forward) and `scratch` (backward) buffers must hold:
+ * [groups,C,2] results followed by per-chunk partial sums */
+int bh_bn_stats_doubles(int groups, int C);
 int bh_bn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
               const float* res, float* y, double* stats, int groups, int rows, int C, float eps, float momentum,
               int flags, int use_running, void* stream);

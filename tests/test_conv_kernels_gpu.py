@@ -1,0 +1,221 @@
+"""Conv-stack kernels (through the C ABI) against plain PyTorch CPU ops in float64.
+
+The MFMA path multiplies exact fp32 products and accumulates in fp32, so against a float64 reference
+the error is fp32 round-off of a K-term dot product: rtol 2e-5 on outputs normalised by their scale."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    from bihome_amd import kernels
+    return kernels
+
+
+def rnd(shape, seed):
+    return np.random.Generator(np.random.PCG64(seed)).standard_normal(shape).astype(np.float32)
+
+
+def close(a, ref, tol=3e-5):
+    a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    scale = np.abs(ref).max() + 1e-30
+    err = np.abs(a - ref).max() / scale
+    assert err < tol, "max normalised error %.3e (tol %.1e)" % (err, tol)
+
+
+# (N, Hi, Ci, Co, k, stride, pad): the Zeng / ResNet-34 / extractor shape census at small N
+CONV_CASES = [
+    (2, 32, 64, 64, 3, 1, 1), (2, 32, 64, 128, 3, 2, 1), (3, 16, 128, 128, 3, 1, 1), (2, 16, 128, 256, 3, 2, 1),
+    (5, 8, 256, 256, 3, 1, 1), (2, 32, 64, 128, 1, 2, 0), (2, 16, 256, 128, 1, 1, 0), (1, 64, 32, 16, 1, 1, 0),
+    (1, 64, 16, 128, 1, 1, 0), (2, 64, 32, 32, 3, 1, 1), (1, 8, 256, 512, 3, 2, 1), (3, 4, 512, 512, 3, 1, 1),
+    (1, 20, 24, 40, 3, 1, 1), (1, 1, 512, 8, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("N,Hi,Ci,Co,k,s,p", CONV_CASES)
+def test_conv2d_fwd_dgrad_wgrad(K, N, Hi, Ci, Co, k, s, p):
+    x = rnd((N, Ci, Hi, Hi), 1)
+    w = (rnd((Co, Ci, k, k), 2) / np.sqrt(Ci * k * k)).astype(np.float32)
+    b = rnd((Co,), 3)
+    d = K.conv_desc(N, Hi, Hi, Ci, Co, k, s, p)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    ref = F.conv2d(xt, wt, bt, stride=s, padding=p)
+    xg = torch.tensor(x).permute(0, 2, 3, 1).contiguous().cuda()                 # NHWC
+    wg = torch.tensor(w).permute(0, 2, 3, 1).contiguous().cuda()                 # [Co][kh][kw][Ci]
+    y = K.conv_fwd(xg, wg, torch.tensor(b).cuda(), d)
+    close(y.cpu().permute(0, 3, 1, 2), ref.detach())
+    gy = rnd(tuple(ref.shape), 4)
+    ref.backward(torch.tensor(gy, dtype=torch.float64))
+    gyg = torch.tensor(gy).permute(0, 2, 3, 1).contiguous().cuda()
+    gx = K.conv_dgrad(gyg, wg, d)
+    close(gx.cpu().permute(0, 3, 1, 2), xt.grad)
+    # accumulate form
+    base = torch.ones_like(gx)
+    gx2 = K.conv_dgrad(gyg, wg, d, out=base.clone())
+    close((gx2 - 1).cpu().permute(0, 3, 1, 2), xt.grad, 1e-4)
+    gw = torch.zeros_like(wg)
+    gb = torch.zeros(Co, device="cuda")
+    K.conv_wgrad(xg, gyg, gw, gb, d)
+    close(gw.cpu().permute(0, 3, 1, 2), wt.grad)
+    close(gb.cpu(), bt.grad)
+
+
+@pytest.mark.parametrize("N,Hi,Ci,Co", [(2, 8, 256, 256), (2, 8, 256, 128), (1, 16, 128, 64), (1, 32, 64, 32), (1, 64, 32, 16)])
+def test_conv_transpose_2x2(K, N, Hi, Ci, Co):
+    x = rnd((N, Ci, Hi, Hi), 5)
+    w = (rnd((Ci, Co, 2, 2), 6) / np.sqrt(Ci)).astype(np.float32)
+    b = rnd((Co,), 7)
+    d = K.conv_desc(N, Hi, Hi, Ci, Co, 2, 2, 0, transposed=True)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    ref = F.conv_transpose2d(xt, wt, bt, stride=2)
+    xg = torch.tensor(x).permute(0, 2, 3, 1).contiguous().cuda()
+    wg = torch.tensor(w).permute(0, 2, 3, 1).contiguous().cuda()                 # [Ci][kh][kw][Co]
+    y = K.conv_fwd(xg, wg, torch.tensor(b).cuda(), d)
+    close(y.cpu().permute(0, 3, 1, 2), ref.detach())
+    gy = rnd(tuple(ref.shape), 8)
+    ref.backward(torch.tensor(gy, dtype=torch.float64))
+    gyg = torch.tensor(gy).permute(0, 2, 3, 1).contiguous().cuda()
+    close(K.conv_dgrad(gyg, wg, d).cpu().permute(0, 3, 1, 2), xt.grad)
+    gw = torch.zeros_like(wg)
+    gb = torch.zeros(Co, device="cuda")
+    K.conv_wgrad(xg, gyg, gw, gb, d)
+    close(gw.cpu().permute(0, 3, 1, 2), wt.grad)
+    close(gb.cpu(), bt.grad)
+
+
+@pytest.mark.parametrize("N,Hi,Ci,Co", [(3, 32, 2, 64), (2, 48, 3, 64)])
+def test_first_conv_nchw_input(K, N, Hi, Ci, Co):
+    """7x7/2 on the NCHW network input (Rethinking.py:31, ResNet34.py:17): scalar gather path."""
+    x = rnd((N, Ci, Hi, Hi), 9)
+    w = rnd((Co, Ci, 7, 7), 10) / 10
+    d = K.conv_desc(N, Hi, Hi, Ci, Co, 7, 2, 3, in_nchw=True)
+    xt = torch.tensor(x, dtype=torch.float64)
+    wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    ref = F.conv2d(xt, wt, None, stride=2, padding=3)
+    wg = torch.tensor(w).permute(0, 2, 3, 1).contiguous().cuda()
+    y = K.conv_fwd(torch.tensor(x).cuda(), wg, None, d)
+    close(y.cpu().permute(0, 3, 1, 2), ref.detach())
+    gy = rnd(tuple(ref.shape), 11)
+    ref.backward(torch.tensor(gy, dtype=torch.float64))
+    gw = torch.zeros_like(wg)
+    K.conv_wgrad(torch.tensor(x).cuda(), torch.tensor(gy).permute(0, 2, 3, 1).contiguous().cuda(), gw, None, d)
+    close(gw.cpu().permute(0, 3, 1, 2), wt.grad)
+
+
+def test_gray_stem_conv_and_its_dgrad(K):
+    """Extractor conv1 on a 1-channel image (PerceptualHead.py:52-55) and the dgrad the warp needs."""
+    N, Hi = 2, 32
+    x = rnd((N, 1, Hi, Hi), 12)
+    w = rnd((64, 1, 7, 7), 13) / 7
+    d = K.conv_desc(N, Hi, Hi, 1, 64, 7, 2, 3)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    ref = F.conv2d(xt, torch.tensor(w, dtype=torch.float64), None, stride=2, padding=3)
+    wg = torch.tensor(w).permute(0, 2, 3, 1).contiguous().cuda()
+    y = K.conv_fwd(torch.tensor(x).reshape(N, Hi, Hi, 1).cuda(), wg, None, d)
+    close(y.cpu().permute(0, 3, 1, 2), ref.detach())
+    gy = rnd(tuple(ref.shape), 14)
+    ref.backward(torch.tensor(gy, dtype=torch.float64))
+    gx = K.conv_dgrad(torch.tensor(gy).permute(0, 2, 3, 1).contiguous().cuda(), wg, d)
+    close(gx.cpu().reshape(N, 1, Hi, Hi), xt.grad)
+
+
+def test_last_conv_nchw_output(K):
+    """1x1 128->2 with bias writing the NCHW perspective field (Rethinking.py:147) and adjoints fed by an
+    NCHW gradient."""
+    N, Hi, Ci, Co = 2, 16, 128, 2
+    x = rnd((N, Ci, Hi, Hi), 15)
+    w = rnd((Co, Ci, 1, 1), 16) / 11
+    b = rnd((Co,), 17)
+    d = K.conv_desc(N, Hi, Hi, Ci, Co, 1, 1, 0, out_nchw=True)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    ref = F.conv2d(xt, wt, bt)
+    xg = torch.tensor(x).permute(0, 2, 3, 1).contiguous().cuda()
+    wg = torch.tensor(w).permute(0, 2, 3, 1).contiguous().cuda()
+    y = K.conv_fwd(xg, wg, torch.tensor(b).cuda(), d)
+    assert tuple(y.shape) == (N, Co, Hi, Hi)
+    close(y.cpu(), ref.detach())
+    gy = rnd(tuple(ref.shape), 18)
+    ref.backward(torch.tensor(gy, dtype=torch.float64))
+    gyg = torch.tensor(gy).cuda()
+    close(K.conv_dgrad(gyg, wg, d).cpu().permute(0, 3, 1, 2), xt.grad)
+    gw = torch.zeros_like(wg)
+    gb = torch.zeros(Co, device="cuda")
+    K.conv_wgrad(xg, gyg, gw, gb, d)
+    close(gw.cpu().permute(0, 3, 1, 2), wt.grad)
+    close(gb.cpu(), bt.grad)
+
+
+@pytest.mark.parametrize("groups,N,H,C,relu,res,training", [
+    (2, 3, 8, 64, True, True, True), (1, 2, 16, 128, True, False, True), (4, 2, 4, 256, False, False, True),
+    (2, 2, 32, 16, True, True, True), (1, 4, 8, 32, False, True, True), (2, 2, 8, 64, True, True, False),
+    (1, 3, 2, 512, True, False, True)])
+def test_batchnorm_fwd_bwd(K, groups, N, H, C, relu, res, training):
+    x = (rnd((groups * N, C, H, H), 20) * 2 + 0.5).astype(np.float32)
+    r = rnd((groups * N, C, H, H), 21) if res else None
+    gamma, beta = (1 + 0.3 * rnd((C,), 22)).astype(np.float32), (0.2 * rnd((C,), 23)).astype(np.float32)
+    rm0, rv0 = (0.1 * rnd((C,), 24)).astype(np.float32), (1 + 0.2 * np.abs(rnd((C,), 25))).astype(np.float32)
+    bn = torch.nn.BatchNorm2d(C).double()
+    bn.weight.data, bn.bias.data = torch.tensor(gamma, dtype=torch.float64), torch.tensor(beta, dtype=torch.float64)
+    bn.running_mean.data, bn.running_var.data = torch.tensor(rm0, dtype=torch.float64), torch.tensor(rv0, dtype=torch.float64)
+    bn.train(training)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    rt = torch.tensor(r, dtype=torch.float64, requires_grad=True) if res else None
+    outs = []
+    for g in range(groups):                          # one reference call per group, in order
+        o = bn(xt[g * N:(g + 1) * N])
+        if res:
+            o = o + rt[g * N:(g + 1) * N]
+        outs.append(F.relu(o) if relu else o)
+    ref = torch.cat(outs, 0)
+    nhwc = lambda a: torch.tensor(a).permute(0, 2, 3, 1).contiguous().cuda()
+    rm, rv = torch.tensor(rm0).cuda(), torch.tensor(rv0).cuda()
+    gm, bt = torch.tensor(gamma).cuda(), torch.tensor(beta).cuda()
+    y, st = K.bn_fwd(nhwc(x), gm, bt, rm, rv, nhwc(r) if res else None, groups, bn.eps, 0.1, relu, training)
+    close(y.cpu().permute(0, 3, 1, 2), ref.detach(), 2e-5)
+    close(rm.cpu(), bn.running_mean, 1e-5)
+    close(rv.cpu(), bn.running_var, 1e-5)
+    gy = rnd(tuple(ref.shape), 26)
+    if relu:   # a ReLU input within rounding of 0 may get a different sign in float32: exclude those few elements
+        gy[np.abs(y.cpu().permute(0, 3, 1, 2).numpy()) < 1e-5] = 0
+        gy[(np.abs(ref.detach().numpy()) < 1e-5) & (ref.detach().numpy() > 0)] = 0
+    ref.backward(torch.tensor(gy, dtype=torch.float64))
+    gg, gb = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    gx, gres = K.bn_bwd(nhwc(gy), y, nhwc(x), gm, st, rm, rv, groups, bn.eps, relu, training, res, gg, gb)
+    close(gx.cpu().permute(0, 3, 1, 2), xt.grad, 5e-5)
+    close(gg.cpu(), bn.weight.grad, 5e-5)
+    close(gb.cpu(), bn.bias.grad, 5e-5)
+    if res:
+        close(gres.cpu().permute(0, 3, 1, 2), rt.grad, 1e-6)
+
+
+@pytest.mark.parametrize("N,H,C", [(2, 64, 64), (1, 17, 8), (3, 8, 256)])
+def test_maxpool_gap_add(K, N, H, C):
+    x = rnd((N, C, H, H), 30)
+    x[0, :, 2:5, 2:5] = 1.5                      # ties inside windows: first-maximum rule
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    ref = F.max_pool2d(xt, 3, 2, 1)
+    xg = torch.tensor(x).permute(0, 2, 3, 1).contiguous().cuda()
+    y = K.maxpool_fwd(xg)
+    assert torch.equal(y.cpu().permute(0, 3, 1, 2).double(), ref.detach())
+    gy = rnd(tuple(ref.shape), 31)
+    ref.backward(torch.tensor(gy, dtype=torch.float64))
+    gx = K.maxpool_bwd(xg, torch.tensor(gy).permute(0, 2, 3, 1).contiguous().cuda())
+    close(gx.cpu().permute(0, 3, 1, 2), xt.grad, 1e-6)
+    g = K.gap_fwd(xg)
+    close(g.cpu().reshape(N, C), x.mean((2, 3)), 1e-6)
+    gg = K.gap_bwd(g, tuple(xg.shape))
+    close(gg.cpu(), np.broadcast_to(g.cpu().numpy() / (H * H), (N, H, H, C)), 1e-6)
+    a, b = torch.tensor(rnd((1001,), 32)).cuda(), torch.tensor(rnd((1001,), 33)).cuda()
+    s = a + b
+    K.add_(a, b)
+    assert torch.equal(a, s)
