@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Benchmark of the biHomE training hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one full training iteration of BASELINE.json configs[1]: s-coco Zeng backbone + biHomE head,
+batch 64 per GPU, 128x128 grayscale synthetic COCO-style pairs, fp32: model.train(), zero_grad, forward,
+backward, (N>1: RCCL all-reduce SUM of the flat gradient), Adam step, MultiStepLR step
+(train.py:296-387).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line with
+the whole-job image-pairs/s, the roofline of the dominant kernel (per-launch HIP-event timing inside this
+process) and, at N=1, the CPU baseline (the oracle = PyTorch-CPU restatement, timed on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="image pairs per GPU")
+    ap.add_argument("--config", default="zeng-bihome")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, seed=42, batch=8, steps=3, warmup=1):
+    """The oracle (plain PyTorch-CPU restatement of the same modules, oracle/bihome_oracle.py) timed on this
+    box's host cores: a bounded sample (bs=8, `steps` full train steps) of the same workload."""
+    from bihome_amd import synth
+    from bihome_amd.weights import load_synthetic
+    from oracle import bihome_oracle as O
+    # threads actually used: PyTorch-CPU conv/BN stop scaling (and collapse under OpenMP oversubscription) well
+    # before the 100+ hardware threads of a GPU host, so the baseline runs on a bounded pool and says so
+    cores = min(os.cpu_count() or 1, int(os.environ.get("BIHOME_CPU_THREADS", "16")))
+    torch.set_num_threads(cores)
+    bb, head = O.build(cfg)
+    load_synthetic(bb, 0)
+    load_synthetic(head.auxiliary_resnet, 0)
+    opt, sched = O.make_optimizer(torch.nn.Sequential(bb, head), cfg["SOLVER"])
+    d = synth.make_pairs(batch, seed=seed)
+    times, budget_s, t_begin = [], 40.0, time.perf_counter()
+    for it in range(warmup + steps):
+        data = {k: torch.tensor(d[k]) for k in ("patch_1", "patch_2", "delta")}
+        t0 = time.perf_counter()
+        O.train_step(bb, head, opt, sched, data)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_begin > budget_s and len(times) > warmup:      # bounded sample
+            break
+    steps = len(times) - warmup
+    t = float(np.median(times[warmup:]))
+    return {"value": batch / t, "unit": "image-pairs/s", "cores": cores, "kind": "port",
+            "sample": "oracle (PyTorch-CPU restatement) full train step, bs=%d, median of %d steps after %d warm-up, "
+                      "%.2f s/step" % (batch, steps, warmup, t)}
+
+
+def roofline_leg(model, data, opt, sched, reducer, nsteps=2):
+    """Per-launch HIP-event timing (events recorded on the launch stream) of every conv/BN launch for a few
+    extra steps; returns the roofline object of the kernel with the largest total time plus a breakdown."""
+    from bihome_amd import kernels as K
+    from bihome_amd.step import train_step
+    K.TIMING = {}
+    for _ in range(nsteps):
+        train_step(model, dict(data), opt, sched, reducer=reducer)
+    torch.cuda.synchronize()
+    rows = []
+    for name, r in K.TIMING.items():
+        ms = sum(a.elapsed_time(b) for a, b in r["events"])
+        rows.append({"kernel": name, "launches_per_step": r["n"] // nsteps, "ms_per_step": ms / nsteps,
+                     "avg_us": 1e3 * ms / max(r["n"], 1), "tflops": r["flops"] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                     "gbs": r["bytes"] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+                     "flops_per_launch": r["flops"] / max(r["n"], 1), "bytes_per_launch": r["bytes"] / max(r["n"], 1)})
+    K.TIMING = None
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    top = rows[0]
+    if top["tflops"] > 0:
+        roof = {"kernel": top["kernel"], "bound": "mfma", "achieved": top["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": top["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "avg_launch_us": top["avg_us"], "flops_per_launch": top["flops_per_launch"],
+                "launches_per_step": top["launches_per_step"]}
+    else:
+        roof = {"kernel": top["kernel"], "bound": "hbm", "achieved": top["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": top["gbs"] / PEAK_HBM_GBS, "traffic": None, "avg_launch_us": top["avg_us"],
+                "bytes_per_launch": top["bytes_per_launch"], "launches_per_step": top["launches_per_step"]}
+    return roof, rows
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    from bihome_amd import configs, synth
+    from bihome_amd.step import attach_reducer, build_model, build_optimizer, mace, train_step
+    from bihome_amd.weights import load_synthetic
+
+    cfg = configs.get(args.config)
+    model = build_model(cfg, "cuda")
+    load_synthetic(model[0], 0)                       # identical replicas on every rank
+    load_synthetic(model[1].auxiliary_resnet, 0)
+    opt, sched = build_optimizer(model, cfg["SOLVER"])
+    reducer = attach_reducer(model) if world > 1 else None
+
+    B = args.batch
+    # each rank owns its contiguous shard of the global batch; synthetic data generated on the host
+    # from seeds, then resident in HBM for the whole run
+    d = synth.make_pairs(B, seed=42 + rank, photometric_max_delta=cfg["DATA"]["PHOTOMETRIC_MAX_DELTA"])
+    data = {k: torch.tensor(d[k]).cuda() for k in ("patch_1", "patch_2", "delta")}
+    torch.manual_seed(1234 + rank)                    # DSAC sample indices: per-rank stream
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss, dgt, dh = train_step(model, dict(data), opt, sched, reducer=reducer)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, dgt, dh = train_step(model, dict(data), opt, sched, reducer=reducer)
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    ms = 1e3 * dt / args.steps
+    value = world * B * args.steps / dt
+    final_loss, final_mace = float(loss.item()), mace(dgt, dh)
+
+    roof, rows = (None, None)
+    if not args.no_roofline:
+        roof, rows = roofline_leg(model, data, opt, sched, reducer)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg)
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
+        out = {
+            "metric": "training image-pairs/s (128x128 patch, bs=64 per GPU, full step: fwd+bwd+Adam)",
+            "value": value, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (seeded COCO-style texture pairs, random-init weights)",
+            "config": {"workload": "BASELINE.json configs[1]: s-coco Zeng (Rethinking/ResNet34 blocks) backbone + biHomE "
+                                   "head, %d pairs/GPU, 128x128 grayscale, fp32 MFMA conv + HIP warp/DLT/triplet kernels" % B,
+                       "global_batch": world * B, "parallelism": "dp%d" % world, "optimizer": "Adam lr 1e-3"},
+            "final_loss": final_loss, "final_mace": final_mace,
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        if rows:
+            out["kernel_breakdown"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()
+                                        if k in ("kernel", "launches_per_step", "ms_per_step", "avg_us", "tflops", "gbs")}
+                                       for r in rows[:12]]
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

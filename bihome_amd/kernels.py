@@ -15,6 +15,58 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# ------------------------------------------------------------------------------------------------
+# optional per-launch timing (bench.py's roofline leg): HIP events on the launch stream around each call
+# ------------------------------------------------------------------------------------------------
+TIMING = None       # None, or dict name -> {"events": [(start, end)], "flops": float, "bytes": float, "n": int}
+
+
+class _Timed:
+    __slots__ = ("name", "flops", "bytes", "ev")
+
+    def __init__(self, name, flops=0.0, nbytes=0.0):
+        self.name, self.flops, self.bytes = name, flops, nbytes
+
+    def __enter__(self):
+        if TIMING is not None:
+            self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.ev[0].record()
+        return self
+
+    def __exit__(self, *exc):
+        if TIMING is not None:
+            self.ev[1].record()
+            r = TIMING.setdefault(self.name, {"events": [], "flops": 0.0, "bytes": 0.0, "n": 0})
+            r["events"].append(self.ev)
+            r["flops"] += self.flops
+            r["bytes"] += self.bytes
+            r["n"] += 1
+
+
+def gemm_variant(Nn, Kc, vec):
+    """Mirror of conv_gemm.hip's dispatch(): which template instantiation a launch uses (the kernel
+    symbol rocprofv3 reports: conv_gemm_kernel<BN, BK, VEC>)."""
+    BN = 128 if Nn > 64 else (64 if Nn > 32 else 32)
+    BK = 16 if (vec and (Kc % 32) != 0 and Kc <= 16) else 32
+    return "conv_gemm_kernel<%d,%d,%s>" % (BN, BK, "true" if vec else "false")
+
+
+def _conv_variant(d, which):
+    if which == "fwd":
+        vec = (not d.in_nchw) and d.Ci % 4 == 0
+        Nn = d.kh * d.kw * d.Co if d.transposed else d.Co
+        return gemm_variant(Nn, d.Ci, vec)
+    vec = (not d.out_nchw) and d.Co % 4 == 0
+    return gemm_variant(d.Ci, d.Co, vec)
+
+
+def conv_flops(d):
+    """Algorithmic flops of one conv launch: 2 * MACs (same count for fwd, dgrad and wgrad)."""
+    if d.transposed:
+        return 2.0 * d.N * d.Hi * d.Wi * d.Ci * d.Co * d.kh * d.kw
+    return 2.0 * d.N * d.Ho * d.Wo * d.Co * d.Ci * d.kh * d.kw
+
+
 def _chk(t, dtype=torch.float32):
     if t is None:
         return
@@ -166,7 +218,8 @@ def conv_out_shape(d):
 def conv_fwd(x, w, bias, d):
     _chk(x); _chk(w); _chk(bias)
     y = torch.empty(conv_out_shape(d), dtype=torch.float32, device=x.device)
-    check(lib.bh_conv_fwd(_p(x), _p(w), _p(bias), _p(y), ctypes.byref(d), _stream()), "bh_conv_fwd")
+    with _Timed(_conv_variant(d, "fwd"), conv_flops(d), 4.0 * (x.numel() + y.numel() + w.numel())):
+        check(lib.bh_conv_fwd(_p(x), _p(w), _p(bias), _p(y), ctypes.byref(d), _stream()), "bh_conv_fwd")
     return y
 
 
@@ -175,13 +228,15 @@ def conv_dgrad(gy, w, d, out=None):
     acc = out is not None
     if out is None:
         out = torch.empty((d.N, d.Hi, d.Wi, d.Ci), dtype=torch.float32, device=gy.device)
-    check(lib.bh_conv_dgrad(_p(gy), _p(w), _p(out), ctypes.byref(d), int(acc), _stream()), "bh_conv_dgrad")
+    with _Timed(_conv_variant(d, "dgrad"), conv_flops(d), 4.0 * (gy.numel() + out.numel() * (2 if acc else 1) + w.numel())):
+        check(lib.bh_conv_dgrad(_p(gy), _p(w), _p(out), ctypes.byref(d), int(acc), _stream()), "bh_conv_dgrad")
     return out
 
 
 def conv_wgrad(x, gy, gw, gbias, d):
     _chk(x); _chk(gy); _chk(gw); _chk(gbias)
-    check(lib.bh_conv_wgrad(_p(x), _p(gy), _p(gw), _p(gbias), ctypes.byref(d), _stream()), "bh_conv_wgrad")
+    with _Timed("wgrad_kernel", conv_flops(d), 4.0 * (x.numel() + gy.numel() + gw.numel())):
+        check(lib.bh_conv_wgrad(_p(x), _p(gy), _p(gw), _p(gbias), ctypes.byref(d), _stream()), "bh_conv_wgrad")
 
 
 def bn_stats_buffer(groups, C, device):
@@ -196,8 +251,10 @@ def bn_fwd(x, gamma, beta, rmean, rvar, res, groups, eps, momentum, relu, traini
     y = torch.empty_like(x)
     stats = bn_stats_buffer(groups, C, x.device)
     flags = (1 if relu else 0) | (2 if res is not None else 0)
-    check(lib.bh_bn_fwd(_p(x), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(res), _p(y), _p(stats), groups, rows, C,
-                        float(eps), float(momentum), flags, 0 if training else 1, _stream()), "bh_bn_fwd")
+    nb = 4.0 * x.numel() * ((2 if training else 1) + 1 + (1 if res is not None else 0))
+    with _Timed("bn_fwd(3 kernels)", 0.0, nb):
+        check(lib.bh_bn_fwd(_p(x), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(res), _p(y), _p(stats), groups, rows, C,
+                            float(eps), float(momentum), flags, 0 if training else 1, _stream()), "bh_bn_fwd")
     return y, stats
 
 
@@ -209,9 +266,11 @@ def bn_bwd(gy, y, x, gamma, stats, rmean, rvar, groups, eps, relu, training, wan
     gres = torch.empty_like(x) if want_gres else None
     scratch = bn_stats_buffer(groups, C, x.device)
     flags = (1 if relu else 0) | (2 if want_gres else 0)
-    check(lib.bh_bn_bwd(_p(gy), _p(y), _p(x), _p(gamma), _p(stats), _p(gx), _p(gres), _p(ggamma), _p(gbeta), _p(scratch),
-                        groups, rows, C, float(eps), flags, 0 if training else 1, _p(rmean), _p(rvar), _stream()),
-          "bh_bn_bwd")
+    nb = 4.0 * x.numel() * (2 * (2 + (1 if relu else 0)) + 1 + (1 if want_gres else 0))
+    with _Timed("bn_bwd(3 kernels)", 0.0, nb):
+        check(lib.bh_bn_bwd(_p(gy), _p(y), _p(x), _p(gamma), _p(stats), _p(gx), _p(gres), _p(ggamma), _p(gbeta),
+                            _p(scratch), groups, rows, C, float(eps), flags, 0 if training else 1, _p(rmean), _p(rvar),
+                            _stream()), "bh_bn_bwd")
     return gx, gres
 
 

@@ -227,7 +227,7 @@ def run_forward(prog, x, groups, training, save):
     return slots[prog.ops[-1].dst], ctx
 
 
-def run_backward(prog, ctx, gout, want_wgrad, want_input_grad):
+def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=None):
     """Adjoint of run_forward. Parameter gradients are accumulated (+=) into each parameter's `.grad`
     tensor (which must already exist, see FlatGrads). Returns the input gradient or None."""
     grads = {prog.ops[-1].dst: gout}
@@ -259,6 +259,10 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad):
                 gw = m.weight.grad if m.weight.dim() == 2 else kview(m.weight.grad)
                 gb = m.bias.grad if (m.bias is not None and m.bias.requires_grad) else None
                 K.conv_wgrad(x, g, gw, gb, d)
+                if on_param_grad is not None:       # gradient of this layer is final: its bucket may leave
+                    on_param_grad(m.weight)
+                    if gb is not None:
+                        on_param_grad(m.bias)
             if need_src_grad:
                 if op.src in grads:
                     K.conv_dgrad(g, wk, d, out=grads[op.src])
@@ -270,6 +274,9 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad):
             gx, gres = K.bn_bwd(g, slots[op.dst], x, m.weight, ctx.stats[i], m.running_mean, m.running_var, ctx.groups,
                                 m.eps, op.relu, ctx.training, op.res is not None and ((op.res != 0) or want_input_grad),
                                 m.weight.grad if train_w else None, m.bias.grad if train_w else None)
+            if train_w and on_param_grad is not None:
+                on_param_grad(m.weight)
+                on_param_grad(m.bias)
             if need_src_grad:
                 contribute(op.src, gx)
             if gres is not None:
@@ -310,7 +317,9 @@ class NetFunction(torch.autograd.Function):
         r = ctx.runner
         if r.flat is not None:
             r.flat.attach(g.device)
-        gin = run_backward(r.prog, ctx.saved, g.contiguous(), want_wgrad=r.flat is not None, want_input_grad=ctx.want_x)
+        hook = r.reducer.param_ready if r.reducer is not None else None
+        gin = run_backward(r.prog, ctx.saved, g.contiguous(), want_wgrad=r.flat is not None, want_input_grad=ctx.want_x,
+                           on_param_grad=hook)
         ctx.saved = None
         return gin, None, None, None
 
@@ -324,6 +333,7 @@ class Runner:
         self.flat = FlatGrads(params) if (trainable and params) else None
         self.anchor = params[0] if (trainable and params) else None
         self._dummy = None
+        self.reducer = None        # bihome_amd.ddp.FlatGradReducer when training data-parallel
 
     def __call__(self, x, groups):
         if not x.is_cuda:

@@ -55,3 +55,16 @@ def predict(model, data):
     for m in model.children():
         out = m.predict_homography(out)
     return out[0]
+
+
+def attach_reducer(model, bucket_bytes=8 << 20):
+    """Data-parallel training: give the backbone's runner a FlatGradReducer (RCCL all-reduce SUM of the
+    flat gradient buffer, launched bucket by bucket from inside the backward pass)."""
+    from .ddp import FlatGradReducer
+    backbone = model[0]
+    if backbone._runner is None:
+        backbone._runner = backbone._build()
+    r = backbone._runner
+    r.flat.ensure(next(backbone.parameters()).device)
+    r.reducer = FlatGradReducer(r.flat, bucket_bytes=bucket_bytes)
+    return r.reducer
