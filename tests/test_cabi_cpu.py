@@ -1,0 +1,100 @@
+"""CPU-side checks of the boundary: the shared library loads without a GPU and exports exactly the
+symbols include/bihome.h declares; host-side program construction; the product never reaches into oracle/."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "bihome.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\bint\s+(bh_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from bihome_amd import _lib
+    syms = header_symbols()
+    assert len(syms) >= 20
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(raw, s), "libbihome_hip.so does not export %s" % s
+    assert sorted(_lib.SIGNATURES) == syms, (set(_lib.SIGNATURES) ^ set(syms))
+    assert _lib.lib.bh_version() >= 1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from bihome_amd import _lib
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.BihomeLibError, match="no CPU fallback"):
+        _lib._load()
+
+
+def test_cpu_tensors_are_refused():
+    from bihome_amd import kernels as K
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        K.h4pt_fwd(torch.zeros(2, 4, 2), 128)
+
+
+def test_product_does_not_import_oracle():
+    bad = []
+    for base in ("bihome_amd", "src"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith(".py"):
+                    t = open(os.path.join(dp, f)).read()
+                    if re.search(r"^\s*(from|import)\s+oracle\b", t, flags=re.M) or "/root/reference" in t:
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad
+
+
+def test_zeng_program_shape():
+    from bihome_amd import configs
+    from bihome_amd.backbones.Rethinking import Model
+    m = Model(**configs.get("zeng-bihome")["MODEL"]["BACKBONE"])
+    r = m._build()
+    kinds = [op.kind for op in r.prog.ops]
+    assert kinds.count("bn") == 54                      # 54 BatchNorms in the backbone
+    assert kinds.count("conv") == 59 and kinds.count("maxpool") == 1
+    assert r.prog.ops[0].extra["in_nchw"] and r.prog.ops[-1].extra["out_nchw"]
+    assert sum(p.numel() for p in m.parameters()) == 10574178
+    # every conv weight is in kernel layout and FlatGrads views alias it stride for stride
+    for p in m.parameters():
+        if p.dim() == 4:
+            assert p.permute(0, 2, 3, 1).is_contiguous()
+    r.flat.attach(torch.device("cpu"))
+    for p in m.parameters():
+        assert p.grad is not None
+        if p.dim() == 4:        # same memory order as the parameter (strides of size-1 dims are free)
+            assert p.grad.permute(0, 2, 3, 1).is_contiguous()
+
+
+def test_conv_desc_and_variant():
+    from bihome_amd import kernels as K
+    d = K.conv_desc(128, 128, 128, 2, 64, 7, 2, 3, in_nchw=True)
+    assert (d.Ho, d.Wo) == (64, 64) and K.conv_out_shape(d) == (128, 64, 64, 64)
+    d = K.conv_desc(4, 8, 8, 256, 128, 2, 2, 0, transposed=True)
+    assert (d.Ho, d.Wo) == (16, 16)
+    assert K.conv_flops(d) == 2.0 * 4 * 64 * 256 * 128 * 4
+    assert K.gemm_variant(256, 256, True) == "conv_gemm_kernel<128,32,true>"
+    assert K.gemm_variant(2, 128, True) == "conv_gemm_kernel<32,32,true>"
+    assert K.gemm_variant(128, 16, True) == "conv_gemm_kernel<128,16,true>"
+    assert K.gemm_variant(64, 2, False) == "conv_gemm_kernel<64,32,false>"
+
+
+def test_synthetic_pairs_are_consistent():
+    """delta_gt really is the homography between the two patches (sanity of the synthetic generator)."""
+    import numpy as np
+    from bihome_amd import synth
+    d = synth.make_pairs(3, seed=5)
+    assert d["patch_1"].shape == (3, 1, 128, 128) and d["delta"].min() >= -32 and d["delta"].max() <= 31
+    c = np.array([[0, 0], [128, 0], [128, 128], [0, 128]], np.float64)
+    for b in range(3):
+        H = synth.four_point_homography(c, c + d["delta"][b])
+        w = synth.warp_bilinear(d["patch_1"][b].transpose(1, 2, 0).astype(np.float64), H, 128, 128)[..., 0]
+        inside = synth.warp_bilinear(np.ones((128, 128, 1)), H, 128, 128)[..., 0] == 1
+        assert np.abs(w - d["patch_2"][b, 0])[inside].mean() < 0.02
