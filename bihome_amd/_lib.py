@@ -37,7 +37,7 @@ SIGNATURES = {
     "bh_bn_stats_doubles": [c_int, c_int],
     "bh_bn_fwd": [P] * 8 + [c_int, c_int, c_int, c_float, c_float, c_int, c_int, P],
     "bh_bn_bwd": [P] * 10 + [c_int, c_int, c_int, c_float, c_int, c_int, P, P, P],
-    "bh_maxpool3s2_fwd": [P, P, c_int, c_int, c_int, c_int, P],
+    "bh_maxpool3s2_fwd": [P, P, P, c_int, c_int, c_int, c_int, P],
     "bh_maxpool3s2_bwd": [P, P, P, c_int, c_int, c_int, c_int, P],
     "bh_gap_fwd": [P, P, c_int, c_int, c_int, P],
     "bh_gap_bwd": [P, P, c_int, c_int, c_int, P],

@@ -7,7 +7,7 @@
 //   backward: reduce partials (sum dy, sum dy*xhat) -> finalize (dgamma/dbeta) -> apply (dx, dres)
 #include "common.h"
 
-#define BN_MAX_CHUNKS 64
+#define BN_MAX_CHUNKS 256
 
 struct BnGeom {
     int groups, rows, C, C4, LPR, RPP, nchunks, rows_per_chunk;
@@ -18,7 +18,7 @@ static bool bn_geom(int groups, int rows, int C, BnGeom& g) {
     g.groups = groups; g.rows = rows; g.C = C; g.C4 = C / 4;
     if (g.C4 > 256 || (256 % g.C4)) return false;
     g.LPR = g.C4; g.RPP = 256 / g.LPR;
-    int n = rows / (g.RPP * 8);
+    int n = rows / (g.RPP * 4);          // >= 4 rows per lane per chunk; up to 256 chunks x groups workgroups
     if (n < 1) n = 1;
     if (n > BN_MAX_CHUNKS) n = BN_MAX_CHUNKS;
     g.rows_per_chunk = (rows + n - 1) / n;
@@ -57,32 +57,37 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const float* __restrict__
     }
 }
 
-// one thread per channel; groups processed in order so that the running statistics see the same
-// sequence of momentum updates as consecutive nn.BatchNorm2d calls
-__global__ void bn_finalize_kernel(const double* __restrict__ part, BnGeom g, float momentum,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var,
-                                   double* __restrict__ stats) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= g.C) return;
+// one wavefront per channel (lanes stride over the chunk partials, shuffle-reduce); groups are processed in
+// order so that the running statistics see the same sequence of momentum updates as consecutive
+// nn.BatchNorm2d calls
+__global__ void __launch_bounds__(64) bn_finalize_kernel(const double* __restrict__ part, BnGeom g, float momentum,
+                                                         float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                         double* __restrict__ stats) {
+    const int c = blockIdx.x, lane = threadIdx.x;
     float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 1.f;
     const double n = (double)g.rows;
     for (int grp = 0; grp < g.groups; ++grp) {
         double s = 0, ss = 0;
-        for (int k = 0; k < g.nchunks; ++k) {
+        for (int k = lane; k < g.nchunks; k += 64) {
             const double* p = part + (((size_t)grp * g.nchunks + k) * g.C + c) * 2;
             s += p[0]; ss += p[1];
         }
+        s = wave_sum(s); ss = wave_sum(ss);
         const double mean = s / n;
         double var = ss / n - mean * mean;
         if (var < 0) var = 0;
-        stats[((size_t)grp * g.C + c) * 2] = mean;
-        stats[((size_t)grp * g.C + c) * 2 + 1] = var;
+        if (lane == 0) {
+            stats[((size_t)grp * g.C + c) * 2] = mean;
+            stats[((size_t)grp * g.C + c) * 2 + 1] = var;
+        }
         const float unb = (float)(n > 1 ? var * n / (n - 1) : var);
         rm = (1.f - momentum) * rm + momentum * (float)mean;
         rv = (1.f - momentum) * rv + momentum * unb;
     }
-    if (running_mean) running_mean[c] = rm;
-    if (running_var) running_var[c] = rv;
+    if (lane == 0) {
+        if (running_mean) running_mean[c] = rm;
+        if (running_var) running_var[c] = rv;
+    }
 }
 
 __device__ __forceinline__ void bn_coeffs(const double* __restrict__ stats, const float* __restrict__ gamma,
@@ -171,23 +176,28 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restr
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, BnGeom g, float* __restrict__ ggamma,
-                                       float* __restrict__ gbeta, double* __restrict__ sums) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= g.C) return;
+__global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const double* __restrict__ part, BnGeom g,
+                                                             float* __restrict__ ggamma, float* __restrict__ gbeta,
+                                                             double* __restrict__ sums) {
+    const int c = blockIdx.x, lane = threadIdx.x;
     double tg = 0, tb = 0;
     for (int grp = 0; grp < g.groups; ++grp) {
         double s1 = 0, s2 = 0;
-        for (int k = 0; k < g.nchunks; ++k) {
+        for (int k = lane; k < g.nchunks; k += 64) {
             const double* p = part + (((size_t)grp * g.nchunks + k) * g.C + c) * 2;
             s1 += p[0]; s2 += p[1];
         }
-        sums[((size_t)grp * g.C + c) * 2] = s1;
-        sums[((size_t)grp * g.C + c) * 2 + 1] = s2;
+        s1 = wave_sum(s1); s2 = wave_sum(s2);
+        if (lane == 0) {
+            sums[((size_t)grp * g.C + c) * 2] = s1;
+            sums[((size_t)grp * g.C + c) * 2 + 1] = s2;
+        }
         tb += s1; tg += s2;
     }
-    if (ggamma) ggamma[c] += (float)tg;
-    if (gbeta) gbeta[c] += (float)tb;
+    if (lane == 0) {
+        if (ggamma) ggamma[c] += (float)tg;
+        if (gbeta) gbeta[c] += (float)tb;
+    }
 }
 
 // grid (nblk, groups)
@@ -260,8 +270,7 @@ int bh_bn_fwd(const float* x, const float* gamma, const float* beta, float* runn
         double* part = stats + (size_t)groups * C * 2;
         hipLaunchKernelGGL(bn_stats_kernel, dim3(g.nchunks, groups), dim3(256), 0, s, x, g, part);
         BH_LAUNCH_CHECK();
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, s, part, g, momentum, running_mean,
-                           running_var, stats);
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, part, g, momentum, running_mean, running_var, stats);
         BH_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(bn_apply_kernel, dim3(apply_blocks(g), groups), dim3(256), 0, s, x, gamma, beta, running_mean,
@@ -282,7 +291,7 @@ int bh_bn_bwd(const float* gy, const float* y, const float* x, const float* gamm
         hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(g.nchunks, groups), dim3(256), 0, s, gy, y, x, stats, running_mean,
                            running_var, g, eps, flags, use_running, part);
         BH_LAUNCH_CHECK();
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, s, part, g, ggamma, gbeta, scratch);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, part, g, ggamma, gbeta, scratch);
         BH_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(apply_blocks(g), groups), dim3(256), 0, s, gy, y, x, gamma, stats,

@@ -35,7 +35,6 @@ struct GemmArgs {
     int ek, eC;            // scatter: kernel (== stride) and real channel count (Nn = ek*ek*eC)
 };
 
-#define BM 128
 
 __device__ __forceinline__ bool src_coord(const GemmArgs& a, int oy, int ox, int t, int& iy, int& ix) {
     const int ky = t / a.kw, kx = t - ky * a.kw;
@@ -54,10 +53,11 @@ __device__ __forceinline__ bool src_coord(const GemmArgs& a, int oy, int ox, int
     return iy >= 0 && iy < a.Hs && ix >= 0 && ix < a.Ws;
 }
 
-template <int BN, int BK, bool VEC>
+template <int BM, int BN, int BK, bool VEC>
 __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
     constexpr int WN = (BN >= 64) ? 2 : 1;         // waves along N
     constexpr int WM = 4 / WN;                     // waves along M
+    static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "tile/wave mismatch");
     constexpr int TM = BM / (WM * 32);             // 32x32 MFMA tiles per wave along M
     constexpr int TN = BN / (WN * 32);
     constexpr int LDA = BM + 1;
@@ -280,27 +280,89 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
     }
 }
 
-template <int BN, int BK, bool VEC>
+template <int BM, int BN, int BK, bool VEC>
 static int launch(const GemmArgs& a, hipStream_t s) {
     dim3 grid((a.M + BM - 1) / BM, (a.Nn + BN - 1) / BN);
-    hipLaunchKernelGGL((conv_gemm_kernel<BN, BK, VEC>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, VEC>), grid, dim3(256), 0, s, a);
     BH_LAUNCH_CHECK();
     return BH_OK;
 }
 
+// Tile choice: the largest tile that still gives the 256 CUs about two workgroups each; the small-spatial
+// layers (8x8x256ch, 16x16x128ch at 2B = 128) otherwise launch only 128-256 workgroups.
 static int dispatch(const GemmArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.Nn <= 0) return BH_OK;
-    const bool vec = !a.src_nchw && (a.Kc % 4 == 0) && (a.Cs % 4 == 0) &&
-                     (a.b_kcontig ? true : true);
+    const bool vec = !a.src_nchw && (a.Kc % 4 == 0) && (a.Cs % 4 == 0);
     if (!vec) {
-        if (a.Nn > 64) return launch<128, 32, false>(a, s);
-        if (a.Nn > 32) return launch<64, 32, false>(a, s);
-        return launch<32, 32, false>(a, s);
+        if (a.Nn > 64) return launch<128, 128, 32, false>(a, s);
+        if (a.Nn > 32) return launch<128, 64, 32, false>(a, s);
+        return launch<128, 32, 32, false>(a, s);
     }
     const bool k16 = (a.Kc % 32) != 0 && a.Kc <= 16;
-    if (a.Nn > 64) return k16 ? launch<128, 16, true>(a, s) : launch<128, 32, true>(a, s);
-    if (a.Nn > 32) return k16 ? launch<64, 16, true>(a, s) : launch<64, 32, true>(a, s);
-    return k16 ? launch<32, 16, true>(a, s) : launch<32, 32, true>(a, s);
+    const long long mt128 = (a.M + 127) / 128;
+    if (a.Nn > 64) {
+        if (k16) return launch<128, 128, 16, true>(a, s);
+        const long long nt = (a.Nn + 127) / 128;
+        if (mt128 * nt >= 400) return launch<128, 128, 32, true>(a, s);
+        if (2 * mt128 * nt >= 400) return launch<64, 128, 32, true>(a, s);
+        return launch<64, 64, 32, true>(a, s);
+    }
+    if (a.Nn > 32) {
+        if (k16) return launch<128, 64, 16, true>(a, s);
+        if (mt128 >= 400) return launch<128, 64, 32, true>(a, s);
+        return launch<64, 64, 32, true>(a, s);
+    }
+    return k16 ? launch<128, 32, 16, true>(a, s) : launch<128, 32, 32, true>(a, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// dgrad of a strided stem conv with ONE input channel (the extractor's 7x7/2 on a grayscale patch,
+// PerceptualHead.py:52-55): gx[n][iy][ix] = sum_{ky,kx valid} sum_c gy[n][(iy+p-ky)/s][(ix+p-kx)/s][c] w[c][ky][kx].
+// As a GEMM this has N = 1 (31/32 of an MFMA tile wasted, 49 mostly-empty taps); here a workgroup owns one
+// output parity class (iy%s, ix%s) so its valid taps are wave-uniform, 16 lanes x float4 read one source
+// pixel's channels coalesced, weights sit transposed in LDS, and the channel sum is a 16-lane xor-shuffle.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) stem_dgrad_c1_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                                                            float* __restrict__ gx, int N, int Hi, int Wi, int Ho, int Wo,
+                                                            int Co, int k, int stride, int pad) {
+    extern __shared__ __attribute__((aligned(16))) float wT[];     // [k*k][Co]
+    for (int i = threadIdx.x; i < k * k * Co; i += 256) {
+        int t = i / Co, c = i - t * Co;
+        wT[i] = w[c * k * k + t];
+    }
+    __syncthreads();
+    const int cls = blockIdx.y, py = cls / stride, px = cls % stride;
+    const int Ha = (Hi - py + stride - 1) / stride, Wa = (Wi - px + stride - 1) / stride;   // pixels of this class
+    const int LP = Co / 4;                        // lanes per pixel (Co = 64 -> 16)
+    const int PPW = 64 / LP;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LP, cl = lane % LP;
+    const long long total = (long long)N * Ha * Wa;
+    const long long wave_global = (long long)blockIdx.x * 4 + wave, nwaves = (long long)gridDim.x * 4;
+    for (long long q0 = wave_global * PPW; q0 < total; q0 += nwaves * PPW) {
+        const long long q = q0 + sub;
+        const bool ok = q < total;
+        const long long qq = ok ? q : 0;
+        const int n = (int)(qq / ((long long)Ha * Wa));
+        const int r = (int)(qq - (long long)n * Ha * Wa);
+        const int a = r / Wa, b = r - a * Wa;
+        const int iy = a * stride + py, ix = b * stride + px;
+        float acc = 0.f;
+        // ky with (iy + pad - ky) % stride == 0
+        for (int ky = (py + pad) % stride; ky < k; ky += stride) {
+            const int oy = (iy + pad - ky) / stride;
+            if (iy + pad - ky < 0 || oy >= Ho) continue;
+            for (int kx = (px + pad) % stride; kx < k; kx += stride) {
+                const int ox = (ix + pad - kx) / stride;
+                if (ix + pad - kx < 0 || ox >= Wo) continue;
+                const float4 g = *reinterpret_cast<const float4*>(gy + (((size_t)n * Ho + oy) * Wo + ox) * Co + cl * 4);
+                const float4 ww = *reinterpret_cast<const float4*>(&wT[(ky * k + kx) * Co + cl * 4]);
+                acc += g.x * ww.x + g.y * ww.y + g.z * ww.z + g.w * ww.w;
+            }
+        }
+        for (int off = 1; off < LP; off <<= 1) acc += __shfl_xor(acc, off, 64);
+        if (ok && cl == 0) gx[((size_t)n * Hi + iy) * Wi + ix] = acc;
+    }
 }
 
 static int check_desc(const bh_conv_desc* d) {
@@ -347,6 +409,15 @@ int bh_conv_dgrad(const float* gy, const float* w, float* gx, const bh_conv_desc
     if (rc) return rc;
     if (!gy || !w || !gx) return BH_E_BADARG;
     if (d->in_nchw) return BH_E_UNSUPPORTED;          // network inputs are data: no dgrad
+    if (!d->transposed && d->Ci == 1 && !d->out_nchw && !accumulate && d->Co % 4 == 0 && d->Co <= 256 &&
+        (64 % (d->Co / 4)) == 0 && d->kh == d->kw && d->stride <= 4) {
+        const size_t lds = sizeof(float) * d->kh * d->kw * d->Co;
+        dim3 grid(512, d->stride * d->stride);
+        hipLaunchKernelGGL(stem_dgrad_c1_kernel, grid, dim3(256), lds, bh_stream(stream), gy, w, gx, d->N, d->Hi, d->Wi, d->Ho,
+                           d->Wo, d->Co, d->kh, d->stride, d->pad);
+        BH_LAUNCH_CHECK();
+        return BH_OK;
+    }
     GemmArgs a = {};
     a.src_nchw = d->out_nchw;                         // gradient of the NCHW network output
     a.Src = gy; a.Bw = w; a.bias = nullptr; a.Out = gx; a.accumulate = accumulate;

@@ -1,9 +1,11 @@
 // NHWC pooling and elementwise glue kernels (all HBM-bound, float4 per lane along channels).
 #include "common.h"
 
-// MaxPool2d(3, stride 2, pad 1): grid-stride over output float4s
-__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int Hi,
-                                                          int Wi, int C4, int Ho, int Wo) {
+// MaxPool2d(3, stride 2, pad 1): grid-stride over output float4s; also records the window position (0..8) of
+// the FIRST maximum (row-major scan, the ATen tie rule) per element, one byte each
+__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          unsigned char* __restrict__ idx, int N, int Hi, int Wi, int C4,
+                                                          int Ho, int Wo) {
     const size_t total = (size_t)N * Ho * Wo * C4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % C4);
@@ -12,23 +14,29 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float* __restric
         const int oy = (int)(p % Ho);
         const int n = (int)(p / Ho);
         float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        uchar4 w = make_uchar4(0, 0, 0, 0);
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = oy * 2 - 1 + ky;
             if (iy < 0 || iy >= Hi) continue;
             for (int kx = 0; kx < 3; ++kx) {
                 const int ix = ox * 2 - 1 + kx;
                 if (ix < 0 || ix >= Wi) continue;
+                const unsigned char t = (unsigned char)(ky * 3 + kx);
                 float4 v = *reinterpret_cast<const float4*>(x + ((((size_t)n * Hi + iy) * Wi + ix) * C4 + c) * 4);
-                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+                if (v.x > m.x) { m.x = v.x; w.x = t; }
+                if (v.y > m.y) { m.y = v.y; w.y = t; }
+                if (v.z > m.z) { m.z = v.z; w.z = t; }
+                if (v.w > m.w) { m.w = v.w; w.w = t; }
             }
         }
         *reinterpret_cast<float4*>(y + i * 4) = m;
+        if (idx) *reinterpret_cast<uchar4*>(idx + i * 4) = w;
     }
 }
 
-// adjoint, gather form (no atomics): an input pixel receives gy of every window whose FIRST maximum
-// (row-major scan, the ATen tie rule) it is.
-__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+// adjoint, gather form (no atomics): an input pixel receives gy of every window (<= 4) whose recorded
+// arg-max position points at it
+__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const unsigned char* __restrict__ idx, const float* __restrict__ gy,
                                                           float* __restrict__ gx, int N, int Hi, int Wi, int C4, int Ho,
                                                           int Wo) {
     const size_t total = (size_t)N * Hi * Wi * C4;
@@ -38,36 +46,19 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float* __restric
         const int ix = (int)(p % Wi); p /= Wi;
         const int iy = (int)(p % Hi);
         const int n = (int)(p / Hi);
-        const float4 me = *reinterpret_cast<const float4*>(x + i * 4);
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        // windows containing (iy, ix): oy in [ceil((iy-1)/2), floor((iy+1)/2)]
-        const int oy0 = max(0, (iy) / 2), oy1 = min(Ho - 1, (iy + 1) / 2);
-        const int ox0 = max(0, (ix) / 2), ox1 = min(Wo - 1, (ix + 1) / 2);
+        const int oy0 = max(0, iy / 2), oy1 = min(Ho - 1, (iy + 1) / 2);
+        const int ox0 = max(0, ix / 2), ox1 = min(Wo - 1, (ix + 1) / 2);
         for (int oy = oy0; oy <= oy1; ++oy)
             for (int ox = ox0; ox <= ox1; ++ox) {
-                // is (iy, ix) the first maximum of window (oy, ox)?
-                bool fx = true, fy = true, fz = true, fw = true;
-                for (int ky = 0; ky < 3; ++ky) {
-                    const int yy = oy * 2 - 1 + ky;
-                    if (yy < 0 || yy >= Hi) continue;
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const int xx = ox * 2 - 1 + kx;
-                        if (xx < 0 || xx >= Wi) continue;
-                        if (yy == iy && xx == ix) continue;
-                        const float4 v = *reinterpret_cast<const float4*>(x + ((((size_t)n * Hi + yy) * Wi + xx) * C4 + c) * 4);
-                        const bool before = (yy < iy) || (yy == iy && xx < ix);
-                        // an earlier element wins ties, a later one only if strictly greater
-                        if (before ? (v.x >= me.x) : (v.x > me.x)) fx = false;
-                        if (before ? (v.y >= me.y) : (v.y > me.y)) fy = false;
-                        if (before ? (v.z >= me.z) : (v.z > me.z)) fz = false;
-                        if (before ? (v.w >= me.w) : (v.w > me.w)) fw = false;
-                    }
-                }
-                const float4 go = *reinterpret_cast<const float4*>(gy + ((((size_t)n * Ho + oy) * Wo + ox) * C4 + c) * 4);
-                if (fx) g.x += go.x;
-                if (fy) g.y += go.y;
-                if (fz) g.z += go.z;
-                if (fw) g.w += go.w;
+                const unsigned char t = (unsigned char)((iy - (oy * 2 - 1)) * 3 + (ix - (ox * 2 - 1)));
+                const size_t o = (((size_t)n * Ho + oy) * Wo + ox) * C4 + c;
+                const uchar4 w = *reinterpret_cast<const uchar4*>(idx + o * 4);
+                const float4 go = *reinterpret_cast<const float4*>(gy + o * 4);
+                if (w.x == t) g.x += go.x;
+                if (w.y == t) g.y += go.y;
+                if (w.z == t) g.z += go.z;
+                if (w.w == t) g.w += go.w;
             }
         *reinterpret_cast<float4*>(gx + i * 4) = g;
     }
@@ -113,20 +104,20 @@ static int nblocks(size_t work) {
 
 extern "C" {
 
-int bh_maxpool3s2_fwd(const float* x, float* y, int N, int Hi, int Wi, int C, void* stream) {
+int bh_maxpool3s2_fwd(const float* x, float* y, unsigned char* argmax, int N, int Hi, int Wi, int C, void* stream) {
     if (!x || !y || C % 4) return C % 4 ? BH_E_UNSUPPORTED : BH_E_BADARG;
     const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(nblocks((size_t)N * Ho * Wo * (C / 4))), dim3(256), 0, bh_stream(stream), x,
-                       y, N, Hi, Wi, C / 4, Ho, Wo);
+                       y, argmax, N, Hi, Wi, C / 4, Ho, Wo);
     BH_LAUNCH_CHECK();
     return BH_OK;
 }
 
-int bh_maxpool3s2_bwd(const float* x, const float* gy, float* gx, int N, int Hi, int Wi, int C, void* stream) {
-    if (!x || !gy || !gx || C % 4) return C % 4 ? BH_E_UNSUPPORTED : BH_E_BADARG;
+int bh_maxpool3s2_bwd(const unsigned char* argmax, const float* gy, float* gx, int N, int Hi, int Wi, int C, void* stream) {
+    if (!argmax || !gy || !gx || C % 4) return C % 4 ? BH_E_UNSUPPORTED : BH_E_BADARG;
     const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblocks((size_t)N * Hi * Wi * (C / 4))), dim3(256), 0, bh_stream(stream), x,
-                       gy, gx, N, Hi, Wi, C / 4, Ho, Wo);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblocks((size_t)N * Hi * Wi * (C / 4))), dim3(256), 0, bh_stream(stream),
+                       argmax, gy, gx, N, Hi, Wi, C / 4, Ho, Wo);
     BH_LAUNCH_CHECK();
     return BH_OK;
 }

@@ -139,6 +139,113 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
     }
 }
 
+// Small-channel variant (min(Np, Nq) <= 32: the 16/32-channel decoder layers at 64x64 / 128x128, where K = pixels
+// is huge and a 64x64 tile would be 3/4 padding): 32x32 tile per WAVE, the four waves of a workgroup split the
+// workgroup's pixel range four ways and never synchronise (wave-private LDS), each adds its partial with atomics.
+#define SLD 36
+template <bool VEC>
+__global__ void __launch_bounds__(256) wgrad_small_kernel(WgradArgs a) {
+    __shared__ float As[4][WBK * SLD];
+    __shared__ float Bs[4][WBK * SLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ncols = a.joint ? a.T * a.Nq : a.Nq;
+    const int qtiles = (ncols + 31) / 32;
+    const int p0 = (blockIdx.x / qtiles) * 32, q0 = (blockIdx.x % qtiles) * 32;
+    const int t = a.joint ? 0 : blockIdx.y;
+    const int bbeg = blockIdx.z * a.rows_per_block;
+    const int bend = min(a.M, bbeg + a.rows_per_block);
+    const int rpw = (((bend - bbeg) + 3) / 4 + WBK - 1) / WBK * WBK;
+    const int mbeg = bbeg + wave * rpw, mend = min(bend, mbeg + rpw);
+    if (mbeg >= mend) return;
+    float* as = As[wave];
+    float* bs = Bs[wave];
+    const int chunk = lane & 7, prow0 = lane >> 3;      // 8 float4 chunks x 8 rows per pass, 4 passes
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    float4 rp[4], rq[4];
+    const int hw = a.Ho * a.Wo;
+
+    auto load_tile = [&](int mk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = mk + prow0 + i * 8;
+            float4 vp = make_float4(0.f, 0.f, 0.f, 0.f), vq = vp;
+            if (m < mend) {
+                const int pc = p0 + chunk * 4;
+                const int nb = m / hw, rr = m - nb * hw, oy = rr / a.Wo, ox = rr - oy * a.Wo;
+                if (a.p_nchw) {
+                    const float* pp = a.P + ((size_t)nb * a.Np + pc) * hw + rr;
+                    if (pc < a.Np) vp.x = pp[0];
+                    if (pc + 1 < a.Np) vp.y = pp[(size_t)hw];
+                    if (pc + 2 < a.Np) vp.z = pp[2 * (size_t)hw];
+                    if (pc + 3 < a.Np) vp.w = pp[3 * (size_t)hw];
+                } else {
+                    const float* pp = a.P + (size_t)m * a.Np + pc;
+                    if ((a.Np & 3) == 0 && pc + 3 < a.Np) vp = *reinterpret_cast<const float4*>(pp);
+                    else {
+                        if (pc < a.Np) vp.x = pp[0];
+                        if (pc + 1 < a.Np) vp.y = pp[1];
+                        if (pc + 2 < a.Np) vp.z = pp[2];
+                        if (pc + 3 < a.Np) vp.w = pp[3];
+                    }
+                }
+                const int qc = q0 + chunk * 4;
+                if (VEC) {
+                    int iy, ix;
+                    if (qc < a.Nq && q_coord(a, oy, ox, t, iy, ix))
+                        vq = *reinterpret_cast<const float4*>(a.Q + (((size_t)nb * a.Hs + iy) * a.Ws + ix) * a.Cq + qc);
+                } else {
+                    float e[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int col = qc + j;
+                        if (col < ncols) {
+                            int tt = a.joint ? col / a.Nq : t;
+                            int c = a.joint ? col - tt * a.Nq : col;
+                            int iy, ix;
+                            if (q_coord(a, oy, ox, tt, iy, ix)) {
+                                size_t off = a.q_nchw ? ((((size_t)nb * a.Cq + c) * a.Hs + iy) * a.Ws + ix)
+                                                      : ((((size_t)nb * a.Hs + iy) * a.Ws + ix) * a.Cq + c);
+                                e[j] = a.Q[off];
+                            }
+                        }
+                    }
+                    vq = make_float4(e[0], e[1], e[2], e[3]);
+                }
+            }
+            rp[i] = vp; rq[i] = vq;
+        }
+    };
+
+    const int kh2 = lane >> 5, l31 = lane & 31;
+    load_tile(mbeg);
+    for (int mk = mbeg; mk < mend; mk += WBK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = prow0 + i * 8;
+            *reinterpret_cast<float4*>(&as[row * SLD + chunk * 4]) = rp[i];
+            *reinterpret_cast<float4*>(&bs[row * SLD + chunk * 4]) = rq[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (mk + WBK < mend) load_tile(mk + WBK);
+#pragma unroll
+        for (int kk = 0; kk < WBK / 2; ++kk) {
+            const int k = 2 * kk + kh2;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[k * SLD + l31], bs[k * SLD + l31], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    const int q = q0 + l31;
+    if (q < ncols) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int p = p0 + (r & 3) + 8 * (r >> 2) + 4 * kh2;
+            if (p < a.Np) atomicAdd(a.Out + (long long)p * a.sOp + (long long)t * a.sOt + q, acc[r]);
+        }
+    }
+}
+
 // column sums of a [M][C] matrix accumulated into out[C] (bias gradients)
 __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ x, int M, int C, int rows_per_block,
                                                      float* __restrict__ out) {
@@ -199,17 +306,25 @@ int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, cons
     }
     a.joint = vec ? 0 : 1;
     const int ncols = a.joint ? a.T * a.Nq : a.Nq;
-    const int tiles = ((a.Np + 63) / 64) * ((ncols + 63) / 64);
+    const bool small = (a.Np <= 32 || ncols <= 32);
+    const int tsz = small ? 32 : 64;
+    const int tiles = ((a.Np + tsz - 1) / tsz) * ((ncols + tsz - 1) / tsz);
     const int ty = a.joint ? 1 : a.T;
     int split = (2048 + tiles * ty - 1) / (tiles * ty);
-    int maxsplit = (a.M + 255) / 256;
+    int maxsplit = (a.M + (small ? 1023 : 255)) / (small ? 1024 : 256);
     if (split > maxsplit) split = maxsplit;
     if (split < 1) split = 1;
-    a.rows_per_block = (((a.M + split - 1) / split) + WBK - 1) / WBK * WBK;
+    const int gran = small ? 4 * WBK : WBK;
+    a.rows_per_block = (((a.M + split - 1) / split) + gran - 1) / gran * gran;
     split = (a.M + a.rows_per_block - 1) / a.rows_per_block;
     dim3 grid(tiles, ty, split);
-    if (vec) hipLaunchKernelGGL((wgrad_kernel<true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((wgrad_kernel<false>), grid, dim3(256), 0, s, a);
+    if (small) {
+        if (vec) hipLaunchKernelGGL((wgrad_small_kernel<true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((wgrad_small_kernel<false>), grid, dim3(256), 0, s, a);
+    } else {
+        if (vec) hipLaunchKernelGGL((wgrad_kernel<true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((wgrad_kernel<false>), grid, dim3(256), 0, s, a);
+    }
     BH_LAUNCH_CHECK();
     if (gbias) {
         // bias gradient = column sums of gy over all output pixels

@@ -18,6 +18,7 @@ def _stream():
 # ------------------------------------------------------------------------------------------------
 # optional per-launch timing (bench.py's roofline leg): HIP events on the launch stream around each call
 # ------------------------------------------------------------------------------------------------
+TIMING_DETAIL = False   # True: key by launch geometry as well (per-layer tables)
 TIMING = None       # None, or dict name -> {"events": [(start, end)], "flops": float, "bytes": float, "n": int}
 
 
@@ -43,21 +44,45 @@ class _Timed:
             r["n"] += 1
 
 
-def gemm_variant(Nn, Kc, vec):
+def gemm_variant(M, Nn, Kc, vec):
     """Mirror of conv_gemm.hip's dispatch(): which template instantiation a launch uses (the kernel
-    symbol rocprofv3 reports: conv_gemm_kernel<BN, BK, VEC>)."""
-    BN = 128 if Nn > 64 else (64 if Nn > 32 else 32)
-    BK = 16 if (vec and (Kc % 32) != 0 and Kc <= 16) else 32
-    return "conv_gemm_kernel<%d,%d,%s>" % (BN, BK, "true" if vec else "false")
+    symbol rocprofv3 reports: conv_gemm_kernel<BM, BN, BK, VEC>)."""
+    fmt = "conv_gemm_kernel<%d,%d,%d,%s>"
+    if not vec:
+        return fmt % (128, 128 if Nn > 64 else (64 if Nn > 32 else 32), 32, "false")
+    k16 = (Kc % 32) != 0 and Kc <= 16
+    mt = (M + 127) // 128
+    if Nn > 64:
+        if k16:
+            return fmt % (128, 128, 16, "true")
+        nt = (Nn + 127) // 128
+        if mt * nt >= 400:
+            return fmt % (128, 128, 32, "true")
+        return fmt % ((64, 128, 32, "true") if 2 * mt * nt >= 400 else (64, 64, 32, "true"))
+    if Nn > 32:
+        if k16:
+            return fmt % (128, 64, 16, "true")
+        return fmt % ((128, 64, 32, "true") if mt >= 400 else (64, 64, 32, "true"))
+    return fmt % (128, 32, 16 if k16 else 32, "true")
 
 
 def _conv_variant(d, which):
+    v = _conv_variant0(d, which)
+    if TIMING_DETAIL:
+        v += " %s N%d %dx%d C%d->%d k%d s%d%s" % (which, d.N, d.Hi, d.Wi, d.Ci, d.Co, d.kh, d.stride, " T" if d.transposed else "")
+    return v
+
+
+def _conv_variant0(d, which):
     if which == "fwd":
         vec = (not d.in_nchw) and d.Ci % 4 == 0
-        Nn = d.kh * d.kw * d.Co if d.transposed else d.Co
-        return gemm_variant(Nn, d.Ci, vec)
+        if d.transposed:
+            return gemm_variant(d.N * d.Hi * d.Wi, d.kh * d.kw * d.Co, d.Ci, vec)
+        return gemm_variant(d.N * d.Ho * d.Wo, d.Co, d.Ci, vec)
+    if (not d.transposed) and d.Ci == 1 and not d.out_nchw:
+        return "stem_dgrad_c1_kernel"
     vec = (not d.out_nchw) and d.Co % 4 == 0
-    return gemm_variant(d.Ci, d.Co, vec)
+    return gemm_variant(d.N * d.Hi * d.Wi, d.Ci, d.Co, vec)
 
 
 def conv_flops(d):
@@ -235,7 +260,7 @@ def conv_dgrad(gy, w, d, out=None):
 
 def conv_wgrad(x, gy, gw, gbias, d):
     _chk(x); _chk(gy); _chk(gw); _chk(gbias)
-    with _Timed("wgrad_kernel", conv_flops(d), 4.0 * (x.numel() + gy.numel() + gw.numel())):
+    with _Timed("wgrad_kernel" + (" N%d %dx%d C%d->%d k%d s%d%s" % (d.N, d.Hi, d.Wi, d.Ci, d.Co, d.kh, d.stride, " T" if d.transposed else "") if TIMING_DETAIL else ""), conv_flops(d), 4.0 * (x.numel() + gy.numel() + gw.numel())):
         check(lib.bh_conv_wgrad(_p(x), _p(gy), _p(gw), _p(gbias), ctypes.byref(d), _stream()), "bh_conv_wgrad")
 
 
@@ -252,7 +277,7 @@ def bn_fwd(x, gamma, beta, rmean, rvar, res, groups, eps, momentum, relu, traini
     stats = bn_stats_buffer(groups, C, x.device)
     flags = (1 if relu else 0) | (2 if res is not None else 0)
     nb = 4.0 * x.numel() * ((2 if training else 1) + 1 + (1 if res is not None else 0))
-    with _Timed("bn_fwd(3 kernels)", 0.0, nb):
+    with _Timed("bn_fwd(3 kernels)" + (" g%d rows%d C%d" % (groups, rows, C) if TIMING_DETAIL else ""), 0.0, nb):
         check(lib.bh_bn_fwd(_p(x), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(res), _p(y), _p(stats), groups, rows, C,
                             float(eps), float(momentum), flags, 0 if training else 1, _stream()), "bh_bn_fwd")
     return y, stats
@@ -267,26 +292,27 @@ def bn_bwd(gy, y, x, gamma, stats, rmean, rvar, groups, eps, relu, training, wan
     scratch = bn_stats_buffer(groups, C, x.device)
     flags = (1 if relu else 0) | (2 if want_gres else 0)
     nb = 4.0 * x.numel() * (2 * (2 + (1 if relu else 0)) + 1 + (1 if want_gres else 0))
-    with _Timed("bn_bwd(3 kernels)", 0.0, nb):
+    with _Timed("bn_bwd(3 kernels)" + (" g%d rows%d C%d" % (groups, rows, C) if TIMING_DETAIL else ""), 0.0, nb):
         check(lib.bh_bn_bwd(_p(gy), _p(y), _p(x), _p(gamma), _p(stats), _p(gx), _p(gres), _p(ggamma), _p(gbeta),
                             _p(scratch), groups, rows, C, float(eps), flags, 0 if training else 1, _p(rmean), _p(rvar),
                             _stream()), "bh_bn_bwd")
     return gx, gres
 
 
-def maxpool_fwd(x):
+def maxpool_fwd(x, want_index=True):
     _chk(x)
     N, Hi, Wi, C = x.shape
     y = torch.empty((N, (Hi - 1) // 2 + 1, (Wi - 1) // 2 + 1, C), dtype=torch.float32, device=x.device)
-    check(lib.bh_maxpool3s2_fwd(_p(x), _p(y), N, Hi, Wi, C, _stream()), "bh_maxpool3s2_fwd")
-    return y
+    idx = torch.empty(y.shape, dtype=torch.uint8, device=x.device) if want_index else None
+    check(lib.bh_maxpool3s2_fwd(_p(x), _p(y), _p(idx), N, Hi, Wi, C, _stream()), "bh_maxpool3s2_fwd")
+    return y, idx
 
 
-def maxpool_bwd(x, gy):
-    _chk(x); _chk(gy)
-    N, Hi, Wi, C = x.shape
-    gx = torch.empty_like(x)
-    check(lib.bh_maxpool3s2_bwd(_p(x), _p(gy), _p(gx), N, Hi, Wi, C, _stream()), "bh_maxpool3s2_bwd")
+def maxpool_bwd(idx, gy, in_shape):
+    _chk(idx, torch.uint8); _chk(gy)
+    N, Hi, Wi, C = in_shape
+    gx = torch.empty(in_shape, dtype=torch.float32, device=gy.device)
+    check(lib.bh_maxpool3s2_bwd(_p(idx), _p(gy), _p(gx), N, Hi, Wi, C, _stream()), "bh_maxpool3s2_bwd")
     return gx
 
 

@@ -216,7 +216,9 @@ def run_forward(prog, x, groups, training, save):
             if save:
                 ctx.stats[i] = st
         elif op.kind == "maxpool":
-            out = K.maxpool_fwd(src)
+            out, idx = K.maxpool_fwd(src, want_index=save)
+            if save:
+                ctx.stats[i] = idx
         elif op.kind == "gap":
             out = K.gap_fwd(src)
         else:
@@ -283,7 +285,7 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
                 contribute(op.res, gres)
         elif op.kind == "maxpool":
             if need_src_grad:
-                contribute(op.src, K.maxpool_bwd(x, g))
+                contribute(op.src, K.maxpool_bwd(ctx.stats[i], g, tuple(x.shape)))
         elif op.kind == "gap":
             if need_src_grad:
                 contribute(op.src, K.gap_bwd(g, tuple(x.shape)))

@@ -141,9 +141,10 @@ int bh_bn_bwd(const float* gy, const float* y, const float* x, const float* gamm
               int groups, int rows, int C, float eps, int flags, int use_running,
               const float* running_mean, const float* running_var, void* stream);
 
-/* MaxPool2d(3, 2, 1) NHWC, and its adjoint (recomputes the arg-max, first max wins like ATen) */
-int bh_maxpool3s2_fwd(const float* x, float* y, int N, int Hi, int Wi, int C, void* stream);
-int bh_maxpool3s2_bwd(const float* x, const float* gy, float* gx, int N, int Hi, int Wi, int C, void* stream);
+/* MaxPool2d(3, 2, 1) NHWC. argmax[N,Ho,Wo,C] (uint8, NULL ok in inference): window position 0..8 of the first
+ * maximum (ATen's tie rule); the adjoint gathers through it (no atomics, no recomputation). */
+int bh_maxpool3s2_fwd(const float* x, float* y, unsigned char* argmax, int N, int Hi, int Wi, int C, void* stream);
+int bh_maxpool3s2_bwd(const unsigned char* argmax, const float* gy, float* gx, int N, int Hi, int Wi, int C, void* stream);
 /* AdaptiveAvgPool2d(1) NHWC -> [N,C], and adjoint */
 int bh_gap_fwd(const float* x, float* y, int N, int HW, int C, void* stream);
 int bh_gap_bwd(const float* gy, float* gx, int N, int HW, int C, void* stream);

@@ -205,11 +205,11 @@ def test_maxpool_gap_add(K, N, H, C):
     xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
     ref = F.max_pool2d(xt, 3, 2, 1)
     xg = torch.tensor(x).permute(0, 2, 3, 1).contiguous().cuda()
-    y = K.maxpool_fwd(xg)
+    y, idx = K.maxpool_fwd(xg)
     assert torch.equal(y.cpu().permute(0, 3, 1, 2).double(), ref.detach())
     gy = rnd(tuple(ref.shape), 31)
     ref.backward(torch.tensor(gy, dtype=torch.float64))
-    gx = K.maxpool_bwd(xg, torch.tensor(gy).permute(0, 2, 3, 1).contiguous().cuda())
+    gx = K.maxpool_bwd(idx, torch.tensor(gy).permute(0, 2, 3, 1).contiguous().cuda(), tuple(xg.shape))
     close(gx.cpu().permute(0, 3, 1, 2), xt.grad, 1e-6)
     g = K.gap_fwd(xg)
     close(g.cpu().reshape(N, C), x.mean((2, 3)), 1e-6)
