@@ -25,7 +25,7 @@ struct GemmArgs {
     int M, Nn, Kc, T;
     int Ho, Wo;            // output-side pixel grid
     int Hs, Ws, Cs;        // source grid and its channel count
-    int kw, stride, pad;
+    int kw, stride, pad, sshift;   // sshift = log2(stride) when it is a power of two, else -1
     int adjoint;           // 0: forward gather, 1: adjoint (dgrad of a strided conv) gather
     int src_nchw;          // scalar path, channels are planes
     long long sBt, sBc, sBn;
@@ -109,26 +109,62 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
 
     float4 ra[AIT], rb[BIT];
 
+    // division-free tile walk for the vectorised path: (tap, ky, kx, channel chunk) of the NEXT tile to load
+    int nx_t = 0, nx_ky = 0, nx_kx = 0, nx_c0 = 0;
+    // per-row anchors: forward iy = ay + ky ; adjoint ty = ay - ky (then >> sshift when strided)
+    int a_ay[AIT], a_ax[AIT];
+    unsigned a_base[AIT];                              // pixel index of (n, 0, 0) in the source grid
+#pragma unroll
+    for (int i = 0; i < AIT; ++i) {
+        a_ay[i] = a.adjoint ? a_oy[i] + a.pad : a_oy[i] * a.stride - a.pad;
+        a_ax[i] = a.adjoint ? a_ox[i] + a.pad : a_ox[i] * a.stride - a.pad;
+        a_base[i] = (unsigned)a_n[i] * (unsigned)(a.Hs * a.Ws);
+    }
+    const float* b_rowptr[BIT_K];
+#pragma unroll
+    for (int i = 0; i < BIT_K; ++i) {
+        int n = n0 + bk_row0 + i * AROWS;
+        b_rowptr[i] = ((bk_row0 + i * AROWS) < BN && n < a.Nn) ? a.Bw + (long long)n * a.sBn + bk_chunk * 4 : nullptr;
+    }
+
     auto load_tile = [&](int kt) {
         if (VEC) {
-            const int t = kt / kchunks, c0 = (kt - t * kchunks) * BK;
+            const int t = nx_t, ky = nx_ky, kx = nx_kx, c0 = nx_c0;
             const int c = c0 + a_chunk * 4;
 #pragma unroll
             for (int i = 0; i < AIT; ++i) {
                 int iy, ix;
+                bool ok = a_ok[i] && c < a.Kc;
+                if (!a.adjoint) {
+                    iy = a_ay[i] + ky; ix = a_ax[i] + kx;
+                } else {
+                    iy = a_ay[i] - ky; ix = a_ax[i] - kx;
+                    if (a.stride > 1) {
+                        if (a.sshift >= 0) {
+                            const int msk = a.stride - 1;
+                            ok = ok && iy >= 0 && ix >= 0 && !((iy | ix) & msk);
+                            iy >>= a.sshift; ix >>= a.sshift;
+                        } else {
+                            ok = ok && iy >= 0 && ix >= 0 && !(iy % a.stride) && !(ix % a.stride);
+                            iy /= a.stride; ix /= a.stride;
+                        }
+                    }
+                }
+                ok = ok && (unsigned)iy < (unsigned)a.Hs && (unsigned)ix < (unsigned)a.Ws;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (a_ok[i] && c < a.Kc && src_coord(a, a_oy[i], a_ox[i], t, iy, ix))
-                    v = *reinterpret_cast<const float4*>(a.Src + (((size_t)a_n[i] * a.Hs + iy) * a.Ws + ix) * a.Cs + c);
+                if (ok) {
+                    const unsigned pix = a_base[i] + (unsigned)(iy * a.Ws + ix);
+                    v = *reinterpret_cast<const float4*>(a.Src + (size_t)pix * a.Cs + c);
+                }
                 ra[i] = v;
             }
             if (a.b_kcontig) {
-                const int cb = c0 + bk_chunk * 4;
+                const long long toff = (long long)t * a.sBt + c0;
+                const bool cok = c0 + bk_chunk * 4 < a.Kc;
 #pragma unroll
                 for (int i = 0; i < BIT_K; ++i) {
-                    int n = n0 + bk_row0 + i * AROWS;
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if ((bk_row0 + i * AROWS) < BN && n < a.Nn && cb < a.Kc)
-                        v = *reinterpret_cast<const float4*>(a.Bw + t * a.sBt + (long long)n * a.sBn + cb);
+                    if (b_rowptr[i] && cok) v = *reinterpret_cast<const float4*>(b_rowptr[i] + toff);
                     rb[i] = v;
                 }
             } else {
@@ -149,6 +185,12 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
                     }
                     rb[i] = v;
                 }
+            }
+            // advance the walk
+            nx_c0 += BK;
+            if (nx_c0 >= a.Kc) {
+                nx_c0 = 0; ++nx_t;
+                if (++nx_kx == a.kw) { nx_kx = 0; ++nx_ky; }
             }
         } else {
             // scalar path (tiny channel counts / NCHW network input): k = t*Kc + c decoded per element
@@ -290,28 +332,41 @@ static int launch(const GemmArgs& a, hipStream_t s) {
 
 // Tile choice: the largest tile that still gives the 256 CUs about two workgroups each; the small-spatial
 // layers (8x8x256ch, 16x16x128ch at 2B = 128) otherwise launch only 128-256 workgroups.
-static int dispatch(const GemmArgs& a, hipStream_t s) {
+static int g_force_bm = 0, g_force_bn = 0;     // tuning hook (bh_debug_force_tile), 0 = automatic
+
+static int dispatch(const GemmArgs& a_in, hipStream_t s) {
+    GemmArgs a = a_in;
+    a.sshift = -1;
+    for (int b = 0; b < 8; ++b)
+        if (a.stride == (1 << b)) a.sshift = b;
     if (a.M <= 0 || a.Nn <= 0) return BH_OK;
     const bool vec = !a.src_nchw && (a.Kc % 4 == 0) && (a.Cs % 4 == 0);
+    if (vec && g_force_bm && (a.Kc % 32) == 0) {
+        const int bm = g_force_bm, bn = g_force_bn;
+        if (bm == 128 && bn == 128) return launch<128, 128, 32, true>(a, s);
+        if (bm == 64 && bn == 128) return launch<64, 128, 32, true>(a, s);
+        if (bm == 64 && bn == 64) return launch<64, 64, 32, true>(a, s);
+        if (bm == 128 && bn == 64) return launch<128, 64, 32, true>(a, s);
+        if (bm == 128 && bn == 32) return launch<128, 32, 32, true>(a, s);
+        return BH_E_UNSUPPORTED;
+    }
     if (!vec) {
         if (a.Nn > 64) return launch<128, 128, 32, false>(a, s);
         if (a.Nn > 32) return launch<128, 64, 32, false>(a, s);
         return launch<128, 32, 32, false>(a, s);
     }
+    // measured on MI355X (scratch/convbench.py): the 64-row tiles (4-5 waves/SIMD resident) beat the 128-row
+    // ones (2-3 waves/SIMD) on every 3x3 layer of the network - latency hiding matters more than tile reuse
+    // at the fp32 MFMA rate
     const bool k16 = (a.Kc % 32) != 0 && a.Kc <= 16;
-    const long long mt128 = (a.M + 127) / 128;
+    const long long mt64 = (a.M + 63) / 64;
     if (a.Nn > 64) {
         if (k16) return launch<128, 128, 16, true>(a, s);
         const long long nt = (a.Nn + 127) / 128;
-        if (mt128 * nt >= 400) return launch<128, 128, 32, true>(a, s);
-        if (2 * mt128 * nt >= 400) return launch<64, 128, 32, true>(a, s);
+        if (mt64 * nt >= 512) return launch<64, 128, 32, true>(a, s);
         return launch<64, 64, 32, true>(a, s);
     }
-    if (a.Nn > 32) {
-        if (k16) return launch<128, 64, 16, true>(a, s);
-        if (mt128 >= 400) return launch<128, 64, 32, true>(a, s);
-        return launch<64, 64, 32, true>(a, s);
-    }
+    if (a.Nn > 32) return k16 ? launch<128, 64, 16, true>(a, s) : launch<64, 64, 32, true>(a, s);
     return k16 ? launch<128, 32, 16, true>(a, s) : launch<128, 32, 32, true>(a, s);
 }
 
@@ -379,6 +434,8 @@ static int check_desc(const bh_conv_desc* d) {
 }
 
 extern "C" {
+
+int bh_debug_force_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn; return BH_OK; }
 
 int bh_conv_fwd(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, void* stream) {
     int rc = check_desc(d);

@@ -20,6 +20,7 @@ struct WgradArgs {
     int kw, stride, pad;
     int q_nchw, p_nchw;
     long long sOp, sOt;
+    int wshift, hwshift;     // log2(Wo), log2(Ho*Wo) when both are powers of two, else -1
     int joint;               // scalar path: GEMM columns run over (t, c) jointly, T' = 1
     int rows_per_block;
 };
@@ -64,7 +65,9 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
             float4 vp = make_float4(0.f, 0.f, 0.f, 0.f), vq = vp;
             if (m < mend) {
                 const int pc = p0 + chunk * 4;
-                const int nb = m / hw, rr = m - nb * hw, oy = rr / a.Wo, ox = rr - oy * a.Wo;
+                int nb, rr, oy, ox;
+                if (a.hwshift >= 0) { nb = m >> a.hwshift; rr = m & (hw - 1); oy = rr >> a.wshift; ox = rr & (a.Wo - 1); }
+                else { nb = m / hw; rr = m - nb * hw; oy = rr / a.Wo; ox = rr - oy * a.Wo; }
                 if (a.p_nchw) {
                     const float* pp = a.P + ((size_t)nb * a.Np + pc) * hw + rr;
                     if (pc < a.Np) vp.x = pp[0];
@@ -173,7 +176,9 @@ __global__ void __launch_bounds__(256) wgrad_small_kernel(WgradArgs a) {
             float4 vp = make_float4(0.f, 0.f, 0.f, 0.f), vq = vp;
             if (m < mend) {
                 const int pc = p0 + chunk * 4;
-                const int nb = m / hw, rr = m - nb * hw, oy = rr / a.Wo, ox = rr - oy * a.Wo;
+                int nb, rr, oy, ox;
+                if (a.hwshift >= 0) { nb = m >> a.hwshift; rr = m & (hw - 1); oy = rr >> a.wshift; ox = rr & (a.Wo - 1); }
+                else { nb = m / hw; rr = m - nb * hw; oy = rr / a.Wo; ox = rr - oy * a.Wo; }
                 if (a.p_nchw) {
                     const float* pp = a.P + ((size_t)nb * a.Np + pc) * hw + rr;
                     if (pc < a.Np) vp.x = pp[0];
@@ -305,6 +310,12 @@ int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, cons
         vec = (d->Co % 4 == 0);
     }
     a.joint = vec ? 0 : 1;
+    a.wshift = a.hwshift = -1;
+    for (int b = 0; b < 24; ++b) {
+        if (a.Wo == (1 << b)) a.wshift = b;
+        if (a.Ho * a.Wo == (1 << b)) a.hwshift = b;
+    }
+    if (a.wshift < 0 || a.hwshift < 0) a.wshift = a.hwshift = -1;
     const int ncols = a.joint ? a.T * a.Nq : a.Nq;
     const bool small = (a.Np <= 32 || ncols <= 32);
     const int tsz = small ? 32 : 64;

@@ -114,6 +114,8 @@ typedef struct {
     int out_nchw;           /* 1: y is NCHW (only for the network output, Co <= 4) */
 } bh_conv_desc;
 
+/* tuning hook (benchmarks only): force the implicit-GEMM tile (BM,BN) for vectorised launches; (0,0) = automatic */
+int bh_debug_force_tile(int bm, int bn);
 /* y = conv(x, w) (+ bias[Co] if bias != NULL) */
 int bh_conv_fwd(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, void* stream);
 /* gx = conv^T(gy, w)  (overwritten; accumulate != 0: gx += ..., used where gradient branches join) */
