@@ -38,6 +38,10 @@ SIGNATURES = {
     "bh_bn_stats_doubles": [c_int, c_int],
     "bh_bn_fwd": [P] * 8 + [c_int, c_int, c_int, c_float, c_float, c_int, c_int, P],
     "bh_bn_bwd": [P] * 10 + [c_int, c_int, c_int, c_float, c_int, c_int, P, P, P],
+    "bh_tail_ws_doubles": [c_int, c_int, c_int],
+    "bh_tail_scratch_floats": [c_int, c_int, c_int],
+    "bh_tail_fwd": [P] * 11 + [c_int] * 6 + [c_float, c_float, c_int, P],
+    "bh_tail_bwd": [P] * 17 + [c_int] * 6 + [c_float, c_int, P],
     "bh_maxpool3s2_fwd": [P, P, P, c_int, c_int, c_int, c_int, P],
     "bh_maxpool3s2_bwd": [P, P, P, c_int, c_int, c_int, c_int, P],
     "bh_gap_fwd": [P, P, c_int, c_int, c_int, P],

@@ -8,6 +8,8 @@ nn.Conv2d / nn.BatchNorm2d leaves below are parameter containers only; the arith
 bihome_amd.net.run_forward / run_backward.  Reference: src/backbones/Rethinking.py:13-156, 284-316 and
 src/backbones/utils.py:60-131.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -70,6 +72,7 @@ class Model(nn.Module):
         self.layer8 = S(nn.Conv2d(16, 128, 1), nn.BatchNorm2d(128), nn.ReLU(), nn.Conv2d(128, 2, 1))
         net.to_kernel_layout_(self)
         self._runner = None
+        self.fuse_tail = os.environ.get("BIHOME_FUSE_TAIL", "1") != "0"
 
     # ---- program ---------------------------------------------------------------------------------
     def _build(self):
@@ -86,8 +89,12 @@ class Model(nn.Module):
                 first = False
             elif i == 8:
                 mods = list(layer)
-                s = prog.sequential(s, mods[:-1])
-                s = prog.conv(s, mods[-1], out_nchw=True)       # perspective field leaves as NCHW
+                if self.fuse_tail:
+                    # conv1x1 + BN + ReLU + conv1x1 in one pass over the 16-channel input (csrc/tail.hip)
+                    s = prog.tail(s, mods[0], mods[1], mods[3])
+                else:
+                    s = prog.sequential(s, mods[:-1])
+                    s = prog.conv(s, mods[-1], out_nchw=True)   # perspective field leaves as NCHW
             else:
                 s = prog.sequential(s, layer)
         return net.Runner(self, prog, trainable=True)

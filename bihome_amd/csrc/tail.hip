@@ -1,0 +1,447 @@
+// Fused network tail of the Zeng backbone (src/backbones/Rethinking.py:145-147, `layer8`):
+//     Conv1x1(Ci -> Cm, bias) -> BatchNorm2d(Cm, training) -> ReLU -> Conv1x1(Cm -> Co, bias) -> NCHW field
+// at full resolution (128x128).  Unfused, the Cm = 128-channel intermediate is a [2B*16384, 128] fp32 tensor
+// (1 GiB at B = 64) that is written, re-read for the statistics, normalised, read by the last conv and touched
+// ~10 more times in the backward pass.  Here it never exists:
+//   * a 1x1 conv is linear, so the batch statistics of its output follow from the first and second moments of
+//     its 16-channel INPUT:  mean_y = W1 mean_x + b1,  var_y[c] = w_c^T Cov(x) w_c   (moments in double);
+//   * forward  = one pass over x: y_c = w_c.x + b1_c -> scale/shift -> ReLU -> 2 dot products, per pixel;
+//   * backward = one reduction pass (thread = channel: dgamma, dbeta, dW2 and S[c][k] = sum_m g_c[m] x_k[m])
+//     + a tiny finalize that turns S and the x-moments into dW1 + one per-pixel pass for dx.
+// K = 16 is far too small for MFMA tiles to pay; these are VALU kernels bounded by reading x (64 B/pixel).
+#include "common.h"
+
+#define TAIL_MAXCI 32
+#define TAIL_CHUNKS 512
+
+struct TailGeom {
+    int groups, rows, hw, Ci, Cm, Co, nchunks, rows_per_chunk;
+};
+
+static bool tail_geom(int groups, int rows, int hw, int Ci, int Cm, int Co, TailGeom& g) {
+    if (groups < 1 || rows < 1 || Ci % 4 || Ci > TAIL_MAXCI || Ci * Ci > 256 || Cm % 64 || Cm > 256 || Co < 1 || Co > 4 ||
+        rows % hw)
+        return false;
+    g.groups = groups; g.rows = rows; g.hw = hw; g.Ci = Ci; g.Cm = Cm; g.Co = Co;
+    int n = rows / 1024;
+    if (n < 1) n = 1;
+    if (n > TAIL_CHUNKS) n = TAIL_CHUNKS;
+    g.rows_per_chunk = (rows + n - 1) / n;
+    g.nchunks = (rows + g.rows_per_chunk - 1) / g.rows_per_chunk;
+    return true;
+}
+
+// workspace layout (doubles):  ystats[groups][Cm][2] | xmom[groups][Ci + Ci*Ci] | partials[groups][nchunks][Ci + Ci*Ci]
+static inline size_t off_xmom(const TailGeom& g) { return (size_t)g.groups * g.Cm * 2; }
+static inline size_t off_part(const TailGeom& g) { return off_xmom(g) + (size_t)g.groups * (g.Ci + g.Ci * g.Ci); }
+
+// ---- first/second moments of x: grid (nchunks, groups), block 256 = Ci x Ci pairs (only Ci*Ci threads active) ----
+__global__ void __launch_bounds__(256) tail_xmoments_kernel(const float* __restrict__ x, TailGeom g, double* __restrict__ part) {
+    __shared__ float xs[64 * TAIL_MAXCI];
+    const int Ci = g.Ci, grp = blockIdx.y, chunk = blockIdx.x;
+    const int rbeg = chunk * g.rows_per_chunk, rend = min(g.rows, rbeg + g.rows_per_chunk);
+    const int i = threadIdx.x / Ci, j = threadIdx.x % Ci;
+    const bool active = (int)threadIdx.x < Ci * Ci;
+    double sxx = 0, sx = 0;
+    const float* base = x + (size_t)grp * g.rows * Ci;
+    for (int r0 = rbeg; r0 < rend; r0 += 64) {
+        const int np = min(64, rend - r0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < np * Ci / 4; e += 256)
+            reinterpret_cast<float4*>(xs)[e] = reinterpret_cast<const float4*>(base + (size_t)r0 * Ci)[e];
+        __syncthreads();
+        if (active) {
+            float axx = 0.f, ax = 0.f;
+            for (int p = 0; p < np; ++p) {
+                const float a = xs[p * Ci + i], b = xs[p * Ci + j];
+                axx += a * b;
+                ax += a;
+            }
+            sxx += axx; sx += ax;
+        }
+    }
+    if (active) {
+        double* p = part + ((size_t)grp * g.nchunks + chunk) * (Ci + Ci * Ci);
+        p[Ci + i * Ci + j] = sxx;
+        if (j == 0) p[i] = sx;
+    }
+}
+
+// ---- one block of 256: reduce partials, derive the BatchNorm statistics of y, update running stats ----
+__global__ void __launch_bounds__(256) tail_stats_finalize_kernel(const double* __restrict__ part, const float* __restrict__ w1,
+                                                                  const float* __restrict__ b1, TailGeom g, float momentum,
+                                                                  float* __restrict__ running_mean,
+                                                                  float* __restrict__ running_var, double* __restrict__ ws) {
+    __shared__ double mom[TAIL_MAXCI + TAIL_MAXCI * TAIL_MAXCI];
+    const int Ci = g.Ci, nm = Ci + Ci * Ci;
+    double* ystats = ws;
+    double* xmom = ws + (size_t)g.groups * g.Cm * 2;
+    const double n = (double)g.rows;
+    float rm = 0.f, rv = 1.f;
+    const int c = threadIdx.x;
+    if (c < g.Cm) { rm = running_mean ? running_mean[c] : 0.f; rv = running_var ? running_var[c] : 1.f; }
+    for (int grp = 0; grp < g.groups; ++grp) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < nm; e += 256) {
+            double s = 0;
+            for (int k = 0; k < g.nchunks; ++k) s += part[((size_t)grp * g.nchunks + k) * nm + e];
+            mom[e] = s;
+            xmom[(size_t)grp * nm + e] = s;
+        }
+        __syncthreads();
+        if (c < g.Cm) {
+            double my = b1 ? (double)b1[c] : 0.0, eyy = 0;
+            for (int i = 0; i < Ci; ++i) {
+                const double wi = w1[c * Ci + i], mi = mom[i] / n;
+                my += wi * mi;
+                double row = 0;
+                for (int j = 0; j < Ci; ++j) row += (double)w1[c * Ci + j] * (mom[Ci + i * Ci + j] / n - mi * (mom[j] / n));
+                eyy += wi * row;
+            }
+            if (eyy < 0) eyy = 0;
+            ystats[((size_t)grp * g.Cm + c) * 2] = my;
+            ystats[((size_t)grp * g.Cm + c) * 2 + 1] = eyy;
+            const float unb = (float)(n > 1 ? eyy * n / (n - 1) : eyy);
+            rm = (1.f - momentum) * rm + momentum * (float)my;
+            rv = (1.f - momentum) * rv + momentum * unb;
+        }
+    }
+    if (c < g.Cm) {
+        if (running_mean) running_mean[c] = rm;
+        if (running_var) running_var[c] = rv;
+    }
+}
+
+// per-channel constants in LDS: w1 row (Ci), b1, mean, invstd, gamma, beta, w2[0..Co)
+struct TailLds {
+    float* w1;    // [Cm][Ci]
+    float* cst;   // [Cm][8]: b1, scale(=gamma*invstd), shift(=beta-mean*scale), w2_0, w2_1, w2_2, w2_3, invstd
+    float* mu;    // [Cm]
+};
+
+__device__ __forceinline__ void tail_load_consts(TailLds& L, float* sm, const TailGeom& g, const float* __restrict__ w1,
+                                                 const float* __restrict__ b1, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, const float* __restrict__ w2,
+                                                 const double* __restrict__ ystats, const float* __restrict__ rmean,
+                                                 const float* __restrict__ rvar, int use_running, int grp, float eps) {
+    L.w1 = sm; L.cst = sm + g.Cm * g.Ci; L.mu = L.cst + g.Cm * 8;
+    for (int e = threadIdx.x; e < g.Cm * g.Ci; e += blockDim.x) L.w1[e] = w1[e];
+    for (int c = threadIdx.x; c < g.Cm; c += blockDim.x) {
+        float mean, var;
+        if (use_running) { mean = rmean[c]; var = rvar[c]; }
+        else { mean = (float)ystats[((size_t)grp * g.Cm + c) * 2]; var = (float)ystats[((size_t)grp * g.Cm + c) * 2 + 1]; }
+        const float invstd = 1.0f / sqrtf(var + eps);
+        const float scale = (gamma ? gamma[c] : 1.f) * invstd;
+        L.cst[c * 8 + 0] = b1 ? b1[c] : 0.f;
+        L.cst[c * 8 + 1] = scale;
+        L.cst[c * 8 + 2] = (beta ? beta[c] : 0.f) - mean * scale;
+        for (int o = 0; o < 4; ++o) L.cst[c * 8 + 3 + o] = (o < g.Co) ? w2[o * g.Cm + c] : 0.f;
+        L.cst[c * 8 + 7] = invstd;
+        L.mu[c] = mean;
+    }
+    __syncthreads();
+}
+
+template <int CI>
+__device__ __forceinline__ void load_x(const float* __restrict__ p, float (&xv)[CI]) {
+#pragma unroll
+    for (int k = 0; k < CI / 4; ++k) {
+        const float4 v = reinterpret_cast<const float4*>(p)[k];
+        xv[4 * k] = v.x; xv[4 * k + 1] = v.y; xv[4 * k + 2] = v.z; xv[4 * k + 3] = v.w;
+    }
+}
+
+// ---- forward: thread per pixel. grid (nblk, groups) ----
+template <int CI>
+__global__ void __launch_bounds__(256) tail_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w1,
+                                                       const float* __restrict__ b1, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ w2,
+                                                       const float* __restrict__ b2, const double* __restrict__ ystats,
+                                                       const float* __restrict__ rmean, const float* __restrict__ rvar,
+                                                       float* __restrict__ out, TailGeom g, float eps, int use_running) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    TailLds L;
+    const int grp = blockIdx.y;
+    tail_load_consts(L, sm, g, w1, b1, gamma, beta, w2, ystats, rmean, rvar, use_running, grp, eps);
+    float bo[4];
+    for (int o = 0; o < 4; ++o) bo[o] = (o < g.Co && b2) ? b2[o] : 0.f;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < g.rows; r += gridDim.x * 256) {
+        const size_t m = (size_t)grp * g.rows + r;
+        float xv[CI];
+        load_x<CI>(x + m * CI, xv);
+        float o0 = bo[0], o1 = bo[1], o2 = bo[2], o3 = bo[3];
+        for (int c = 0; c < g.Cm; ++c) {
+            const float* wr = L.w1 + c * CI;
+            const float* cs = L.cst + c * 8;
+            float y = cs[0];
+#pragma unroll
+            for (int k = 0; k < CI; ++k) y = fmaf(wr[k], xv[k], y);
+            const float z = fmaxf(fmaf(y, cs[1], cs[2]), 0.f);
+            o0 = fmaf(z, cs[3], o0); o1 = fmaf(z, cs[4], o1); o2 = fmaf(z, cs[5], o2); o3 = fmaf(z, cs[6], o3);
+        }
+        const size_t img = m / g.hw, p = m - img * g.hw;
+        float* op = out + img * g.Co * g.hw + p;
+        op[0] = o0;
+        if (g.Co > 1) op[(size_t)g.hw] = o1;
+        if (g.Co > 2) op[2 * (size_t)g.hw] = o2;
+        if (g.Co > 3) op[3 * (size_t)g.hw] = o3;
+    }
+}
+
+// ---- backward reduction: thread = channel c; grid (nchunks, groups), block Cm ----
+// partial layout per (grp, chunk): [Cm][4 + CI] floats = { dbeta, dgamma, dW2_0..: see below }
+//   q[0] = sum gbn, q[1] = sum gbn*yhat, q[2..2+Co) = sum g_o * z, q[6..6+CI) = sum gbn * x_k   (stride 6 + CI)
+template <int CI>
+__global__ void __launch_bounds__(256) tail_bwd_reduce_kernel(const float* __restrict__ gout, const float* __restrict__ x,
+                                                              const float* __restrict__ w1, const float* __restrict__ b1,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ w2, const double* __restrict__ ystats,
+                                                              const float* __restrict__ rmean, const float* __restrict__ rvar,
+                                                              float* __restrict__ part, TailGeom g, float eps, int use_running) {
+    __shared__ __attribute__((aligned(16))) float xs[64 * CI];
+    __shared__ float gs[64 * 4];
+    const int grp = blockIdx.y, chunk = blockIdx.x, c = threadIdx.x;
+    const int rbeg = chunk * g.rows_per_chunk, rend = min(g.rows, rbeg + g.rows_per_chunk);
+    // this thread's channel constants in registers
+    float wr[CI];
+#pragma unroll
+    for (int k = 0; k < CI; ++k) wr[k] = w1[c * CI + k];
+    float mean, var;
+    if (use_running) { mean = rmean[c]; var = rvar[c]; }
+    else { mean = (float)ystats[((size_t)grp * g.Cm + c) * 2]; var = (float)ystats[((size_t)grp * g.Cm + c) * 2 + 1]; }
+    const float invstd = 1.0f / sqrtf(var + eps);
+    const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f, bb = b1 ? b1[c] : 0.f;
+    const float scale = gm * invstd, shift = bt - mean * scale;
+    float w2c[4];
+    for (int o = 0; o < 4; ++o) w2c[o] = (o < g.Co) ? w2[o * g.Cm + c] : 0.f;
+    float q0 = 0.f, q1 = 0.f, qz[4] = {0.f, 0.f, 0.f, 0.f}, qs[CI];
+#pragma unroll
+    for (int k = 0; k < CI; ++k) qs[k] = 0.f;
+    const float* xbase = x + (size_t)grp * g.rows * CI;
+    for (int r0 = rbeg; r0 < rend; r0 += 64) {
+        const int np = min(64, rend - r0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < np * CI / 4; e += blockDim.x)
+            reinterpret_cast<float4*>(xs)[e] = reinterpret_cast<const float4*>(xbase + (size_t)r0 * CI)[e];
+        for (int e = threadIdx.x; e < np * 4; e += blockDim.x) {
+            const int p = e >> 2, o = e & 3;
+            const size_t m = (size_t)grp * g.rows + r0 + p;
+            const size_t img = m / g.hw, pp = m - img * g.hw;
+            gs[e] = (o < g.Co) ? gout[(img * g.Co + o) * g.hw + pp] : 0.f;
+        }
+        __syncthreads();
+        for (int p = 0; p < np; ++p) {
+            const float* xv = xs + p * CI;
+            float y = bb;
+#pragma unroll
+            for (int k = 0; k < CI; ++k) y = fmaf(wr[k], xv[k], y);
+            const float yh = (y - mean) * invstd;
+            const float zz = fmaf(y, scale, shift);          // same expression as the forward kernel (same ReLU mask)
+            const float z = fmaxf(zz, 0.f);
+            const float g0 = gs[p * 4], g1 = gs[p * 4 + 1], g2 = gs[p * 4 + 2], g3 = gs[p * 4 + 3];
+            float gz = g0 * w2c[0] + g1 * w2c[1] + g2 * w2c[2] + g3 * w2c[3];
+            const float gbn = (zz > 0.f) ? gz : 0.f;
+            q0 += gbn; q1 = fmaf(gbn, yh, q1);
+            qz[0] = fmaf(g0, z, qz[0]); qz[1] = fmaf(g1, z, qz[1]); qz[2] = fmaf(g2, z, qz[2]); qz[3] = fmaf(g3, z, qz[3]);
+#pragma unroll
+            for (int k = 0; k < CI; ++k) qs[k] = fmaf(gbn, xv[k], qs[k]);
+        }
+    }
+    float* q = part + (((size_t)grp * g.nchunks + chunk) * g.Cm + c) * (6 + CI);
+    q[0] = q0; q[1] = q1; q[2] = qz[0]; q[3] = qz[1]; q[4] = qz[2]; q[5] = qz[3];
+#pragma unroll
+    for (int k = 0; k < CI; ++k) q[6 + k] = qs[k];
+}
+
+// ---- backward finalize: one wave per channel (grid Cm, block 64) ----
+// coef[groups][Cm][4] = { A = gamma*invstd, kbeta = dbeta_g/n, kgamma = dgamma_g/n, unused }
+template <int CI>
+__global__ void __launch_bounds__(64) tail_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gout_sum,
+                                                               const float* __restrict__ w1, const float* __restrict__ b1,
+                                                               const float* __restrict__ gamma, const double* __restrict__ ws,
+                                                               const float* __restrict__ rmean, const float* __restrict__ rvar,
+                                                               TailGeom g, float eps, int use_running, float* __restrict__ gw1,
+                                                               float* __restrict__ ggamma, float* __restrict__ gbeta,
+                                                               float* __restrict__ gw2, float* __restrict__ coef) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const int nm = CI + CI * CI;
+    const double* ystats = ws;
+    const double* xmom = ws + (size_t)g.groups * g.Cm * 2;
+    const double n = (double)g.rows;
+    double tgam = 0, tbet = 0, tw2[4] = {0, 0, 0, 0}, tw1[CI];
+    for (int k = 0; k < CI; ++k) tw1[k] = 0;
+    for (int grp = 0; grp < g.groups; ++grp) {
+        double acc[6 + CI];
+        for (int e = 0; e < 6 + CI; ++e) acc[e] = 0;
+        for (int k = lane; k < g.nchunks; k += 64) {
+            const float* q = part + (((size_t)grp * g.nchunks + k) * g.Cm + c) * (6 + CI);
+            for (int e = 0; e < 6 + CI; ++e) acc[e] += (double)q[e];
+        }
+        for (int e = 0; e < 6 + CI; ++e) acc[e] = wave_sum(acc[e]);
+        double mean, var;
+        if (use_running) { mean = rmean[c]; var = rvar[c]; }
+        else { mean = ystats[((size_t)grp * g.Cm + c) * 2]; var = ystats[((size_t)grp * g.Cm + c) * 2 + 1]; }
+        const double invstd = 1.0 / sqrt((double)(float)var + (double)eps);
+        const double gm = gamma ? (double)gamma[c] : 1.0;
+        const double A = gm * invstd;
+        const double kb = use_running ? 0.0 : acc[0] / n, kg = use_running ? 0.0 : acc[1] / n;
+        tbet += acc[0]; tgam += acc[1];
+        for (int o = 0; o < 4; ++o) tw2[o] += acc[2 + o];
+        // dW1[c][k] = A * ( S[c][k] - kb * sum_m x_k - kg * sum_m yhat_c x_k ),
+        //   sum_m yhat_c x_k = invstd * ( sum_j W1[c][j] Sxx[j][k] + (b1_c - mean) * Sx[k] )
+        const double* mo = xmom + (size_t)grp * nm;
+        for (int k = 0; k < CI; ++k) {
+            double syx = ((b1 ? (double)b1[c] : 0.0) - mean) * mo[k];
+            for (int j = 0; j < CI; ++j) syx += (double)w1[c * CI + j] * mo[CI + j * CI + k];
+            syx *= invstd;
+            tw1[k] += A * (acc[6 + k] - kb * mo[k] - kg * syx);
+        }
+        if (lane == 0) {
+            float* cf = coef + ((size_t)grp * g.Cm + c) * 4;
+            cf[0] = (float)A; cf[1] = (float)kb; cf[2] = (float)kg; cf[3] = 0.f;
+        }
+    }
+    if (lane == 0) {
+        if (ggamma) ggamma[c] += (float)tgam;
+        if (gbeta) gbeta[c] += (float)tbet;
+        if (gw2) for (int o = 0; o < g.Co; ++o) gw2[o * g.Cm + c] += (float)tw2[o];
+        if (gw1) for (int k = 0; k < CI; ++k) gw1[c * CI + k] += (float)tw1[k];
+    }
+}
+
+// ---- backward dx: thread per pixel. grid (nblk, groups) ----
+template <int CI>
+__global__ void __launch_bounds__(256) tail_bwd_dx_kernel(const float* __restrict__ gout, const float* __restrict__ x,
+                                                          const float* __restrict__ w1, const float* __restrict__ b1,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ w2, const double* __restrict__ ystats,
+                                                          const float* __restrict__ rmean, const float* __restrict__ rvar,
+                                                          const float* __restrict__ coef, float* __restrict__ gx, TailGeom g,
+                                                          float eps, int use_running) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    TailLds L;
+    const int grp = blockIdx.y;
+    tail_load_consts(L, sm, g, w1, b1, gamma, beta, w2, ystats, rmean, rvar, use_running, grp, eps);
+    float* cf = L.mu + g.Cm;                 // [Cm][4] copy of coef for this group
+    for (int e = threadIdx.x; e < g.Cm * 4; e += 256) cf[e] = coef[(size_t)grp * g.Cm * 4 + e];
+    __syncthreads();
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < g.rows; r += gridDim.x * 256) {
+        const size_t m = (size_t)grp * g.rows + r;
+        float xv[CI], gxv[CI];
+        load_x<CI>(x + m * CI, xv);
+#pragma unroll
+        for (int k = 0; k < CI; ++k) gxv[k] = 0.f;
+        const size_t img = m / g.hw, p = m - img * g.hw;
+        const float* gp = gout + img * g.Co * g.hw + p;
+        const float g0 = gp[0], g1 = g.Co > 1 ? gp[(size_t)g.hw] : 0.f, g2 = g.Co > 2 ? gp[2 * (size_t)g.hw] : 0.f,
+                    g3 = g.Co > 3 ? gp[3 * (size_t)g.hw] : 0.f;
+        for (int c = 0; c < g.Cm; ++c) {
+            const float* wr = L.w1 + c * CI;
+            const float* cs = L.cst + c * 8;
+            float y = cs[0];
+#pragma unroll
+            for (int k = 0; k < CI; ++k) y = fmaf(wr[k], xv[k], y);
+            const float yh = (y - L.mu[c]) * cs[7];
+            const float zz = fmaf(y, cs[1], cs[2]);
+            const float gz = g0 * cs[3] + g1 * cs[4] + g2 * cs[5] + g3 * cs[6];
+            const float gbn = (zz > 0.f) ? gz : 0.f;
+            const float gy = cf[c * 4] * (gbn - cf[c * 4 + 1] - yh * cf[c * 4 + 2]);
+#pragma unroll
+            for (int k = 0; k < CI; ++k) gxv[k] = fmaf(gy, wr[k], gxv[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < CI / 4; ++k)
+            reinterpret_cast<float4*>(gx + m * CI)[k] = make_float4(gxv[4 * k], gxv[4 * k + 1], gxv[4 * k + 2], gxv[4 * k + 3]);
+    }
+}
+
+// sum over all pixels of each NCHW output-gradient plane (bias gradient of the last conv): grid (64, Co), block 256
+__global__ void __launch_bounds__(256) tail_gb2_kernel(const float* __restrict__ gout, int N, int Co, int hw, float* __restrict__ gb2) {
+    __shared__ double sm[4];
+    const int o = blockIdx.y;
+    double acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)N * hw; i += (size_t)gridDim.x * 256) {
+        const size_t n = i / hw, p = i - n * hw;
+        acc += gout[(n * Co + o) * hw + p];
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(gb2 + o, (float)(sm[0] + sm[1] + sm[2] + sm[3]));
+}
+
+static int fwd_blocks(const TailGeom& g) {
+    int nb = (g.rows + 255) / 256;
+    int cap = 4096 / g.groups;
+    return nb > cap ? cap : nb;
+}
+
+extern "C" {
+
+int bh_tail_ws_doubles(int groups, int Ci, int Cm) {
+    return groups * Cm * 2 + groups * (Ci + Ci * Ci) * (1 + TAIL_CHUNKS);
+}
+int bh_tail_scratch_floats(int groups, int Ci, int Cm) { return groups * TAIL_CHUNKS * Cm * (6 + Ci) + groups * Cm * 4; }
+
+int bh_tail_fwd(const float* x, const float* w1, const float* b1, const float* gamma, const float* beta, float* running_mean,
+                float* running_var, const float* w2, const float* b2, float* out, double* ws, int groups, int rows, int hw,
+                int Ci, int Cm, int Co, float eps, float momentum, int use_running, void* stream) {
+    TailGeom g;
+    if (!x || !w1 || !w2 || !out || !ws) return BH_E_BADARG;
+    if (!tail_geom(groups, rows, hw, Ci, Cm, Co, g) || (Ci != 16 && Ci != 32 && Ci != 8)) return BH_E_UNSUPPORTED;
+    if (use_running && (!running_mean || !running_var)) return BH_E_BADARG;
+    hipStream_t s = bh_stream(stream);
+    if (!use_running) {
+        hipLaunchKernelGGL(tail_xmoments_kernel, dim3(g.nchunks, groups), dim3(256), 0, s, x, g, ws + off_part(g));
+        BH_LAUNCH_CHECK();
+        hipLaunchKernelGGL(tail_stats_finalize_kernel, dim3(1), dim3(256), 0, s, ws + off_part(g), w1, b1, g, momentum,
+                           running_mean, running_var, ws);
+        BH_LAUNCH_CHECK();
+    }
+    const size_t lds = sizeof(float) * (Cm * Ci + Cm * 8 + Cm);
+    dim3 grid(fwd_blocks(g), groups);
+#define TAIL_FWD(CI_)                                                                                                       \
+    hipLaunchKernelGGL((tail_fwd_kernel<CI_>), grid, dim3(256), lds, s, x, w1, b1, gamma, beta, w2, b2, ws, running_mean,  \
+                       running_var, out, g, eps, use_running)
+    if (Ci == 16) TAIL_FWD(16); else if (Ci == 32) TAIL_FWD(32); else TAIL_FWD(8);
+#undef TAIL_FWD
+    BH_LAUNCH_CHECK();
+    return BH_OK;
+}
+
+int bh_tail_bwd(const float* gout, const float* x, const float* w1, const float* b1, const float* gamma, const float* beta,
+                const float* w2, const double* ws, const float* running_mean, const float* running_var, float* gx, float* gw1,
+                float* ggamma, float* gbeta, float* gw2, float* gb2, float* scratch, int groups, int rows, int hw, int Ci, int Cm,
+                int Co, float eps, int use_running, void* stream) {
+    TailGeom g;
+    if (!gout || !x || !w1 || !w2 || !ws || !scratch) return BH_E_BADARG;
+    if (!tail_geom(groups, rows, hw, Ci, Cm, Co, g) || (Ci != 16 && Ci != 32 && Ci != 8)) return BH_E_UNSUPPORTED;
+    hipStream_t s = bh_stream(stream);
+    float* part = scratch;
+    float* coef = scratch + (size_t)groups * TAIL_CHUNKS * Cm * (6 + Ci);
+    const size_t lds = sizeof(float) * (Cm * Ci + Cm * 8 + Cm + Cm * 4);
+    dim3 grid(fwd_blocks(g), groups);
+#define TAIL_BWD(CI_)                                                                                                        \
+    do {                                                                                                                     \
+        hipLaunchKernelGGL((tail_bwd_reduce_kernel<CI_>), dim3(g.nchunks, groups), dim3(Cm), 0, s, gout, x, w1, b1, gamma,  \
+                           beta, w2, ws, running_mean, running_var, part, g, eps, use_running);                              \
+        BH_LAUNCH_CHECK();                                                                                                   \
+        hipLaunchKernelGGL((tail_bwd_finalize_kernel<CI_>), dim3(Cm), dim3(64), 0, s, part, nullptr, w1, b1, gamma, ws,      \
+                           running_mean, running_var, g, eps, use_running, gw1, ggamma, gbeta, gw2, coef);                   \
+        BH_LAUNCH_CHECK();                                                                                                   \
+        if (gx) {                                                                                                            \
+            hipLaunchKernelGGL((tail_bwd_dx_kernel<CI_>), grid, dim3(256), lds, s, gout, x, w1, b1, gamma, beta, w2, ws,     \
+                               running_mean, running_var, coef, gx, g, eps, use_running);                                    \
+            BH_LAUNCH_CHECK();                                                                                               \
+        }                                                                                                                    \
+    } while (0)
+    if (Ci == 16) TAIL_BWD(16); else if (Ci == 32) TAIL_BWD(32); else TAIL_BWD(8);
+#undef TAIL_BWD
+    if (gb2) {
+        hipLaunchKernelGGL(tail_gb2_kernel, dim3(64, Co), dim3(256), 0, s, gout, groups * rows / hw, Co, hw, gb2);
+        BH_LAUNCH_CHECK();
+    }
+    return BH_OK;
+}
+
+}  // extern "C"

@@ -116,6 +116,12 @@ class Program:
         self.ops.append(Op("bn", src, dst, mod, relu=relu, res=res))
         return dst
 
+    def tail(self, src, conv1, bn, conv2):
+        """Fused Conv1x1 + BatchNorm + ReLU + Conv1x1 -> NCHW (bh_tail_fwd/bwd)."""
+        dst = self._new()
+        self.ops.append(Op("tail", src, dst, (conv1, bn, conv2)))
+        return dst
+
     def maxpool(self, src):
         dst = self._new()
         self.ops.append(Op("maxpool", src, dst))
@@ -215,6 +221,16 @@ def run_forward(prog, x, groups, training, save):
                 m._bh_pending_batches = getattr(m, "_bh_pending_batches", 0) + groups
             if save:
                 ctx.stats[i] = st
+        elif op.kind == "tail":
+            c1, bn, c2 = op.mod
+            N, h, w, _ = src.shape
+            out, ws = K.tail_fwd(src, kview(c1.weight), c1.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                 kview(c2.weight), c2.bias, groups, h * w, bn.eps,
+                                 bn.momentum if bn.momentum is not None else 0.1, training)
+            if training:
+                bn._bh_pending_batches = getattr(bn, "_bh_pending_batches", 0) + groups
+            if save:
+                ctx.stats[i] = ws
         elif op.kind == "maxpool":
             out, idx = K.maxpool_fwd(src, want_index=save)
             if save:
@@ -283,6 +299,21 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
                 contribute(op.src, gx)
             if gres is not None:
                 contribute(op.res, gres)
+        elif op.kind == "tail":
+            c1, bn, c2 = op.mod
+            tr = want_wgrad and c1.weight.requires_grad
+            N, h, w, _ = x.shape
+            gx = K.tail_bwd(g, x, kview(c1.weight), c1.bias, bn.weight, bn.bias, kview(c2.weight), ctx.stats[i],
+                            bn.running_mean, bn.running_var, ctx.groups, h * w, bn.eps, ctx.training, need_src_grad,
+                            kview(c1.weight.grad) if tr else None, bn.weight.grad if tr else None,
+                            bn.bias.grad if tr else None, kview(c2.weight.grad) if tr else None,
+                            c2.bias.grad if (tr and c2.bias is not None) else None)
+            if tr and on_param_grad is not None:
+                for p_ in (c2.weight, c2.bias, bn.weight, bn.bias, c1.weight, c1.bias):
+                    if p_ is not None:
+                        on_param_grad(p_)
+            if need_src_grad:
+                contribute(op.src, gx)
         elif op.kind == "maxpool":
             if need_src_grad:
                 contribute(op.src, K.maxpool_bwd(ctx.stats[i], g, tuple(x.shape)))

@@ -143,6 +143,24 @@ int bh_bn_bwd(const float* gy, const float* y, const float* x, const float* gamm
               int groups, int rows, int C, float eps, int flags, int use_running,
               const float* running_mean, const float* running_var, void* stream);
 
+/* Fused tail of the Zeng backbone, `layer8` (src/backbones/Rethinking.py:145-147):
+ *   Conv2d(Ci,Cm,1,bias) -> BatchNorm2d(Cm) -> ReLU -> Conv2d(Cm,Co,1,bias), NHWC x[groups*rows,Ci] -> NCHW out[N,Co,h,w]
+ * (hw = h*w pixels per image, rows = pixels per group).  The Cm-channel intermediate is never materialised: its batch
+ * statistics are derived from the first/second moments of x (a 1x1 conv is linear).  Ci in {8,16}, Cm multiple of
+ * 64 (<= 256), Co <= 4.  ws: bh_tail_ws_doubles() doubles (kept for the adjoint); scratch: bh_tail_scratch_floats(). */
+int bh_tail_ws_doubles(int groups, int Ci, int Cm);
+int bh_tail_scratch_floats(int groups, int Ci, int Cm);
+int bh_tail_fwd(const float* x, const float* w1, const float* b1, const float* gamma, const float* beta,
+                float* running_mean, float* running_var, const float* w2, const float* b2, float* out, double* ws,
+                int groups, int rows, int hw, int Ci, int Cm, int Co, float eps, float momentum, int use_running,
+                void* stream);
+/* adjoint: gout[N,Co,h,w] -> gx[groups*rows,Ci] (overwritten, NULL ok); gw1[Cm][Ci], ggamma, gbeta, gw2[Co][Cm], gb2 += */
+int bh_tail_bwd(const float* gout, const float* x, const float* w1, const float* b1, const float* gamma,
+                const float* beta, const float* w2, const double* ws, const float* running_mean,
+                const float* running_var, float* gx, float* gw1, float* ggamma, float* gbeta, float* gw2, float* gb2,
+                float* scratch, int groups, int rows, int hw, int Ci, int Cm, int Co, float eps, int use_running,
+                void* stream);
+
 /* MaxPool2d(3, 2, 1) NHWC. argmax[N,Ho,Wo,C] (uint8, NULL ok in inference): window position 0..8 of the first
  * maximum (ATen's tie rule); the adjoint gathers through it (no atomics, no recomputation). */
 int bh_maxpool3s2_fwd(const float* x, float* y, unsigned char* argmax, int N, int Hi, int Wi, int C, void* stream);

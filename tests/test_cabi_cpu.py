@@ -58,9 +58,13 @@ def test_zeng_program_shape():
     m = Model(**configs.get("zeng-bihome")["MODEL"]["BACKBONE"])
     r = m._build()
     kinds = [op.kind for op in r.prog.ops]
-    assert kinds.count("bn") == 54                      # 54 BatchNorms in the backbone
-    assert kinds.count("conv") == 59 and kinds.count("maxpool") == 1
-    assert r.prog.ops[0].extra["in_nchw"] and r.prog.ops[-1].extra["out_nchw"]
+    # 54 BatchNorms / 59 convs in the backbone; the last conv+BN+ReLU+conv is one fused "tail" op
+    assert kinds.count("bn") == 53 and kinds.count("tail") == 1
+    assert kinds.count("conv") == 57 and kinds.count("maxpool") == 1
+    assert r.prog.ops[0].extra["in_nchw"] and r.prog.ops[-1].kind == "tail"
+    m.fuse_tail = False
+    kinds = [op.kind for op in m._build().prog.ops]
+    assert kinds.count("bn") == 54 and kinds.count("conv") == 59 and m._build().prog.ops[-1].extra["out_nchw"]
     assert sum(p.numel() for p in m.parameters()) == 10574178
     # every conv weight is in kernel layout and FlatGrads views alias it stride for stride
     for p in m.parameters():

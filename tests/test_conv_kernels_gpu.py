@@ -219,3 +219,50 @@ def test_maxpool_gap_add(K, N, H, C):
     s = a + b
     K.add_(a, b)
     assert torch.equal(a, s)
+
+
+@pytest.mark.parametrize("groups,N,H,Ci,Cm,Co,training", [(2, 2, 16, 16, 128, 2, True), (1, 3, 8, 16, 128, 2, True),
+                                                          (2, 1, 32, 8, 64, 3, True), (2, 2, 16, 16, 128, 2, False)])
+def test_fused_tail_fwd_bwd(K, groups, N, H, Ci, Cm, Co, training):
+    """conv1x1+BN+ReLU+conv1x1 fused (csrc/tail.hip) against the unfused float64 PyTorch chain, one BN call per group."""
+    NN = groups * N
+    x = (rnd((NN, Ci, H, H), 40) * 1.5 + 0.3).astype(np.float32)
+    w1 = (rnd((Cm, Ci, 1, 1), 41) / np.sqrt(Ci)).astype(np.float32)
+    b1 = rnd((Cm,), 42)
+    gamma, beta = (1 + 0.3 * rnd((Cm,), 43)).astype(np.float32), (0.3 * rnd((Cm,), 44)).astype(np.float32)
+    w2 = (rnd((Co, Cm, 1, 1), 45) / np.sqrt(Cm)).astype(np.float32)
+    b2 = rnd((Co,), 46)
+    rm0, rv0 = (0.1 * rnd((Cm,), 47)).astype(np.float32), (1 + 0.2 * np.abs(rnd((Cm,), 48))).astype(np.float32)
+    D = lambda a: torch.tensor(a, dtype=torch.float64)
+    xt, w1t, b1t, w2t, b2t = [D(a).requires_grad_(True) for a in (x, w1, b1, w2, b2)]
+    bn = torch.nn.BatchNorm2d(Cm).double()
+    bn.weight.data, bn.bias.data, bn.running_mean.data, bn.running_var.data = D(gamma), D(beta), D(rm0), D(rv0)
+    bn.train(training)
+    pre, outs = [], []
+    for g in range(groups):
+        p = bn(F.conv2d(xt[g * N:(g + 1) * N], w1t, b1t))
+        pre.append(p)
+        outs.append(F.conv2d(F.relu(p), w2t, b2t))
+    ref = torch.cat(outs, 0)
+    C = lambda a: torch.tensor(a).cuda()
+    xg = C(x).permute(0, 2, 3, 1).contiguous()
+    rm, rv = C(rm0), C(rv0)
+    args = (C(w1).reshape(Cm, Ci), C(b1), C(gamma), C(beta), rm, rv, C(w2).reshape(Co, Cm), C(b2))
+    out, ws = K.tail_fwd(xg, *args, groups, H * H, bn.eps, 0.1, training)
+    close(out.cpu(), ref.detach(), 3e-5)
+    close(rm.cpu(), bn.running_mean, 1e-5)
+    close(rv.cpu(), bn.running_var, 2e-5)
+    gy = rnd(tuple(ref.shape), 49)
+    # ReLU inputs within rounding of zero may take the other branch in float32: keep them out of the gradient check
+    near = (torch.cat(pre, 0).detach().abs() < 1e-4).any(1, keepdim=True).numpy()
+    gy = np.where(np.broadcast_to(near, gy.shape), 0, gy).astype(np.float32)
+    ref.backward(D(gy))
+    gw1, gg, gb, gw2, gb2 = [torch.zeros(s, device="cuda") for s in ((Cm, Ci), (Cm,), (Cm,), (Co, Cm), (Co,))]
+    gx = K.tail_bwd(C(gy), xg, args[0], args[1], args[2], args[3], args[6], ws, rm, rv, groups, H * H, bn.eps, training, True,
+                    gw1, gg, gb, gw2, gb2)
+    close(gx.cpu().permute(0, 3, 1, 2), xt.grad, 1e-4)
+    close(gw1.cpu().reshape(Cm, Ci, 1, 1), w1t.grad, 1e-4)
+    close(gw2.cpu().reshape(Co, Cm, 1, 1), w2t.grad, 1e-4)
+    close(gg.cpu(), bn.weight.grad, 1e-4)
+    close(gb.cpu(), bn.bias.grad, 1e-4)
+    close(gb2.cpu(), b2t.grad, 1e-5)
