@@ -348,6 +348,8 @@ static int dispatch(const GemmArgs& a_in, hipStream_t s) {
         if (bm == 64 && bn == 64) return launch<64, 64, 32, true>(a, s);
         if (bm == 128 && bn == 64) return launch<128, 64, 32, true>(a, s);
         if (bm == 128 && bn == 32) return launch<128, 32, 32, true>(a, s);
+        if (bm == 6464 && (a.Kc % 64) == 0) return launch<64, 64, 64, true>(a, s);        // BK = 64 experiments
+        if (bm == 64128 && (a.Kc % 64) == 0) return launch<64, 128, 64, true>(a, s);
         return BH_E_UNSUPPORTED;
     }
     if (!vec) {
@@ -377,21 +379,24 @@ static int dispatch(const GemmArgs& a_in, hipStream_t s) {
 // output parity class (iy%s, ix%s) so its valid taps are wave-uniform, 16 lanes x float4 read one source
 // pixel's channels coalesced, weights sit transposed in LDS, and the channel sum is a 16-lane xor-shuffle.
 // ---------------------------------------------------------------------------------------------
+template <int KK, int ST>     // KK = kernel size, ST = stride (compile-time: the tap loops unroll and their loads batch)
 __global__ void __launch_bounds__(256) stem_dgrad_c1_kernel(const float* __restrict__ gy, const float* __restrict__ w,
                                                             float* __restrict__ gx, int N, int Hi, int Wi, int Ho, int Wo,
-                                                            int Co, int k, int stride, int pad) {
+                                                            int Co, int pad) {
     extern __shared__ __attribute__((aligned(16))) float wT[];     // [k*k][Co]
-    for (int i = threadIdx.x; i < k * k * Co; i += 256) {
+    for (int i = threadIdx.x; i < KK * KK * Co; i += 256) {
         int t = i / Co, c = i - t * Co;
-        wT[i] = w[c * k * k + t];
+        wT[i] = w[c * KK * KK + t];
     }
     __syncthreads();
-    const int cls = blockIdx.y, py = cls / stride, px = cls % stride;
-    const int Ha = (Hi - py + stride - 1) / stride, Wa = (Wi - px + stride - 1) / stride;   // pixels of this class
+    constexpr int NT = (KK + ST - 1) / ST;          // taps per axis for one parity class
+    const int cls = blockIdx.y, py = cls / ST, px = cls % ST;
+    const int Ha = (Hi - py + ST - 1) / ST, Wa = (Wi - px + ST - 1) / ST;   // pixels of this class
     const int LP = Co / 4;                        // lanes per pixel (Co = 64 -> 16)
     const int PPW = 64 / LP;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane / LP, cl = lane % LP;
+    const int ky0 = (py + pad) % ST, kx0 = (px + pad) % ST;
     const long long total = (long long)N * Ha * Wa;
     const long long wave_global = (long long)blockIdx.x * 4 + wave, nwaves = (long long)gridDim.x * 4;
     for (long long q0 = wave_global * PPW; q0 < total; q0 += nwaves * PPW) {
@@ -401,20 +406,31 @@ __global__ void __launch_bounds__(256) stem_dgrad_c1_kernel(const float* __restr
         const int n = (int)(qq / ((long long)Ha * Wa));
         const int r = (int)(qq - (long long)n * Ha * Wa);
         const int a = r / Wa, b = r - a * Wa;
-        const int iy = a * stride + py, ix = b * stride + px;
-        float acc = 0.f;
-        // ky with (iy + pad - ky) % stride == 0
-        for (int ky = (py + pad) % stride; ky < k; ky += stride) {
-            const int oy = (iy + pad - ky) / stride;
-            if (iy + pad - ky < 0 || oy >= Ho) continue;
-            for (int kx = (px + pad) % stride; kx < k; kx += stride) {
-                const int ox = (ix + pad - kx) / stride;
-                if (ix + pad - kx < 0 || ox >= Wo) continue;
-                const float4 g = *reinterpret_cast<const float4*>(gy + (((size_t)n * Ho + oy) * Wo + ox) * Co + cl * 4);
-                const float4 ww = *reinterpret_cast<const float4*>(&wT[(ky * k + kx) * Co + cl * 4]);
-                acc += g.x * ww.x + g.y * ww.y + g.z * ww.z + g.w * ww.w;
+        const int iy = a * ST + py, ix = b * ST + px;
+        // source rows/cols for tap index (ty, tx): oy = (iy + pad - ky0)/ST - ty
+        const int oyb = (iy + pad - ky0) / ST, oxb = (ix + pad - kx0) / ST;
+        float4 gv[NT][NT];
+#pragma unroll
+        for (int ty = 0; ty < NT; ++ty)
+#pragma unroll
+            for (int tx = 0; tx < NT; ++tx) {
+                const int oy = oyb - ty, ox = oxb - tx;
+                const bool v = (ky0 + ty * ST < KK) && (kx0 + tx * ST < KK) && oy >= 0 && oy < Ho && ox >= 0 && ox < Wo;
+                gv[ty][tx] = v ? *reinterpret_cast<const float4*>(gy + (((size_t)n * Ho + oy) * Wo + ox) * Co + cl * 4)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-        }
+        float acc = 0.f;
+#pragma unroll
+        for (int ty = 0; ty < NT; ++ty)
+#pragma unroll
+            for (int tx = 0; tx < NT; ++tx) {
+                const int ky = ky0 + ty * ST, kx = kx0 + tx * ST;
+                if (ky < KK && kx < KK) {
+                    const float4 ww = *reinterpret_cast<const float4*>(&wT[(ky * KK + kx) * Co + cl * 4]);
+                    const float4 g = gv[ty][tx];
+                    acc += g.x * ww.x + g.y * ww.y + g.z * ww.z + g.w * ww.w;
+                }
+            }
         for (int off = 1; off < LP; off <<= 1) acc += __shfl_xor(acc, off, 64);
         if (ok && cl == 0) gx[((size_t)n * Hi + iy) * Wi + ix] = acc;
     }
@@ -467,11 +483,11 @@ int bh_conv_dgrad(const float* gy, const float* w, float* gx, const bh_conv_desc
     if (!gy || !w || !gx) return BH_E_BADARG;
     if (d->in_nchw) return BH_E_UNSUPPORTED;          // network inputs are data: no dgrad
     if (!d->transposed && d->Ci == 1 && !d->out_nchw && !accumulate && d->Co % 4 == 0 && d->Co <= 256 &&
-        (64 % (d->Co / 4)) == 0 && d->kh == d->kw && d->stride <= 4) {
+        (64 % (d->Co / 4)) == 0 && d->kh == 7 && d->kw == 7 && d->stride == 2) {
         const size_t lds = sizeof(float) * d->kh * d->kw * d->Co;
-        dim3 grid(512, d->stride * d->stride);
-        hipLaunchKernelGGL(stem_dgrad_c1_kernel, grid, dim3(256), lds, bh_stream(stream), gy, w, gx, d->N, d->Hi, d->Wi, d->Ho,
-                           d->Wo, d->Co, d->kh, d->stride, d->pad);
+        dim3 grid(1024, d->stride * d->stride);
+        hipLaunchKernelGGL((stem_dgrad_c1_kernel<7, 2>), grid, dim3(256), lds, bh_stream(stream), gy, w, gx, d->N, d->Hi,
+                           d->Wi, d->Ho, d->Wo, d->Co, d->pad);
         BH_LAUNCH_CHECK();
         return BH_OK;
     }

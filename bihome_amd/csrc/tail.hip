@@ -67,7 +67,16 @@ __global__ void __launch_bounds__(256) tail_xmoments_kernel(const float* __restr
     }
 }
 
-// ---- one block of 256: reduce partials, derive the BatchNorm statistics of y, update running stats ----
+// ---- reduce the per-chunk moment partials: grid (Ci + Ci*Ci, groups), one wave each ----
+__global__ void __launch_bounds__(64) tail_xmom_reduce_kernel(const double* __restrict__ part, TailGeom g, double* __restrict__ xmom) {
+    const int nm = g.Ci + g.Ci * g.Ci, e = blockIdx.x, grp = blockIdx.y;
+    double s = 0;
+    for (int k = threadIdx.x; k < g.nchunks; k += 64) s += part[((size_t)grp * g.nchunks + k) * nm + e];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) xmom[(size_t)grp * nm + e] = s;
+}
+
+// ---- one block of 256: derive the BatchNorm statistics of y from the x moments, update running stats ----
 __global__ void __launch_bounds__(256) tail_stats_finalize_kernel(const double* __restrict__ part, const float* __restrict__ w1,
                                                                   const float* __restrict__ b1, TailGeom g, float momentum,
                                                                   float* __restrict__ running_mean,
@@ -82,12 +91,7 @@ __global__ void __launch_bounds__(256) tail_stats_finalize_kernel(const double* 
     if (c < g.Cm) { rm = running_mean ? running_mean[c] : 0.f; rv = running_var ? running_var[c] : 1.f; }
     for (int grp = 0; grp < g.groups; ++grp) {
         __syncthreads();
-        for (int e = threadIdx.x; e < nm; e += 256) {
-            double s = 0;
-            for (int k = 0; k < g.nchunks; ++k) s += part[((size_t)grp * g.nchunks + k) * nm + e];
-            mom[e] = s;
-            xmom[(size_t)grp * nm + e] = s;
-        }
+        for (int e = threadIdx.x; e < nm; e += 256) mom[e] = xmom[(size_t)grp * nm + e];
         __syncthreads();
         if (c < g.Cm) {
             double my = b1 ? (double)b1[c] : 0.0, eyy = 0;
@@ -393,6 +397,9 @@ int bh_tail_fwd(const float* x, const float* w1, const float* b1, const float* g
     hipStream_t s = bh_stream(stream);
     if (!use_running) {
         hipLaunchKernelGGL(tail_xmoments_kernel, dim3(g.nchunks, groups), dim3(256), 0, s, x, g, ws + off_part(g));
+        BH_LAUNCH_CHECK();
+        hipLaunchKernelGGL(tail_xmom_reduce_kernel, dim3(Ci + Ci * Ci, groups), dim3(64), 0, s, ws + off_part(g), g,
+                           ws + off_xmom(g));
         BH_LAUNCH_CHECK();
         hipLaunchKernelGGL(tail_stats_finalize_kernel, dim3(1), dim3(256), 0, s, ws + off_part(g), w1, b1, g, momentum,
                            running_mean, running_var, ws);

@@ -3,7 +3,7 @@ import torch
 from bihome_amd import kernels as K
 from bihome_amd._lib import lib
 shapes=[(128,32,64,64,3,1,1),(128,16,128,128,3,1,1),(128,8,256,256,3,1,1),(128,64,64,64,3,1,1),(128,128,32,32,3,1,1),(128,16,256,256,3,1,1)]
-tiles=[(0,0),(128,128),(64,128),(128,64),(64,64),(128,32)]
+tiles=[(0,0),(64,128),(64,64),(6464,0),(64128,0)]
 def bench(fn, n=20):
     for _ in range(3): fn()
     torch.cuda.synchronize()
