@@ -70,6 +70,23 @@ def cpu_baseline(cfg, seed=42, batch=8, steps=3, warmup=1):
                       "%.2f s/step" % (batch, steps, warmup, t)}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*pmc_traffic.json, made by
+    tools/pmc_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, with the
+    gfx950 FETCH_SIZE x2 correction).  PMC counters cannot be read from inside the process, so this is the recorded
+    value of the profiled build, or None when no summary matches."""
+    import glob
+    key = kernel.replace(" ", "")
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
+        try:
+            ks = json.load(open(path))["kernels"]
+        except Exception:
+            continue
+        if key in ks:
+            return ks[key]["traffic_bytes_per_launch"]
+    return None
+
+
 def roofline_leg(model, data, opt, sched, reducer, nsteps=2):
     """Per-launch HIP-event timing (events recorded on the launch stream) of every conv/BN launch for a few
     extra steps; returns the roofline object of the kernel with the largest total time plus a breakdown."""
@@ -89,14 +106,16 @@ def roofline_leg(model, data, opt, sched, reducer, nsteps=2):
     K.TIMING = None
     rows.sort(key=lambda r: -r["ms_per_step"])
     top = rows[0]
+    traffic = pmc_traffic(top["kernel"])
     if top["tflops"] > 0:
         roof = {"kernel": top["kernel"], "bound": "mfma", "achieved": top["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": top["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "unit": "TFLOP/s", "frac": top["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": top["bytes_per_launch"],
                 "avg_launch_us": top["avg_us"], "flops_per_launch": top["flops_per_launch"],
                 "launches_per_step": top["launches_per_step"]}
     else:
         roof = {"kernel": top["kernel"], "bound": "hbm", "achieved": top["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "frac": top["gbs"] / PEAK_HBM_GBS, "traffic": None, "avg_launch_us": top["avg_us"],
+                "frac": top["gbs"] / PEAK_HBM_GBS, "traffic": traffic, "avg_launch_us": top["avg_us"],
                 "bytes_per_launch": top["bytes_per_launch"], "launches_per_step": top["launches_per_step"]}
     return roof, rows
 
@@ -108,12 +127,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)          # (dev only: several ranks may share one GPU with BIHOME_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        backend = os.environ.get("BIHOME_DIST_BACKEND", "nccl")       # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from bihome_amd import configs, synth
     from bihome_amd.step import attach_reducer, build_model, build_optimizer, mace, train_step
@@ -164,7 +189,7 @@ def main():
         dist.barrier()
     if rank == 0:
         out = {
-            "metric": "training image-pairs/s (128x128 patch, bs=64 per GPU, full step: fwd+bwd+Adam)",
+            "metric": "training image-pairs/s (128x128 patch, bs=%d per GPU, full step: fwd+bwd+Adam)" % B,
             "value": value, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (seeded COCO-style texture pairs, random-init weights)",

@@ -81,6 +81,17 @@ def _conv_variant0(d, which):
     return gemm_variant(d.N * d.Hi * d.Wi, d.Ci, d.Co, vec)
 
 
+def _wgrad_variant(d):
+    """Mirror of wgrad.hip's dispatch: kernel symbol of a weight-gradient launch."""
+    if d.transposed:
+        Np, Nq, vec = d.Ci, d.Co, d.Co % 4 == 0
+    else:
+        Np, Nq, vec = d.Co, d.Ci, (not d.in_nchw) and d.Ci % 4 == 0
+    ncols = Nq if vec else d.kh * d.kw * Nq
+    small = Np <= 32 or ncols <= 32
+    return "%s<%s>" % ("wgrad_small_kernel" if small else "wgrad_kernel", "true" if vec else "false")
+
+
 def conv_flops(d):
     """Algorithmic flops of one conv launch: 2 * MACs (same count for fwd, dgrad and wgrad)."""
     if d.transposed:
@@ -256,7 +267,7 @@ def conv_dgrad(gy, w, d, out=None):
 
 def conv_wgrad(x, gy, gw, gbias, d):
     _chk(x); _chk(gy); _chk(gw); _chk(gbias)
-    with _Timed("wgrad_kernel" + (" N%d %dx%d C%d->%d k%d s%d%s" % (d.N, d.Hi, d.Wi, d.Ci, d.Co, d.kh, d.stride, " T" if d.transposed else "") if TIMING_DETAIL else ""), conv_flops(d), 4.0 * (x.numel() + gy.numel() + gw.numel())):
+    with _Timed(_wgrad_variant(d) + (" N%d %dx%d C%d->%d k%d s%d%s" % (d.N, d.Hi, d.Wi, d.Ci, d.Co, d.kh, d.stride, " T" if d.transposed else "") if TIMING_DETAIL else ""), conv_flops(d), 4.0 * (x.numel() + gy.numel() + gw.numel())):
         check(lib.bh_conv_wgrad(_p(x), _p(gy), _p(gw), _p(gbias), ctypes.byref(d), _stream()), "bh_conv_wgrad")
 
 
