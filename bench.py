@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="image pairs per GPU")
     ap.add_argument("--config", default="zeng-bihome")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
+                    help="conv operand precision; the headline config (BASELINE.json configs[1]) is f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -145,6 +147,8 @@ def main():
     from bihome_amd.weights import load_synthetic
 
     cfg = configs.get(args.config)
+    cfg["MODEL"]["BACKBONE"]["PRECISION"] = args.precision
+    cfg["MODEL"]["HEAD"]["PRECISION"] = args.precision
     model = build_model(cfg, "cuda")
     load_synthetic(model[0], 0)                       # identical replicas on every rank
     load_synthetic(model[1].auxiliary_resnet, 0)
@@ -191,10 +195,10 @@ def main():
         out = {
             "metric": "training image-pairs/s (128x128 patch, bs=%d per GPU, full step: fwd+bwd+Adam)" % B,
             "value": value, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
             "data": "synthetic (seeded COCO-style texture pairs, random-init weights)",
             "config": {"workload": "BASELINE.json configs[1]: s-coco Zeng (Rethinking/ResNet34 blocks) backbone + biHomE "
-                                   "head, %d pairs/GPU, 128x128 grayscale, fp32 MFMA conv + HIP warp/DLT/triplet kernels" % B,
+                                   "head, %d pairs/GPU, 128x128 grayscale, %s MFMA conv + HIP warp/DLT/triplet kernels" % (B, args.precision),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "optimizer": "Adam lr 1e-3"},
             "final_loss": final_loss, "final_mace": final_mace,
             "roofline": roof, "cpu_baseline": cpu,

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libbihome_hip.so")
 
 class BhConvDesc(Structure):
     _fields_ = [(n, c_int) for n in ("N", "Hi", "Wi", "Ci", "Ho", "Wo", "Co", "kh", "kw", "stride", "pad",
-                                     "transposed", "in_nchw", "out_nchw")]
+                                     "transposed", "in_nchw", "out_nchw", "precision")]
 
 
 P = c_void_p

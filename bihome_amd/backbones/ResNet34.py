@@ -2,6 +2,8 @@
 torchvision-layout resnet34 with a 2-channel conv1 and an 8-way fc (src/backbones/ResNet34.py:6-50),
 executed by the gfx950 kernels.  State-dict keys `resnet34.{conv1,bn1,layer1..4,fc}.*` as upstream.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -47,6 +49,9 @@ class Model(nn.Module):
         self.resnet34 = _ResNet34(2, 8)
         self.variant = str.lower(kwargs['VARIANT']) if 'VARIANT' in kwargs else 'oneline'
         assert 'oneline' in self.variant or 'doubleline' in self.variant, 'Only OneLine or DoubleLine variant is supported'
+        # optional extra kwarg (ignored upstream): conv operand precision 'f32' (default, exact) or 'bf16' (bf16 MFMA operands,
+        # fp32 accumulate/storage - BASELINE.json configs[3])
+        self.precision = kwargs.get('PRECISION', os.environ.get('BIHOME_PRECISION', 'f32'))
         net.to_kernel_layout_(self)
         self._runner = None
 
@@ -59,7 +64,7 @@ class Model(nn.Module):
             for blk in getattr(r, name):
                 s = prog.basic_block(s, blk)
         s = prog.conv(prog.gap(s), r.fc)
-        return net.Runner(self, prog, trainable=True)
+        return net.Runner(self, prog, trainable=True, precision=self.precision)
 
     def single_forward(self, x, groups=1):
         if self._runner is None:

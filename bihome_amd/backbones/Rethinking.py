@@ -70,6 +70,9 @@ class Model(nn.Module):
         self.layer6 = S(U(64, 64), U(64, 64), D(64))
         self.layer7 = S(U(32, 32), D(32))
         self.layer8 = S(nn.Conv2d(16, 128, 1), nn.BatchNorm2d(128), nn.ReLU(), nn.Conv2d(128, 2, 1))
+        # optional extra kwarg (ignored upstream): conv operand precision 'f32' (default, exact) or 'bf16' (bf16 MFMA operands,
+        # fp32 accumulate/storage - BASELINE.json configs[3])
+        self.precision = kwargs.get('PRECISION', os.environ.get('BIHOME_PRECISION', 'f32'))
         net.to_kernel_layout_(self)
         self._runner = None
         self.fuse_tail = os.environ.get("BIHOME_FUSE_TAIL", "1") != "0"
@@ -97,7 +100,7 @@ class Model(nn.Module):
                     s = prog.conv(s, mods[-1], out_nchw=True)   # perspective field leaves as NCHW
             else:
                 s = prog.sequential(s, layer)
-        return net.Runner(self, prog, trainable=True)
+        return net.Runner(self, prog, trainable=True, precision=self.precision)
 
     def _forward(self, x, groups=1):
         if self._runner is None:

@@ -16,6 +16,9 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct GemmArgs {
     const float* Src;
@@ -32,6 +35,7 @@ struct GemmArgs {
     int b_kcontig;         // 1: sBc == 1, 0: sBn == 1
     int epi;               // 0: NHWC [M][Nn]; 1: ConvTranspose scatter; 2: NCHW
     int accumulate;        // Out += result
+    int bf16;              // operands rounded to bf16 (fp32 accumulate) where the vectorised path applies
     int ek, eC;            // scatter: kernel (== stride) and real channel count (Nn = ek*ek*eC)
 };
 
@@ -53,7 +57,7 @@ __device__ __forceinline__ bool src_coord(const GemmArgs& a, int oy, int ox, int
     return iy >= 0 && iy < a.Hs && ix >= 0 && ix < a.Ws;
 }
 
-template <int BM, int BN, int BK, bool VEC>
+template <int BM, int BN, int BK, bool VEC, bool BF16 = false>
 __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
     constexpr int WN = (BN >= 64) ? 2 : 1;         // waves along N
     constexpr int WM = 4 / WN;                     // waves along M
@@ -66,8 +70,17 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
     constexpr int AROWS = 256 / CH;                // rows covered per pass
     constexpr int AIT = BM / AROWS;
     constexpr int BIT_K = (BN + AROWS - 1) / AROWS;   // K-contiguous B: rows = n
-    __shared__ float As[BK * LDA];
-    __shared__ float Bs[BK * LDB_N];
+    // BF16 operand mode (mixed precision: fp32 tensors in HBM, operands rounded to bf16 while staging, fp32
+    // accumulate on v_mfma_f32_32x32x16_bf16): tiles are row-major [row][BK + 8] bf16 - the 80-byte row stride makes
+    // the ds_read_b128 fragment reads bank-conflict free and the float4 -> bf16x4 staging writes need no transpose.
+    static_assert(!BF16 || (VEC && BK == 32), "bf16 operand mode needs the vectorised loader and BK = 32");
+    constexpr int LDH = BK + 8;
+    constexpr int A_FLOATS = BF16 ? (BM * LDH / 2) : BK * LDA;
+    constexpr int B_FLOATS = BF16 ? (BN * LDH / 2) : BK * LDB_N;
+    __shared__ __attribute__((aligned(16))) float As[A_FLOATS];
+    __shared__ __attribute__((aligned(16))) float Bs[B_FLOATS];
+    __bf16* Ah = reinterpret_cast<__bf16*>(As);
+    __bf16* Bh = reinterpret_cast<__bf16*>(Bs);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -234,6 +247,36 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
     };
 
     auto store_tile = [&]() {
+        if constexpr (BF16) {
+#pragma unroll
+            for (int i = 0; i < AIT; ++i) {
+                const int row = a_row0 + i * AROWS;
+                f32x4v v = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+                *reinterpret_cast<bf16x4*>(&Ah[row * LDH + a_chunk * 4]) = __builtin_convertvector(v, bf16x4);
+            }
+            if (a.b_kcontig) {
+#pragma unroll
+                for (int i = 0; i < BIT_K; ++i) {
+                    const int row = bk_row0 + i * AROWS;
+                    if (row < BN) {
+                        f32x4v v = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
+                        *reinterpret_cast<bf16x4*>(&Bh[row * LDH + bk_chunk * 4]) = __builtin_convertvector(v, bf16x4);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < BIT_N; ++i) {
+                    const int kr = bn_row0 + i * BROWS_N;
+                    if (kr < BK) {
+                        Bh[(bn_chunk * 4 + 0) * LDH + kr] = (__bf16)rb[i].x;
+                        Bh[(bn_chunk * 4 + 1) * LDH + kr] = (__bf16)rb[i].y;
+                        Bh[(bn_chunk * 4 + 2) * LDH + kr] = (__bf16)rb[i].z;
+                        Bh[(bn_chunk * 4 + 3) * LDH + kr] = (__bf16)rb[i].w;
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < AIT; ++i) {
             const int row = a_row0 + i * AROWS;
@@ -270,6 +313,23 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
         store_tile();
         __syncthreads();
         if (kt + 1 < ktiles) load_tile(kt + 1);
+        if constexpr (BF16) {
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    af[i] = *reinterpret_cast<const bf16x8*>(&Ah[((wm * TM + i) * 32 + l31) * LDH + ks * 16 + kh2 * 8]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    bf[j] = *reinterpret_cast<const bf16x8*>(&Bh[((wn * TN + j) * 32 + l31) * LDH + ks * 16 + kh2 * 8]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        } else
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             const int k = 2 * kk + kh2;
@@ -322,10 +382,10 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
     }
 }
 
-template <int BM, int BN, int BK, bool VEC>
+template <int BM, int BN, int BK, bool VEC, bool BF16 = false>
 static int launch(const GemmArgs& a, hipStream_t s) {
     dim3 grid((a.M + BM - 1) / BM, (a.Nn + BN - 1) / BN);
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, VEC>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, VEC, BF16>), grid, dim3(256), 0, s, a);
     BH_LAUNCH_CHECK();
     return BH_OK;
 }
@@ -341,6 +401,20 @@ static int dispatch(const GemmArgs& a_in, hipStream_t s) {
         if (a.stride == (1 << b)) a.sshift = b;
     if (a.M <= 0 || a.Nn <= 0) return BH_OK;
     const bool vec = !a.src_nchw && (a.Kc % 4 == 0) && (a.Cs % 4 == 0);
+    if (vec && a.bf16 && (a.Kc % 32) == 0) {
+        // bf16 operands: the MFMA is 16x faster, the kernel is bound by staging traffic -> widest N tile that fits
+        int bm = g_force_bm, bn = g_force_bn;
+        if (!bm) {      // measured (scratch/bf16bench.py): 64-wide N tiles; 64-row tiles while the grid is small
+            if (a.Nn <= 32) { bm = 128; bn = 32; }
+            else { bn = 64; bm = (((a.M + 127) / 128) * ((a.Nn + 63) / 64) < 1024) ? 64 : 128; }
+        }
+        if (bm == 128 && bn == 128) return launch<128, 128, 32, true, true>(a, s);
+        if (bm == 64 && bn == 128) return launch<64, 128, 32, true, true>(a, s);
+        if (bm == 64 && bn == 64) return launch<64, 64, 32, true, true>(a, s);
+        if (bm == 128 && bn == 64) return launch<128, 64, 32, true, true>(a, s);
+        if (bm == 128 && bn == 32) return launch<128, 32, 32, true, true>(a, s);
+        return BH_E_UNSUPPORTED;
+    }
     if (vec && g_force_bm && (a.Kc % 32) == 0) {
         const int bm = g_force_bm, bn = g_force_bn;
         if (bm == 128 && bn == 128) return launch<128, 128, 32, true>(a, s);
@@ -458,7 +532,7 @@ int bh_conv_fwd(const float* x, const float* w, const float* bias, float* y, con
     if (rc) return rc;
     if (!x || !w || !y) return BH_E_BADARG;
     GemmArgs a = {};
-    a.Src = x; a.Bw = w; a.bias = bias; a.Out = y;
+    a.Src = x; a.Bw = w; a.bias = bias; a.Out = y; a.bf16 = d->precision == 1;
     a.Hs = d->Hi; a.Ws = d->Wi; a.Cs = d->Ci; a.Kc = d->Ci;
     if (!d->transposed) {
         a.M = d->N * d->Ho * d->Wo; a.Nn = d->Co; a.T = d->kh * d->kw;
@@ -493,7 +567,7 @@ int bh_conv_dgrad(const float* gy, const float* w, float* gx, const bh_conv_desc
     }
     GemmArgs a = {};
     a.src_nchw = d->out_nchw;                         // gradient of the NCHW network output
-    a.Src = gy; a.Bw = w; a.bias = nullptr; a.Out = gx; a.accumulate = accumulate;
+    a.Src = gy; a.Bw = w; a.bias = nullptr; a.Out = gx; a.accumulate = accumulate; a.bf16 = d->precision == 1;
     a.M = d->N * d->Hi * d->Wi; a.Nn = d->Ci; a.Kc = d->Co; a.T = d->kh * d->kw;
     a.Ho = d->Hi; a.Wo = d->Wi;               // output-side grid of this GEMM = conv input grid
     a.Hs = d->Ho; a.Ws = d->Wo; a.Cs = d->Co;  // gathered source = gy grid

@@ -9,6 +9,7 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct WgradArgs {
     const float* P;
@@ -36,10 +37,16 @@ __device__ __forceinline__ bool q_coord(const WgradArgs& a, int oy, int ox, int 
 }
 
 // grid: (ptiles*qtiles, T', splitK)
-template <bool VEC>
+// BF16 = operands rounded to bf16 while staging (fp32 accumulate, v_mfma_f32_32x32x16_bf16): tiles are stored
+// [channel][pixel + pad] so that the 8 consecutive k (= pixels) of a fragment are one ds_read_b128; lanes run along
+// pixels in the loader so the transposed 2-byte LDS writes of a wave are contiguous.
+template <bool VEC, bool BF16 = false>
 __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
-    __shared__ float As[WBK * WLD];
-    __shared__ float Bs[WBK * WLD];
+    constexpr int WLH = WBK + 8;
+    __shared__ __attribute__((aligned(16))) float As[BF16 ? 64 * WLH / 2 : WBK * WLD];
+    __shared__ __attribute__((aligned(16))) float Bs[BF16 ? 64 * WLH / 2 : WBK * WLD];
+    __bf16* Ah = reinterpret_cast<__bf16*>(As);
+    __bf16* Bh = reinterpret_cast<__bf16*>(Bs);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int ncols = a.joint ? a.T * a.Nq : a.Nq;
@@ -50,7 +57,8 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
     const int mend = min(a.M, mbeg + a.rows_per_block);
     if (mbeg >= mend) return;
 
-    const int chunk = tid & 15, prow0 = tid >> 4;     // 16 float4 chunks x 16 rows per pass, 2 passes
+    // fp32: 16 float4 chunks x 16 pixel rows per pass, 2 passes; bf16: 32 pixel rows x 8 chunks per pass, 2 passes
+    const int chunk0 = BF16 ? (tid >> 5) : (tid & 15), prow0 = BF16 ? (tid & 31) : (tid >> 4);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -61,7 +69,8 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
     auto load_tile = [&](int mk) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int m = mk + prow0 + i * 16;
+            const int chunk = BF16 ? chunk0 + 8 * i : chunk0;
+            const int m = mk + (BF16 ? prow0 : prow0 + i * 16);
             float4 vp = make_float4(0.f, 0.f, 0.f, 0.f), vq = vp;
             if (m < mend) {
                 const int pc = p0 + chunk * 4;
@@ -117,18 +126,35 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
     for (int mk = mbeg; mk < mend; mk += WBK) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int row = prow0 + i * 16;
-            *reinterpret_cast<float4*>(&As[row * WLD + chunk * 4]) = rp[i];
-            *reinterpret_cast<float4*>(&Bs[row * WLD + chunk * 4]) = rq[i];
+            if constexpr (BF16) {
+                const int ch = (chunk0 + 8 * i) * 4;
+                Ah[(ch + 0) * WLH + prow0] = (__bf16)rp[i].x; Ah[(ch + 1) * WLH + prow0] = (__bf16)rp[i].y;
+                Ah[(ch + 2) * WLH + prow0] = (__bf16)rp[i].z; Ah[(ch + 3) * WLH + prow0] = (__bf16)rp[i].w;
+                Bh[(ch + 0) * WLH + prow0] = (__bf16)rq[i].x; Bh[(ch + 1) * WLH + prow0] = (__bf16)rq[i].y;
+                Bh[(ch + 2) * WLH + prow0] = (__bf16)rq[i].z; Bh[(ch + 3) * WLH + prow0] = (__bf16)rq[i].w;
+            } else {
+                const int row = prow0 + i * 16;
+                *reinterpret_cast<float4*>(&As[row * WLD + chunk0 * 4]) = rp[i];
+                *reinterpret_cast<float4*>(&Bs[row * WLD + chunk0 * 4]) = rq[i];
+            }
         }
         __syncthreads();
         if (mk + WBK < mend) load_tile(mk + WBK);
+        if constexpr (BF16) {
 #pragma unroll
-        for (int kk = 0; kk < WBK / 2; ++kk) {
-            const int k = 2 * kk + kh2;
-            float av = As[k * WLD + wm * 32 + l31];
-            float bv = Bs[k * WLD + wn * 32 + l31];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            for (int ks = 0; ks < WBK / 16; ++ks) {
+                const bf16x8 av = *reinterpret_cast<const bf16x8*>(&Ah[(wm * 32 + l31) * WLH + ks * 16 + kh2 * 8]);
+                const bf16x8 bv = *reinterpret_cast<const bf16x8*>(&Bh[(wn * 32 + l31) * WLH + ks * 16 + kh2 * 8]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < WBK / 2; ++kk) {
+                const int k = 2 * kk + kh2;
+                float av = As[k * WLD + wm * 32 + l31];
+                float bv = Bs[k * WLD + wn * 32 + l31];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            }
         }
         __syncthreads();
     }
@@ -333,7 +359,8 @@ int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, cons
         if (vec) hipLaunchKernelGGL((wgrad_small_kernel<true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((wgrad_small_kernel<false>), grid, dim3(256), 0, s, a);
     } else {
-        if (vec) hipLaunchKernelGGL((wgrad_kernel<true>), grid, dim3(256), 0, s, a);
+        if (vec && d->precision == 1) hipLaunchKernelGGL((wgrad_kernel<true, true>), grid, dim3(256), 0, s, a);
+        else if (vec) hipLaunchKernelGGL((wgrad_kernel<true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((wgrad_kernel<false>), grid, dim3(256), 0, s, a);
     }
     BH_LAUNCH_CHECK();

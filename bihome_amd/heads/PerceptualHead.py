@@ -15,6 +15,8 @@ Data flow of one training forward (both directions stacked along the batch axis,
     bh_triplet_l1_fwd + bh_bihome_loss_fwd -> loss
 and the adjoint chain back to pf in `_BiHomELoss.backward` / `_DltFunction.backward`.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -59,6 +61,7 @@ class AuxiliaryResnet(nn.Module):
             raise NotImplementedError("AUXILIARY_RESNET_FREEZE=False is not used by any shipped config")
         for p in self.resnet.parameters():          # PerceptualHead.py:36-39
             p.requires_grad = False
+        self.precision = kwargs.get('PRECISION', os.environ.get('BIHOME_PRECISION', 'f32'))
         net.to_kernel_layout_(self)
         self._runners = {}
 
@@ -77,7 +80,7 @@ class AuxiliaryResnet(nn.Module):
             s = prog.maxpool(s)
             for blk in r.layer1:
                 s = prog.basic_block(s, blk)
-            self._runners[in_ch] = net.Runner(self, prog, trainable=False)
+            self._runners[in_ch] = net.Runner(self, prog, trainable=False, precision=self.precision)
         return self._runners[in_ch]
 
     def forward(self, x, groups=1):

@@ -230,8 +230,12 @@ def bihome_loss_bwd(g_loss, f1, f2, f1w, f2w, m1w, m2w, m1, m2, M1, M2, numden, 
 # ------------------------------------------------------------------------------------------------
 # conv stacks
 # ------------------------------------------------------------------------------------------------
-def conv_desc(N, Hi, Wi, Ci, Co, k, stride, pad, transposed=False, in_nchw=False, out_nchw=False):
+PRECISION = {"f32": 0, "fp32": 0, "bf16": 1}
+
+
+def conv_desc(N, Hi, Wi, Ci, Co, k, stride, pad, transposed=False, in_nchw=False, out_nchw=False, precision=0):
     d = BhConvDesc()
+    d.precision = int(precision)
     d.N, d.Hi, d.Wi, d.Ci, d.Co = N, Hi, Wi, Ci, Co
     d.kh = d.kw = k
     d.stride, d.pad = stride, pad

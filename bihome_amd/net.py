@@ -183,20 +183,20 @@ class Ctx:
         self.slots, self.stats, self.descs, self.weights = {}, {}, {}, {}
 
 
-def _conv_geometry(mod, x_shape, in_nchw, out_nchw):
+def _conv_geometry(mod, x_shape, in_nchw, out_nchw, precision=0):
     if in_nchw:
         N, Ci, Hi, Wi = x_shape
     else:
         N, Hi, Wi, Ci = x_shape
     if isinstance(mod, nn.Linear):
-        return K.conv_desc(N, Hi, Wi, Ci, mod.out_features, 1, 1, 0)
+        return K.conv_desc(N, Hi, Wi, Ci, mod.out_features, 1, 1, 0, precision=precision)
     k, s, p = mod.kernel_size[0], mod.stride[0], mod.padding[0]
     tr = isinstance(mod, nn.ConvTranspose2d)
     Co = mod.out_channels
-    return K.conv_desc(N, Hi, Wi, Ci, Co, k, s, p, transposed=tr, in_nchw=in_nchw, out_nchw=out_nchw)
+    return K.conv_desc(N, Hi, Wi, Ci, Co, k, s, p, transposed=tr, in_nchw=in_nchw, out_nchw=out_nchw, precision=precision)
 
 
-def run_forward(prog, x, groups, training, save):
+def run_forward(prog, x, groups, training, save, precision=0):
     """x: NHWC (or NCHW when the first conv is flagged in_nchw). Returns (out, ctx|None)."""
     ctx = Ctx() if save else None
     slots = {0: x}
@@ -206,7 +206,7 @@ def run_forward(prog, x, groups, training, save):
         src = slots[op.src]
         if op.kind == "conv":
             e = op.extra
-            d = _conv_geometry(op.mod, src.shape, e["in_nchw"], e["out_nchw"])
+            d = _conv_geometry(op.mod, src.shape, e["in_nchw"], e["out_nchw"], precision)
             w = e["weight_fn"](op.mod.weight) if e["weight_fn"] else op.mod.weight
             wk = kview(w)
             out = K.conv_fwd(src, wk, op.mod.bias, d)
@@ -341,7 +341,7 @@ class NetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, anchor, runner, groups):
         need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-        out, saved = run_forward(runner.prog, x, groups, runner.module.training, save=need)
+        out, saved = run_forward(runner.prog, x, groups, runner.module.training, save=need, precision=runner.precision)
         ctx.runner, ctx.saved, ctx.want_x = runner, saved, ctx.needs_input_grad[0]
         return out
 
@@ -360,8 +360,9 @@ class NetFunction(torch.autograd.Function):
 class Runner:
     """Binds a Program to its nn.Module (parameter container) and, if trainable, a FlatGrads buffer."""
 
-    def __init__(self, module, prog, trainable):
+    def __init__(self, module, prog, trainable, precision="f32"):
         self.module, self.prog = module, prog
+        self.precision = K.PRECISION[str(precision).lower()]     # conv operand precision (0 fp32, 1 bf16 operands)
         params = [p for p in module.parameters() if p.requires_grad]
         self.flat = FlatGrads(params) if (trainable and params) else None
         self.anchor = params[0] if (trainable and params) else None

@@ -112,6 +112,8 @@ typedef struct {
     int transposed;         /* 0: Conv2d ; 1: ConvTranspose2d with kernel == stride, pad 0 */
     int in_nchw;            /* 1: x is NCHW (only for the network inputs, Ci <= 4) */
     int out_nchw;           /* 1: y is NCHW (only for the network output, Co <= 4) */
+    int precision;          /* 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1: operands rounded to bf16 while staging,
+                             * fp32 accumulate (v_mfma_f32_32x32x16_bf16), tensors stay fp32 in HBM */
 } bh_conv_desc;
 
 /* tuning hook (benchmarks only): force the implicit-GEMM tile (BM,BN) for vectorised launches; (0,0) = automatic */

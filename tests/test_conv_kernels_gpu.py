@@ -266,3 +266,26 @@ def test_fused_tail_fwd_bwd(K, groups, N, H, Ci, Cm, Co, training):
     close(gg.cpu(), bn.weight.grad, 1e-4)
     close(gb.cpu(), bn.bias.grad, 1e-4)
     close(gb2.cpu(), b2t.grad, 1e-5)
+
+
+@pytest.mark.parametrize("N,Hi,Ci,Co,k,s,p", [(2, 32, 64, 64, 3, 1, 1), (2, 16, 128, 256, 3, 2, 1), (3, 8, 256, 256, 3, 1, 1),
+                                              (2, 16, 256, 128, 1, 1, 0)])
+def test_bf16_operand_mode(K, N, Hi, Ci, Co, k, s, p):
+    """precision=1: operands rounded to bf16 while staging, fp32 accumulate (BASELINE.json configs[3]).  Tolerance =
+    bf16 round-off (2^-9 per operand) of a K-term dot product against the float64 result: 1e-2 normalised."""
+    x = rnd((N, Ci, Hi, Hi), 50)
+    w = (rnd((Co, Ci, k, k), 51) / np.sqrt(Ci * k * k)).astype(np.float32)
+    d = K.conv_desc(N, Hi, Hi, Ci, Co, k, s, p, precision=1)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    ref = F.conv2d(xt, wt, None, stride=s, padding=p)
+    xg = torch.tensor(x).permute(0, 2, 3, 1).contiguous().cuda()
+    wg = torch.tensor(w).permute(0, 2, 3, 1).contiguous().cuda()
+    close(K.conv_fwd(xg, wg, None, d).cpu().permute(0, 3, 1, 2), ref.detach(), 1e-2)
+    gy = rnd(tuple(ref.shape), 52)
+    ref.backward(torch.tensor(gy, dtype=torch.float64))
+    gyg = torch.tensor(gy).permute(0, 2, 3, 1).contiguous().cuda()
+    close(K.conv_dgrad(gyg, wg, d).cpu().permute(0, 3, 1, 2), xt.grad, 1e-2)
+    gw = torch.zeros_like(wg)
+    K.conv_wgrad(xg, gyg, gw, None, d)
+    close(gw.cpu().permute(0, 3, 1, 2), wt.grad, 1e-2)

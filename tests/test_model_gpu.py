@@ -208,3 +208,26 @@ def test_detone_step_vs_golden(golden):
         gn = params[name].grad.double().norm().item()
         ref, spread = g64["gradnorm/" + name], abs(g64["gradnorm/" + name] - g32["gradnorm/" + name])
         assert abs(gn - ref) <= max(5 * spread, 2e-3 * ref), (name, gn, ref, spread)
+
+
+def test_zeng_bf16_operand_mode_first_step(golden):
+    """Mixed-precision conv mode (bf16 MFMA operands, fp32 accumulate and storage): first-step loss and MACE stay
+    close to the float64 reference; tolerance = bf16 operand rounding through 59 conv layers (stated, not 1e-4)."""
+    from bihome_amd.step import build_model, mace
+    cfg = configs.get("zeng-bihome")
+    cfg["MODEL"]["BACKBONE"]["PRECISION"] = "bf16"
+    cfg["MODEL"]["HEAD"]["PRECISION"] = "bf16"
+    model = build_model(cfg)
+    load_synthetic(model[0], 0)
+    load_synthetic(model[1].auxiliary_resnet, 0)
+    g64 = golden("zeng_b8_f64")
+    g32 = golden("zeng_b8_f32")
+    d = synth.make_pairs(8, seed=42)
+    model.train()
+    data = {k: cuda(d[k]) for k in ("patch_1", "patch_2", "delta")}
+    data["choice_12"], data["choice_21"] = cuda(g32["choice_12"][0], torch.int64), cuda(g32["choice_21"][0], torch.int64)
+    loss, dgt, dh = model(data)
+    loss.backward()
+    assert abs(loss.item() - g64["loss"][0]) <= 0.1 * abs(g64["loss"][0]), (loss.item(), g64["loss"][0])
+    assert abs(mace(dgt, dh) - g64["mace"][0]) < 0.1
+    assert all(torch.isfinite(p.grad).all() for p in model[0].parameters())
