@@ -54,5 +54,10 @@ DETONE_BIHOME = {
 
 
 def get(name):
-    cfg = {"zeng-bihome": ZENG_BIHOME, "detone-bihome": DETONE_BIHOME}[name]
-    return copy.deepcopy(cfg)
+    """'zeng-bihome' / 'detone-bihome' = config/s-coco/*; the '-pds' variants = config/pds-coco/* (the two trees differ
+    only in HomographyNetPrep's photometric max_delta, 0 vs 32, and the log dir)."""
+    base = name[:-4] if name.endswith("-pds") else name
+    cfg = copy.deepcopy({"zeng-bihome": ZENG_BIHOME, "detone-bihome": DETONE_BIHOME}[base])
+    if name.endswith("-pds"):
+        cfg["DATA"]["PHOTOMETRIC_MAX_DELTA"] = 32
+    return cfg

@@ -35,6 +35,7 @@ struct GemmArgs {
     int b_kcontig;         // 1: sBc == 1, 0: sBn == 1
     int epi;               // 0: NHWC [M][Nn]; 1: ConvTranspose scatter; 2: NCHW
     int accumulate;        // Out += result
+    int prio;              // experiment: s_setprio(1) around the MFMA block
     int bf16;              // operands rounded to bf16 (fp32 accumulate) where the vectorised path applies
     int ek, eC;            // scatter: kernel (== stride) and real channel count (Nn = ek*ek*eC)
 };
@@ -329,7 +330,8 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
             }
-        } else
+        } else {
+        if (a.prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             const int k = 2 * kk + kh2;
@@ -343,6 +345,8 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (a.prio) __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
     }
@@ -392,10 +396,11 @@ static int launch(const GemmArgs& a, hipStream_t s) {
 
 // Tile choice: the largest tile that still gives the 256 CUs about two workgroups each; the small-spatial
 // layers (8x8x256ch, 16x16x128ch at 2B = 128) otherwise launch only 128-256 workgroups.
-static int g_force_bm = 0, g_force_bn = 0;     // tuning hook (bh_debug_force_tile), 0 = automatic
+static int g_force_bm = 0, g_force_bn = 0, g_prio = 0;     // tuning hook (bh_debug_force_tile), 0 = automatic
 
 static int dispatch(const GemmArgs& a_in, hipStream_t s) {
     GemmArgs a = a_in;
+    a.prio = g_prio;
     a.sshift = -1;
     for (int b = 0; b < 8; ++b)
         if (a.stride == (1 << b)) a.sshift = b;
@@ -525,7 +530,10 @@ static int check_desc(const bh_conv_desc* d) {
 
 extern "C" {
 
-int bh_debug_force_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn; return BH_OK; }
+int bh_debug_force_tile(int bm, int bn) {
+    if (bm == -1) { g_prio = bn; return BH_OK; }      // (-1, x): toggle the s_setprio experiment
+    g_force_bm = bm; g_force_bn = bn; return BH_OK;
+}
 
 int bh_conv_fwd(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, void* stream) {
     int rc = check_desc(d);

@@ -231,3 +231,58 @@ def test_zeng_bf16_operand_mode_first_step(golden):
     assert abs(loss.item() - g64["loss"][0]) <= 0.1 * abs(g64["loss"][0]), (loss.item(), g64["loss"][0])
     assert abs(mace(dgt, dh) - g64["mace"][0]) < 0.1
     assert all(torch.isfinite(p.grad).all() for p in model[0].parameters())
+
+
+def test_checkpoint_compatibility_and_multi_hypothesis_eval(zeng, golden):
+    """SURVEY 8(f2,f3): a state dict in the reference's layout (plain OIHW tensors, keys as upstream: here produced
+    by the oracle modules, whose keys equal the reference's) loads into the drop-in modules although their conv
+    weights live in channels_last memory; and predict_homography with RANSAC_HYPOTHESIS_NO=4 selects the same
+    hypothesis index (bit-exact) and delta as the reference run recorded in the golden file."""
+    import io
+    from bihome_amd.step import build_model
+    cfg, model = zeng
+    bb, head = O.build(cfg)
+    load_synthetic(bb, 3)                      # a different seed than the fixture's model
+    load_synthetic(head.auxiliary_resnet, 3)
+    buf = io.BytesIO()
+    torch.save({"model": torch.nn.Sequential(bb, head).state_dict()}, buf)        # CheckPointer.save layout (checkpoint.py:31-53)
+    buf.seek(0)
+    sd = torch.load(buf, map_location="cpu")["model"]
+    model2 = build_model(cfg)
+    missing = model2.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    for p in model2[0].parameters():
+        if p.dim() == 4:
+            assert p.permute(0, 2, 3, 1).is_contiguous()          # still kernel layout after loading
+    d = synth.make_pairs(2, seed=13)
+    bb.double().train()
+    ref = bb({k: torch.tensor(d[k], dtype=torch.float64) for k in ("patch_1", "patch_2")})["pf_hat_12"]
+    model2.train()
+    got = model2[0]({k: cuda(d[k]) for k in ("patch_1", "patch_2")})["pf_hat_12"]
+    assert relerr(got.detach().cpu(), ref.detach()) < 1e-4
+    rt = model2.state_dict()
+    assert set(rt.keys()) == set(sd.keys()) and all(rt[k].shape == sd[k].shape for k in sd)
+    # multi-hypothesis eval path
+    g = golden("dsac_n4_f32")
+    cfg4 = configs.get("zeng-bihome")
+    cfg4["MODEL"]["HEAD"].update(RANSAC_HYPOTHESIS_NO=4, POINTS_PER_HYPOTHESIS=16)
+    head4 = build_model(cfg4)[1].eval()
+    dd = synth.make_head_inputs(8, 11, noise=2.0)
+    with torch.no_grad():
+        dh, _ = head4.predict_homography({"pf_hat_12": cuda(dd["pf_hat_12"]), "choice": cuda(g["choice"], torch.int64)})
+    assert np.array_equal(head4.last["best"].cpu().numpy(), g["best"])
+    np.testing.assert_allclose(dh.cpu().numpy(), g["delta_hat"], atol=5e-2)
+
+
+def test_pds_config_trains():
+    """pds-coco variant (photometric distortion of both images): one step runs and gives a finite loss/MACE."""
+    from bihome_amd.step import build_model, build_optimizer, mace, train_step
+    cfg = configs.get("zeng-bihome-pds")
+    assert cfg["DATA"]["PHOTOMETRIC_MAX_DELTA"] == 32
+    model = build_model(cfg)
+    load_synthetic(model[0], 0)
+    load_synthetic(model[1].auxiliary_resnet, 0)
+    opt, sched = build_optimizer(model, cfg["SOLVER"])
+    d = synth.make_pairs(4, seed=8, photometric_max_delta=32)
+    loss, dgt, dh = train_step(model, {k: cuda(d[k]) for k in ("patch_1", "patch_2", "delta")}, opt, sched)
+    assert np.isfinite(loss.item()) and np.isfinite(mace(dgt, dh))
