@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--config", default="zeng-bihome")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
                     help="conv operand precision; the headline config (BASELINE.json configs[1]) is f32")
+    ap.add_argument("--gpu-datagen", action="store_true",
+                    help="draw a fresh batch every step with the device-side pair generator (bh_synth_pairs) inside the "
+                         "timed region, instead of reusing one resident batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -167,12 +170,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    gen = None
+    if args.gpu_datagen:
+        from bihome_amd.synth_gpu import GpuPairGenerator
+        gen = GpuPairGenerator(n_images=16, seed=42 + rank, photometric_max_delta=cfg["DATA"]["PHOTOMETRIC_MAX_DELTA"])
+
+    def batch():
+        return gen.next(B) if gen is not None else dict(data)
+
     for _ in range(args.warmup):
-        loss, dgt, dh = train_step(model, dict(data), opt, sched, reducer=reducer)
+        loss, dgt, dh = train_step(model, batch(), opt, sched, reducer=reducer)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, dgt, dh = train_step(model, dict(data), opt, sched, reducer=reducer)
+        loss, dgt, dh = train_step(model, batch(), opt, sched, reducer=reducer)
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -196,7 +207,8 @@ def main():
             "metric": "training image-pairs/s (128x128 patch, bs=%d per GPU, full step: fwd+bwd+Adam)" % B,
             "value": value, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
-            "data": "synthetic (seeded COCO-style texture pairs, random-init weights)",
+            "data": "synthetic (seeded COCO-style texture pairs, random-init weights%s)" % (
+                "; fresh batch per step from the device-side generator" if args.gpu_datagen else "; one resident batch"),
             "config": {"workload": "BASELINE.json configs[1]: s-coco Zeng (Rethinking/ResNet34 blocks) backbone + biHomE "
                                    "head, %d pairs/GPU, 128x128 grayscale, %s MFMA conv + HIP warp/DLT/triplet kernels" % (B, args.precision),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "optimizer": "Adam lr 1e-3"},

@@ -163,6 +163,16 @@ int bh_tail_bwd(const float* gout, const float* x, const float* w1, const float*
                 float* scratch, int groups, int rows, int hw, int Ci, int Cm, int Co, float eps, int use_running,
                 void* stream);
 
+/* Synthetic pair generator (next-row f1): HomographyNetPrep + DictToGrayscale + DictStandardize (+ brightness/contrast
+ * of PhotometricDistortSimple) of src/data/transforms.py:296-330,344-378,441-725 for B samples in one launch.
+ * images[n_images,3,Hs,Ws] float RGB 0..255 (resident); img_idx[B]; origin[B,2] = top-left corner (x0,y0) of the
+ * patch; Hpatch[B,9] double = bh_h4pt_fwd(delta) in patch coordinates; photo[B,4] = {brightness1, contrast1,
+ * brightness2, contrast2} or NULL.  patch1 = crop, patch2(x) = image(origin + Hpatch.x) bilinear; both
+ * standardised ((g/255 - mean)/std), [B,1,P,P]. */
+int bh_synth_pairs(const float* images, const int* img_idx, const float* origin, const double* Hpatch, const float* photo,
+                   int B, int n_images, int Hs, int Ws, int P, float mean, float std, float* patch1, float* patch2,
+                   void* stream);
+
 /* MaxPool2d(3, 2, 1) NHWC. argmax[N,Ho,Wo,C] (uint8, NULL ok in inference): window position 0..8 of the first
  * maximum (ATen's tie rule); the adjoint gathers through it (no atomics, no recomputation). */
 int bh_maxpool3s2_fwd(const float* x, float* y, unsigned char* argmax, int N, int Hi, int Wi, int C, void* stream);

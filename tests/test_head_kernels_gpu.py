@@ -187,3 +187,29 @@ def test_head_chain_against_golden(K, golden):
         out, cov = K.warp_fwd(dev(d[src]), H64, 4)
         np.testing.assert_allclose(out.cpu().numpy()[..., ::4, ::4], g["warp_sub_" + tag], atol=2e-3)
         np.testing.assert_allclose(cov.cpu().numpy(), g["mask_pooled_" + tag], atol=2e-4)
+
+
+def test_gpu_pair_generator_matches_host_generator(K):
+    """bh_synth_pairs against the numpy generator (bihome_amd/synth.py) on the same image, position and delta."""
+    from bihome_amd.synth_gpu import GpuPairGenerator
+    gen = GpuPairGenerator(n_images=3, seed=5)
+    idx, origin, delta, _ = gen.draw(6)
+    out = gen.make(idx, origin, delta)
+    imgs = gen.images.cpu().numpy()
+    c = np.array([[0, 0], [128, 0], [128, 128], [0, 128]], np.float64)
+    for b in range(6):
+        img = imgs[int(idx[b])].transpose(1, 2, 0).astype(np.float64)
+        x0, y0 = int(origin[b, 0]), int(origin[b, 1])
+        H = synth.four_point_homography(c, c + delta[b].cpu().numpy().astype(np.float64))
+        T = np.array([[1, 0, x0], [0, 1, y0], [0, 0, 1.0]])
+        crop2 = synth.warp_bilinear(img, T @ H, 128, 128)
+        crop1 = img[y0:y0 + 128, x0:x0 + 128]
+        for got, crop in ((out["patch_1"][b, 0], crop1), (out["patch_2"][b, 0], crop2)):
+            g = crop[..., 0] * 0.299 + crop[..., 1] * 0.587 + crop[..., 2] * 0.114
+            ref = (g / 255 - 0.443) / 0.129
+            np.testing.assert_allclose(got.cpu().numpy(), ref, atol=2e-3)
+    assert delta.min() >= -32 and delta.max() <= 31 and origin[:, 0].min() >= 32
+    # photometric variant runs and changes the statistics
+    gen2 = GpuPairGenerator(n_images=2, seed=6, photometric_max_delta=32)
+    o2 = gen2.next(8)
+    assert torch.isfinite(o2["patch_1"]).all() and torch.isfinite(o2["patch_2"]).all()
