@@ -76,8 +76,13 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
     // the ds_read_b128 fragment reads bank-conflict free and the float4 -> bf16x4 staging writes need no transpose.
     static_assert(!BF16 || (VEC && BK == 32), "bf16 operand mode needs the vectorised loader and BK = 32");
     constexpr int LDH = BK + 8;
-    constexpr int A_FLOATS = BF16 ? (BM * LDH / 2) : BK * LDA;
-    constexpr int B_FLOATS = BF16 ? (BN * LDH / 2) : BK * LDB_N;
+    // C4 layout (vectorised fp32 path): tiles are stored as float4 k-chunks, [BK/4][rows + 1] x float4.  One
+    // ds_write_b128 stages a loaded float4 (the +1 row of padding spreads the 8 chunk-lanes of a row over all 32
+    // banks), one ds_read_b128 feeds FOUR MFMAs (the two half-waves take chunks 2c and 2c+1, so MFMA step j
+    // multiplies k = 8c + j and 8c + 4 + j; any pairing of k is valid for a sum over k).
+    constexpr bool C4 = VEC && !BF16;
+    constexpr int A_FLOATS = BF16 ? (BM * LDH / 2) : (C4 ? CH * (BM + 1) * 4 : BK * LDA);
+    constexpr int B_FLOATS = BF16 ? (BN * LDH / 2) : (C4 ? CH * (BN + 1) * 4 : BK * LDB_N);
     __shared__ __attribute__((aligned(16))) float As[A_FLOATS];
     __shared__ __attribute__((aligned(16))) float Bs[B_FLOATS];
     __bf16* Ah = reinterpret_cast<__bf16*>(As);
@@ -108,7 +113,12 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
     const int bn_chunk = tid % NCH, bn_row0 = tid / NCH;
     constexpr int BROWS_N = 256 / NCH;
     constexpr int BIT_N = (BK + BROWS_N - 1) / BROWS_N;
-    constexpr int BIT = (BIT_K > BIT_N) ? BIT_K : BIT_N;
+    // C4 layout, N-contiguous B: lanes run along k (conflict-free scalar LDS writes), 256/BK n-chunks per pass
+    constexpr int C4_CPP = 256 / BK;
+    constexpr int BIT_N4 = (NCH + C4_CPP - 1) / C4_CPP;
+    const int b4_k = tid % BK, b4_c0 = tid / BK;
+    constexpr int BIT01 = (BIT_K > BIT_N) ? BIT_K : BIT_N;
+    constexpr int BIT = (BIT01 > BIT_N4) ? BIT01 : BIT_N4;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -179,6 +189,23 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
                 for (int i = 0; i < BIT_K; ++i) {
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (b_rowptr[i] && cok) v = *reinterpret_cast<const float4*>(b_rowptr[i] + toff);
+                    rb[i] = v;
+                }
+            } else if constexpr (C4) {
+                const int c2 = c0 + b4_k;
+#pragma unroll
+                for (int i = 0; i < BIT_N4; ++i) {
+                    const int chn = b4_c0 + i * C4_CPP, n = n0 + chn * 4;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (chn < NCH && c2 < a.Kc) {
+                        const float* p = a.Bw + t * a.sBt + (long long)c2 * a.sBc + n;
+                        if (n + 3 < a.Nn) v = *reinterpret_cast<const float4*>(p);
+                        else {
+                            if (n < a.Nn) v.x = p[0];
+                            if (n + 1 < a.Nn) v.y = p[1];
+                            if (n + 2 < a.Nn) v.z = p[2];
+                        }
+                    }
                     rb[i] = v;
                 }
             } else {
@@ -278,6 +305,30 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
             }
             return;
         }
+        if constexpr (C4) {
+#pragma unroll
+            for (int i = 0; i < AIT; ++i) {
+                const int row = a_row0 + i * AROWS;
+                *reinterpret_cast<float4*>(&As[(a_chunk * (BM + 1) + row) * 4]) = ra[i];
+            }
+            if (a.b_kcontig) {
+#pragma unroll
+                for (int i = 0; i < BIT_K; ++i) {
+                    const int row = bk_row0 + i * AROWS;
+                    if (row < BN) *reinterpret_cast<float4*>(&Bs[(bk_chunk * (BN + 1) + row) * 4]) = rb[i];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < BIT_N4; ++i) {
+                    const int chn = b4_c0 + i * C4_CPP;
+                    if (chn < NCH) {
+                        float* q = &Bs[((b4_k >> 2) * (BN + 1) + chn * 4) * 4 + (b4_k & 3)];
+                        q[0] = rb[i].x; q[4] = rb[i].y; q[8] = rb[i].z; q[12] = rb[i].w;
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < AIT; ++i) {
             const int row = a_row0 + i * AROWS;
@@ -311,9 +362,9 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
 
     load_tile(0);
     for (int kt = 0; kt < ktiles; ++kt) {
-        store_tile();
+        if (!(a.prio & 4) || kt == 0) store_tile();           // (ablation bits, bh_debug_force_tile(-1, x): 2 = no reloads, 4 = no restaging)
         __syncthreads();
-        if (kt + 1 < ktiles) load_tile(kt + 1);
+        if (kt + 1 < ktiles && !(a.prio & 2)) load_tile(kt + 1);
         if constexpr (BF16) {
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
@@ -330,23 +381,52 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
             }
-        } else {
-        if (a.prio) __builtin_amdgcn_s_setprio(1);
+        } else if constexpr (C4) {
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            const int k = 2 * kk + kh2;
-            float av[TM], bv[TN];
+            for (int c2 = 0; c2 < CH / 2; ++c2) {
+                const int ch = 2 * c2 + kh2;
+                float4 af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = As[k * LDA + (wm * TM + i) * 32 + l31];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = Bs[k * ldb + (wn * TN + j) * 32 + l31];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
+                    af[i] = *reinterpret_cast<const float4*>(&As[(ch * (BM + 1) + (wm * TM + i) * 32 + l31) * 4]);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    bf[j] = *reinterpret_cast<const float4*>(&Bs[(ch * (BN + 1) + (wn * TN + j) * 32 + l31) * 4]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else {
+        if (a.prio & 1) __builtin_amdgcn_s_setprio(1);
+        // fragments of KG k-pairs are read from LDS up front, then their MFMAs issue back to back (the compiler
+        // otherwise interleaves each ds_read with a full lgkmcnt(0) wait right in front of its MFMA)
+        constexpr int KG = (TM * TN >= 4) ? 4 : 8;
+#pragma unroll
+        for (int kg = 0; kg < BK / 2; kg += KG) {
+            float av[KG][TM], bv[KG][TN];
+#pragma unroll
+            for (int q = 0; q < KG; ++q) {
+                const int k = 2 * (kg + q) + kh2;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) av[q][i] = As[k * LDA + (wm * TM + i) * 32 + l31];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bv[q][j] = Bs[k * ldb + (wn * TN + j) * 32 + l31];
+            }
+#pragma unroll
+            for (int q = 0; q < KG; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][i], bv[q][j], acc[i][j], 0, 0, 0);
         }
-        if (a.prio) __builtin_amdgcn_s_setprio(0);
+        if (a.prio & 1) __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
     }
@@ -441,13 +521,17 @@ static int dispatch(const GemmArgs& a_in, hipStream_t s) {
     // at the fp32 MFMA rate
     const bool k16 = (a.Kc % 32) != 0 && a.Kc <= 16;
     const long long mt64 = (a.M + 63) / 64;
+    const bool k64 = (a.Kc % 64) == 0;
     if (a.Nn > 64) {
         if (k16) return launch<128, 128, 16, true>(a, s);
         const long long nt = (a.Nn + 127) / 128;
-        if (mt64 * nt >= 512) return launch<64, 128, 32, true>(a, s);
-        return launch<64, 64, 32, true>(a, s);
+        if (a.Nn >= 256 && mt64 * nt >= 512) return launch<64, 128, 32, true>(a, s);
+        return k64 ? launch<64, 64, 64, true>(a, s) : launch<64, 64, 32, true>(a, s);
     }
-    if (a.Nn > 32) return k16 ? launch<128, 64, 16, true>(a, s) : launch<64, 64, 32, true>(a, s);
+    if (a.Nn > 32) {
+        if (k16) return launch<128, 64, 16, true>(a, s);
+        return k64 ? launch<64, 64, 64, true>(a, s) : launch<64, 64, 32, true>(a, s);
+    }
     return k16 ? launch<128, 32, 16, true>(a, s) : launch<128, 32, 32, true>(a, s);
 }
 

@@ -52,13 +52,18 @@ def gemm_variant(M, Nn, Kc, vec):
         return fmt % (128, 128 if Nn > 64 else (64 if Nn > 32 else 32), 32, "false")
     k16 = (Kc % 32) != 0 and Kc <= 16
     mt64 = (M + 63) // 64
+    k64 = Kc % 64 == 0
     if Nn > 64:
         if k16:
             return fmt % (128, 128, 16, "true")
         nt = (Nn + 127) // 128
-        return fmt % ((64, 128, 32, "true") if mt64 * nt >= 512 else (64, 64, 32, "true"))
+        if Nn >= 256 and mt64 * nt >= 512:
+            return fmt % (64, 128, 32, "true")
+        return fmt % (64, 64, 64 if k64 else 32, "true")
     if Nn > 32:
-        return fmt % ((128, 64, 16, "true") if k16 else (64, 64, 32, "true"))
+        if k16:
+            return fmt % (128, 64, 16, "true")
+        return fmt % (64, 64, 64 if k64 else 32, "true")
     return fmt % (128, 32, 16 if k16 else 32, "true")
 
 

@@ -15,8 +15,8 @@ for (N,H,Ci,Co,k,s,p) in shapes:
     d=K.conv_desc(N,H,H,Ci,Co,k,s,p)
     x=torch.randn(N,H,H,Ci,device='cuda'); w=torch.randn(Co,k,k,Ci,device='cuda')*0.05
     fl=K.conv_flops(d); out=[]
-    for rep in range(3):
-        for pr in (0,1):
+    for rep in range(2):
+        for pr in (0,2,6):
             lib.bh_debug_force_tile(-1,pr)
             out.append('p%d %.0f'%(pr, fl/bench(lambda: K.conv_fwd(x,w,None,d))/1e9))
     print((N,H,Ci,Co), ' '.join(out), flush=True)
