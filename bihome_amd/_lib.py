@@ -37,7 +37,7 @@ SIGNATURES = {
     "bh_conv_wgrad": [P, P, P, P, POINTER(BhConvDesc), P],
     "bh_bn_stats_doubles": [c_int, c_int],
     "bh_bn_fwd": [P] * 8 + [c_int, c_int, c_int, c_float, c_float, c_int, c_int, P],
-    "bh_bn_bwd": [P] * 10 + [c_int, c_int, c_int, c_float, c_int, c_int, P, P, P],
+    "bh_bn_bwd": [P] * 11 + [c_int, c_int, c_int, c_float, c_int, c_int, P, P, P],
     "bh_tail_ws_doubles": [c_int, c_int, c_int],
     "bh_tail_scratch_floats": [c_int, c_int, c_int],
     "bh_tail_fwd": [P] * 11 + [c_int] * 6 + [c_float, c_float, c_int, P],

@@ -135,7 +135,8 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__
 
 // backward reduce: grid (nchunks, groups)
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restrict__ gy, const float* __restrict__ y,
-                                                            const float* __restrict__ x, const double* __restrict__ stats,
+                                                            const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const double* __restrict__ stats,
                                                             const float* __restrict__ rmean, const float* __restrict__ rvar,
                                                             BnGeom g, float eps, int flags, int use_running,
                                                             double* __restrict__ part) {
@@ -143,26 +144,26 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restr
     const int cq = threadIdx.x % g.LPR, r0 = threadIdx.x / g.LPR;
     const int grp = blockIdx.y, chunk = blockIdx.x;
     const int rbeg = chunk * g.rows_per_chunk, rend = min(g.rows, rbeg + g.rows_per_chunk);
-    float mean[4], invstd[4];
+    float mean[4], invstd[4], sc[4], sh[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float sc, sh;
-        bn_coeffs(stats, nullptr, nullptr, rmean, rvar, use_running, grp, g.C, cq * 4 + i, eps, mean[i], invstd[i], sc, sh);
-    }
+    for (int i = 0; i < 4; ++i)
+        bn_coeffs(stats, gamma, beta, rmean, rvar, use_running, grp, g.C, cq * 4 + i, eps, mean[i], invstd[i], sc[i], sh[i]);
     const size_t gbase = ((size_t)grp * g.rows) * g.C + cq * 4;
-    const bool relu = flags & 1;
+    const bool relu = flags & 1, mask_from_x = flags & 4;     // bit 2: no residual -> y = relu(x*sc+sh), recompute the mask
     double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int r = rbeg + r0; r < rend; r += g.RPP) {
         const size_t off = gbase + (size_t)r * g.C;
         float4 d = *reinterpret_cast<const float4*>(gy + off);
+        float4 a = *reinterpret_cast<const float4*>(x + off);
         if (relu) {
-            float4 o = *reinterpret_cast<const float4*>(y + off);
+            float4 o;
+            if (mask_from_x) o = make_float4(a.x * sc[0] + sh[0], a.y * sc[1] + sh[1], a.z * sc[2] + sh[2], a.w * sc[3] + sh[3]);
+            else o = *reinterpret_cast<const float4*>(y + off);
             if (!(o.x > 0.f)) d.x = 0.f;
             if (!(o.y > 0.f)) d.y = 0.f;
             if (!(o.z > 0.f)) d.z = 0.f;
             if (!(o.w > 0.f)) d.w = 0.f;
         }
-        float4 a = *reinterpret_cast<const float4*>(x + off);
         v[0] += d.x; v[1] += d.y; v[2] += d.z; v[3] += d.w;
         v[4] += (double)(d.x * ((a.x - mean[0]) * invstd[0]));
         v[5] += (double)(d.y * ((a.y - mean[1]) * invstd[1]));
@@ -203,19 +204,19 @@ __global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const double* __res
 // grid (nblk, groups)
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ gy, const float* __restrict__ y,
                                                            const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
                                                            const double* __restrict__ stats, const float* __restrict__ rmean,
                                                            const float* __restrict__ rvar, const double* __restrict__ sums,
                                                            float* __restrict__ gx, float* __restrict__ gres, BnGeom g,
                                                            float eps, int flags, int use_running) {
     const int cq = threadIdx.x % g.LPR, r0 = threadIdx.x / g.LPR;
     const int grp = blockIdx.y;
-    float mean[4], invstd[4], sc[4], k1[4], k2[4];
+    float mean[4], invstd[4], sc[4], sh[4], k1[4], k2[4];
     const float invn = 1.0f / (float)g.rows;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        float sh;
         const int c = cq * 4 + i;
-        bn_coeffs(stats, gamma, nullptr, rmean, rvar, use_running, grp, g.C, c, eps, mean[i], invstd[i], sc[i], sh);
+        bn_coeffs(stats, gamma, beta, rmean, rvar, use_running, grp, g.C, c, eps, mean[i], invstd[i], sc[i], sh[i]);
         if (use_running) { k1[i] = 0.f; k2[i] = 0.f; }
         else {
             k1[i] = (float)(sums[((size_t)grp * g.C + c) * 2]) * invn;
@@ -223,19 +224,21 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
         }
     }
     const size_t gbase = ((size_t)grp * g.rows) * g.C + cq * 4;
-    const bool relu = flags & 1;
+    const bool relu = flags & 1, mask_from_x = flags & 4;
     for (int r = blockIdx.x * g.RPP + r0; r < g.rows; r += gridDim.x * g.RPP) {
         const size_t off = gbase + (size_t)r * g.C;
         float4 d = *reinterpret_cast<const float4*>(gy + off);
+        float4 a = *reinterpret_cast<const float4*>(x + off);
         if (relu) {
-            float4 o = *reinterpret_cast<const float4*>(y + off);
+            float4 o;
+            if (mask_from_x) o = make_float4(a.x * sc[0] + sh[0], a.y * sc[1] + sh[1], a.z * sc[2] + sh[2], a.w * sc[3] + sh[3]);
+            else o = *reinterpret_cast<const float4*>(y + off);
             if (!(o.x > 0.f)) d.x = 0.f;
             if (!(o.y > 0.f)) d.y = 0.f;
             if (!(o.z > 0.f)) d.z = 0.f;
             if (!(o.w > 0.f)) d.w = 0.f;
         }
         if (gres) *reinterpret_cast<float4*>(gres + off) = d;
-        float4 a = *reinterpret_cast<const float4*>(x + off);
         float4 o;
         o.x = sc[0] * (d.x - k1[0] - (a.x - mean[0]) * invstd[0] * k2[0]);
         o.y = sc[1] * (d.y - k1[1] - (a.y - mean[1]) * invstd[1] * k2[1]);
@@ -279,22 +282,23 @@ int bh_bn_fwd(const float* x, const float* gamma, const float* beta, float* runn
     return BH_OK;
 }
 
-int bh_bn_bwd(const float* gy, const float* y, const float* x, const float* gamma, const double* stats, float* gx,
+int bh_bn_bwd(const float* gy, const float* y, const float* x, const float* gamma, const float* beta, const double* stats, float* gx,
               float* gres, float* ggamma, float* gbeta, double* scratch, int groups, int rows, int C, float eps, int flags,
               int use_running, const float* running_mean, const float* running_var, void* stream) {
     BnGeom g;
-    if (!gy || !x || !gx || !stats || !scratch || ((flags & 1) && !y)) return BH_E_BADARG;
+    if (!gy || !x || !gx || !stats || !scratch || ((flags & 1) && !(flags & 4) && !y)) return BH_E_BADARG;
+    if ((flags & 4) && (flags & 2)) return BH_E_BADARG;        // the mask can only be recomputed without a residual input
     if (!bn_geom(groups, rows, C, g)) return BH_E_UNSUPPORTED;
     hipStream_t s = bh_stream(stream);
     double* part = scratch + (size_t)groups * C * 2;
     if (!use_running || ggamma || gbeta) {
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(g.nchunks, groups), dim3(256), 0, s, gy, y, x, stats, running_mean,
-                           running_var, g, eps, flags, use_running, part);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(g.nchunks, groups), dim3(256), 0, s, gy, y, x, gamma, beta, stats,
+                           running_mean, running_var, g, eps, flags, use_running, part);
         BH_LAUNCH_CHECK();
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, part, g, ggamma, gbeta, scratch);
         BH_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(apply_blocks(g), groups), dim3(256), 0, s, gy, y, x, gamma, stats,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(apply_blocks(g), groups), dim3(256), 0, s, gy, y, x, gamma, beta, stats,
                        running_mean, running_var, scratch, gx, gres, g, eps, flags, use_running);
     BH_LAUNCH_CHECK();
     return BH_OK;

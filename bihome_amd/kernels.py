@@ -299,17 +299,20 @@ def bn_fwd(x, gamma, beta, rmean, rvar, res, groups, eps, momentum, relu, traini
     return y, stats
 
 
-def bn_bwd(gy, y, x, gamma, stats, rmean, rvar, groups, eps, relu, training, want_gres, ggamma=None, gbeta=None):
+def bn_bwd(gy, y, x, gamma, stats, rmean, rvar, groups, eps, relu, training, want_gres, ggamma=None, gbeta=None, beta=None,
+           had_res=None):
     _chk(gy); _chk(x)
     C = x.shape[-1]
     rows = x.numel() // C // groups
     gx = torch.empty_like(x)
     gres = torch.empty_like(x) if want_gres else None
     scratch = bn_stats_buffer(groups, C, x.device)
-    flags = (1 if relu else 0) | (2 if want_gres else 0)
-    nb = 4.0 * x.numel() * (2 * (2 + (1 if relu else 0)) + 1 + (1 if want_gres else 0))
+    had_res = want_gres if had_res is None else had_res
+    mask_from_x = relu and not had_res          # y = relu(x*scale+shift): the mask is recomputed, y is not read
+    flags = (1 if relu else 0) | (2 if want_gres else 0) | (4 if mask_from_x else 0)
+    nb = 4.0 * x.numel() * (2 * (2 + (1 if (relu and not mask_from_x) else 0)) + 1 + (1 if want_gres else 0))
     with _Timed("bn_bwd(3 kernels)" + (" g%d rows%d C%d" % (groups, rows, C) if TIMING_DETAIL else ""), 0.0, nb):
-        check(lib.bh_bn_bwd(_p(gy), _p(y), _p(x), _p(gamma), _p(stats), _p(gx), _p(gres), _p(ggamma), _p(gbeta),
+        check(lib.bh_bn_bwd(_p(gy), _p(y), _p(x), _p(gamma), _p(beta), _p(stats), _p(gx), _p(gres), _p(ggamma), _p(gbeta),
                             _p(scratch), groups, rows, C, float(eps), flags, 0 if training else 1, _p(rmean), _p(rvar),
                             _stream()), "bh_bn_bwd")
     return gx, gres

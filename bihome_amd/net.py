@@ -291,7 +291,8 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
             train_w = want_wgrad and m.weight is not None and m.weight.requires_grad
             gx, gres = K.bn_bwd(g, slots[op.dst], x, m.weight, ctx.stats[i], m.running_mean, m.running_var, ctx.groups,
                                 m.eps, op.relu, ctx.training, op.res is not None and ((op.res != 0) or want_input_grad),
-                                m.weight.grad if train_w else None, m.bias.grad if train_w else None)
+                                m.weight.grad if train_w else None, m.bias.grad if train_w else None, beta=m.bias,
+                                had_res=op.res is not None)
             if train_w and on_param_grad is not None:
                 on_param_grad(m.weight)
                 on_param_grad(m.bias)

@@ -139,8 +139,9 @@ int bh_bn_fwd(const float* x, const float* gamma, const float* beta, float* runn
               const float* res, float* y, double* stats, int groups, int rows, int C, float eps, float momentum,
               int flags, int use_running, void* stream);
 /* adjoint. gy: grad w.r.t. y; y: the forward output (for the relu mask); x: forward input.
- * -> gx (overwritten), gres (written when non-NULL: = masked gy), ggamma/gbeta += (NULL ok => frozen) */
-int bh_bn_bwd(const float* gy, const float* y, const float* x, const float* gamma, const double* stats,
+ * -> gx (overwritten), gres (written when non-NULL: = masked gy), ggamma/gbeta += (NULL ok => frozen).
+ * flags bit2 (only without residual): recompute the ReLU mask from x (y is not read, may be NULL). */
+int bh_bn_bwd(const float* gy, const float* y, const float* x, const float* gamma, const float* beta, const double* stats,
               float* gx, float* gres, float* ggamma, float* gbeta, double* scratch /*[groups,C,2]*/,
               int groups, int rows, int C, float eps, int flags, int use_running,
               const float* running_mean, const float* running_var, void* stream);

@@ -190,7 +190,7 @@ def test_batchnorm_fwd_bwd(K, groups, N, H, C, relu, res, training):
         gy[(np.abs(ref.detach().numpy()) < 1e-5) & (ref.detach().numpy() > 0)] = 0
     ref.backward(torch.tensor(gy, dtype=torch.float64))
     gg, gb = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
-    gx, gres = K.bn_bwd(nhwc(gy), y, nhwc(x), gm, st, rm, rv, groups, bn.eps, relu, training, res, gg, gb)
+    gx, gres = K.bn_bwd(nhwc(gy), y, nhwc(x), gm, st, rm, rv, groups, bn.eps, relu, training, res, gg, gb, beta=bt)
     close(gx.cpu().permute(0, 3, 1, 2), xt.grad, 5e-5)
     close(gg.cpu(), bn.weight.grad, 5e-5)
     close(gb.cpu(), bn.bias.grad, 5e-5)
