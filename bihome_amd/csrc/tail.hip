@@ -204,7 +204,10 @@ __global__ void __launch_bounds__(256) tail_bwd_reduce_kernel(const float* __res
                                                               float* __restrict__ part, TailGeom g, float eps, int use_running) {
     __shared__ __attribute__((aligned(16))) float xs[64 * CI];
     __shared__ float gs[64 * 4];
-    const int grp = blockIdx.y, chunk = blockIdx.x, c = threadIdx.x;
+    // block = nsub * Cm threads: thread (sub, c) accumulates channel c over every nsub-th pixel of the chunk (more
+    // resident waves than one thread per channel); each sub writes its own partial, the finalize sums them all
+    const int grp = blockIdx.y, chunk = blockIdx.x, c = threadIdx.x % g.Cm, sub = threadIdx.x / g.Cm;
+    const int nsub = blockDim.x / g.Cm;
     const int rbeg = chunk * g.rows_per_chunk, rend = min(g.rows, rbeg + g.rows_per_chunk);
     // this thread's channel constants in registers
     float wr[CI];
@@ -234,7 +237,7 @@ __global__ void __launch_bounds__(256) tail_bwd_reduce_kernel(const float* __res
             gs[e] = (o < g.Co) ? gout[(img * g.Co + o) * g.hw + pp] : 0.f;
         }
         __syncthreads();
-        for (int p = 0; p < np; ++p) {
+        for (int p = sub; p < np; p += nsub) {
             const float* xv = xs + p * CI;
             float y = bb;
 #pragma unroll
@@ -251,7 +254,7 @@ __global__ void __launch_bounds__(256) tail_bwd_reduce_kernel(const float* __res
             for (int k = 0; k < CI; ++k) qs[k] = fmaf(gbn, xv[k], qs[k]);
         }
     }
-    float* q = part + (((size_t)grp * g.nchunks + chunk) * g.Cm + c) * (6 + CI);
+    float* q = part + ((((size_t)grp * g.nchunks + chunk) * nsub + sub) * g.Cm + c) * (6 + CI);
     q[0] = q0; q[1] = q1; q[2] = qz[0]; q[3] = qz[1]; q[4] = qz[2]; q[5] = qz[3];
 #pragma unroll
     for (int k = 0; k < CI; ++k) q[6 + k] = qs[k];
@@ -260,7 +263,7 @@ __global__ void __launch_bounds__(256) tail_bwd_reduce_kernel(const float* __res
 // ---- backward finalize: one wave per channel (grid Cm, block 64) ----
 // coef[groups][Cm][4] = { A = gamma*invstd, kbeta = dbeta_g/n, kgamma = dgamma_g/n, unused }
 template <int CI>
-__global__ void __launch_bounds__(64) tail_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gout_sum,
+__global__ void __launch_bounds__(64) tail_bwd_finalize_kernel(const float* __restrict__ part, int nsub,
                                                                const float* __restrict__ w1, const float* __restrict__ b1,
                                                                const float* __restrict__ gamma, const double* __restrict__ ws,
                                                                const float* __restrict__ rmean, const float* __restrict__ rvar,
@@ -277,8 +280,8 @@ __global__ void __launch_bounds__(64) tail_bwd_finalize_kernel(const float* __re
     for (int grp = 0; grp < g.groups; ++grp) {
         double acc[6 + CI];
         for (int e = 0; e < 6 + CI; ++e) acc[e] = 0;
-        for (int k = lane; k < g.nchunks; k += 64) {
-            const float* q = part + (((size_t)grp * g.nchunks + k) * g.Cm + c) * (6 + CI);
+        for (int k = lane; k < g.nchunks * nsub; k += 64) {
+            const float* q = part + (((size_t)grp * g.nchunks * nsub + k) * g.Cm + c) * (6 + CI);
             for (int e = 0; e < 6 + CI; ++e) acc[e] += (double)q[e];
         }
         for (int e = 0; e < 6 + CI; ++e) acc[e] = wave_sum(acc[e]);
@@ -385,7 +388,7 @@ extern "C" {
 int bh_tail_ws_doubles(int groups, int Ci, int Cm) {
     return groups * Cm * 2 + groups * (Ci + Ci * Ci) * (1 + TAIL_CHUNKS);
 }
-int bh_tail_scratch_floats(int groups, int Ci, int Cm) { return groups * TAIL_CHUNKS * Cm * (6 + Ci) + groups * Cm * 4; }
+int bh_tail_scratch_floats(int groups, int Ci, int Cm) { return groups * TAIL_CHUNKS * 4 * Cm * (6 + Ci) + groups * Cm * 4; }
 
 int bh_tail_fwd(const float* x, const float* w1, const float* b1, const float* gamma, const float* beta, float* running_mean,
                 float* running_var, const float* w2, const float* b2, float* out, double* ws, int groups, int rows, int hw,
@@ -424,16 +427,17 @@ int bh_tail_bwd(const float* gout, const float* x, const float* w1, const float*
     if (!gout || !x || !w1 || !w2 || !ws || !scratch) return BH_E_BADARG;
     if (!tail_geom(groups, rows, hw, Ci, Cm, Co, g) || (Ci != 16 && Ci != 32 && Ci != 8)) return BH_E_UNSUPPORTED;
     hipStream_t s = bh_stream(stream);
+    const int nsub = 256 / Cm;                  // Cm in {64,128,256} -> 4, 2, 1 pixel sub-streams per block
     float* part = scratch;
-    float* coef = scratch + (size_t)groups * TAIL_CHUNKS * Cm * (6 + Ci);
+    float* coef = scratch + (size_t)groups * TAIL_CHUNKS * 4 * Cm * (6 + Ci);
     const size_t lds = sizeof(float) * (Cm * Ci + Cm * 8 + Cm + Cm * 4);
     dim3 grid(fwd_blocks(g), groups);
 #define TAIL_BWD(CI_)                                                                                                        \
     do {                                                                                                                     \
-        hipLaunchKernelGGL((tail_bwd_reduce_kernel<CI_>), dim3(g.nchunks, groups), dim3(Cm), 0, s, gout, x, w1, b1, gamma,  \
-                           beta, w2, ws, running_mean, running_var, part, g, eps, use_running);                              \
+        hipLaunchKernelGGL((tail_bwd_reduce_kernel<CI_>), dim3(g.nchunks, groups), dim3(Cm * nsub), 0, s, gout, x, w1, b1,  \
+                           gamma, beta, w2, ws, running_mean, running_var, part, g, eps, use_running);                       \
         BH_LAUNCH_CHECK();                                                                                                   \
-        hipLaunchKernelGGL((tail_bwd_finalize_kernel<CI_>), dim3(Cm), dim3(64), 0, s, part, nullptr, w1, b1, gamma, ws,      \
+        hipLaunchKernelGGL((tail_bwd_finalize_kernel<CI_>), dim3(Cm), dim3(64), 0, s, part, nsub, w1, b1, gamma, ws,         \
                            running_mean, running_var, g, eps, use_running, gw1, ggamma, gbeta, gw2, coef);                   \
         BH_LAUNCH_CHECK();                                                                                                   \
         if (gx) {                                                                                                            \
