@@ -277,6 +277,102 @@ __global__ void __launch_bounds__(256) wgrad_small_kernel(WgradArgs a) {
     }
 }
 
+// Small-channel, taps-fused variant (VEC path, Np <= 32 or Nq <= 32, T = NT taps known at compile time): a wave
+// owns a 32x32 (p, q) tile for ALL taps - NT accumulators - so the plain operand P (gy) is read from memory once
+// per pixel instead of once per tap, and the NT gathered Q tiles of one 32-pixel step hit the same cache lines.
+// grid: (ptiles*qtiles, T/NT, splitK); the four waves of a workgroup split its pixel range and never synchronise.
+template <int NT>
+__global__ void __launch_bounds__(256) wgrad_small_taps_kernel(WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[4][WBK * SLD];
+    __shared__ __attribute__((aligned(16))) float Bs[4][WBK * SLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qtiles = (a.Nq + 31) / 32;
+    const int p0 = (blockIdx.x / qtiles) * 32, q0 = (blockIdx.x % qtiles) * 32;
+    const int bbeg = blockIdx.z * a.rows_per_block;
+    const int bend = min(a.M, bbeg + a.rows_per_block);
+    const int rpw = (((bend - bbeg) + 3) / 4 + WBK - 1) / WBK * WBK;
+    const int mbeg = bbeg + wave * rpw, mend = min(bend, mbeg + rpw);
+    if (mbeg >= mend) return;
+    const int t0 = blockIdx.y * NT;                     // this workgroup's group of NT consecutive taps
+    float* as = As[wave];
+    float* bs = Bs[wave];
+    const int chunk = lane & 7, prow0 = lane >> 3;      // 8 float4 chunks x 8 rows per pass, 4 passes
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    const int hw = a.Ho * a.Wo;
+    const int kh2 = lane >> 5, l31 = lane & 31;
+    const int pc = p0 + chunk * 4, qc = q0 + chunk * 4;
+    const bool pvec = (a.Np & 3) == 0;
+
+    for (int mk = mbeg; mk < mend; mk += WBK) {
+        // rows of this step handled by this lane: decode once, reuse for every tap
+        int r_nb[4], r_oy[4], r_ox[4];
+        bool r_ok[4];
+        float4 rp[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = mk + prow0 + i * 8;
+            r_ok[i] = m < mend;
+            const int mm = r_ok[i] ? m : mbeg;
+            int rr;
+            if (a.hwshift >= 0) { r_nb[i] = mm >> a.hwshift; rr = mm & (hw - 1); r_oy[i] = rr >> a.wshift; r_ox[i] = rr & (a.Wo - 1); }
+            else { r_nb[i] = mm / hw; rr = mm - r_nb[i] * hw; r_oy[i] = rr / a.Wo; r_ox[i] = rr - r_oy[i] * a.Wo; }
+            float4 vp = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r_ok[i]) {
+                const float* pp = a.P + (size_t)mm * a.Np + pc;
+                if (pvec && pc + 3 < a.Np) vp = *reinterpret_cast<const float4*>(pp);
+                else {
+                    if (pc < a.Np) vp.x = pp[0];
+                    if (pc + 1 < a.Np) vp.y = pp[1];
+                    if (pc + 2 < a.Np) vp.z = pp[2];
+                    if (pc + 3 < a.Np) vp.w = pp[3];
+                }
+            }
+            rp[i] = vp;
+        }
+        auto load_q = [&](int t, float4 (&rq)[4]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int iy, ix;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r_ok[i] && qc < a.Nq && q_coord(a, r_oy[i], r_ox[i], t, iy, ix))
+                    v = *reinterpret_cast<const float4*>(a.Q + (((size_t)r_nb[i] * a.Hs + iy) * a.Ws + ix) * a.Cq + qc);
+                rq[i] = v;
+            }
+        };
+        float4 rq[4];
+        load_q(t0, rq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&as[(prow0 + i * 8) * SLD + chunk * 4]) = rp[i];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&bs[(prow0 + i * 8) * SLD + chunk * 4]) = rq[i];
+            __builtin_amdgcn_wave_barrier();
+            if (t + 1 < NT) load_q(t0 + t + 1, rq);
+#pragma unroll
+            for (int kk = 0; kk < WBK / 2; ++kk) {
+                const int k = 2 * kk + kh2;
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(as[k * SLD + l31], bs[k * SLD + l31], acc[t], 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    const int q = q0 + l31;
+    if (q < a.Nq) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = p0 + (r & 3) + 8 * (r >> 2) + 4 * kh2;
+                if (p < a.Np) atomicAdd(a.Out + (long long)p * a.sOp + (long long)(t0 + t) * a.sOt + q, acc[t][r]);
+            }
+    }
+}
+
 // column sums of a [M][C] matrix accumulated into out[C] (bias gradients)
 __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ x, int M, int C, int rows_per_block,
                                                      float* __restrict__ out) {
@@ -355,7 +451,19 @@ int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, cons
     a.rows_per_block = (((a.M + split - 1) / split) + gran - 1) / gran * gran;
     split = (a.M + a.rows_per_block - 1) / a.rows_per_block;
     dim3 grid(tiles, ty, split);
-    if (small) {
+    if (small && vec && !a.p_nchw && (a.T == 9 || a.T == 4) && d->precision == 0) {
+        // taps-fused: one launch dimension less, pixel ranges sized for ~2048 wave-level work items
+        const int groups_y = (a.T == 9) ? 3 : 2;        // 3 taps (T = 9) or 2 taps (T = 4) per wave: 48 / 32 accumulator regs
+        int sp = (2048 + tiles * groups_y - 1) / (tiles * groups_y);
+        const int mx = (a.M + 1023) / 1024;
+        if (sp > mx) sp = mx;
+        if (sp < 1) sp = 1;
+        a.rows_per_block = (((a.M + sp - 1) / sp) + 4 * WBK - 1) / (4 * WBK) * (4 * WBK);
+        sp = (a.M + a.rows_per_block - 1) / a.rows_per_block;
+        dim3 g2(tiles, groups_y, sp);
+        if (a.T == 9) hipLaunchKernelGGL((wgrad_small_taps_kernel<3>), g2, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((wgrad_small_taps_kernel<2>), g2, dim3(256), 0, s, a);
+    } else if (small) {
         if (vec) hipLaunchKernelGGL((wgrad_small_kernel<true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((wgrad_small_kernel<false>), grid, dim3(256), 0, s, a);
     } else {
