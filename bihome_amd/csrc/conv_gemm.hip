@@ -19,6 +19,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int v4i32 __attribute__((ext_vector_type(4)));
 
 struct GemmArgs {
     const float* Src;
@@ -35,6 +36,9 @@ struct GemmArgs {
     int b_kcontig;         // 1: sBc == 1, 0: sBn == 1
     int epi;               // 0: NHWC [M][Nn]; 1: ConvTranspose scatter; 2: NCHW
     int accumulate;        // Out += result
+    int use_buf;           // buffer-descriptor loads with per-row tap masks (vectorised path; see load_tile)
+    unsigned src_bytes, bw_bytes;
+    long long src_elems, bw_elems;   // tensor sizes (host side: buffer descriptors)
     int prio;              // experiment: s_setprio(1) around the MFMA block
     int bf16;              // operands rounded to bf16 (fp32 accumulate) where the vectorised path applies
     int ek, eC;            // scatter: kernel (== stride) and real channel count (Nn = ek*ek*eC)
@@ -151,8 +155,90 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
         b_rowptr[i] = ((bk_row0 + i * AROWS) < BN && n < a.Nn) ? a.Bw + (long long)n * a.sBn + bk_chunk * 4 : nullptr;
     }
 
+    // ---- buffer-load fast path (use_buf): every A row keeps ONE 32-bit byte offset (its anchor pixel) and a bit
+    // mask of the taps that fall inside the source image; a tile's address is that offset + a wave-uniform tap/
+    // chunk offset, invalid taps get an out-of-range offset and the buffer descriptor returns zeros.  No per-load
+    // bounds arithmetic, no 64-bit address math, no divergent branches around the loads.
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    unsigned a_voff[AIT];
+    unsigned long long a_mask[AIT];
+    unsigned bK_voff[BIT_K], bN_voff[BIT];
+    __amdgpu_buffer_rsrc_t rsA, rsB;
+    if (VEC && a.use_buf) {
+        rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Src), 0, a.src_bytes, 0x00020000);
+        rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Bw), 0, a.bw_bytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < AIT; ++i) {
+            const int pix = (int)a_base[i] + a_ay[i] * a.Ws + a_ax[i];
+            a_voff[i] = ((unsigned)pix * (unsigned)a.Cs + (unsigned)(a_chunk * 4)) * 4u;
+            unsigned long long mk = 0;
+            int t = 0;
+            for (int ky = 0; ky * a.kw < a.T; ++ky)
+                for (int kx = 0; kx < a.kw; ++kx, ++t) {
+                    const int iy = a.adjoint ? a_ay[i] - ky : a_ay[i] + ky, ix = a.adjoint ? a_ax[i] - kx : a_ax[i] + kx;
+                    if (a_ok[i] && (unsigned)iy < (unsigned)a.Hs && (unsigned)ix < (unsigned)a.Ws) mk |= 1ull << t;
+                }
+            a_mask[i] = mk;
+        }
+#pragma unroll
+        for (int i = 0; i < BIT_K; ++i) {
+            const int n = n0 + bk_row0 + i * AROWS;
+            bK_voff[i] = ((bk_row0 + i * AROWS) < BN && n < a.Nn) ? (unsigned)((long long)n * a.sBn + bk_chunk * 4) * 4u : OOB;
+        }
+        if constexpr (C4 || BF16) {
+#pragma unroll
+            for (int i = 0; i < BIT; ++i) {
+                if (C4) {
+                    const int chn = b4_c0 + i * C4_CPP, n = n0 + chn * 4;
+                    bN_voff[i] = (i < BIT_N4 && chn < NCH && n < a.Nn) ? (unsigned)((long long)b4_k * a.sBc + n) * 4u : OOB;
+                } else {
+                    const int kr = bn_row0 + i * BROWS_N, n = n0 + bn_chunk * 4;
+                    bN_voff[i] = (i < BIT_N && kr < BK && n < a.Nn) ? (unsigned)((long long)kr * a.sBc + n) * 4u : OOB;
+                }
+            }
+        }
+    }
+
     auto load_tile = [&](int kt) {
-        if (VEC) {
+        if (VEC && a.use_buf) {
+            if constexpr (C4 || BF16) {
+            const int t = nx_t, c0 = nx_c0;
+            const int tap_pix = nx_ky * a.Ws + nx_kx;
+            const unsigned toffA = (unsigned)((a.adjoint ? -tap_pix : tap_pix) * a.Cs + c0) * 4u;
+            const bool cokA = c0 + a_chunk * 4 < a.Kc;
+#pragma unroll
+            for (int i = 0; i < AIT; ++i) {
+                const bool ok = ((a_mask[i] >> t) & 1ull) && cokA;
+                const v4i32 v = __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? a_voff[i] + toffA : OOB, 0, 0);
+                ra[i] = __builtin_bit_cast(float4, v);
+            }
+            if (a.b_kcontig) {
+                const unsigned toffB = (unsigned)((long long)t * a.sBt + c0) * 4u;
+                const bool cokB = c0 + bk_chunk * 4 < a.Kc;
+#pragma unroll
+                for (int i = 0; i < BIT_K; ++i) {
+                    const v4i32 v = __builtin_amdgcn_raw_buffer_load_b128(rsB, (cokB && bK_voff[i] != OOB) ? bK_voff[i] + toffB : OOB, 0, 0);
+                    rb[i] = __builtin_bit_cast(float4, v);
+                }
+            } else {
+                const unsigned toffB = (unsigned)((long long)t * a.sBt + (long long)c0 * a.sBc) * 4u;
+                constexpr int NB = C4 ? BIT_N4 : BIT_N;
+                const bool cokB = c0 + (C4 ? b4_k : 0) < a.Kc;
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    bool ok = cokB && bN_voff[i] != OOB;
+                    if (!C4) ok = ok && (c0 + bn_row0 + i * BROWS_N < a.Kc);
+                    const v4i32 v = __builtin_amdgcn_raw_buffer_load_b128(rsB, ok ? bN_voff[i] + toffB : OOB, 0, 0);
+                    rb[i] = __builtin_bit_cast(float4, v);
+                }
+            }
+            nx_c0 += BK;
+            if (nx_c0 >= a.Kc) {
+                nx_c0 = 0; ++nx_t;
+                if (++nx_kx == a.kw) { nx_kx = 0; ++nx_ky; }
+            }
+            }
+        } else if (VEC) {
             const int t = nx_t, ky = nx_ky, kx = nx_kx, c0 = nx_c0;
             const int c = c0 + a_chunk * 4;
 #pragma unroll
@@ -476,7 +562,7 @@ static int launch(const GemmArgs& a, hipStream_t s) {
 
 // Tile choice: the largest tile that still gives the 256 CUs about two workgroups each; the small-spatial
 // layers (8x8x256ch, 16x16x128ch at 2B = 128) otherwise launch only 128-256 workgroups.
-static int g_force_bm = 0, g_force_bn = 0, g_prio = 0;     // tuning hook (bh_debug_force_tile), 0 = automatic
+static int g_force_bm = 0, g_force_bn = 0, g_prio = 0, g_no_buf = 0;     // tuning hook (bh_debug_force_tile), 0 = automatic
 
 static int dispatch(const GemmArgs& a_in, hipStream_t s) {
     GemmArgs a = a_in;
@@ -486,6 +572,10 @@ static int dispatch(const GemmArgs& a_in, hipStream_t s) {
         if (a.stride == (1 << b)) a.sshift = b;
     if (a.M <= 0 || a.Nn <= 0) return BH_OK;
     const bool vec = !a.src_nchw && (a.Kc % 4 == 0) && (a.Cs % 4 == 0);
+    a.use_buf = vec && !(a.adjoint && a.stride > 1) && (a.Nn % 4 == 0) && a.T <= 64 && a.src_elems > 0 &&
+                a.src_elems < (1ll << 29) && a.bw_elems > 0 && a.bw_elems < (1ll << 29) && (a.Kc % 32 == 0) && !g_no_buf;
+    a.src_bytes = (unsigned)(a.src_elems * 4);
+    a.bw_bytes = (unsigned)(a.bw_elems * 4);
     if (vec && a.bf16 && (a.Kc % 32) == 0) {
         // bf16 operands: the MFMA is 16x faster, the kernel is bound by staging traffic -> widest N tile that fits
         int bm = g_force_bm, bn = g_force_bn;
@@ -521,7 +611,7 @@ static int dispatch(const GemmArgs& a_in, hipStream_t s) {
     // at the fp32 MFMA rate
     const bool k16 = (a.Kc % 32) != 0 && a.Kc <= 16;
     const long long mt64 = (a.M + 63) / 64;
-    const bool k64 = (a.Kc % 64) == 0;
+    const bool k64 = (a.Kc % 64) == 0 && a.Kc >= 256;      // BK = 64 only pays on the long-K (256-channel) layers
     if (a.Nn > 64) {
         if (k16) return launch<128, 128, 16, true>(a, s);
         const long long nt = (a.Nn + 127) / 128;
@@ -530,7 +620,7 @@ static int dispatch(const GemmArgs& a_in, hipStream_t s) {
     }
     if (a.Nn > 32) {
         if (k16) return launch<128, 64, 16, true>(a, s);
-        return k64 ? launch<64, 64, 64, true>(a, s) : launch<64, 64, 32, true>(a, s);
+        return launch<64, 64, 32, true>(a, s);
     }
     return k16 ? launch<128, 32, 16, true>(a, s) : launch<128, 32, 32, true>(a, s);
 }
@@ -615,7 +705,8 @@ static int check_desc(const bh_conv_desc* d) {
 extern "C" {
 
 int bh_debug_force_tile(int bm, int bn) {
-    if (bm == -1) { g_prio = bn; return BH_OK; }      // (-1, x): toggle the s_setprio experiment
+    if (bm == -1) { g_prio = bn; return BH_OK; }
+    if (bm == -2) { g_no_buf = bn; return BH_OK; }      // (-2, 1): disable the buffer-load fast path      // (-1, x): toggle the s_setprio experiment
     g_force_bm = bm; g_force_bn = bn; return BH_OK;
 }
 
@@ -626,6 +717,8 @@ int bh_conv_fwd(const float* x, const float* w, const float* bias, float* y, con
     GemmArgs a = {};
     a.Src = x; a.Bw = w; a.bias = bias; a.Out = y; a.bf16 = d->precision == 1;
     a.Hs = d->Hi; a.Ws = d->Wi; a.Cs = d->Ci; a.Kc = d->Ci;
+    a.src_elems = (long long)d->N * d->Hi * d->Wi * d->Ci;
+    a.bw_elems = (long long)d->Co * d->kh * d->kw * d->Ci;
     if (!d->transposed) {
         a.M = d->N * d->Ho * d->Wo; a.Nn = d->Co; a.T = d->kh * d->kw;
         a.Ho = d->Ho; a.Wo = d->Wo; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad;
@@ -663,6 +756,8 @@ int bh_conv_dgrad(const float* gy, const float* w, float* gx, const bh_conv_desc
     a.M = d->N * d->Hi * d->Wi; a.Nn = d->Ci; a.Kc = d->Co; a.T = d->kh * d->kw;
     a.Ho = d->Hi; a.Wo = d->Wi;               // output-side grid of this GEMM = conv input grid
     a.Hs = d->Ho; a.Ws = d->Wo; a.Cs = d->Co;  // gathered source = gy grid
+    a.src_elems = (long long)d->N * d->Ho * d->Wo * d->Co;
+    a.bw_elems = (long long)d->Co * d->kh * d->kw * d->Ci;
     a.kw = d->kw;
     if (!d->transposed) {
         a.adjoint = 1; a.stride = d->stride; a.pad = d->pad;

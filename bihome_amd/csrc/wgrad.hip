@@ -10,6 +10,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int v4i32 __attribute__((ext_vector_type(4)));
 
 struct WgradArgs {
     const float* P;
@@ -22,6 +23,8 @@ struct WgradArgs {
     int q_nchw, p_nchw;
     long long sOp, sOt;
     int wshift, hwshift;     // log2(Wo), log2(Ho*Wo) when both are powers of two, else -1
+    int use_buf;             // buffer-descriptor loads (vectorised, NHWC operands): no branches / 64-bit address math
+    unsigned p_bytes, q_bytes;
     int joint;               // scalar path: GEMM columns run over (t, c) jointly, T' = 1
     int rows_per_block;
 };
@@ -66,12 +69,32 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
     float4 rp[2], rq[2];
     const int hw = a.Ho * a.Wo;
 
+    __amdgpu_buffer_rsrc_t rsP, rsQ;
+    if (VEC && a.use_buf) {
+        rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.P), 0, a.p_bytes, 0x00020000);
+        rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Q), 0, a.q_bytes, 0x00020000);
+    }
+    const int tky = t / a.kw, tkx = t - tky * a.kw;
     auto load_tile = [&](int mk) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int chunk = BF16 ? chunk0 + 8 * i : chunk0;
             const int m = mk + (BF16 ? prow0 : prow0 + i * 16);
             float4 vp = make_float4(0.f, 0.f, 0.f, 0.f), vq = vp;
+            if (VEC && a.use_buf) {
+                const int pc = p0 + chunk * 4, qc = q0 + chunk * 4;
+                int nb, rr, oy, ox;
+                if (a.hwshift >= 0) { nb = m >> a.hwshift; rr = m & (hw - 1); oy = rr >> a.wshift; ox = rr & (a.Wo - 1); }
+                else { nb = m / hw; rr = m - nb * hw; oy = rr / a.Wo; ox = rr - oy * a.Wo; }
+                const int iy = oy * a.stride - a.pad + tky, ix = ox * a.stride - a.pad + tkx;
+                const bool okp = m < mend && pc < a.Np;
+                const bool okq = m < mend && qc < a.Nq && (unsigned)iy < (unsigned)a.Hs && (unsigned)ix < (unsigned)a.Ws;
+                const unsigned vop = ((unsigned)m * (unsigned)a.Np + (unsigned)pc) * 4u;
+                const unsigned voq = ((((unsigned)nb * (unsigned)a.Hs + (unsigned)iy) * (unsigned)a.Ws + (unsigned)ix) * (unsigned)a.Cq + (unsigned)qc) * 4u;
+                rp[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsP, okp ? vop : 0xFFFFFFF0u, 0, 0));
+                rq[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsQ, okq ? voq : 0xFFFFFFF0u, 0, 0));
+                continue;
+            }
             if (m < mend) {
                 const int pc = p0 + chunk * 4;
                 int nb, rr, oy, ox;
@@ -432,6 +455,11 @@ int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, cons
         vec = (d->Co % 4 == 0);
     }
     a.joint = vec ? 0 : 1;
+    {
+        const long long pe = (long long)a.M * a.Np, qe = (long long)d->N * a.Hs * a.Ws * a.Cq;
+        a.use_buf = vec && !a.p_nchw && !a.q_nchw && (a.Np % 4 == 0) && pe < (1ll << 29) && qe < (1ll << 29);
+        a.p_bytes = (unsigned)(pe * 4); a.q_bytes = (unsigned)(qe * 4);
+    }
     a.wshift = a.hwshift = -1;
     for (int b = 0; b < 24; ++b) {
         if (a.Wo == (1 << b)) a.wshift = b;

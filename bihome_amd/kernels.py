@@ -52,7 +52,7 @@ def gemm_variant(M, Nn, Kc, vec):
         return fmt % (128, 128 if Nn > 64 else (64 if Nn > 32 else 32), 32, "false")
     k16 = (Kc % 32) != 0 and Kc <= 16
     mt64 = (M + 63) // 64
-    k64 = Kc % 64 == 0
+    k64 = Kc % 64 == 0 and Kc >= 256
     if Nn > 64:
         if k16:
             return fmt % (128, 128, 16, "true")
@@ -63,7 +63,7 @@ def gemm_variant(M, Nn, Kc, vec):
     if Nn > 32:
         if k16:
             return fmt % (128, 64, 16, "true")
-        return fmt % (64, 64, 64 if k64 else 32, "true")
+        return fmt % (64, 64, 32, "true")
     return fmt % (128, 32, 16 if k16 else 32, "true")
 
 
