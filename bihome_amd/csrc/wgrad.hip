@@ -197,8 +197,8 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
 #define SLD 36
 template <bool VEC>
 __global__ void __launch_bounds__(256) wgrad_small_kernel(WgradArgs a) {
-    __shared__ float As[4][WBK * SLD];
-    __shared__ float Bs[4][WBK * SLD];
+    __shared__ __attribute__((aligned(16))) float As[4][WBK * SLD];
+    __shared__ __attribute__((aligned(16))) float Bs[4][WBK * SLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ncols = a.joint ? a.T * a.Nq : a.Nq;
     const int qtiles = (ncols + 31) / 32;
@@ -207,8 +207,7 @@ __global__ void __launch_bounds__(256) wgrad_small_kernel(WgradArgs a) {
     const int bbeg = blockIdx.z * a.rows_per_block;
     const int bend = min(a.M, bbeg + a.rows_per_block);
     const int rpw = (((bend - bbeg) + 3) / 4 + WBK - 1) / WBK * WBK;
-    const int mbeg = bbeg + wave * rpw, mend = min(bend, mbeg + rpw);
-    if (mbeg >= mend) return;
+    const int mbeg = bbeg + wave * rpw, mend = min(bend, mbeg + rpw);      // may be empty: the wave then only joins the reduction
     float* as = As[wave];
     float* bs = Bs[wave];
     const int chunk = lane & 7, prow0 = lane >> 3;      // 8 float4 chunks x 8 rows per pass, 4 passes
@@ -273,7 +272,7 @@ __global__ void __launch_bounds__(256) wgrad_small_kernel(WgradArgs a) {
     };
 
     const int kh2 = lane >> 5, l31 = lane & 31;
-    load_tile(mbeg);
+    if (mbeg < mend) load_tile(mbeg);
     for (int mk = mbeg; mk < mend; mk += WBK) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -290,13 +289,18 @@ __global__ void __launch_bounds__(256) wgrad_small_kernel(WgradArgs a) {
         }
         __builtin_amdgcn_wave_barrier();
     }
-    const int q = q0 + l31;
-    if (q < ncols) {
+    // add the four waves' partials of the same tile in LDS, then one atomic per element per workgroup
+    float* red = &As[0][0];
+    __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int p = p0 + (r & 3) + 8 * (r >> 2) + 4 * kh2;
-            if (p < a.Np) atomicAdd(a.Out + (long long)p * a.sOp + (long long)t * a.sOt + q, acc[r]);
-        }
+    for (int r = 0; r < 16; ++r) red[wave * 1024 + r * 64 + lane] = acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = tid + 256 * j, r = idx >> 6, ln = idx & 63;
+        const float v = red[idx] + red[1024 + idx] + red[2048 + idx] + red[3072 + idx];
+        const int p = p0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), q = q0 + (ln & 31);
+        if (p < a.Np && q < ncols) atomicAdd(a.Out + (long long)p * a.sOp + (long long)t * a.sOt + q, v);
     }
 }
 
@@ -314,8 +318,7 @@ __global__ void __launch_bounds__(256) wgrad_small_taps_kernel(WgradArgs a) {
     const int bbeg = blockIdx.z * a.rows_per_block;
     const int bend = min(a.M, bbeg + a.rows_per_block);
     const int rpw = (((bend - bbeg) + 3) / 4 + WBK - 1) / WBK * WBK;
-    const int mbeg = bbeg + wave * rpw, mend = min(bend, mbeg + rpw);
-    if (mbeg >= mend) return;
+    const int mbeg = bbeg + wave * rpw, mend = min(bend, mbeg + rpw);      // may be empty: the wave then only joins the reduction
     const int t0 = blockIdx.y * NT;                     // this workgroup's group of NT consecutive taps
     float* as = As[wave];
     float* bs = Bs[wave];
@@ -329,6 +332,11 @@ __global__ void __launch_bounds__(256) wgrad_small_taps_kernel(WgradArgs a) {
     const int kh2 = lane >> 5, l31 = lane & 31;
     const int pc = p0 + chunk * 4, qc = q0 + chunk * 4;
     const bool pvec = (a.Np & 3) == 0;
+    __amdgpu_buffer_rsrc_t rsP, rsQ;
+    if (a.use_buf) {
+        rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.P), 0, a.p_bytes, 0x00020000);
+        rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Q), 0, a.q_bytes, 0x00020000);
+    }
 
     for (int mk = mbeg; mk < mend; mk += WBK) {
         // rows of this step handled by this lane: decode once, reuse for every tap
@@ -344,7 +352,10 @@ __global__ void __launch_bounds__(256) wgrad_small_taps_kernel(WgradArgs a) {
             if (a.hwshift >= 0) { r_nb[i] = mm >> a.hwshift; rr = mm & (hw - 1); r_oy[i] = rr >> a.wshift; r_ox[i] = rr & (a.Wo - 1); }
             else { r_nb[i] = mm / hw; rr = mm - r_nb[i] * hw; r_oy[i] = rr / a.Wo; r_ox[i] = rr - r_oy[i] * a.Wo; }
             float4 vp = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r_ok[i]) {
+            if (a.use_buf) {
+                const unsigned vop = ((unsigned)mm * (unsigned)a.Np + (unsigned)pc) * 4u;
+                vp = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsP, (r_ok[i] && pc < a.Np) ? vop : 0xFFFFFFF0u, 0, 0));
+            } else if (r_ok[i]) {
                 const float* pp = a.P + (size_t)mm * a.Np + pc;
                 if (pvec && pc + 3 < a.Np) vp = *reinterpret_cast<const float4*>(pp);
                 else {
@@ -361,7 +372,11 @@ __global__ void __launch_bounds__(256) wgrad_small_taps_kernel(WgradArgs a) {
             for (int i = 0; i < 4; ++i) {
                 int iy, ix;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (r_ok[i] && qc < a.Nq && q_coord(a, r_oy[i], r_ox[i], t, iy, ix))
+                const bool ok = q_coord(a, r_oy[i], r_ox[i], t, iy, ix) && r_ok[i] && qc < a.Nq;
+                if (a.use_buf) {
+                    const unsigned voq = ((((unsigned)r_nb[i] * (unsigned)a.Hs + (unsigned)iy) * (unsigned)a.Ws + (unsigned)ix) * (unsigned)a.Cq + (unsigned)qc) * 4u;
+                    v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsQ, ok ? voq : 0xFFFFFFF0u, 0, 0));
+                } else if (ok)
                     v = *reinterpret_cast<const float4*>(a.Q + (((size_t)r_nb[i] * a.Hs + iy) * a.Ws + ix) * a.Cq + qc);
                 rq[i] = v;
             }
@@ -384,15 +399,22 @@ __global__ void __launch_bounds__(256) wgrad_small_taps_kernel(WgradArgs a) {
             __builtin_amdgcn_wave_barrier();
         }
     }
-    const int q = q0 + l31;
-    if (q < a.Nq) {
+    // the four waves hold partial sums of the SAME 32x32 tile: add them in LDS first, then one atomic per element
+    // per workgroup (the output is tiny - e.g. 9x32x32 - so every split-K partial lands on the same few addresses)
+    float* red = &As[0][0];                      // 4 x 1024 floats
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
+        __syncthreads();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int p = p0 + (r & 3) + 8 * (r >> 2) + 4 * kh2;
-                if (p < a.Np) atomicAdd(a.Out + (long long)p * a.sOp + (long long)(t0 + t) * a.sOt + q, acc[t][r]);
-            }
+        for (int r = 0; r < 16; ++r) red[wave * 1024 + r * 64 + lane] = acc[t][r];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = tid + 256 * j, r = idx >> 6, ln = idx & 63;
+            const float v = red[idx] + red[1024 + idx] + red[2048 + idx] + red[3072 + idx];
+            const int p = p0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), q = q0 + (ln & 31);
+            if (p < a.Np && q < a.Nq) atomicAdd(a.Out + (long long)p * a.sOp + (long long)(t0 + t) * a.sOt + q, v);
+        }
     }
 }
 
