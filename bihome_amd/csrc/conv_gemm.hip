@@ -562,6 +562,7 @@ static int launch(const GemmArgs& a, hipStream_t s) {
 
 // Tile choice: the largest tile that still gives the 256 CUs about two workgroups each; the small-spatial
 // layers (8x8x256ch, 16x16x128ch at 2B = 128) otherwise launch only 128-256 workgroups.
+extern int g_wgrad_target;
 static int g_force_bm = 0, g_force_bn = 0, g_prio = 0, g_no_buf = 0;     // tuning hook (bh_debug_force_tile), 0 = automatic
 
 static int dispatch(const GemmArgs& a_in, hipStream_t s) {
@@ -705,8 +706,9 @@ static int check_desc(const bh_conv_desc* d) {
 extern "C" {
 
 int bh_debug_force_tile(int bm, int bn) {
-    if (bm == -1) { g_prio = bn; return BH_OK; }
-    if (bm == -2) { g_no_buf = bn; return BH_OK; }      // (-2, 1): disable the buffer-load fast path      // (-1, x): toggle the s_setprio experiment
+    if (bm == -1) { g_prio = bn; return BH_OK; }            // (-1, bits): 1 s_setprio, 2 no global reloads, 4 no LDS restaging (ablations)
+    if (bm == -2) { g_no_buf = bn; return BH_OK; }          // (-2, 1): disable the buffer-load fast path
+    if (bm == -3) { g_wgrad_target = bn; return BH_OK; }    // (-3, n): wgrad split-K work items per launch
     g_force_bm = bm; g_force_bn = bn; return BH_OK;
 }
 

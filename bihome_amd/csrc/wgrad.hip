@@ -449,6 +449,8 @@ __global__ void __launch_bounds__(256) plane_sum_kernel(const float* __restrict_
     if (threadIdx.x == 0) atomicAdd(out, sm[0] + sm[1] + sm[2] + sm[3]);
 }
 
+int g_wgrad_target = 4096;      // split-K work items per launch (tuning hook: bh_debug_force_tile(-3, n))
+
 extern "C" {
 
 int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, const bh_conv_desc* d, void* stream) {
@@ -493,7 +495,7 @@ int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, cons
     const int tsz = small ? 32 : 64;
     const int tiles = ((a.Np + tsz - 1) / tsz) * ((ncols + tsz - 1) / tsz);
     const int ty = a.joint ? 1 : a.T;
-    int split = (2048 + tiles * ty - 1) / (tiles * ty);
+    int split = (g_wgrad_target + tiles * ty - 1) / (tiles * ty);
     int maxsplit = (a.M + (small ? 1023 : 255)) / (small ? 1024 : 256);
     if (split > maxsplit) split = maxsplit;
     if (split < 1) split = 1;
