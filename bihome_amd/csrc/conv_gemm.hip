@@ -690,6 +690,46 @@ __global__ void __launch_bounds__(256) stem_dgrad_c1_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// col2im for the same 1-input-channel stem dgrad, second half of the two-step form:
+//   step 1 (a plain 1x1 implicit GEMM on the MFMA): Tm[m][t] = sum_c gy[m][c] * w[c][t]   for every SOURCE pixel m, tap t
+//   step 2 (this kernel): gx[n][iy][ix] = sum over the valid taps of Tm[(n, (iy+p-ky)/s, (ix+p-kx)/s)][ky*k+kx]
+// Every element of Tm is used exactly once, so the total traffic is |gy| + 2|Tm| instead of 49/4 cached re-reads of
+// gy per output pixel.  A workgroup owns one output parity class, lanes run along the class row (consecutive
+// source pixels), ldT = padded row length of Tm.
+// ---------------------------------------------------------------------------------------------
+template <int KK, int ST>
+__global__ void __launch_bounds__(256) col2im_c1_kernel(const float* __restrict__ Tm, float* __restrict__ gx, int N, int Hi,
+                                                        int Wi, int Ho, int Wo, int pad, int ldT) {
+    constexpr int NT = (KK + ST - 1) / ST;
+    const int cls = blockIdx.y, py = cls / ST, px = cls % ST;
+    const int Ha = (Hi - py + ST - 1) / ST, Wa = (Wi - px + ST - 1) / ST;
+    const int ky0 = (py + pad) % ST, kx0 = (px + pad) % ST;
+    const long long total = (long long)N * Ha * Wa;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256) {
+        const int n = (int)(q / ((long long)Ha * Wa));
+        const int r = (int)(q - (long long)n * Ha * Wa);
+        const int a = r / Wa, b = r - a * Wa;
+        const int iy = a * ST + py, ix = b * ST + px;
+        const int oyb = (iy + pad - ky0) / ST, oxb = (ix + pad - kx0) / ST;
+        float v[NT][NT];
+#pragma unroll
+        for (int ty = 0; ty < NT; ++ty)
+#pragma unroll
+            for (int tx = 0; tx < NT; ++tx) {
+                const int oy = oyb - ty, ox = oxb - tx, ky = ky0 + ty * ST, kx = kx0 + tx * ST;
+                const bool ok = ky < KK && kx < KK && oy >= 0 && oy < Ho && ox >= 0 && ox < Wo;
+                v[ty][tx] = ok ? Tm[(((size_t)n * Ho + oy) * Wo + ox) * ldT + ky * KK + kx] : 0.f;
+            }
+        float acc = 0.f;
+#pragma unroll
+        for (int ty = 0; ty < NT; ++ty)
+#pragma unroll
+            for (int tx = 0; tx < NT; ++tx) acc += v[ty][tx];
+        gx[((size_t)n * Hi + iy) * Wi + ix] = acc;
+    }
+}
+
 static int check_desc(const bh_conv_desc* d) {
     if (!d) return BH_E_BADARG;
     if (d->transposed) {
@@ -704,6 +744,15 @@ static int check_desc(const bh_conv_desc* d) {
 }
 
 extern "C" {
+
+int bh_col2im_c1(const float* Tm, float* gx, const bh_conv_desc* d, int ldT, void* stream) {
+    if (!Tm || !gx || !d) return BH_E_BADARG;
+    if (d->transposed || d->Ci != 1 || d->kh != 7 || d->kw != 7 || d->stride != 2 || ldT < 49) return BH_E_UNSUPPORTED;
+    hipLaunchKernelGGL((col2im_c1_kernel<7, 2>), dim3(1024, 4), dim3(256), 0, bh_stream(stream), Tm, gx, d->N, d->Hi, d->Wi,
+                       d->Ho, d->Wo, d->pad, ldT);
+    BH_LAUNCH_CHECK();
+    return BH_OK;
+}
 
 int bh_debug_force_tile(int bm, int bn) {
     if (bm == -1) { g_prio = bn; return BH_OK; }            // (-1, bits): 1 s_setprio, 2 no global reloads, 4 no LDS restaging (ablations)

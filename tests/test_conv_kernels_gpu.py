@@ -110,9 +110,9 @@ def test_first_conv_nchw_input(K, N, Hi, Ci, Co):
     close(gw.cpu().permute(0, 3, 1, 2), wt.grad)
 
 
-def test_gray_stem_conv_and_its_dgrad(K):
+@pytest.mark.parametrize("N,Hi", [(2, 32), (8, 64)])       # small: direct gather kernel; large: 1x1 GEMM + col2im
+def test_gray_stem_conv_and_its_dgrad(K, N, Hi):
     """Extractor conv1 on a 1-channel image (PerceptualHead.py:52-55) and the dgrad the warp needs."""
-    N, Hi = 2, 32
     x = rnd((N, 1, Hi, Hi), 12)
     w = rnd((64, 1, 7, 7), 13) / 7
     d = K.conv_desc(N, Hi, Hi, 1, 64, 7, 2, 3)
