@@ -580,7 +580,7 @@ static int dispatch(const GemmArgs& a_in, hipStream_t s) {
     if (vec && a.bf16 && (a.Kc % 32) == 0) {
         // bf16 operands: the MFMA is 16x faster, the kernel is bound by staging traffic -> widest N tile that fits
         int bm = g_force_bm, bn = g_force_bn;
-        if (!bm) {      // measured (scratch/bf16bench.py): 64-wide N tiles; 64-row tiles while the grid is small
+        if (!bm) {      // measured (tools/bf16_microbench.py): 64-wide N tiles; 64-row tiles while the grid is small
             if (a.Nn <= 32) { bm = 128; bn = 32; }
             else { bn = 64; bm = (((a.M + 127) / 128) * ((a.Nn + 63) / 64) < 1024) ? 64 : 128; }
         }
@@ -607,7 +607,7 @@ static int dispatch(const GemmArgs& a_in, hipStream_t s) {
         if (a.Nn > 32) return launch<128, 64, 32, false>(a, s);
         return launch<128, 32, 32, false>(a, s);
     }
-    // measured on MI355X (scratch/convbench.py): the 64-row tiles (4-5 waves/SIMD resident) beat the 128-row
+    // measured on MI355X (tools/conv_microbench.py): the 64-row tiles (4-5 waves/SIMD resident) beat the 128-row
     // ones (2-3 waves/SIMD) on every 3x3 layer of the network - latency hiding matters more than tile reuse
     // at the fp32 MFMA rate
     const bool k16 = (a.Kc % 32) != 0 && a.Kc <= 16;

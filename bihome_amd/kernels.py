@@ -44,10 +44,14 @@ class _Timed:
             r["n"] += 1
 
 
-def gemm_variant(M, Nn, Kc, vec):
+def gemm_variant(M, Nn, Kc, vec, bf16=False):
     """Mirror of conv_gemm.hip's dispatch(): which template instantiation a launch uses (the kernel
-    symbol rocprofv3 reports: conv_gemm_kernel<BM, BN, BK, VEC>)."""
-    fmt = "conv_gemm_kernel<%d,%d,%d,%s>"
+    symbol rocprofv3 reports: conv_gemm_kernel<BM, BN, BK, VEC, BF16>)."""
+    fmt = "conv_gemm_kernel<%d,%d,%d,%s," + ("true>" if (bf16 and vec and Kc % 32 == 0) else "false>")
+    if bf16 and vec and Kc % 32 == 0:
+        if Nn <= 32:
+            return fmt % (128, 32, 32, "true")
+        return fmt % (64 if ((M + 127) // 128) * ((Nn + 63) // 64) < 1024 else 128, 64, 32, "true")
     if not vec:
         return fmt % (128, 128 if Nn > 64 else (64 if Nn > 32 else 32), 32, "false")
     k16 = (Kc % 32) != 0 and Kc <= 16
@@ -78,12 +82,12 @@ def _conv_variant0(d, which):
     if which == "fwd":
         vec = (not d.in_nchw) and d.Ci % 4 == 0
         if d.transposed:
-            return gemm_variant(d.N * d.Hi * d.Wi, d.kh * d.kw * d.Co, d.Ci, vec)
-        return gemm_variant(d.N * d.Ho * d.Wo, d.Co, d.Ci, vec)
+            return gemm_variant(d.N * d.Hi * d.Wi, d.kh * d.kw * d.Co, d.Ci, vec, d.precision == 1)
+        return gemm_variant(d.N * d.Ho * d.Wo, d.Co, d.Ci, vec, d.precision == 1)
     if (not d.transposed) and d.Ci == 1 and not d.out_nchw:
         return "stem_dgrad_c1_kernel"
     vec = (not d.out_nchw) and d.Co % 4 == 0
-    return gemm_variant(d.N * d.Hi * d.Wi, d.Ci, d.Co, vec)
+    return gemm_variant(d.N * d.Hi * d.Wi, d.Ci, d.Co, vec, d.precision == 1)
 
 
 def _wgrad_variant(d):
@@ -94,7 +98,11 @@ def _wgrad_variant(d):
         Np, Nq, vec = d.Co, d.Ci, (not d.in_nchw) and d.Ci % 4 == 0
     ncols = Nq if vec else d.kh * d.kw * Nq
     small = Np <= 32 or ncols <= 32
-    return "%s<%s>" % ("wgrad_small_kernel" if small else "wgrad_kernel", "true" if vec else "false")
+    if small and vec and d.precision == 0 and d.kh * d.kw in (9, 4) and not d.out_nchw:
+        return "wgrad_small_taps_kernel<%d>" % (3 if d.kh * d.kw == 9 else 2)
+    if small:
+        return "wgrad_small_kernel<%s>" % ("true" if vec else "false")
+    return "wgrad_kernel<%s,%s>" % ("true" if vec else "false", "true" if (vec and d.precision == 1) else "false")
 
 
 def conv_flops(d):

@@ -1,3 +1,4 @@
+"""bf16-operand mode micro-benchmark: error vs the fp32 path and TFLOP/s of fwd/dgrad/wgrad."""
 import sys; sys.path.insert(0,'.')
 import torch
 from bihome_amd import kernels as K

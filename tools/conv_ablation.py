@@ -1,3 +1,4 @@
+"""conv_gemm ablations through bh_debug_force_tile(-1, bits): 2 = skip global reloads, 4 = skip LDS restaging (results are wrong by construction; timing only)."""
 import sys; sys.path.insert(0,'.')
 import torch
 from bihome_amd import kernels as K

@@ -1,3 +1,4 @@
+"""Implicit-GEMM conv micro-benchmark: TFLOP/s of fwd/dgrad per forced tile (bh_debug_force_tile) and of wgrad, on the network's main 3x3 shapes."""
 import sys; sys.path.insert(0,'.')
 import torch
 from bihome_amd import kernels as K

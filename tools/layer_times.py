@@ -1,3 +1,4 @@
+"""Per-launch (per layer) HIP-event timing table of one Zeng+biHomE training step at bs 64: python tools/layer_times.py"""
 import sys, json; sys.path.insert(0,'.')
 import torch
 from bihome_amd import configs, synth, kernels as K
@@ -18,4 +19,4 @@ for name,r in K.TIMING.items():
 rows.sort(reverse=True)
 tot=sum(r[0] for r in rows)
 print('total timed ms/step', tot)
-for r in rows[:60]: print('%8.3f ms x%d %7.1f TF %7.0f GB/s  %s'%r)
+for r in rows[:34]: print('%8.3f ms x%d %7.1f TF %7.0f GB/s  %s'%r)

@@ -1,3 +1,4 @@
+"""Sweep of the wgrad split-K work-item target (bh_debug_force_tile(-3, n))."""
 import sys; sys.path.insert(0,'.')
 import torch
 from bihome_amd import kernels as K
