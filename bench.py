@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="image pairs per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="image pairs per GPU (default: the config's DATA.BATCH_SIZE)")
     ap.add_argument("--config", default="zeng-bihome")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
                     help="conv operand precision; the headline config (BASELINE.json configs[1]) is f32")
@@ -125,6 +125,14 @@ def roofline_leg(model, data, opt, sched, reducer, nsteps=2):
     return roof, rows
 
 
+WORKLOADS = {
+    "zeng-bihome": "BASELINE.json configs[1]: s-coco Zeng (Rethinking/ResNet34 blocks)",
+    "zeng-bihome-pds": "BASELINE.json configs[2]: pds-coco Zeng (photometric-distorted)",
+    "detone-bihome": "BASELINE.json configs[3]: s-coco ResNet-34 regressor",
+    "zeng-bihome-rgb256": "BASELINE.json configs[4]: 256x256 RGB Zeng (build-side extension)",
+}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -158,10 +166,13 @@ def main():
     opt, sched = build_optimizer(model, cfg["SOLVER"])
     reducer = attach_reducer(model) if world > 1 else None
 
-    B = args.batch
+    B = args.batch or cfg["DATA"]["BATCH_SIZE"]
     # each rank owns its contiguous shard of the global batch; synthetic data generated on the host
     # from seeds, then resident in HBM for the whole run
-    d = synth.make_pairs(B, seed=42 + rank, photometric_max_delta=cfg["DATA"]["PHOTOMETRIC_MAX_DELTA"])
+    D = cfg["DATA"]
+    P, CH = D["PATCH_SIZE"], D.get("PATCH_CHANNELS", 1)
+    d = synth.make_pairs(B, patch=P, rho=D["RHO"], seed=42 + rank, photometric_max_delta=D["PHOTOMETRIC_MAX_DELTA"],
+                         channels=CH)
     data = {k: torch.tensor(d[k]).cuda() for k in ("patch_1", "patch_2", "delta")}
     torch.manual_seed(1234 + rank)                    # DSAC sample indices: per-rank stream
 
@@ -198,19 +209,21 @@ def main():
     if not args.no_roofline:
         roof, rows = roofline_leg(model, data, opt, sched, reducer)
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and CH == 1:    # the reference (and so the oracle) has no RGB path
         cpu = cpu_baseline(cfg)
     if dist is not None:
         dist.barrier()
     if rank == 0:
         out = {
-            "metric": "training image-pairs/s (128x128 patch, bs=%d per GPU, full step: fwd+bwd+Adam)" % B,
+            "metric": "training image-pairs/s (%dx%d patch, bs=%d per GPU, full step: fwd+bwd+Adam)" % (P, P, B),
             "value": value, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
             "data": "synthetic (seeded COCO-style texture pairs, random-init weights%s)" % (
                 "; fresh batch per step from the device-side generator" if args.gpu_datagen else "; one resident batch"),
-            "config": {"workload": "BASELINE.json configs[1]: s-coco Zeng (Rethinking/ResNet34 blocks) backbone + biHomE "
-                                   "head, %d pairs/GPU, 128x128 grayscale, %s MFMA conv + HIP warp/DLT/triplet kernels" % (B, args.precision),
+            "config": {"workload": "%s: %s backbone + biHomE head, %d pairs/GPU, %dx%d %s, %s MFMA conv + HIP "
+                                   "warp/DLT/triplet kernels" % (
+                                       WORKLOADS.get(args.config, args.config), cfg["MODEL"]["BACKBONE"]["NAME"], B, P, P,
+                                       "RGB" if CH == 3 else "grayscale", args.precision),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "optimizer": "Adam lr 1e-3"},
             "final_loss": final_loss, "final_mace": final_mace,
             "roofline": roof, "cpu_baseline": cpu,

@@ -62,7 +62,10 @@ class Model(nn.Module):
             raise RuntimeError("PRETRAINED_RESNET=True needs the ImageNet checkpoint URL (Rethinking.py:178-183); "
                                "no network here - load weights with load_state_dict instead")
         S, U, D = nn.Sequential, resnet34_unit, deconv_unit
-        self.layer1 = S(_conv(2, 64, 7, 2, 3), nn.BatchNorm2d(64), nn.ReLU(), nn.MaxPool2d(3, 2, 1))
+        # optional extra kwarg (upstream hard-wires 2 = two grayscale patches, Rethinking.py:31): channels per patch;
+        # 3 gives the 6-channel stem of BASELINE.json configs[4] (256x256 RGB pairs)
+        self.patch_channels = int(kwargs.get('PATCH_CHANNELS', 1))
+        self.layer1 = S(_conv(2 * self.patch_channels, 64, 7, 2, 3), nn.BatchNorm2d(64), nn.ReLU(), nn.MaxPool2d(3, 2, 1))
         self.layer2 = S(U(64, 64), U(64, 64), U(64, 64))
         self.layer3 = S(U(64, 128, 2), U(128, 128), U(128, 128), U(128, 128))
         self.layer4 = S(U(128, 256, 2), *[U(256, 256) for _ in range(5)], D(256))

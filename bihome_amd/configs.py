@@ -55,7 +55,15 @@ DETONE_BIHOME = {
 
 def get(name):
     """'zeng-bihome' / 'detone-bihome' = config/s-coco/*; the '-pds' variants = config/pds-coco/* (the two trees differ
-    only in HomographyNetPrep's photometric max_delta, 0 vs 32, and the log dir)."""
+    only in HomographyNetPrep's photometric max_delta, 0 vs 32, and the log dir).  'zeng-bihome-rgb256' is the
+    build-side extension BASELINE.json configs[4] names (256x256 RGB patches, 6-channel stem; no upstream
+    counterpart - SURVEY.md 0)."""
+    if name == "zeng-bihome-rgb256":
+        cfg = copy.deepcopy(ZENG_BIHOME)
+        cfg["MODEL"]["BACKBONE"].update(IMAGE_SIZE=256, PATCH_CHANNELS=3)
+        cfg["MODEL"]["HEAD"].update(PATCH_SIZE=256)
+        cfg["DATA"].update(BATCH_SIZE=32, RHO=64, PATCH_SIZE=256, PATCH_CHANNELS=3)
+        return cfg
     base = name[:-4] if name.endswith("-pds") else name
     cfg = copy.deepcopy({"zeng-bihome": ZENG_BIHOME, "detone-bihome": DETONE_BIHOME}[base])
     if name.endswith("-pds"):

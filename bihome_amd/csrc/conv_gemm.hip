@@ -698,9 +698,10 @@ __global__ void __launch_bounds__(256) stem_dgrad_c1_kernel(const float* __restr
 // gy per output pixel.  A workgroup owns one output parity class, lanes run along the class row (consecutive
 // source pixels), ldT = padded row length of Tm.
 // ---------------------------------------------------------------------------------------------
-template <int KK, int ST>
+template <int KK, int ST, int CI>
 __global__ void __launch_bounds__(256) col2im_c1_kernel(const float* __restrict__ Tm, float* __restrict__ gx, int N, int Hi,
                                                         int Wi, int Ho, int Wo, int pad, int ldT) {
+    // CI = stem input channels (1: grayscale patch, 3: RGB patch); Tm column = tap*CI + c; gx is NCHW [N][CI][Hi][Wi]
     constexpr int NT = (KK + ST - 1) / ST;
     const int cls = blockIdx.y, py = cls / ST, px = cls % ST;
     const int Ha = (Hi - py + ST - 1) / ST, Wa = (Wi - px + ST - 1) / ST;
@@ -712,21 +713,26 @@ __global__ void __launch_bounds__(256) col2im_c1_kernel(const float* __restrict_
         const int a = r / Wa, b = r - a * Wa;
         const int iy = a * ST + py, ix = b * ST + px;
         const int oyb = (iy + pad - ky0) / ST, oxb = (ix + pad - kx0) / ST;
-        float v[NT][NT];
+        float v[NT][NT][CI];
 #pragma unroll
         for (int ty = 0; ty < NT; ++ty)
 #pragma unroll
             for (int tx = 0; tx < NT; ++tx) {
                 const int oy = oyb - ty, ox = oxb - tx, ky = ky0 + ty * ST, kx = kx0 + tx * ST;
                 const bool ok = ky < KK && kx < KK && oy >= 0 && oy < Ho && ox >= 0 && ox < Wo;
-                v[ty][tx] = ok ? Tm[(((size_t)n * Ho + oy) * Wo + ox) * ldT + ky * KK + kx] : 0.f;
+                const float* tp = Tm + (((size_t)n * Ho + oy) * Wo + ox) * ldT + (ky * KK + kx) * CI;
+#pragma unroll
+                for (int c = 0; c < CI; ++c) v[ty][tx][c] = ok ? tp[c] : 0.f;
             }
-        float acc = 0.f;
 #pragma unroll
-        for (int ty = 0; ty < NT; ++ty)
+        for (int c = 0; c < CI; ++c) {
+            float acc = 0.f;
 #pragma unroll
-            for (int tx = 0; tx < NT; ++tx) acc += v[ty][tx];
-        gx[((size_t)n * Hi + iy) * Wi + ix] = acc;
+            for (int ty = 0; ty < NT; ++ty)
+#pragma unroll
+                for (int tx = 0; tx < NT; ++tx) acc += v[ty][tx][c];
+            gx[(((size_t)n * CI + c) * Hi + iy) * Wi + ix] = acc;
+        }
     }
 }
 
@@ -747,9 +753,15 @@ extern "C" {
 
 int bh_col2im_c1(const float* Tm, float* gx, const bh_conv_desc* d, int ldT, void* stream) {
     if (!Tm || !gx || !d) return BH_E_BADARG;
-    if (d->transposed || d->Ci != 1 || d->kh != 7 || d->kw != 7 || d->stride != 2 || ldT < 49) return BH_E_UNSUPPORTED;
-    hipLaunchKernelGGL((col2im_c1_kernel<7, 2>), dim3(1024, 4), dim3(256), 0, bh_stream(stream), Tm, gx, d->N, d->Hi, d->Wi,
-                       d->Ho, d->Wo, d->pad, ldT);
+    if (d->transposed || (d->Ci != 1 && d->Ci != 3) || d->kh != 7 || d->kw != 7 || d->stride != 2 || ldT < 49 * d->Ci)
+        return BH_E_UNSUPPORTED;
+    if (d->Ci > 1 && !d->in_nchw) return BH_E_UNSUPPORTED;      // multi-channel stems read/write the NCHW network input
+    if (d->Ci == 1)
+        hipLaunchKernelGGL((col2im_c1_kernel<7, 2, 1>), dim3(1024, 4), dim3(256), 0, bh_stream(stream), Tm, gx, d->N, d->Hi,
+                           d->Wi, d->Ho, d->Wo, d->pad, ldT);
+    else
+        hipLaunchKernelGGL((col2im_c1_kernel<7, 2, 3>), dim3(1024, 4), dim3(256), 0, bh_stream(stream), Tm, gx, d->N, d->Hi,
+                           d->Wi, d->Ho, d->Wo, d->pad, ldT);
     BH_LAUNCH_CHECK();
     return BH_OK;
 }
@@ -791,7 +803,7 @@ int bh_conv_dgrad(const float* gy, const float* w, float* gx, const bh_conv_desc
     int rc = check_desc(d);
     if (rc) return rc;
     if (!gy || !w || !gx) return BH_E_BADARG;
-    if (d->in_nchw) return BH_E_UNSUPPORTED;          // network inputs are data: no dgrad
+    if (d->in_nchw && (d->transposed || accumulate)) return BH_E_UNSUPPORTED;
     if (!d->transposed && d->Ci == 1 && !d->out_nchw && !accumulate && d->Co % 4 == 0 && d->Co <= 256 &&
         (64 % (d->Co / 4)) == 0 && d->kh == 7 && d->kw == 7 && d->stride == 2) {
         const size_t lds = sizeof(float) * d->kh * d->kw * d->Co;
@@ -819,7 +831,7 @@ int bh_conv_dgrad(const float* gy, const float* w, float* gx, const bh_conv_desc
         a.adjoint = 0; a.stride = d->stride; a.pad = 0;
         a.sBt = d->Co; a.sBc = 1; a.sBn = (long long)a.T * d->Co; a.b_kcontig = 1;
     }
-    a.epi = 0;
+    a.epi = d->in_nchw ? 2 : 0;                       // gradient w.r.t. an NCHW network input (RGB patch into the extractor)
     return dispatch(a, bh_stream(stream));
 }
 

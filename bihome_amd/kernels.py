@@ -276,30 +276,35 @@ _STEM_WT = {}
 
 
 def _stem_dgrad_two_step(gy, w, d):
-    """dgrad of the 1-input-channel 7x7/2 stem as (1x1 MFMA GEMM gy x w^T -> per-source-pixel tap table) + col2im."""
-    key = (w.data_ptr(), w._version, str(w.device))
+    """dgrad of the 1- or 3-input-channel 7x7/2 stem as (1x1 MFMA GEMM gy x w^T -> per-source-pixel tap table) + col2im.
+    w is the kernel-layout weight [Co][7][7][Ci]; the result is NCHW [N,Ci,Hi,Wi] (== NHWC for Ci = 1)."""
+    key = (w.data_ptr(), w._version, str(w.device), d.Ci)
+    cols = 49 * d.Ci
+    ld = (cols + 3) // 4 * 4                                                          # 52 / 148
     wt = _STEM_WT.get(key)
     if wt is None:
         _STEM_WT.clear()
-        wt = torch.zeros(52, 1, 1, d.Co, dtype=torch.float32, device=w.device)       # [taps padded to 52][Co]
-        wt[:49, 0, 0, :] = w.reshape(d.Co, 49).t()
+        wt = torch.zeros(ld, 1, 1, d.Co, dtype=torch.float32, device=w.device)        # [tap*Ci + c, padded][Co]
+        wt[:cols, 0, 0, :] = w.reshape(d.Co, cols).t()
         _STEM_WT[key] = wt
-    d1 = conv_desc(d.N, d.Ho, d.Wo, d.Co, 52, 1, 1, 0, precision=d.precision)
-    tm = conv_fwd(gy, wt, None, d1)                                                   # [N,Ho,Wo,52]
-    gx = torch.empty((d.N, d.Hi, d.Wi, 1), dtype=torch.float32, device=gy.device)
+    d1 = conv_desc(d.N, d.Ho, d.Wo, d.Co, ld, 1, 1, 0, precision=d.precision)
+    tm = conv_fwd(gy, wt, None, d1)                                                   # [N,Ho,Wo,ld]
+    shape = (d.N, d.Hi, d.Wi, 1) if d.Ci == 1 else (d.N, d.Ci, d.Hi, d.Wi)
+    gx = torch.empty(shape, dtype=torch.float32, device=gy.device)
     with _Timed("col2im_c1_kernel", 0.0, 4.0 * (tm.numel() + gx.numel())):
-        check(lib.bh_col2im_c1(_p(tm), _p(gx), ctypes.byref(d), 52, _stream()), "bh_col2im_c1")
+        check(lib.bh_col2im_c1(_p(tm), _p(gx), ctypes.byref(d), ld, _stream()), "bh_col2im_c1")
     return gx
 
 
 def conv_dgrad(gy, w, d, out=None):
     _chk(gy); _chk(w)
-    if (out is None and d.Ci == 1 and not d.transposed and d.kh == 7 and d.stride == 2 and not d.out_nchw
-            and d.Co % 4 == 0 and d.N * d.Ho * d.Wo >= 4096):
+    if (out is None and not d.transposed and d.kh == 7 and d.stride == 2 and not d.out_nchw
+            and (d.Ci == 1 or (d.Ci == 3 and d.in_nchw)) and d.Co % 4 == 0 and d.N * d.Ho * d.Wo >= 4096):
         return _stem_dgrad_two_step(gy, w, d)
     acc = out is not None
     if out is None:
-        out = torch.empty((d.N, d.Hi, d.Wi, d.Ci), dtype=torch.float32, device=gy.device)
+        shape = (d.N, d.Ci, d.Hi, d.Wi) if d.in_nchw else (d.N, d.Hi, d.Wi, d.Ci)
+        out = torch.empty(shape, dtype=torch.float32, device=gy.device)
     with _Timed(_conv_variant(d, "dgrad"), conv_flops(d), 4.0 * (gy.numel() + out.numel() * (2 if acc else 1) + w.numel())):
         check(lib.bh_conv_dgrad(_p(gy), _p(w), _p(out), ctypes.byref(d), int(acc), _stream()), "bh_conv_dgrad")
     return out

@@ -120,10 +120,12 @@ typedef struct {
 int bh_debug_force_tile(int bm, int bn);
 /* y = conv(x, w) (+ bias[Co] if bias != NULL) */
 int bh_conv_fwd(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, void* stream);
-/* gx = conv^T(gy, w)  (overwritten; accumulate != 0: gx += ..., used where gradient branches join) */
+/* gx = conv^T(gy, w)  (overwritten; accumulate != 0: gx += ..., used where gradient branches join).
+ * d->in_nchw: gx is written NCHW (gradient w.r.t. an NCHW network input; no accumulate, not transposed). */
 int bh_conv_dgrad(const float* gy, const float* w, float* gx, const bh_conv_desc* d, int accumulate, void* stream);
-/* Second half of the two-step dgrad of a 1-input-channel 7x7/2 stem (the extractor's conv1 on a grayscale patch):
- * Tm[N*Ho*Wo][ldT] = gy x w^T (one 1x1 bh_conv_fwd launch, ldT >= 49 padded taps) -> gx[N,Hi,Wi,1] = col2im(Tm). */
+/* Second half of the two-step dgrad of the extractor's 7x7/2 stem on a grayscale (Ci = 1) or RGB (Ci = 3, in_nchw) patch:
+ * Tm[N*Ho*Wo][ldT] = gy x w^T (one 1x1 bh_conv_fwd launch; column = tap*Ci + c, ldT >= 49*Ci padded)
+ * -> gx[N,Ci,Hi,Wi] = col2im(Tm). */
 int bh_col2im_c1(const float* Tm, float* gx, const bh_conv_desc* d, int ldT, void* stream);
 /* gw += x^T * gy ; gbias += sum gy  (accumulated: caller zeroes; gbias NULL ok) */
 int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, const bh_conv_desc* d, void* stream);
