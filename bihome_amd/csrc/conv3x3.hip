@@ -1,0 +1,243 @@
+// 3x3 / stride 1 / pad 1 convolution (forward and dgrad) as a halo-tiled implicit GEMM on the gfx950 f32-input MFMA.
+//
+// The generic implicit-GEMM kernel (conv_gemm.hip) re-gathers the A operand from L2 once per tap: for a 3x3 conv
+// every input pixel crosses the L2 -> LDS path nine times and a 64x64 tile moves 16 KB per 64x64x32 MFMA step.
+// Here a workgroup owns two 8x8-pixel sub-tiles (128 GEMM rows) x 64 output channels.  For each 32-channel chunk
+// the two 10x10 input halos are brought into LDS ONCE and all nine taps read them with a shifted address; only
+// the 32x64 weight slab of a tap is streamed per step.  Per MFMA the L2 -> LDS traffic is ~3x lower, the LDS read
+// traffic ~25% lower (each wave owns 64x32 of the tile: two A fragments share one B fragment).
+//
+// All staging is direct-to-LDS (buffer_load_dwordx4 ... lds): no staging VGPRs, no ds_write pass; out-of-image halo
+// pixels and out-of-range channels use an out-of-range buffer offset, which the hardware turns into zeros in LDS.
+// LDS image (lane-linear per wave instruction, 1 KB = 64 x float4):
+//   halo stage : [8 k-planes][2 sub-tiles][100 halo pixels] x float4     (a k-plane = 4 consecutive channels)
+//   B, forward : [8 k-planes][64 n] x float4          (weights [Co][tap][Ci] are k-contiguous: same C4 scheme)
+//   B, dgrad   : [32 k][64 n] floats                  (weights are n-contiguous: fragments by 4 x ds_read_b32)
+// One ds_read_b128 feeds four v_mfma_f32_32x32x2_f32 (half-wave 0 takes plane 2q, half-wave 1 plane 2q+1; MFMA
+// step j contracts channel 8q+j with 8q+4+j - any pairing is valid inside a sum over k).
+// Double-buffered: the weight slab of step t+1 and (one wave instruction per tap step) the halo of the next
+// chunk are in flight while the 32 MFMAs per wave of step t run; one barrier per step.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+struct C3Args {
+    const float* Src;
+    const float* Wt;
+    const float* bias;
+    float* Out;
+    int N, H, W;
+    int Kc, Nn;            // contraction channels (= source channels), output channels
+    int Cw;                // innermost dim of the weight tensor [Co][9][Cw]
+    int accumulate;
+    unsigned src_bytes, w_bytes;
+    int tiles_x, tiles_per_img, subtiles;
+};
+
+constexpr int C3_HALO_BYTES = 8 * 200 * 16;          // 25600
+constexpr int C3_B_BYTES = 8192;
+constexpr int C3_LDS_BYTES = 2 * C3_HALO_BYTES + 2 * C3_B_BYTES;      // 67584
+
+// BN = 64: wave (wm, wn) owns sub-tile wm x channels [32 wn, 32 wn + 32) (two A fragments per B fragment);
+// BN = 32: wave w owns rows [32 w, 32 w + 32) of the 128-row tile x all 32 channels (the 32-channel decoder layers).
+template <bool FLIP, int BN>
+__global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
+    constexpr int TM = BN == 64 ? 2 : 1;
+    constexpr int BINS = BN == 64 ? 2 : 1;                 // weight-slab wave instructions per wave and step
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh2 = lane >> 5;
+    const int wm = BN == 64 ? (wave & 1) : (wave >> 1);    // sub-tile of this wave
+    const int wn = BN == 64 ? (wave >> 1) : 0;
+    const int wh = BN == 64 ? 0 : (wave & 1);              // BN = 32: upper / lower four pixel rows of the sub-tile
+    const int n0 = blockIdx.y * BN;
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Src), 0, a.src_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wt), 0, a.w_bytes, 0x00020000);
+
+    // ---- halo slots of this lane: slot q = (j*4 + wave)*64 + lane of the [8][2][100] image ----
+    unsigned hoff[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int ci = j * 4 + wave, q = ci * 64 + lane;
+        unsigned off = OOB;
+        if (ci < 25) {
+            const int plane = q / 200, rem = q - plane * 200, s = rem / 100, hp = rem - s * 100;
+            const int hy = hp / 10, hx = hp - hy * 10;
+            const int g = blockIdx.x * 2 + s;
+            if (g < a.subtiles) {
+                const int img = g / a.tiles_per_img, t = g - img * a.tiles_per_img;
+                const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+                const int y = ty * 8 + hy - 1, x = tx * 8 + hx - 1;
+                if ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
+                    off = ((unsigned)((img * a.H + y) * a.W + x) * (unsigned)a.Kc + (unsigned)(plane * 4)) * 4u;
+            }
+        }
+        hoff[j] = off;
+    }
+    // ---- weight slab slots ----
+    unsigned boff[2] = {0u, 0u};    // (fixed size: a template-dependent array type as a builtin operand silently drops
+                                    //  the host-side kernel stub with this compiler)
+#pragma unroll
+    for (int i = 0; i < BINS; ++i) {
+        const int idx = i * 4 + wave;                      // 1 KB wave instruction of the slab image
+        if (!FLIP) {            // B[k][n] = W[n][tap][c0 + k]: image [8 planes][BN n] x float4
+            const int plane = BN == 64 ? idx : idx * 2 + (lane >> 5), n = n0 + (BN == 64 ? lane : (lane & 31));
+            boff[i] = n < a.Nn ? ((unsigned)(n * 9) * (unsigned)a.Cw + (unsigned)(plane * 4)) * 4u : OOB;
+        } else {                // B[k][n] = W[c0 + k][8 - tap][n]: image [32 k][BN n] floats, BN/4 lanes x float4 per k row
+            constexpr int LPR = BN / 4;
+            const int k = idx * (64 / LPR) + lane / LPR, n = n0 + (lane % LPR) * 4;
+            boff[i] = n < a.Nn ? ((unsigned)(k * 9) * (unsigned)a.Cw + (unsigned)n) * 4u : OOB;
+        }
+    }
+#define issue_B(c, tap, bs)                                                                                             \
+    do {                                                                                                                \
+        const unsigned soff_ = FLIP ? (unsigned)(((c) * 32 * 9 + (8 - (tap))) * a.Cw) * 4u                             \
+                                    : (unsigned)((tap) * a.Cw + (c) * 32) * 4u;                                        \
+        char* base_ = smem + 2 * C3_HALO_BYTES + (bs) * C3_B_BYTES + wave * 1024;                                       \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_ptr)(base_), 16, boff[0], soff_, 0, 0);                 \
+        if (BINS == 2)                                                                                                  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_ptr)(base_ + 4096), 16, boff[1], soff_, 0, 0); \
+    } while (0)
+#define C3_ISSUE_HALO(j, c, hs)                                                                                         \
+    do {                                                                                                                \
+        if ((j) < 6 || wave == 0)                                                                                       \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_ptr)(smem + (hs) * C3_HALO_BYTES + ((j) * 4 + wave) * 1024), \
+                                                     16, hoff[j], (unsigned)((c) * 32) * 4u, 0, 0);                     \
+    } while (0)
+
+    f32x16 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    const int nch = a.Kc / 32;
+    // lane-constant parts of the fragment addresses (bytes)
+    const int a_lane = (kh2 * 200 + wm * 100 + (wh * 4 + (l31 >> 3)) * 10 + (l31 & 7)) * 16;
+    const int b_lane = FLIP ? (kh2 * 4 * BN + wn * 32 + l31) * 4 : (kh2 * BN + wn * 32 + l31) * 16;
+
+#pragma unroll
+    for (int j = 0; j < 7; ++j) C3_ISSUE_HALO(j, 0, 0);
+    issue_B(0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int bs = 0;
+    for (int c = 0; c < nch; ++c) {
+        const int hs = c & 1;
+        const char* hbase = smem + hs * C3_HALO_BYTES + a_lane;
+        const bool more = c + 1 < nch;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            // all fragment reads of the step come first: the compiler orders every later LDS read behind an
+            // outstanding LDS-DMA with a full vmcnt(0), so the prefetch is issued only after them
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const char* ap = hbase + (dy * 10 + dx) * 16;
+            const char* bp = smem + 2 * C3_HALO_BYTES + bs * C3_B_BYTES + b_lane;
+            float4 af[TM][4], b[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i][q] = *reinterpret_cast<const float4*>(ap + q * 6400 + i * 640);
+                if (!FLIP) b[q] = *reinterpret_cast<const float4*>(bp + q * (2 * BN * 16));
+                else {
+                    b[q].x = *reinterpret_cast<const float*>(bp + (q * 8 + 0) * (BN * 4));
+                    b[q].y = *reinterpret_cast<const float*>(bp + (q * 8 + 1) * (BN * 4));
+                    b[q].z = *reinterpret_cast<const float*>(bp + (q * 8 + 2) * (BN * 4));
+                    b[q].w = *reinterpret_cast<const float*>(bp + (q * 8 + 3) * (BN * 4));
+                }
+            }
+            if (tap < 8) issue_B(c, tap + 1, bs ^ 1);
+            else if (more) issue_B(c + 1, 0, bs ^ 1);
+            if (tap < 7 && more) C3_ISSUE_HALO(tap, c + 1, hs ^ 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q].x, b[q].x, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q].y, b[q].y, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q].z, b[q].z, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q].w, b[q].w, acc[i], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keep the MFMAs of this step in front of the wait: they hide the DMA
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            bs ^= 1;
+        }
+    }
+#undef C3_ISSUE_HALO
+#undef issue_B
+
+    // ---- epilogue: C/D layout col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m) ----
+    const int g = blockIdx.x * 2 + wm;
+    const int n = n0 + wn * 32 + l31;
+    if (g >= a.subtiles || n >= a.Nn) return;
+    const int img = g / a.tiles_per_img, t = g - img * a.tiles_per_img;
+    const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    const float bv = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (i + wh) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh2;
+            const int y = ty * 8 + (m >> 3), x = tx * 8 + (m & 7);
+            const size_t off = ((size_t)(img * a.H + y) * a.W + x) * a.Nn + n;
+            float v = acc[i][r] + bv;
+            if (a.accumulate) v += a.Out[off];
+            a.Out[off] = v;
+        }
+}
+
+static int g_c3_disable = 0, g_c3_min_blocks = 256;
+void bh_conv3x3_tune(int disable, int min_blocks) {
+    g_c3_disable = disable;
+    if (min_blocks > 0) g_c3_min_blocks = min_blocks;
+}
+
+// *taken = 1 when the shape is eligible and the launch was made; returns BH_OK or a hipError_t
+int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* out, const bh_conv_desc* d, int dgrad,
+                   int accumulate, hipStream_t stream, int* taken) {
+    *taken = 0;
+    if (g_c3_disable || d->transposed || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->in_nchw ||
+        d->out_nchw || d->precision != 0)
+        return 0;
+    if (d->Hi % 8 || d->Wi % 8 || d->Ho != d->Hi || d->Wo != d->Wi) return 0;
+    const int Kc = dgrad ? d->Co : d->Ci, Nn = dgrad ? d->Ci : d->Co;
+    if (Kc % 32 || Nn % 32) return 0;
+    const int bn_tile = (Nn % 64) ? 32 : 64;
+    const long long src_bytes = (long long)d->N * d->Hi * d->Wi * Kc * 4, w_bytes = (long long)d->Co * 9 * d->Ci * 4;
+    if (src_bytes >= (1ll << 31) || w_bytes >= (1ll << 31)) return 0;
+    C3Args a = {};
+    a.Src = src; a.Wt = w; a.bias = bias; a.Out = out;
+    a.N = d->N; a.H = d->Hi; a.W = d->Wi; a.Kc = Kc; a.Nn = Nn; a.Cw = d->Ci; a.accumulate = accumulate;
+    a.src_bytes = (unsigned)src_bytes; a.w_bytes = (unsigned)w_bytes;
+    a.tiles_x = d->Wi / 8; a.tiles_per_img = (d->Hi / 8) * a.tiles_x; a.subtiles = d->N * a.tiles_per_img;
+    dim3 grid((a.subtiles + 1) / 2, Nn / bn_tile);
+    if ((int)(grid.x * grid.y) < g_c3_min_blocks) return 0;
+    static bool attr_set = false;
+    const void* fns[4] = {reinterpret_cast<const void*>(conv3x3_halo_kernel<false, 64>),
+                          reinterpret_cast<const void*>(conv3x3_halo_kernel<true, 64>),
+                          reinterpret_cast<const void*>(conv3x3_halo_kernel<false, 32>),
+                          reinterpret_cast<const void*>(conv3x3_halo_kernel<true, 32>)};
+    if (!attr_set) {
+        for (int i = 0; i < 4; ++i) {
+            hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS_BYTES);
+            if (e != hipSuccess) return (int)e;
+        }
+        attr_set = true;
+    }
+    if (bn_tile == 64) {
+        if (!dgrad) hipLaunchKernelGGL((conv3x3_halo_kernel<false, 64>), grid, dim3(256), C3_LDS_BYTES, stream, a);
+        else hipLaunchKernelGGL((conv3x3_halo_kernel<true, 64>), grid, dim3(256), C3_LDS_BYTES, stream, a);
+    } else {
+        if (!dgrad) hipLaunchKernelGGL((conv3x3_halo_kernel<false, 32>), grid, dim3(256), C3_LDS_BYTES, stream, a);
+        else hipLaunchKernelGGL((conv3x3_halo_kernel<true, 32>), grid, dim3(256), C3_LDS_BYTES, stream, a);
+    }
+    BH_LAUNCH_CHECK();
+    *taken = 1;
+    return BH_OK;
+}

@@ -736,6 +736,10 @@ __global__ void __launch_bounds__(256) col2im_c1_kernel(const float* __restrict_
     }
 }
 
+void bh_conv3x3_tune(int disable, int min_blocks);
+int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* out, const bh_conv_desc* d, int dgrad,
+                   int accumulate, hipStream_t stream, int* taken);
+
 static int check_desc(const bh_conv_desc* d) {
     if (!d) return BH_E_BADARG;
     if (d->transposed) {
@@ -770,6 +774,8 @@ int bh_debug_force_tile(int bm, int bn) {
     if (bm == -1) { g_prio = bn; return BH_OK; }            // (-1, bits): 1 s_setprio, 2 no global reloads, 4 no LDS restaging (ablations)
     if (bm == -2) { g_no_buf = bn; return BH_OK; }          // (-2, 1): disable the buffer-load fast path
     if (bm == -3) { g_wgrad_target = bn; return BH_OK; }    // (-3, n): wgrad split-K work items per launch
+    if (bm == -4) { bh_conv3x3_tune(bn, 0); return BH_OK; } // (-4, 1): disable the halo-tiled 3x3 kernel
+    if (bm == -5) { bh_conv3x3_tune(0, bn); return BH_OK; } // (-5, n): minimum workgroups for the halo-tiled 3x3 kernel
     g_force_bm = bm; g_force_bn = bn; return BH_OK;
 }
 
@@ -777,6 +783,11 @@ int bh_conv_fwd(const float* x, const float* w, const float* bias, float* y, con
     int rc = check_desc(d);
     if (rc) return rc;
     if (!x || !w || !y) return BH_E_BADARG;
+    {
+        int taken = 0;
+        rc = bh_conv3x3_try(x, w, bias, y, d, 0, 0, bh_stream(stream), &taken);
+        if (rc || taken) return rc;
+    }
     GemmArgs a = {};
     a.Src = x; a.Bw = w; a.bias = bias; a.Out = y; a.bf16 = d->precision == 1;
     a.Hs = d->Hi; a.Ws = d->Wi; a.Cs = d->Ci; a.Kc = d->Ci;
@@ -804,6 +815,11 @@ int bh_conv_dgrad(const float* gy, const float* w, float* gx, const bh_conv_desc
     if (rc) return rc;
     if (!gy || !w || !gx) return BH_E_BADARG;
     if (d->in_nchw && (d->transposed || accumulate)) return BH_E_UNSUPPORTED;
+    {
+        int taken = 0;
+        rc = bh_conv3x3_try(gy, w, nullptr, gx, d, 1, accumulate, bh_stream(stream), &taken);
+        if (rc || taken) return rc;
+    }
     if (!d->transposed && d->Ci == 1 && !d->out_nchw && !accumulate && d->Co % 4 == 0 && d->Co <= 256 &&
         (64 % (d->Co / 4)) == 0 && d->kh == 7 && d->kw == 7 && d->stride == 2) {
         const size_t lds = sizeof(float) * d->kh * d->kw * d->Co;
