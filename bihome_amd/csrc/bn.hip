@@ -1,10 +1,13 @@
 // Training-mode BatchNorm2d on NHWC feature maps ([groups*rows, C], C contiguous), with `groups`
 // independent sub-batches stacked along the row axis (one group per reference forward call).
 // HBM-bound streaming kernels: float4 per lane along channels, a lane keeps its 4 channels for its
-// whole row range, statistics are accumulated in double and combined through per-chunk partials
-// (deterministic; no atomics).
-//   forward : stats partials -> finalize (mean/var, running stats) -> apply (+residual, +ReLU)
-//   backward: reduce partials (sum dy, sum dy*xhat) -> finalize (dgamma/dbeta) -> apply (dx, dres)
+// whole row range.  Per-channel sums are accumulated in double: every workgroup reduces its rows and
+// adds one double per channel into a caller-zeroed [groups][C][2] buffer with hardware f64 atomics
+// (global_atomic_add_f64), so there is no finalize launch - the consumer kernels derive mean / variance
+// (forward) and the two gradient sums (backward) from those totals on the fly.
+//   forward : [stats sums, unless the producing conv already accumulated them] -> apply (+residual, +ReLU,
+//             running statistics updated by workgroup 0)
+//   backward: reduce sums (sum dy, sum dy*xhat) -> apply (dx, dres; dgamma/dbeta added by workgroup 0)
 #include "common.h"
 
 #define BN_MAX_CHUNKS 256
@@ -38,7 +41,7 @@ __device__ __forceinline__ void reduce_rows(double (&v)[NV], int LPR, int RPP, d
 }
 
 // grid (nchunks, groups)
-__global__ void __launch_bounds__(256) bn_stats_kernel(const float* __restrict__ x, BnGeom g, double* __restrict__ part) {
+__global__ void __launch_bounds__(256) bn_stats_kernel(const float* __restrict__ x, BnGeom g, double* __restrict__ sums) {
     __shared__ double sm[256 * 8];
     const int cq = threadIdx.x % g.LPR, r0 = threadIdx.x / g.LPR;
     const int grp = blockIdx.y, chunk = blockIdx.x;
@@ -52,52 +55,45 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const float* __restrict__
     }
     reduce_rows<8>(v, g.LPR, g.RPP, sm);
     if ((int)threadIdx.x < g.LPR) {
-        double* p = part + (((size_t)grp * g.nchunks + chunk) * g.C + cq * 4) * 2;
-        for (int i = 0; i < 4; ++i) { p[i * 2] = v[i]; p[i * 2 + 1] = v[4 + i]; }
+        const int slot = blockIdx.x % BH_BN_SUM_SLOTS;
+        for (int i = 0; i < 4; ++i) {
+            atomicAdd(&sums[bn_sum_index(slot, g.groups, grp, g.C, cq * 4 + i, 0)], v[i]);
+            atomicAdd(&sums[bn_sum_index(slot, g.groups, grp, g.C, cq * 4 + i, 1)], v[4 + i]);
+        }
     }
 }
 
-// one wavefront per channel (lanes stride over the chunk partials, shuffle-reduce); groups are processed in
-// order so that the running statistics see the same sequence of momentum updates as consecutive
-// nn.BatchNorm2d calls
-__global__ void __launch_bounds__(64) bn_finalize_kernel(const double* __restrict__ part, BnGeom g, float momentum,
-                                                         float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                         double* __restrict__ stats) {
-    const int c = blockIdx.x, lane = threadIdx.x;
-    float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 1.f;
+// running statistics: groups are processed in order so that the buffers see the same sequence of momentum
+// updates as consecutive nn.BatchNorm2d calls (one call per group upstream)
+__device__ __forceinline__ void bn_update_running(const double* __restrict__ sums, const BnGeom& g, float momentum,
+                                                  float* __restrict__ running_mean, float* __restrict__ running_var) {
     const double n = (double)g.rows;
-    for (int grp = 0; grp < g.groups; ++grp) {
-        double s = 0, ss = 0;
-        for (int k = lane; k < g.nchunks; k += 64) {
-            const double* p = part + (((size_t)grp * g.nchunks + k) * g.C + c) * 2;
-            s += p[0]; ss += p[1];
+    for (int c = threadIdx.x; c < g.C; c += blockDim.x) {
+        float rm = running_mean[c], rv = running_var[c];
+        for (int grp = 0; grp < g.groups; ++grp) {
+            const double mean = bn_sum_total(sums, g.groups, grp, g.C, c, 0) / n;
+            double var = bn_sum_total(sums, g.groups, grp, g.C, c, 1) / n - mean * mean;
+            if (var < 0) var = 0;
+            const float unb = (float)(n > 1 ? var * n / (n - 1) : var);
+            rm = (1.f - momentum) * rm + momentum * (float)mean;
+            rv = (1.f - momentum) * rv + momentum * unb;
         }
-        s = wave_sum(s); ss = wave_sum(ss);
-        const double mean = s / n;
-        double var = ss / n - mean * mean;
-        if (var < 0) var = 0;
-        if (lane == 0) {
-            stats[((size_t)grp * g.C + c) * 2] = mean;
-            stats[((size_t)grp * g.C + c) * 2 + 1] = var;
-        }
-        const float unb = (float)(n > 1 ? var * n / (n - 1) : var);
-        rm = (1.f - momentum) * rm + momentum * (float)mean;
-        rv = (1.f - momentum) * rv + momentum * unb;
-    }
-    if (lane == 0) {
-        if (running_mean) running_mean[c] = rm;
-        if (running_var) running_var[c] = rv;
+        running_mean[c] = rm;
+        running_var[c] = rv;
     }
 }
 
 __device__ __forceinline__ void bn_coeffs(const double* __restrict__ stats, const float* __restrict__ gamma,
                                           const float* __restrict__ beta, const float* __restrict__ rmean,
-                                          const float* __restrict__ rvar, int use_running, int grp, int C, int c, float eps,
-                                          float& mean, float& invstd, float& scale, float& shift) {
+                                          const float* __restrict__ rvar, int use_running, int groups, int grp, int C, int c,
+                                          float eps, double rows, float& mean, float& invstd, float& scale, float& shift) {
     if (use_running) { mean = rmean[c]; invstd = 1.0f / sqrtf(rvar[c] + eps); }
-    else {
-        mean = (float)stats[((size_t)grp * C + c) * 2];
-        invstd = 1.0f / sqrtf((float)stats[((size_t)grp * C + c) * 2 + 1] + eps);
+    else {                                                      // stats = [groups][C][2] sums (x, x^2) over `rows` rows
+        const double m = bn_sum_total(stats, groups, grp, C, c, 0) / rows;
+        double var = bn_sum_total(stats, groups, grp, C, c, 1) / rows - m * m;
+        if (var < 0) var = 0;
+        mean = (float)m;
+        invstd = 1.0f / sqrtf((float)var + eps);
     }
     const float gm = gamma ? gamma[c] : 1.f;
     scale = gm * invstd;
@@ -109,15 +105,17 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ beta, const float* __restrict__ rmean,
                                                        const float* __restrict__ rvar, const float* __restrict__ res,
                                                        float* __restrict__ y, const double* __restrict__ stats, BnGeom g,
-                                                       float eps, int flags, int use_running) {
+                                                       float eps, int flags, int use_running, float momentum,
+                                                       float* __restrict__ upd_mean, float* __restrict__ upd_var) {
     const int cq = threadIdx.x % g.LPR, r0 = threadIdx.x / g.LPR;
     const int grp = blockIdx.y;
     float sc[4], sh[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float m, is;
-        bn_coeffs(stats, gamma, beta, rmean, rvar, use_running, grp, g.C, cq * 4 + i, eps, m, is, sc[i], sh[i]);
+        bn_coeffs(stats, gamma, beta, rmean, rvar, use_running, g.groups, grp, g.C, cq * 4 + i, eps, (double)g.rows, m, is, sc[i], sh[i]);
     }
+    if (upd_mean && blockIdx.x == 0 && blockIdx.y == 0) bn_update_running(stats, g, momentum, upd_mean, upd_var);
     const size_t gbase = ((size_t)grp * g.rows) * g.C + cq * 4;
     const bool relu = flags & 1, addres = (flags & 2) && res;
     for (int r = blockIdx.x * g.RPP + r0; r < g.rows; r += gridDim.x * g.RPP) {
@@ -147,7 +145,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restr
     float mean[4], invstd[4], sc[4], sh[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-        bn_coeffs(stats, gamma, beta, rmean, rvar, use_running, grp, g.C, cq * 4 + i, eps, mean[i], invstd[i], sc[i], sh[i]);
+        bn_coeffs(stats, gamma, beta, rmean, rvar, use_running, g.groups, grp, g.C, cq * 4 + i, eps, (double)g.rows, mean[i], invstd[i], sc[i], sh[i]);
     const size_t gbase = ((size_t)grp * g.rows) * g.C + cq * 4;
     const bool relu = flags & 1, mask_from_x = flags & 4;     // bit 2: no residual -> y = relu(x*sc+sh), recompute the mask
     double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -177,9 +175,13 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restr
     }
 }
 
+// one wavefront per channel: totals of the chunk partials (deterministic), dgamma / dbeta, and the compact
+// coefficient table the apply kernel starts from: coef[grp][c] = (mean, invstd, mean(dy), mean(dy * xhat))
 __global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const double* __restrict__ part, BnGeom g,
+                                                             const double* __restrict__ stats, const float* __restrict__ rmean,
+                                                             const float* __restrict__ rvar, float eps, int use_running,
                                                              float* __restrict__ ggamma, float* __restrict__ gbeta,
-                                                             double* __restrict__ sums) {
+                                                             float4* __restrict__ coef) {
     const int c = blockIdx.x, lane = threadIdx.x;
     double tg = 0, tb = 0;
     for (int grp = 0; grp < g.groups; ++grp) {
@@ -190,8 +192,11 @@ __global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const double* __res
         }
         s1 = wave_sum(s1); s2 = wave_sum(s2);
         if (lane == 0) {
-            sums[((size_t)grp * g.C + c) * 2] = s1;
-            sums[((size_t)grp * g.C + c) * 2 + 1] = s2;
+            float mean, invstd, sc, sh;
+            bn_coeffs(stats, nullptr, nullptr, rmean, rvar, use_running, g.groups, grp, g.C, c, eps, (double)g.rows, mean, invstd, sc, sh);
+            const float invn = 1.0f / (float)g.rows;
+            coef[(size_t)grp * g.C + c] = use_running ? make_float4(mean, invstd, 0.f, 0.f)
+                                                      : make_float4(mean, invstd, (float)s1 * invn, (float)s2 * invn);
         }
         tb += s1; tg += s2;
     }
@@ -205,23 +210,19 @@ __global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const double* __res
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ gy, const float* __restrict__ y,
                                                            const float* __restrict__ x, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta,
-                                                           const double* __restrict__ stats, const float* __restrict__ rmean,
-                                                           const float* __restrict__ rvar, const double* __restrict__ sums,
+                                                           const float4* __restrict__ coef,
                                                            float* __restrict__ gx, float* __restrict__ gres, BnGeom g,
-                                                           float eps, int flags, int use_running) {
+                                                           int flags) {
     const int cq = threadIdx.x % g.LPR, r0 = threadIdx.x / g.LPR;
     const int grp = blockIdx.y;
     float mean[4], invstd[4], sc[4], sh[4], k1[4], k2[4];
-    const float invn = 1.0f / (float)g.rows;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = cq * 4 + i;
-        bn_coeffs(stats, gamma, beta, rmean, rvar, use_running, grp, g.C, c, eps, mean[i], invstd[i], sc[i], sh[i]);
-        if (use_running) { k1[i] = 0.f; k2[i] = 0.f; }
-        else {
-            k1[i] = (float)(sums[((size_t)grp * g.C + c) * 2]) * invn;
-            k2[i] = (float)(sums[((size_t)grp * g.C + c) * 2 + 1]) * invn;
-        }
+        const float4 q = coef[(size_t)grp * g.C + c];            // (mean, invstd, mean dy, mean dy*xhat) from the finalize kernel
+        mean[i] = q.x; invstd[i] = q.y; k1[i] = q.z; k2[i] = q.w;
+        sc[i] = (gamma ? gamma[c] : 1.f) * q.y;
+        sh[i] = (beta ? beta[c] : 0.f) - q.x * sc[i];
     }
     const size_t gbase = ((size_t)grp * g.rows) * g.C + cq * 4;
     const bool relu = flags & 1, mask_from_x = flags & 4;
@@ -257,9 +258,19 @@ static int apply_blocks(const BnGeom& g) {
     return nb;
 }
 
+// per-channel sums of an NHWC tensor into caller-zeroed sums[groups][C][2] (used by bh_bn_fwd and by the conv entry
+// point that hands the statistics to the BatchNorm that follows it)
+int bn_launch_stats(const float* x, int groups, int rows, int C, double* sums, hipStream_t s) {
+    BnGeom g;
+    if (!bn_geom(groups, rows, C, g)) return BH_E_UNSUPPORTED;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(g.nchunks, groups), dim3(256), 0, s, x, g, sums);
+    BH_LAUNCH_CHECK();
+    return BH_OK;
+}
+
 extern "C" {
 
-int bh_bn_stats_doubles(int groups, int C) { return groups * C * 2 * (1 + BN_MAX_CHUNKS); }
+int bh_bn_stats_doubles(int groups, int C) { return (int)BH_BN_SUM_DOUBLES(groups, C); }
 
 int bh_bn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
               const float* res, float* y, double* stats, int groups, int rows, int C, float eps, float momentum,
@@ -269,15 +280,14 @@ int bh_bn_fwd(const float* x, const float* gamma, const float* beta, float* runn
     if (!bn_geom(groups, rows, C, g)) return BH_E_UNSUPPORTED;
     if (use_running && (!running_mean || !running_var)) return BH_E_BADARG;
     hipStream_t s = bh_stream(stream);
-    if (!use_running) {
-        double* part = stats + (size_t)groups * C * 2;
-        hipLaunchKernelGGL(bn_stats_kernel, dim3(g.nchunks, groups), dim3(256), 0, s, x, g, part);
-        BH_LAUNCH_CHECK();
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, part, g, momentum, running_mean, running_var, stats);
+    if (!use_running && !(flags & 8)) {                       // bit 3: the producer already accumulated the sums
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(g.nchunks, groups), dim3(256), 0, s, x, g, stats);
         BH_LAUNCH_CHECK();
     }
+    const bool upd = !use_running && running_mean && running_var;
     hipLaunchKernelGGL(bn_apply_kernel, dim3(apply_blocks(g), groups), dim3(256), 0, s, x, gamma, beta, running_mean,
-                       running_var, res, y, stats, g, eps, flags, use_running);
+                       running_var, res, y, stats, g, eps, flags, use_running, momentum, upd ? running_mean : nullptr,
+                       upd ? running_var : nullptr);
     BH_LAUNCH_CHECK();
     return BH_OK;
 }
@@ -290,18 +300,27 @@ int bh_bn_bwd(const float* gy, const float* y, const float* x, const float* gamm
     if ((flags & 4) && (flags & 2)) return BH_E_BADARG;        // the mask can only be recomputed without a residual input
     if (!bn_geom(groups, rows, C, g)) return BH_E_UNSUPPORTED;
     hipStream_t s = bh_stream(stream);
+    // scratch: [groups][C] float4 coefficient table, then the per-chunk partial sums
+    float4* coef = reinterpret_cast<float4*>(scratch);
     double* part = scratch + (size_t)groups * C * 2;
-    if (!use_running || ggamma || gbeta) {
+    const bool need_sums = !use_running || ggamma || gbeta;
+    if (need_sums) {
         hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(g.nchunks, groups), dim3(256), 0, s, gy, y, x, gamma, beta, stats,
                            running_mean, running_var, g, eps, flags, use_running, part);
         BH_LAUNCH_CHECK();
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, part, g, ggamma, gbeta, scratch);
-        BH_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(apply_blocks(g), groups), dim3(256), 0, s, gy, y, x, gamma, beta, stats,
-                       running_mean, running_var, scratch, gx, gres, g, eps, flags, use_running);
+    // (eval mode without trainable affine parameters: nchunks = 0 makes the finalize kernel write the table only)
+    BnGeom gf = g;
+    if (!need_sums) gf.nchunks = 0;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, part, gf, stats, running_mean, running_var, eps,
+                       use_running, ggamma, gbeta, coef);
+    BH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(apply_blocks(g), groups), dim3(256), 0, s, gy, y, x, gamma, beta, coef,
+                       gx, gres, g, flags);
     BH_LAUNCH_CHECK();
     return BH_OK;
 }
+
+int bh_bn_scratch_doubles(int groups, int C) { return groups * C * 2 * (1 + BN_MAX_CHUNKS); }
 
 }  // extern "C"

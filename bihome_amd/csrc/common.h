@@ -10,7 +10,26 @@
         if (e__ != hipSuccess) return (int)e__;            \
     } while (0)
 
+// BatchNorm sums buffers: entry (group, channel, moment) lives at double index ((group*C + channel)*2 + moment) *
+// BH_BN_SUM_STRIDE, i.e. on its own 128-byte line - f64 atomics to one line are serialised by the memory-side atomic
+// unit, and a whole reduce kernel's workgroups arrive within a few microseconds of each other
+#define BH_BN_SUM_STRIDE 16
+// (replicating the table over several slots was measured too: the consumers' extra strided loads cost more than the
+// shorter atomic tail saves, so there is one slot)
+#define BH_BN_SUM_SLOTS 1
+#define BH_BN_SUM_DOUBLES(groups, C) ((size_t)BH_BN_SUM_SLOTS * (groups) * (C) * 2 * BH_BN_SUM_STRIDE)
+
 static inline hipStream_t bh_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+__device__ __forceinline__ size_t bn_sum_index(int slot, int groups, int grp, int C, int c, int mom) {
+    return ((((size_t)slot * groups + grp) * C + c) * 2 + mom) * BH_BN_SUM_STRIDE;
+}
+__device__ __forceinline__ double bn_sum_total(const double* __restrict__ buf, int groups, int grp, int C, int c, int mom) {
+    double t = 0;
+#pragma unroll
+    for (int s = 0; s < BH_BN_SUM_SLOTS; ++s) t += buf[bn_sum_index(s, groups, grp, C, c, mom)];
+    return t;
+}
 
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {

@@ -33,6 +33,8 @@ struct C3Args {
     int accumulate;
     unsigned src_bytes, w_bytes;
     int tiles_x, tiles_per_img, subtiles;
+    double* bn_sums;       // optional [groups][Nn][2]: += per-channel (sum, sum of squares) of the output (forward only)
+    int imgs_per_group, groups;
 };
 
 constexpr int C3_HALO_BYTES = 8 * 200 * 16;          // 25600
@@ -175,21 +177,62 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
     // ---- epilogue: C/D layout col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m) ----
     const int g = blockIdx.x * 2 + wm;
     const int n = n0 + wn * 32 + l31;
-    if (g >= a.subtiles || n >= a.Nn) return;
-    const int img = g / a.tiles_per_img, t = g - img * a.tiles_per_img;
+    const bool valid = g < a.subtiles && n < a.Nn;
+    const int gg = g < a.subtiles ? g : 0;
+    const int img = gg / a.tiles_per_img, t = gg - img * a.tiles_per_img;
     const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
-    const float bv = a.bias ? a.bias[n] : 0.0f;
+    const float bv = (a.bias && n < a.Nn) ? a.bias[n] : 0.0f;
+    double s1 = 0.0, s2 = 0.0;                     // BatchNorm statistics of the tile (a.bn_sums): sum y, sum y^2
+    if (valid) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = (i + wh) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh2;
-            const int y = ty * 8 + (m >> 3), x = tx * 8 + (m & 7);
-            const size_t off = ((size_t)(img * a.H + y) * a.W + x) * a.Nn + n;
-            float v = acc[i][r] + bv;
-            if (a.accumulate) v += a.Out[off];
-            a.Out[off] = v;
+            for (int r = 0; r < 16; ++r) {
+                const int m = (i + wh) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh2;
+                const int y = ty * 8 + (m >> 3), x = tx * 8 + (m & 7);
+                const size_t off = ((size_t)(img * a.H + y) * a.W + x) * a.Nn + n;
+                float v = acc[i][r] + bv;
+                if (a.accumulate) v += a.Out[off];
+                a.Out[off] = v;
+                s1 += (double)v;
+                s2 += (double)v * (double)v;
+            }
+    }
+    if (a.bn_sums) {
+        // column sums: the two half-waves hold the two row halves of a column; the waves that share the channel range
+        // are merged through LDS (free after the last barrier of the main loop) when they belong to the same
+        // statistics group, then one f64 atomic per (channel, moment) goes to the [groups][C][2] totals
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        double* red = reinterpret_cast<double*>(smem);          // [4 waves][32 columns][2]
+        int* grp_of = reinterpret_cast<int*>(smem + 4 * 32 * 2 * 8);
+        const int grp = img / a.imgs_per_group;
+        if (kh2 == 0) { red[(wave * 32 + l31) * 2] = s1; red[(wave * 32 + l31) * 2 + 1] = s2; }
+        if (lane == 0) grp_of[wave] = g < a.subtiles ? grp : -1;
+        __syncthreads();
+        constexpr int SHARE = BN == 64 ? 2 : 4;                  // waves per channel range
+        // thread -> (channel range cr, column, moment); waves of range cr: BN=64: wave = wm + 2*cr; BN=32: all four
+        if (tid < (4 / SHARE) * 64) {
+            const int cr = tid >> 6, col = (tid >> 1) & 31, mom = tid & 1;
+            const int nn = n0 + cr * 32 + col;
+            if (nn < a.Nn) {
+                int done = 0;                                    // bit w: wave already merged
+#pragma unroll
+                for (int w0 = 0; w0 < SHARE; ++w0) {
+                    const int wv0 = BN == 64 ? (w0 + 2 * cr) : w0;
+                    const int g0 = grp_of[wv0];
+                    if (g0 < 0 || (done >> w0) & 1) continue;
+                    double tot = red[(wv0 * 32 + col) * 2 + mom];
+#pragma unroll
+                    for (int w1 = w0 + 1; w1 < SHARE; ++w1) {
+                        const int wv1 = BN == 64 ? (w1 + 2 * cr) : w1;
+                        if (grp_of[wv1] == g0) { tot += red[(wv1 * 32 + col) * 2 + mom]; done |= 1 << w1; }
+                    }
+                    atomicAdd(&a.bn_sums[bn_sum_index(blockIdx.x % BH_BN_SUM_SLOTS, a.groups, g0, a.Nn, nn, mom)], tot);
+                }
+            }
         }
+    }
 }
 
 static int g_c3_disable = 0, g_c3_min_blocks = 256;
@@ -200,7 +243,7 @@ void bh_conv3x3_tune(int disable, int min_blocks) {
 
 // *taken = 1 when the shape is eligible and the launch was made; returns BH_OK or a hipError_t
 int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* out, const bh_conv_desc* d, int dgrad,
-                   int accumulate, hipStream_t stream, int* taken) {
+                   int accumulate, hipStream_t stream, int* taken, double* bn_sums, int groups) {
     *taken = 0;
     if (g_c3_disable || d->transposed || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->in_nchw ||
         d->out_nchw || d->precision != 0)
@@ -215,6 +258,8 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
     a.Src = src; a.Wt = w; a.bias = bias; a.Out = out;
     a.N = d->N; a.H = d->Hi; a.W = d->Wi; a.Kc = Kc; a.Nn = Nn; a.Cw = d->Ci; a.accumulate = accumulate;
     a.src_bytes = (unsigned)src_bytes; a.w_bytes = (unsigned)w_bytes;
+    if (bn_sums && (dgrad || groups < 1 || d->N % groups)) return BH_E_BADARG;
+    a.bn_sums = bn_sums; a.imgs_per_group = bn_sums ? d->N / groups : 1; a.groups = groups;
     a.tiles_x = d->Wi / 8; a.tiles_per_img = (d->Hi / 8) * a.tiles_x; a.subtiles = d->N * a.tiles_per_img;
     dim3 grid((a.subtiles + 1) / 2, Nn / bn_tile);
     if ((int)(grid.x * grid.y) < g_c3_min_blocks) return 0;

@@ -738,7 +738,8 @@ __global__ void __launch_bounds__(256) col2im_c1_kernel(const float* __restrict_
 
 void bh_conv3x3_tune(int disable, int min_blocks);
 int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* out, const bh_conv_desc* d, int dgrad,
-                   int accumulate, hipStream_t stream, int* taken);
+                   int accumulate, hipStream_t stream, int* taken, double* bn_sums, int groups);
+int bn_launch_stats(const float* x, int groups, int rows, int C, double* sums, hipStream_t s);
 
 static int check_desc(const bh_conv_desc* d) {
     if (!d) return BH_E_BADARG;
@@ -785,7 +786,7 @@ int bh_conv_fwd(const float* x, const float* w, const float* bias, float* y, con
     if (!x || !w || !y) return BH_E_BADARG;
     {
         int taken = 0;
-        rc = bh_conv3x3_try(x, w, bias, y, d, 0, 0, bh_stream(stream), &taken);
+        rc = bh_conv3x3_try(x, w, bias, y, d, 0, 0, bh_stream(stream), &taken, nullptr, 1);
         if (rc || taken) return rc;
     }
     GemmArgs a = {};
@@ -810,6 +811,19 @@ int bh_conv_fwd(const float* x, const float* w, const float* bias, float* y, con
     return dispatch(a, bh_stream(stream));
 }
 
+int bh_conv_fwd_bnstats(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, double* sums,
+                        int groups, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!x || !w || !y || !sums || groups < 1 || d->N % groups || d->out_nchw || d->transposed) return BH_E_BADARG;
+    int taken = 0;
+    rc = bh_conv3x3_try(x, w, bias, y, d, 0, 0, bh_stream(stream), &taken, sums, groups);
+    if (rc || taken) return rc;
+    rc = bh_conv_fwd(x, w, bias, y, d, stream);
+    if (rc) return rc;
+    return bn_launch_stats(y, groups, (d->N / groups) * d->Ho * d->Wo, d->Co, sums, bh_stream(stream));
+}
+
 int bh_conv_dgrad(const float* gy, const float* w, float* gx, const bh_conv_desc* d, int accumulate, void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
@@ -817,7 +831,7 @@ int bh_conv_dgrad(const float* gy, const float* w, float* gx, const bh_conv_desc
     if (d->in_nchw && (d->transposed || accumulate)) return BH_E_UNSUPPORTED;
     {
         int taken = 0;
-        rc = bh_conv3x3_try(gy, w, nullptr, gx, d, 1, accumulate, bh_stream(stream), &taken);
+        rc = bh_conv3x3_try(gy, w, nullptr, gx, d, 1, accumulate, bh_stream(stream), &taken, nullptr, 1);
         if (rc || taken) return rc;
     }
     if (!d->transposed && d->Ci == 1 && !d->out_nchw && !accumulate && d->Co % 4 == 0 && d->Co <= 256 &&

@@ -284,11 +284,18 @@ def conv_out_shape(d):
     return (d.N, d.Co, d.Ho, d.Wo) if d.out_nchw else (d.N, d.Ho, d.Wo, d.Co)
 
 
-def conv_fwd(x, w, bias, d):
+def conv_fwd(x, w, bias, d, bn_sums=None, groups=1):
+    """bn_sums: zeroed [groups*Co*2] float64 buffer - the conv also accumulates the batch statistics of its output for the
+    BatchNorm that follows (bn_fwd(..., stats=bn_sums, stats_ready=True))."""
     _chk(x); _chk(w); _chk(bias)
     y = torch.empty(conv_out_shape(d), dtype=torch.float32, device=x.device)
     with _Timed(_conv_variant(d, "fwd"), conv_flops(d), 4.0 * (x.numel() + y.numel() + w.numel())):
-        check(lib.bh_conv_fwd(_p(x), _p(w), _p(bias), _p(y), ctypes.byref(d), _stream()), "bh_conv_fwd")
+        if bn_sums is None:
+            check(lib.bh_conv_fwd(_p(x), _p(w), _p(bias), _p(y), ctypes.byref(d), _stream()), "bh_conv_fwd")
+        else:
+            _chk(bn_sums, torch.float64)
+            check(lib.bh_conv_fwd_bnstats(_p(x), _p(w), _p(bias), _p(y), ctypes.byref(d), _p(bn_sums), groups, _stream()),
+                  "bh_conv_fwd_bnstats")
     return y
 
 
@@ -336,33 +343,47 @@ def conv_wgrad(x, gy, gw, gbias, d):
         check(lib.bh_conv_wgrad(_p(x), _p(gy), _p(gw), _p(gbias), ctypes.byref(d), _stream()), "bh_conv_wgrad")
 
 
+BN_SUM_STRIDE = 16                                     # doubles between entries (one 128-byte line each; csrc/common.h)
+BN_SUM_SLOTS = 1
+
+
+def bn_stats_doubles(groups, C):
+    return BN_SUM_SLOTS * groups * C * 2 * BN_SUM_STRIDE    # == lib.bh_bn_stats_doubles(groups, C)
+
+
 def bn_stats_buffer(groups, C, device):
-    return torch.empty(lib.bh_bn_stats_doubles(groups, C), dtype=torch.float64, device=device)
+    """Zeroed [BN_SUM_SLOTS,groups,C,2,BN_SUM_STRIDE] float64 sums buffer (entry at [...,0], total = sum over slots; the
+    kernels accumulate with f64 atomics)."""
+    return torch.zeros(lib.bh_bn_stats_doubles(groups, C), dtype=torch.float64, device=device)
 
 
-def bn_fwd(x, gamma, beta, rmean, rvar, res, groups, eps, momentum, relu, training):
-    """x [groups*rows..., C] NHWC (any leading shape); returns (y, stats)."""
+def bn_fwd(x, gamma, beta, rmean, rvar, res, groups, eps, momentum, relu, training, stats=None, stats_ready=False):
+    """x [groups*rows..., C] NHWC (any leading shape); returns (y, stats).  stats: optional zeroed sums buffer (a slice of
+    the caller's arena); stats_ready: the producing conv already accumulated the sums (conv_fwd(..., bn_sums=stats))."""
     _chk(x); _chk(res)
     C = x.shape[-1]
     rows = x.numel() // C // groups
     y = torch.empty_like(x)
-    stats = bn_stats_buffer(groups, C, x.device)
-    flags = (1 if relu else 0) | (2 if res is not None else 0)
-    nb = 4.0 * x.numel() * ((2 if training else 1) + 1 + (1 if res is not None else 0))
-    with _Timed("bn_fwd(3 kernels)" + (" g%d rows%d C%d" % (groups, rows, C) if TIMING_DETAIL else ""), 0.0, nb):
+    if stats is None:
+        stats = bn_stats_buffer(groups, C, x.device)
+        stats_ready = False
+    flags = (1 if relu else 0) | (2 if res is not None else 0) | (8 if stats_ready else 0)
+    nb = 4.0 * x.numel() * ((2 if (training and not stats_ready) else 1) + 1 + (1 if res is not None else 0))
+    with _Timed("bn_fwd(%d kernels)" % (2 if (training and not stats_ready) else 1) + (" g%d rows%d C%d" % (groups, rows, C) if TIMING_DETAIL else ""), 0.0, nb):
         check(lib.bh_bn_fwd(_p(x), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(res), _p(y), _p(stats), groups, rows, C,
                             float(eps), float(momentum), flags, 0 if training else 1, _stream()), "bh_bn_fwd")
     return y, stats
 
 
 def bn_bwd(gy, y, x, gamma, stats, rmean, rvar, groups, eps, relu, training, want_gres, ggamma=None, gbeta=None, beta=None,
-           had_res=None):
+           had_res=None, scratch=None):
     _chk(gy); _chk(x)
     C = x.shape[-1]
     rows = x.numel() // C // groups
     gx = torch.empty_like(x)
     gres = torch.empty_like(x) if want_gres else None
-    scratch = bn_stats_buffer(groups, C, x.device)
+    if scratch is None:
+        scratch = torch.empty(lib.bh_bn_scratch_doubles(groups, C), dtype=torch.float64, device=x.device)
     had_res = want_gres if had_res is None else had_res
     mask_from_x = relu and not had_res          # y = relu(x*scale+shift): the mask is recomputed, y is not read
     flags = (1 if relu else 0) | (2 if want_gres else 0) | (4 if mask_from_x else 0)

@@ -202,6 +202,28 @@ def run_forward(prog, x, groups, training, save, precision=0):
     slots = {0: x}
     if save:
         ctx.groups, ctx.training = groups, training
+    # BatchNorm sums: one zeroed float64 arena for the whole pass (the kernels accumulate with atomics); a conv whose
+    # only consumer is a training-mode BatchNorm accumulates that layer's statistics in its own epilogue
+    bn_off, total = {}, 0
+    for i, op in enumerate(prog.ops):
+        if op.kind == "bn":
+            bn_off[i] = total
+            total += K.bn_stats_doubles(groups, op.mod.num_features)
+    arena = torch.zeros(total, dtype=torch.float64, device=x.device) if total else None
+    fused_stats = {}                                      # conv op index -> bn op index
+    if training:
+        users = {}
+        for op in prog.ops:
+            users[op.src] = users.get(op.src, 0) + 1
+            if op.res is not None:
+                users[op.res] = users.get(op.res, 0) + 1
+        producer = {op.dst: j for j, op in enumerate(prog.ops)}
+        for i, op in enumerate(prog.ops):
+            j = producer.get(op.src)
+            if (op.kind == "bn" and j is not None and prog.ops[j].kind == "conv" and users.get(op.src, 0) == 1
+                    and not prog.ops[j].extra["out_nchw"] and not isinstance(prog.ops[j].mod, nn.ConvTranspose2d)):
+                fused_stats[j] = i
+    ready = set()
     for i, op in enumerate(prog.ops):
         src = slots[op.src]
         if op.kind == "conv":
@@ -209,14 +231,22 @@ def run_forward(prog, x, groups, training, save, precision=0):
             d = _conv_geometry(op.mod, src.shape, e["in_nchw"], e["out_nchw"], precision)
             w = e["weight_fn"](op.mod.weight) if e["weight_fn"] else op.mod.weight
             wk = kview(w)
-            out = K.conv_fwd(src, wk, op.mod.bias, d)
+            if i in fused_stats and d.N % groups == 0:
+                b = fused_stats[i]
+                out = K.conv_fwd(src, wk, op.mod.bias, d,
+                                 bn_sums=arena[bn_off[b]:bn_off[b] + K.bn_stats_doubles(groups, d.Co)], groups=groups)
+                ready.add(b)
+            else:
+                out = K.conv_fwd(src, wk, op.mod.bias, d)
             if save:
                 ctx.descs[i], ctx.weights[i] = d, wk
         elif op.kind == "bn":
             m = op.mod
             res = slots[op.res] if op.res is not None else None
             out, st = K.bn_fwd(src, m.weight, m.bias, m.running_mean, m.running_var, res, groups, m.eps,
-                               m.momentum if m.momentum is not None else 0.1, op.relu, training)
+                               m.momentum if m.momentum is not None else 0.1, op.relu, training,
+                               stats=arena[bn_off[i]:bn_off[i] + K.bn_stats_doubles(groups, m.num_features)],
+                               stats_ready=i in ready)
             if training:        # flushed to the `num_batches_tracked` buffer lazily (flush_counters): no per-layer launch
                 m._bh_pending_batches = getattr(m, "_bh_pending_batches", 0) + groups
             if save:

@@ -120,6 +120,12 @@ typedef struct {
 int bh_debug_force_tile(int bm, int bn);
 /* y = conv(x, w) (+ bias[Co] if bias != NULL) */
 int bh_conv_fwd(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, void* stream);
+/* y = conv(x, w) + bias, and sums (bh_bn_stats_doubles(groups, Co) doubles, caller-zeroed) += per-channel (sum y, sum y^2) of each of the
+ * `groups` sub-batches stacked along N: the batch statistics of the BatchNorm that follows, accumulated in the conv
+ * epilogue where the halo-tiled 3x3 kernel applies (one extra statistics launch otherwise).  Pass the buffer to
+ * bh_bn_fwd with flags bit3.  NHWC output, not transposed. */
+int bh_conv_fwd_bnstats(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, double* sums,
+                        int groups, void* stream);
 /* gx = conv^T(gy, w)  (overwritten; accumulate != 0: gx += ..., used where gradient branches join).
  * d->in_nchw: gx is written NCHW (gradient w.r.t. an NCHW network input; no accumulate, not transposed). */
 int bh_conv_dgrad(const float* gy, const float* w, float* gx, const bh_conv_desc* d, int accumulate, void* stream);
@@ -137,9 +143,13 @@ int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, cons
  *   stats[groups, C, 2] double = {mean, biased var}; running stats are updated group after group
  *   with `momentum`, unbiased variance, exactly like consecutive nn.BatchNorm2d calls.
  *   flags: bit0 relu, bit1 residual add (y = act(bn(x) + res)). eval mode: use_running = 1. */
-/* number of doubles the `stats` (forward) and `scratch` (backward) buffers must hold:
- * [groups,C,2] results followed by per-chunk partial sums */
+/* stats (forward): bh_bn_stats_doubles() doubles = [groups,C,2] per-channel sums (sum x, sum x^2), each entry on its
+ * own 128-byte line (same-line f64 atomics serialise; layout in csrc/common.h).  Accumulated with f64 atomics: MUST BE
+ * ZERO on entry unless eval mode; flags bit3 = the sums were already accumulated by bh_conv_fwd_bnstats.  Kept for the
+ * adjoint.  scratch (backward): bh_bn_scratch_doubles() doubles, need not be initialised (coefficient table +
+ * per-chunk partial sums, reduced deterministically). */
 int bh_bn_stats_doubles(int groups, int C);
+int bh_bn_scratch_doubles(int groups, int C);
 int bh_bn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
               const float* res, float* y, double* stats, int groups, int rows, int C, float eps, float momentum,
               int flags, int use_running, void* stream);
@@ -147,7 +157,7 @@ int bh_bn_fwd(const float* x, const float* gamma, const float* beta, float* runn
  * -> gx (overwritten), gres (written when non-NULL: = masked gy), ggamma/gbeta += (NULL ok => frozen).
  * flags bit2 (only without residual): recompute the ReLU mask from x (y is not read, may be NULL). */
 int bh_bn_bwd(const float* gy, const float* y, const float* x, const float* gamma, const float* beta, const double* stats,
-              float* gx, float* gres, float* ggamma, float* gbeta, double* scratch /*[groups,C,2]*/,
+              float* gx, float* gres, float* ggamma, float* gbeta, double* scratch,
               int groups, int rows, int C, float eps, int flags, int use_running,
               const float* running_mean, const float* running_var, void* stream);
 

@@ -289,3 +289,35 @@ def test_bf16_operand_mode(K, N, Hi, Ci, Co, k, s, p):
     gw = torch.zeros_like(wg)
     K.conv_wgrad(xg, gyg, gw, None, d)
     close(gw.cpu().permute(0, 3, 1, 2), wt.grad, 1e-2)
+
+
+@pytest.mark.parametrize("N,H,Ci,Co,k,groups", [
+    (8, 16, 32, 64, 3, 2),      # halo-tiled 3x3 kernel, BN = 64: statistics in the conv epilogue
+    (6, 8, 64, 32, 3, 2),       # BN = 32 variant; 8x8 images: the two sub-tiles of a workgroup can sit in different groups
+    (2, 8, 32, 64, 3, 2),       # one image per group: every workgroup straddles the group boundary
+    (4, 8, 16, 32, 1, 2),       # 1x1 conv: generic kernel + statistics launch
+])
+def test_conv_fwd_with_batchnorm_sums(K, N, H, Ci, Co, k, groups):
+    """bh_conv_fwd_bnstats: per-group, per-channel (sum y, sum y^2) of the conv output, as BatchNorm consumes them."""
+    from bihome_amd._lib import lib
+    lib.bh_debug_force_tile(-5, 1)          # let the halo kernel take these small grids
+    try:
+        x = torch.tensor(rnd((N, H, H, Ci), 70)).cuda()
+        w = torch.tensor(rnd((Co, k, k, Ci), 71) * 0.1).cuda()
+        b = torch.tensor(rnd((Co,), 72)).cuda()
+        d = K.conv_desc(N, H, H, Ci, Co, k, 1, k // 2)
+        sums = K.bn_stats_buffer(groups, Co, "cuda")
+        y = K.conv_fwd(x, w, b, d, bn_sums=sums, groups=groups)
+        y0 = K.conv_fwd(x, w, b, d)
+        assert torch.equal(y, y0)
+        yd = y0.double().reshape(groups, -1, Co)
+        ref = torch.stack([yd.sum(1), (yd * yd).sum(1)], -1)          # [groups, Co, 2]
+        close(sums.reshape(K.BN_SUM_SLOTS, groups, Co, 2, K.BN_SUM_STRIDE)[..., 0].sum(0).cpu(), ref.cpu(), 1e-6)
+        # and through BatchNorm: identical output whether the sums come from the conv or from the statistics kernel
+        gm, bt = torch.ones(Co, device="cuda"), torch.zeros(Co, device="cuda")
+        rm, rv = torch.zeros(Co, device="cuda"), torch.ones(Co, device="cuda")
+        o1, _ = K.bn_fwd(y, gm, bt, rm.clone(), rv.clone(), None, groups, 1e-5, 0.1, True, True, stats=sums, stats_ready=True)
+        o2, _ = K.bn_fwd(y, gm, bt, rm.clone(), rv.clone(), None, groups, 1e-5, 0.1, True, True)
+        close(o1.cpu(), o2.cpu(), 1e-5)
+    finally:
+        lib.bh_debug_force_tile(-5, 256)
