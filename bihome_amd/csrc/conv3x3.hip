@@ -20,7 +20,15 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x8v __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+// two k-planes (2 x float4) of a fragment -> the 8 bf16 operands of one v_mfma_f32_32x32x16_bf16 lane (round to nearest even)
+__device__ __forceinline__ bf16x8 c3_pack_bf16(const float4& lo, const float4& hi) {
+    f32x8v v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return __builtin_convertvector(v, bf16x8);
+}
 
 struct C3Args {
     const float* Src;
@@ -43,7 +51,10 @@ constexpr int C3_LDS_BYTES = 2 * C3_HALO_BYTES + 2 * C3_B_BYTES;      // 67584
 
 // BN = 64: wave (wm, wn) owns sub-tile wm x channels [32 wn, 32 wn + 32) (two A fragments per B fragment);
 // BN = 32: wave w owns rows [32 w, 32 w + 32) of the 128-row tile x all 32 channels (the 32-channel decoder layers).
-template <bool FLIP, int BN>
+// BF16 (bh_conv_desc.precision = 1): same fp32 LDS image, the fragments are rounded to bf16 in registers and fed to
+// v_mfma_f32_32x32x16_bf16 (16 channels per instruction: half-wave 0 holds planes 4s, 4s+2, half-wave 1 planes 4s+1,
+// 4s+3 of the A and of the B fragment alike); fp32 accumulate.  The MFMA time drops 16x, the kernel becomes LDS-bound.
+template <bool FLIP, int BN, bool BF16 = false>
 __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
     constexpr int TM = BN == 64 ? 2 : 1;
     constexpr int BINS = BN == 64 ? 2 : 1;                 // weight-slab wave instructions per wave and step
@@ -154,6 +165,15 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
             if (tap < 8) issue_B(c, tap + 1, bs ^ 1);
             else if (more) issue_B(c + 1, 0, bs ^ 1);
             if (tap < 7 && more) C3_ISSUE_HALO(tap, c + 1, hs ^ 1);
+            if constexpr (BF16) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 bb = c3_pack_bf16(b[2 * s2], b[2 * s2 + 1]);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c3_pack_bf16(af[i][2 * s2], af[i][2 * s2 + 1]), bb, acc[i], 0, 0, 0);
+                }
+            } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -164,6 +184,7 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
                 for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q].z, b[q].z, acc[i], 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q].w, b[q].w, acc[i], 0, 0, 0);
+            }
             }
             __builtin_amdgcn_sched_barrier(0);      // keep the MFMAs of this step in front of the wait: they hide the DMA
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -246,7 +267,7 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
                    int accumulate, hipStream_t stream, int* taken, double* bn_sums, int groups) {
     *taken = 0;
     if (g_c3_disable || d->transposed || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->in_nchw ||
-        d->out_nchw || d->precision != 0)
+        d->out_nchw || (d->precision != 0 && d->precision != 1))
         return 0;
     if (d->Hi % 8 || d->Wi % 8 || d->Ho != d->Hi || d->Wo != d->Wi) return 0;
     const int Kc = dgrad ? d->Co : d->Ci, Nn = dgrad ? d->Ci : d->Co;
@@ -264,24 +285,21 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
     dim3 grid((a.subtiles + 1) / 2, Nn / bn_tile);
     if ((int)(grid.x * grid.y) < g_c3_min_blocks) return 0;
     static bool attr_set = false;
-    const void* fns[4] = {reinterpret_cast<const void*>(conv3x3_halo_kernel<false, 64>),
-                          reinterpret_cast<const void*>(conv3x3_halo_kernel<true, 64>),
-                          reinterpret_cast<const void*>(conv3x3_halo_kernel<false, 32>),
-                          reinterpret_cast<const void*>(conv3x3_halo_kernel<true, 32>)};
+    typedef void (*kern_t)(C3Args);
+    static const kern_t fns[8] = {conv3x3_halo_kernel<false, 64, false>, conv3x3_halo_kernel<true, 64, false>,
+                                  conv3x3_halo_kernel<false, 32, false>, conv3x3_halo_kernel<true, 32, false>,
+                                  conv3x3_halo_kernel<false, 64, true>,  conv3x3_halo_kernel<true, 64, true>,
+                                  conv3x3_halo_kernel<false, 32, true>,  conv3x3_halo_kernel<true, 32, true>};
     if (!attr_set) {
-        for (int i = 0; i < 4; ++i) {
-            hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS_BYTES);
+        for (int i = 0; i < 8; ++i) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[i]), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               C3_LDS_BYTES);
             if (e != hipSuccess) return (int)e;
         }
         attr_set = true;
     }
-    if (bn_tile == 64) {
-        if (!dgrad) hipLaunchKernelGGL((conv3x3_halo_kernel<false, 64>), grid, dim3(256), C3_LDS_BYTES, stream, a);
-        else hipLaunchKernelGGL((conv3x3_halo_kernel<true, 64>), grid, dim3(256), C3_LDS_BYTES, stream, a);
-    } else {
-        if (!dgrad) hipLaunchKernelGGL((conv3x3_halo_kernel<false, 32>), grid, dim3(256), C3_LDS_BYTES, stream, a);
-        else hipLaunchKernelGGL((conv3x3_halo_kernel<true, 32>), grid, dim3(256), C3_LDS_BYTES, stream, a);
-    }
+    const kern_t fn = fns[(d->precision == 1 ? 4 : 0) + (bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0)];
+    hipLaunchKernelGGL(fn, grid, dim3(256), C3_LDS_BYTES, stream, a);
     BH_LAUNCH_CHECK();
     *taken = 1;
     return BH_OK;

@@ -84,7 +84,7 @@ C3_MIN_BLOCKS = 256          # mirror of conv3x3.hip g_c3_min_blocks
 def _c3_variant(d, dgrad):
     """Mirror of bh_conv3x3_try: the halo-tiled 3x3 kernel's symbol when the launch is eligible, else None."""
     if (d.transposed or d.kh != 3 or d.kw != 3 or d.stride != 1 or d.pad != 1 or d.in_nchw or d.out_nchw
-            or d.precision != 0 or d.Hi % 8 or d.Wi % 8):
+            or d.precision not in (0, 1) or d.Hi % 8 or d.Wi % 8):
         return None
     Kc, Nn = (d.Co, d.Ci) if dgrad else (d.Ci, d.Co)
     if Kc % 32 or Nn % 32 or d.N * d.Hi * d.Wi * Kc * 4 >= 2 ** 31:
@@ -92,7 +92,7 @@ def _c3_variant(d, dgrad):
     bn = 32 if Nn % 64 else 64
     if ((d.N * (d.Hi // 8) * (d.Wi // 8) + 1) // 2) * (Nn // bn) < C3_MIN_BLOCKS:
         return None
-    return "conv3x3_halo_kernel<%s,%d>" % ("true" if dgrad else "false", bn)
+    return "conv3x3_halo_kernel<%s,%d,%s>" % ("true" if dgrad else "false", bn, "true" if d.precision == 1 else "false")
 
 
 def _conv_variant0(d, which):

@@ -19,4 +19,4 @@ for name,r in K.TIMING.items():
 rows.sort(reverse=True)
 tot=sum(r[0] for r in rows)
 print('total timed ms/step', tot)
-for r in rows[:34]: print('%8.3f ms x%d %7.1f TF %7.0f GB/s  %s'%r)
+for r in rows[:70]: print('%8.3f ms x%d %7.1f TF %7.0f GB/s  %s'%r)
