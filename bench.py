@@ -57,14 +57,17 @@ def cpu_baseline(cfg, seed=42, batch=8, steps=3, warmup=1):
     torch.set_num_threads(cores)
     bb, head = O.build(cfg)
     load_synthetic(bb, 0)
-    load_synthetic(head.auxiliary_resnet, 0)
+    if hasattr(head, "auxiliary_resnet"):
+        load_synthetic(head.auxiliary_resnet, 0)
     opt, sched = O.make_optimizer(torch.nn.Sequential(bb, head), cfg["SOLVER"])
-    d = synth.make_pairs(batch, seed=seed)
+    d = synth.make_pairs(batch, seed=seed, target=True)
+    name = cfg["SOLVER"]["LOSS"]
+    loss_fn = getattr(torch.nn, name)() if hasattr(torch.nn, name) else None     # supervised "-orig" configs
     times, budget_s, t_begin = [], 40.0, time.perf_counter()
     for it in range(warmup + steps):
-        data = {k: torch.tensor(d[k]) for k in ("patch_1", "patch_2", "delta")}
+        data = {k: torch.tensor(d[k]) for k in ("patch_1", "patch_2", "delta", "target")}
         t0 = time.perf_counter()
-        O.train_step(bb, head, opt, sched, data)
+        O.train_step(bb, head, opt, sched, data, loss_fn=loss_fn)
         times.append(time.perf_counter() - t0)
         if time.perf_counter() - t_begin > budget_s and len(times) > warmup:      # bounded sample
             break
@@ -99,7 +102,7 @@ def roofline_leg(model, data, opt, sched, reducer, nsteps=2):
     from bihome_amd.step import train_step
     K.TIMING = {}
     for _ in range(nsteps):
-        train_step(model, dict(data), opt, sched, reducer=reducer)
+        train_step(model, dict(data), opt, sched, reducer=reducer, loss_fn=LOSS_FN[0])
     torch.cuda.synchronize()
     rows = []
     for name, r in K.TIMING.items():
@@ -125,7 +128,11 @@ def roofline_leg(model, data, opt, sched, reducer, nsteps=2):
     return roof, rows
 
 
+LOSS_FN = ["biHomE"]           # the loss of the running config (roofline_leg re-runs train steps)
+
 WORKLOADS = {
+    "zeng-orig": "config/s-coco/zeng-orig (supervised SmoothL1 on the perspective field, OneLine Zeng backbone)",
+    "detone-orig": "config/s-coco/detone-orig (supervised MSE on the 4-point offsets, ResNet-34 regressor)",
     "zeng-bihome": "BASELINE.json configs[1]: s-coco Zeng (Rethinking/ResNet34 blocks)",
     "zeng-bihome-pds": "BASELINE.json configs[2]: pds-coco Zeng (photometric-distorted)",
     "detone-bihome": "BASELINE.json configs[3]: s-coco ResNet-34 regressor",
@@ -162,7 +169,8 @@ def main():
     cfg["MODEL"]["HEAD"]["PRECISION"] = args.precision
     model = build_model(cfg, "cuda")
     load_synthetic(model[0], 0)                       # identical replicas on every rank
-    load_synthetic(model[1].auxiliary_resnet, 0)
+    if hasattr(model[1], "auxiliary_resnet"):
+        load_synthetic(model[1].auxiliary_resnet, 0)
     opt, sched = build_optimizer(model, cfg["SOLVER"])
     reducer = attach_reducer(model) if world > 1 else None
 
@@ -171,9 +179,13 @@ def main():
     # from seeds, then resident in HBM for the whole run
     D = cfg["DATA"]
     P, CH = D["PATCH_SIZE"], D.get("PATCH_CHANNELS", 1)
+    KEYS = ("patch_1", "patch_2", "delta", "target", "corners")
     d = synth.make_pairs(B, patch=P, rho=D["RHO"], seed=42 + rank, photometric_max_delta=D["PHOTOMETRIC_MAX_DELTA"],
-                         channels=CH)
-    data = {k: torch.tensor(d[k]).cuda() for k in ("patch_1", "patch_2", "delta")}
+                         channels=CH, target=CH == 1)
+    data = {k: torch.tensor(d[k]).cuda() for k in KEYS if k in d}
+    from bihome_amd.step import build_loss
+    loss_fn = build_loss(cfg["SOLVER"])
+    LOSS_FN[0] = loss_fn
     torch.manual_seed(1234 + rank)                    # DSAC sample indices: per-rank stream
 
     def sync():
@@ -190,11 +202,11 @@ def main():
         return gen.next(B) if gen is not None else dict(data)
 
     for _ in range(args.warmup):
-        loss, dgt, dh = train_step(model, batch(), opt, sched, reducer=reducer)
+        loss, dgt, dh = train_step(model, batch(), opt, sched, reducer=reducer, loss_fn=loss_fn)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, dgt, dh = train_step(model, batch(), opt, sched, reducer=reducer)
+        loss, dgt, dh = train_step(model, batch(), opt, sched, reducer=reducer, loss_fn=loss_fn)
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -204,6 +216,13 @@ def main():
     ms = 1e3 * dt / args.steps
     value = world * B * args.steps / dt
     final_loss, final_mace = float(loss.item()), mace(dgt, dh)
+
+    # inference leg (eval.py:80-112): eval-mode forward + DLT on fresh batches, BatchNorms folded into the convs
+    from bihome_amd.step import evaluate
+    ev = [{k: torch.tensor(v).cuda() for k, v in synth.make_pairs(B, patch=P, rho=D["RHO"], seed=1000 + rank + 7 * i,
+                                                                   channels=CH, target=CH == 1).items() if k in KEYS}
+          for i in range(2)]
+    eval_mace, eval_ms = evaluate(model, [ev[i % 2] for i in range(6)])
 
     roof, rows = (None, None)
     if not args.no_roofline:
@@ -220,12 +239,16 @@ def main():
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
             "data": "synthetic (seeded COCO-style texture pairs, random-init weights%s)" % (
                 "; fresh batch per step from the device-side generator" if args.gpu_datagen else "; one resident batch"),
-            "config": {"workload": "%s: %s backbone + biHomE head, %d pairs/GPU, %dx%d %s, %s MFMA conv + HIP "
+            "config": {"workload": "%s: %s backbone + %s head, %d pairs/GPU, %dx%d %s, %s MFMA conv + HIP "
                                    "warp/DLT/triplet kernels" % (
-                                       WORKLOADS.get(args.config, args.config), cfg["MODEL"]["BACKBONE"]["NAME"], B, P, P,
+                                       WORKLOADS.get(args.config, args.config), cfg["MODEL"]["BACKBONE"]["NAME"],
+                                       cfg["MODEL"]["HEAD"]["NAME"], B, P, P,
                                        "RGB" if CH == 3 else "grayscale", args.precision),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "optimizer": "Adam lr 1e-3"},
             "final_loss": final_loss, "final_mace": final_mace,
+            "eval": {"mace": eval_mace, "ms_per_batch": eval_ms, "pairs_per_s_per_gpu": 1e3 * B / eval_ms,
+                     "note": "predict_homography in eval mode (BatchNorm folded), held-out synthetic pairs, random-init "
+                             "weights after the timed steps"},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if rows:

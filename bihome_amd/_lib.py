@@ -33,6 +33,7 @@ SIGNATURES = {
     "bh_bihome_loss_bwd": [P] * 14 + [c_int, c_int, c_int, c_float] + [P] * 6 + [P],
     "bh_debug_force_tile": [c_int, c_int],
     "bh_conv_fwd": [P, P, P, P, POINTER(BhConvDesc), P],
+    "bh_conv_fwd_act": [P, P, P, P, P, POINTER(BhConvDesc), c_int, P],
     "bh_conv_fwd_bnstats": [P, P, P, P, POINTER(BhConvDesc), P, c_int, P],
     "bh_conv_dgrad": [P, P, P, POINTER(BhConvDesc), c_int, P],
     "bh_col2im_c1": [P, P, POINTER(BhConvDesc), c_int, P],

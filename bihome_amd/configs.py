@@ -53,6 +53,38 @@ DETONE_BIHOME = {
 }
 
 
+# the supervised baselines of the same two backbones (config/s-coco/zeng-orig-lr-1e-3.yaml, detone-orig-lr-5e-3.yaml):
+# one direction only (VARIANT OneLine), NoOpHead, a torch loss on (target, output) - train.py:318-322
+ZENG_ORIG = {
+    "MODEL": {
+        "BACKBONE": {
+            "NAME": "Rethinking", "VARIANT": "OneLine", "IMAGE_SIZE": 128, "RESNET_BLOCK": "ResNet34",
+            "PRETRAINED_RESNET": False, "IMAGE_KEY": ["image"], "PATCH_KEYS": ["patch_1", "patch_2"],
+            "TARGET_KEYS": ["pf_hat_12"],
+        },
+        "HEAD": {"NAME": "NoOpHead", "TARGET_GEN": "all_points",
+                 "LEARNING_KEYS": ["target", "pf_hat_12", "delta", "pf_hat_12"]},
+    },
+    "SOLVER": {"OPTIMIZER": "Adam", "MOMENTUM_1": 0.9, "MOMENTUM_2": 0.999, "LR": 0.001,
+               "MILESTONES": [30000, 60000, 90000], "LR_DECAY": 0.1, "LOSS": "SmoothL1Loss"},
+    "DATA": {"BATCH_SIZE": 64, "RHO": 32, "PATCH_SIZE": 128, "PHOTOMETRIC_MAX_DELTA": 0, "TARGET_GEN": "all_points"},
+}
+
+DETONE_ORIG = {
+    "MODEL": {
+        "BACKBONE": {
+            "NAME": "ResNet34", "VARIANT": "OneLine", "PRETRAINED_RESNET": False,
+            "IMAGE_KEY": ["image"], "PATCH_KEYS": ["patch_1", "patch_2"], "TARGET_KEYS": ["delta_hat_12"],
+        },
+        "HEAD": {"NAME": "NoOpHead", "TARGET_GEN": "4_points",
+                 "LEARNING_KEYS": ["delta", "delta_hat_12", "delta", "delta_hat_12"]},
+    },
+    "SOLVER": {"OPTIMIZER": "Adam", "MOMENTUM_1": 0.9, "MOMENTUM_2": 0.999, "LR": 0.005,
+               "MILESTONES": [30000, 60000, 90000], "LR_DECAY": 0.1, "LOSS": "MSELoss"},
+    "DATA": {"BATCH_SIZE": 64, "RHO": 32, "PATCH_SIZE": 128, "PHOTOMETRIC_MAX_DELTA": 0, "TARGET_GEN": "4_points"},
+}
+
+
 def get(name):
     """'zeng-bihome' / 'detone-bihome' = config/s-coco/*; the '-pds' variants = config/pds-coco/* (the two trees differ
     only in HomographyNetPrep's photometric max_delta, 0 vs 32, and the log dir).  'zeng-bihome-rgb256' is the
@@ -65,7 +97,8 @@ def get(name):
         cfg["DATA"].update(BATCH_SIZE=32, RHO=64, PATCH_SIZE=256, PATCH_CHANNELS=3)
         return cfg
     base = name[:-4] if name.endswith("-pds") else name
-    cfg = copy.deepcopy({"zeng-bihome": ZENG_BIHOME, "detone-bihome": DETONE_BIHOME}[base])
+    cfg = copy.deepcopy({"zeng-bihome": ZENG_BIHOME, "detone-bihome": DETONE_BIHOME, "zeng-orig": ZENG_ORIG,
+                         "detone-orig": DETONE_ORIG}[base])
     if name.endswith("-pds"):
         cfg["DATA"]["PHOTOMETRIC_MAX_DELTA"] = 32
     return cfg

@@ -41,6 +41,8 @@ struct C3Args {
     int accumulate;
     unsigned src_bytes, w_bytes;
     int tiles_x, tiles_per_img, subtiles;
+    const float* res;      // optional residual (same layout as Out) and ReLU applied in the epilogue (inference path)
+    int relu;
     double* bn_sums;       // optional [groups][Nn][2]: += per-channel (sum, sum of squares) of the output (forward only)
     int imgs_per_group, groups;
 };
@@ -214,6 +216,8 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
                 const size_t off = ((size_t)(img * a.H + y) * a.W + x) * a.Nn + n;
                 float v = acc[i][r] + bv;
                 if (a.accumulate) v += a.Out[off];
+                if (a.res) v += a.res[off];
+                if (a.relu) v = fmaxf(v, 0.0f);
                 a.Out[off] = v;
                 s1 += (double)v;
                 s2 += (double)v * (double)v;
@@ -264,7 +268,7 @@ void bh_conv3x3_tune(int disable, int min_blocks) {
 
 // *taken = 1 when the shape is eligible and the launch was made; returns BH_OK or a hipError_t
 int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* out, const bh_conv_desc* d, int dgrad,
-                   int accumulate, hipStream_t stream, int* taken, double* bn_sums, int groups) {
+                   int accumulate, hipStream_t stream, int* taken, double* bn_sums, int groups, const float* res, int relu) {
     *taken = 0;
     if (g_c3_disable || d->transposed || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->in_nchw ||
         d->out_nchw || (d->precision != 0 && d->precision != 1))
@@ -280,6 +284,7 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
     a.N = d->N; a.H = d->Hi; a.W = d->Wi; a.Kc = Kc; a.Nn = Nn; a.Cw = d->Ci; a.accumulate = accumulate;
     a.src_bytes = (unsigned)src_bytes; a.w_bytes = (unsigned)w_bytes;
     if (bn_sums && (dgrad || groups < 1 || d->N % groups)) return BH_E_BADARG;
+    a.res = res; a.relu = relu;
     a.bn_sums = bn_sums; a.imgs_per_group = bn_sums ? d->N / groups : 1; a.groups = groups;
     a.tiles_x = d->Wi / 8; a.tiles_per_img = (d->Hi / 8) * a.tiles_x; a.subtiles = d->N * a.tiles_per_img;
     dim3 grid((a.subtiles + 1) / 2, Nn / bn_tile);

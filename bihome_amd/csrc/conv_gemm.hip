@@ -42,6 +42,8 @@ struct GemmArgs {
     int prio;              // experiment: s_setprio(1) around the MFMA block
     int bf16;              // operands rounded to bf16 (fp32 accumulate) where the vectorised path applies
     int ek, eC;            // scatter: kernel (== stride) and real channel count (Nn = ek*ek*eC)
+    const float* res;      // optional residual added in the epilogue (same layout as Out)
+    int relu;              // epilogue ReLU (inference: BatchNorm folded into the weights, activation fused)
 };
 
 
@@ -546,6 +548,8 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
                     }
                 }
                 if (a.accumulate) v += a.Out[off];
+                if (a.res) v += a.res[off];
+                if (a.relu) v = fmaxf(v, 0.0f);
                 a.Out[off] = v;
             }
         }
@@ -738,7 +742,8 @@ __global__ void __launch_bounds__(256) col2im_c1_kernel(const float* __restrict_
 
 void bh_conv3x3_tune(int disable, int min_blocks);
 int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* out, const bh_conv_desc* d, int dgrad,
-                   int accumulate, hipStream_t stream, int* taken, double* bn_sums, int groups);
+                   int accumulate, hipStream_t stream, int* taken, double* bn_sums, int groups, const float* res = nullptr,
+                   int relu = 0);
 int bn_launch_stats(const float* x, int groups, int rows, int C, double* sums, hipStream_t s);
 
 static int check_desc(const bh_conv_desc* d) {
@@ -780,16 +785,19 @@ int bh_debug_force_tile(int bm, int bn) {
     g_force_bm = bm; g_force_bn = bn; return BH_OK;
 }
 
-int bh_conv_fwd(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, void* stream) {
+static int conv_fwd_impl(const float* x, const float* w, const float* bias, const float* res, float* y, const bh_conv_desc* d,
+                         int relu, void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!x || !w || !y) return BH_E_BADARG;
+    if (res && d->out_nchw) return BH_E_UNSUPPORTED;
     {
         int taken = 0;
-        rc = bh_conv3x3_try(x, w, bias, y, d, 0, 0, bh_stream(stream), &taken, nullptr, 1);
+        rc = bh_conv3x3_try(x, w, bias, y, d, 0, 0, bh_stream(stream), &taken, nullptr, 1, res, relu);
         if (rc || taken) return rc;
     }
     GemmArgs a = {};
+    a.res = res; a.relu = relu;
     a.Src = x; a.Bw = w; a.bias = bias; a.Out = y; a.bf16 = d->precision == 1;
     a.Hs = d->Hi; a.Ws = d->Wi; a.Cs = d->Ci; a.Kc = d->Ci;
     a.src_elems = (long long)d->N * d->Hi * d->Wi * d->Ci;
@@ -809,6 +817,15 @@ int bh_conv_fwd(const float* x, const float* w, const float* bias, float* y, con
         a.epi = 1; a.ek = d->stride; a.eC = d->Co;
     }
     return dispatch(a, bh_stream(stream));
+}
+
+int bh_conv_fwd(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, void* stream) {
+    return conv_fwd_impl(x, w, bias, nullptr, y, d, 0, stream);
+}
+
+int bh_conv_fwd_act(const float* x, const float* w, const float* bias, const float* res, float* y, const bh_conv_desc* d,
+                    int relu, void* stream) {
+    return conv_fwd_impl(x, w, bias, res, y, d, relu, stream);
 }
 
 int bh_conv_fwd_bnstats(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, double* sums,

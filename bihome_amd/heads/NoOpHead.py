@@ -1,0 +1,79 @@
+"""Drop-in for `src/heads/NoOpHead.py` (the head of the supervised "-orig" experiments: config/*/zeng-orig-*.yaml,
+detone-orig-*.yaml).  It only routes tensors: `forward` returns (ground_truth, network_output, delta_gt, delta_hat) for
+the torch loss in train.py:318-322; with TARGET_GEN = 'all_points' delta_hat is read off the four corners of the
+predicted perspective field (NoOpHead.py:33-50).  All indexing runs on the device the backbone wrote to.
+
+`predict_homography`:
+  * '4_points'  (NoOpHead.py:59-73): H = four_point_to_homography(corners, delta_hat, crop=False) - the 8x8 solve on
+    the gfx950 kernel (bh_h4pt_fwd) in patch coordinates, conjugated by the translation to the patch corner.
+  * 'all_points' (NoOpHead.py:75-110): upstream fits cv2.findHomography(RANSAC, 10 px) to all P*P correspondences of
+    the field on the host (cv2 is not available here, also not to the oracle).  Here a uniform 32 x 16 lattice of those
+    correspondences goes through the DLT kernel (bh_dlt_fwd, no sampling): the least-squares homography, the same
+    estimate as upstream's inlier refit when every residual is below the 10 px threshold; a stated difference otherwise
+    (exact for a field that is a homography's, tests/test_model_gpu.py).
+"""
+import torch
+import torch.nn as nn
+
+from .. import kernels as K
+
+
+class Model(nn.Module):
+
+    def __init__(self, backbone, **kwargs):
+        super().__init__()
+        self.target_gen = kwargs['TARGET_GEN']                   # '4_points' or 'all_points'
+        self.learning_keys = kwargs['LEARNING_KEYS']             # ground_truth, network_output, delta_gt, delta_hat
+        if self.target_gen not in ('4_points', 'all_points'):
+            raise ValueError("TARGET_GEN must be '4_points' or 'all_points'")
+
+    def forward(self, data):
+        ret = [data[key] for key in self.learning_keys[:-1]]
+        last = data[self.learning_keys[-1]]
+        if self.target_gen == '4_points':
+            ret.append(last)
+        else:
+            h, w = last.shape[-2:]
+            # corners in the order top-left, top-right, bottom-right, bottom-left; channel 0 = x, 1 = y
+            ys = torch.tensor([0, 0, h - 1, h - 1], device=last.device)
+            xs = torch.tensor([0, w - 1, w - 1, 0], device=last.device)
+            ret.append(last[:, :, ys, xs].permute(0, 2, 1).contiguous())          # [B,4,2]
+        return ret
+
+    def predict_homography(self, data):
+        if self.target_gen == '4_points':
+            if 'corners' not in data:
+                raise KeyError("predict_homography('4_points') needs data['corners'] (NoOpHead.py:62-65)")
+            delta_hat = data[self.learning_keys[3]]
+            return delta_hat, self._h_from_corners(data['corners'], delta_hat)
+        return self._postprocess(data[self.learning_keys[1]])
+
+    @staticmethod
+    def _h_from_corners(corners, delta_hat):
+        """H with H(corners_i) = corners_i + delta_i for an axis-aligned square patch: T(c0) . H_patch . T(-c0)."""
+        B = delta_hat.shape[0]
+        delta = delta_hat.reshape(B, 4, 2).to(torch.float32).contiguous()
+        corners = corners.reshape(B, 4, 2).to(delta.device, torch.float64)
+        size = float((corners[0, 1, 0] - corners[0, 0, 0]).item())
+        H64, _ = K.h4pt_fwd(delta, size)
+        Hp = H64.view(B, 3, 3)
+        T = torch.eye(3, dtype=torch.float64, device=delta.device).repeat(B, 1, 1)
+        Ti = T.clone()
+        T[:, 0, 2], T[:, 1, 2] = corners[:, 0, 0], corners[:, 0, 1]
+        Ti[:, 0, 2], Ti[:, 1, 2] = -corners[:, 0, 0], -corners[:, 0, 1]
+        H = T @ Hp @ Ti
+        return (H / H[:, 2:3, 2:3]).to(torch.float32)
+
+    @staticmethod
+    def _postprocess(perspective_field):
+        pf = perspective_field.to(torch.float32).contiguous()
+        if not pf.is_cuda:
+            raise RuntimeError("bihome_amd heads run on the MI355X only; no CPU fallback (use oracle/ for CPU checks)")
+        B, _, h, w = pf.shape
+        # the DLT kernel takes up to 512 correspondences per problem: a uniform 32 x 16 lattice over the field
+        ny, nx = min(h, 32), min(w, 16)
+        ys = ((torch.arange(ny, device=pf.device, dtype=torch.float64) + 0.5) * h / ny).long()
+        xs = ((torch.arange(nx, device=pf.device, dtype=torch.float64) + 0.5) * w / nx).long()
+        choice = (ys[:, None] * w + xs[None, :]).reshape(1, -1).repeat(B, 1).contiguous()
+        Hd, dh, _ = K.dlt_fwd(pf, choice, 1, ny * nx)
+        return dh.view(B, 4, 2), Hd.view(B, 3, 3)

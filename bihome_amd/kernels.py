@@ -284,13 +284,17 @@ def conv_out_shape(d):
     return (d.N, d.Co, d.Ho, d.Wo) if d.out_nchw else (d.N, d.Ho, d.Wo, d.Co)
 
 
-def conv_fwd(x, w, bias, d, bn_sums=None, groups=1):
-    """bn_sums: zeroed [groups*Co*2] float64 buffer - the conv also accumulates the batch statistics of its output for the
-    BatchNorm that follows (bn_fwd(..., stats=bn_sums, stats_ready=True))."""
-    _chk(x); _chk(w); _chk(bias)
+def conv_fwd(x, w, bias, d, bn_sums=None, groups=1, res=None, relu=False):
+    """bn_sums: zeroed float64 sums buffer - the conv also accumulates the batch statistics of its output for the
+    BatchNorm that follows (bn_fwd(..., stats=bn_sums, stats_ready=True)).  res / relu: inference epilogue
+    y = act(conv + bias + res) (BatchNorm folded into w, bias by the caller)."""
+    _chk(x); _chk(w); _chk(bias); _chk(res)
     y = torch.empty(conv_out_shape(d), dtype=torch.float32, device=x.device)
     with _Timed(_conv_variant(d, "fwd"), conv_flops(d), 4.0 * (x.numel() + y.numel() + w.numel())):
-        if bn_sums is None:
+        if res is not None or relu:
+            check(lib.bh_conv_fwd_act(_p(x), _p(w), _p(bias), _p(res), _p(y), ctypes.byref(d), int(bool(relu)), _stream()),
+                  "bh_conv_fwd_act")
+        elif bn_sums is None:
             check(lib.bh_conv_fwd(_p(x), _p(w), _p(bias), _p(y), ctypes.byref(d), _stream()), "bh_conv_fwd")
         else:
             _chk(bn_sums, torch.float64)

@@ -13,6 +13,8 @@ MI355X-first choices:
   * every launch goes to the current HIP stream with static shapes, so a whole step can be captured
     in a HIP graph.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -196,8 +198,39 @@ def _conv_geometry(mod, x_shape, in_nchw, out_nchw, precision=0):
     return K.conv_desc(N, Hi, Wi, Ci, Co, k, s, p, transposed=tr, in_nchw=in_nchw, out_nchw=out_nchw, precision=precision)
 
 
-def run_forward(prog, x, groups, training, save, precision=0):
-    """x: NHWC (or NCHW when the first conv is flagged in_nchw). Returns (out, ctx|None)."""
+def _folded(cache, conv, bn, weight_fn):
+    """Eval-mode BatchNorm folded into the preceding conv: w' = w * s[co], b' = b * s + t with s = gamma / sqrt(var + eps),
+    t = beta - mean * s (running statistics).  Cached per (conv, bn) pair until a parameter / buffer version changes."""
+    key = (id(conv), id(bn))
+    vers = tuple(t._version for t in (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+                 if t is not None)
+    hit = cache.get(key)
+    if hit is not None and hit[0] == vers:
+        return hit[1], hit[2]
+    with torch.no_grad():
+        s = torch.rsqrt(bn.running_var + bn.eps)
+        if bn.weight is not None:
+            s = s * bn.weight
+        t = -bn.running_mean * s
+        if bn.bias is not None:
+            t = t + bn.bias
+        w = weight_fn(conv.weight) if weight_fn else conv.weight
+        if isinstance(conv, nn.ConvTranspose2d):                  # [Ci, Co, kh, kw]
+            wf = (w * s.view(1, -1, 1, 1)).contiguous(memory_format=torch.channels_last)
+        elif w.dim() == 4:
+            wf = (w * s.view(-1, 1, 1, 1)).contiguous(memory_format=torch.channels_last)
+        else:
+            wf = (w * s.view(-1, 1)).contiguous()
+        bf = (conv.bias * s + t) if conv.bias is not None else t
+        bf = bf.contiguous()
+    cache[key] = (vers, wf, bf)
+    return wf, bf
+
+
+def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None):
+    """x: NHWC (or NCHW when the first conv is flagged in_nchw). Returns (out, ctx|None).
+    fold_cache (inference only: not training, nothing saved): a dict - every conv whose only consumer is a BatchNorm
+    runs with that BatchNorm folded into its weights and the ReLU / residual add fused into its epilogue."""
     ctx = Ctx() if save else None
     slots = {0: x}
     if save:
@@ -223,10 +256,33 @@ def run_forward(prog, x, groups, training, save, precision=0):
             if (op.kind == "bn" and j is not None and prog.ops[j].kind == "conv" and users.get(op.src, 0) == 1
                     and not prog.ops[j].extra["out_nchw"] and not isinstance(prog.ops[j].mod, nn.ConvTranspose2d)):
                 fused_stats[j] = i
+    folded = {}                                           # bn op index -> conv op index (conv deferred to the bn's position)
+    if fold_cache is not None and not training and not save:
+        users = {}
+        for op in prog.ops:
+            users[op.src] = users.get(op.src, 0) + 1
+            if op.res is not None:
+                users[op.res] = users.get(op.res, 0) + 1
+        producer = {op.dst: j for j, op in enumerate(prog.ops)}
+        for i, op in enumerate(prog.ops):
+            j = producer.get(op.src)
+            if (op.kind == "bn" and j is not None and prog.ops[j].kind == "conv" and users.get(op.src, 0) == 1
+                    and not prog.ops[j].extra["out_nchw"]):
+                folded[i] = j
+    deferred = set(folded.values())
     ready = set()
     for i, op in enumerate(prog.ops):
-        src = slots[op.src]
-        if op.kind == "conv":
+        if i in deferred:
+            continue
+        src = slots.get(op.src)
+        if i in folded:
+            cop = prog.ops[folded[i]]
+            e = cop.extra
+            csrc = slots[cop.src]
+            d = _conv_geometry(cop.mod, csrc.shape, e["in_nchw"], e["out_nchw"], precision)
+            wf, bf = _folded(fold_cache, cop.mod, op.mod, e["weight_fn"])
+            out = K.conv_fwd(csrc, kview(wf), bf, d, res=slots[op.res] if op.res is not None else None, relu=op.relu)
+        elif op.kind == "conv":
             e = op.extra
             d = _conv_geometry(op.mod, src.shape, e["in_nchw"], e["out_nchw"], precision)
             w = e["weight_fn"](op.mod.weight) if e["weight_fn"] else op.mod.weight
@@ -370,9 +426,14 @@ class NetFunction(torch.autograd.Function):
     node has trainable state; parameter gradients are written by the kernels into `.grad` directly."""
 
     @staticmethod
-    def forward(ctx, x, anchor, runner, groups):
-        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-        out, saved = run_forward(runner.prog, x, groups, runner.module.training, save=need, precision=runner.precision)
+    def forward(ctx, x, anchor, runner, groups, grad_mode=True):
+        # (needs_input_grad reflects requires_grad of the inputs even under torch.no_grad(): the caller passes the mode)
+        need = grad_mode and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
+        training = runner.module.training
+        if training:
+            runner._fold.clear()            # running statistics are about to change (the kernels write them in place)
+        out, saved = run_forward(runner.prog, x, groups, training, save=need, precision=runner.precision,
+                                 fold_cache=runner._fold if (runner.fold_bn and not training and not need) else None)
         ctx.runner, ctx.saved, ctx.want_x = runner, saved, ctx.needs_input_grad[0]
         return out
 
@@ -385,7 +446,7 @@ class NetFunction(torch.autograd.Function):
         gin = run_backward(r.prog, ctx.saved, g.contiguous(), want_wgrad=r.flat is not None, want_input_grad=ctx.want_x,
                            on_param_grad=hook)
         ctx.saved = None
-        return gin, None, None, None
+        return gin, None, None, None, None
 
 
 class Runner:
@@ -399,6 +460,8 @@ class Runner:
         self.anchor = params[0] if (trainable and params) else None
         self._dummy = None
         self.reducer = None        # bihome_amd.ddp.FlatGradReducer when training data-parallel
+        self._fold = {}            # eval-mode BatchNorm folding cache (run_forward / _folded)
+        self.fold_bn = os.environ.get("BIHOME_FOLD_BN", "1") != "0"
 
     def __call__(self, x, groups):
         if not x.is_cuda:
@@ -409,4 +472,4 @@ class Runner:
             if self._dummy is None or self._dummy.device != x.device:
                 self._dummy = torch.zeros(1, device=x.device)
             anchor = self._dummy
-        return NetFunction.apply(x, anchor, self, groups)
+        return NetFunction.apply(x, anchor, self, groups, torch.is_grad_enabled())

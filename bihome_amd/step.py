@@ -26,10 +26,24 @@ def build_optimizer(model, solver):
     return opt, sched
 
 
-def train_step(model, data, opt, sched, clip=-1.0, reducer=None):
+def build_loss(solver):
+    """train.py:712-715: a torch.nn loss module by name ('MSELoss', 'L1Loss', 'SmoothL1Loss': the supervised "-orig"
+    experiments) or the string itself ('biHomE' / 'iHomE' / 'TripletLoss': the head computes the loss)."""
+    name = solver["LOSS"]
+    try:
+        return getattr(torch.nn, name)()
+    except AttributeError:
+        return name
+
+
+def train_step(model, data, opt, sched, clip=-1.0, reducer=None, loss_fn="biHomE"):
     model.train()                                                   # train.py:296
     opt.zero_grad()                                                 # train.py:305
-    loss, delta_gt, delta_hat = model(data)                         # train.py:357
+    if isinstance(loss_fn, torch.nn.Module):                        # train.py:318-322 (ground truth first, as upstream)
+        ground_truth, network_output, delta_gt, delta_hat = model(data)
+        loss = loss_fn(ground_truth, network_output)
+    else:
+        loss, delta_gt, delta_hat = model(data)                     # train.py:357
     loss.backward()                                                 # train.py:379
     if reducer is not None:
         reducer.allreduce()                                         # RCCL SUM over ranks (SURVEY.md 8(e))
@@ -55,6 +69,24 @@ def predict(model, data):
     for m in model.children():
         out = m.predict_homography(out)
     return out[0]
+
+
+def evaluate(model, batches):
+    """eval.py:80-112,339-341: model.eval(), no grad, per-batch `predict_homography` timed with device events (the first
+    batch is dropped from the timing like upstream), MACE per batch.  Returns (mean MACE, mean model ms per batch)."""
+    model.eval()
+    maces, times = [], []
+    with torch.no_grad():
+        for data in batches:
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record()
+            delta_hat = predict(model, data)
+            t1.record()
+            torch.cuda.synchronize()
+            times.append(t0.elapsed_time(t1))
+            maces.append(mace(data["delta"], delta_hat))
+    times = times[1:] if len(times) > 1 else times
+    return float(sum(maces) / len(maces)), float(sum(times) / len(times))
 
 
 def attach_reducer(model, bucket_bytes=8 << 20):

@@ -76,7 +76,7 @@ def _photometric(rng, img, max_delta):
     return img
 
 
-def make_pairs(batch, patch=128, rho=32, seed=42, photometric_max_delta=0, channels=1, pool=4):
+def make_pairs(batch, patch=128, rho=32, seed=42, photometric_max_delta=0, channels=1, pool=4, target=False):
     """Return dict of float32 arrays: patch_1, patch_2 [B,C,P,P] (standardised), delta [B,4,2]
     (ground-truth 4-point offsets, integers in [-rho, rho-1]), corners [B,4,2], homography [B,3,3]."""
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -114,7 +114,12 @@ def make_pairs(batch, patch=128, rho=32, seed=42, photometric_max_delta=0, chann
             else:
                 dst[b] = ((crop.astype(np.float32) / 255) - 0.443).transpose(2, 0, 1) / 0.129
         deltas[b], corners_all[b], Hs[b] = delta, corners, H
-    return {"patch_1": p1, "patch_2": p2, "delta": deltas, "corners": corners_all, "homography": Hs}
+    out = {"patch_1": p1, "patch_2": p2, "delta": deltas, "corners": corners_all, "homography": Hs}
+    if target:      # HomographyNetPrep 'all_points' (transforms.py:635-685): pf(x) = H x - x over the patch of image 1
+        c = np.array([[0, 0], [patch, 0], [patch, patch], [0, patch]], np.float64)
+        out["target"] = np.stack([perspective_field(four_point_homography(c, c + deltas[b].astype(np.float64)), patch)
+                                  for b in range(batch)]).astype(np.float32)
+    return out
 
 
 def perspective_field(H, patch=128):

@@ -120,6 +120,10 @@ typedef struct {
 int bh_debug_force_tile(int bm, int bn);
 /* y = conv(x, w) (+ bias[Co] if bias != NULL) */
 int bh_conv_fwd(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, void* stream);
+/* y = act(conv(x, w) + bias + res): res (NULL ok) has the layout of y, relu != 0 applies max(.,0).  The inference path:
+ * an eval-mode BatchNorm is folded into (w, bias) by the host and its ReLU / residual add ride in the conv epilogue. */
+int bh_conv_fwd_act(const float* x, const float* w, const float* bias, const float* res, float* y, const bh_conv_desc* d,
+                    int relu, void* stream);
 /* y = conv(x, w) + bias, and sums (bh_bn_stats_doubles(groups, Co) doubles, caller-zeroed) += per-channel (sum y, sum y^2) of each of the
  * `groups` sub-batches stacked along N: the batch statistics of the BatchNorm that follows, accumulated in the conv
  * epilogue where the halo-tiled 3x3 kernel applies (one extra statistics launch otherwise).  Pass the buffer to

@@ -367,6 +367,29 @@ class BiHomEHead(nn.Module):
 # Step harness (train.py:296-387, 402-403)
 # --------------------------------------------------------------------------------------------
 
+class NoOpHead(nn.Module):
+    """src/heads/NoOpHead.py:10-53: the head of the supervised "-orig" experiments; routes (ground_truth,
+    network_output, delta_gt, delta_hat) to the torch loss of train.py:318-322.  'all_points': delta_hat is the
+    predicted field at the four patch corners (:33-50)."""
+
+    def __init__(self, backbone, **kw):
+        super().__init__()
+        self.target_gen, self.learning_keys = kw["TARGET_GEN"], kw["LEARNING_KEYS"]
+
+    def forward(self, data, *unused):
+        ret = [data[k] for k in self.learning_keys[:-1]]
+        last = data[self.learning_keys[-1]]
+        if self.target_gen == "4_points":
+            ret.append(last)
+        else:
+            h, w = last.shape[-2:]
+            d = torch.zeros((last.shape[0], 4, 2), dtype=last.dtype)
+            for i, (yy, xx) in enumerate(((0, 0), (0, w - 1), (h - 1, w - 1), (h - 1, 0))):
+                d[:, i, 0], d[:, i, 1] = last[:, 0, yy, xx], last[:, 1, yy, xx]
+            ret.append(d)
+        return ret
+
+
 def mace(delta_gt, delta_hat):
     """train.py:402-403 / eval.py:133-134."""
     a = delta_gt.detach().cpu().numpy().reshape(-1, 2)
@@ -380,7 +403,7 @@ def build(cfg, dtype=torch.float32, seed=0):
     this file free of product imports)."""
     bcfg, hcfg = cfg["MODEL"]["BACKBONE"], cfg["MODEL"]["HEAD"]
     bb = (ZengBackbone if bcfg["NAME"] == "Rethinking" else ResNet34Backbone)(**bcfg)
-    head = BiHomEHead(bb, **hcfg)
+    head = (NoOpHead if hcfg["NAME"] == "NoOpHead" else BiHomEHead)(bb, **hcfg)
     return bb, head
 
 
@@ -391,11 +414,16 @@ def make_optimizer(model, solver):
     return opt, sched
 
 
-def train_step(bb, head, opt, sched, data, choice_12=None, choice_21=None, clip=-1.0):
-    """One iteration of train.py:296-387 (model.train(), zero_grad, forward, backward, clip, step)."""
+def train_step(bb, head, opt, sched, data, choice_12=None, choice_21=None, clip=-1.0, loss_fn=None):
+    """One iteration of train.py:296-387 (model.train(), zero_grad, forward, backward, clip, step).
+    loss_fn: a torch.nn loss module for the supervised branch (train.py:318-322), None for the biHomE head loss."""
     bb.train(); head.train()
     opt.zero_grad()
-    loss, delta_gt, delta_hat = head(bb(data), choice_12, choice_21)
+    if loss_fn is not None:
+        ground_truth, network_output, delta_gt, delta_hat = head(bb(data))
+        loss = loss_fn(ground_truth, network_output)
+    else:
+        loss, delta_gt, delta_hat = head(bb(data), choice_12, choice_21)
     loss.backward()
     if clip > 0:
         torch.nn.utils.clip_grad_norm_(list(bb.parameters()), clip)

@@ -229,6 +229,60 @@ def run_detone_scenario(ref_bb_cls, ref_head_cls, cfg, dtype, batch=4, seed=5):
     return out
 
 
+def run_orig_scenario(ref_bb_cls, ref_head_cls, cfg, dtype, batch, seed, steps=2):
+    """The supervised "-orig" experiments (reference backbone, OneLine + reference NoOpHead + torch loss,
+    train.py:318-322,379-387): `steps` Adam steps on one batch, then an eval-mode forward."""
+    from bihome_amd import synth
+    from bihome_amd.weights import load_synthetic
+    bb = ref_bb_cls(**cfg["MODEL"]["BACKBONE"])
+    head = ref_head_cls(bb, **cfg["MODEL"]["HEAD"])
+    load_synthetic(bb, seed=0)
+    model = torch.nn.Sequential(bb, head).to(dtype)
+    sol = cfg["SOLVER"]
+    opt = torch.optim.Adam(model.parameters(), lr=sol["LR"], betas=(sol["MOMENTUM_1"], sol["MOMENTUM_2"]), weight_decay=0)
+    loss_fn = getattr(torch.nn, sol["LOSS"])()
+    d = synth.make_pairs(batch, seed=seed, target=True)
+    out = {"loss": [], "mace": []}
+    key0 = cfg["MODEL"]["BACKBONE"]["TARGET_KEYS"][0]
+    for it in range(steps):
+        model.train()
+        data = {k: t(d[k], dtype) for k in ("patch_1", "patch_2", "delta", "target")}
+        opt.zero_grad()
+        ground_truth, network_output, delta_gt, delta_hat = model(data)
+        loss = loss_fn(ground_truth, network_output)
+        loss.backward()
+        if it == 0:
+            out["output0"] = sub(network_output) if network_output.dim() == 4 else network_output.detach().double().numpy().copy()
+            out["output0_csum"] = csum(network_output)
+            out["delta_hat0"] = delta_hat.detach().double().numpy().copy()
+            names = dict(bb.named_parameters())
+            for name in list(names)[:2] + list(names)[-2:]:
+                out["gradnorm/" + name] = np.float64(names[name].grad.double().norm().item())
+        opt.step()
+        out["loss"].append(loss.item())
+        out["mace"].append(float(np.mean(np.linalg.norm(
+            (delta_gt - delta_hat).detach().double().numpy().reshape(-1, 2), axis=-1))))
+    model.eval()
+    with torch.no_grad():
+        data = {k: t(d[k], dtype) for k in ("patch_1", "patch_2", "delta", "target")}
+        bb(data)
+        out["eval_output"] = sub(data[key0]) if data[key0].dim() == 4 else data[key0].detach().double().numpy().copy()
+        out["eval_output_csum"] = csum(data[key0])
+    out["loss"], out["mace"] = np.array(out["loss"]), np.array(out["mace"])
+    return out
+
+
+def _orig(importlib, Rethinking, ResNet34, configs, dtype, tag, outdir):
+    NoOpHead = importlib.import_module("src.heads.NoOpHead")
+    assert os.path.realpath(NoOpHead.__file__).startswith(os.path.realpath(REF)), NoOpHead.__file__
+    r = run_orig_scenario(Rethinking.Model, NoOpHead.Model, configs.get("zeng-orig"), dtype, batch=4, seed=21)
+    np.savez_compressed(os.path.join(outdir, "zeng_orig_b4_%s.npz" % tag), **r)
+    print("zeng-orig", tag, "loss", r["loss"], "mace", r["mace"])
+    r = run_orig_scenario(ResNet34.Model, NoOpHead.Model, configs.get("detone-orig"), dtype, batch=4, seed=22)
+    np.savez_compressed(os.path.join(outdir, "detone_orig_b4_%s.npz" % tag), **r)
+    print("detone-orig", tag, "loss", r["loss"], "mace", r["mace"])
+
+
 def main():
     install_standins()
     import importlib
@@ -243,7 +297,11 @@ def main():
     torch.set_num_threads(8)
     import warnings
     warnings.filterwarnings("ignore")
+    orig_only = "--orig-only" in sys.argv          # regenerate just the supervised "-orig" fixtures
     for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        if orig_only:
+            _orig(importlib, Rethinking, ResNet34, configs, dtype, tag, outdir)
+            continue
         r = run_head_scenario(PerceptualHead.Model, zeng, dtype)
         np.savez_compressed(os.path.join(outdir, "head_b8_%s.npz" % tag), **r)
         print("head", tag, "loss", r["loss"], "mace", r["mace"])
@@ -256,6 +314,7 @@ def main():
         r = run_detone_scenario(ResNet34.Model, PerceptualHead.Model, detone, dtype)
         np.savez_compressed(os.path.join(outdir, "detone_b4_%s.npz" % tag), **r)
         print("detone", tag, "loss", r["loss"])
+        _orig(importlib, Rethinking, ResNet34, configs, dtype, tag, outdir)
 
 
 if __name__ == "__main__":

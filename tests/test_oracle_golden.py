@@ -91,3 +91,34 @@ def test_detone_first_step(golden):
     np.testing.assert_allclose(dh.detach().numpy(), g["delta_hat_12"], rtol=1e-4, atol=1e-5)
     gn = dict(bb.named_parameters())["resnet34.fc.weight"].grad.double().norm().item()
     np.testing.assert_allclose(gn, g["gradnorm/resnet34.fc.weight"], rtol=1e-3)
+
+
+@pytest.mark.parametrize("name,batch,seed", [("zeng-orig", 4, 21), ("detone-orig", 4, 22)])
+def test_supervised_orig_configs(golden, name, batch, seed):
+    """The supervised "-orig" experiments (same backbones, OneLine, NoOpHead + torch loss, train.py:318-322): the oracle's
+    first two Adam steps and an eval-mode forward against the reference's own modules."""
+    g = golden(name.replace("-", "_") + "_b4_f64")
+    cfg = configs.get(name)
+    bb, head = O.build(cfg)
+    assert isinstance(head, O.NoOpHead)
+    load_synthetic(bb, 0)
+    bb.double(); head.double()
+    opt, sched = O.make_optimizer(torch.nn.Sequential(bb, head), cfg["SOLVER"])
+    loss_fn = getattr(torch.nn, cfg["SOLVER"]["LOSS"])()
+    d = synth.make_pairs(batch, seed=seed, target=True)
+    key0 = cfg["MODEL"]["BACKBONE"]["TARGET_KEYS"][0]
+    for it in range(2):
+        data = {k: _t(d[k], torch.float64) for k in ("patch_1", "patch_2", "delta", "target")}
+        loss, dgt, dh = O.train_step(bb, head, opt, sched, data, loss_fn=loss_fn)
+        assert abs(loss.item() - g["loss"][it]) <= 1e-8 * abs(g["loss"][it])
+        np.testing.assert_allclose(O.mace(dgt, dh), g["mace"][it], rtol=1e-7)
+        if it == 0:
+            out = data[key0].detach()
+            np.testing.assert_allclose(out[..., ::8, ::8].numpy() if out.dim() == 4 else out.numpy(), g["output0"], atol=1e-8)
+            np.testing.assert_allclose(dh.numpy(), g["delta_hat0"], atol=1e-8)
+    bb.eval()
+    with torch.no_grad():
+        data = {k: _t(d[k], torch.float64) for k in ("patch_1", "patch_2", "delta", "target")}
+        bb(data)
+    out = data[key0]
+    np.testing.assert_allclose(out[..., ::8, ::8].numpy() if out.dim() == 4 else out.numpy(), g["eval_output"], atol=1e-7)
