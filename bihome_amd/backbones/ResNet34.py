@@ -43,9 +43,10 @@ class Model(nn.Module):
         super().__init__()
         self.patch_keys = kwargs['PATCH_KEYS']
         self.target_keys = kwargs['TARGET_KEYS']
-        if kwargs.get('PRETRAINED_RESNET'):
-            raise RuntimeError("PRETRAINED_RESNET=True needs the torchvision ImageNet checkpoint; no network here - "
-                               "load weights with load_state_dict instead")
+        pre = kwargs.get('PRETRAINED_RESNET')
+        if pre is True:
+            raise RuntimeError("PRETRAINED_RESNET=True downloads the torchvision ImageNet checkpoint upstream (ResNet34.py:15); "
+                               "no network here - pass the path of resnet34-333f7ec4.pth as PRETRAINED_RESNET instead")
         self.resnet34 = _ResNet34(2, 8)
         self.variant = str.lower(kwargs['VARIANT']) if 'VARIANT' in kwargs else 'oneline'
         assert 'oneline' in self.variant or 'doubleline' in self.variant, 'Only OneLine or DoubleLine variant is supported'
@@ -53,6 +54,10 @@ class Model(nn.Module):
         # fp32 accumulate/storage - BASELINE.json configs[3])
         self.precision = kwargs.get('PRECISION', os.environ.get('BIHOME_PRECISION', 'f32'))
         net.to_kernel_layout_(self)
+        if isinstance(pre, str) and pre:           # torchvision resnet34 ImageNet state dict; conv1 / fc stay fresh (ResNet34.py:15-19)
+            from ..weights import load_imagenet_resnet34
+            load_imagenet_resnet34(self, pre)
+            net.to_kernel_layout_(self)
         self._runner = None
 
     def _build(self):

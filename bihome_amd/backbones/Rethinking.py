@@ -58,9 +58,10 @@ class Model(nn.Module):
         assert 'oneline' in self.variant or 'doubleline' in self.variant, 'Only OneLine or DoubleLine variant is supported'
         if self.resnet_block != 'ResNet34':
             raise NotImplementedError("only RESNET_BLOCK='ResNet34' is built (every shipped config uses it)")
-        if kwargs.get('PRETRAINED_RESNET'):
-            raise RuntimeError("PRETRAINED_RESNET=True needs the ImageNet checkpoint URL (Rethinking.py:178-183); "
-                               "no network here - load weights with load_state_dict instead")
+        pre = kwargs.get('PRETRAINED_RESNET')
+        if pre is True:
+            raise RuntimeError("PRETRAINED_RESNET=True downloads resnet34-333f7ec4.pth upstream (Rethinking.py:178-183); no "
+                               "network here - pass the path of that file as PRETRAINED_RESNET instead")
         S, U, D = nn.Sequential, resnet34_unit, deconv_unit
         # optional extra kwarg (upstream hard-wires 2 = two grayscale patches, Rethinking.py:31): channels per patch;
         # 3 gives the 6-channel stem of BASELINE.json configs[4] (256x256 RGB pairs)
@@ -79,6 +80,10 @@ class Model(nn.Module):
         net.to_kernel_layout_(self)
         self._runner = None
         self.fuse_tail = os.environ.get("BIHOME_FUSE_TAIL", "1") != "0"
+        if isinstance(pre, str) and pre:           # path of the torchvision resnet34 ImageNet state dict (Rethinking.py:158-282)
+            from ..weights import load_imagenet_resnet34
+            load_imagenet_resnet34(self, pre)
+            net.to_kernel_layout_(self)
 
     # ---- program ---------------------------------------------------------------------------------
     def _build(self):

@@ -63,3 +63,48 @@ def load_synthetic(module, seed=0):
     key names - and therefore the values - do not depend on how the modules are wrapped."""
     module.load_state_dict(synthetic_state_dict(module, seed))
     return module
+
+
+# -----------------------------------------------------------------------------------------------
+# ImageNet ResNet-34 initialisation (PRETRAINED_RESNET: True upstream).  Upstream downloads
+# resnet34-333f7ec4.pth (Rethinking.py:178-183; torchvision inside ResNet34.py:15); there is no network here, so the
+# caller hands over that state dict (a path or a dict) and these functions place it.
+# -----------------------------------------------------------------------------------------------
+_UNIT = {"conv1": "upper_branch.0", "bn1": "upper_branch.1", "conv2": "upper_branch.3", "bn2": "upper_branch.4",
+         "downsample": "lower_branch"}
+
+
+def zeng_keys_from_torchvision(tv_state):
+    """torchvision resnet34 `layer{1,2,3}.<i>.<conv1|bn1|conv2|bn2|downsample.<j>>.<p>` -> the Zeng backbone's
+    `layer{2,3,4}.<i>.<upper_branch.{0,1,3,4}|lower_branch.<j>>.<p>` (the placement Rethinking.py:189-282 performs; stem,
+    layer4 and fc of the ImageNet net are not used by it)."""
+    out = {}
+    for key, value in tv_state.items():
+        parts = key.split(".")
+        if parts[0] not in ("layer1", "layer2", "layer3") or parts[2] not in _UNIT:
+            continue
+        stage = "layer%d" % (int(parts[0][5:]) + 1)
+        out[".".join([stage, parts[1], _UNIT[parts[2]]] + parts[3:])] = value
+    return out
+
+
+def load_imagenet_resnet34(backbone, tv_state):
+    """Place torchvision ImageNet resnet34 weights into a bihome_amd backbone (Rethinking.Model or ResNet34.Model).
+    tv_state: state dict or path to resnet34-333f7ec4.pth.  Returns the list of keys that were loaded.  Shapes are
+    checked (a mismatch raises, where upstream only prints); for the ResNet-34 regressor the 2-channel conv1 and the
+    8-way fc keep their fresh initialisation exactly as ResNet34.py:15-19 replaces them after loading."""
+    import torch
+    if isinstance(tv_state, (str, bytes)):
+        tv_state = torch.load(tv_state, map_location="cpu")
+    own = backbone.state_dict()
+    if hasattr(backbone, "resnet34"):
+        mapped = {"resnet34." + k: v for k, v in tv_state.items() if not (k.startswith("conv1.") or k.startswith("fc."))}
+    else:
+        mapped = zeng_keys_from_torchvision(tv_state)
+    for k, v in mapped.items():
+        if k not in own:
+            raise KeyError("ImageNet key %s has no counterpart in %s" % (k, type(backbone).__name__))
+        if tuple(own[k].shape) != tuple(v.shape):
+            raise ValueError("ImageNet tensor %s has shape %s, the backbone expects %s" % (k, tuple(v.shape), tuple(own[k].shape)))
+    backbone.load_state_dict(mapped, strict=False)
+    return sorted(mapped)

@@ -103,3 +103,26 @@ def test_synthetic_pairs_are_consistent():
         w = synth.warp_bilinear(d["patch_1"][b].transpose(1, 2, 0).astype(np.float64), H, 128, 128)[..., 0]
         inside = synth.warp_bilinear(np.ones((128, 128, 1)), H, 128, 128)[..., 0] == 1
         assert np.abs(w - d["patch_2"][b, 0])[inside].mean() < 0.02
+
+
+def test_imagenet_resnet34_key_placement():
+    """PRETRAINED_RESNET: torchvision resnet34 keys land where Rethinking.py:189-282 / ResNet34.py:15-19
+    put them.  Checked against the reference's torchvision-layout container built by the oracle (no network: random
+    tensors of the right shapes stand for the ImageNet file)."""
+    import torch
+    from bihome_amd.weights import zeng_keys_from_torchvision
+    from oracle import bihome_oracle as O
+    tv = O._TVResNet34()                                  # torchvision.models.resnet34 layout
+    g = torch.Generator().manual_seed(0)
+    state = {k: torch.randn(v.shape, generator=g) if v.dtype.is_floating_point else v.clone() for k, v in tv.state_dict().items()}
+    mapped = zeng_keys_from_torchvision(state)
+    zeng = O.ZengBackbone(PATCH_KEYS=["patch_1", "patch_2"], TARGET_KEYS=["pf_hat_12"], RESNET_BLOCK="ResNet34",
+                          VARIANT="OneLine", IMAGE_SIZE=128)
+    own = zeng.state_dict()
+    # every unit of layer2-4 is covered, nothing else is touched, shapes agree
+    assert set(mapped) == {k for k in own if k.split(".")[0] in ("layer2", "layer3", "layer4")
+                           and k.split(".")[1].isdigit() and int(k.split(".")[1]) < {"layer2": 3, "layer3": 4, "layer4": 6}[k.split(".")[0]]}
+    for k, v in mapped.items():
+        assert tuple(own[k].shape) == tuple(v.shape), k
+    assert torch.equal(mapped["layer3.0.lower_branch.0.weight"], state["layer2.0.downsample.0.weight"])
+    assert torch.equal(mapped["layer4.5.upper_branch.4.running_var"], state["layer3.5.bn2.running_var"])

@@ -359,3 +359,35 @@ def test_supervised_orig_configs_vs_golden(golden, name, batch, seed):
     if name == "zeng-orig":         # NoOpHead._postprocess on an exact field recovers the 4-point offsets
         dh2, H = model[1]._postprocess(cuda(d["target"]))
         assert relerr(dh2.cpu(), d["delta"]) < 1e-3
+
+
+def test_pretrained_resnet_path_loads_imagenet_layout(tmp_path):
+    """PRETRAINED_RESNET = path of a torchvision resnet34 state dict (upstream downloads it): both backbones load it into
+    the right modules, keep the kernel (channels_last) weight layout and still run."""
+    import importlib
+    tv = O._TVResNet34()
+    g = torch.Generator().manual_seed(1)
+    state = {k: (0.05 * torch.randn(v.shape, generator=g) if v.dtype.is_floating_point else v.clone())
+             for k, v in tv.state_dict().items()}
+    for k in state:
+        if k.endswith("running_var"):
+            state[k] = state[k].abs() + 0.5
+    path = str(tmp_path / "resnet34.pth")
+    torch.save(state, path)
+    d = synth.make_pairs(2, seed=3)
+    data = {k: cuda(d[k]) for k in ("patch_1", "patch_2")}
+    cfg = configs.get("zeng-bihome")["MODEL"]["BACKBONE"]
+    cfg["PRETRAINED_RESNET"] = path
+    bb = importlib.import_module("src.backbones.Rethinking").Model(**cfg).cuda()
+    assert torch.equal(bb.state_dict()["layer3.0.lower_branch.0.weight"].cpu(), state["layer2.0.downsample.0.weight"])
+    out = bb(dict(data))
+    assert torch.isfinite(out["pf_hat_12"]).all()
+    cfg = configs.get("detone-bihome")["MODEL"]["BACKBONE"]
+    cfg["PRETRAINED_RESNET"] = path
+    rb = importlib.import_module("src.backbones.ResNet34").Model(**cfg).cuda()
+    assert torch.equal(rb.state_dict()["resnet34.layer4.2.conv2.weight"].cpu(), state["layer4.2.conv2.weight"])
+    assert rb.state_dict()["resnet34.conv1.weight"].shape == (64, 2, 7, 7)
+    out = rb(dict(data))
+    assert torch.isfinite(out["delta_hat_12"]).all()
+    with pytest.raises(RuntimeError, match="no network"):
+        importlib.import_module("src.backbones.ResNet34").Model(**dict(cfg, PRETRAINED_RESNET=True))
