@@ -33,6 +33,7 @@ class FlatGradReducer:
         self.group = group
         self.op = op if op is not None else dist.ReduceOp.SUM
         self.bucket_elems = max(1, bucket_bytes // 4)
+        self.wait_streams = []       # side streams that produce gradients (net.run_backward's wgrad stream)
         # buckets are built from the END of the flat buffer (the layers whose gradients appear first)
         self.buckets = []            # list of (lo, hi) element ranges, in launch order
         self.param_bucket = {}       # id(param) -> bucket index
@@ -76,6 +77,8 @@ class FlatGradReducer:
             self.launched[b] = True
             return
         lo, hi = self.buckets[b]
+        for s in self.wait_streams:                 # wgrad kernels of this bucket may still be queued on the side stream
+            torch.cuda.current_stream().wait_stream(s)
         self.works.append(dist.all_reduce(self.fg.flat[lo:hi], op=self.op, group=self.group, async_op=True))
         self.launched[b] = True
 

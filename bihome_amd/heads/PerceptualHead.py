@@ -132,8 +132,13 @@ class _BiHomELoss(torch.autograd.Function):
         B = B2 // 2
         aux = head.auxiliary_resnet
         delta = delta.contiguous()
-        with torch.no_grad():
-            feat = aux(patches, groups=2)                       # :358,:367  (patch_1 then patch_2 statistics)
+        ready = getattr(head, "_feat_ready", None)
+        if ready is not None:                                   # prefetched on the side stream under the backbone
+            feat = ready[0]
+            torch.cuda.current_stream().wait_event(ready[1])
+        else:
+            with torch.no_grad():
+                feat = aux(patches, groups=2)                   # :358,:367  (patch_1 then patch_2 statistics)
         H64, H32 = K.h4pt_fwd(delta, h)                          # _warp -> four_point_to_homography :237-243
         pool = 4
         warped, cov = K.warp_fwd(patches, H64, pool)             # :371,:382,:392,:401,:447-459
@@ -196,6 +201,40 @@ class Model(nn.Module):
         self.triplet_mu = kwargs['TRIPLET_MU']
         self.auxiliary_resnet = AuxiliaryResnet(**kwargs)
         self.last = {}
+        # The features of the two unwarped patches depend on the batch only, not on the backbone: their extractor pass is
+        # enqueued on the side HIP stream when the backbone's forward starts and runs under the backbone's kernels; the
+        # loss picks the result up behind an event.  (The reference runs the same extractor calls, in the same order,
+        # after the backbone: PerceptualHead.py:358,367.)
+        self._prefetched = None
+        self.prefetch_features = os.environ.get("BIHOME_PREFETCH_FEATURES", "1") != "0"
+        if isinstance(backbone, nn.Module):
+            backbone.register_forward_pre_hook(self._prefetch_hook)
+
+    def _stack_patches(self, data):
+        e1, e2 = self.patch_keys
+        p1, p2 = data[e1], data[e2]
+        B = p1.shape[0]
+        return torch.cat([p1.reshape(B, -1, self.patch_size, self.patch_size),
+                          p2.reshape(B, -1, self.patch_size, self.patch_size)], 0)
+
+    def _prefetch_hook(self, module, args):
+        self._prefetched = None
+        if not (self.prefetch_features and self.training and torch.is_grad_enabled() and args and isinstance(args[0], dict)):
+            return
+        data = args[0]
+        if self.patch_keys[0] not in data or not data[self.patch_keys[0]].is_cuda:
+            return
+        patches = self._stack_patches(data)
+        main = torch.cuda.current_stream()
+        side = net.side_stream(patches.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side), torch.no_grad():
+            feat = self.auxiliary_resnet(patches, groups=2)     # :358,:367 (patch_1 then patch_2 statistics)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        patches.record_stream(side)
+        feat.record_stream(main)
+        self._prefetched = (data[self.patch_keys[0]], data[self.patch_keys[1]], patches, feat, ev)
 
     # ---- DSAC -----------------------------------------------------------------------------------------
     @staticmethod
@@ -237,9 +276,13 @@ class Model(nn.Module):
             self.last_dlt = Hd
         else:
             delta = torch.cat([data[self.delta_hat_keys[0]].reshape(B, 4, 2), data[self.delta_hat_keys[1]].reshape(B, 4, 2)], 0)
-        patches = torch.cat([p1.reshape(B, -1, self.patch_size, self.patch_size),
-                             p2.reshape(B, -1, self.patch_size, self.patch_size)], 0)
+        pre, self._prefetched = self._prefetched, None
+        if pre is not None and pre[0] is p1 and pre[1] is p2:
+            patches, self._feat_ready = pre[2], (pre[3], pre[4])
+        else:
+            patches, self._feat_ready = self._stack_patches(data), None
         loss = _BiHomELoss.apply(delta, patches, self)
+        self._feat_ready = None
         if 'summary_writer' in data:                            # PerceptualHead.py:678-697 (syncs; log steps only)
             step = data['summary_writer_step']
             l4 = self.last["loss4"].tolist()

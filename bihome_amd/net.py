@@ -331,9 +331,28 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None):
     return slots[prog.ops[-1].dst], ctx
 
 
-def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=None):
+_SIDE_STREAMS = {}
+
+
+def side_stream(device):
+    """The per-device HIP stream that carries the weight-gradient GEMMs (and the head's feature prefetch): they have no
+    consumer inside the backward chain, so they run under the dgrad / BatchNorm kernels of the main stream."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+    return _SIDE_STREAMS[key]
+
+
+def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=None, wgrad_stream=None):
     """Adjoint of run_forward. Parameter gradients are accumulated (+=) into each parameter's `.grad`
-    tensor (which must already exist, see FlatGrads). Returns the input gradient or None."""
+    tensor (which must already exist, see FlatGrads). Returns the input gradient or None.
+    wgrad_stream: a second HIP stream for the conv weight-gradient launches.  The backward chain on the main stream is
+    dgrad -> BatchNorm backward -> dgrad ...: the wgrad of a layer only needs that layer's output gradient, so it is
+    enqueued behind an event and overlaps the chain (MFMA-bound wgrad under the HBM-bound BatchNorm kernels); the
+    main stream joins the side stream before returning."""
+    main = torch.cuda.current_stream() if wgrad_stream is not None else None
+    if wgrad_stream is not None:
+        wgrad_stream.wait_stream(main)          # activations, zeroed gradient buffer
     grads = {prog.ops[-1].dst: gout}
     slots = ctx.slots
     consumed_by = {}
@@ -362,7 +381,15 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
             if want_wgrad and m.weight.requires_grad and op.extra["weight_fn"] is None:
                 gw = m.weight.grad if m.weight.dim() == 2 else kview(m.weight.grad)
                 gb = m.bias.grad if (m.bias is not None and m.bias.requires_grad) else None
-                K.conv_wgrad(x, g, gw, gb, d)
+                if wgrad_stream is None:
+                    K.conv_wgrad(x, g, gw, gb, d)
+                else:
+                    ev = torch.cuda.Event()
+                    ev.record(main)                                   # g is final here
+                    g.record_stream(wgrad_stream)
+                    with torch.cuda.stream(wgrad_stream):
+                        wgrad_stream.wait_event(ev)
+                        K.conv_wgrad(x, g, gw, gb, d)
                 if on_param_grad is not None:       # gradient of this layer is final: its bucket may leave
                     on_param_grad(m.weight)
                     if gb is not None:
@@ -407,6 +434,8 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
         elif op.kind == "gap":
             if need_src_grad:
                 contribute(op.src, K.gap_bwd(g, tuple(x.shape)))
+    if wgrad_stream is not None:
+        main.wait_stream(wgrad_stream)          # the optimiser (and the release of the activations) follows
     return grads.get(0)
 
 
@@ -443,8 +472,11 @@ class NetFunction(torch.autograd.Function):
         if r.flat is not None:
             r.flat.attach(g.device)
         hook = r.reducer.param_ready if r.reducer is not None else None
+        side = side_stream(g.device) if (r.wgrad_on_side_stream and r.flat is not None) else None
+        if r.reducer is not None:
+            r.reducer.wait_streams = [side] if side is not None else []
         gin = run_backward(r.prog, ctx.saved, g.contiguous(), want_wgrad=r.flat is not None, want_input_grad=ctx.want_x,
-                           on_param_grad=hook)
+                           on_param_grad=hook, wgrad_stream=side)
         ctx.saved = None
         return gin, None, None, None, None
 
@@ -462,6 +494,7 @@ class Runner:
         self.reducer = None        # bihome_amd.ddp.FlatGradReducer when training data-parallel
         self._fold = {}            # eval-mode BatchNorm folding cache (run_forward / _folded)
         self.fold_bn = os.environ.get("BIHOME_FOLD_BN", "1") != "0"
+        self.wgrad_on_side_stream = os.environ.get("BIHOME_WGRAD_STREAM", "1") != "0"
 
     def __call__(self, x, groups):
         if not x.is_cuda:
