@@ -16,6 +16,11 @@ class BhConvDesc(Structure):
                                      "transposed", "in_nchw", "out_nchw", "precision")]
 
 
+class BhBnReduce(Structure):
+    _fields_ = [("z", c_void_p), ("y", c_void_p), ("stats", c_void_p), ("gamma", c_void_p), ("beta", c_void_p),
+                ("eps", c_float), ("relu", c_int)]
+
+
 P = c_void_p
 # name -> argtypes (all return int).  Must list every symbol include/bihome.h declares.
 SIGNATURES = {
@@ -36,6 +41,7 @@ SIGNATURES = {
     "bh_conv_fwd_act": [P, P, P, P, P, POINTER(BhConvDesc), c_int, P],
     "bh_conv_fwd_bnstats": [P, P, P, P, POINTER(BhConvDesc), P, c_int, P],
     "bh_conv_dgrad": [P, P, P, POINTER(BhConvDesc), c_int, P],
+    "bh_conv_dgrad_bnreduce": [P, P, P, POINTER(BhConvDesc), c_int, POINTER(BhBnReduce), P, c_int, P],
     "bh_col2im_c1": [P, P, POINTER(BhConvDesc), c_int, P],
     "bh_conv_wgrad": [P, P, P, P, POINTER(BhConvDesc), P],
     "bh_bn_stats_doubles": [c_int, c_int],

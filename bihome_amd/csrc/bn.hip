@@ -212,17 +212,40 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ beta,
                                                            const float4* __restrict__ coef,
                                                            float* __restrict__ gx, float* __restrict__ gres, BnGeom g,
-                                                           int flags) {
+                                                           int flags, const double* __restrict__ stats,
+                                                           const double* __restrict__ sums, float eps,
+                                                           float* __restrict__ ggamma, float* __restrict__ gbeta) {
     const int cq = threadIdx.x % g.LPR, r0 = threadIdx.x / g.LPR;
     const int grp = blockIdx.y;
     float mean[4], invstd[4], sc[4], sh[4], k1[4], k2[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = cq * 4 + i;
-        const float4 q = coef[(size_t)grp * g.C + c];            // (mean, invstd, mean dy, mean dy*xhat) from the finalize kernel
-        mean[i] = q.x; invstd[i] = q.y; k1[i] = q.z; k2[i] = q.w;
-        sc[i] = (gamma ? gamma[c] : 1.f) * q.y;
-        sh[i] = (beta ? beta[c] : 0.f) - q.x * sc[i];
+        if (coef) {
+            const float4 q = coef[(size_t)grp * g.C + c];        // (mean, invstd, mean dy, mean dy*xhat) from the finalize kernel
+            mean[i] = q.x; invstd[i] = q.y; k1[i] = q.z; k2[i] = q.w;
+            sc[i] = (gamma ? gamma[c] : 1.f) * q.y;
+            sh[i] = (beta ? beta[c] : 0.f) - q.x * sc[i];
+        } else {
+            // the gradient sums were accumulated by the dgrad that produced gy (bh_conv_dgrad_bnreduce): no reduce /
+            // finalize launches, the coefficients come straight from the two padded sums tables
+            bn_coeffs(stats, gamma, beta, nullptr, nullptr, 0, g.groups, grp, g.C, c, eps, (double)g.rows, mean[i], invstd[i],
+                      sc[i], sh[i]);
+            const float invn = 1.0f / (float)g.rows;
+            k1[i] = (float)bn_sum_total(sums, g.groups, grp, g.C, c, 0) * invn;
+            k2[i] = (float)bn_sum_total(sums, g.groups, grp, g.C, c, 1) * invn;
+        }
+    }
+    if (!coef && (ggamma || gbeta) && blockIdx.x == 0 && blockIdx.y == 0) {       // dgamma / dbeta: totals over the groups
+        for (int c = threadIdx.x; c < g.C; c += blockDim.x) {
+            double tb = 0, tg = 0;
+            for (int q = 0; q < g.groups; ++q) {
+                tb += bn_sum_total(sums, g.groups, q, g.C, c, 0);
+                tg += bn_sum_total(sums, g.groups, q, g.C, c, 1);
+            }
+            if (ggamma) ggamma[c] += (float)tg;
+            if (gbeta) gbeta[c] += (float)tb;
+        }
     }
     const size_t gbase = ((size_t)grp * g.rows) * g.C + cq * 4;
     const bool relu = flags & 1, mask_from_x = flags & 4;
@@ -300,6 +323,13 @@ int bh_bn_bwd(const float* gy, const float* y, const float* x, const float* gamm
     if ((flags & 4) && (flags & 2)) return BH_E_BADARG;        // the mask can only be recomputed without a residual input
     if (!bn_geom(groups, rows, C, g)) return BH_E_UNSUPPORTED;
     hipStream_t s = bh_stream(stream);
+    if (flags & 16) {            // scratch = padded sums accumulated by bh_conv_dgrad_bnreduce (training mode only)
+        if (use_running) return BH_E_BADARG;
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(apply_blocks(g), groups), dim3(256), 0, s, gy, y, x, gamma, beta,
+                           (const float4*)nullptr, gx, gres, g, flags, stats, (const double*)scratch, eps, ggamma, gbeta);
+        BH_LAUNCH_CHECK();
+        return BH_OK;
+    }
     // scratch: [groups][C] float4 coefficient table, then the per-chunk partial sums
     float4* coef = reinterpret_cast<float4*>(scratch);
     double* part = scratch + (size_t)groups * C * 2;
@@ -316,7 +346,8 @@ int bh_bn_bwd(const float* gy, const float* y, const float* x, const float* gamm
                        use_running, ggamma, gbeta, coef);
     BH_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(apply_blocks(g), groups), dim3(256), 0, s, gy, y, x, gamma, beta, coef,
-                       gx, gres, g, flags);
+                       gx, gres, g, flags, (const double*)nullptr, (const double*)nullptr, eps, (float*)nullptr,
+                       (float*)nullptr);
     BH_LAUNCH_CHECK();
     return BH_OK;
 }

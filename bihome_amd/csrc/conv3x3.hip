@@ -43,6 +43,17 @@ struct C3Args {
     int tiles_x, tiles_per_img, subtiles;
     const float* res;      // optional residual (same layout as Out) and ReLU applied in the epilogue (inference path)
     int relu;
+    // optional (dgrad): the tensor written here is the gradient w.r.t. the OUTPUT of a training-mode BatchNorm (+ReLU);
+    // the epilogue also accumulates that BatchNorm's backward sums (sum g*mask, sum g*mask*xhat) into bn_sums, so its
+    // adjoint needs no separate reduce pass.  bnr_z: the BatchNorm input, bnr_y: its output (ReLU mask when a residual
+    // was added; NULL -> the mask is recomputed from z), bnr_stats: forward sums (mean / variance), rows per group
+    const float* bnr_z;
+    const float* bnr_y;
+    const double* bnr_stats;
+    const float* bnr_gamma;
+    const float* bnr_beta;
+    float bnr_eps;
+    int bnr_relu, bnr_rows;
     double* bn_sums;       // optional [groups][Nn][2]: += per-channel (sum, sum of squares) of the output (forward only)
     int imgs_per_group, groups;
 };
@@ -206,21 +217,62 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
     const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
     const float bv = (a.bias && n < a.Nn) ? a.bias[n] : 0.0f;
     double s1 = 0.0, s2 = 0.0;                     // BatchNorm statistics of the tile (a.bn_sums): sum y, sum y^2
+    float r_mean = 0.f, r_invstd = 0.f, r_sc = 0.f, r_sh = 0.f;
+    if (a.bnr_z && valid) {                        // coefficients of the BatchNorm whose output gradient this tile is
+        const int grp = img / a.imgs_per_group;
+        const double rows = (double)a.bnr_rows;
+        const double mu = a.bnr_stats[bn_sum_index(0, a.groups, grp, a.Nn, n, 0)] / rows;
+        double var = a.bnr_stats[bn_sum_index(0, a.groups, grp, a.Nn, n, 1)] / rows - mu * mu;
+        if (var < 0) var = 0;
+        r_mean = (float)mu;
+        r_invstd = 1.0f / sqrtf((float)var + a.bnr_eps);
+        r_sc = (a.bnr_gamma ? a.bnr_gamma[n] : 1.f) * r_invstd;
+        r_sh = (a.bnr_beta ? a.bnr_beta[n] : 0.f) - r_mean * r_sc;
+    }
     if (valid) {
+        // phase 1: every global read of the epilogue (old gradient, residual, BatchNorm input / output) is issued before
+        // the first store - a load behind a store would otherwise wait for that store (one vmcnt queue, in order)
+        unsigned offs[TM][16];                       // element offsets (< 2^29: the host checks the tensor sizes)
+        float old[TM][16], zin[TM][16], yin[TM][16];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = (i + wh) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh2;
                 const int y = ty * 8 + (m >> 3), x = tx * 8 + (m & 7);
-                const size_t off = ((size_t)(img * a.H + y) * a.W + x) * a.Nn + n;
-                float v = acc[i][r] + bv;
-                if (a.accumulate) v += a.Out[off];
-                if (a.res) v += a.res[off];
+                offs[i][r] = (unsigned)((img * a.H + y) * a.W + x) * (unsigned)a.Nn + (unsigned)n;
+            }
+        const bool rd_old = a.accumulate, rd_res = a.res != nullptr, rd_z = a.bnr_z != nullptr;
+        const bool rd_y = rd_z && a.bnr_relu && a.bnr_y != nullptr;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float o = rd_old ? a.Out[offs[i][r]] : 0.f;
+                if (rd_res) o += a.res[offs[i][r]];
+                old[i][r] = o;
+                zin[i][r] = rd_z ? a.bnr_z[offs[i][r]] : 0.f;
+                yin[i][r] = rd_y ? a.bnr_y[offs[i][r]] : 0.f;
+            }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[i][r] + bv + old[i][r];
                 if (a.relu) v = fmaxf(v, 0.0f);
-                a.Out[off] = v;
-                s1 += (double)v;
-                s2 += (double)v * (double)v;
+                a.Out[offs[i][r]] = v;
+                if (rd_z) {
+                    const float zv = zin[i][r];
+                    if (a.bnr_relu) {
+                        const float yv = rd_y ? yin[i][r] : zv * r_sc + r_sh;
+                        if (!(yv > 0.f)) v = 0.f;
+                    }
+                    s1 += (double)v;
+                    s2 += (double)(v * ((zv - r_mean) * r_invstd));
+                } else {
+                    s1 += (double)v;
+                    s2 += (double)v * (double)v;
+                }
             }
     }
     if (a.bn_sums) {
@@ -268,7 +320,8 @@ void bh_conv3x3_tune(int disable, int min_blocks) {
 
 // *taken = 1 when the shape is eligible and the launch was made; returns BH_OK or a hipError_t
 int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* out, const bh_conv_desc* d, int dgrad,
-                   int accumulate, hipStream_t stream, int* taken, double* bn_sums, int groups, const float* res, int relu) {
+                   int accumulate, hipStream_t stream, int* taken, double* bn_sums, int groups, const float* res, int relu,
+                   const bh_bn_reduce* bnr) {
     *taken = 0;
     if (g_c3_disable || d->transposed || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->in_nchw ||
         d->out_nchw || (d->precision != 0 && d->precision != 1))
@@ -278,12 +331,18 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
     if (Kc % 32 || Nn % 32) return 0;
     const int bn_tile = (Nn % 64) ? 32 : 64;
     const long long src_bytes = (long long)d->N * d->Hi * d->Wi * Kc * 4, w_bytes = (long long)d->Co * 9 * d->Ci * 4;
-    if (src_bytes >= (1ll << 31) || w_bytes >= (1ll << 31)) return 0;
+    const long long out_bytes = (long long)d->N * d->Hi * d->Wi * Nn * 4;
+    if (src_bytes >= (1ll << 31) || w_bytes >= (1ll << 31) || out_bytes >= (1ll << 31)) return 0;
     C3Args a = {};
     a.Src = src; a.Wt = w; a.bias = bias; a.Out = out;
     a.N = d->N; a.H = d->Hi; a.W = d->Wi; a.Kc = Kc; a.Nn = Nn; a.Cw = d->Ci; a.accumulate = accumulate;
     a.src_bytes = (unsigned)src_bytes; a.w_bytes = (unsigned)w_bytes;
-    if (bn_sums && (dgrad || groups < 1 || d->N % groups)) return BH_E_BADARG;
+    if (bn_sums && ((dgrad != 0) != (bnr != nullptr) || groups < 1 || d->N % groups)) return BH_E_BADARG;
+    if (bnr) {
+        if (!bnr->z || !bnr->stats) return BH_E_BADARG;
+        a.bnr_z = bnr->z; a.bnr_y = bnr->y; a.bnr_stats = bnr->stats; a.bnr_gamma = bnr->gamma; a.bnr_beta = bnr->beta;
+        a.bnr_eps = bnr->eps; a.bnr_relu = bnr->relu; a.bnr_rows = (d->N / groups) * d->Hi * d->Wi;
+    }
     a.res = res; a.relu = relu;
     a.bn_sums = bn_sums; a.imgs_per_group = bn_sums ? d->N / groups : 1; a.groups = groups;
     a.tiles_x = d->Wi / 8; a.tiles_per_img = (d->Hi / 8) * a.tiles_x; a.subtiles = d->N * a.tiles_per_img;

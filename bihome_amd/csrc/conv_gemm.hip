@@ -743,7 +743,7 @@ __global__ void __launch_bounds__(256) col2im_c1_kernel(const float* __restrict_
 void bh_conv3x3_tune(int disable, int min_blocks);
 int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* out, const bh_conv_desc* d, int dgrad,
                    int accumulate, hipStream_t stream, int* taken, double* bn_sums, int groups, const float* res = nullptr,
-                   int relu = 0);
+                   int relu = 0, const bh_bn_reduce* bnr = nullptr);
 int bn_launch_stats(const float* x, int groups, int rows, int C, double* sums, hipStream_t s);
 
 static int check_desc(const bh_conv_desc* d) {
@@ -839,6 +839,17 @@ int bh_conv_fwd_bnstats(const float* x, const float* w, const float* bias, float
     rc = bh_conv_fwd(x, w, bias, y, d, stream);
     if (rc) return rc;
     return bn_launch_stats(y, groups, (d->N / groups) * d->Ho * d->Wo, d->Co, sums, bh_stream(stream));
+}
+
+int bh_conv_dgrad_bnreduce(const float* gy, const float* w, float* gx, const bh_conv_desc* d, int accumulate,
+                           const bh_bn_reduce* bnr, double* sums, int groups, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!gy || !w || !gx || !bnr || !sums) return BH_E_BADARG;
+    int taken = 0;
+    rc = bh_conv3x3_try(gy, w, nullptr, gx, d, 1, accumulate, bh_stream(stream), &taken, sums, groups, nullptr, 0, bnr);
+    if (rc) return rc;
+    return taken ? BH_OK : BH_E_UNSUPPORTED;       // only where the halo-tiled 3x3 kernel applies: the caller checks
 }
 
 int bh_conv_dgrad(const float* gy, const float* w, float* gx, const bh_conv_desc* d, int accumulate, void* stream) {

@@ -4,7 +4,7 @@ import ctypes
 
 import torch
 
-from ._lib import BhConvDesc, check, lib
+from ._lib import BhBnReduce, BhConvDesc, check, lib
 
 
 def _p(t):
@@ -87,7 +87,7 @@ def _c3_variant(d, dgrad):
             or d.precision not in (0, 1) or d.Hi % 8 or d.Wi % 8):
         return None
     Kc, Nn = (d.Co, d.Ci) if dgrad else (d.Ci, d.Co)
-    if Kc % 32 or Nn % 32 or d.N * d.Hi * d.Wi * Kc * 4 >= 2 ** 31:
+    if Kc % 32 or Nn % 32 or d.N * d.Hi * d.Wi * max(Kc, Nn) * 4 >= 2 ** 31:
         return None
     bn = 32 if Nn % 64 else 64
     if ((d.N * (d.Hi // 8) * (d.Wi // 8) + 1) // 2) * (Nn // bn) < C3_MIN_BLOCKS:
@@ -327,8 +327,27 @@ def _stem_dgrad_two_step(gy, w, d):
     return gx
 
 
-def conv_dgrad(gy, w, d, out=None):
+def dgrad_bn_reduce_ok(d):
+    """True when conv_dgrad(..., bn_reduce=...) is available for this conv (the halo-tiled 3x3 kernel takes its dgrad)."""
+    return _c3_variant(d, True) is not None
+
+
+def conv_dgrad(gy, w, d, out=None, bn_reduce=None):
+    """bn_reduce (only when dgrad_bn_reduce_ok(d)): dict(z, y, stats, gamma, beta, eps, relu, sums, groups) of the
+    BatchNorm whose output gradient this call completes - its backward sums are accumulated into `sums` (zeroed
+    bn_stats_buffer) in the conv epilogue; pass them to bn_bwd(..., sums_ready=sums)."""
     _chk(gy); _chk(w)
+    if bn_reduce is not None:
+        acc = out is not None
+        if out is None:
+            out = torch.empty((d.N, d.Hi, d.Wi, d.Ci), dtype=torch.float32, device=gy.device)
+        b = bn_reduce
+        _chk(b["z"]); _chk(b["y"]); _chk(b["stats"], torch.float64); _chk(b["sums"], torch.float64)
+        st = BhBnReduce(_p(b["z"]), _p(b["y"]), _p(b["stats"]), _p(b["gamma"]), _p(b["beta"]), float(b["eps"]), int(bool(b["relu"])))
+        with _Timed(_conv_variant(d, "dgrad"), conv_flops(d), 4.0 * (gy.numel() + out.numel() * (3 if acc else 2) + w.numel())):
+            check(lib.bh_conv_dgrad_bnreduce(_p(gy), _p(w), _p(out), ctypes.byref(d), int(acc), ctypes.byref(st), _p(b["sums"]),
+                                             int(b["groups"]), _stream()), "bh_conv_dgrad_bnreduce")
+        return out
     if (out is None and not d.transposed and d.kh == 7 and d.stride == 2 and not d.out_nchw
             and (d.Ci == 1 or (d.Ci == 3 and d.in_nchw)) and d.Co % 4 == 0 and d.N * d.Ho * d.Wo >= 4096):
         return _stem_dgrad_two_step(gy, w, d)
@@ -380,19 +399,23 @@ def bn_fwd(x, gamma, beta, rmean, rvar, res, groups, eps, momentum, relu, traini
 
 
 def bn_bwd(gy, y, x, gamma, stats, rmean, rvar, groups, eps, relu, training, want_gres, ggamma=None, gbeta=None, beta=None,
-           had_res=None, scratch=None):
+           had_res=None, scratch=None, sums_ready=None):
+    """sums_ready: the gradient sums buffer filled by conv_dgrad(..., bn_reduce=...) - reduce / finalize are skipped."""
     _chk(gy); _chk(x)
     C = x.shape[-1]
     rows = x.numel() // C // groups
     gx = torch.empty_like(x)
     gres = torch.empty_like(x) if want_gres else None
-    if scratch is None:
+    if sums_ready is not None:
+        scratch = sums_ready
+    elif scratch is None:
         scratch = torch.empty(lib.bh_bn_scratch_doubles(groups, C), dtype=torch.float64, device=x.device)
     had_res = want_gres if had_res is None else had_res
     mask_from_x = relu and not had_res          # y = relu(x*scale+shift): the mask is recomputed, y is not read
-    flags = (1 if relu else 0) | (2 if want_gres else 0) | (4 if mask_from_x else 0)
-    nb = 4.0 * x.numel() * (2 * (2 + (1 if (relu and not mask_from_x) else 0)) + 1 + (1 if want_gres else 0))
-    with _Timed("bn_bwd(3 kernels)" + (" g%d rows%d C%d" % (groups, rows, C) if TIMING_DETAIL else ""), 0.0, nb):
+    flags = (1 if relu else 0) | (2 if want_gres else 0) | (4 if mask_from_x else 0) | (16 if sums_ready is not None else 0)
+    passes = 1 if sums_ready is not None else 2
+    nb = 4.0 * x.numel() * (passes * (2 + (1 if (relu and not mask_from_x) else 0)) + 1 + (1 if want_gres else 0))
+    with _Timed("bn_bwd(%d kernels)" % (1 if sums_ready is not None else 3) + (" g%d rows%d C%d" % (groups, rows, C) if TIMING_DETAIL else ""), 0.0, nb):
         check(lib.bh_bn_bwd(_p(gy), _p(y), _p(x), _p(gamma), _p(beta), _p(stats), _p(gx), _p(gres), _p(ggamma), _p(gbeta),
                             _p(scratch), groups, rows, C, float(eps), flags, 0 if training else 1, _p(rmean), _p(rvar),
                             _stream()), "bh_bn_bwd")

@@ -368,6 +368,29 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
         else:
             grads[slot] = g
 
+    # A conv dgrad that COMPLETES the gradient of a training-mode BatchNorm's output (it is the last consumer of that
+    # slot in backward order) also accumulates that BatchNorm's backward sums in its epilogue (bh_conv_dgrad_bnreduce),
+    # so the BatchNorm adjoint is one apply launch instead of reduce + finalize + apply.
+    fuse_bn = {}                                          # conv op index -> bn op index
+    if ctx.training and os.environ.get("BIHOME_FUSE_BN_REDUCE", "1") != "0":
+        producer = {op.dst: j for j, op in enumerate(prog.ops)}
+        last_consumer = {}
+        for j, op in enumerate(prog.ops):                 # the lowest-index consumer is processed last
+            for sl in (op.src, op.res):
+                if sl is not None and sl not in last_consumer:
+                    last_consumer[sl] = j
+        for j, op in enumerate(prog.ops):
+            b = producer.get(op.src)
+            if (op.kind == "conv" and b is not None and prog.ops[b].kind == "bn" and last_consumer.get(op.src) == j
+                    and j in ctx.descs and K.dgrad_bn_reduce_ok(ctx.descs[j]) and ctx.descs[j].N % ctx.groups == 0):
+                fuse_bn[j] = b
+    red_off, total = {}, 0
+    for b in fuse_bn.values():
+        red_off[b] = total
+        total += K.bn_stats_doubles(ctx.groups, prog.ops[b].mod.num_features)
+    red_arena = torch.zeros(total, dtype=torch.float64, device=gout.device) if total else None
+    bn_reduced = {}
+
     for i in range(len(prog.ops) - 1, -1, -1):
         op = prog.ops[i]
         g = grads.pop(op.dst, None)
@@ -395,17 +418,26 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
                     if gb is not None:
                         on_param_grad(m.bias)
             if need_src_grad:
+                red = None
+                if i in fuse_bn:
+                    b = fuse_bn[i]
+                    bop, bm = prog.ops[b], prog.ops[b].mod
+                    sums = red_arena[red_off[b]:red_off[b] + K.bn_stats_doubles(ctx.groups, bm.num_features)]
+                    red = dict(z=slots[bop.src], y=slots[bop.dst] if (bop.relu and bop.res is not None) else None,
+                               stats=ctx.stats[b], gamma=bm.weight, beta=bm.bias, eps=bm.eps, relu=bop.relu, sums=sums,
+                               groups=ctx.groups)
+                    bn_reduced[b] = sums
                 if op.src in grads:
-                    K.conv_dgrad(g, wk, d, out=grads[op.src])
+                    K.conv_dgrad(g, wk, d, out=grads[op.src], bn_reduce=red)
                 else:
-                    grads[op.src] = K.conv_dgrad(g, wk, d)
+                    grads[op.src] = K.conv_dgrad(g, wk, d, bn_reduce=red)
         elif op.kind == "bn":
             m = op.mod
             train_w = want_wgrad and m.weight is not None and m.weight.requires_grad
             gx, gres = K.bn_bwd(g, slots[op.dst], x, m.weight, ctx.stats[i], m.running_mean, m.running_var, ctx.groups,
                                 m.eps, op.relu, ctx.training, op.res is not None and ((op.res != 0) or want_input_grad),
                                 m.weight.grad if train_w else None, m.bias.grad if train_w else None, beta=m.bias,
-                                had_res=op.res is not None)
+                                had_res=op.res is not None, sums_ready=bn_reduced.get(i))
             if train_w and on_param_grad is not None:
                 on_param_grad(m.weight)
                 on_param_grad(m.bias)

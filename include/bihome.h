@@ -133,6 +133,24 @@ int bh_conv_fwd_bnstats(const float* x, const float* w, const float* bias, float
 /* gx = conv^T(gy, w)  (overwritten; accumulate != 0: gx += ..., used where gradient branches join).
  * d->in_nchw: gx is written NCHW (gradient w.r.t. an NCHW network input; no accumulate, not transposed). */
 int bh_conv_dgrad(const float* gy, const float* w, float* gx, const bh_conv_desc* d, int accumulate, void* stream);
+/* The BatchNorm (+ReLU) whose OUTPUT gradient a dgrad produces: z = its input, y = its output (needed for the ReLU mask
+ * only when a residual was added; NULL: the mask is recomputed from z), stats = its forward sums (bh_bn_fwd). */
+typedef struct bh_bn_reduce {
+    const float* z;
+    const float* y;
+    const double* stats;
+    const float* gamma;
+    const float* beta;
+    float eps;
+    int relu;
+} bh_bn_reduce;
+/* bh_conv_dgrad that also accumulates, in its epilogue, the backward sums of that BatchNorm (sum g*mask, sum g*mask*xhat
+ * per group and channel) into `sums` (bh_bn_stats_doubles(groups, Ci) doubles, caller-zeroed): pass them to bh_bn_bwd
+ * with flags bit4 and its reduce pass is skipped.  gx must be the FINAL gradient (accumulate = 1 adds to the partial
+ * sum already in gx).  Only for shapes the halo-tiled 3x3 kernel takes (3x3, stride 1, pad 1, H, W multiples of 8,
+ * Co % 32 == 0, Ci % 32 == 0, fp32 or bf16 operands); BH_E_UNSUPPORTED otherwise and nothing is written. */
+int bh_conv_dgrad_bnreduce(const float* gy, const float* w, float* gx, const bh_conv_desc* d, int accumulate,
+                           const bh_bn_reduce* bnr, double* sums, int groups, void* stream);
 /* Second half of the two-step dgrad of the extractor's 7x7/2 stem on a grayscale (Ci = 1) or RGB (Ci = 3, in_nchw) patch:
  * Tm[N*Ho*Wo][ldT] = gy x w^T (one 1x1 bh_conv_fwd launch; column = tap*Ci + c, ldT >= 49*Ci padded)
  * -> gx[N,Ci,Hi,Wi] = col2im(Tm). */
@@ -159,7 +177,9 @@ int bh_bn_fwd(const float* x, const float* gamma, const float* beta, float* runn
               int flags, int use_running, void* stream);
 /* adjoint. gy: grad w.r.t. y; y: the forward output (for the relu mask); x: forward input.
  * -> gx (overwritten), gres (written when non-NULL: = masked gy), ggamma/gbeta += (NULL ok => frozen).
- * flags bit2 (only without residual): recompute the ReLU mask from x (y is not read, may be NULL). */
+ * flags bit2 (only without residual): recompute the ReLU mask from x (y is not read, may be NULL).
+ * flags bit4: `scratch` already holds the gradient sums (bh_bn_stats_doubles() layout) accumulated by
+ * bh_conv_dgrad_bnreduce - one launch instead of three. */
 int bh_bn_bwd(const float* gy, const float* y, const float* x, const float* gamma, const float* beta, const double* stats,
               float* gx, float* gres, float* ggamma, float* gbeta, double* scratch,
               int groups, int rows, int C, float eps, int flags, int use_running,

@@ -321,3 +321,46 @@ def test_conv_fwd_with_batchnorm_sums(K, N, H, Ci, Co, k, groups):
         close(o1.cpu(), o2.cpu(), 1e-5)
     finally:
         lib.bh_debug_force_tile(-5, 256)
+
+
+@pytest.mark.parametrize("N,H,C,Co,groups,relu,res,acc", [
+    (8, 16, 64, 64, 2, True, False, False),     # inner BatchNorm of a residual unit: mask recomputed from z
+    (8, 16, 64, 32, 2, True, True, True),       # block-output BatchNorm: residual added, gradient joined (accumulate)
+    (4, 8, 32, 64, 2, False, False, False),     # no ReLU, 32-channel variant of the dgrad kernel
+])
+def test_dgrad_epilogue_accumulates_batchnorm_backward_sums(K, N, H, C, Co, groups, relu, res, acc):
+    """bh_conv_dgrad_bnreduce + bh_bn_bwd(flags bit4) against the three-launch BatchNorm adjoint on the same gradient."""
+    from bihome_amd._lib import lib
+    lib.bh_debug_force_tile(-5, 1)
+    K.C3_MIN_BLOCKS = 1                      # (the Python mirror of the same threshold)
+    try:
+        z = torch.tensor(rnd((N, H, H, C), 80) * 1.5 + 0.3).cuda()
+        r = torch.tensor(rnd((N, H, H, C), 81)).cuda() if res else None
+        gm, bt = torch.tensor(1 + 0.3 * rnd((C,), 82)).cuda(), torch.tensor(0.2 * rnd((C,), 83)).cuda()
+        rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+        y, st = K.bn_fwd(z, gm, bt, rm, rv, r, groups, 1e-5, 0.1, relu, True)
+        # the conv that consumes y: 3x3, C -> Co
+        d = K.conv_desc(N, H, H, C, Co, 3, 1, 1)
+        w = torch.tensor(rnd((Co, 3, 3, C), 84) * 0.1).cuda()
+        gy = torch.tensor(rnd((N, H, H, Co), 85)).cuda()
+        part = torch.tensor(rnd((N, H, H, C), 86)).cuda() if acc else None      # gradient already joined from another branch
+        # reference path: plain dgrad, then the three-launch adjoint
+        g_ref = K.conv_dgrad(gy, w, d, out=part.clone()) if acc else K.conv_dgrad(gy, w, d)
+        gg0, gb0 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        gx0, gr0 = K.bn_bwd(g_ref, y, z, gm, st, rm, rv, groups, 1e-5, relu, True, res, gg0, gb0, beta=bt)
+        # fused path
+        sums = K.bn_stats_buffer(groups, C, "cuda")
+        red = dict(z=z, y=y if (relu and res) else None, stats=st, gamma=gm, beta=bt, eps=1e-5, relu=relu, sums=sums, groups=groups)
+        assert K.dgrad_bn_reduce_ok(d)
+        g_f = K.conv_dgrad(gy, w, d, out=part.clone(), bn_reduce=red) if acc else K.conv_dgrad(gy, w, d, bn_reduce=red)
+        assert torch.equal(g_f, g_ref)
+        gg1, gb1 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        gx1, gr1 = K.bn_bwd(g_f, y, z, gm, st, rm, rv, groups, 1e-5, relu, True, res, gg1, gb1, beta=bt, sums_ready=sums)
+        close(gx1.cpu(), gx0.cpu(), 2e-5)
+        close(gg1.cpu(), gg0.cpu(), 2e-5)
+        close(gb1.cpu(), gb0.cpu(), 2e-5)
+        if res:
+            assert torch.equal(gr1, gr0)
+    finally:
+        lib.bh_debug_force_tile(-5, 256)
+        K.C3_MIN_BLOCKS = 256
