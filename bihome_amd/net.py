@@ -526,7 +526,9 @@ class Runner:
         self.reducer = None        # bihome_amd.ddp.FlatGradReducer when training data-parallel
         self._fold = {}            # eval-mode BatchNorm folding cache (run_forward / _folded)
         self.fold_bn = os.environ.get("BIHOME_FOLD_BN", "1") != "0"
-        self.wgrad_on_side_stream = os.environ.get("BIHOME_WGRAD_STREAM", "1") != "0"
+        # opt-in (BIHOME_OVERLAP=1 or bench.py --overlap): +3% step throughput, but kernels of the two streams share the
+        # GPU, so per-kernel durations (rocprof, the roofline leg) are no longer those of the kernel alone
+        self.wgrad_on_side_stream = os.environ.get("BIHOME_OVERLAP", "0") == "1"
 
     def __call__(self, x, groups):
         if not x.is_cuda:
