@@ -391,3 +391,37 @@ def test_pretrained_resnet_path_loads_imagenet_layout(tmp_path):
     assert torch.isfinite(out["delta_hat_12"]).all()
     with pytest.raises(RuntimeError, match="no network"):
         importlib.import_module("src.backbones.ResNet34").Model(**dict(cfg, PRETRAINED_RESNET=True))
+
+
+@pytest.mark.parametrize("B,patch", [(3, 128), (1, 128), (5, 64)])
+def test_ragged_batches_first_step_vs_oracle(B, patch):
+    """Odd / minimal batch sizes and a second patch size: the stacked-direction layout (2B images, 2 statistics groups),
+    the odd sub-tile counts of the 3x3 kernel and the fallbacks for small grids against the float64 oracle on the
+    same inputs, weights and DSAC indices (first forward + loss + MACE; B = 1 has one image per BatchNorm group)."""
+    from bihome_amd.step import build_model, mace
+    cfg = configs.get("zeng-bihome")
+    cfg["MODEL"]["BACKBONE"]["IMAGE_SIZE"] = patch
+    cfg["MODEL"]["HEAD"]["PATCH_SIZE"] = patch
+    model = build_model(cfg)
+    load_synthetic(model[0], 0)
+    load_synthetic(model[1].auxiliary_resnet, 0)
+    bb, head = O.build(cfg)
+    load_synthetic(bb, 0)
+    load_synthetic(head.auxiliary_resnet, 0)
+    bb.double().train(); head.double().train()
+    d = synth.make_pairs(B, patch=patch, rho=patch // 4, seed=50 + B)
+    g = torch.Generator().manual_seed(B)
+    c12 = torch.randint(0, patch * patch, (B, 128), generator=g)
+    c21 = torch.randint(0, patch * patch, (B, 128), generator=g)
+    ref_data = {k: torch.tensor(d[k], dtype=torch.float64) for k in ("patch_1", "patch_2", "delta")}
+    ref_loss, ref_gt, ref_dh = head(bb(ref_data), c12, c21)
+    model.train()
+    data = {k: cuda(d[k]) for k in ("patch_1", "patch_2", "delta")}
+    data["choice_12"], data["choice_21"] = c12.cuda(), c21.cuda()
+    loss, dgt, dh = model(data)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert relerr(data["pf_hat_12"].detach().cpu(), ref_data["pf_hat_12"].detach()) < 5e-4
+    assert abs(loss.item() - ref_loss.item()) <= 2e-4 * abs(ref_loss.item()) + 1e-6
+    assert abs(mace(dgt, dh) - O.mace(ref_gt, ref_dh)) < 2e-3
+    assert all(torch.isfinite(p.grad).all() for p in model[0].parameters())
