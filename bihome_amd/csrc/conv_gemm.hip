@@ -745,6 +745,9 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
                    int accumulate, hipStream_t stream, int* taken, double* bn_sums, int groups, const float* res = nullptr,
                    int relu = 0, const bh_bn_reduce* bnr = nullptr);
 int bn_launch_stats(const float* x, int groups, int rows, int C, double* sums, hipStream_t s);
+void bh_stem7_tune(int disable);
+int bh_stem7_try(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, int relu,
+                 hipStream_t stream, int* taken);
 
 static int check_desc(const bh_conv_desc* d) {
     if (!d) return BH_E_BADARG;
@@ -782,6 +785,7 @@ int bh_debug_force_tile(int bm, int bn) {
     if (bm == -3) { g_wgrad_target = bn; return BH_OK; }    // (-3, n): wgrad split-K work items per launch
     if (bm == -4) { bh_conv3x3_tune(bn, 0); return BH_OK; } // (-4, 1): disable the halo-tiled 3x3 kernel
     if (bm == -5) { bh_conv3x3_tune(0, bn); return BH_OK; } // (-5, n): minimum workgroups for the halo-tiled 3x3 kernel
+    if (bm == -6) { bh_stem7_tune(bn); return BH_OK; }      // (-6, 1): disable the dedicated 7x7 stem forward kernel
     g_force_bm = bm; g_force_bn = bn; return BH_OK;
 }
 
@@ -791,6 +795,11 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, cons
     if (rc) return rc;
     if (!x || !w || !y) return BH_E_BADARG;
     if (res && d->out_nchw) return BH_E_UNSUPPORTED;
+    if (!res) {
+        int taken = 0;
+        rc = bh_stem7_try(x, w, bias, y, d, relu, bh_stream(stream), &taken);
+        if (rc || taken) return rc;
+    }
     {
         int taken = 0;
         rc = bh_conv3x3_try(x, w, bias, y, d, 0, 0, bh_stream(stream), &taken, nullptr, 1, res, relu);

@@ -1,0 +1,135 @@
+// Forward of the 7x7 / stride 2 / pad 3 stem convolutions (Rethinking.py:31 layer1, ResNet34.py:17 conv1, the extractor's
+// resnet.conv1 of PerceptualHead.py:52-55): few input channels (1 grayscale patch, 2 stacked patches, 3 RGB, 6 stacked
+// RGB) -> 64 channels, NCHW image planes in, NHWC out.
+//
+// As an implicit GEMM this is K = 49*Cin (49 ... 294) with a gather that no vector load serves; the generic kernel
+// runs it on its scalar path at ~20 TFLOP/s.  Here a persistent workgroup keeps the whole transposed filter bank
+// Wt[k = (c, ky, kx)][64] in LDS, and per 8x8 output tile stages the 21x21 input patch of every channel once; the A
+// fragment of MFMA step kk is then ONE ds_read_b32 at (lane's pixel base) + (compile-time offset of tap k), the k loop
+// is fully unrolled so those offsets are literals (the two half-waves take k = 2kk and 2kk+1).  The output (the only
+// large stream: 64 channels x 4 B per pixel) is written as 128-byte rows.  fp32 MFMA (v_mfma_f32_32x32x2_f32) in
+// every precision mode.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Stem7Args {
+    const float* x;        // [N][CIN][Hi][Wi]
+    const float* w;        // [64][7][7][CIN]
+    const float* bias;     // [64] or NULL
+    float* y;              // [N][Ho][Wo][64]
+    int N, Hi, Wi, Ho, Wo;
+    int tiles_x, tiles_per_img, ntiles;
+    int relu;              // epilogue ReLU (inference: BatchNorm folded into w / bias)
+};
+
+template <int CIN>
+__global__ void __launch_bounds__(256) stem7_fwd_kernel(Stem7Args a) {
+    constexpr int K = 49 * CIN;
+    constexpr int KP = (K + 3) / 4 * 4;                 // 52, 100, 148, 296: zero-padded filter rows
+    constexpr int PW = 21, PCH = PW * PW;               // input patch of an 8x8 output tile: (8-1)*2 + 7 = 21
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Wt = sm;                                     // [KP][64]
+    float* patch = sm + KP * 64;                        // [CIN][21][21]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh2 = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+
+    for (int i = tid; i < KP * 64; i += 256) Wt[i] = 0.f;
+    __syncthreads();
+    for (int i = tid; i < 64 * K; i += 256) {           // w[n][t][c] -> Wt[c*49 + t][n]
+        const int n = i / K, r = i - n * K, t = r / CIN, c = r - t * CIN;
+        Wt[(c * 49 + t) * 64 + n] = a.w[i];
+    }
+    // lane's pixel inside the tile: rows [wm*32, wm*32+32) -> output (py, px) = (wm*4 + l31/8, l31%8)
+    const int py = wm * 4 + (l31 >> 3), px = l31 & 7;
+    const float* abase = patch + (2 * py) * PW + 2 * px;
+    const float* bbase = Wt + wn * 32 + l31;
+    const float bv = a.bias ? a.bias[wn * 32 + l31] : 0.f;
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int img = tile / a.tiles_per_img, t = tile - img * a.tiles_per_img;
+        const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+        const int iy0 = ty * 16 - 3, ix0 = tx * 16 - 3;
+        __syncthreads();                                 // previous tile's fragment reads are done (and Wt is complete)
+        for (int i = tid; i < CIN * PCH; i += 256) {
+            const int c = i / PCH, r = i - c * PCH, yy = r / PW, xx = r - yy * PW;
+            const int iy = iy0 + yy, ix = ix0 + xx;
+            float v = 0.f;
+            if ((unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi)
+                v = a.x[(((size_t)img * CIN + c) * a.Hi + iy) * a.Wi + ix];
+            patch[i] = v;
+        }
+        __syncthreads();
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KP / 2; ++kk) {
+            // taps of the two half-waves (compile-time): k -> (c, ky, kx) -> patch offset; padded k read offset 0 (Wt row is 0)
+            const int k0 = 2 * kk, k1 = 2 * kk + 1;
+            const int o0 = k0 < K ? (k0 / 49) * PCH + ((k0 % 49) / 7) * PW + (k0 % 49) % 7 : 0;
+            const int o1 = k1 < K ? (k1 / 49) * PCH + ((k1 % 49) / 7) * PW + (k1 % 49) % 7 : 0;
+            const float av = abase[kh2 ? o1 : o0];
+            const float bw = bbase[(kh2 ? k1 : k0) * 64];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bw, acc, 0, 0, 0);
+        }
+        // C/D layout: col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh2;
+            const int oy = ty * 8 + (m >> 3), ox = tx * 8 + (m & 7);
+            float v = acc[r] + bv;
+            if (a.relu) v = fmaxf(v, 0.f);
+            a.y[(((size_t)img * a.Ho + oy) * a.Wo + ox) * 64 + wn * 32 + l31] = v;
+        }
+    }
+}
+
+template <int CIN>
+static int stem7_launch(const Stem7Args& a, hipStream_t s) {
+    constexpr int KP = (49 * CIN + 3) / 4 * 4;
+    const size_t lds = sizeof(float) * (KP * 64 + CIN * 21 * 21);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem7_fwd_kernel<CIN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int per_cu = lds > 40 * 1024 ? (lds > 80 * 1024 ? 1 : 2) : 4;
+    int blocks = 256 * per_cu;
+    if (blocks > a.ntiles) blocks = a.ntiles;
+    hipLaunchKernelGGL((stem7_fwd_kernel<CIN>), dim3(blocks), dim3(256), lds, s, a);
+    BH_LAUNCH_CHECK();
+    return BH_OK;
+}
+
+static int g_stem7_disable = 0;
+void bh_stem7_tune(int disable) { g_stem7_disable = disable; }
+
+// *taken = 1 when the shape is a stem this kernel takes and the launch was made
+int bh_stem7_try(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, int relu,
+                 hipStream_t stream, int* taken) {
+    *taken = 0;
+    if (g_stem7_disable || d->transposed || d->kh != 7 || d->kw != 7 || d->stride != 2 || d->pad != 3 || d->Co != 64 ||
+        d->out_nchw)
+        return BH_OK;
+    if (!(d->Ci == 1 || ((d->Ci == 2 || d->Ci == 3 || d->Ci == 6) && d->in_nchw))) return BH_OK;
+    if (d->Ho % 8 || d->Wo % 8 || d->Ho * 2 != d->Hi || d->Wo * 2 != d->Wi) return BH_OK;
+    Stem7Args a = {};
+    a.x = x; a.w = w; a.bias = bias; a.y = y; a.relu = relu;
+    a.N = d->N; a.Hi = d->Hi; a.Wi = d->Wi; a.Ho = d->Ho; a.Wo = d->Wo;
+    a.tiles_x = d->Wo / 8; a.tiles_per_img = (d->Ho / 8) * a.tiles_x; a.ntiles = d->N * a.tiles_per_img;
+    if (a.ntiles < 256) return BH_OK;
+    int rc;
+    switch (d->Ci) {
+        case 1: rc = stem7_launch<1>(a, stream); break;
+        case 2: rc = stem7_launch<2>(a, stream); break;
+        case 3: rc = stem7_launch<3>(a, stream); break;
+        default: rc = stem7_launch<6>(a, stream); break;
+    }
+    if (rc) return rc;
+    *taken = 1;
+    return BH_OK;
+}

@@ -95,7 +95,20 @@ def _c3_variant(d, dgrad):
     return "conv3x3_halo_kernel<%s,%d,%s>" % ("true" if dgrad else "false", bn, "true" if d.precision == 1 else "false")
 
 
+def _stem7_variant(d):
+    """Mirror of bh_stem7_try (csrc/stem7.hip)."""
+    if (d.transposed or d.kh != 7 or d.kw != 7 or d.stride != 2 or d.pad != 3 or d.Co != 64 or d.out_nchw
+            or not (d.Ci == 1 or (d.Ci in (2, 3, 6) and d.in_nchw)) or d.Ho % 8 or d.Wo % 8 or d.Ho * 2 != d.Hi
+            or d.Wo * 2 != d.Wi or d.N * (d.Ho // 8) * (d.Wo // 8) < 256):
+        return None
+    return "stem7_fwd_kernel<%d>" % d.Ci
+
+
 def _conv_variant0(d, which):
+    if which == "fwd":
+        st = _stem7_variant(d)
+        if st is not None:
+            return st
     c3 = _c3_variant(d, which != "fwd")
     if c3 is not None:
         return c3

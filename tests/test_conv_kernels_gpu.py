@@ -364,3 +364,30 @@ def test_dgrad_epilogue_accumulates_batchnorm_backward_sums(K, N, H, C, Co, grou
     finally:
         lib.bh_debug_force_tile(-5, 256)
         K.C3_MIN_BLOCKS = 256
+
+
+@pytest.mark.parametrize("N,H,Ci,relu", [(4, 128, 1, False), (4, 128, 2, False), (2, 256, 3, False), (1, 256, 6, True)])
+def test_stem7_forward_kernel(K, N, H, Ci, relu):
+    """csrc/stem7.hip (7x7 / stride 2 / pad 3 stems, NCHW planes -> NHWC) against torch float64 and the generic kernel."""
+    from bihome_amd._lib import lib
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, Ci, H, H, generator=g, dtype=torch.float64)
+    w = torch.randn(64, Ci, 7, 7, generator=g, dtype=torch.float64) * 0.1
+    b = torch.randn(64, generator=g, dtype=torch.float64)
+    ref = F.conv2d(x, w, b, 2, 3)
+    if relu:
+        ref = F.relu(ref)
+    d = K.conv_desc(N, H, H, Ci, 64, 7, 2, 3, in_nchw=Ci != 1)
+    assert K._conv_variant(d, "fwd") == "stem7_fwd_kernel<%d>" % Ci
+    xk = x.float().cuda().contiguous()
+    if Ci == 1:
+        xk = xk.view(N, H, H, 1)
+    wk = w.float().cuda().permute(0, 2, 3, 1).contiguous()
+    y = K.conv_fwd(xk, wk, b.float().cuda(), d, relu=relu)
+    close(y.permute(0, 3, 1, 2).cpu(), ref, 2e-5)
+    lib.bh_debug_force_tile(-6, 1)
+    try:
+        y0 = K.conv_fwd(xk, wk, b.float().cuda(), d, relu=relu)
+    finally:
+        lib.bh_debug_force_tile(-6, 0)
+    close(y.cpu(), y0.cpu(), 2e-5)
