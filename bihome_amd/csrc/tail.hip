@@ -11,6 +11,8 @@
 // K = 16 is far too small for MFMA tiles to pay; these are VALU kernels bounded by reading x (64 B/pixel).
 #include "common.h"
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 #define TAIL_MAXCI 32
 #define TAIL_CHUNKS 512
 
@@ -169,26 +171,44 @@ __global__ void __launch_bounds__(256) tail_fwd_kernel(const float* __restrict__
     tail_load_consts(L, sm, g, w1, b1, gamma, beta, w2, ystats, rmean, rvar, use_running, grp, eps);
     float bo[4];
     for (int o = 0; o < 4; ++o) bo[o] = (o < g.Co && b2) ? b2[o] : 0.f;
-    for (int r = blockIdx.x * 256 + threadIdx.x; r < g.rows; r += gridDim.x * 256) {
-        const size_t m = (size_t)grp * g.rows + r;
-        float xv[CI];
-        load_x<CI>(x + m * CI, xv);
-        float o0 = bo[0], o1 = bo[1], o2 = bo[2], o3 = bo[3];
+    // two pixels per thread, float2 arithmetic: the channel loop is FMA-bound and v_pk_fma_f32 issues two fp32 FMAs per
+    // lane per cycle (the weight / constant operands are the same for both pixels)
+    const int stride = gridDim.x * 256;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < g.rows; r += 2 * stride) {
+        const int r1 = r + stride;
+        const bool has1 = r1 < g.rows;
+        const size_t m0 = (size_t)grp * g.rows + r, m1 = has1 ? (size_t)grp * g.rows + r1 : m0;
+        float xa[CI], xb[CI];
+        load_x<CI>(x + m0 * CI, xa);
+        load_x<CI>(x + m1 * CI, xb);
+        f32x2 xv[CI];
+#pragma unroll
+        for (int k = 0; k < CI; ++k) xv[k] = f32x2{xa[k], xb[k]};
+        f32x2 o0 = f32x2{bo[0], bo[0]}, o1 = f32x2{bo[1], bo[1]}, o2 = f32x2{bo[2], bo[2]}, o3 = f32x2{bo[3], bo[3]};
         for (int c = 0; c < g.Cm; ++c) {
             const float* wr = L.w1 + c * CI;
             const float* cs = L.cst + c * 8;
-            float y = cs[0];
+            f32x2 y = f32x2{cs[0], cs[0]};
 #pragma unroll
-            for (int k = 0; k < CI; ++k) y = fmaf(wr[k], xv[k], y);
-            const float z = fmaxf(fmaf(y, cs[1], cs[2]), 0.f);
-            o0 = fmaf(z, cs[3], o0); o1 = fmaf(z, cs[4], o1); o2 = fmaf(z, cs[5], o2); o3 = fmaf(z, cs[6], o3);
+            for (int k = 0; k < CI; ++k) y = __builtin_elementwise_fma(f32x2{wr[k], wr[k]}, xv[k], y);
+            f32x2 z = __builtin_elementwise_fma(y, f32x2{cs[1], cs[1]}, f32x2{cs[2], cs[2]});
+            z = __builtin_elementwise_max(z, f32x2{0.f, 0.f});
+            o0 = __builtin_elementwise_fma(z, f32x2{cs[3], cs[3]}, o0);
+            o1 = __builtin_elementwise_fma(z, f32x2{cs[4], cs[4]}, o1);
+            o2 = __builtin_elementwise_fma(z, f32x2{cs[5], cs[5]}, o2);
+            o3 = __builtin_elementwise_fma(z, f32x2{cs[6], cs[6]}, o3);
         }
-        const size_t img = m / g.hw, p = m - img * g.hw;
-        float* op = out + img * g.Co * g.hw + p;
-        op[0] = o0;
-        if (g.Co > 1) op[(size_t)g.hw] = o1;
-        if (g.Co > 2) op[2 * (size_t)g.hw] = o2;
-        if (g.Co > 3) op[3 * (size_t)g.hw] = o3;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 1 && !has1) break;
+            const size_t m = h ? m1 : m0;
+            const size_t img = m / g.hw, p = m - img * g.hw;
+            float* op = out + img * g.Co * g.hw + p;
+            op[0] = o0[h];
+            if (g.Co > 1) op[(size_t)g.hw] = o1[h];
+            if (g.Co > 2) op[2 * (size_t)g.hw] = o2[h];
+            if (g.Co > 3) op[3 * (size_t)g.hw] = o3[h];
+        }
     }
 }
 
