@@ -44,6 +44,11 @@ struct GemmArgs {
     int ek, eC;            // scatter: kernel (== stride) and real channel count (Nn = ek*ek*eC)
     const float* res;      // optional residual added in the epilogue (same layout as Out)
     int relu;              // epilogue ReLU (inference: BatchNorm folded into the weights, activation fused)
+    // optional: per-channel (sum, sum of squares) of the output accumulated into the padded BatchNorm sums table
+    // (forward statistics of the BatchNorm that follows).  bn_rpg = GEMM rows per statistics group, a multiple of
+    // every BM (host check), so a tile never straddles groups; bn_C = channels of the table (eC for the scatter epilogue)
+    double* bn_sums;
+    int bn_rpg, bn_groups, bn_C;
 };
 
 
@@ -520,6 +525,9 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
     }
 
     // ---- epilogue: C/D layout col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m) ----
+    double st1[TN], st2[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { st1[j] = 0.0; st2[j] = 0.0; }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + (wn * TN + j) * 32 + l31;
@@ -551,6 +559,33 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
                 if (a.res) v += a.res[off];
                 if (a.relu) v = fmaxf(v, 0.0f);
                 a.Out[off] = v;
+                st1[j] += (double)v;
+                st2[j] += (double)v * (double)v;
+            }
+        }
+    }
+    if (a.bn_sums) {
+        // column sums of the tile: half-waves merged by a shuffle, the WM waves of a column range through LDS (the
+        // operand tiles are dead after the last barrier of the k loop), one f64 atomic per (column, moment)
+        double* red = reinterpret_cast<double*>(As);            // [WM][BN][2]
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const double s1 = st1[j] + __shfl_xor(st1[j], 32, 64), s2 = st2[j] + __shfl_xor(st2[j], 32, 64);
+            if (kh2 == 0) {
+                const int col = (wn * TN + j) * 32 + l31;
+                red[(wm * BN + col) * 2] = s1;
+                red[(wm * BN + col) * 2 + 1] = s2;
+            }
+        }
+        __syncthreads();
+        if (tid < BN * 2) {
+            const int col = tid >> 1, mom = tid & 1, n = n0 + col;
+            if (n < a.Nn) {
+                double tot = 0.0;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) tot += red[(w * BN + col) * 2 + mom];
+                const int co = a.epi == 1 ? n % a.eC : n;
+                atomicAdd(&a.bn_sums[bn_sum_index(0, a.bn_groups, m0 / a.bn_rpg, a.bn_C, co, mom)], tot);
             }
         }
     }
@@ -566,7 +601,7 @@ static int launch(const GemmArgs& a, hipStream_t s) {
 
 // Tile choice: the largest tile that still gives the 256 CUs about two workgroups each; the small-spatial
 // layers (8x8x256ch, 16x16x128ch at 2B = 128) otherwise launch only 128-256 workgroups.
-extern int g_wgrad_target;
+extern int g_wgrad_target, g_wgrad_noflush;
 static int g_force_bm = 0, g_force_bn = 0, g_prio = 0, g_no_buf = 0;     // tuning hook (bh_debug_force_tile), 0 = automatic
 
 static int dispatch(const GemmArgs& a_in, hipStream_t s) {
@@ -785,28 +820,37 @@ int bh_debug_force_tile(int bm, int bn) {
     if (bm == -3) { g_wgrad_target = bn; return BH_OK; }    // (-3, n): wgrad split-K work items per launch
     if (bm == -4) { bh_conv3x3_tune(bn, 0); return BH_OK; } // (-4, 1): disable the halo-tiled 3x3 kernel
     if (bm == -5) { bh_conv3x3_tune(0, bn); return BH_OK; } // (-5, n): minimum workgroups for the halo-tiled 3x3 kernel
-    if (bm == -6) { bh_stem7_tune(bn); return BH_OK; }      // (-6, 1): disable the dedicated 7x7 stem forward kernel
+    if (bm == -6) { bh_stem7_tune(bn); return BH_OK; }
+    if (bm == -7) { g_wgrad_noflush = bn; return BH_OK; }   // (-7, 1): ablation - wgrad without its atomic flush      // (-6, 1): disable the dedicated 7x7 stem forward kernel
     g_force_bm = bm; g_force_bn = bn; return BH_OK;
 }
 
 static int conv_fwd_impl(const float* x, const float* w, const float* bias, const float* res, float* y, const bh_conv_desc* d,
-                         int relu, void* stream) {
+                         int relu, void* stream, double* bn_sums = nullptr, int groups = 1) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!x || !w || !y) return BH_E_BADARG;
     if (res && d->out_nchw) return BH_E_UNSUPPORTED;
-    if (!res) {
+    if (!res && !bn_sums) {
         int taken = 0;
         rc = bh_stem7_try(x, w, bias, y, d, relu, bh_stream(stream), &taken);
         if (rc || taken) return rc;
     }
-    {
+    if (!bn_sums) {
         int taken = 0;
         rc = bh_conv3x3_try(x, w, bias, y, d, 0, 0, bh_stream(stream), &taken, nullptr, 1, res, relu);
         if (rc || taken) return rc;
     }
     GemmArgs a = {};
     a.res = res; a.relu = relu;
+    if (bn_sums) {
+        // rows of the GEMM per statistics group (input pixels for the transposed conv, whose taps scatter inside the image)
+        const long long rpg = (long long)(d->N / groups) * (d->transposed ? d->Hi * d->Wi : d->Ho * d->Wo);
+        // every workgroup ends with one atomic per (channel, moment): beyond ~2k workgroups per address the atomic unit
+        // (one same-address f64 atomic per ~30 ns) is slower than a separate statistics pass
+        if (d->out_nchw || rpg % 128 || rpg * groups > 2048ll * 64) return BH_E_UNSUPPORTED;
+        a.bn_sums = bn_sums; a.bn_rpg = (int)rpg; a.bn_groups = groups; a.bn_C = d->Co;
+    }
     a.Src = x; a.Bw = w; a.bias = bias; a.Out = y; a.bf16 = d->precision == 1;
     a.Hs = d->Hi; a.Ws = d->Wi; a.Cs = d->Ci; a.Kc = d->Ci;
     a.src_elems = (long long)d->N * d->Hi * d->Wi * d->Ci;
@@ -841,12 +885,19 @@ int bh_conv_fwd_bnstats(const float* x, const float* w, const float* bias, float
                         int groups, void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
-    if (!x || !w || !y || !sums || groups < 1 || d->N % groups || d->out_nchw || d->transposed) return BH_E_BADARG;
+    if (!x || !w || !y || !sums || groups < 1 || d->N % groups || d->out_nchw) return BH_E_BADARG;
     int taken = 0;
     rc = bh_conv3x3_try(x, w, bias, y, d, 0, 0, bh_stream(stream), &taken, sums, groups);
     if (rc || taken) return rc;
-    rc = bh_conv_fwd(x, w, bias, y, d, stream);
+    rc = bh_stem7_try(x, w, bias, y, d, 0, bh_stream(stream), &taken);        // (statistics by the separate kernel below)
     if (rc) return rc;
+    if (!taken) {
+        rc = conv_fwd_impl(x, w, bias, nullptr, y, d, 0, stream, sums, groups);   // generic kernel, statistics in its epilogue
+        if (rc == BH_OK) return rc;
+        if (rc != BH_E_UNSUPPORTED) return rc;
+        rc = bh_conv_fwd(x, w, bias, y, d, stream);
+        if (rc) return rc;
+    }
     return bn_launch_stats(y, groups, (d->N / groups) * d->Ho * d->Wo, d->Co, sums, bh_stream(stream));
 }
 

@@ -27,6 +27,7 @@ struct WgradArgs {
     unsigned p_bytes, q_bytes;
     int joint;               // scalar path: GEMM columns run over (t, c) jointly, T' = 1
     int rows_per_block;
+    int noflush;             // ablation (bh_debug_force_tile(-7, 1)): skip the atomic flush
 };
 
 #define WBK 32
@@ -186,7 +187,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int p = p0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh2;
-            if (p < a.Np) atomicAdd(a.Out + (long long)p * a.sOp + (long long)t * a.sOt + q, acc[r]);
+            if (p < a.Np && !a.noflush) atomicAdd(a.Out + (long long)p * a.sOp + (long long)t * a.sOt + q, acc[r]);
         }
     }
 }
@@ -481,6 +482,7 @@ __global__ void __launch_bounds__(256) plane_sum_kernel(const float* __restrict_
     if (threadIdx.x == 0) atomicAdd(out, sm[0] + sm[1] + sm[2] + sm[3]);
 }
 
+int g_wgrad_noflush = 0;
 int g_wgrad_target = 4096;      // split-K work items per launch (tuning hook: bh_debug_force_tile(-3, n))
 
 extern "C" {
@@ -533,6 +535,7 @@ int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, cons
     if (split < 1) split = 1;
     const int gran = small ? 4 * WBK : WBK;
     a.rows_per_block = (((a.M + split - 1) / split) + gran - 1) / gran * gran;
+    a.noflush = g_wgrad_noflush;
     split = (a.M + a.rows_per_block - 1) / a.rows_per_block;
     dim3 grid(tiles, ty, split);
     if (small && vec && !a.p_nchw && (a.T == 9 || a.T == 4) && d->precision == 0) {

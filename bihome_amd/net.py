@@ -254,7 +254,7 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None):
         for i, op in enumerate(prog.ops):
             j = producer.get(op.src)
             if (op.kind == "bn" and j is not None and prog.ops[j].kind == "conv" and users.get(op.src, 0) == 1
-                    and not prog.ops[j].extra["out_nchw"] and not isinstance(prog.ops[j].mod, nn.ConvTranspose2d)):
+                    and not prog.ops[j].extra["out_nchw"] and prog.ops[j].mod.weight.dim() == 4):
                 fused_stats[j] = i
     folded = {}                                           # bn op index -> conv op index (conv deferred to the bn's position)
     if fold_cache is not None and not training and not save:

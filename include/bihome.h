@@ -126,8 +126,8 @@ int bh_conv_fwd_act(const float* x, const float* w, const float* bias, const flo
                     int relu, void* stream);
 /* y = conv(x, w) + bias, and sums (bh_bn_stats_doubles(groups, Co) doubles, caller-zeroed) += per-channel (sum y, sum y^2) of each of the
  * `groups` sub-batches stacked along N: the batch statistics of the BatchNorm that follows, accumulated in the conv
- * epilogue where the halo-tiled 3x3 kernel applies (one extra statistics launch otherwise).  Pass the buffer to
- * bh_bn_fwd with flags bit3.  NHWC output, not transposed. */
+ * epilogue (halo-tiled 3x3 kernel; generic implicit GEMM incl. ConvTranspose2d when the pixels of a group are a
+ * multiple of 128; one extra statistics launch otherwise).  Pass the buffer to bh_bn_fwd with flags bit3.  NHWC output. */
 int bh_conv_fwd_bnstats(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, double* sums,
                         int groups, void* stream);
 /* gx = conv^T(gy, w)  (overwritten; accumulate != 0: gx += ..., used where gradient branches join).

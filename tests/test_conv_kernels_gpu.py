@@ -295,7 +295,9 @@ def test_bf16_operand_mode(K, N, Hi, Ci, Co, k, s, p):
     (8, 16, 32, 64, 3, 2),      # halo-tiled 3x3 kernel, BN = 64: statistics in the conv epilogue
     (6, 8, 64, 32, 3, 2),       # BN = 32 variant; 8x8 images: the two sub-tiles of a workgroup can sit in different groups
     (2, 8, 32, 64, 3, 2),       # one image per group: every workgroup straddles the group boundary
-    (4, 8, 16, 32, 1, 2),       # 1x1 conv: generic kernel + statistics launch
+    (4, 8, 16, 32, 1, 2),       # 1x1 conv: generic kernel, statistics in its epilogue (128 pixels per group)
+    (2, 4, 16, 32, 1, 2),       # 16 pixels per group: generic kernel + statistics launch
+    (4, 16, 32, 128, 1, 2),     # 128-wide N tile
 ])
 def test_conv_fwd_with_batchnorm_sums(K, N, H, Ci, Co, k, groups):
     """bh_conv_fwd_bnstats: per-group, per-channel (sum y, sum y^2) of the conv output, as BatchNorm consumes them."""
@@ -391,3 +393,18 @@ def test_stem7_forward_kernel(K, N, H, Ci, relu):
     finally:
         lib.bh_debug_force_tile(-6, 0)
     close(y.cpu(), y0.cpu(), 2e-5)
+
+
+@pytest.mark.parametrize("N,H,Ci,Co,groups", [(4, 8, 32, 32, 2), (8, 8, 64, 32, 2)])
+def test_conv_transpose_fwd_with_batchnorm_sums(K, N, H, Ci, Co, groups):
+    """ConvTranspose2d(2, 2) -> BatchNorm (the decoder's lower branch): statistics accumulated in the scatter epilogue."""
+    x = torch.tensor(rnd((N, H, H, Ci), 90)).cuda()
+    w = torch.tensor(rnd((Ci, 2, 2, Co), 91) * 0.1).cuda()
+    d = K.conv_desc(N, H, H, Ci, Co, 2, 2, 0, transposed=True)
+    sums = K.bn_stats_buffer(groups, Co, "cuda")
+    y = K.conv_fwd(x, w, None, d, bn_sums=sums, groups=groups)
+    y0 = K.conv_fwd(x, w, None, d)
+    assert torch.equal(y, y0)
+    yd = y0.double().reshape(groups, -1, Co)
+    ref = torch.stack([yd.sum(1), (yd * yd).sum(1)], -1)
+    close(sums.reshape(K.BN_SUM_SLOTS, groups, Co, 2, K.BN_SUM_STRIDE)[..., 0].sum(0).cpu(), ref.cpu(), 1e-6)
