@@ -41,6 +41,7 @@ SIGNATURES = {
     "bh_conv_fwd_act": [P, P, P, P, P, POINTER(BhConvDesc), c_int, P],
     "bh_conv_fwd_bnstats": [P, P, P, P, POINTER(BhConvDesc), P, c_int, P],
     "bh_conv_dgrad": [P, P, P, POINTER(BhConvDesc), c_int, P],
+    "bh_conv_dgrad_s2": [P, P, P, POINTER(BhConvDesc), c_int, P, P],
     "bh_conv_dgrad_bnreduce": [P, P, P, POINTER(BhConvDesc), c_int, POINTER(BhBnReduce), P, c_int, P],
     "bh_col2im_c1": [P, P, POINTER(BhConvDesc), c_int, P],
     "bh_conv_wgrad": [P, P, P, P, POINTER(BhConvDesc), P],

@@ -42,6 +42,7 @@ struct GemmArgs {
     int prio;              // experiment: s_setprio(1) around the MFMA block
     int bf16;              // operands rounded to bf16 (fp32 accumulate) where the vectorised path applies
     int ek, eC;            // scatter: kernel (== stride) and real channel count (Nn = ek*ek*eC)
+    int etap0;             // scatter: tap index of column 0 (a parity class of a strided dgrad writes ONE tap position)
     const float* res;      // optional residual added in the epilogue (same layout as Out)
     int relu;              // epilogue ReLU (inference: BatchNorm folded into the weights, activation fused)
     // optional: per-channel (sum, sum of squares) of the output accumulated into the padded BatchNorm sums table
@@ -533,7 +534,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
         const int n = n0 + (wn * TN + j) * 32 + l31;
         if (n >= a.Nn) continue;
         int co = n, tap = 0;
-        if (a.epi == 1) { tap = n / a.eC; co = n - tap * a.eC; }
+        if (a.epi == 1) { tap = n / a.eC; co = n - tap * a.eC; tap += a.etap0; }
         const float bv = a.bias ? a.bias[co] : 0.0f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -899,6 +900,86 @@ int bh_conv_fwd_bnstats(const float* x, const float* w, const float* bias, float
         if (rc) return rc;
     }
     return bn_launch_stats(y, groups, (d->N / groups) * d->Ho * d->Wo, d->Co, sums, bh_stream(stream));
+}
+
+// ---------------------------------------------------------------------------------------------
+// dgrad of a stride-2 conv (3x3 pad 1, or 1x1 pad 0) by output parity class.  The adjoint gather of the generic kernel
+// visits all kh*kw taps for every input pixel although only those with (iy + pad - ky) even exist: 3/4 of the MFMA work
+// is on zeros.  Per class (iy%2, ix%2) the valid taps form a dense 1x1 / 1x2 / 2x1 / 2x2 stride-1 convolution over gy
+// (pad 0), so each class is one forward-gather launch of the same kernel on class-packed, transposed weights
+// Wc[ci][ty][tx][co] whose scatter epilogue writes pixel (2a + py, 2b + px).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pack_s2_dgrad_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co,
+                                                                    int Ci, int k, int pad) {
+    // wp = four class blocks; class (py, px): taps ky = ky0 + 2*ty (ty < nty), source row a + cy - ty; packed tap index
+    // ky' = nty - 1 - ty so that source row = a + ky' (forward rule, pad 0).  Layout per class [Ci][nty][ntx][Co].
+    const int total = Co * k * k * Ci;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int ci = i % Ci, t = (i / Ci) % (k * k), co = i / (Ci * k * k);
+        const int ky = t / k, kx = t - ky * k;
+        // class of this tap: (iy + pad - ky) even  <=>  iy = (ky - pad) mod 2
+        const int py = ((ky - pad) % 2 + 2) % 2, px = ((kx - pad) % 2 + 2) % 2;
+        const int ky0 = (py + pad) % 2, kx0 = (px + pad) % 2;
+        const int nty = (k - ky0 + 1) / 2, ntx = (k - kx0 + 1) / 2;
+        const int ty = (ky - ky0) / 2, tx = (kx - kx0) / 2;
+        // class block offsets in order (0,0), (0,1), (1,0), (1,1)
+        int base = 0;
+        for (int c = 0; c < py * 2 + px; ++c) {
+            const int qy = c >> 1, qx = c & 1;
+            const int a0 = (qy + pad) % 2, b0 = (qx + pad) % 2;
+            base += Ci * ((k - a0 + 1) / 2) * ((k - b0 + 1) / 2) * Co;
+        }
+        wp[base + ((ci * nty + (nty - 1 - ty)) * ntx + (ntx - 1 - tx)) * Co + co] = w[i];
+    }
+}
+
+int bh_conv_dgrad_s2(const float* gy, const float* w, float* gx, const bh_conv_desc* d, int accumulate, float* wpack,
+                     void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!gy || !w || !gx || !wpack) return BH_E_BADARG;
+    const bool k3 = d->kh == 3 && d->kw == 3 && d->pad == 1, k1 = d->kh == 1 && d->kw == 1 && d->pad == 0;
+    if (d->transposed || d->stride != 2 || !(k3 || k1) || d->in_nchw || d->out_nchw || (d->Hi & 1) || (d->Wi & 1) ||
+        d->Ho * 2 != d->Hi || d->Wo * 2 != d->Wi || (d->Co % 4) || (d->Ci % 4))
+        return BH_E_UNSUPPORTED;
+    hipStream_t s = bh_stream(stream);
+    const int k = d->kh, pad = d->pad;
+    const int total = d->Co * k * k * d->Ci;
+    hipLaunchKernelGGL(pack_s2_dgrad_weights_kernel, dim3((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256), dim3(256), 0, s,
+                       w, wpack, d->Co, d->Ci, k, pad);
+    BH_LAUNCH_CHECK();
+    if (k1 && !accumulate) {                       // three of the four classes have no tap: their gradient is zero
+        hipError_t e = hipMemsetAsync(gx, 0, sizeof(float) * (size_t)d->N * d->Hi * d->Wi * d->Ci, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    long long base = 0;
+    for (int c = 0; c < 4; ++c) {
+        const int py = c >> 1, px = c & 1;
+        const int ky0 = (py + pad) % 2, kx0 = (px + pad) % 2;
+        const int nty = (k - ky0 + 1) / 2, ntx = (k - kx0 + 1) / 2;
+        if (nty > 0 && ntx > 0) {
+            // source rows: a + cy - ty with cy = (py + pad - ky0) / 2; with the flipped packed order the first packed tap
+            // reads row a + cy - (nty - 1): the forward rule iy = a - padv + ky' needs padv = (nty - 1) - cy
+            const int cy = (py + pad - ky0) / 2, cx = (px + pad - kx0) / 2;
+            const int padv_y = (nty - 1) - cy, padv_x = (ntx - 1) - cx;
+            if (padv_y != 0 || padv_x != 0) return BH_E_UNSUPPORTED;      // (0 for the two supported geometries)
+            GemmArgs a = {};
+            a.Src = gy; a.Bw = wpack + base; a.bias = nullptr; a.Out = gx; a.accumulate = accumulate; a.bf16 = d->precision == 1;
+            a.M = d->N * d->Ho * d->Wo; a.Nn = d->Ci; a.Kc = d->Co; a.T = nty * ntx; a.kw = ntx;
+            a.Ho = d->Ho; a.Wo = d->Wo;                 // class grid (Hi/2 x Wi/2) == gy grid
+            a.Hs = d->Ho; a.Ws = d->Wo; a.Cs = d->Co;
+            a.src_elems = (long long)d->N * d->Ho * d->Wo * d->Co;
+            a.bw_elems = (long long)d->Ci * nty * ntx * d->Co;
+            a.adjoint = 0; a.stride = 1; a.pad = 0;
+            // B[t][k = co][n = ci] = Wc[ci][t][co]
+            a.sBt = d->Co; a.sBc = 1; a.sBn = (long long)a.T * d->Co; a.b_kcontig = 1;
+            a.epi = 1; a.ek = 2; a.eC = d->Ci; a.etap0 = py * 2 + px;
+            rc = dispatch(a, s);
+            if (rc) return rc;
+        }
+        base += (long long)d->Ci * nty * ntx * d->Co;
+    }
+    return BH_OK;
 }
 
 int bh_conv_dgrad_bnreduce(const float* gy, const float* w, float* gx, const bh_conv_desc* d, int accumulate,

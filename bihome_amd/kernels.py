@@ -365,6 +365,18 @@ def conv_dgrad(gy, w, d, out=None, bn_reduce=None):
             and (d.Ci == 1 or (d.Ci == 3 and d.in_nchw)) and d.Co % 4 == 0 and d.N * d.Ho * d.Wo >= 4096):
         return _stem_dgrad_two_step(gy, w, d)
     acc = out is not None
+    if (not d.transposed and d.stride == 2 and not d.in_nchw and not d.out_nchw and d.Co % 4 == 0 and d.Ci % 4 == 0
+            and d.Hi % 2 == 0 and d.Wi % 2 == 0 and d.Ho * 2 == d.Hi and d.Wo * 2 == d.Wi
+            and ((d.kh == 3 and d.kw == 3 and d.pad == 1) or (d.kh == 1 and d.kw == 1 and d.pad == 0))):
+        # stride-2 dgrad by output parity class (csrc/conv_gemm.hip bh_conv_dgrad_s2)
+        if out is None:
+            out = torch.empty((d.N, d.Hi, d.Wi, d.Ci), dtype=torch.float32, device=gy.device)
+        wpack = torch.empty(w.numel(), dtype=torch.float32, device=gy.device)
+        nlaunch = 5 if d.kh == 3 else (2 + (0 if acc else 1))
+        with _Timed("conv_dgrad_s2(%d kernels)" % nlaunch + (" N%d %dx%d C%d->%d k%d" % (d.N, d.Hi, d.Wi, d.Ci, d.Co, d.kh) if TIMING_DETAIL else ""),
+                    conv_flops(d) / 4.0 * (1.0 if d.kh == 1 else 1.0), 4.0 * (gy.numel() + out.numel() * (2 if acc else 1) + 2 * w.numel())):
+            check(lib.bh_conv_dgrad_s2(_p(gy), _p(w), _p(out), ctypes.byref(d), int(acc), _p(wpack), _stream()), "bh_conv_dgrad_s2")
+        return out
     if out is None:
         shape = (d.N, d.Ci, d.Hi, d.Wi) if d.in_nchw else (d.N, d.Hi, d.Wi, d.Ci)
         out = torch.empty(shape, dtype=torch.float32, device=gy.device)

@@ -133,6 +133,11 @@ int bh_conv_fwd_bnstats(const float* x, const float* w, const float* bias, float
 /* gx = conv^T(gy, w)  (overwritten; accumulate != 0: gx += ..., used where gradient branches join).
  * d->in_nchw: gx is written NCHW (gradient w.r.t. an NCHW network input; no accumulate, not transposed). */
 int bh_conv_dgrad(const float* gy, const float* w, float* gx, const bh_conv_desc* d, int accumulate, void* stream);
+/* dgrad of a stride-2 conv (3x3 pad 1 or 1x1 pad 0, even Hi/Wi, NHWC) by output parity class: four dense stride-1
+ * launches on class-packed weights instead of one adjoint gather that multiplies 3/4 zeros.  wpack: scratch of
+ * Co*kh*kw*Ci floats (rewritten by every call).  BH_E_UNSUPPORTED for any other geometry (use bh_conv_dgrad). */
+int bh_conv_dgrad_s2(const float* gy, const float* w, float* gx, const bh_conv_desc* d, int accumulate, float* wpack,
+                     void* stream);
 /* The BatchNorm (+ReLU) whose OUTPUT gradient a dgrad produces: z = its input, y = its output (needed for the ReLU mask
  * only when a residual was added; NULL: the mask is recomputed from z), stats = its forward sums (bh_bn_fwd). */
 typedef struct bh_bn_reduce {
