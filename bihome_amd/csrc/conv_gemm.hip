@@ -42,6 +42,7 @@ struct GemmArgs {
     int prio;              // experiment: s_setprio(1) around the MFMA block
     int bf16;              // operands rounded to bf16 (fp32 accumulate) where the vectorised path applies
     int ek, eC;            // scatter: kernel (== stride) and real channel count (Nn = ek*ek*eC)
+    int ewshift, ehwshift; // log2(Wo), log2(Ho*Wo) when both are powers of two (epilogue pixel decode by shifts), else -1
     int etap0;             // scatter: tap index of column 0 (a parity class of a strided dgrad writes ONE tap position)
     const float* res;      // optional residual added in the epilogue (same layout as Out)
     int relu;              // epilogue ReLU (inference: BatchNorm folded into the weights, activation fused)
@@ -547,8 +548,17 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
                 if (a.epi == 0) {
                     off = (size_t)m * a.Nn + n;
                 } else {
-                    const int hw = a.Ho * a.Wo;
-                    const int nb = m / hw, rr = m - nb * hw, oy = rr / a.Wo, ox = rr - oy * a.Wo;
+                    int nb, oy, ox;
+                    if (a.ehwshift >= 0) {
+                        nb = m >> a.ehwshift;
+                        const int rr = m & ((1 << a.ehwshift) - 1);
+                        oy = rr >> a.ewshift; ox = rr & ((1 << a.ewshift) - 1);
+                    } else {
+                        const int hw = a.Ho * a.Wo;
+                        nb = m / hw;
+                        const int rr = m - nb * hw;
+                        oy = rr / a.Wo; ox = rr - oy * a.Wo;
+                    }
                     if (a.epi == 1) {
                         const int ay = tap / a.ek, ax = tap - ay * a.ek;
                         off = (((size_t)nb * (a.Ho * a.ek) + (oy * a.ek + ay)) * (a.Wo * a.ek) + (ox * a.ek + ax)) * a.eC + co;
@@ -611,6 +621,12 @@ static int dispatch(const GemmArgs& a_in, hipStream_t s) {
     a.sshift = -1;
     for (int b = 0; b < 8; ++b)
         if (a.stride == (1 << b)) a.sshift = b;
+    a.ewshift = a.ehwshift = -1;
+    for (int b = 0; b < 16; ++b)
+        if (a.Wo == (1 << b)) a.ewshift = b;
+    for (int b = 0; b < 31; ++b)
+        if ((long long)a.Ho * a.Wo == (1ll << b)) a.ehwshift = b;
+    if (a.ewshift < 0) a.ehwshift = -1;
     if (a.M <= 0 || a.Nn <= 0) return BH_OK;
     const bool vec = !a.src_nchw && (a.Kc % 4 == 0) && (a.Cs % 4 == 0);
     a.use_buf = vec && !(a.adjoint && a.stride > 1) && (a.Nn % 4 == 0) && a.T <= 64 && a.src_elems > 0 &&
