@@ -527,45 +527,56 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
     }
 
     // ---- epilogue: C/D layout col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m) ----
+    // element offset = row part (pixel of m) + column part (channel / tap of n): the 64-bit pixel arithmetic is done once
+    // per row and once per column, one add per element; columns are the inner loop so that the stores of adjacent taps /
+    // channels of one pixel leave back to back
     double st1[TN], st2[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) { st1[j] = 0.0; st2[j] = 0.0; }
+    size_t cpart[TN];
+    float bvj[TN];
+    bool nok[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
+        st1[j] = 0.0; st2[j] = 0.0;
         const int n = n0 + (wn * TN + j) * 32 + l31;
-        if (n >= a.Nn) continue;
+        nok[j] = n < a.Nn;
         int co = n, tap = 0;
         if (a.epi == 1) { tap = n / a.eC; co = n - tap * a.eC; tap += a.etap0; }
-        const float bv = a.bias ? a.bias[co] : 0.0f;
+        bvj[j] = (a.bias && nok[j]) ? a.bias[co] : 0.0f;
+        if (a.epi == 0) cpart[j] = (size_t)n;
+        else if (a.epi == 1) {
+            const int ay = tap / a.ek, ax = tap - ay * a.ek;
+            cpart[j] = ((size_t)ay * (a.Wo * a.ek) + ax) * a.eC + co;
+        } else cpart[j] = (size_t)n * a.Ho * a.Wo;
+    }
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh2;
-                if (m >= a.M) continue;
-                float v = acc[i][j][r] + bv;
-                size_t off;
-                if (a.epi == 0) {
-                    off = (size_t)m * a.Nn + n;
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh2;
+            if (m >= a.M) continue;
+            size_t rpart;
+            if (a.epi == 0) {
+                rpart = (size_t)m * a.Nn;
+            } else {
+                int nb, oy, ox;
+                if (a.ehwshift >= 0) {
+                    nb = m >> a.ehwshift;
+                    const int rr = m & ((1 << a.ehwshift) - 1);
+                    oy = rr >> a.ewshift; ox = rr & ((1 << a.ewshift) - 1);
                 } else {
-                    int nb, oy, ox;
-                    if (a.ehwshift >= 0) {
-                        nb = m >> a.ehwshift;
-                        const int rr = m & ((1 << a.ehwshift) - 1);
-                        oy = rr >> a.ewshift; ox = rr & ((1 << a.ewshift) - 1);
-                    } else {
-                        const int hw = a.Ho * a.Wo;
-                        nb = m / hw;
-                        const int rr = m - nb * hw;
-                        oy = rr / a.Wo; ox = rr - oy * a.Wo;
-                    }
-                    if (a.epi == 1) {
-                        const int ay = tap / a.ek, ax = tap - ay * a.ek;
-                        off = (((size_t)nb * (a.Ho * a.ek) + (oy * a.ek + ay)) * (a.Wo * a.ek) + (ox * a.ek + ax)) * a.eC + co;
-                    } else {
-                        off = (((size_t)nb * a.Nn + n) * a.Ho + oy) * a.Wo + ox;
-                    }
+                    const int hw = a.Ho * a.Wo;
+                    nb = m / hw;
+                    const int rr = m - nb * hw;
+                    oy = rr / a.Wo; ox = rr - oy * a.Wo;
                 }
+                if (a.epi == 1) rpart = (((size_t)nb * (a.Ho * a.ek) + oy * a.ek) * (a.Wo * a.ek) + ox * a.ek) * a.eC;
+                else rpart = (size_t)nb * a.Nn * a.Ho * a.Wo + (size_t)oy * a.Wo + ox;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (!nok[j]) continue;
+                const size_t off = rpart + cpart[j];
+                float v = acc[i][j][r] + bvj[j];
                 if (a.accumulate) v += a.Out[off];
                 if (a.res) v += a.res[off];
                 if (a.relu) v = fmaxf(v, 0.0f);
