@@ -125,7 +125,7 @@ __device__ static void jacobi9(double* A, double* V, int lane) {
         if (lane < 9)
             for (int j = 0; j < 9; ++j) { double v = A[lane * 9 + j]; if (j == lane) dia += v * v; else off += v * v; }
         off = wave_sum(off); dia = wave_sum(dia);
-        if (off <= 1e-40 * dia || off == 0.0) break;
+        if (off <= 1e-30 * dia || off == 0.0) break;      // off-diagonal Frobenius mass below 1e-15 of the diagonal: converged in double
         for (int p = 0; p < 8; ++p)
             for (int q = p + 1; q < 9; ++q) {
                 double apq = A[p * 9 + q];
