@@ -36,6 +36,8 @@ SIGNATURES = {
     "bh_triplet_l1_fwd": [P] * 8 + [c_int, c_int, c_int, P, P, P, P],
     "bh_bihome_loss_fwd": [P, P, P, c_int, c_float, P, P],
     "bh_bihome_loss_bwd": [P] * 14 + [c_int, c_int, c_int, c_float] + [P] * 6 + [P],
+    "bh_oneline_loss_fwd": [P, P, P, P, P, c_int, c_int, c_int, c_float, P, P, P, P],
+    "bh_oneline_loss_bwd": [P, P, P, P, P, P, P, c_int, c_int, c_int, P, P, P],
     "bh_debug_force_tile": [c_int, c_int],
     "bh_conv_fwd": [P, P, P, P, POINTER(BhConvDesc), P],
     "bh_conv_fwd_act": [P, P, P, P, P, POINTER(BhConvDesc), c_int, P],

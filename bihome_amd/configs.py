@@ -85,6 +85,19 @@ DETONE_ORIG = {
 }
 
 
+def _ihome(base):
+    """iHomE (one-line) variant of a biHomE config: one direction, hinge with a numeric margin (PerceptualHead.py:465-538).
+    No yaml for it ships upstream (train.py:330 names the loss 'iHomE'); the kwargs follow the biHomE configs."""
+    cfg = copy.deepcopy(base)
+    cfg["MODEL"]["BACKBONE"]["VARIANT"] = "OneLine"
+    cfg["MODEL"]["BACKBONE"]["TARGET_KEYS"] = cfg["MODEL"]["BACKBONE"]["TARGET_KEYS"][:1]
+    h = cfg["MODEL"]["HEAD"]
+    h["TRIPLET_LOSS"], h["TRIPLET_MARGIN"] = "one-line", 1.0
+    h["DELTA_HAT_KEYS"], h["PF_KEYS"] = h["DELTA_HAT_KEYS"][:1], h["PF_KEYS"][:1]
+    cfg["SOLVER"]["LOSS"] = "iHomE"
+    return cfg
+
+
 def get(name):
     """'zeng-bihome' / 'detone-bihome' = config/s-coco/*; the '-pds' variants = config/pds-coco/* (the two trees differ
     only in HomographyNetPrep's photometric max_delta, 0 vs 32, and the log dir).  'zeng-bihome-rgb256' is the
@@ -96,6 +109,8 @@ def get(name):
         cfg["MODEL"]["HEAD"].update(PATCH_SIZE=256)
         cfg["DATA"].update(BATCH_SIZE=32, RHO=64, PATCH_SIZE=256, PATCH_CHANNELS=3)
         return cfg
+    if name in ("zeng-ihome", "detone-ihome"):
+        return _ihome(ZENG_BIHOME if name == "zeng-ihome" else DETONE_BIHOME)
     base = name[:-4] if name.endswith("-pds") else name
     cfg = copy.deepcopy({"zeng-bihome": ZENG_BIHOME, "detone-bihome": DETONE_BIHOME, "zeng-orig": ZENG_ORIG,
                          "detone-orig": DETONE_ORIG}[base])

@@ -149,7 +149,119 @@ __global__ void __launch_bounds__(256) triplet_bwd_kernel(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// one-line variant (iHomE, PerceptualHead.py:465-538): a single warped direction and a hinge,
+//   loss_b = sum_p w max(|f1w - f2|_1 - |f1 - f2|_1 + margin, 0) / max(sum_p w, 1),  w = m1w * m2
+// T[B,hw] keeps the pre-hinge value; numden[B,2] = { sum w*hinge, sum w }.  grid (TRIP_BLOCKS_PER_SAMPLE, B)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) oneline_fwd_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                          const float* __restrict__ f1w, const float* __restrict__ m1w,
+                                                          const float* __restrict__ m2, int hw, int C, float margin,
+                                                          float* __restrict__ T, double* __restrict__ numden) {
+    __shared__ double part[4][2];
+    const int b = blockIdx.y;
+    const int LP = min(64, C / 4), PPW = 64 / LP;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LP, cl = lane % LP;
+    const int wave_global = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
+    double a_n = 0, a_d = 0;
+    for (int p0 = wave_global * PPW; p0 < hw; p0 += nwaves * PPW) {
+        const int p = p0 + sub;
+        float s1 = 0, s3 = 0;
+        if (p < hw) {
+            const size_t base = ((size_t)b * hw + p) * C;
+            for (int c = cl * 4; c < C; c += LP * 4) {
+                const float4 a1 = ld4(f1 + base + c), a2 = ld4(f2 + base + c), a1w = ld4(f1w + base + c);
+                s1 += l1_4(a1w, a2);
+                s3 += l1_4(a1, a2);
+            }
+        }
+        for (int off = 1; off < LP; off <<= 1) { s1 += __shfl_xor(s1, off, 64); s3 += __shfl_xor(s3, off, 64); }
+        if (p < hw && cl == 0) {
+            const size_t q = (size_t)b * hw + p;
+            const float t = s1 - s3 + margin;
+            T[q] = t;
+            const float w = m1w[q] * (m2 ? m2[q] : 1.0f);
+            a_n += (double)(w * fmaxf(t, 0.0f)); a_d += (double)w;
+        }
+    }
+    a_n = wave_sum(a_n); a_d = wave_sum(a_d);
+    if (lane == 0) { part[wave][0] = a_n; part[wave][1] = a_d; }
+    __syncthreads();
+    if (threadIdx.x < 2)
+        atomicAdd(numden + (size_t)b * 2 + threadIdx.x, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+__global__ void __launch_bounds__(256) oneline_loss_kernel(const double* __restrict__ numden, int B, float* __restrict__ loss) {
+    __shared__ double part[4];
+    double l = 0;
+    for (int b = threadIdx.x; b < B; b += 256) l += (double)((float)numden[b * 2] / fmaxf((float)numden[b * 2 + 1], 1.0f));
+    l = wave_sum(l);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = l;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = (float)(part[0] + part[1] + part[2] + part[3]);
+}
+
+__global__ void __launch_bounds__(256) oneline_bwd_kernel(const float* __restrict__ g_loss, const float* __restrict__ f2,
+                                                          const float* __restrict__ f1w, const float* __restrict__ m1w,
+                                                          const float* __restrict__ m2, const float* __restrict__ T,
+                                                          const double* __restrict__ numden, int hw, int C,
+                                                          float* __restrict__ g_f1w, float* __restrict__ g_m1w) {
+    const int b = blockIdx.y;
+    const float g = g_loss[0];
+    const float N = (float)numden[b * 2], D = (float)numden[b * 2 + 1];
+    const float den = fmaxf(D, 1.0f);
+    const float dd = (D > 1.0f) ? -N / (den * den) : 0.0f;
+    const int LP = min(64, C / 4), PPW = 64 / LP;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LP, cl = lane % LP;
+    const int wave_global = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
+    for (int p0 = wave_global * PPW; p0 < hw; p0 += nwaves * PPW) {
+        const int p = p0 + sub;
+        if (p >= hw) continue;
+        const size_t q = (size_t)b * hw + p;
+        const float mm2 = m2 ? m2[q] : 1.0f, t = T[q];
+        const float k = (t > 0.0f) ? g * m1w[q] * mm2 / den : 0.0f;         // hinge: no gradient where it is inactive
+        const size_t base = q * C;
+        for (int c = cl * 4; c < C; c += LP * 4) {
+            const float4 a2 = ld4(f2 + base + c), a1w = ld4(f1w + base + c);
+            *reinterpret_cast<float4*>(g_f1w + base + c) =
+                make_float4(k * sgn(a1w.x - a2.x), k * sgn(a1w.y - a2.y), k * sgn(a1w.z - a2.z), k * sgn(a1w.w - a2.w));
+        }
+        if (cl == 0) g_m1w[q] = g * mm2 * (fmaxf(t, 0.0f) / den + dd);
+    }
+}
+
 extern "C" {
+
+int bh_oneline_loss_fwd(const float* f1, const float* f2, const float* f1w, const float* m1w, const float* m2, int B, int hw,
+                        int C, float margin, float* T, double* numden, float* loss, void* stream) {
+    if (!f1 || !f2 || !f1w || !m1w || !T || !numden || !loss || B < 0) return BH_E_BADARG;
+    if (C % 4 || C < 4 || (C / 4 < 64 && (64 % (C / 4)))) return BH_E_UNSUPPORTED;
+    hipStream_t s = bh_stream(stream);
+    if (B > 0) {
+        hipError_t e = hipMemsetAsync(numden, 0, sizeof(double) * 2 * (size_t)B, s);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(oneline_fwd_kernel, dim3(TRIP_BLOCKS_PER_SAMPLE, B), dim3(256), 0, s, f1, f2, f1w, m1w, m2, hw, C,
+                           margin, T, numden);
+        BH_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(oneline_loss_kernel, dim3(1), dim3(256), 0, s, numden, B, loss);
+    BH_LAUNCH_CHECK();
+    return BH_OK;
+}
+
+int bh_oneline_loss_bwd(const float* g_loss, const float* f2, const float* f1w, const float* m1w, const float* m2,
+                        const float* T, const double* numden, int B, int hw, int C, float* g_f1w, float* g_m1w,
+                        void* stream) {
+    if (!g_loss || !f2 || !f1w || !m1w || !T || !numden || !g_f1w || !g_m1w || B < 0) return BH_E_BADARG;
+    if (C % 4 || C < 4 || (C / 4 < 64 && (64 % (C / 4)))) return BH_E_UNSUPPORTED;
+    if (B == 0) return BH_OK;
+    hipLaunchKernelGGL(oneline_bwd_kernel, dim3(TRIP_BLOCKS_PER_SAMPLE, B), dim3(256), 0, bh_stream(stream), g_loss, f2, f1w,
+                       m1w, m2, T, numden, hw, C, g_f1w, g_m1w);
+    BH_LAUNCH_CHECK();
+    return BH_OK;
+}
 
 int bh_triplet_l1_fwd(const float* f1, const float* f2, const float* f1w, const float* f2w, const float* m1w,
                       const float* m2w, const float* m1, const float* m2, int B, int hw, int C, float* M1, float* M2,

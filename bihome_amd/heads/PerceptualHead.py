@@ -173,6 +173,50 @@ class _BiHomELoss(torch.autograd.Function):
         return gdelta, None, None
 
 
+class _IHomELoss(torch.autograd.Function):
+    """triplet_resnet_loss, one-line branch (iHomE; PerceptualHead.py:320-538): only patch_1 is warped, hinge with a
+    numeric margin.  patches[2B,1,h,w] = cat(patch_1, patch_2); delta[B,4,2] = delta_hat_12."""
+
+    @staticmethod
+    def forward(ctx, delta, patches, head):
+        B2, _, h, w = patches.shape
+        B = B2 // 2
+        aux = head.auxiliary_resnet
+        delta = delta.contiguous()
+        ready = getattr(head, "_feat_ready", None)
+        if ready is not None:
+            feat = ready[0]
+            torch.cuda.current_stream().wait_event(ready[1])
+        else:
+            with torch.no_grad():
+                feat = aux(patches, groups=2)                   # :358,:367 (patch_1, then patch_2)
+        H64, H32 = K.h4pt_fwd(delta, h)                          # :371 -> four_point_to_homography
+        pool = 4
+        p1 = patches[:B].contiguous()
+        warped, cov = K.warp_fwd(p1, H64, pool)                  # :371,:382 + downsample (:447-451)
+        with torch.enable_grad():
+            wl = warped.detach().requires_grad_(True)
+            featw = aux(wl, groups=1)                            # :377
+        loss, T, numden = K.oneline_loss_fwd(feat[:B], feat[B:], featw.detach(), cov, head.triplet_margin)   # :474-533
+        ctx.head, ctx.pool = head, pool
+        ctx.saved = (delta, p1, H64, feat[B:], featw, wl, cov, T, numden)
+        head.last = {"loss4": loss, "H_4pt": H32, "warped": warped, "coverage": cov}
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        delta, p1, H64, f2, featw, wl, cov, T, numden = ctx.saved
+        ctx.saved = None
+        h = p1.shape[-1]
+        g = g_loss.reshape(1).to(torch.float32).contiguous()
+        gfw, gcov = K.oneline_loss_bwd(g, f2, featw.detach(), cov, T, numden)
+        (gwarp,) = torch.autograd.grad(featw, wl, gfw)
+        gH = torch.zeros_like(H64)
+        K.warp_bwd(p1, H64, gwarp.contiguous(), gcov, ctx.pool, gH=gH)
+        gdelta = K.h4pt_bwd(delta, H64, gH, h)
+        return gdelta, None, None
+
+
 # -----------------------------------------------------------------------------------------------
 class Model(nn.Module):
 
@@ -191,14 +235,21 @@ class Model(nn.Module):
             if kwargs.get('SCORING_METHOD', 'repr_error') != 'repr_error':
                 raise NotImplementedError("only SCORING_METHOD='repr_error' is built")
         self.triplet_version = kwargs['TRIPLET_LOSS']
-        ok = ('double-line' in self.triplet_version and 'dual' not in self.triplet_version
-              and kwargs.get('TRIPLET_DISTANCE') == 'l1' and kwargs.get('TRIPLET_AGGREGATION') == 'channel-agnostic'
-              and isinstance(kwargs.get('TRIPLET_MARGIN'), str) and not len(kwargs.get('MASK_KEYS', []))
-              and 'upsample' not in str(kwargs.get('SAMPLING_STRATEGY', '')))
+        common = ('dual' not in self.triplet_version and kwargs.get('TRIPLET_DISTANCE') == 'l1'
+                  and not len(kwargs.get('MASK_KEYS', [])) and 'upsample' not in str(kwargs.get('SAMPLING_STRATEGY', ''))
+                  and not kwargs.get('MASK_CRD', False))
+        self.one_line = 'one-line' in self.triplet_version
+        if self.one_line:                  # iHomE: PerceptualHead.py:465-538, hinge with a numeric margin
+            ok = common and isinstance(kwargs.get('TRIPLET_MARGIN'), (int, float))
+        else:                              # biHomE: PerceptualHead.py:540-665
+            ok = (common and 'double-line' in self.triplet_version and isinstance(kwargs.get('TRIPLET_MARGIN'), str)
+                  and kwargs.get('TRIPLET_AGGREGATION') == 'channel-agnostic')
         if not ok:
-            raise NotImplementedError("only the biHomE configuration (double-line / l1 / channel-agnostic / str margin / "
-                                      "no MASK_KEYS / downsample-mask) is built - see SURVEY.md 2 for what is out of scope")
-        self.triplet_mu = kwargs['TRIPLET_MU']
+            raise NotImplementedError("built: biHomE (double-line / l1 / channel-agnostic / str margin) and iHomE (one-line / l1 / "
+                                      "numeric margin), no MASK_KEYS / MASK_CRD, downsample-mask - see SURVEY.md 2 for what is out of "
+                                      "scope")
+        self.triplet_mu = kwargs.get('TRIPLET_MU', 0.0)
+        self.triplet_margin = kwargs.get('TRIPLET_MARGIN')
         self.auxiliary_resnet = AuxiliaryResnet(**kwargs)
         self.last = {}
         # The features of the two unwarped patches depend on the batch only, not on the backbone: their extractor pass is
@@ -264,6 +315,8 @@ class Model(nn.Module):
         if not p1.is_cuda:
             raise RuntimeError("bihome_amd heads run on the MI355X only; no CPU fallback (use oracle/ for CPU checks)")
         B = p1.shape[0]
+        if self.one_line:
+            return self._forward_one_line(data, p1, p2, B)
         if not len(self.delta_hat_keys):
             pf = self._stacked_pf(data)
             N = pf.shape[-1] * pf.shape[-2]
@@ -289,6 +342,29 @@ class Model(nn.Module):
             data['summary_writer'].add_scalars('loss_comp', {'ln1': l4[1], 'ln2': l4[2], 'ln3': l4[3]}, step)
         delta_gt = data['delta'] if 'delta' in data else None
         return loss, delta_gt, delta[:B]
+
+    def _forward_one_line(self, data, p1, p2, B):
+        """One direction only (PerceptualHead.py:154-176,222-223): delta_hat_12 from the DLT on pf_hat_12 (or given)."""
+        if not len(self.delta_hat_keys):
+            pf = data[self.pf_keys[0]].contiguous()
+            N = pf.shape[-1] * pf.shape[-2]
+            c12 = self._choices(data, 'choice_12', B, N, pf.device)
+            if self.hypothesis_no != 1:
+                raise NotImplementedError("training with RANSAC_HYPOTHESIS_NO > 1 is not used by any shipped config")
+            dh, Hd = _DltFunction.apply(pf, c12, self.hypothesis_no, self.point_per_hypothesis)
+            delta = dh.reshape(B, 4, 2)           # (the softmax score of a single hypothesis is 1: :505-511,:708-710)
+            self.last_dlt = Hd
+        else:
+            delta = data[self.delta_hat_keys[0]].reshape(B, 4, 2)
+        pre, self._prefetched = self._prefetched, None
+        if pre is not None and pre[0] is p1 and pre[1] is p2:
+            patches, self._feat_ready = pre[2], (pre[3], pre[4])
+        else:
+            patches, self._feat_ready = self._stack_patches(data), None
+        loss = _IHomELoss.apply(delta, patches, self)
+        self._feat_ready = None
+        delta_gt = data['delta'] if 'delta' in data else None
+        return loss, delta_gt, delta
 
     def predict_homography(self, data):
         if len(self.delta_hat_keys):

@@ -252,6 +252,29 @@ def triplet_l1_fwd(f1, f2, f1w, f2w, m1w, m2w, m1=None, m2=None):
     return M1, M2, numden
 
 
+def oneline_loss_fwd(f1, f2, f1w, m1w, margin, m2=None):
+    """iHomE one-line hinge loss (PerceptualHead.py:465-538): returns (loss[1], T[B,hf,wf], numden[B,2])."""
+    for t in (f1, f2, f1w, m1w, m2):
+        _chk(t)
+    B, hf, wf, C = f1.shape
+    T = torch.empty(B, hf, wf, dtype=torch.float32, device=f1.device)
+    numden = torch.empty(B, 2, dtype=torch.float64, device=f1.device)
+    loss = torch.empty(1, dtype=torch.float32, device=f1.device)
+    check(lib.bh_oneline_loss_fwd(_p(f1), _p(f2), _p(f1w), _p(m1w), _p(m2), B, hf * wf, C, float(margin), _p(T), _p(numden),
+                                  _p(loss), _stream()), "bh_oneline_loss_fwd")
+    return loss, T, numden
+
+
+def oneline_loss_bwd(g_loss, f2, f1w, m1w, T, numden, m2=None):
+    _chk(g_loss)
+    B, hf, wf, C = f1w.shape
+    g_f1w = torch.empty_like(f1w)
+    g_m1w = torch.empty(B, hf, wf, dtype=torch.float32, device=f1w.device)
+    check(lib.bh_oneline_loss_bwd(_p(g_loss), _p(f2), _p(f1w), _p(m1w), _p(m2), _p(T), _p(numden), B, hf * wf, C, _p(g_f1w),
+                                  _p(g_m1w), _stream()), "bh_oneline_loss_bwd")
+    return g_f1w, g_m1w
+
+
 def bihome_loss_fwd(numden, H1, H2, mu):
     _chk(numden, torch.float64); _chk(H1, torch.float64); _chk(H2, torch.float64)
     loss4 = torch.empty(4, dtype=torch.float32, device=numden.device)

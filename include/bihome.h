@@ -98,6 +98,16 @@ int bh_bihome_loss_bwd(const float* g_loss, const float* f1, const float* f2, co
                        float* g_f1w, float* g_f2w, float* g_m1w, float* g_m2w,
                        double* gH1, double* gH2, void* stream);
 
+/* One-line variant (iHomE; triplet_resnet_loss 'one-line' / l1 / numeric margin: PerceptualHead.py:465-538):
+ *   loss = sum_b [ sum_p w max(|f1w-f2|_1 - |f1-f2|_1 + margin, 0) / max(sum_p w, 1) ],  w = m1w * m2 (m2 NULL => ones)
+ * T[B,hw] = pre-hinge value (kept for the adjoint), numden[B,2] double, loss[1]. */
+int bh_oneline_loss_fwd(const float* f1, const float* f2, const float* f1w, const float* m1w, const float* m2, int B, int hw,
+                        int C, float margin, float* T, double* numden, float* loss, void* stream);
+/* adjoint: g_loss[1] -> g_f1w[B,hw,C], g_m1w[B,hw] (overwritten) */
+int bh_oneline_loss_bwd(const float* g_loss, const float* f2, const float* f1w, const float* m1w, const float* m2,
+                        const float* T, const double* numden, int B, int hw, int C, float* g_f1w, float* g_m1w,
+                        void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Conv stacks (Rethinking._forward src/backbones/Rethinking.py:284-294 with blocks
  * src/backbones/utils.py:60-131; ResNet34 src/backbones/ResNet34.py:15-28; AuxiliaryResnet.forward

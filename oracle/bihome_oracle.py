@@ -267,10 +267,15 @@ class BiHomEHead(nn.Module):
             self.pf_keys = kw["PF_KEYS"]
             self.hypothesis_no = kw["RANSAC_HYPOTHESIS_NO"]
             self.points_per_hypothesis = kw["POINTS_PER_HYPOTHESIS"]
-        assert "double-line" in kw["TRIPLET_LOSS"] and kw["TRIPLET_DISTANCE"] == "l1"
-        assert kw["TRIPLET_AGGREGATION"] == "channel-agnostic" and isinstance(kw["TRIPLET_MARGIN"], str)
-        assert not len(kw["MASK_KEYS"])
-        self.triplet_mu = kw["TRIPLET_MU"]
+        self.one_line = "one-line" in kw["TRIPLET_LOSS"]                                 # iHomE (:465-538)
+        assert kw["TRIPLET_DISTANCE"] == "l1" and not len(kw["MASK_KEYS"]) and not kw.get("MASK_CRD", False)
+        if self.one_line:
+            assert isinstance(kw["TRIPLET_MARGIN"], (int, float))
+        else:
+            assert "double-line" in kw["TRIPLET_LOSS"]
+            assert kw["TRIPLET_AGGREGATION"] == "channel-agnostic" and isinstance(kw["TRIPLET_MARGIN"], str)
+        self.triplet_margin = kw["TRIPLET_MARGIN"]
+        self.triplet_mu = kw.get("TRIPLET_MU", 0.0)
         self.auxiliary_resnet = AuxiliaryResnet()
         self.last = {}
 
@@ -313,6 +318,13 @@ class BiHomEHead(nn.Module):
         return warp_image(image, H), H
 
     def forward(self, data, choice_12=None, choice_21=None):                              # :148-235
+        if self.one_line:
+            if not len(self.delta_hat_keys):
+                d12, H12, scores = self._delta_from_pf(data[self.pf_keys[0]], choice_12)
+                self.last.update(H_dlt_12=H12)
+            else:
+                d12, scores = data[self.delta_hat_keys[0]], None
+            return self.one_line_loss(data, d12, scores)
         if not len(self.delta_hat_keys):
             d12, H12, _ = self._delta_from_pf(data[self.pf_keys[0]], choice_12)
             d21, H21, _ = self._delta_from_pf(data[self.pf_keys[1]], choice_21)
@@ -353,6 +365,32 @@ class BiHomEHead(nn.Module):
                          mask_pooled_12=m1w, mask_pooled_21=m2w, f1=f1, f2=f2, f1w=f1w, f2w=f2w,
                          delta_hat_12=d12, delta_hat_21=d21)
         return loss, data.get("delta"), d12                                               # :703-714
+
+    def one_line_loss(self, data, d12, scores=None):                                      # :320-538 ('one-line', 'l1')
+        p1, p2 = data[self.patch_keys[0]], data[self.patch_keys[1]]
+        B, n, i = d12.shape[0], self.hypothesis_no, self.patch_size
+        assert n == 1
+        aux = self.auxiliary_resnet
+        f1 = aux(p1)                                                                      # :358
+        f2 = aux(p2)                                                                      # :367
+        d12 = d12.reshape(B * n, 4, 2)
+        p1w, h1 = self._warp(p1, d12)                                                     # :371
+        f1w = aux(p1w)                                                                    # :377
+        m1w, _ = self._warp(torch.ones_like(p1), d12)                                     # :382
+        k = i // f1w.shape[-1]                                                            # :450
+        m1w = F.avg_pool2d(m1w, k).squeeze(1)                                             # :451-452
+        m2 = F.avg_pool2d(torch.ones_like(p2), k).squeeze(1)                              # :453
+        l1 = (f1w - f2).abs().sum(1)                                                      # :481
+        l3 = (f1 - f2).abs().sum(1)                                                       # :482
+        loss_mat = torch.max(l1 - l3 + torch.ones_like(l1) * self.triplet_margin, torch.zeros_like(l1))   # :505
+        if scores is not None:
+            loss_mat = loss_mat * scores.reshape(B * n, 1, 1)                             # :508-511
+        den = (m1w * m2).sum((-1, -2))                                                    # :523
+        loss = ((m1w * m2 * loss_mat).sum((-1, -2)) / torch.max(den, torch.ones_like(den))).sum()   # :524-538
+        self.last.update(H_4pt_12=h1, warp_12=p1w, mask_pooled_12=m1w, f1=f1, f2=f2, f1w=f1w, delta_hat_12=d12)
+        if scores is not None:
+            d12 = (d12 * scores.reshape(B * n, 1, 1)).reshape(B, n, 4, 2).sum(1)          # :708-710
+        return loss, data.get("delta"), d12
 
     def predict_homography(self, data, choice=None):                                      # :716-767
         if len(self.delta_hat_keys):

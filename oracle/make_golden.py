@@ -272,6 +272,43 @@ def run_orig_scenario(ref_bb_cls, ref_head_cls, cfg, dtype, batch, seed, steps=2
     return out
 
 
+def run_ihome_scenario(ref_bb_cls, ref_head_cls, cfg, dtype, batch=4, seed=31, steps=2):
+    """iHomE (one-line): reference Rethinking (OneLine) + reference PerceptualHead with TRIPLET_LOSS='one-line' and a
+    numeric margin; `steps` Adam steps on one batch with the multinomial draws recorded."""
+    from bihome_amd import synth
+    from bihome_amd.weights import load_synthetic
+    bb = ref_bb_cls(**cfg["MODEL"]["BACKBONE"])
+    head = ref_head_cls(bb, **cfg["MODEL"]["HEAD"])
+    load_synthetic(bb, seed=0)
+    load_synthetic(head.auxiliary_resnet, seed=0)
+    model = torch.nn.Sequential(bb, head).to(dtype)
+    s = cfg["SOLVER"]
+    opt = torch.optim.Adam(model.parameters(), lr=s["LR"], betas=(s["MOMENTUM_1"], s["MOMENTUM_2"]), weight_decay=0)
+    d = synth.make_pairs(batch, seed=seed)
+    out = {"loss": [], "mace": [], "choice_12": []}
+    model.train()
+    for it in range(steps):
+        opt.zero_grad()
+        data = {k: t(d[k], dtype) for k in ("patch_1", "patch_2", "delta")}
+        torch.manual_seed(3000 + it)
+        with RecordMultinomial() as rec:
+            loss, delta_gt, delta_hat = model(data)
+        loss.backward()
+        if it == 0:
+            out["pf_hat_12_sub"] = sub(data["pf_hat_12"], 8)
+            out["delta_hat_12"] = delta_hat.detach().double().numpy().copy()
+            for name in ("layer1.0.weight", "layer4.6.upper_branch.0.weight", "layer8.3.weight", "layer8.3.bias"):
+                out["gradnorm/" + name] = np.float64(dict(bb.named_parameters())[name].grad.double().norm().item())
+        opt.step()
+        out["loss"].append(loss.item())
+        out["mace"].append(float(np.mean(np.linalg.norm(delta_gt.numpy().reshape(-1, 2) -
+                                                        delta_hat.detach().numpy().reshape(-1, 2), axis=-1))))
+        out["choice_12"].append(rec.calls[0].reshape(batch, -1).numpy())
+    for k in ("loss", "mace", "choice_12"):
+        out[k] = np.asarray(out[k])
+    return out
+
+
 def _orig(importlib, Rethinking, ResNet34, configs, dtype, tag, outdir):
     NoOpHead = importlib.import_module("src.heads.NoOpHead")
     assert os.path.realpath(NoOpHead.__file__).startswith(os.path.realpath(REF)), NoOpHead.__file__
@@ -281,6 +318,10 @@ def _orig(importlib, Rethinking, ResNet34, configs, dtype, tag, outdir):
     r = run_orig_scenario(ResNet34.Model, NoOpHead.Model, configs.get("detone-orig"), dtype, batch=4, seed=22)
     np.savez_compressed(os.path.join(outdir, "detone_orig_b4_%s.npz" % tag), **r)
     print("detone-orig", tag, "loss", r["loss"], "mace", r["mace"])
+    PerceptualHead = importlib.import_module("src.heads.PerceptualHead")
+    r = run_ihome_scenario(Rethinking.Model, PerceptualHead.Model, configs.get("zeng-ihome"), dtype)
+    np.savez_compressed(os.path.join(outdir, "zeng_ihome_b4_%s.npz" % tag), **r)
+    print("zeng-ihome", tag, "loss", r["loss"], "mace", r["mace"])
 
 
 def main():

@@ -213,3 +213,27 @@ def test_gpu_pair_generator_matches_host_generator(K):
     gen2 = GpuPairGenerator(n_images=2, seed=6, photometric_max_delta=32)
     o2 = gen2.next(8)
     assert torch.isfinite(o2["patch_1"]).all() and torch.isfinite(o2["patch_2"]).all()
+
+
+@pytest.mark.parametrize("B,hf,C,margin", [(3, 32, 64, 1.0), (2, 8, 128, 0.0), (1, 16, 64, 25.0)])
+def test_oneline_hinge_loss_fwd_bwd(B, hf, C, margin):
+    """bh_oneline_loss_fwd/bwd (iHomE, PerceptualHead.py:474-538) against torch float64 autograd of the same formula."""
+    import torch.nn.functional as F
+    from bihome_amd import kernels as K
+    g = torch.Generator().manual_seed(B * 7 + hf)
+    f1, f2 = torch.randn(B, hf, hf, C, generator=g), torch.randn(B, hf, hf, C, generator=g)
+    f1w = (f2 + 0.7 * torch.randn(B, hf, hf, C, generator=g))
+    m1w = torch.rand(B, hf, hf, generator=g)
+    m1w[0, :2] = 0
+    if B > 1:
+        m1w[1] *= 1e-4                                     # denominator below 1: max(den, 1) branch
+    a, b, c, m = (t.double().requires_grad_(rq) for t, rq in ((f1, False), (f2, False), (f1w, True), (m1w, True)))
+    t = (c - b).abs().sum(-1) - (a - b).abs().sum(-1) + margin
+    den = m.sum((-1, -2))
+    ref = ((m * torch.clamp(t, min=0)).sum((-1, -2)) / torch.max(den, torch.ones_like(den))).sum()
+    ref.backward()
+    loss, T, numden = K.oneline_loss_fwd(f1.cuda(), f2.cuda(), f1w.cuda(), m1w.cuda(), margin)
+    assert abs(loss.item() - ref.item()) <= 2e-5 * abs(ref.item()) + 1e-6
+    gf, gm = K.oneline_loss_bwd(torch.ones(1, device="cuda"), f2.cuda(), f1w.cuda(), m1w.cuda(), T, numden)
+    assert (gf.cpu().double() - c.grad).abs().max().item() <= 2e-5 * c.grad.abs().max().item() + 1e-7
+    assert (gm.cpu().double() - m.grad).abs().max().item() <= 2e-4 * m.grad.abs().max().item() + 1e-6

@@ -425,3 +425,29 @@ def test_ragged_batches_first_step_vs_oracle(B, patch):
     assert abs(loss.item() - ref_loss.item()) <= 2e-4 * abs(ref_loss.item()) + 1e-6
     assert abs(mace(dgt, dh) - O.mace(ref_gt, ref_dh)) < 2e-3
     assert all(torch.isfinite(p.grad).all() for p in model[0].parameters())
+
+
+def test_ihome_one_line_vs_golden(golden):
+    """iHomE (one-line hinge loss, PerceptualHead.py:465-538) on the HIP path against the reference's own modules: first
+    step tight, second step within the reference's float32-vs-float64 spread."""
+    from bihome_amd.step import build_model, build_optimizer, mace, train_step
+    g32, g64 = golden("zeng_ihome_b4_f32"), golden("zeng_ihome_b4_f64")
+    cfg = configs.get("zeng-ihome")
+    model = build_model(cfg)
+    load_synthetic(model[0], 0)
+    load_synthetic(model[1].auxiliary_resnet, 0)
+    opt, sched = build_optimizer(model, cfg["SOLVER"])
+    d = synth.make_pairs(4, seed=31)
+    losses, maces = [], []
+    for it in range(2):
+        data = {k: cuda(d[k]) for k in ("patch_1", "patch_2", "delta")}
+        data["choice_12"] = cuda(g32["choice_12"][it], torch.int64)
+        loss, dgt, dh = train_step(model, data, opt, sched)
+        losses.append(loss.item()); maces.append(mace(dgt, dh))
+        if it == 0:
+            assert relerr(data["pf_hat_12"].detach().cpu()[..., ::8, ::8], g64["pf_hat_12_sub"]) < 2e-4
+            assert relerr(dh.cpu(), g64["delta_hat_12"]) < 1e-3
+    assert abs(losses[0] - g64["loss"][0]) <= 2e-4 * abs(g64["loss"][0]), (losses, g64["loss"])
+    assert abs(maces[0] - g64["mace"][0]) < 1e-3
+    spread = abs(g32["loss"][1] - g64["loss"][1])
+    assert abs(losses[1] - g64["loss"][1]) <= max(20 * spread, 2e-3 * abs(g64["loss"][1])), (losses, g64["loss"], g32["loss"])

@@ -122,3 +122,24 @@ def test_supervised_orig_configs(golden, name, batch, seed):
         bb(data)
     out = data[key0]
     np.testing.assert_allclose(out[..., ::8, ::8].numpy() if out.dim() == 4 else out.numpy(), g["eval_output"], atol=1e-7)
+
+
+def test_ihome_one_line(golden):
+    """iHomE (TRIPLET_LOSS 'one-line', numeric margin; PerceptualHead.py:465-538): the oracle's two Adam steps against the
+    reference's own PerceptualHead + Rethinking (OneLine) on recorded DSAC draws."""
+    g = golden("zeng_ihome_b4_f64")
+    cfg = configs.get("zeng-ihome")
+    bb, head = O.build(cfg)
+    assert head.one_line
+    load_synthetic(bb, 0)
+    load_synthetic(head.auxiliary_resnet, 0)
+    bb.double(); head.double()
+    opt, sched = O.make_optimizer(torch.nn.Sequential(bb, head), cfg["SOLVER"])
+    d = synth.make_pairs(4, seed=31)
+    for it in range(2):
+        data = {k: _t(d[k], torch.float64) for k in ("patch_1", "patch_2", "delta")}
+        loss, dgt, dh = O.train_step(bb, head, opt, sched, data, choice_12=_t(g["choice_12"][it], torch.int64))
+        assert abs(loss.item() - g["loss"][it]) <= 1e-8 * abs(g["loss"][it])
+        np.testing.assert_allclose(O.mace(dgt, dh), g["mace"][it], rtol=1e-7)
+        if it == 0:
+            np.testing.assert_allclose(dh.numpy(), g["delta_hat_12"], atol=1e-7)
