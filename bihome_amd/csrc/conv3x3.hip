@@ -56,6 +56,7 @@ struct C3Args {
     int bnr_relu, bnr_rows;
     double* bn_sums;       // optional [groups][Nn][2]: += per-channel (sum, sum of squares) of the output (forward only)
     int imgs_per_group, groups;
+    int dbg_nch;           // ablation: number of channel chunks to run (-1 = all)
 };
 
 constexpr int C3_HALO_BYTES = 8 * 200 * 16;          // 25600
@@ -139,7 +140,7 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
-    const int nch = a.Kc / 32;
+    const int nch = a.dbg_nch >= 0 ? a.dbg_nch : a.Kc / 32;     // (ablation hook: bh_debug_force_tile(-8, n) caps the chunk loop)
     // lane-constant parts of the fragment addresses (bytes)
     const int a_lane = (kh2 * 200 + wm * 100 + (wh * 4 + (l31 >> 3)) * 10 + (l31 & 7)) * 16;
     const int b_lane = FLIP ? (kh2 * 4 * BN + wn * 32 + l31) * 4 : (kh2 * BN + wn * 32 + l31) * 16;
@@ -312,8 +313,9 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
     }
 }
 
-static int g_c3_disable = 0, g_c3_min_blocks = 256;
+static int g_c3_disable = 0, g_c3_min_blocks = 256, g_c3_dbg_nch = -1;
 void bh_conv3x3_tune(int disable, int min_blocks) {
+    if (disable <= -100) { g_c3_dbg_nch = -100 - disable - 1; return; }     // -100 -> -1 (all), -101 -> 0 chunks, -102 -> 1 ...
     g_c3_disable = disable;
     if (min_blocks > 0) g_c3_min_blocks = min_blocks;
 }
@@ -343,7 +345,7 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
         a.bnr_z = bnr->z; a.bnr_y = bnr->y; a.bnr_stats = bnr->stats; a.bnr_gamma = bnr->gamma; a.bnr_beta = bnr->beta;
         a.bnr_eps = bnr->eps; a.bnr_relu = bnr->relu; a.bnr_rows = (d->N / groups) * d->Hi * d->Wi;
     }
-    a.res = res; a.relu = relu;
+    a.res = res; a.relu = relu; a.dbg_nch = g_c3_dbg_nch;
     a.bn_sums = bn_sums; a.imgs_per_group = bn_sums ? d->N / groups : 1; a.groups = groups;
     a.tiles_x = d->Wi / 8; a.tiles_per_img = (d->Hi / 8) * a.tiles_x; a.subtiles = d->N * a.tiles_per_img;
     dim3 grid((a.subtiles + 1) / 2, Nn / bn_tile);
