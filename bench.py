@@ -118,12 +118,24 @@ def roofline_leg(model, data, opt, sched, reducer, nsteps=2):
     rows.sort(key=lambda r: -r["ms_per_step"])
     top = rows[0]
     traffic = pmc_traffic(top["kernel"])
+    # the same launches grouped by kernel template (all instantiations of one __global__ function)
+    fam = {}
+    for r in rows:
+        f = fam.setdefault(r["kernel"].split("<")[0].split("(")[0], {"ms_per_step": 0.0, "flops": 0.0, "launches_per_step": 0})
+        f["ms_per_step"] += r["ms_per_step"]
+        f["flops"] += r["flops_per_launch"] * r["launches_per_step"]
+        f["launches_per_step"] += r["launches_per_step"]
+    families = [{"kernel": k, "launches_per_step": v["launches_per_step"], "ms_per_step": round(v["ms_per_step"], 3),
+                 "tflops": round(v["flops"] / (v["ms_per_step"] * 1e-3) / 1e12, 2) if v["ms_per_step"] > 0 else 0.0,
+                 "frac_of_f32_mfma_peak": round(v["flops"] / (v["ms_per_step"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+                 if v["ms_per_step"] > 0 else 0.0}
+                for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms_per_step"])[:4]]
     if top["tflops"] > 0:
         roof = {"kernel": top["kernel"], "bound": "mfma", "achieved": top["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": top["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": top["bytes_per_launch"],
                 "avg_launch_us": top["avg_us"], "flops_per_launch": top["flops_per_launch"],
-                "launches_per_step": top["launches_per_step"]}
+                "launches_per_step": top["launches_per_step"], "by_kernel_template": families}
     else:
         roof = {"kernel": top["kernel"], "bound": "hbm", "achieved": top["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": top["gbs"] / PEAK_HBM_GBS, "traffic": traffic, "avg_launch_us": top["avg_us"],

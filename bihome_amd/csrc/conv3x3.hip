@@ -68,31 +68,39 @@ constexpr int C3_LDS_BYTES = 2 * C3_HALO_BYTES + 2 * C3_B_BYTES;      // 67584
 // BF16 (bh_conv_desc.precision = 1): same fp32 LDS image, the fragments are rounded to bf16 in registers and fed to
 // v_mfma_f32_32x32x16_bf16 (16 channels per instruction: half-wave 0 holds planes 4s, 4s+2, half-wave 1 planes 4s+1,
 // 4s+3 of the A and of the B fragment alike); fp32 accumulate.  The MFMA time drops 16x, the kernel becomes LDS-bound.
-template <bool FLIP, int BN, bool BF16 = false>
+// SUBT = 8x8 sub-tiles per workgroup.  2 (default): 128 GEMM rows, 67.5 KB of LDS, two workgroups per CU.  1 (BN = 64
+// only): 64 rows, a wave owns 32 rows x 32 channels, 41.6 KB of LDS, three workgroups per CU - more weight-slab traffic
+// and LDS reads per MFMA, but three workgroups drift out of lockstep and cover each other's prologue / epilogue.
+template <bool FLIP, int BN, bool BF16 = false, int SUBT = 2>
 __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
-    constexpr int TM = BN == 64 ? 2 : 1;
+    static_assert(SUBT == 2 || BN == 64, "one sub-tile per workgroup is built for the 64-channel tile only");
+    constexpr int TM = (BN == 64 && SUBT == 2) ? 2 : 1;
+    constexpr int HPL = 100 * SUBT;                        // halo slots per k-plane
+    constexpr int HALO_B = 8 * HPL * 16;                   // bytes of one halo stage
+    constexpr int HINS = (8 * HPL + 63) / 64;              // wave instructions per halo stage (25 / 13)
+    constexpr int HJ = (HINS + 3) / 4;                     // ... per wave (7 / 4)
     constexpr int BINS = BN == 64 ? 2 : 1;                 // weight-slab wave instructions per wave and step
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kh2 = lane >> 5;
-    const int wm = BN == 64 ? (wave & 1) : (wave >> 1);    // sub-tile of this wave
+    const int wm = SUBT == 1 ? 0 : (BN == 64 ? (wave & 1) : (wave >> 1));    // sub-tile of this wave
     const int wn = BN == 64 ? (wave >> 1) : 0;
-    const int wh = BN == 64 ? 0 : (wave & 1);              // BN = 32: upper / lower four pixel rows of the sub-tile
+    const int wh = (BN == 64 && SUBT == 2) ? 0 : (wave & 1);   // 32-row waves: upper / lower four pixel rows of the sub-tile
     const int n0 = blockIdx.y * BN;
     constexpr unsigned OOB = 0xFFFFFFF0u;
     __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Src), 0, a.src_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wt), 0, a.w_bytes, 0x00020000);
 
     // ---- halo slots of this lane: slot q = (j*4 + wave)*64 + lane of the [8][2][100] image ----
-    unsigned hoff[7];
+    unsigned hoff[7] = {OOB, OOB, OOB, OOB, OOB, OOB, OOB};   // (fixed size, first HJ used: see the note at boff)
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
+    for (int j = 0; j < HJ; ++j) {
         const int ci = j * 4 + wave, q = ci * 64 + lane;
         unsigned off = OOB;
-        if (ci < 25) {
-            const int plane = q / 200, rem = q - plane * 200, s = rem / 100, hp = rem - s * 100;
+        if (ci < HINS && q < 8 * HPL) {
+            const int plane = q / HPL, rem = q - plane * HPL, s = rem / 100, hp = rem - s * 100;
             const int hy = hp / 10, hx = hp - hy * 10;
-            const int g = blockIdx.x * 2 + s;
+            const int g = blockIdx.x * SUBT + s;
             if (g < a.subtiles) {
                 const int img = g / a.tiles_per_img, t = g - img * a.tiles_per_img;
                 const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
@@ -122,16 +130,18 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
     do {                                                                                                                \
         const unsigned soff_ = FLIP ? (unsigned)(((c) * 32 * 9 + (8 - (tap))) * a.Cw) * 4u                             \
                                     : (unsigned)((tap) * a.Cw + (c) * 32) * 4u;                                        \
-        char* base_ = smem + 2 * C3_HALO_BYTES + (bs) * C3_B_BYTES + wave * 1024;                                       \
+        char* base_ = smem + 2 * HALO_B + (bs) * C3_B_BYTES + wave * 1024;                                              \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_ptr)(base_), 16, boff[0], soff_, 0, 0);                 \
         if (BINS == 2)                                                                                                  \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_ptr)(base_ + 4096), 16, boff[1], soff_, 0, 0); \
     } while (0)
+    // (the last wave instruction of a stage is partial - 64 resp. 32 of its lanes: the others are masked off, an
+    //  out-of-range lane would still write zeros past the stage)
 #define C3_ISSUE_HALO(j, c, hs)                                                                                         \
     do {                                                                                                                \
-        if ((j) < 6 || wave == 0)                                                                                       \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_ptr)(smem + (hs) * C3_HALO_BYTES + ((j) * 4 + wave) * 1024), \
-                                                     16, hoff[j], (unsigned)((c) * 32) * 4u, 0, 0);                     \
+        if ((j) < HJ && (j) * 4 + wave < HINS && (((j) * 4 + wave) * 64 + lane) < 8 * HPL)                              \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_ptr)(smem + (hs) * HALO_B + ((j) * 4 + wave) * 1024), \
+                                                     16, hoff[(j) < HJ ? (j) : 0], (unsigned)((c) * 32) * 4u, 0, 0);    \
     } while (0)
 
     f32x16 acc[TM];
@@ -142,11 +152,11 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
 
     const int nch = a.dbg_nch >= 0 ? a.dbg_nch : a.Kc / 32;     // (ablation hook: bh_debug_force_tile(-8, n) caps the chunk loop)
     // lane-constant parts of the fragment addresses (bytes)
-    const int a_lane = (kh2 * 200 + wm * 100 + (wh * 4 + (l31 >> 3)) * 10 + (l31 & 7)) * 16;
+    const int a_lane = (kh2 * HPL + wm * 100 + (wh * 4 + (l31 >> 3)) * 10 + (l31 & 7)) * 16;
     const int b_lane = FLIP ? (kh2 * 4 * BN + wn * 32 + l31) * 4 : (kh2 * BN + wn * 32 + l31) * 16;
 
 #pragma unroll
-    for (int j = 0; j < 7; ++j) C3_ISSUE_HALO(j, 0, 0);
+    for (int j = 0; j < HJ; ++j) C3_ISSUE_HALO(j, 0, 0);
     issue_B(0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -154,7 +164,7 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
     int bs = 0;
     for (int c = 0; c < nch; ++c) {
         const int hs = c & 1;
-        const char* hbase = smem + hs * C3_HALO_BYTES + a_lane;
+        const char* hbase = smem + hs * HALO_B + a_lane;
         const bool more = c + 1 < nch;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -162,12 +172,12 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
             // outstanding LDS-DMA with a full vmcnt(0), so the prefetch is issued only after them
             const int dy = tap / 3, dx = tap - dy * 3;
             const char* ap = hbase + (dy * 10 + dx) * 16;
-            const char* bp = smem + 2 * C3_HALO_BYTES + bs * C3_B_BYTES + b_lane;
+            const char* bp = smem + 2 * HALO_B + bs * C3_B_BYTES + b_lane;
             float4 af[TM][4], b[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[i][q] = *reinterpret_cast<const float4*>(ap + q * 6400 + i * 640);
+                for (int i = 0; i < TM; ++i) af[i][q] = *reinterpret_cast<const float4*>(ap + q * (2 * HPL * 16) + i * 640);
                 if (!FLIP) b[q] = *reinterpret_cast<const float4*>(bp + q * (2 * BN * 16));
                 else {
                     b[q].x = *reinterpret_cast<const float*>(bp + (q * 8 + 0) * (BN * 4));
@@ -178,7 +188,7 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
             }
             if (tap < 8) issue_B(c, tap + 1, bs ^ 1);
             else if (more) issue_B(c + 1, 0, bs ^ 1);
-            if (tap < 7 && more) C3_ISSUE_HALO(tap, c + 1, hs ^ 1);
+            if (tap < HJ && more) C3_ISSUE_HALO(tap, c + 1, hs ^ 1);
             if constexpr (BF16) {
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
@@ -210,7 +220,7 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
 #undef issue_B
 
     // ---- epilogue: C/D layout col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m) ----
-    const int g = blockIdx.x * 2 + wm;
+    const int g = blockIdx.x * SUBT + wm;
     const int n = n0 + wn * 32 + l31;
     const bool valid = g < a.subtiles && n < a.Nn;
     const int gg = g < a.subtiles ? g : 0;
@@ -313,9 +323,10 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
     }
 }
 
-static int g_c3_disable = 0, g_c3_min_blocks = 256, g_c3_dbg_nch = -1;
+static int g_c3_disable = 0, g_c3_min_blocks = 256, g_c3_dbg_nch = -1, g_c3_subt = 2;
 void bh_conv3x3_tune(int disable, int min_blocks) {
-    if (disable <= -100) { g_c3_dbg_nch = -100 - disable - 1; return; }     // -100 -> -1 (all), -101 -> 0 chunks, -102 -> 1 ...
+    if (disable <= -100) { g_c3_dbg_nch = -100 - disable - 1; return; }
+    if (disable >= 11 && disable <= 13) { g_c3_subt = disable - 10; return; }      // 1 / 2 (automatic) / 3 (always two) sub-tiles per workgroup     // -100 -> -1 (all), -101 -> 0 chunks, -102 -> 1 ...
     g_c3_disable = disable;
     if (min_blocks > 0) g_c3_min_blocks = min_blocks;
 }
@@ -348,24 +359,32 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
     a.res = res; a.relu = relu; a.dbg_nch = g_c3_dbg_nch;
     a.bn_sums = bn_sums; a.imgs_per_group = bn_sums ? d->N / groups : 1; a.groups = groups;
     a.tiles_x = d->Wi / 8; a.tiles_per_img = (d->Hi / 8) * a.tiles_x; a.subtiles = d->N * a.tiles_per_img;
-    dim3 grid((a.subtiles + 1) / 2, Nn / bn_tile);
-    if ((int)(grid.x * grid.y) < g_c3_min_blocks) return 0;
+    // one sub-tile per workgroup where two would leave half of the 512 workgroup slots empty (the 8x8x256-channel layers:
+    // +6 %); elsewhere the 128-row tile is as fast or faster (measured, tools/conv3x3_check.py --subt1)
+    const bool few = (long long)((a.subtiles + 1) / 2) * (Nn / bn_tile) <= 256;
+    const int subt = (bn_tile == 64 && (g_c3_subt == 1 || (g_c3_subt == 2 && few))) ? 1 : 2;
+    dim3 grid((a.subtiles + subt - 1) / subt, Nn / bn_tile);
+    if ((int)(((a.subtiles + 1) / 2) * grid.y) < g_c3_min_blocks) return 0;
     static bool attr_set = false;
     typedef void (*kern_t)(C3Args);
-    static const kern_t fns[8] = {conv3x3_halo_kernel<false, 64, false>, conv3x3_halo_kernel<true, 64, false>,
-                                  conv3x3_halo_kernel<false, 32, false>, conv3x3_halo_kernel<true, 32, false>,
-                                  conv3x3_halo_kernel<false, 64, true>,  conv3x3_halo_kernel<true, 64, true>,
-                                  conv3x3_halo_kernel<false, 32, true>,  conv3x3_halo_kernel<true, 32, true>};
+    static const kern_t fns[12] = {conv3x3_halo_kernel<false, 64, false>, conv3x3_halo_kernel<true, 64, false>,
+                                   conv3x3_halo_kernel<false, 32, false>, conv3x3_halo_kernel<true, 32, false>,
+                                   conv3x3_halo_kernel<false, 64, true>,  conv3x3_halo_kernel<true, 64, true>,
+                                   conv3x3_halo_kernel<false, 32, true>,  conv3x3_halo_kernel<true, 32, true>,
+                                   conv3x3_halo_kernel<false, 64, false, 1>, conv3x3_halo_kernel<true, 64, false, 1>,
+                                   conv3x3_halo_kernel<false, 64, true, 1>,  conv3x3_halo_kernel<true, 64, true, 1>};
+    constexpr int LDS1 = 2 * (8 * 100 * 16) + 2 * C3_B_BYTES;           // one sub-tile per workgroup: 41,984 B
     if (!attr_set) {
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 12; ++i) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[i]), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               C3_LDS_BYTES);
+                                               i < 8 ? C3_LDS_BYTES : LDS1);
             if (e != hipSuccess) return (int)e;
         }
         attr_set = true;
     }
-    const kern_t fn = fns[(d->precision == 1 ? 4 : 0) + (bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0)];
-    hipLaunchKernelGGL(fn, grid, dim3(256), C3_LDS_BYTES, stream, a);
+    const kern_t fn = subt == 1 ? fns[8 + (d->precision == 1 ? 2 : 0) + (dgrad ? 1 : 0)]
+                                : fns[(d->precision == 1 ? 4 : 0) + (bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0)];
+    hipLaunchKernelGGL(fn, grid, dim3(256), subt == 1 ? LDS1 : C3_LDS_BYTES, stream, a);
     BH_LAUNCH_CHECK();
     *taken = 1;
     return BH_OK;

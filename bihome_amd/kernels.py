@@ -90,9 +90,11 @@ def _c3_variant(d, dgrad):
     if Kc % 32 or Nn % 32 or d.N * d.Hi * d.Wi * max(Kc, Nn) * 4 >= 2 ** 31:
         return None
     bn = 32 if Nn % 64 else 64
-    if ((d.N * (d.Hi // 8) * (d.Wi // 8) + 1) // 2) * (Nn // bn) < C3_MIN_BLOCKS:
+    pairs = ((d.N * (d.Hi // 8) * (d.Wi // 8) + 1) // 2) * (Nn // bn)
+    if pairs < C3_MIN_BLOCKS:
         return None
-    return "conv3x3_halo_kernel<%s,%d,%s>" % ("true" if dgrad else "false", bn, "true" if d.precision == 1 else "false")
+    subt = 1 if (bn == 64 and pairs <= 256) else 2          # one 8x8 sub-tile per workgroup on the small grids
+    return "conv3x3_halo_kernel<%s,%d,%s,%d>" % ("true" if dgrad else "false", bn, "true" if d.precision == 1 else "false", subt)
 
 
 def _stem7_variant(d):

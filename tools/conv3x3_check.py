@@ -16,6 +16,8 @@ def bench(fn, n=20):
 shapes = [(128, 32, 64, 64), (128, 16, 128, 128), (128, 8, 256, 256), (128, 64, 64, 64), (3, 8, 32, 64), (5, 24, 64, 128),
           (128, 32, 128, 128), (128, 16, 256, 256), (128, 64, 32, 32), (128, 128, 32, 32), (5, 24, 32, 32), (7, 8, 64, 96)]
 PREC = 1 if '--bf16' in sys.argv else 0
+if '--subt1' in sys.argv:
+    lib.bh_debug_force_tile(-9, 1)
 lib.bh_debug_force_tile(-5, 1)
 for (N, H, Ci, Co) in shapes:
     d = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=PREC)
