@@ -623,7 +623,7 @@ static int launch(const GemmArgs& a, hipStream_t s) {
 
 // Tile choice: the largest tile that still gives the 256 CUs about two workgroups each; the small-spatial
 // layers (8x8x256ch, 16x16x128ch at 2B = 128) otherwise launch only 128-256 workgroups.
-extern int g_wgrad_target, g_wgrad_noflush;
+extern int g_wgrad_target, g_wgrad_noflush, g_wgrad_xcd_map;
 static int g_force_bm = 0, g_force_bn = 0, g_prio = 0, g_no_buf = 0;     // tuning hook (bh_debug_force_tile), 0 = automatic
 
 static int dispatch(const GemmArgs& a_in, hipStream_t s) {
@@ -850,6 +850,7 @@ int bh_debug_force_tile(int bm, int bn) {
     if (bm == -5) { bh_conv3x3_tune(0, bn); return BH_OK; } // (-5, n): minimum workgroups for the halo-tiled 3x3 kernel
     if (bm == -6) { bh_stem7_tune(bn); return BH_OK; }
     if (bm == -7) { g_wgrad_noflush = bn; return BH_OK; }
+    if (bm == -10) { g_wgrad_xcd_map = bn; return BH_OK; }              // (-10, 0|1): XCD-aware wgrad work order off / on
     if (bm == -9) { bh_conv3x3_tune(10 + bn, 0); return BH_OK; }     // (-9, 1|2): 3x3 kernel sub-tiles per workgroup (64-channel tile)
     if (bm == -8) { bh_conv3x3_tune(-101 - bn, 0); return BH_OK; }  // (-8, n): ablation - 3x3 kernel runs n channel chunks only (-1: all)   // (-7, 1): ablation - wgrad without its atomic flush      // (-6, 1): disable the dedicated 7x7 stem forward kernel
     g_force_bm = bm; g_force_bn = bn; return BH_OK;

@@ -15,6 +15,10 @@ for (N,H,Ci,Co) in [(128,32,64,64),(128,16,128,128),(128,8,256,256)]:
     x=torch.randn(N,H,H,Ci,device='cuda'); gy=torch.randn(N,H,H,Co,device='cuda'); gw=torch.zeros(Co,3,3,Ci,device='cuda')
     fl=K.conv_flops(d)
     out=[]
+    for xm in (0,1):
+        lib.bh_debug_force_tile(-10,xm)
+        t=bench(lambda: K.conv_wgrad(x,gy,gw,None,d)); out.append('xcdmap%d: %.0fus %.0fTF'%(xm,t*1e3,fl/t/1e9))
+    lib.bh_debug_force_tile(-10,0)
     for nf in (0,1):
         lib.bh_debug_force_tile(-7,nf)
         for tgt in (4096,2048,1024):
