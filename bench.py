@@ -118,6 +118,15 @@ def roofline_leg(model, data, opt, sched, reducer, nsteps=2):
     rows.sort(key=lambda r: -r["ms_per_step"])
     top = rows[0]
     traffic = pmc_traffic(top["kernel"])
+    # BASELINE.json's HBM-bound part: homography warp + perceptual-feature L1 / triplet reduction (SURVEY.md 8(d) bytes)
+    hp = [r for r in rows if r["kernel"] in ("warp_fwd_kernel", "warp_bwd_kernel", "triplet_fwd_kernel", "triplet_bwd_kernel")]
+    hbm_path = None
+    if hp:
+        ms_ = sum(r["ms_per_step"] for r in hp)
+        by_ = sum(r["bytes_per_launch"] * r["launches_per_step"] for r in hp)
+        hbm_path = {"kernels": {r["kernel"]: {"us": round(r["avg_us"], 1), "GB/s": round(r["gbs"], 1)} for r in hp},
+                    "algorithmic_bytes_per_step": by_, "ms_per_step": round(ms_, 4), "achieved_GBs": round(by_ / (ms_ * 1e-3) / 1e9, 1),
+                    "frac_of_hbm_peak": round(by_ / (ms_ * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
     # the same launches grouped by kernel template (all instantiations of one __global__ function)
     fam = {}
     for r in rows:
@@ -135,7 +144,8 @@ def roofline_leg(model, data, opt, sched, reducer, nsteps=2):
                 "unit": "TFLOP/s", "frac": top["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": top["bytes_per_launch"],
                 "avg_launch_us": top["avg_us"], "flops_per_launch": top["flops_per_launch"],
-                "launches_per_step": top["launches_per_step"], "by_kernel_template": families}
+                "launches_per_step": top["launches_per_step"], "by_kernel_template": families,
+                "warp_perceptual_path": hbm_path}
     else:
         roof = {"kernel": top["kernel"], "bound": "hbm", "achieved": top["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": top["gbs"] / PEAK_HBM_GBS, "traffic": traffic, "avg_launch_us": top["avg_us"],

@@ -145,6 +145,115 @@ __global__ void __launch_bounds__(256) warp_bwd_kernel(const float* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// pool = 4 fast path (the shipped configuration: 128x128 patches, 32x32 features): four consecutive pixels of a row per
+// thread, so the output is one 16-byte store per lane, a thread's four pixels are exactly one pooling-window row (the
+// pooled coverage needs two shuffles over the wave's four rows), and the adjoint's nine double sums are reduced over a
+// quarter of the wavefronts.  Per-pixel arithmetic is the same as in the generic kernels (same results).
+// grid (w/64, h/16, B), block 256 = 16 (x quads) x 16 (rows); a wave = 16 quads x 4 rows.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) warp_fwd4_kernel(const float* __restrict__ img, const double* __restrict__ H64, int C,
+                                                        int h, int w, float* __restrict__ out, float* __restrict__ cov) {
+    const int b = blockIdx.z;
+    const int tq = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int xq = blockIdx.x * 64 + tq * 4, y = blockIdx.y * 16 + ty;
+    int x0[4], y0[4];
+    float w00[4], w01[4], w10[4], w11[4];
+    bool v00[4], v01[4], v10[4], v11[4];
+    float cv = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float u, v, iz;
+        bool guard;
+        project(H64 + (size_t)b * 9, xq + i, y, u, v, iz, guard);
+        const Tap t = make_tap(u, v, w, h);
+        x0[i] = (int)fminf(fmaxf(t.x0f, -2.0f), (float)w); y0[i] = (int)fminf(fmaxf(t.y0f, -2.0f), (float)h);
+        w00[i] = (1 - t.fx) * (1 - t.fy); w01[i] = t.fx * (1 - t.fy); w10[i] = (1 - t.fx) * t.fy; w11[i] = t.fx * t.fy;
+        v00[i] = t.vx0 && t.vy0; v01[i] = t.vx1 && t.vy0; v10[i] = t.vx0 && t.vy1; v11[i] = t.vx1 && t.vy1;
+        cv += (v00[i] ? w00[i] : 0.0f) + (v01[i] ? w01[i] : 0.0f) + (v10[i] ? w10[i] : 0.0f) + (v11[i] ? w11[i] : 0.0f);
+    }
+    if (img) {
+        for (int c = 0; c < C; ++c) {
+            const float* p = img + ((size_t)b * C + c) * h * w;
+            float o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float acc = 0.0f;
+                if (v00[i]) acc += p[y0[i] * w + x0[i]] * w00[i];
+                if (v01[i]) acc += p[y0[i] * w + x0[i] + 1] * w01[i];
+                if (v10[i]) acc += p[(y0[i] + 1) * w + x0[i]] * w10[i];
+                if (v11[i]) acc += p[(y0[i] + 1) * w + x0[i] + 1] * w11[i];
+                o[i] = acc;
+            }
+            *reinterpret_cast<float4*>(out + ((size_t)b * C + c) * h * w + (size_t)y * w + xq) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    if (cov) {
+        cv += __shfl_xor(cv, 16, 64);                 // the four rows of the wave (lane = (ty & 3) * 16 + tq)
+        cv += __shfl_xor(cv, 32, 64);
+        if ((ty & 3) == 0) cov[(size_t)b * (h / 4) * (w / 4) + (size_t)(y / 4) * (w / 4) + xq / 4] = cv * (1.0f / 16.0f);
+    }
+}
+
+__global__ void __launch_bounds__(256) warp_bwd4_kernel(const float* __restrict__ img, const double* __restrict__ H64,
+                                                        const float* __restrict__ g_out, const float* __restrict__ g_cov, int C,
+                                                        int h, int w, double* __restrict__ gH) {
+    __shared__ double part[4][9];
+    const int b = blockIdx.z;
+    const int tq = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int xq = blockIdx.x * 64 + tq * 4, y = blockIdx.y * 16 + ty;
+    const float gc = g_cov ? g_cov[(size_t)b * (h / 4) * (w / 4) + (size_t)(y / 4) * (w / 4) + xq / 4] * (1.0f / 16.0f) : 0.0f;
+    double s[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s[k] = 0.0;
+    float4 go4[4];                                     // up to 4 channels cached (C = 1 or 3 here); more are re-read
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        go4[c] = (img && g_out && c < C) ? *reinterpret_cast<const float4*>(g_out + ((size_t)b * C + c) * h * w + (size_t)y * w + xq)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int x = xq + i;
+        float u, v, iz;
+        bool guard;
+        project(H64 + (size_t)b * 9, x, y, u, v, iz, guard);
+        const Tap t = make_tap(u, v, w, h);
+        const int x0 = (int)fminf(fmaxf(t.x0f, -2.0f), (float)w), y0 = (int)fminf(fmaxf(t.y0f, -2.0f), (float)h);
+        const bool v00 = t.vx0 && t.vy0, v01 = t.vx1 && t.vy0, v10 = t.vx0 && t.vy1, v11 = t.vx1 && t.vy1;
+        float gu = 0.0f, gv = 0.0f;
+        if (img && g_out) {
+            for (int c = 0; c < C; ++c) {
+                const float* p = img + ((size_t)b * C + c) * h * w;
+                float go;
+                if (c < 4) { const float4 q = go4[c]; go = i == 0 ? q.x : (i == 1 ? q.y : (i == 2 ? q.z : q.w)); }
+                else go = g_out[((size_t)b * C + c) * h * w + (size_t)y * w + x];
+                const float p00 = v00 ? p[y0 * w + x0] : 0.0f, p01 = v01 ? p[y0 * w + x0 + 1] : 0.0f;
+                const float p10 = v10 ? p[(y0 + 1) * w + x0] : 0.0f, p11 = v11 ? p[(y0 + 1) * w + x0 + 1] : 0.0f;
+                gu += go * ((p01 - p00) * (1 - t.fy) + (p11 - p10) * t.fy);
+                gv += go * ((p10 - p00) * (1 - t.fx) + (p11 - p01) * t.fx);
+            }
+        }
+        if (g_cov) {
+            const float o00 = v00 ? 1.0f : 0.0f, o01 = v01 ? 1.0f : 0.0f, o10 = v10 ? 1.0f : 0.0f, o11 = v11 ? 1.0f : 0.0f;
+            gu += gc * ((o01 - o00) * (1 - t.fy) + (o11 - o10) * t.fy);
+            gv += gc * ((o10 - o00) * (1 - t.fx) + (o11 - o01) * t.fx);
+        }
+        const double fx = (double)x, fy = (double)y, dgu = (double)gu, dgv = (double)gv, diz = (double)iz;
+        s[0] += dgu * diz * fx; s[1] += dgu * diz * fy; s[2] += dgu * diz;
+        s[3] += dgv * diz * fx; s[4] += dgv * diz * fy; s[5] += dgv * diz;
+        const double gz = guard ? 0.0 : -(dgu * (double)u + dgv * (double)v) * diz;
+        s[6] += gz * fx; s[7] += gz * fy; s[8] += gz;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s[k] = wave_sum(s[k]);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0)
+        for (int k = 0; k < 9; ++k) part[wave][k] = s[k];
+    __syncthreads();
+    if (threadIdx.x < 9)
+        atomicAdd(gH + (size_t)b * 9 + threadIdx.x, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
 extern "C" {
 
 int bh_warp_fwd(const float* img, const double* H64, int B, int C, int h, int w, int pool, float* out, float* cov,
@@ -152,6 +261,11 @@ int bh_warp_fwd(const float* img, const double* H64, int B, int C, int h, int w,
     if (!H64 || B < 0 || (img && !out) || (!img && !cov)) return BH_E_BADARG;
     if ((h % 16) || (w % 16) || (pool != 1 && pool != 2 && pool != 4 && pool != 8 && pool != 16)) return BH_E_UNSUPPORTED;
     if (B == 0) return BH_OK;
+    if (pool == 4 && (w % 64) == 0) {
+        hipLaunchKernelGGL(warp_fwd4_kernel, dim3(w / 64, h / 16, B), dim3(256), 0, bh_stream(stream), img, H64, C, h, w, out, cov);
+        BH_LAUNCH_CHECK();
+        return BH_OK;
+    }
     hipLaunchKernelGGL(warp_fwd_kernel, dim3(w / 16, h / 16, B), dim3(256), 0, bh_stream(stream), img, H64, C, h, w, pool,
                        out, cov);
     BH_LAUNCH_CHECK();
@@ -163,6 +277,12 @@ int bh_warp_bwd(const float* img, const double* H64, const float* g_out, const f
     if (!H64 || !gH || B < 0 || (g_out && !img)) return BH_E_BADARG;
     if ((h % 16) || (w % 16) || (pool != 1 && pool != 2 && pool != 4 && pool != 8 && pool != 16)) return BH_E_UNSUPPORTED;
     if (B == 0) return BH_OK;
+    if (pool == 4 && (w % 64) == 0) {
+        hipLaunchKernelGGL(warp_bwd4_kernel, dim3(w / 64, h / 16, B), dim3(256), 0, bh_stream(stream), img, H64, g_out, g_cov, C,
+                           h, w, gH);
+        BH_LAUNCH_CHECK();
+        return BH_OK;
+    }
     hipLaunchKernelGGL(warp_bwd_kernel, dim3(w / 16, h / 16, B), dim3(256), 0, bh_stream(stream), img, H64, g_out, g_cov,
                        C, h, w, pool, gH);
     BH_LAUNCH_CHECK();

@@ -217,7 +217,8 @@ def warp_fwd(img, H64, pool=4, want_cov=True):
     B, C, h, w = img.shape
     out = torch.empty_like(img)
     cov = torch.empty(B, h // pool, w // pool, dtype=torch.float32, device=img.device) if want_cov else None
-    check(lib.bh_warp_fwd(_p(img), _p(H64), B, C, h, w, pool, _p(out), _p(cov), _stream()), "bh_warp_fwd")
+    with _Timed("warp_fwd_kernel", 0.0, 4.0 * (img.numel() + out.numel() + (cov.numel() if want_cov else 0))):     # 8 B/px/channel
+        check(lib.bh_warp_fwd(_p(img), _p(H64), B, C, h, w, pool, _p(out), _p(cov), _stream()), "bh_warp_fwd")
     return out, cov
 
 
@@ -234,7 +235,8 @@ def warp_bwd(img, H64, g_out, g_cov, pool=4, gH=None):
     B, C, h, w = img.shape
     if gH is None:
         gH = torch.zeros(B, 9, dtype=torch.float64, device=img.device)
-    check(lib.bh_warp_bwd(_p(img), _p(H64), _p(g_out), _p(g_cov), B, C, h, w, pool, _p(gH), _stream()), "bh_warp_bwd")
+    with _Timed("warp_bwd_kernel", 0.0, 4.0 * (img.numel() + g_out.numel() + g_cov.numel())):
+        check(lib.bh_warp_bwd(_p(img), _p(H64), _p(g_out), _p(g_cov), B, C, h, w, pool, _p(gH), _stream()), "bh_warp_bwd")
     return gH
 
 
@@ -249,8 +251,9 @@ def triplet_l1_fwd(f1, f2, f1w, f2w, m1w, m2w, m1=None, m2=None):
     M1 = torch.empty(B, hf, wf, dtype=torch.float32, device=f1.device)
     M2 = torch.empty_like(M1)
     numden = torch.empty(B, 4, dtype=torch.float64, device=f1.device)
-    check(lib.bh_triplet_l1_fwd(_p(f1), _p(f2), _p(f1w), _p(f2w), _p(m1w), _p(m2w), _p(m1), _p(m2), B, hf * wf, C,
-                                _p(M1), _p(M2), _p(numden), _stream()), "bh_triplet_l1_fwd")
+    with _Timed("triplet_fwd_kernel", 0.0, 4.0 * (4 * f1.numel() + 4 * M1.numel())):      # 4 feature maps in, masks in, M1 / M2 out
+        check(lib.bh_triplet_l1_fwd(_p(f1), _p(f2), _p(f1w), _p(f2w), _p(m1w), _p(m2w), _p(m1), _p(m2), B, hf * wf, C,
+                                    _p(M1), _p(M2), _p(numden), _stream()), "bh_triplet_l1_fwd")
     return M1, M2, numden
 
 
@@ -292,9 +295,10 @@ def bihome_loss_bwd(g_loss, f1, f2, f1w, f2w, m1w, m2w, m1, m2, M1, M2, numden, 
     g_m1w, g_m2w = torch.empty_like(m1w), torch.empty_like(m2w)
     gH1 = torch.empty(B, 9, dtype=torch.float64, device=f1.device)
     gH2 = torch.empty_like(gH1)
-    check(lib.bh_bihome_loss_bwd(_p(g_loss), _p(f1), _p(f2), _p(f1w), _p(f2w), _p(m1w), _p(m2w), _p(m1), _p(m2), _p(M1),
-                                 _p(M2), _p(numden), _p(H1), _p(H2), B, hf * wf, C, float(mu), _p(g_f1w), _p(g_f2w),
-                                 _p(g_m1w), _p(g_m2w), _p(gH1), _p(gH2), _stream()), "bh_bihome_loss_bwd")
+    with _Timed("triplet_bwd_kernel", 0.0, 4.0 * (6 * f1.numel() + 6 * M1.numel())):      # 4 feature maps in, 2 gradients out
+        check(lib.bh_bihome_loss_bwd(_p(g_loss), _p(f1), _p(f2), _p(f1w), _p(f2w), _p(m1w), _p(m2w), _p(m1), _p(m2), _p(M1),
+                                     _p(M2), _p(numden), _p(H1), _p(H2), B, hf * wf, C, float(mu), _p(g_f1w), _p(g_f2w),
+                                     _p(g_m1w), _p(g_m2w), _p(gH1), _p(gH2), _stream()), "bh_bihome_loss_bwd")
     return g_f1w, g_f2w, g_m1w, g_m2w, gH1, gH2
 
 
