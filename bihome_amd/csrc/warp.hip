@@ -157,9 +157,10 @@ __global__ void __launch_bounds__(256) warp_fwd4_kernel(const float* __restrict_
     const int b = blockIdx.z;
     const int tq = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int xq = blockIdx.x * 64 + tq * 4, y = blockIdx.y * 16 + ty;
-    int x0[4], y0[4];
+    // branch-free taps: every tap index is clamped into the image and an out-of-bounds tap gets weight 0, so the sixteen
+    // gathers of a thread issue back to back instead of sitting behind per-tap branches
+    int i00[4], i01[4], i10[4], i11[4];
     float w00[4], w01[4], w10[4], w11[4];
-    bool v00[4], v01[4], v10[4], v11[4];
     float cv = 0.0f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -167,10 +168,15 @@ __global__ void __launch_bounds__(256) warp_fwd4_kernel(const float* __restrict_
         bool guard;
         project(H64 + (size_t)b * 9, xq + i, y, u, v, iz, guard);
         const Tap t = make_tap(u, v, w, h);
-        x0[i] = (int)fminf(fmaxf(t.x0f, -2.0f), (float)w); y0[i] = (int)fminf(fmaxf(t.y0f, -2.0f), (float)h);
-        w00[i] = (1 - t.fx) * (1 - t.fy); w01[i] = t.fx * (1 - t.fy); w10[i] = (1 - t.fx) * t.fy; w11[i] = t.fx * t.fy;
-        v00[i] = t.vx0 && t.vy0; v01[i] = t.vx1 && t.vy0; v10[i] = t.vx0 && t.vy1; v11[i] = t.vx1 && t.vy1;
-        cv += (v00[i] ? w00[i] : 0.0f) + (v01[i] ? w01[i] : 0.0f) + (v10[i] ? w10[i] : 0.0f) + (v11[i] ? w11[i] : 0.0f);
+        const int x0 = (int)fminf(fmaxf(t.x0f, -2.0f), (float)w), y0 = (int)fminf(fmaxf(t.y0f, -2.0f), (float)h);
+        const int xa = min(max(x0, 0), w - 1), xb = min(max(x0 + 1, 0), w - 1);
+        const int ya = min(max(y0, 0), h - 1), yb = min(max(y0 + 1, 0), h - 1);
+        i00[i] = ya * w + xa; i01[i] = ya * w + xb; i10[i] = yb * w + xa; i11[i] = yb * w + xb;
+        w00[i] = (t.vx0 && t.vy0) ? (1 - t.fx) * (1 - t.fy) : 0.0f;
+        w01[i] = (t.vx1 && t.vy0) ? t.fx * (1 - t.fy) : 0.0f;
+        w10[i] = (t.vx0 && t.vy1) ? (1 - t.fx) * t.fy : 0.0f;
+        w11[i] = (t.vx1 && t.vy1) ? t.fx * t.fy : 0.0f;
+        cv += w00[i] + w01[i] + w10[i] + w11[i];
     }
     if (img) {
         for (int c = 0; c < C; ++c) {
@@ -178,11 +184,12 @@ __global__ void __launch_bounds__(256) warp_fwd4_kernel(const float* __restrict_
             float o[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                const float p00 = p[i00[i]], p01 = p[i01[i]], p10 = p[i10[i]], p11 = p[i11[i]];
                 float acc = 0.0f;
-                if (v00[i]) acc += p[y0[i] * w + x0[i]] * w00[i];
-                if (v01[i]) acc += p[y0[i] * w + x0[i] + 1] * w01[i];
-                if (v10[i]) acc += p[(y0[i] + 1) * w + x0[i]] * w10[i];
-                if (v11[i]) acc += p[(y0[i] + 1) * w + x0[i] + 1] * w11[i];
+                acc += p00 * w00[i];
+                acc += p01 * w01[i];
+                acc += p10 * w10[i];
+                acc += p11 * w11[i];
                 o[i] = acc;
             }
             *reinterpret_cast<float4*>(out + ((size_t)b * C + c) * h * w + (size_t)y * w + xq) = make_float4(o[0], o[1], o[2], o[3]);
@@ -220,6 +227,8 @@ __global__ void __launch_bounds__(256) warp_bwd4_kernel(const float* __restrict_
         const Tap t = make_tap(u, v, w, h);
         const int x0 = (int)fminf(fmaxf(t.x0f, -2.0f), (float)w), y0 = (int)fminf(fmaxf(t.y0f, -2.0f), (float)h);
         const bool v00 = t.vx0 && t.vy0, v01 = t.vx1 && t.vy0, v10 = t.vx0 && t.vy1, v11 = t.vx1 && t.vy1;
+        const int xa = min(max(x0, 0), w - 1), xb = min(max(x0 + 1, 0), w - 1);       // clamped: loads are unconditional
+        const int ya = min(max(y0, 0), h - 1), yb = min(max(y0 + 1, 0), h - 1);
         float gu = 0.0f, gv = 0.0f;
         if (img && g_out) {
             for (int c = 0; c < C; ++c) {
@@ -227,8 +236,8 @@ __global__ void __launch_bounds__(256) warp_bwd4_kernel(const float* __restrict_
                 float go;
                 if (c < 4) { const float4 q = go4[c]; go = i == 0 ? q.x : (i == 1 ? q.y : (i == 2 ? q.z : q.w)); }
                 else go = g_out[((size_t)b * C + c) * h * w + (size_t)y * w + x];
-                const float p00 = v00 ? p[y0 * w + x0] : 0.0f, p01 = v01 ? p[y0 * w + x0 + 1] : 0.0f;
-                const float p10 = v10 ? p[(y0 + 1) * w + x0] : 0.0f, p11 = v11 ? p[(y0 + 1) * w + x0 + 1] : 0.0f;
+                const float q00 = p[ya * w + xa], q01 = p[ya * w + xb], q10 = p[yb * w + xa], q11 = p[yb * w + xb];
+                const float p00 = v00 ? q00 : 0.0f, p01 = v01 ? q01 : 0.0f, p10 = v10 ? q10 : 0.0f, p11 = v11 ? q11 : 0.0f;
                 gu += go * ((p01 - p00) * (1 - t.fy) + (p11 - p10) * t.fy);
                 gv += go * ((p10 - p00) * (1 - t.fx) + (p11 - p01) * t.fx);
             }
