@@ -416,7 +416,7 @@ def conv_dgrad(gy, w, d, out=None, bn_reduce=None):
 
 def conv_wgrad(x, gy, gw, gbias, d):
     _chk(x); _chk(gy); _chk(gw); _chk(gbias)
-    with _Timed(_wgrad_variant(d) + (" N%d %dx%d C%d->%d k%d s%d%s" % (d.N, d.Hi, d.Wi, d.Ci, d.Co, d.kh, d.stride, " T" if d.transposed else "") if TIMING_DETAIL else ""), conv_flops(d), 4.0 * (x.numel() + gy.numel() + gw.numel())):
+    with _Timed(_wgrad_variant(d) + ("+colsum" if gbias is not None else "") + (" N%d %dx%d C%d->%d k%d s%d%s" % (d.N, d.Hi, d.Wi, d.Ci, d.Co, d.kh, d.stride, " T" if d.transposed else "") if TIMING_DETAIL else ""), conv_flops(d), 4.0 * (x.numel() + gy.numel() + gw.numel())):
         check(lib.bh_conv_wgrad(_p(x), _p(gy), _p(gw), _p(gbias), ctypes.byref(d), _stream()), "bh_conv_wgrad")
 
 
