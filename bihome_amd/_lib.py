@@ -47,6 +47,7 @@ SIGNATURES = {
     "bh_conv_dgrad_bnreduce": [P, P, P, POINTER(BhConvDesc), c_int, POINTER(BhBnReduce), P, c_int, P],
     "bh_col2im_c1": [P, P, POINTER(BhConvDesc), c_int, P],
     "bh_conv_wgrad": [P, P, P, P, POINTER(BhConvDesc), P],
+    "bh_conv_bias_grad": [P, P, POINTER(BhConvDesc), P],
     "bh_bn_stats_doubles": [c_int, c_int],
     "bh_bn_scratch_doubles": [c_int, c_int],
     "bh_bn_fwd": [P] * 8 + [c_int, c_int, c_int, c_float, c_float, c_int, c_int, P],

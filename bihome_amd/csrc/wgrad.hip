@@ -500,6 +500,34 @@ int g_wgrad_target = 4096;      // split-K work items per launch (tuning hook: b
 
 extern "C" {
 
+int bh_conv_bias_grad(const float* gy, float* gbias, const bh_conv_desc* d, void* stream) {
+    if (!gy || !gbias || !d) return BH_E_BADARG;
+    hipStream_t s = bh_stream(stream);
+    // bias gradient = column sums of gy over all output pixels
+    const int M = d->N * d->Ho * d->Wo, C = d->Co;
+    int blocks = (M + 1023) / 1024;
+    if (blocks > 1024) blocks = 1024;
+    int rpb = (M + blocks - 1) / blocks;
+    if (d->out_nchw) {
+        // planes: treat each (n, c) plane as a [hw][1] matrix
+        const int hwp = d->Ho * d->Wo;
+        for (int c = 0; c < C; ++c) {
+            hipLaunchKernelGGL(plane_sum_kernel, dim3(64), dim3(256), 0, s, gy, d->N, C, c, hwp, gbias + c);
+            BH_LAUNCH_CHECK();
+        }
+    } else if (C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0) {
+        const int rpp = 256 / (C / 4);
+        int nb = (M + rpp * 8 - 1) / (rpp * 8);
+        if (nb > 512) nb = 512;          // every workgroup ends with C same-address atomics (~28 ns each, serialised)
+        hipLaunchKernelGGL(colsum4_kernel, dim3(nb), dim3(256), 0, s, gy, M, C, gbias);
+        BH_LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL(colsum_kernel, dim3(blocks, (C + 63) / 64), dim3(256), 0, s, gy, M, C, rpb, gbias);
+        BH_LAUNCH_CHECK();
+    }
+    return BH_OK;
+}
+
 int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, const bh_conv_desc* d, void* stream) {
     if (!d || !x || !gy || !gw) return BH_E_BADARG;
     if (d->out_nchw && (d->Co > 4 || d->transposed)) return BH_E_UNSUPPORTED;
@@ -576,30 +604,7 @@ int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, cons
         else hipLaunchKernelGGL((wgrad_kernel<false>), grid, dim3(256), 0, s, a);
     }
     BH_LAUNCH_CHECK();
-    if (gbias) {
-        // bias gradient = column sums of gy over all output pixels
-        const int M = d->N * d->Ho * d->Wo, C = d->Co;
-        int blocks = (M + 1023) / 1024;
-        if (blocks > 1024) blocks = 1024;
-        int rpb = (M + blocks - 1) / blocks;
-        if (d->out_nchw) {
-            // planes: treat each (n, c) plane as a [hw][1] matrix
-            const int hwp = d->Ho * d->Wo;
-            for (int c = 0; c < C; ++c) {
-                hipLaunchKernelGGL(plane_sum_kernel, dim3(64), dim3(256), 0, s, gy, d->N, C, c, hwp, gbias + c);
-                BH_LAUNCH_CHECK();
-            }
-        } else if (C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0) {
-            const int rpp = 256 / (C / 4);
-            int nb = (M + rpp * 8 - 1) / (rpp * 8);
-            if (nb > 512) nb = 512;          // every workgroup ends with C same-address atomics (~28 ns each, serialised)
-            hipLaunchKernelGGL(colsum4_kernel, dim3(nb), dim3(256), 0, s, gy, M, C, gbias);
-            BH_LAUNCH_CHECK();
-        } else {
-            hipLaunchKernelGGL(colsum_kernel, dim3(blocks, (C + 63) / 64), dim3(256), 0, s, gy, M, C, rpb, gbias);
-            BH_LAUNCH_CHECK();
-        }
-    }
+    if (gbias) return bh_conv_bias_grad(gy, gbias, d, stream);
     return BH_OK;
 }
 

@@ -415,9 +415,14 @@ def conv_dgrad(gy, w, d, out=None, bn_reduce=None):
 
 
 def conv_wgrad(x, gy, gw, gbias, d):
+    """gw += x^T gy (split-K MFMA kernel, fp32 atomics); gbias += column sums of gy (separate launch, own timing entry so
+    that the wgrad entry is the kernel rocprofv3 lists under the same name)."""
     _chk(x); _chk(gy); _chk(gw); _chk(gbias)
-    with _Timed(_wgrad_variant(d) + ("+colsum" if gbias is not None else "") + (" N%d %dx%d C%d->%d k%d s%d%s" % (d.N, d.Hi, d.Wi, d.Ci, d.Co, d.kh, d.stride, " T" if d.transposed else "") if TIMING_DETAIL else ""), conv_flops(d), 4.0 * (x.numel() + gy.numel() + gw.numel())):
-        check(lib.bh_conv_wgrad(_p(x), _p(gy), _p(gw), _p(gbias), ctypes.byref(d), _stream()), "bh_conv_wgrad")
+    with _Timed(_wgrad_variant(d) + (" N%d %dx%d C%d->%d k%d s%d%s" % (d.N, d.Hi, d.Wi, d.Ci, d.Co, d.kh, d.stride, " T" if d.transposed else "") if TIMING_DETAIL else ""), conv_flops(d), 4.0 * (x.numel() + gy.numel() + gw.numel())):
+        check(lib.bh_conv_wgrad(_p(x), _p(gy), _p(gw), None, ctypes.byref(d), _stream()), "bh_conv_wgrad")
+    if gbias is not None:
+        with _Timed("bias_grad(colsum)", 0.0, 4.0 * gy.numel()):
+            check(lib.bh_conv_bias_grad(_p(gy), _p(gbias), ctypes.byref(d), _stream()), "bh_conv_bias_grad")
 
 
 BN_SUM_STRIDE = 16                                     # doubles between entries (one 128-byte line each; csrc/common.h)

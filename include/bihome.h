@@ -172,6 +172,8 @@ int bh_conv_dgrad_bnreduce(const float* gy, const float* w, float* gx, const bh_
 int bh_col2im_c1(const float* Tm, float* gx, const bh_conv_desc* d, int ldT, void* stream);
 /* gw += x^T * gy ; gbias += sum gy  (accumulated: caller zeroes; gbias NULL ok) */
 int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, const bh_conv_desc* d, void* stream);
+/* the bias part alone: gbias[Co] += sum of gy over all output pixels (what bh_conv_wgrad does when gbias != NULL) */
+int bh_conv_bias_grad(const float* gy, float* gbias, const bh_conv_desc* d, void* stream);
 
 /* Training-mode BatchNorm2d over `groups` independent sub-batches stacked along N (the reference
  * runs the backbone once per direction and the extractor once per patch, each call with its own
