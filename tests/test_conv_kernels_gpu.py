@@ -408,3 +408,30 @@ def test_conv_transpose_fwd_with_batchnorm_sums(K, N, H, Ci, Co, groups):
     yd = y0.double().reshape(groups, -1, Co)
     ref = torch.stack([yd.sum(1), (yd * yd).sum(1)], -1)
     close(sums.reshape(K.BN_SUM_SLOTS, groups, Co, 2, K.BN_SUM_STRIDE)[..., 0].sum(0).cpu(), ref.cpu(), 1e-6)
+
+
+def test_c_abi_error_codes(K):
+    """The C ABI reports misuse instead of computing something else: -1 = bad argument, -2 = unsupported geometry
+    (include/bihome.h); the Python binding turns both into BihomeLibError."""
+    import ctypes
+    from bihome_amd._lib import BihomeLibError, lib
+    x = torch.zeros(2, 8, 8, 32, device="cuda")
+    w = torch.zeros(32, 3, 3, 32, device="cuda")
+    d = K.conv_desc(2, 8, 8, 32, 32, 3, 1, 1)
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = ctypes.c_void_p
+    assert lib.bh_conv_fwd(None, P(w.data_ptr()), None, P(x.data_ptr()), ctypes.byref(d), s) == -1
+    assert lib.bh_conv_dgrad_s2(P(x.data_ptr()), P(w.data_ptr()), P(x.data_ptr()), ctypes.byref(d), 0, P(w.data_ptr()), s) == -2
+    bad = K.conv_desc(2, 8, 8, 32, 32, 3, 2, 1, transposed=True)          # ConvTranspose2d needs kernel == stride
+    y = torch.zeros(2, 16, 16, 32, device="cuda")
+    assert lib.bh_conv_wgrad(P(x.data_ptr()), P(y.data_ptr()), P(w.data_ptr()), None, ctypes.byref(bad), s) == -2
+    st = K.bn_stats_buffer(1, 6, "cuda")
+    z = torch.zeros(4, 6, device="cuda")
+    assert lib.bh_bn_fwd(P(z.data_ptr()), None, None, None, None, None, P(z.data_ptr()), P(st.data_ptr()), 1, 4, 6, 1e-5, 0.1, 0, 0, s) == -2
+    img = torch.zeros(1, 1, 24, 24, device="cuda")
+    H = torch.eye(3, dtype=torch.float64, device="cuda").reshape(1, 9)
+    assert lib.bh_warp_fwd(P(img.data_ptr()), P(H.data_ptr()), 1, 1, 24, 24, 4, P(img.data_ptr()), None, s) == -2
+    with pytest.raises(BihomeLibError, match="BH_E_UNSUPPORTED"):
+        K.warp_fwd(img, H)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        K.conv_fwd(x.cpu(), w, None, d)
