@@ -57,6 +57,8 @@ struct C3Args {
     double* bn_sums;       // optional [groups][Nn][2]: += per-channel (sum, sum of squares) of the output (forward only)
     int imgs_per_group, groups;
     int dbg_nch;           // ablation: number of channel chunks to run (-1 = all)
+    int stagger;           // 0 none; 1: workgroups with bit 8 of their launch index set start late; 2: odd ones
+    int stagger_sleeps;    // ... by this many s_sleep(127) (8128 cycles each)
 };
 
 constexpr int C3_HALO_BYTES = 8 * 200 * 16;          // 25600
@@ -150,6 +152,15 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
+    // Stagger: the two workgroups of a CU start together and stay in lockstep, so their memory phases (prologue loads,
+    // epilogue stores) coincide and the matrix pipe idles; delaying every second first-round workgroup by about one
+    // memory phase makes each of them compute alone (at twice the rate) while its neighbour loads / stores.
+    if (a.stagger) {
+        const unsigned lid = blockIdx.x + gridDim.x * blockIdx.y;
+        const bool late = a.stagger == 1 ? ((lid >> 8) & 1) && lid < 512 : (lid & 1) && lid < 512;
+        if (late)
+            for (int i = 0; i < a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     const int nch = a.dbg_nch >= 0 ? a.dbg_nch : a.Kc / 32;     // (ablation hook: bh_debug_force_tile(-8, n) caps the chunk loop)
     // lane-constant parts of the fragment addresses (bytes)
     const int a_lane = (kh2 * HPL + wm * 100 + (wh * 4 + (l31 >> 3)) * 10 + (l31 & 7)) * 16;
@@ -323,9 +334,11 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
     }
 }
 
-static int g_c3_disable = 0, g_c3_min_blocks = 256, g_c3_dbg_nch = -1, g_c3_subt = 2;
+static int g_c3_disable = 0, g_c3_min_blocks = 256, g_c3_dbg_nch = -1, g_c3_subt = 2, g_c3_stagger = -1, g_c3_stagger_sleeps = 1;
 void bh_conv3x3_tune(int disable, int min_blocks) {
     if (disable <= -100) { g_c3_dbg_nch = -100 - disable - 1; return; }
+    if (disable >= 19 && disable < 23) { g_c3_stagger = disable - 20; return; }            // stagger mode -1 (automatic) / 0 / 1 / 2
+    if (disable >= 30 && disable < 60) { g_c3_stagger_sleeps = disable - 30; return; }      // ... number of sleeps
     if (disable >= 11 && disable <= 13) { g_c3_subt = disable - 10; return; }      // 1 / 2 (automatic) / 3 (always two) sub-tiles per workgroup     // -100 -> -1 (all), -101 -> 0 chunks, -102 -> 1 ...
     g_c3_disable = disable;
     if (min_blocks > 0) g_c3_min_blocks = min_blocks;
@@ -384,6 +397,10 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
     }
     const kern_t fn = subt == 1 ? fns[8 + (d->precision == 1 ? 2 : 0) + (dgrad ? 1 : 0)]
                                 : fns[(d->precision == 1 ? 4 : 0) + (bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0)];
+    // start stagger (experiment hook, off: in a back-to-back micro-benchmark it takes 128x32x32x64 from 101 to 93 us, in the
+    // training step - where other kernels sit between these launches - it changes nothing; tools/conv3x3_stagger.py)
+    a.stagger = g_c3_stagger > 0 ? g_c3_stagger : 0;
+    a.stagger_sleeps = g_c3_stagger_sleeps;
     hipLaunchKernelGGL(fn, grid, dim3(256), subt == 1 ? LDS1 : C3_LDS_BYTES, stream, a);
     BH_LAUNCH_CHECK();
     *taken = 1;

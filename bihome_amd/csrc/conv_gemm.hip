@@ -851,6 +851,8 @@ int bh_debug_force_tile(int bm, int bn) {
     if (bm == -6) { bh_stem7_tune(bn); return BH_OK; }
     if (bm == -7) { g_wgrad_noflush = bn; return BH_OK; }
     if (bm == -10) { g_wgrad_xcd_map = bn; return BH_OK; }              // (-10, 0|1): XCD-aware wgrad work order off / on
+    if (bm == -12) { bh_conv3x3_tune(20 + bn, 0); return BH_OK; }      // (-12, 0|1|2): 3x3 kernel start stagger mode
+    if (bm == -13) { bh_conv3x3_tune(30 + bn, 0); return BH_OK; }      // (-13, n): ... delay in s_sleep(127) units
     if (bm == -9) { bh_conv3x3_tune(10 + bn, 0); return BH_OK; }     // (-9, 1|2): 3x3 kernel sub-tiles per workgroup (64-channel tile)
     if (bm == -8) { bh_conv3x3_tune(-101 - bn, 0); return BH_OK; }  // (-8, n): ablation - 3x3 kernel runs n channel chunks only (-1: all)   // (-7, 1): ablation - wgrad without its atomic flush      // (-6, 1): disable the dedicated 7x7 stem forward kernel
     g_force_bm = bm; g_force_bn = bn; return BH_OK;
