@@ -809,6 +809,7 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
                    int relu = 0, const bh_bn_reduce* bnr = nullptr);
 int bn_launch_stats(const float* x, int groups, int rows, int C, double* sums, hipStream_t s);
 void bh_stem7_tune(int disable);
+void bh_warp_tune(int which, int n);
 int bh_stem7_try(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, int relu,
                  hipStream_t stream, int* taken);
 
@@ -851,6 +852,8 @@ int bh_debug_force_tile(int bm, int bn) {
     if (bm == -6) { bh_stem7_tune(bn); return BH_OK; }
     if (bm == -7) { g_wgrad_noflush = bn; return BH_OK; }
     if (bm == -10) { g_wgrad_xcd_map = bn; return BH_OK; }              // (-10, 0|1): XCD-aware wgrad work order off / on
+    if (bm == -14) { bh_warp_tune(0, bn); return BH_OK; }               // (-14, 1|2): warp forward rows per thread
+    if (bm == -15) { bh_warp_tune(1, bn); return BH_OK; }               // (-15, 1|2|4): warp adjoint rows per thread
     if (bm == -12) { bh_conv3x3_tune(20 + bn, 0); return BH_OK; }      // (-12, 0|1|2): 3x3 kernel start stagger mode
     if (bm == -13) { bh_conv3x3_tune(30 + bn, 0); return BH_OK; }      // (-13, n): ... delay in s_sleep(127) units
     if (bm == -9) { bh_conv3x3_tune(10 + bn, 0); return BH_OK; }     // (-9, 1|2): 3x3 kernel sub-tiles per workgroup (64-channel tile)

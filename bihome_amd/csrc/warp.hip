@@ -146,112 +146,172 @@ __global__ void __launch_bounds__(256) warp_bwd_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// pool = 4 fast path (the shipped configuration: 128x128 patches, 32x32 features): four consecutive pixels of a row per
-// thread, so the output is one 16-byte store per lane, a thread's four pixels are exactly one pooling-window row (the
-// pooled coverage needs two shuffles over the wave's four rows), and the adjoint's nine double sums are reduced over a
-// quarter of the wavefronts.  Per-pixel arithmetic is the same as in the generic kernels (same results).
-// grid (w/64, h/16, B), block 256 = 16 (x quads) x 16 (rows); a wave = 16 quads x 4 rows.
+// pool = 4 fast path (the shipped configuration: 128x128 patches, 32x32 features).  At 64-128 images of 128x128 these
+// launches move ~17-25 MB and are bound by VALU issue, not by HBM (wave64 on 16-lane SIMDs: the generic kernels spend
+// ~95 / ~215 vector instructions per pixel), so this path is written for instruction count:
+//   * four consecutive pixels of a row per thread and RPT rows per thread: the output is one 16-byte store per lane,
+//     a thread's four pixels are one pooling-window row (the pooled coverage needs two shuffles over the wave's four
+//     rows), and the adjoint's nine double sums are reduced across the wave once per 4*RPT pixels;
+//   * taps clamped into the image with the validity folded into per-axis weights (w00 = wx0 * wy0, products with an
+//     exact 0 or 1 - same values as masking), unsigned 32-bit indexing, 1/qz as v_rcp_f32 + one Newton step;
+//   * adjoint: per row sum(a) and sum(a * x) are accumulated and multiplied by y once per row.
+// grid (w/64, h/(16*RPT), B), block 256 = 16 (x quads) x 16 (rows); a wave = 16 quads x 4 rows; row r of a thread is
+// y = (blockIdx.y * RPT + r) * 16 + ty.
 // ---------------------------------------------------------------------------------------------
+struct Hf { float h0, h1, h2, h3, h4, h5, h6, h7, h8; };
+__device__ __forceinline__ Hf load_h(const double* __restrict__ Hm) {
+    Hf f;
+    f.h0 = (float)Hm[0]; f.h1 = (float)Hm[1]; f.h2 = (float)Hm[2]; f.h3 = (float)Hm[3]; f.h4 = (float)Hm[4];
+    f.h5 = (float)Hm[5]; f.h6 = (float)Hm[6]; f.h7 = (float)Hm[7]; f.h8 = (float)Hm[8];
+    return f;
+}
+
+struct Tap4 {
+    float u, v, iz, fx, fy;
+    float wx0, wx1, wy0, wy1;      // per-axis bilinear weights, 0 where that tap column / row is outside the image
+    bool vx0, vx1, vy0, vy1, guard;
+    unsigned o00, o01, o10, o11;   // byte offsets of the taps inside one image plane; 0xFFFFFFFF (= out of range for the
+                                   // buffer load, which then returns 0) for a tap outside the image
+};
+
+__device__ __forceinline__ Tap4 make_tap4(const Hf& H, int x, int y, int w, int h) {
+    Tap4 t;
+    const float fxp = (float)x, fyp = (float)y;
+    const float qx = H.h0 * fxp + H.h1 * fyp + H.h2, qy = H.h3 * fxp + H.h4 * fyp + H.h5, qz = H.h6 * fxp + H.h7 * fyp + H.h8;
+    t.guard = !(fabsf(qz) > 1e-8f);
+    float r = __builtin_amdgcn_rcpf(qz);
+    r = __builtin_fmaf(__builtin_fmaf(-qz, r, 1.0f), r, r);     // one Newton step: within an ulp of 1/qz, exact for qz = 1
+    t.iz = t.guard ? 1.0f : r;
+    t.u = qx * t.iz;
+    t.v = qy * t.iz;
+    const float x0f = floorf(t.u), y0f = floorf(t.v);
+    t.fx = t.u - x0f;
+    t.fy = t.v - y0f;
+    // clamp in float first so that wild coordinates (inf / nan / huge) become plain out-of-bounds integers
+    const int x0 = (int)fminf(fmaxf(x0f, -2.0f), (float)w), y0 = (int)fminf(fmaxf(y0f, -2.0f), (float)h);
+    t.vx0 = (unsigned)x0 < (unsigned)w; t.vx1 = (unsigned)(x0 + 1) < (unsigned)w;
+    t.vy0 = (unsigned)y0 < (unsigned)h; t.vy1 = (unsigned)(y0 + 1) < (unsigned)h;
+    t.wx0 = t.vx0 ? 1.0f - t.fx : 0.0f; t.wx1 = t.vx1 ? t.fx : 0.0f;
+    t.wy0 = t.vy0 ? 1.0f - t.fy : 0.0f; t.wy1 = t.vy1 ? t.fy : 0.0f;
+    const int w4 = 4 * w;
+    const int o = y0 * w4 + 4 * x0;
+    t.o00 = (t.vx0 && t.vy0) ? (unsigned)o : 0xFFFFFFFFu;
+    t.o01 = (t.vx1 && t.vy0) ? (unsigned)(o + 4) : 0xFFFFFFFFu;
+    t.o10 = (t.vx0 && t.vy1) ? (unsigned)(o + w4) : 0xFFFFFFFFu;
+    t.o11 = (t.vx1 && t.vy1) ? (unsigned)(o + w4 + 4) : 0xFFFFFFFFu;
+    return t;
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const float* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float ldtap(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+}
+
+template <int RPT>
 __global__ void __launch_bounds__(256) warp_fwd4_kernel(const float* __restrict__ img, const double* __restrict__ H64, int C,
                                                         int h, int w, float* __restrict__ out, float* __restrict__ cov) {
     const int b = blockIdx.z;
     const int tq = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int xq = blockIdx.x * 64 + tq * 4, y = blockIdx.y * 16 + ty;
-    // branch-free taps: every tap index is clamped into the image and an out-of-bounds tap gets weight 0, so the sixteen
-    // gathers of a thread issue back to back instead of sitting behind per-tap branches
-    int i00[4], i01[4], i10[4], i11[4];
-    float w00[4], w01[4], w10[4], w11[4];
-    float cv = 0.0f;
+    const int xq = blockIdx.x * 64 + tq * 4;
+    const Hf H = load_h(H64 + (size_t)b * 9);
+    const unsigned plane = (unsigned)h * (unsigned)w;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float u, v, iz;
-        bool guard;
-        project(H64 + (size_t)b * 9, xq + i, y, u, v, iz, guard);
-        const Tap t = make_tap(u, v, w, h);
-        const int x0 = (int)fminf(fmaxf(t.x0f, -2.0f), (float)w), y0 = (int)fminf(fmaxf(t.y0f, -2.0f), (float)h);
-        const int xa = min(max(x0, 0), w - 1), xb = min(max(x0 + 1, 0), w - 1);
-        const int ya = min(max(y0, 0), h - 1), yb = min(max(y0 + 1, 0), h - 1);
-        i00[i] = ya * w + xa; i01[i] = ya * w + xb; i10[i] = yb * w + xa; i11[i] = yb * w + xb;
-        w00[i] = (t.vx0 && t.vy0) ? (1 - t.fx) * (1 - t.fy) : 0.0f;
-        w01[i] = (t.vx1 && t.vy0) ? t.fx * (1 - t.fy) : 0.0f;
-        w10[i] = (t.vx0 && t.vy1) ? (1 - t.fx) * t.fy : 0.0f;
-        w11[i] = (t.vx1 && t.vy1) ? t.fx * t.fy : 0.0f;
-        cv += w00[i] + w01[i] + w10[i] + w11[i];
-    }
-    if (img) {
-        for (int c = 0; c < C; ++c) {
-            const float* p = img + ((size_t)b * C + c) * h * w;
-            float o[4];
+    for (int r = 0; r < RPT; ++r) {
+        const int y = (blockIdx.y * RPT + r) * 16 + ty;
+        unsigned o00[4], o01[4], o10[4], o11[4];
+        float w00[4], w01[4], w10[4], w11[4];
+        float cv = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float p00 = p[i00[i]], p01 = p[i01[i]], p10 = p[i10[i]], p11 = p[i11[i]];
-                float acc = 0.0f;
-                acc += p00 * w00[i];
-                acc += p01 * w01[i];
-                acc += p10 * w10[i];
-                acc += p11 * w11[i];
-                o[i] = acc;
-            }
-            *reinterpret_cast<float4*>(out + ((size_t)b * C + c) * h * w + (size_t)y * w + xq) = make_float4(o[0], o[1], o[2], o[3]);
+        for (int i = 0; i < 4; ++i) {
+            const Tap4 t = make_tap4(H, xq + i, y, w, h);
+            o00[i] = t.o00; o01[i] = t.o01; o10[i] = t.o10; o11[i] = t.o11;
+            w00[i] = t.wx0 * t.wy0; w01[i] = t.wx1 * t.wy0; w10[i] = t.wx0 * t.wy1; w11[i] = t.wx1 * t.wy1;
+            cv += w00[i] + w01[i] + w10[i] + w11[i];
         }
-    }
-    if (cov) {
-        cv += __shfl_xor(cv, 16, 64);                 // the four rows of the wave (lane = (ty & 3) * 16 + tq)
-        cv += __shfl_xor(cv, 32, 64);
-        if ((ty & 3) == 0) cov[(size_t)b * (h / 4) * (w / 4) + (size_t)(y / 4) * (w / 4) + xq / 4] = cv * (1.0f / 16.0f);
+        if (img) {
+            for (int c = 0; c < C; ++c) {
+                const __amdgpu_buffer_rsrc_t rs = plane_rsrc(img + ((size_t)b * C + c) * plane, plane * 4u);
+                float o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float p00 = ldtap(rs, o00[i]), p01 = ldtap(rs, o01[i]), p10 = ldtap(rs, o10[i]), p11 = ldtap(rs, o11[i]);
+                    float acc = p00 * w00[i];
+                    acc += p01 * w01[i];
+                    acc += p10 * w10[i];
+                    acc += p11 * w11[i];
+                    o[i] = acc;
+                }
+                *reinterpret_cast<float4*>(out + ((size_t)b * C + c) * plane + (unsigned)y * (unsigned)w + xq) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        if (cov) {
+            cv += __shfl_xor(cv, 16, 64);                 // the four rows of the wave (lane = (ty & 3) * 16 + tq)
+            cv += __shfl_xor(cv, 32, 64);
+            if ((ty & 3) == 0) cov[(size_t)b * (h / 4) * (w / 4) + (size_t)(y / 4) * (w / 4) + xq / 4] = cv * (1.0f / 16.0f);
+        }
     }
 }
 
+template <int RPT>
 __global__ void __launch_bounds__(256) warp_bwd4_kernel(const float* __restrict__ img, const double* __restrict__ H64,
                                                         const float* __restrict__ g_out, const float* __restrict__ g_cov, int C,
                                                         int h, int w, double* __restrict__ gH) {
     __shared__ double part[4][9];
     const int b = blockIdx.z;
     const int tq = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int xq = blockIdx.x * 64 + tq * 4, y = blockIdx.y * 16 + ty;
-    const float gc = g_cov ? g_cov[(size_t)b * (h / 4) * (w / 4) + (size_t)(y / 4) * (w / 4) + xq / 4] * (1.0f / 16.0f) : 0.0f;
+    const int xq = blockIdx.x * 64 + tq * 4;
+    const Hf H = load_h(H64 + (size_t)b * 9);
+    const unsigned plane = (unsigned)h * (unsigned)w;
+    const bool have_img = img && g_out;
     double s[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) s[k] = 0.0;
-    float4 go4[4];                                     // up to 4 channels cached (C = 1 or 3 here); more are re-read
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-        go4[c] = (img && g_out && c < C) ? *reinterpret_cast<const float4*>(g_out + ((size_t)b * C + c) * h * w + (size_t)y * w + xq)
-                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < RPT; ++r) {
+        const int y = (blockIdx.y * RPT + r) * 16 + ty;
+        const unsigned pix = (unsigned)y * (unsigned)w + xq;
+        const float gc = g_cov ? g_cov[(size_t)b * (h / 4) * (w / 4) + (size_t)(y / 4) * (w / 4) + xq / 4] * (1.0f / 16.0f) : 0.0f;
+        float gu[4], gv[4];
+        Tap4 t[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int x = xq + i;
-        float u, v, iz;
-        bool guard;
-        project(H64 + (size_t)b * 9, x, y, u, v, iz, guard);
-        const Tap t = make_tap(u, v, w, h);
-        const int x0 = (int)fminf(fmaxf(t.x0f, -2.0f), (float)w), y0 = (int)fminf(fmaxf(t.y0f, -2.0f), (float)h);
-        const bool v00 = t.vx0 && t.vy0, v01 = t.vx1 && t.vy0, v10 = t.vx0 && t.vy1, v11 = t.vx1 && t.vy1;
-        const int xa = min(max(x0, 0), w - 1), xb = min(max(x0 + 1, 0), w - 1);       // clamped: loads are unconditional
-        const int ya = min(max(y0, 0), h - 1), yb = min(max(y0 + 1, 0), h - 1);
-        float gu = 0.0f, gv = 0.0f;
-        if (img && g_out) {
+        for (int i = 0; i < 4; ++i) {
+            t[i] = make_tap4(H, xq + i, y, w, h);
+            // coverage part: d/du of sum(valid taps' weights) = (vx1 - vx0) * (wy0 + wy1), same for v
+            const float sy = t[i].wy0 + t[i].wy1, sx = t[i].wx0 + t[i].wx1;
+            gu[i] = gc * ((t[i].vx1 ? sy : 0.0f) - (t[i].vx0 ? sy : 0.0f));
+            gv[i] = gc * ((t[i].vy1 ? sx : 0.0f) - (t[i].vy0 ? sx : 0.0f));
+        }
+        if (have_img) {
             for (int c = 0; c < C; ++c) {
-                const float* p = img + ((size_t)b * C + c) * h * w;
-                float go;
-                if (c < 4) { const float4 q = go4[c]; go = i == 0 ? q.x : (i == 1 ? q.y : (i == 2 ? q.z : q.w)); }
-                else go = g_out[((size_t)b * C + c) * h * w + (size_t)y * w + x];
-                const float q00 = p[ya * w + xa], q01 = p[ya * w + xb], q10 = p[yb * w + xa], q11 = p[yb * w + xb];
-                const float p00 = v00 ? q00 : 0.0f, p01 = v01 ? q01 : 0.0f, p10 = v10 ? q10 : 0.0f, p11 = v11 ? q11 : 0.0f;
-                gu += go * ((p01 - p00) * (1 - t.fy) + (p11 - p10) * t.fy);
-                gv += go * ((p10 - p00) * (1 - t.fx) + (p11 - p01) * t.fx);
+                const __amdgpu_buffer_rsrc_t rs = plane_rsrc(img + ((size_t)b * C + c) * plane, plane * 4u);
+                const float4 go4 = *reinterpret_cast<const float4*>(g_out + ((size_t)b * C + c) * plane + pix);
+                const float go[4] = {go4.x, go4.y, go4.z, go4.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    // taps outside the image load 0: they contribute nothing (grid_sampler_2d_backward)
+                    const float p00 = ldtap(rs, t[i].o00), p01 = ldtap(rs, t[i].o01), p10 = ldtap(rs, t[i].o10), p11 = ldtap(rs, t[i].o11);
+                    // d(bilinear)/du = sum_taps val * d(weight)/du; the per-axis weights are 0 on rows / columns outside
+                    gu[i] += go[i] * ((p01 - p00) * t[i].wy0 + (p11 - p10) * t[i].wy1);
+                    gv[i] += go[i] * ((p10 - p00) * t[i].wx0 + (p11 - p01) * t[i].wx1);
+                }
             }
         }
-        if (g_cov) {
-            const float o00 = v00 ? 1.0f : 0.0f, o01 = v01 ? 1.0f : 0.0f, o10 = v10 ? 1.0f : 0.0f, o11 = v11 ? 1.0f : 0.0f;
-            gu += gc * ((o01 - o00) * (1 - t.fy) + (o11 - o10) * t.fy);
-            gv += gc * ((o10 - o00) * (1 - t.fx) + (o11 - o01) * t.fx);
+        // u = qx*iz, v = qy*iz, iz = 1/qz (or 1 under the guard): per row  A = sum a, Ax = sum a*x  for a in (gu*iz, gv*iz, gz);
+        // the per-pixel products are float (like u, v and the weights), the sums double
+        double au = 0, aux = 0, av = 0, avx = 0, az = 0, azx = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double fx = (double)(xq + i);
+            const float a = gu[i] * t[i].iz, bq = gv[i] * t[i].iz;
+            const float gz = t[i].guard ? 0.0f : -(gu[i] * t[i].u + gv[i] * t[i].v) * t[i].iz;
+            au += (double)a; aux += (double)a * fx; av += (double)bq; avx += (double)bq * fx; az += (double)gz; azx += (double)gz * fx;
         }
-        const double fx = (double)x, fy = (double)y, dgu = (double)gu, dgv = (double)gv, diz = (double)iz;
-        s[0] += dgu * diz * fx; s[1] += dgu * diz * fy; s[2] += dgu * diz;
-        s[3] += dgv * diz * fx; s[4] += dgv * diz * fy; s[5] += dgv * diz;
-        const double gz = guard ? 0.0 : -(dgu * (double)u + dgv * (double)v) * diz;
-        s[6] += gz * fx; s[7] += gz * fy; s[8] += gz;
+        const double fy = (double)y;
+        s[0] += aux; s[1] += au * fy; s[2] += au;
+        s[3] += avx; s[4] += av * fy; s[5] += av;
+        s[6] += azx; s[7] += az * fy; s[8] += az;
     }
 #pragma unroll
     for (int k = 0; k < 9; ++k) s[k] = wave_sum(s[k]);
@@ -263,6 +323,13 @@ __global__ void __launch_bounds__(256) warp_bwd4_kernel(const float* __restrict_
         atomicAdd(gH + (size_t)b * 9 + threadIdx.x, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
+// rows per thread of the pool = 4 kernels (tuning hook: bh_debug_force_tile(-14 / -15, n))
+static int g_warp_rpt_fwd = 1, g_warp_rpt_bwd = 2;       // measured (tools/hbm_path_bench.py): fwd 11.6 / 12.0 us, adjoint 14.7 / 13.4 / 15.4 us
+void bh_warp_tune(int which, int n) {
+    if (which == 0) g_warp_rpt_fwd = n;
+    else g_warp_rpt_bwd = n;
+}
+
 extern "C" {
 
 int bh_warp_fwd(const float* img, const double* H64, int B, int C, int h, int w, int pool, float* out, float* cov,
@@ -271,7 +338,9 @@ int bh_warp_fwd(const float* img, const double* H64, int B, int C, int h, int w,
     if ((h % 16) || (w % 16) || (pool != 1 && pool != 2 && pool != 4 && pool != 8 && pool != 16)) return BH_E_UNSUPPORTED;
     if (B == 0) return BH_OK;
     if (pool == 4 && (w % 64) == 0) {
-        hipLaunchKernelGGL(warp_fwd4_kernel, dim3(w / 64, h / 16, B), dim3(256), 0, bh_stream(stream), img, H64, C, h, w, out, cov);
+        const int rpt = (g_warp_rpt_fwd == 2 && h % 32 == 0) ? 2 : 1;
+        if (rpt == 2) hipLaunchKernelGGL(warp_fwd4_kernel<2>, dim3(w / 64, h / 32, B), dim3(256), 0, bh_stream(stream), img, H64, C, h, w, out, cov);
+        else hipLaunchKernelGGL(warp_fwd4_kernel<1>, dim3(w / 64, h / 16, B), dim3(256), 0, bh_stream(stream), img, H64, C, h, w, out, cov);
         BH_LAUNCH_CHECK();
         return BH_OK;
     }
@@ -287,8 +356,13 @@ int bh_warp_bwd(const float* img, const double* H64, const float* g_out, const f
     if ((h % 16) || (w % 16) || (pool != 1 && pool != 2 && pool != 4 && pool != 8 && pool != 16)) return BH_E_UNSUPPORTED;
     if (B == 0) return BH_OK;
     if (pool == 4 && (w % 64) == 0) {
-        hipLaunchKernelGGL(warp_bwd4_kernel, dim3(w / 64, h / 16, B), dim3(256), 0, bh_stream(stream), img, H64, g_out, g_cov, C,
-                           h, w, gH);
+        int rpt = g_warp_rpt_bwd;
+        while (rpt > 1 && h % (16 * rpt)) rpt >>= 1;
+        const dim3 grid(w / 64, h / (16 * rpt), B);
+        hipStream_t s = bh_stream(stream);
+        if (rpt >= 4) hipLaunchKernelGGL(warp_bwd4_kernel<4>, grid, dim3(256), 0, s, img, H64, g_out, g_cov, C, h, w, gH);
+        else if (rpt == 2) hipLaunchKernelGGL(warp_bwd4_kernel<2>, grid, dim3(256), 0, s, img, H64, g_out, g_cov, C, h, w, gH);
+        else hipLaunchKernelGGL(warp_bwd4_kernel<1>, grid, dim3(256), 0, s, img, H64, g_out, g_cov, C, h, w, gH);
         BH_LAUNCH_CHECK();
         return BH_OK;
     }
