@@ -115,10 +115,15 @@ __device__ static Hartley hartley_stats(const double* px, const double* py, int 
 #define DLT_MAXPTS 8   // points per lane: P <= 512
 
 // Jacobi eigen-decomposition of the symmetric 9x9 matrix in LDS A (destroyed); V gets eigenvectors in columns.
+// Parallel (round-robin) ordering: round r of a sweep rotates the four disjoint pairs {(r+k) mod 9, (r-k) mod 9},
+// k = 1..4 (index r sits out; every pair {a, b} occurs once per sweep, in the round with 2r = a+b mod 9), so a sweep is
+// 9 dependent steps instead of 36.  The rotations of a round commute (disjoint index pairs): first A J and V J
+// (lane = (row, pair), columns p and q), then J^T (A J) (lane = (column, pair), rows p and q).
 __device__ static void jacobi9(double* A, double* V, int lane) {
     if (lane < 9)
         for (int j = 0; j < 9; ++j) V[lane * 9 + j] = (lane == j) ? 1.0 : 0.0;
     __syncthreads();
+    const int k = lane >> 2, pr = lane & 3;       // lanes 0..35: row / column k, pair pr
     for (int sweep = 0; sweep < 16; ++sweep) {
         // convergence: off-diagonal mass vs diagonal mass
         double off = 0, dia = 0;
@@ -126,34 +131,34 @@ __device__ static void jacobi9(double* A, double* V, int lane) {
             for (int j = 0; j < 9; ++j) { double v = A[lane * 9 + j]; if (j == lane) dia += v * v; else off += v * v; }
         off = wave_sum(off); dia = wave_sum(dia);
         if (off <= 1e-30 * dia || off == 0.0) break;      // off-diagonal Frobenius mass below 1e-15 of the diagonal: converged in double
-        for (int p = 0; p < 8; ++p)
-            for (int q = p + 1; q < 9; ++q) {
-                double apq = A[p * 9 + q];
-                double app = A[p * 9 + p], aqq = A[q * 9 + q];
-                __syncthreads();
-                if (fabs(apq) > 1e-300) {
-                    double theta = (aqq - app) / (2.0 * apq);
-                    double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                    double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                    // columns p,q of A and V (lane = row k)
-                    if (lane < 9) {
-                        double akp = A[lane * 9 + p], akq = A[lane * 9 + q];
-                        A[lane * 9 + p] = c * akp - s * akq;
-                        A[lane * 9 + q] = s * akp + c * akq;
-                        double vkp = V[lane * 9 + p], vkq = V[lane * 9 + q];
-                        V[lane * 9 + p] = c * vkp - s * vkq;
-                        V[lane * 9 + q] = s * vkp + c * vkq;
-                    }
-                    __syncthreads();
-                    // rows p,q of A (lane = column k)
-                    if (lane < 9) {
-                        double apk = A[p * 9 + lane], aqk = A[q * 9 + lane];
-                        A[p * 9 + lane] = c * apk - s * aqk;
-                        A[q * 9 + lane] = s * apk + c * aqk;
-                    }
-                    __syncthreads();
-                }
+        for (int r = 0; r < 9; ++r) {
+            int ia = r + pr + 1, ib = r + 8 - pr;
+            ia = ia >= 9 ? ia - 9 : ia; ib = ib >= 9 ? ib - 9 : ib;
+            const int p = min(ia, ib), q = max(ia, ib);
+            const double apq = A[p * 9 + q], app = A[p * 9 + p], aqq = A[q * 9 + q];
+            double c = 1.0, s = 0.0;
+            if (fabs(apq) > 1e-300) {
+                const double theta = (aqq - app) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                c = 1.0 / sqrt(t * t + 1.0); s = t * c;
             }
+            __syncthreads();                      // every lane has read its pair's entries
+            if (k < 9) {
+                const double akp = A[k * 9 + p], akq = A[k * 9 + q];
+                A[k * 9 + p] = c * akp - s * akq;
+                A[k * 9 + q] = s * akp + c * akq;
+                const double vkp = V[k * 9 + p], vkq = V[k * 9 + q];
+                V[k * 9 + p] = c * vkp - s * vkq;
+                V[k * 9 + q] = s * vkp + c * vkq;
+            }
+            __syncthreads();
+            if (k < 9) {
+                const double apk = A[p * 9 + k], aqk = A[q * 9 + k];
+                A[p * 9 + k] = c * apk - s * aqk;
+                A[q * 9 + k] = s * apk + c * aqk;
+            }
+            __syncthreads();
+        }
     }
     __syncthreads();
 }
