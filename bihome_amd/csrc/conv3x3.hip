@@ -30,6 +30,9 @@ __device__ __forceinline__ bf16x8 c3_pack_bf16(const float4& lo, const float4& h
     return __builtin_convertvector(v, bf16x8);
 }
 
+// pixel row (0..7) of the 8x4 strip held by lane quad q = l31 >> 2: 0 1 3 2 5 4 6 7 (see a_lane in the kernel)
+__device__ __forceinline__ int c3_strip_row(int q) { return q ^ (((q >> 1) ^ (q >> 2)) & 1); }
+
 struct C3Args {
     const float* Src;
     const float* Wt;
@@ -59,6 +62,7 @@ struct C3Args {
     int dbg_nch;           // ablation: number of channel chunks to run (-1 = all)
     int stagger;           // 0 none; 1: workgroups with bit 8 of their launch index set start late; 2: odd ones
     int stagger_sleeps;    // ... by this many s_sleep(127) (8128 cycles each)
+    int dbg_noload;        // ablation bits: 1 no weight-slab DMA in the loop, 2 no halo DMA in the loop (wrong results, timing only)
 };
 
 constexpr int C3_HALO_BYTES = 8 * 200 * 16;          // 25600
@@ -87,7 +91,7 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
     const int l31 = lane & 31, kh2 = lane >> 5;
     const int wm = SUBT == 1 ? 0 : (BN == 64 ? (wave & 1) : (wave >> 1));    // sub-tile of this wave
     const int wn = BN == 64 ? (wave >> 1) : 0;
-    const int wh = (BN == 64 && SUBT == 2) ? 0 : (wave & 1);   // 32-row waves: upper / lower four pixel rows of the sub-tile
+    const int wh = (BN == 64 && SUBT == 2) ? 0 : (wave & 1);   // 32-row waves: left / right 8x4 strip of the sub-tile
     const int n0 = blockIdx.y * BN;
     constexpr unsigned OOB = 0xFFFFFFF0u;
     __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Src), 0, a.src_bytes, 0x00020000);
@@ -163,7 +167,13 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
     }
     const int nch = a.dbg_nch >= 0 ? a.dbg_nch : a.Kc / 32;     // (ablation hook: bh_debug_force_tile(-8, n) caps the chunk loop)
     // lane-constant parts of the fragment addresses (bytes)
-    const int a_lane = (kh2 * HPL + wm * 100 + (wh * 4 + (l31 >> 3)) * 10 + (l31 & 7)) * 16;
+    // GEMM row l31 of a wave's 32-row fragment <-> pixel (c3_strip_row(l31 >> 2), 4 * strip + (l31 & 3)) of the 8x8 sub-tile:
+    // an 8-row x 4-column strip, strip = wh for the 32-row waves, = the fragment index i for the 64-row waves.
+    // ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32), 64 banks of 4 B: with this
+    // order the first group reads the even rows of the strip (halo slots 0-3, 20-23, 40-43, 60-63 = all sixteen 16-byte
+    // slots of a 256-byte bank row), the second the odd rows - conflict-free for every tap shift; the row-major 4x8
+    // block used before was 3-way conflicted (13.8 vs 8.2 LDS cycles per read, tools/lds_pattern_bench.hip).
+    const int a_lane = (kh2 * HPL + wm * 100 + c3_strip_row(l31 >> 2) * 10 + wh * 4 + (l31 & 3)) * 16;
     const int b_lane = FLIP ? (kh2 * 4 * BN + wn * 32 + l31) * 4 : (kh2 * BN + wn * 32 + l31) * 16;
 
 #pragma unroll
@@ -188,7 +198,7 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[i][q] = *reinterpret_cast<const float4*>(ap + q * (2 * HPL * 16) + i * 640);
+                for (int i = 0; i < TM; ++i) af[i][q] = *reinterpret_cast<const float4*>(ap + q * (2 * HPL * 16) + i * 64);
                 if (!FLIP) b[q] = *reinterpret_cast<const float4*>(bp + q * (2 * BN * 16));
                 else {
                     b[q].x = *reinterpret_cast<const float*>(bp + (q * 8 + 0) * (BN * 4));
@@ -197,9 +207,11 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
                     b[q].w = *reinterpret_cast<const float*>(bp + (q * 8 + 3) * (BN * 4));
                 }
             }
-            if (tap < 8) issue_B(c, tap + 1, bs ^ 1);
-            else if (more) issue_B(c + 1, 0, bs ^ 1);
-            if (tap < HJ && more) C3_ISSUE_HALO(tap, c + 1, hs ^ 1);
+            if (!(a.dbg_noload & 1)) {
+                if (tap < 8) issue_B(c, tap + 1, bs ^ 1);
+                else if (more) issue_B(c + 1, 0, bs ^ 1);
+            }
+            if (tap < HJ && more && !(a.dbg_noload & 2)) C3_ISSUE_HALO(tap, c + 1, hs ^ 1);
             if constexpr (BF16) {
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
@@ -260,8 +272,7 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = (i + wh) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh2;
-                const int y = ty * 8 + (m >> 3), x = tx * 8 + (m & 7);
+                const int y = ty * 8 + c3_strip_row(2 * (r >> 2) + kh2), x = tx * 8 + (i + wh) * 4 + (r & 3);
                 offs[i][r] = (unsigned)((img * a.H + y) * a.W + x) * (unsigned)a.Nn + (unsigned)n;
             }
         const bool rd_old = a.accumulate, rd_res = a.res != nullptr, rd_z = a.bnr_z != nullptr;
@@ -334,9 +345,11 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
     }
 }
 
+static int g_c3_noload = 0;
 static int g_c3_disable = 0, g_c3_min_blocks = 256, g_c3_dbg_nch = -1, g_c3_subt = 2, g_c3_stagger = -1, g_c3_stagger_sleeps = 1;
 void bh_conv3x3_tune(int disable, int min_blocks) {
     if (disable <= -100) { g_c3_dbg_nch = -100 - disable - 1; return; }
+    if (disable >= 60 && disable < 64) { g_c3_noload = disable - 60; return; }
     if (disable >= 19 && disable < 23) { g_c3_stagger = disable - 20; return; }            // stagger mode -1 (automatic) / 0 / 1 / 2
     if (disable >= 30 && disable < 60) { g_c3_stagger_sleeps = disable - 30; return; }      // ... number of sleeps
     if (disable >= 11 && disable <= 13) { g_c3_subt = disable - 10; return; }      // 1 / 2 (automatic) / 3 (always two) sub-tiles per workgroup     // -100 -> -1 (all), -101 -> 0 chunks, -102 -> 1 ...
@@ -401,6 +414,7 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
     // training step - where other kernels sit between these launches - it changes nothing; tools/conv3x3_stagger.py)
     a.stagger = g_c3_stagger > 0 ? g_c3_stagger : 0;
     a.stagger_sleeps = g_c3_stagger_sleeps;
+    a.dbg_noload = g_c3_noload;
     hipLaunchKernelGGL(fn, grid, dim3(256), subt == 1 ? LDS1 : C3_LDS_BYTES, stream, a);
     BH_LAUNCH_CHECK();
     *taken = 1;

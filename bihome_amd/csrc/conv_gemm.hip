@@ -852,6 +852,7 @@ int bh_debug_force_tile(int bm, int bn) {
     if (bm == -6) { bh_stem7_tune(bn); return BH_OK; }
     if (bm == -7) { g_wgrad_noflush = bn; return BH_OK; }
     if (bm == -10) { g_wgrad_xcd_map = bn; return BH_OK; }              // (-10, 0|1): XCD-aware wgrad work order off / on
+    if (bm == -18) { bh_conv3x3_tune(60 + bn, 0); return BH_OK; }       // (-18, bits): 3x3 kernel ablation - 1 no weight DMA, 2 no halo DMA in the loop
     if (bm == -14) { bh_warp_tune(0, bn); return BH_OK; }               // (-14, 1|2): warp forward rows per thread
     if (bm == -15) { bh_warp_tune(1, bn); return BH_OK; }               // (-15, 1|2|4): warp adjoint rows per thread
     if (bm == -12) { bh_conv3x3_tune(20 + bn, 0); return BH_OK; }      // (-12, 0|1|2): 3x3 kernel start stagger mode
