@@ -205,6 +205,82 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
     }
 }
 
+// Stride-1 "same" convolutions on NHWC fp32 operands with power-of-two Wo and Ho*Wo, M % 32 == 0, Np % 64 == 0,
+// Nq % 64 == 0 (every 3x3 layer of the backbones from 64 channels up): same tiling and split-K as wgrad_kernel, written
+// for VALU instruction count.  On gfx950 a VALU instruction does NOT issue under a running MFMA of another wave - each one
+// costs ~3.3 cycles of a 64-cycle v_mfma_f32_32x32x2_f32 slot (tools/mfma_coexec_bench.hip; SQ_VALU_MFMA_COEXEC_CYCLES is 0)
+// - and the generic loader spends ~100 of them per 16 MFMAs on pixel decoding and bounds.  Here the gathered operand of
+// tap (dy, dx) is the plain operand shifted by dy*Wo + dx pixels (the shift is folded into the buffer base), the
+// advancing pixel index lives in the scalar offset of the buffer load, and a tap is valid iff t = m mod Ho*Wo and
+// x = t mod Wo lie in workgroup-uniform windows: 8 VALU per gathered row, none for the plain rows.
+__global__ void __launch_bounds__(256) wgrad_s1_kernel(WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[WBK * WLD];
+    __shared__ __attribute__((aligned(16))) float Bs[WBK * WLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int qtiles = a.Nq >> 6;
+    const int p0 = (blockIdx.x / qtiles) * 64, q0 = (blockIdx.x % qtiles) * 64;
+    const int t = blockIdx.y;
+    const int mbeg = blockIdx.z * a.rows_per_block;
+    const int mend = min(a.M, mbeg + a.rows_per_block);          // a multiple of 32, like mbeg
+    if (mbeg >= mend) return;
+    const int chunk0 = tid & 15, prow0 = tid >> 4;               // 16 float4 chunks x 16 pixel rows per pass, 2 passes
+    const int tky = t / a.kw, dy = tky - a.pad, dx = t - tky * a.kw - a.pad;
+    const int hw = a.Ho * a.Wo;
+    // validity windows: (unsigned)(t - lo_t) < n_t  and  (unsigned)(x - lo_x) < n_x
+    const unsigned lo_t = dy < 0 ? (unsigned)(-dy * a.Wo) : 0u, n_t = (unsigned)(hw - (dy < 0 ? -dy : dy) * a.Wo);
+    const unsigned lo_x = dx < 0 ? (unsigned)(-dx) : 0u, n_x = (unsigned)(a.Wo - (dx < 0 ? -dx : dx));
+    const long long shift = (long long)(dy * a.Wo + dx) * a.Cq;  // elements
+    const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.P), 0, a.p_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Q + shift), 0, 0x80000000u, 0x00020000);
+    unsigned vP[2], vQ[2];
+    int rowi[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        rowi[i] = prow0 + 16 * i;
+        vP[i] = ((unsigned)rowi[i] * (unsigned)a.Np + (unsigned)(p0 + chunk0 * 4)) * 4u;
+        vQ[i] = ((unsigned)rowi[i] * (unsigned)a.Cq + (unsigned)(q0 + chunk0 * 4)) * 4u;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    float4 rp[2], rq[2];
+    auto load_tile = [&](int mk) {
+        const unsigned sP = (unsigned)mk * (unsigned)a.Np * 4u, sQ = (unsigned)mk * (unsigned)a.Cq * 4u;     // scalar
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned tt = (unsigned)(mk + rowi[i]) & (unsigned)(hw - 1);
+            const unsigned xx = tt & (unsigned)(a.Wo - 1);
+            const bool ok = (tt - lo_t) < n_t && (xx - lo_x) < n_x;
+            rp[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsP, vP[i], sP, 0));
+            rq[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsQ, ok ? vQ[i] : 0xFFFFFFF0u, sQ, 0));
+        }
+    };
+    const int kh2 = lane >> 5, l31 = lane & 31;
+    float* const wa = &As[prow0 * WLD + chunk0 * 4];
+    float* const wb = &Bs[prow0 * WLD + chunk0 * 4];
+    const float* const ra = &As[kh2 * WLD + wm * 32 + l31];
+    const float* const rb = &Bs[kh2 * WLD + wn * 32 + l31];
+    load_tile(mbeg);
+    for (int mk = mbeg; mk < mend; mk += WBK) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<float4*>(wa + i * 16 * WLD) = rp[i];
+            *reinterpret_cast<float4*>(wb + i * 16 * WLD) = rq[i];
+        }
+        __syncthreads();
+        if (mk + WBK < mend) load_tile(mk + WBK);
+#pragma unroll
+        for (int kk = 0; kk < WBK / 2; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[2 * kk * WLD], rb[2 * kk * WLD], acc, 0, 0, 0);
+        __syncthreads();
+    }
+    if (a.noflush) return;
+    float* const o = a.Out + (long long)(p0 + wm * 32 + 4 * kh2) * a.sOp + (long long)t * a.sOt + q0 + wn * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) atomicAdd(o + (long long)((r & 3) + 8 * (r >> 2)) * a.sOp, acc[r]);
+}
+
 // Small-channel variant (min(Np, Nq) <= 32: the 16/32-channel decoder layers at 64x64 / 128x128, where K = pixels
 // is huge and a 64x64 tile would be 3/4 padding): 32x32 tile per WAVE, the four waves of a workgroup split the
 // workgroup's pixel range four ways and never synchronise (wave-private LDS), each adds its partial with atomics.
@@ -495,7 +571,8 @@ __global__ void __launch_bounds__(256) plane_sum_kernel(const float* __restrict_
     if (threadIdx.x == 0) atomicAdd(out, sm[0] + sm[1] + sm[2] + sm[3]);
 }
 
-int g_wgrad_noflush = 0, g_wgrad_xcd_map = 0;   // (XCD-aware order: measured 7-18 % slower)
+int g_wgrad_noflush = 0, g_wgrad_xcd_map = 0, g_wgrad_s1 = 1;          // stride-1 fast path on / off (bh_debug_force_tile(-16, n))   // (XCD-aware order: measured 7-18 % slower)
+int g_wgrad_s1_target = 2048;  // split-K work items per launch of the stride-1 kernel (bh_debug_force_tile(-17, n))
 int g_wgrad_target = 4096;      // split-K work items per launch (tuning hook: bh_debug_force_tile(-3, n))
 
 extern "C" {
@@ -598,6 +675,14 @@ int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, cons
     } else if (small) {
         if (vec) hipLaunchKernelGGL((wgrad_small_kernel<true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((wgrad_small_kernel<false>), grid, dim3(256), 0, s, a);
+    } else if (g_wgrad_s1 && vec && a.use_buf && d->precision == 0 && !d->transposed && d->stride == 1 && d->Ho == d->Hi &&
+               d->Wo == d->Wi && a.hwshift >= 0 && a.M % WBK == 0 && a.Np % 64 == 0 && a.Nq % 64 == 0 && !a.xcd_map) {
+        int sp = g_wgrad_s1_target / (tiles * ty);        // round DOWN: at most `target` workgroups (8 fit on a CU: 2048 = one full round)
+        if (sp > maxsplit) sp = maxsplit;
+        if (sp < 1) sp = 1;
+        a.rows_per_block = (((a.M + sp - 1) / sp) + WBK - 1) / WBK * WBK;
+        sp = (a.M + a.rows_per_block - 1) / a.rows_per_block;
+        hipLaunchKernelGGL(wgrad_s1_kernel, dim3(tiles, ty, sp), dim3(256), 0, s, a);
     } else {
         if (vec && d->precision == 1) hipLaunchKernelGGL((wgrad_kernel<true, true>), grid, dim3(256), 0, s, a);
         else if (vec) hipLaunchKernelGGL((wgrad_kernel<true>), grid, dim3(256), 0, s, a);
