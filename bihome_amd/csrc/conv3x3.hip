@@ -42,7 +42,8 @@ struct C3Args {
     int Kc, Nn;            // contraction channels (= source channels), output channels
     int Cw;                // innermost dim of the weight tensor [Co][9][Cw]
     int accumulate;
-    unsigned src_bytes, w_bytes;
+    unsigned src_bytes, w_bytes, out_bytes;
+    int tx_shift, tpi_shift;   // log2(tiles_x), log2(tiles_per_img) when both are powers of two, else -1
     int tiles_x, tiles_per_img, subtiles;
     const float* res;      // optional residual (same layout as Out) and ReLU applied in the epilogue (inference path)
     int relu;
@@ -87,7 +88,7 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
     constexpr int HJ = (HINS + 3) / 4;                     // ... per wave (7 / 4)
     constexpr int BINS = BN == 64 ? 2 : 1;                 // weight-slab wave instructions per wave and step
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: LDS-DMA bases stay in SGPRs)
     const int l31 = lane & 31, kh2 = lane >> 5;
     const int wm = SUBT == 1 ? 0 : (BN == 64 ? (wave & 1) : (wave >> 1));    // sub-tile of this wave
     const int wn = BN == 64 ? (wave >> 1) : 0;
@@ -97,23 +98,35 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
     __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Src), 0, a.src_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wt), 0, a.w_bytes, 0x00020000);
 
-    // ---- halo slots of this lane: slot q = (j*4 + wave)*64 + lane of the [8][2][100] image ----
+    // ---- halo slots of this lane: slot q = (j*4 + wave)*64 + lane of the [8][SUBT][100] image ----
+    // (written for instruction count - VALU work does not overlap the other workgroup's MFMAs: the per-sub-tile origin
+    //  is computed once, with shifts when the tile grid is a power of two, and the slot -> (plane, sub-tile, hy, hx)
+    //  decoding uses small-range multiply-shift divisions)
+    int org[SUBT];                                   // pixel index of halo position (0, 0) of each sub-tile, or INT_MIN
+    int oy0[SUBT], ox0[SUBT];
+#pragma unroll
+    for (int s = 0; s < SUBT; ++s) {
+        const int g = blockIdx.x * SUBT + s;
+        int img, ty, tx;
+        if (a.tpi_shift >= 0) { img = g >> a.tpi_shift; const int t = g & (a.tiles_per_img - 1); ty = t >> a.tx_shift; tx = t & (a.tiles_x - 1); }
+        else { img = g / a.tiles_per_img; const int t = g - img * a.tiles_per_img; ty = t / a.tiles_x; tx = t - ty * a.tiles_x; }
+        oy0[s] = ty * 8 - 1; ox0[s] = tx * 8 - 1;
+        org[s] = g < a.subtiles ? (img * a.H + oy0[s]) * a.W + ox0[s] : (int)0x80000000;
+    }
     unsigned hoff[7] = {OOB, OOB, OOB, OOB, OOB, OOB, OOB};   // (fixed size, first HJ used: see the note at boff)
 #pragma unroll
     for (int j = 0; j < HJ; ++j) {
-        const int ci = j * 4 + wave, q = ci * 64 + lane;
+        const int ci = j * 4 + wave, q = ci * 64 + lane;     // q < 1664
         unsigned off = OOB;
         if (ci < HINS && q < 8 * HPL) {
-            const int plane = q / HPL, rem = q - plane * HPL, s = rem / 100, hp = rem - s * 100;
-            const int hy = hp / 10, hx = hp - hy * 10;
-            const int g = blockIdx.x * SUBT + s;
-            if (g < a.subtiles) {
-                const int img = g / a.tiles_per_img, t = g - img * a.tiles_per_img;
-                const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
-                const int y = ty * 8 + hy - 1, x = tx * 8 + hx - 1;
-                if ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
-                    off = ((unsigned)((img * a.H + y) * a.W + x) * (unsigned)a.Kc + (unsigned)(plane * 4)) * 4u;
-            }
+            const int plane = SUBT == 2 ? (q * 5243) >> 20 : (q * 10486) >> 20;      // q / 200, q / 100 for q < 1700
+            const int rem = q - plane * HPL;
+            const int s = SUBT == 2 ? (rem >= 100 ? 1 : 0) : 0, hp = rem - s * 100;
+            const int hy = (hp * 205) >> 11, hx = hp - hy * 10;                        // hp / 10 for hp < 100
+            const int y = (s ? oy0[SUBT - 1] : oy0[0]) + hy, x = (s ? ox0[SUBT - 1] : ox0[0]) + hx;
+            const int o = s ? org[SUBT - 1] : org[0];
+            if (o != (int)0x80000000 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
+                off = ((unsigned)(o + hy * a.W + hx) * (unsigned)a.Kc + (unsigned)(plane * 4)) * 4u;
         }
         hoff[j] = off;
     }
@@ -243,12 +256,16 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
 #undef issue_B
 
     // ---- epilogue: C/D layout col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m) ----
+    // Element (i, r) of a lane is pixel (c3_strip_row(2*(r>>2) + kh2), 4*(i + wh) + (r&3)) of the sub-tile: the row part of
+    // its address is one of four per-lane VGPRs, the column part (4*(i + wh) + (r&3)) * Nn is workgroup-uniform and rides in
+    // the scalar offset of the buffer instruction - no per-element address arithmetic.
     const int g = blockIdx.x * SUBT + wm;
     const int n = n0 + wn * 32 + l31;
     const bool valid = g < a.subtiles && n < a.Nn;
     const int gg = g < a.subtiles ? g : 0;
-    const int img = gg / a.tiles_per_img, t = gg - img * a.tiles_per_img;
-    const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    int img, ty, tx;
+    if (a.tpi_shift >= 0) { img = gg >> a.tpi_shift; const int t = gg & (a.tiles_per_img - 1); ty = t >> a.tx_shift; tx = t & (a.tiles_x - 1); }
+    else { img = gg / a.tiles_per_img; const int t = gg - img * a.tiles_per_img; ty = t / a.tiles_x; tx = t - ty * a.tiles_x; }
     const float bv = (a.bias && n < a.Nn) ? a.bias[n] : 0.0f;
     double s1 = 0.0, s2 = 0.0;                     // BatchNorm statistics of the tile (a.bn_sums): sum y, sum y^2
     float r_mean = 0.f, r_invstd = 0.f, r_sc = 0.f, r_sh = 0.f;
@@ -264,49 +281,72 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
         r_sh = (a.bnr_beta ? a.bnr_beta[n] : 0.f) - r_mean * r_sc;
     }
     if (valid) {
-        // phase 1: every global read of the epilogue (old gradient, residual, BatchNorm input / output) is issued before
-        // the first store - a load behind a store would otherwise wait for that store (one vmcnt queue, in order)
-        unsigned offs[TM][16];                       // element offsets (< 2^29: the host checks the tensor sizes)
-        float old[TM][16], zin[TM][16], yin[TM][16];
+        unsigned rowoff[4];                          // byte offsets (< 2^31: the host checks the tensor sizes)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int rq = 0; rq < 4; ++rq)
+            rowoff[rq] = ((unsigned)((img * a.H + ty * 8 + c3_strip_row(2 * rq + kh2)) * a.W + tx * 8) * (unsigned)a.Nn + (unsigned)n) * 4u;
+        const unsigned colstep = (unsigned)a.Nn * 4u;                                   // one pixel to the right
+        const unsigned col0 = (unsigned)(wh * 4) * colstep;
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(a.Out, 0, a.out_bytes, 0x00020000);
+#define C3_SOFF(i, r) (col0 + (unsigned)((i) * 4 + ((r) & 3)) * colstep)
+        if (!a.accumulate && !a.res && !a.bnr_z) {
+            // plain store (+ bias, ReLU) and the forward statistics: partial sums of a fragment quad in float, totals in double
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int y = ty * 8 + c3_strip_row(2 * (r >> 2) + kh2), x = tx * 8 + (i + wh) * 4 + (r & 3);
-                offs[i][r] = (unsigned)((img * a.H + y) * a.W + x) * (unsigned)a.Nn + (unsigned)n;
-            }
-        const bool rd_old = a.accumulate, rd_res = a.res != nullptr, rd_z = a.bnr_z != nullptr;
-        const bool rd_y = rd_z && a.bnr_relu && a.bnr_y != nullptr;
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+                for (int rq = 0; rq < 4; ++rq) {
+                    float q1 = 0.f, q2 = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float o = rd_old ? a.Out[offs[i][r]] : 0.f;
-                if (rd_res) o += a.res[offs[i][r]];
-                old[i][r] = o;
-                zin[i][r] = rd_z ? a.bnr_z[offs[i][r]] : 0.f;
-                yin[i][r] = rd_y ? a.bnr_y[offs[i][r]] : 0.f;
-            }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[i][r] + bv + old[i][r];
-                if (a.relu) v = fmaxf(v, 0.0f);
-                a.Out[offs[i][r]] = v;
-                if (rd_z) {
-                    const float zv = zin[i][r];
-                    if (a.bnr_relu) {
-                        const float yv = rd_y ? yin[i][r] : zv * r_sc + r_sh;
-                        if (!(yv > 0.f)) v = 0.f;
+                    for (int c = 0; c < 4; ++c) {
+                        float v = acc[i][rq * 4 + c] + bv;
+                        if (a.relu) v = fmaxf(v, 0.0f);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsO, rowoff[rq], C3_SOFF(i, c), 0);
+                        q1 += v; q2 = __builtin_fmaf(v, v, q2);
                     }
-                    s1 += (double)v;
-                    s2 += (double)(v * ((zv - r_mean) * r_invstd));
-                } else {
-                    s1 += (double)v;
-                    s2 += (double)v * (double)v;
+                    s1 += (double)q1; s2 += (double)q2;
                 }
-            }
+        } else {
+            // phase 1: every global read of the epilogue (old gradient, residual, BatchNorm input / output) is issued before
+            // the first store - a load behind a store would otherwise wait for that store (one vmcnt queue, in order)
+            float old[TM][16], zin[TM][16], yin[TM][16];
+            const bool rd_old = a.accumulate, rd_res = a.res != nullptr, rd_z = a.bnr_z != nullptr;
+            const bool rd_y = rd_z && a.bnr_relu && a.bnr_y != nullptr;
+            const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rd_res ? a.res : a.Out), 0, a.out_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rd_z ? a.bnr_z : a.Out), 0, a.out_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rd_y ? a.bnr_y : a.Out), 0, a.out_bytes, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned vo = rowoff[r >> 2], so = C3_SOFF(i, r);
+                    old[i][r] = 0.f; zin[i][r] = 0.f; yin[i][r] = 0.f;
+                    if (rd_old) old[i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsO, vo, so, 0));
+                    if (rd_res) old[i][r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, vo, so, 0));
+                    if (rd_z) zin[i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsZ, vo, so, 0));
+                    if (rd_y) yin[i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsY, vo, so, 0));
+                }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][r] + bv + old[i][r];
+                    if (a.relu) v = fmaxf(v, 0.0f);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsO, rowoff[r >> 2], C3_SOFF(i, r), 0);
+                    if (rd_z) {
+                        const float zv = zin[i][r];
+                        if (a.bnr_relu) {
+                            const float yv = rd_y ? yin[i][r] : zv * r_sc + r_sh;
+                            if (!(yv > 0.f)) v = 0.f;
+                        }
+                        s1 += (double)v;
+                        s2 += (double)(v * ((zv - r_mean) * r_invstd));
+                    } else {
+                        s1 += (double)v;
+                        s2 += (double)v * (double)v;
+                    }
+                }
+        }
+#undef C3_SOFF
     }
     if (a.bn_sums) {
         // column sums: the two half-waves hold the two row halves of a column; the waves that share the channel range
@@ -375,7 +415,7 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
     C3Args a = {};
     a.Src = src; a.Wt = w; a.bias = bias; a.Out = out;
     a.N = d->N; a.H = d->Hi; a.W = d->Wi; a.Kc = Kc; a.Nn = Nn; a.Cw = d->Ci; a.accumulate = accumulate;
-    a.src_bytes = (unsigned)src_bytes; a.w_bytes = (unsigned)w_bytes;
+    a.src_bytes = (unsigned)src_bytes; a.w_bytes = (unsigned)w_bytes; a.out_bytes = (unsigned)out_bytes;
     if (bn_sums && ((dgrad != 0) != (bnr != nullptr) || groups < 1 || d->N % groups)) return BH_E_BADARG;
     if (bnr) {
         if (!bnr->z || !bnr->stats) return BH_E_BADARG;
@@ -385,6 +425,12 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
     a.res = res; a.relu = relu; a.dbg_nch = g_c3_dbg_nch;
     a.bn_sums = bn_sums; a.imgs_per_group = bn_sums ? d->N / groups : 1; a.groups = groups;
     a.tiles_x = d->Wi / 8; a.tiles_per_img = (d->Hi / 8) * a.tiles_x; a.subtiles = d->N * a.tiles_per_img;
+    a.tx_shift = a.tpi_shift = -1;
+    for (int b = 0; b < 24; ++b) {
+        if (a.tiles_x == (1 << b)) a.tx_shift = b;
+        if (a.tiles_per_img == (1 << b)) a.tpi_shift = b;
+    }
+    if (a.tx_shift < 0 || a.tpi_shift < 0) a.tx_shift = a.tpi_shift = -1;
     // one sub-tile per workgroup where two would leave half of the 512 workgroup slots empty (the 8x8x256-channel layers:
     // +6 %); elsewhere the 128-row tile is as fast or faster (measured, tools/conv3x3_check.py --subt1)
     const bool few = (long long)((a.subtiles + 1) / 2) * (Nn / bn_tile) <= 256;
