@@ -18,6 +18,7 @@
 // Double-buffered: the weight slab of step t+1 and (one wave instruction per tap step) the halo of the next
 // chunk are in flight while the 32 MFMAs per wave of step t run; one barrier per step.
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x8v __attribute__((ext_vector_type(8)));
@@ -306,45 +307,78 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
                     s1 += (double)q1; s2 += (double)q2;
                 }
         } else {
-            // phase 1: every global read of the epilogue (old gradient, residual, BatchNorm input / output) is issued before
-            // the first store - a load behind a store would otherwise wait for that store (one vmcnt queue, in order)
-            float old[TM][16], zin[TM][16], yin[TM][16];
+            // Generic epilogue, instantiated per combination of (old gradient / residual present, BatchNorm reduce with or
+            // without a saved output) so that no variant carries the loads, zero fills and selects of the others.
+            // Phase 1 issues every global read (old gradient, residual, BatchNorm input / output) before the first store -
+            // a load behind a store would otherwise wait for that store (one vmcnt queue, in order).
             const bool rd_old = a.accumulate, rd_res = a.res != nullptr, rd_z = a.bnr_z != nullptr;
             const bool rd_y = rd_z && a.bnr_relu && a.bnr_y != nullptr;
-            const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rd_res ? a.res : a.Out), 0, a.out_bytes, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rd_z ? a.bnr_z : a.Out), 0, a.out_bytes, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rd_y ? a.bnr_y : a.Out), 0, a.out_bytes, 0x00020000);
+            const float c_x0 = -r_mean * r_invstd;                     // xhat = z * invstd + c_x0
+            auto body = [&](auto EXTRA, auto ZMODE) {                  // ZMODE 0: forward statistics, 1: reduce (mask from z), 2: reduce (mask from y)
+                constexpr bool HAS_EXTRA = decltype(EXTRA)::value;
+                constexpr int ZM = decltype(ZMODE)::value;
+                float ext[HAS_EXTRA ? TM : 1][16], zin[ZM > 0 ? TM : 1][16], yin[ZM == 2 ? TM : 1][16];
+                if constexpr (HAS_EXTRA) {
+                    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rd_res ? a.res : a.Out), 0, a.out_bytes, 0x00020000);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const unsigned vo = rowoff[r >> 2], so = C3_SOFF(i, r);
-                    old[i][r] = 0.f; zin[i][r] = 0.f; yin[i][r] = 0.f;
-                    if (rd_old) old[i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsO, vo, so, 0));
-                    if (rd_res) old[i][r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, vo, so, 0));
-                    if (rd_z) zin[i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsZ, vo, so, 0));
-                    if (rd_y) yin[i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsY, vo, so, 0));
-                }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[i][r] + bv + old[i][r];
-                    if (a.relu) v = fmaxf(v, 0.0f);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsO, rowoff[r >> 2], C3_SOFF(i, r), 0);
-                    if (rd_z) {
-                        const float zv = zin[i][r];
-                        if (a.bnr_relu) {
-                            const float yv = rd_y ? yin[i][r] : zv * r_sc + r_sh;
-                            if (!(yv > 0.f)) v = 0.f;
+                        for (int r = 0; r < 16; ++r) {
+                            float o = 0.f;
+                            if (rd_old) o = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsO, rowoff[r >> 2], C3_SOFF(i, r), 0));
+                            if (rd_res) o += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, rowoff[r >> 2], C3_SOFF(i, r), 0));
+                            ext[i][r] = o;
                         }
-                        s1 += (double)v;
-                        s2 += (double)(v * ((zv - r_mean) * r_invstd));
-                    } else {
-                        s1 += (double)v;
-                        s2 += (double)v * (double)v;
-                    }
                 }
+                if constexpr (ZM > 0) {
+                    const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bnr_z), 0, a.out_bytes, 0x00020000);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            zin[i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsZ, rowoff[r >> 2], C3_SOFF(i, r), 0));
+                }
+                if constexpr (ZM == 2) {
+                    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bnr_y), 0, a.out_bytes, 0x00020000);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            yin[i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsY, rowoff[r >> 2], C3_SOFF(i, r), 0));
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        float q1 = 0.f, q2 = 0.f;                          // partial sums of a fragment quad in float, totals in double
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const int r = rq * 4 + c;
+                            float v = acc[i][r] + bv;
+                            if constexpr (HAS_EXTRA) v += ext[i][r];
+                            if (a.relu) v = fmaxf(v, 0.0f);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsO, rowoff[rq], C3_SOFF(i, r), 0);
+                            if constexpr (ZM > 0) {
+                                const float zv = zin[i][r];
+                                if (a.bnr_relu) {
+                                    const float yv = ZM == 2 ? yin[i][r] : __builtin_fmaf(zv, r_sc, r_sh);
+                                    if (!(yv > 0.f)) v = 0.f;
+                                }
+                                q1 += v; q2 = __builtin_fmaf(v, __builtin_fmaf(zv, r_invstd, c_x0), q2);
+                            } else {
+                                q1 += v; q2 = __builtin_fmaf(v, v, q2);
+                            }
+                        }
+                        s1 += (double)q1; s2 += (double)q2;
+                    }
+            };
+            using T_ = std::true_type; using F_ = std::false_type;
+            using Z0 = std::integral_constant<int, 0>; using Z1 = std::integral_constant<int, 1>; using Z2 = std::integral_constant<int, 2>;
+            if (rd_old || rd_res) {
+                if (!rd_z) body(T_{}, Z0{}); else if (!rd_y) body(T_{}, Z1{}); else body(T_{}, Z2{});
+            } else {
+                if (!rd_z) body(F_{}, Z0{}); else if (!rd_y) body(F_{}, Z1{}); else body(F_{}, Z2{});
+            }
         }
 #undef C3_SOFF
     }
