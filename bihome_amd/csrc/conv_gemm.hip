@@ -114,11 +114,18 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
         int m = m0 + a_row0 + i * AROWS;
         a_ok[i] = m < a.M;
         int mm = a_ok[i] ? m : 0;
-        int hw = a.Ho * a.Wo;
-        a_n[i] = mm / hw;
-        int r = mm - a_n[i] * hw;
-        a_oy[i] = r / a.Wo;
-        a_ox[i] = r - a_oy[i] * a.Wo;
+        if (a.ehwshift >= 0) {                     // power-of-two output grid: shifts (an integer division is ~35 VALU
+            a_n[i] = mm >> a.ehwshift;             //  instructions, and VALU work does not overlap other waves' MFMAs)
+            const int r = mm & ((1 << a.ehwshift) - 1);
+            a_oy[i] = r >> a.ewshift;
+            a_ox[i] = r & ((1 << a.ewshift) - 1);
+        } else {
+            int hw = a.Ho * a.Wo;
+            a_n[i] = mm / hw;
+            int r = mm - a_n[i] * hw;
+            a_oy[i] = r / a.Wo;
+            a_ox[i] = r - a_oy[i] * a.Wo;
+        }
     }
     // ---- B rows ----
     const int bk_chunk = tid % CH, bk_row0 = tid / CH;                    // K-contiguous orientation
