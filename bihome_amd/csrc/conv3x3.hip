@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
     do {                                                                                                                \
         const unsigned soff_ = FLIP ? (unsigned)(((c) * 32 * 9 + (8 - (tap))) * a.Cw) * 4u                             \
                                     : (unsigned)((tap) * a.Cw + (c) * 32) * 4u;                                        \
-        char* base_ = smem + 2 * HALO_B + (bs) * C3_B_BYTES + wave * 1024;                                              \
+        char* base_ = smem + slab0 + (bs) * C3_B_BYTES + wave * 1024;                                              \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_ptr)(base_), 16, boff[0], soff_, 0, 0);                 \
         if (BINS == 2)                                                                                                  \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_ptr)(base_ + 4096), 16, boff[1], soff_, 0, 0); \
@@ -180,6 +180,9 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
             for (int i = 0; i < a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
     }
     const int nch = a.dbg_nch >= 0 ? a.dbg_nch : a.Kc / 32;     // (ablation hook: bh_debug_force_tile(-8, n) caps the chunk loop)
+    // a single chunk (32 source channels) never touches the second halo stage: the host then launches with one stage less
+    // of LDS (41.6 instead of 67.2 KB: three workgroups per CU for the 32-channel layers) and the slabs move down
+    const int slab0 = (a.Kc / 32 > 1 ? 2 : 1) * HALO_B;
     // lane-constant parts of the fragment addresses (bytes)
     // GEMM row l31 of a wave's 32-row fragment <-> pixel (c3_strip_row(l31 >> 2), 4 * strip + (l31 & 3)) of the 8x8 sub-tile:
     // an 8-row x 4-column strip, strip = wh for the 32-row waves, = the fragment index i for the 64-row waves.
@@ -207,7 +210,7 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
             // outstanding LDS-DMA with a full vmcnt(0), so the prefetch is issued only after them
             const int dy = tap / 3, dx = tap - dy * 3;
             const char* ap = hbase + (dy * 10 + dx) * 16;
-            const char* bp = smem + 2 * HALO_B + bs * C3_B_BYTES + b_lane;
+            const char* bp = smem + slab0 + bs * C3_B_BYTES + b_lane;
             float4 af[TM][4], b[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -495,7 +498,8 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
     a.stagger = g_c3_stagger > 0 ? g_c3_stagger : 0;
     a.stagger_sleeps = g_c3_stagger_sleeps;
     a.dbg_noload = g_c3_noload;
-    hipLaunchKernelGGL(fn, grid, dim3(256), subt == 1 ? LDS1 : C3_LDS_BYTES, stream, a);
+    const int lds = (subt == 1 ? LDS1 : C3_LDS_BYTES) - (Kc / 32 > 1 ? 0 : 8 * 100 * subt * 16);      // single chunk: one halo stage
+    hipLaunchKernelGGL(fn, grid, dim3(256), lds, stream, a);
     BH_LAUNCH_CHECK();
     *taken = 1;
     return BH_OK;
