@@ -630,7 +630,7 @@ static int launch(const GemmArgs& a, hipStream_t s) {
 
 // Tile choice: the largest tile that still gives the 256 CUs about two workgroups each; the small-spatial
 // layers (8x8x256ch, 16x16x128ch at 2B = 128) otherwise launch only 128-256 workgroups.
-extern int g_wgrad_target, g_wgrad_noflush, g_wgrad_xcd_map, g_wgrad_s1, g_wgrad_s1_target;
+extern int g_wgrad_target, g_wgrad_noflush, g_wgrad_xcd_map, g_wgrad_s1, g_wgrad_s1_target, g_wgrad_s3_target;
 static int g_force_bm = 0, g_force_bn = 0, g_prio = 0, g_no_buf = 0;     // tuning hook (bh_debug_force_tile), 0 = automatic
 
 static int dispatch(const GemmArgs& a_in, hipStream_t s) {
@@ -859,7 +859,8 @@ int bh_debug_force_tile(int bm, int bn) {
     if (bm == -6) { bh_stem7_tune(bn); return BH_OK; }
     if (bm == -7) { g_wgrad_noflush = bn; return BH_OK; }
     if (bm == -10) { g_wgrad_xcd_map = bn; return BH_OK; }              // (-10, 0|1): XCD-aware wgrad work order off / on
-    if (bm == -16) { g_wgrad_s1 = bn; return BH_OK; }                    // (-16, 0|1): stride-1 wgrad fast path off / on
+    if (bm == -16) { g_wgrad_s1 = bn; return BH_OK; }                    // (-16, 0|1|3): stride-1 wgrad fast path off / one tap / three taps per workgroup
+    if (bm == -19) { g_wgrad_s3_target = bn; return BH_OK; }             // (-19, n): workgroups per launch of the three-tap wgrad variant
     if (bm == -17) { g_wgrad_s1_target = bn; return BH_OK; }             // (-17, n): its split-K work items per launch
     if (bm == -18) { bh_conv3x3_tune(60 + bn, 0); return BH_OK; }       // (-18, bits): 3x3 kernel ablation - 1 no weight DMA, 2 no halo DMA in the loop
     if (bm == -14) { bh_warp_tune(0, bn); return BH_OK; }               // (-14, 1|2): warp forward rows per thread

@@ -213,26 +213,36 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
 // tap (dy, dx) is the plain operand shifted by dy*Wo + dx pixels (the shift is folded into the buffer base), the
 // advancing pixel index lives in the scalar offset of the buffer load, and a tap is valid iff t = m mod Ho*Wo and
 // x = t mod Wo lie in workgroup-uniform windows: 8 VALU per gathered row, none for the plain rows.
+// NT = taps per workgroup: 1, or 3 (kw = 3: the three taps of a kernel row share the plain operand tile - one gy load and
+// one A fragment read feed three MFMAs, a barrier every 48 MFMAs per wave instead of every 16, a third less L2 traffic).
+template <int NT>
 __global__ void __launch_bounds__(256) wgrad_s1_kernel(WgradArgs a) {
     __shared__ __attribute__((aligned(16))) float As[WBK * WLD];
-    __shared__ __attribute__((aligned(16))) float Bs[WBK * WLD];
+    __shared__ __attribute__((aligned(16))) float Bs[NT][WBK * WLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int qtiles = a.Nq >> 6;
     const int p0 = (blockIdx.x / qtiles) * 64, q0 = (blockIdx.x % qtiles) * 64;
-    const int t = blockIdx.y;
+    const int t0 = blockIdx.y * NT;                              // first tap of this workgroup
     const int mbeg = blockIdx.z * a.rows_per_block;
     const int mend = min(a.M, mbeg + a.rows_per_block);          // a multiple of 32, like mbeg
     if (mbeg >= mend) return;
     const int chunk0 = tid & 15, prow0 = tid >> 4;               // 16 float4 chunks x 16 pixel rows per pass, 2 passes
-    const int tky = t / a.kw, dy = tky - a.pad, dx = t - tky * a.kw - a.pad;
+    const int tky = t0 / a.kw, dy = tky - a.pad, dx0 = t0 - tky * a.kw - a.pad;       // taps (dy, dx0 + j), j < NT
     const int hw = a.Ho * a.Wo;
-    // validity windows: (unsigned)(t - lo_t) < n_t  and  (unsigned)(x - lo_x) < n_x
+    // validity windows: (unsigned)(t - lo_t) < n_t  and  (unsigned)(x - lo_x[j]) < n_x[j]
     const unsigned lo_t = dy < 0 ? (unsigned)(-dy * a.Wo) : 0u, n_t = (unsigned)(hw - (dy < 0 ? -dy : dy) * a.Wo);
-    const unsigned lo_x = dx < 0 ? (unsigned)(-dx) : 0u, n_x = (unsigned)(a.Wo - (dx < 0 ? -dx : dx));
-    const long long shift = (long long)(dy * a.Wo + dx) * a.Cq;  // elements
+    unsigned lo_x[NT], n_x[NT];
+    __amdgpu_buffer_rsrc_t rsQ[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int dx = dx0 + j;
+        lo_x[j] = dx < 0 ? (unsigned)(-dx) : 0u;
+        n_x[j] = (unsigned)(a.Wo - (dx < 0 ? -dx : dx));
+        const long long shift = (long long)(dy * a.Wo + dx) * a.Cq;      // elements: the tap shift is folded into the base
+        rsQ[j] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Q + shift), 0, 0x80000000u, 0x00020000);
+    }
     const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.P), 0, a.p_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Q + shift), 0, 0x80000000u, 0x00020000);
     unsigned vP[2], vQ[2];
     int rowi[2];
 #pragma unroll
@@ -241,44 +251,56 @@ __global__ void __launch_bounds__(256) wgrad_s1_kernel(WgradArgs a) {
         vP[i] = ((unsigned)rowi[i] * (unsigned)a.Np + (unsigned)(p0 + chunk0 * 4)) * 4u;
         vQ[i] = ((unsigned)rowi[i] * (unsigned)a.Cq + (unsigned)(q0 + chunk0 * 4)) * 4u;
     }
-    f32x16 acc;
+    f32x16 acc[NT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    float4 rp[2], rq[2];
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    float4 rp[2], rq[NT][2];
     auto load_tile = [&](int mk) {
         const unsigned sP = (unsigned)mk * (unsigned)a.Np * 4u, sQ = (unsigned)mk * (unsigned)a.Cq * 4u;     // scalar
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const unsigned tt = (unsigned)(mk + rowi[i]) & (unsigned)(hw - 1);
             const unsigned xx = tt & (unsigned)(a.Wo - 1);
-            const bool ok = (tt - lo_t) < n_t && (xx - lo_x) < n_x;
+            const bool okt = (tt - lo_t) < n_t;
             rp[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsP, vP[i], sP, 0));
-            rq[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsQ, ok ? vQ[i] : 0xFFFFFFF0u, sQ, 0));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const bool ok = okt && (xx - lo_x[j]) < n_x[j];
+                rq[j][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsQ[j], ok ? vQ[i] : 0xFFFFFFF0u, sQ, 0));
+            }
         }
     };
     const int kh2 = lane >> 5, l31 = lane & 31;
-    float* const wa = &As[prow0 * WLD + chunk0 * 4];
-    float* const wb = &Bs[prow0 * WLD + chunk0 * 4];
+    const int woff = prow0 * WLD + chunk0 * 4;
     const float* const ra = &As[kh2 * WLD + wm * 32 + l31];
-    const float* const rb = &Bs[kh2 * WLD + wn * 32 + l31];
+    const int roff = kh2 * WLD + wn * 32 + l31;
     load_tile(mbeg);
     for (int mk = mbeg; mk < mend; mk += WBK) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<float4*>(wa + i * 16 * WLD) = rp[i];
-            *reinterpret_cast<float4*>(wb + i * 16 * WLD) = rq[i];
+            *reinterpret_cast<float4*>(&As[woff + i * 16 * WLD]) = rp[i];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) *reinterpret_cast<float4*>(&Bs[j][woff + i * 16 * WLD]) = rq[j][i];
         }
         __syncthreads();
         if (mk + WBK < mend) load_tile(mk + WBK);
 #pragma unroll
-        for (int kk = 0; kk < WBK / 2; ++kk)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[2 * kk * WLD], rb[2 * kk * WLD], acc, 0, 0, 0);
+        for (int kk = 0; kk < WBK / 2; ++kk) {
+            const float av = ra[2 * kk * WLD];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Bs[j][roff + 2 * kk * WLD], acc[j], 0, 0, 0);
+        }
         __syncthreads();
     }
     if (a.noflush) return;
-    float* const o = a.Out + (long long)(p0 + wm * 32 + 4 * kh2) * a.sOp + (long long)t * a.sOt + q0 + wn * 32 + l31;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) atomicAdd(o + (long long)((r & 3) + 8 * (r >> 2)) * a.sOp, acc[r]);
+    for (int j = 0; j < NT; ++j) {
+        float* const o = a.Out + (long long)(p0 + wm * 32 + 4 * kh2) * a.sOp + (long long)(t0 + j) * a.sOt + q0 + wn * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) atomicAdd(o + (long long)((r & 3) + 8 * (r >> 2)) * a.sOp, acc[j][r]);
+    }
 }
 
 // Small-channel variant (min(Np, Nq) <= 32: the 16/32-channel decoder layers at 64x64 / 128x128, where K = pixels
@@ -571,7 +593,9 @@ __global__ void __launch_bounds__(256) plane_sum_kernel(const float* __restrict_
     if (threadIdx.x == 0) atomicAdd(out, sm[0] + sm[1] + sm[2] + sm[3]);
 }
 
-int g_wgrad_noflush = 0, g_wgrad_xcd_map = 0, g_wgrad_s1 = 1;          // stride-1 fast path on / off (bh_debug_force_tile(-16, n))   // (XCD-aware order: measured 7-18 % slower)
+int g_wgrad_noflush = 0, g_wgrad_xcd_map = 0, g_wgrad_s1 = 1;          // stride-1 fast path: 0 off, 1 one tap per workgroup, 3 a kernel row of taps (bh_debug_force_tile(-16, n); 3 is faster
+                                              // back to back on the 64-channel layers - 97 vs 105 us - and 3 % slower in the training step)
+int g_wgrad_s3_target = 768;   // workgroups per launch of the three-tap variant (bh_debug_force_tile(-19, n))   // (XCD-aware order: measured 7-18 % slower)
 int g_wgrad_s1_target = 2048;  // split-K work items per launch of the stride-1 kernel (bh_debug_force_tile(-17, n))
 int g_wgrad_target = 4096;      // split-K work items per launch (tuning hook: bh_debug_force_tile(-3, n))
 
@@ -677,12 +701,15 @@ int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, cons
         else hipLaunchKernelGGL((wgrad_small_kernel<false>), grid, dim3(256), 0, s, a);
     } else if (g_wgrad_s1 && vec && a.use_buf && d->precision == 0 && !d->transposed && d->stride == 1 && d->Ho == d->Hi &&
                d->Wo == d->Wi && a.hwshift >= 0 && a.M % WBK == 0 && a.Np % 64 == 0 && a.Nq % 64 == 0 && !a.xcd_map) {
-        int sp = g_wgrad_s1_target / (tiles * ty);        // round DOWN: at most `target` workgroups (8 fit on a CU: 2048 = one full round)
+        const int nt = (g_wgrad_s1 >= 3 && a.kw == 3) ? 3 : 1;           // taps per workgroup
+        const int gy = ty / nt;
+        int sp = (nt == 3 ? g_wgrad_s3_target : g_wgrad_s1_target) / (tiles * gy);        // round DOWN: at most `target` workgroups
         if (sp > maxsplit) sp = maxsplit;
         if (sp < 1) sp = 1;
         a.rows_per_block = (((a.M + sp - 1) / sp) + WBK - 1) / WBK * WBK;
         sp = (a.M + a.rows_per_block - 1) / a.rows_per_block;
-        hipLaunchKernelGGL(wgrad_s1_kernel, dim3(tiles, ty, sp), dim3(256), 0, s, a);
+        if (nt == 3) hipLaunchKernelGGL(wgrad_s1_kernel<3>, dim3(tiles, gy, sp), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(wgrad_s1_kernel<1>, dim3(tiles, gy, sp), dim3(256), 0, s, a);
     } else {
         if (vec && d->precision == 1) hipLaunchKernelGGL((wgrad_kernel<true, true>), grid, dim3(256), 0, s, a);
         else if (vec) hipLaunchKernelGGL((wgrad_kernel<true>), grid, dim3(256), 0, s, a);

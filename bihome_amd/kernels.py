@@ -125,7 +125,7 @@ def _conv_variant0(d, which):
     return gemm_variant(d.N * d.Hi * d.Wi, d.Ci, d.Co, vec, d.precision == 1)
 
 
-WGRAD_S1 = True          # mirrors g_wgrad_s1 (bh_debug_force_tile(-16, n))
+WGRAD_S1 = 1             # mirrors g_wgrad_s1 (bh_debug_force_tile(-16, n)): 0 off, 1 one tap, 3 three taps per workgroup
 
 
 def _wgrad_variant(d):
@@ -145,7 +145,7 @@ def _wgrad_variant(d):
     if (WGRAD_S1 and vec and d.precision == 0 and not d.transposed and d.stride == 1 and d.Ho == d.Hi and d.Wo == d.Wi
             and not d.out_nchw and pow2(d.Wo) and pow2(d.Ho * d.Wo) and M % 32 == 0 and Np % 64 == 0 and Nq % 64 == 0
             and Np % 4 == 0 and M * Np < (1 << 29) and d.N * d.Hi * d.Wi * d.Ci < (1 << 29)):
-        return "wgrad_s1_kernel"
+        return "wgrad_s1_kernel<%d>" % (3 if (WGRAD_S1 >= 3 and d.kw == 3) else 1)
     return "wgrad_kernel<%s,%s>" % ("true" if vec else "false", "true" if (vec and d.precision == 1) else "false")
 
 

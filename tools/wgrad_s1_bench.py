@@ -23,11 +23,12 @@ for (N, H, Ci, Co, k) in [(128, 32, 64, 64, 3), (128, 16, 128, 128, 3), (128, 8,
     gw = torch.zeros_like(ref)
     t0 = bench(lambda: K.conv_wgrad(x, gy, gw, None, d))
     out = ['generic %.0f us %.0f TF' % (t0 * 1e3, fl / t0 / 1e9)]
-    for kg in (2048, 4096, 6144, 8192):
-        lib.bh_debug_force_tile(-16, 1); lib.bh_debug_force_tile(-17, kg)
-        g2 = torch.zeros_like(ref); K.conv_wgrad(x, gy, g2, None, d)
-        err = ((g2 - ref).abs().max() / ref.abs().max()).item()
-        t1 = bench(lambda: K.conv_wgrad(x, gy, gw, None, d))
-        out.append('s1/%d %.0f us %.0f TF (%.0e)' % (kg, t1 * 1e3, fl / t1 / 1e9, err))
-    lib.bh_debug_force_tile(-17, 2048)
+    for mode, hook, tgts in ((1, -17, (2048,)), (3, -19, (512, 768, 1024, 1536))):
+        for tg in tgts:
+            lib.bh_debug_force_tile(-16, mode); lib.bh_debug_force_tile(hook, tg)
+            g2 = torch.zeros_like(ref); K.conv_wgrad(x, gy, g2, None, d)
+            err = ((g2 - ref).abs().max() / ref.abs().max()).item()
+            t1 = bench(lambda: K.conv_wgrad(x, gy, gw, None, d))
+            out.append('nt%d/%d %.0f us %.0f TF (%.0e)' % (mode, tg, t1 * 1e3, fl / t1 / 1e9, err))
+    lib.bh_debug_force_tile(-16, 1); lib.bh_debug_force_tile(-17, 2048); lib.bh_debug_force_tile(-19, 768)
     print((N, H, Ci, Co, k), ' | '.join(out), flush=True)
