@@ -71,7 +71,9 @@ __device__ __forceinline__ bool src_coord(const GemmArgs& a, int oy, int ox, int
     return iy >= 0 && iy < a.Hs && ix >= 0 && ix < a.Ws;
 }
 
-template <int BM, int BN, int BK, bool VEC, bool BF16 = false>
+// BUF: the buffer-descriptor loader (GemmArgs::use_buf) as a compile-time switch, so that the instantiation that runs
+// does not also carry the pointer-based loader's prologue (VALU work is paid at MFMA price on this chip)
+template <int BM, int BN, int BK, bool VEC, bool BF16 = false, bool BUF = false>
 __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
     constexpr int WN = (BN >= 64) ? 2 : 1;         // waves along N
     constexpr int WM = 4 / WN;                     // waves along M
@@ -180,7 +182,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
     unsigned long long a_mask[AIT];
     unsigned bK_voff[BIT_K], bN_voff[BIT];
     __amdgpu_buffer_rsrc_t rsA, rsB;
-    if (VEC && a.use_buf) {
+    if constexpr (VEC && BUF) {
         rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Src), 0, a.src_bytes, 0x00020000);
         rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Bw), 0, a.bw_bytes, 0x00020000);
 #pragma unroll
@@ -216,7 +218,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
     }
 
     auto load_tile = [&](int kt) {
-        if (VEC && a.use_buf) {
+        if constexpr (VEC && BUF) {
             if constexpr (C4 || BF16) {
             const int t = nx_t, c0 = nx_c0;
             const int tap_pix = nx_ky * a.Ws + nx_kx;
@@ -623,7 +625,12 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
 template <int BM, int BN, int BK, bool VEC, bool BF16 = false>
 static int launch(const GemmArgs& a, hipStream_t s) {
     dim3 grid((a.M + BM - 1) / BM, (a.Nn + BN - 1) / BN);
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, VEC, BF16>), grid, dim3(256), 0, s, a);
+    if constexpr (VEC) {
+        if (a.use_buf) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, VEC, BF16, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, VEC, BF16, false>), grid, dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, VEC, BF16, false>), grid, dim3(256), 0, s, a);
+    }
     BH_LAUNCH_CHECK();
     return BH_OK;
 }

@@ -44,10 +44,13 @@ class _Timed:
             r["n"] += 1
 
 
-def gemm_variant(M, Nn, Kc, vec, bf16=False):
+def gemm_variant(M, Nn, Kc, vec, bf16=False, buf_ok=True, src_elems=1, bw_elems=1, T=1):
     """Mirror of conv_gemm.hip's dispatch(): which template instantiation a launch uses (the kernel
-    symbol rocprofv3 reports: conv_gemm_kernel<BM, BN, BK, VEC, BF16>)."""
-    fmt = "conv_gemm_kernel<%d,%d,%d,%s," + ("true>" if (bf16 and vec and Kc % 32 == 0) else "false>")
+    symbol rocprofv3 reports: conv_gemm_kernel<BM, BN, BK, VEC, BF16, BUF>).  buf_ok: not a strided adjoint."""
+    buf = (vec and buf_ok and Nn % 4 == 0 and T <= 64 and 0 < src_elems < (1 << 29) and 0 < bw_elems < (1 << 29)
+           and Kc % 32 == 0)
+    fmt = ("conv_gemm_kernel<%d,%d,%d,%s," + ("true," if (bf16 and vec and Kc % 32 == 0) else "false,")
+           + ("true>" if buf else "false>"))
     if bf16 and vec and Kc % 32 == 0:
         if Nn <= 32:
             return fmt % (128, 32, 32, "true")
@@ -116,13 +119,16 @@ def _conv_variant0(d, which):
         return c3
     if which == "fwd":
         vec = (not d.in_nchw) and d.Ci % 4 == 0
+        src, bw = d.N * d.Hi * d.Wi * d.Ci, d.Co * d.kh * d.kw * d.Ci
         if d.transposed:
-            return gemm_variant(d.N * d.Hi * d.Wi, d.kh * d.kw * d.Co, d.Ci, vec, d.precision == 1)
-        return gemm_variant(d.N * d.Ho * d.Wo, d.Co, d.Ci, vec, d.precision == 1)
+            return gemm_variant(d.N * d.Hi * d.Wi, d.kh * d.kw * d.Co, d.Ci, vec, d.precision == 1, True, src, bw, 1)
+        return gemm_variant(d.N * d.Ho * d.Wo, d.Co, d.Ci, vec, d.precision == 1, True, src, bw, d.kh * d.kw)
     if (not d.transposed) and d.Ci == 1 and not d.out_nchw:
         return "stem_dgrad_c1_kernel"
     vec = (not d.out_nchw) and d.Co % 4 == 0
-    return gemm_variant(d.N * d.Hi * d.Wi, d.Ci, d.Co, vec, d.precision == 1)
+    src, bw = d.N * d.Ho * d.Wo * d.Co, d.Co * d.kh * d.kw * d.Ci
+    return gemm_variant(d.N * d.Hi * d.Wi, d.Ci, d.Co, vec, d.precision == 1, d.transposed or d.stride == 1, src, bw,
+                        d.kh * d.kw)
 
 
 WGRAD_S1 = 1             # mirrors g_wgrad_s1 (bh_debug_force_tile(-16, n)): 0 off, 1 one tap, 3 three taps per workgroup

@@ -84,11 +84,11 @@ def test_conv_desc_and_variant():
     d = K.conv_desc(4, 8, 8, 256, 128, 2, 2, 0, transposed=True)
     assert (d.Ho, d.Wo) == (16, 16)
     assert K.conv_flops(d) == 2.0 * 4 * 64 * 256 * 128 * 4
-    assert K.gemm_variant(1 << 20, 256, 256, True) == "conv_gemm_kernel<64,128,32,true,false>"
-    assert K.gemm_variant(8192, 256, 256, True) == "conv_gemm_kernel<64,64,64,true,false>"
-    assert K.gemm_variant(1 << 21, 2, 128, True) == "conv_gemm_kernel<128,32,32,true,false>"
-    assert K.gemm_variant(1 << 21, 128, 16, True) == "conv_gemm_kernel<128,128,16,true,false>"
-    assert K.gemm_variant(1 << 19, 64, 2, False) == "conv_gemm_kernel<128,64,32,false,false>"
+    assert K.gemm_variant(1 << 20, 256, 256, True) == "conv_gemm_kernel<64,128,32,true,false,true>"
+    assert K.gemm_variant(8192, 256, 256, True) == "conv_gemm_kernel<64,64,64,true,false,true>"
+    assert K.gemm_variant(1 << 21, 2, 128, True) == "conv_gemm_kernel<128,32,32,true,false,false>"      # Nn % 4 != 0: pointer loader
+    assert K.gemm_variant(1 << 21, 128, 16, True) == "conv_gemm_kernel<128,128,16,true,false,false>"    # Kc % 32 != 0
+    assert K.gemm_variant(1 << 19, 64, 2, False) == "conv_gemm_kernel<128,64,32,false,false,false>"
 
 
 def test_synthetic_pairs_are_consistent():
