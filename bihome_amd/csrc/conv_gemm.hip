@@ -38,6 +38,7 @@ struct GemmArgs {
     int accumulate;        // Out += result
     int use_buf;           // buffer-descriptor loads with per-row tap masks (vectorised path; see load_tile)
     unsigned src_bytes, bw_bytes;
+    unsigned out_bytes;    // bytes of the output tensor when below 2^31 (32-bit epilogue addressing through a buffer descriptor), else 0
     long long src_elems, bw_elems;   // tensor sizes (host side: buffer descriptors)
     int prio;              // experiment: s_setprio(1) around the MFMA block
     int bf16;              // operands rounded to bf16 (fp32 accumulate) where the vectorised path applies
@@ -540,9 +541,9 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
     // per row and once per column, one add per element; columns are the inner loop so that the stores of adjacent taps /
     // channels of one pixel leave back to back
     double st1[TN], st2[TN];
-    size_t cpart[TN];
     float bvj[TN];
     bool nok[TN];
+    int cco[TN], ctap[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         st1[j] = 0.0; st2[j] = 0.0;
@@ -550,11 +551,89 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
         nok[j] = n < a.Nn;
         int co = n, tap = 0;
         if (a.epi == 1) { tap = n / a.eC; co = n - tap * a.eC; tap += a.etap0; }
+        cco[j] = co; ctap[j] = tap;
         bvj[j] = (a.bias && nok[j]) ? a.bias[co] : 0.0f;
+    }
+    const bool want_stats = a.bn_sums != nullptr;
+    if (a.out_bytes) {
+        // 32-bit addressing through buffer descriptors (out-of-range rows / columns get an out-of-range offset: the
+        // store is dropped, a load returns 0); statistics as float partial sums per fragment quad, totals in double,
+        // and only when a BatchNorm table was passed
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(a.Out, 0, a.out_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.Out), 0, a.out_bytes, 0x00020000);
+        unsigned cp[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + l31;
+            if (a.epi == 0) cp[j] = (unsigned)n * 4u;
+            else if (a.epi == 1) {
+                const int ay = ctap[j] / a.ek, ax = ctap[j] - ay * a.ek;
+                cp[j] = ((unsigned)(ay * (a.Wo * a.ek) + ax) * (unsigned)a.eC + (unsigned)cco[j]) * 4u;
+            } else cp[j] = (unsigned)n * (unsigned)(a.Ho * a.Wo) * 4u;
+            if (!nok[j]) cp[j] = 0xFFFFFFF0u;
+        }
+        const bool extra = a.accumulate || a.res;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                float q1[TN], q2[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) { q1[j] = 0.f; q2[j] = 0.f; }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int r = rq * 4 + c;
+                    const int m = m0 + (wm * TM + i) * 32 + c + 8 * rq + 4 * kh2;
+                    unsigned rp;
+                    if (a.epi == 0) {
+                        rp = (unsigned)m * (unsigned)a.Nn * 4u;
+                    } else {
+                        int nb, oy, ox;
+                        if (a.ehwshift >= 0) {
+                            nb = m >> a.ehwshift;
+                            const int rr = m & ((1 << a.ehwshift) - 1);
+                            oy = rr >> a.ewshift; ox = rr & ((1 << a.ewshift) - 1);
+                        } else {
+                            const int hw = a.Ho * a.Wo;
+                            nb = m / hw;
+                            const int rr = m - nb * hw;
+                            oy = rr / a.Wo; ox = rr - oy * a.Wo;
+                        }
+                        if (a.epi == 1) rp = (((unsigned)(nb * (a.Ho * a.ek) + oy * a.ek) * (unsigned)(a.Wo * a.ek) + (unsigned)(ox * a.ek)) * (unsigned)a.eC) * 4u;
+                        else rp = ((unsigned)nb * (unsigned)a.Nn * (unsigned)(a.Ho * a.Wo) + (unsigned)(oy * a.Wo + ox)) * 4u;
+                    }
+                    const bool mok = m < a.M;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const unsigned off = (mok && nok[j]) ? rp + cp[j] : 0xFFFFFFF0u;
+                        float v = acc[i][j][r] + bvj[j];
+                        if (extra) {
+                            if (a.accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsO, off, 0, 0));
+                            if (a.res) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, off, 0, 0));
+                        }
+                        if (a.relu) v = fmaxf(v, 0.0f);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsO, off, 0, 0);
+                        if (want_stats) {
+                            const float vs = (mok && nok[j]) ? v : 0.f;
+                            q1[j] += vs; q2[j] = __builtin_fmaf(vs, vs, q2[j]);
+                        }
+                    }
+                }
+                if (want_stats) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) { st1[j] += (double)q1[j]; st2[j] += (double)q2[j]; }
+                }
+            }
+        }
+    } else {
+    size_t cpart[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + l31;
         if (a.epi == 0) cpart[j] = (size_t)n;
         else if (a.epi == 1) {
-            const int ay = tap / a.ek, ax = tap - ay * a.ek;
-            cpart[j] = ((size_t)ay * (a.Wo * a.ek) + ax) * a.eC + co;
+            const int ay = ctap[j] / a.ek, ax = ctap[j] - ay * a.ek;
+            cpart[j] = ((size_t)ay * (a.Wo * a.ek) + ax) * a.eC + cco[j];
         } else cpart[j] = (size_t)n * a.Ho * a.Wo;
     }
 #pragma unroll
@@ -594,6 +673,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
                 st2[j] += (double)v * (double)v;
             }
         }
+    }
     }
     if (a.bn_sums) {
         // column sums of the tile: half-waves merged by a shuffle, the WM waves of a column range through LDS (the
@@ -658,6 +738,10 @@ static int dispatch(const GemmArgs& a_in, hipStream_t s) {
                 a.src_elems < (1ll << 29) && a.bw_elems > 0 && a.bw_elems < (1ll << 29) && (a.Kc % 32 == 0) && !g_no_buf;
     a.src_bytes = (unsigned)(a.src_elems * 4);
     a.bw_bytes = (unsigned)(a.bw_elems * 4);
+    {
+        const long long oe = a.epi == 1 ? (long long)a.M * a.ek * a.ek * a.eC : (long long)a.M * a.Nn;
+        a.out_bytes = (oe > 0 && oe < (1ll << 29)) ? (unsigned)(oe * 4) : 0u;
+    }
     if (vec && a.bf16 && (a.Kc % 32) == 0) {
         // bf16 operands: the MFMA is 16x faster, the kernel is bound by staging traffic -> widest N tile that fits
         int bm = g_force_bm, bn = g_force_bn;
