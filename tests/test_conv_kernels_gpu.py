@@ -368,6 +368,35 @@ def test_dgrad_epilogue_accumulates_batchnorm_backward_sums(K, N, H, C, Co, grou
         K.C3_MIN_BLOCKS = 256
 
 
+@pytest.mark.parametrize("N,H,Ci,Co,k", [(2, 8, 64, 64, 3), (1, 32, 64, 128, 3), (3, 16, 128, 64, 3), (2, 4, 64, 64, 3),
+                                         (2, 16, 64, 128, 1), (1, 16, 64, 64, 5)])
+def test_wgrad_stride1_fast_path_matches_generic_kernel(K, N, H, Ci, Co, k):
+    """wgrad_s1_kernel<1> / <3> (tap shift folded into the buffer base, window tests for the borders) against the generic
+    split-K kernel and torch float64, including maps narrower than the tile step and a 5x5 kernel."""
+    from bihome_amd._lib import lib
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, H, H, Ci, generator=g).cuda()
+    gy = torch.randn(N, H, H, Co, generator=g).cuda()
+    d = K.conv_desc(N, H, H, Ci, Co, k, 1, k // 2)
+    ref64 = torch.nn.grad.conv2d_weight(x.double().cpu().permute(0, 3, 1, 2), (Co, Ci, k, k), gy.double().cpu().permute(0, 3, 1, 2),
+                                        stride=1, padding=k // 2).permute(0, 2, 3, 1)
+    out = {}
+    try:
+        for mode in (0, 1, 3):
+            lib.bh_debug_force_tile(-16, mode)
+            K.WGRAD_S1 = mode
+            gw = torch.zeros(Co, k, k, Ci, device="cuda")
+            K.conv_wgrad(x, gy, gw, None, d)
+            out[mode] = gw.cpu()
+    finally:
+        lib.bh_debug_force_tile(-16, 1)
+        K.WGRAD_S1 = 1
+    assert K._wgrad_variant(d) == "wgrad_s1_kernel<1>"
+    scale = float(ref64.abs().max())
+    for mode in (0, 1, 3):
+        assert float((out[mode].double() - ref64).abs().max()) < 2e-5 * scale + 1e-5, mode
+
+
 @pytest.mark.parametrize("N,H,Ci,relu", [(4, 128, 1, False), (4, 128, 2, False), (2, 256, 3, False), (1, 256, 6, True)])
 def test_stem7_forward_kernel(K, N, H, Ci, relu):
     """csrc/stem7.hip (7x7 / stride 2 / pad 3 stems, NCHW planes -> NHWC) against torch float64 and the generic kernel."""
