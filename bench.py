@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--overlap", action="store_true",
                     help="second HIP stream: wgrad GEMMs under the dgrad/BatchNorm chain, extractor prefetch under the backbone "
                          "(+3%% pairs/s; off by default so that per-kernel durations are those of each kernel alone)")
+    ap.add_argument("--hook", action="append", default=[], metavar="A,B",
+                    help="tuning experiments: call bh_debug_force_tile(A, B) before the run (see csrc/conv_gemm.hip)")
     return ap.parse_args()
 
 
@@ -204,6 +206,11 @@ def main():
 
     if args.overlap:
         os.environ["BIHOME_OVERLAP"] = "1"
+    if args.hook:
+        from bihome_amd._lib import lib
+        for h in args.hook:
+            a_, b_ = (int(v) for v in h.split(","))
+            lib.bh_debug_force_tile(a_, b_)
     cfg = configs.get(args.config)
     cfg["MODEL"]["BACKBONE"]["PRECISION"] = args.precision
     cfg["MODEL"]["HEAD"]["PRECISION"] = args.precision

@@ -215,10 +215,14 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
 // x = t mod Wo lie in workgroup-uniform windows: 8 VALU per gathered row, none for the plain rows.
 // NT = taps per workgroup: 1, or 3 (kw = 3: the three taps of a kernel row share the plain operand tile - one gy load and
 // one A fragment read feed three MFMAs, a barrier every 48 MFMAs per wave instead of every 16, a third less L2 traffic).
-template <int NT>
+// BF16: operands rounded to bf16 while staging, fp32 accumulate on v_mfma_f32_32x32x16_bf16; tiles are stored
+// [channel][pixel + pad] like wgrad_kernel's bf16 path (lanes run along pixels in the loader: one pixel row and two
+// float4 channel chunks per lane, so the tap test is evaluated once per lane and step).
+template <int NT, bool BF16 = false>
 __global__ void __launch_bounds__(256) wgrad_s1_kernel(WgradArgs a) {
-    __shared__ __attribute__((aligned(16))) float As[WBK * WLD];
-    __shared__ __attribute__((aligned(16))) float Bs[NT][WBK * WLD];
+    constexpr int WLH = WBK + 8;
+    __shared__ __attribute__((aligned(16))) float As[BF16 ? 64 * WLH / 2 : WBK * WLD];
+    __shared__ __attribute__((aligned(16))) float Bs[NT][BF16 ? 64 * WLH / 2 : WBK * WLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int qtiles = a.Nq >> 6;
@@ -227,7 +231,9 @@ __global__ void __launch_bounds__(256) wgrad_s1_kernel(WgradArgs a) {
     const int mbeg = blockIdx.z * a.rows_per_block;
     const int mend = min(a.M, mbeg + a.rows_per_block);          // a multiple of 32, like mbeg
     if (mbeg >= mend) return;
-    const int chunk0 = tid & 15, prow0 = tid >> 4;               // 16 float4 chunks x 16 pixel rows per pass, 2 passes
+    // fp32: 16 float4 chunks x 16 pixel rows per pass, 2 passes (rows prow0, prow0 + 16, one chunk);
+    // bf16: 32 pixel rows x 8 chunks per pass, 2 passes (one row, chunks chunk0 and chunk0 + 8)
+    const int chunk0 = BF16 ? (tid >> 5) : (tid & 15), prow0 = BF16 ? (tid & 31) : (tid >> 4);
     const int tky = t0 / a.kw, dy = tky - a.pad, dx0 = t0 - tky * a.kw - a.pad;       // taps (dy, dx0 + j), j < NT
     const int hw = a.Ho * a.Wo;
     // validity windows: (unsigned)(t - lo_t) < n_t  and  (unsigned)(x - lo_x[j]) < n_x[j]
@@ -247,9 +253,10 @@ __global__ void __launch_bounds__(256) wgrad_s1_kernel(WgradArgs a) {
     int rowi[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        rowi[i] = prow0 + 16 * i;
-        vP[i] = ((unsigned)rowi[i] * (unsigned)a.Np + (unsigned)(p0 + chunk0 * 4)) * 4u;
-        vQ[i] = ((unsigned)rowi[i] * (unsigned)a.Cq + (unsigned)(q0 + chunk0 * 4)) * 4u;
+        rowi[i] = BF16 ? prow0 : prow0 + 16 * i;
+        const int ch = BF16 ? chunk0 + 8 * i : chunk0;
+        vP[i] = ((unsigned)rowi[i] * (unsigned)a.Np + (unsigned)(p0 + ch * 4)) * 4u;
+        vQ[i] = ((unsigned)rowi[i] * (unsigned)a.Cq + (unsigned)(q0 + ch * 4)) * 4u;
     }
     f32x16 acc[NT];
 #pragma unroll
@@ -259,38 +266,70 @@ __global__ void __launch_bounds__(256) wgrad_s1_kernel(WgradArgs a) {
     float4 rp[2], rq[NT][2];
     auto load_tile = [&](int mk) {
         const unsigned sP = (unsigned)mk * (unsigned)a.Np * 4u, sQ = (unsigned)mk * (unsigned)a.Cq * 4u;     // scalar
+        bool okj[2][NT];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < (BF16 ? 1 : 2); ++i) {
             const unsigned tt = (unsigned)(mk + rowi[i]) & (unsigned)(hw - 1);
             const unsigned xx = tt & (unsigned)(a.Wo - 1);
             const bool okt = (tt - lo_t) < n_t;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) okj[i][j] = okt && (xx - lo_x[j]) < n_x[j];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
             rp[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsP, vP[i], sP, 0));
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const bool ok = okt && (xx - lo_x[j]) < n_x[j];
-                rq[j][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsQ[j], ok ? vQ[i] : 0xFFFFFFF0u, sQ, 0));
-            }
+            for (int j = 0; j < NT; ++j)
+                rq[j][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsQ[j], okj[BF16 ? 0 : i][j] ? vQ[i] : 0xFFFFFFF0u, sQ, 0));
         }
     };
     const int kh2 = lane >> 5, l31 = lane & 31;
     const int woff = prow0 * WLD + chunk0 * 4;
     const float* const ra = &As[kh2 * WLD + wm * 32 + l31];
     const int roff = kh2 * WLD + wn * 32 + l31;
+    __bf16* const Ah = reinterpret_cast<__bf16*>(As);
     load_tile(mbeg);
     for (int mk = mbeg; mk < mend; mk += WBK) {
+        if constexpr (BF16) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<float4*>(&As[woff + i * 16 * WLD]) = rp[i];
+            for (int i = 0; i < 2; ++i) {
+                const int ch = (chunk0 + 8 * i) * 4;
+                Ah[(ch + 0) * WLH + prow0] = (__bf16)rp[i].x; Ah[(ch + 1) * WLH + prow0] = (__bf16)rp[i].y;
+                Ah[(ch + 2) * WLH + prow0] = (__bf16)rp[i].z; Ah[(ch + 3) * WLH + prow0] = (__bf16)rp[i].w;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) *reinterpret_cast<float4*>(&Bs[j][woff + i * 16 * WLD]) = rq[j][i];
+                for (int j = 0; j < NT; ++j) {
+                    __bf16* const Bj = reinterpret_cast<__bf16*>(&Bs[j][0]);
+                    Bj[(ch + 0) * WLH + prow0] = (__bf16)rq[j][i].x; Bj[(ch + 1) * WLH + prow0] = (__bf16)rq[j][i].y;
+                    Bj[(ch + 2) * WLH + prow0] = (__bf16)rq[j][i].z; Bj[(ch + 3) * WLH + prow0] = (__bf16)rq[j][i].w;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                *reinterpret_cast<float4*>(&As[woff + i * 16 * WLD]) = rp[i];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) *reinterpret_cast<float4*>(&Bs[j][woff + i * 16 * WLD]) = rq[j][i];
+            }
         }
         __syncthreads();
         if (mk + WBK < mend) load_tile(mk + WBK);
+        if constexpr (BF16) {
 #pragma unroll
-        for (int kk = 0; kk < WBK / 2; ++kk) {
-            const float av = ra[2 * kk * WLD];
+            for (int ks = 0; ks < WBK / 16; ++ks) {
+                const bf16x8 av = *reinterpret_cast<const bf16x8*>(&Ah[(wm * 32 + l31) * WLH + ks * 16 + kh2 * 8]);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Bs[j][roff + 2 * kk * WLD], acc[j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) {
+                    const bf16x8 bv = *reinterpret_cast<const bf16x8*>(&reinterpret_cast<const __bf16*>(&Bs[j][0])[(wn * 32 + l31) * WLH + ks * 16 + kh2 * 8]);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[j], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < WBK / 2; ++kk) {
+                const float av = ra[2 * kk * WLD];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Bs[j][roff + 2 * kk * WLD], acc[j], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
@@ -699,17 +738,21 @@ int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, cons
     } else if (small) {
         if (vec) hipLaunchKernelGGL((wgrad_small_kernel<true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((wgrad_small_kernel<false>), grid, dim3(256), 0, s, a);
-    } else if (g_wgrad_s1 && vec && a.use_buf && d->precision == 0 && !d->transposed && d->stride == 1 && d->Ho == d->Hi &&
+    } else if (g_wgrad_s1 && vec && a.use_buf && (d->precision == 0 || d->precision == 1) && !d->transposed && d->stride == 1 && d->Ho == d->Hi &&
                d->Wo == d->Wi && a.hwshift >= 0 && a.M % WBK == 0 && a.Np % 64 == 0 && a.Nq % 64 == 0 && !a.xcd_map) {
-        const int nt = (g_wgrad_s1 >= 3 && a.kw == 3) ? 3 : 1;           // taps per workgroup
+        // taps per workgroup: in bf16 mode the loop is so short that the launch is bound by its operand traffic (each tap
+        // re-reads x and gy: 320 MB per launch) - three taps per workgroup share gy and a third of it goes away
+        const int nt = (a.kw == 3 && (g_wgrad_s1 >= 3 || d->precision == 1)) ? 3 : 1;
         const int gy = ty / nt;
         int sp = (nt == 3 ? g_wgrad_s3_target : g_wgrad_s1_target) / (tiles * gy);        // round DOWN: at most `target` workgroups
         if (sp > maxsplit) sp = maxsplit;
         if (sp < 1) sp = 1;
         a.rows_per_block = (((a.M + sp - 1) / sp) + WBK - 1) / WBK * WBK;
         sp = (a.M + a.rows_per_block - 1) / a.rows_per_block;
-        if (nt == 3) hipLaunchKernelGGL(wgrad_s1_kernel<3>, dim3(tiles, gy, sp), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(wgrad_s1_kernel<1>, dim3(tiles, gy, sp), dim3(256), 0, s, a);
+        if (d->precision == 1 && nt == 3) hipLaunchKernelGGL((wgrad_s1_kernel<3, true>), dim3(tiles, gy, sp), dim3(256), 0, s, a);
+        else if (d->precision == 1) hipLaunchKernelGGL((wgrad_s1_kernel<1, true>), dim3(tiles, gy, sp), dim3(256), 0, s, a);
+        else if (nt == 3) hipLaunchKernelGGL((wgrad_s1_kernel<3, false>), dim3(tiles, gy, sp), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((wgrad_s1_kernel<1, false>), dim3(tiles, gy, sp), dim3(256), 0, s, a);
     } else {
         if (vec && d->precision == 1) hipLaunchKernelGGL((wgrad_kernel<true, true>), grid, dim3(256), 0, s, a);
         else if (vec) hipLaunchKernelGGL((wgrad_kernel<true>), grid, dim3(256), 0, s, a);

@@ -148,10 +148,12 @@ def _wgrad_variant(d):
         return "wgrad_small_kernel<%s>" % ("true" if vec else "false")
     M = d.N * d.Ho * d.Wo
     pow2 = lambda v: v > 0 and (v & (v - 1)) == 0
-    if (WGRAD_S1 and vec and d.precision == 0 and not d.transposed and d.stride == 1 and d.Ho == d.Hi and d.Wo == d.Wi
+    if (WGRAD_S1 and vec and d.precision in (0, 1) and not d.transposed and d.stride == 1 and d.Ho == d.Hi and d.Wo == d.Wi
             and not d.out_nchw and pow2(d.Wo) and pow2(d.Ho * d.Wo) and M % 32 == 0 and Np % 64 == 0 and Nq % 64 == 0
             and Np % 4 == 0 and M * Np < (1 << 29) and d.N * d.Hi * d.Wi * d.Ci < (1 << 29)):
-        return "wgrad_s1_kernel<%d>" % (3 if (WGRAD_S1 >= 3 and d.kw == 3) else 1)
+        if d.precision == 1:
+            return "wgrad_s1_kernel<%d,true>" % (3 if d.kw == 3 else 1)
+        return "wgrad_s1_kernel<%d,false>" % (3 if (WGRAD_S1 >= 3 and d.kw == 3) else 1)
     return "wgrad_kernel<%s,%s>" % ("true" if vec else "false", "true" if (vec and d.precision == 1) else "false")
 
 
