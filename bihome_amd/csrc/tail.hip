@@ -93,15 +93,15 @@ __global__ void __launch_bounds__(256) tail_stats_finalize_kernel(const double* 
     if (c < g.Cm) { rm = running_mean ? running_mean[c] : 0.f; rv = running_var ? running_var[c] : 1.f; }
     for (int grp = 0; grp < g.groups; ++grp) {
         __syncthreads();
-        for (int e = threadIdx.x; e < nm; e += 256) mom[e] = xmom[(size_t)grp * nm + e];
+        for (int e = threadIdx.x; e < nm; e += 256) mom[e] = xmom[(size_t)grp * nm + e] / n;      // E[x_i], E[x_i x_j]
         __syncthreads();
         if (c < g.Cm) {
             double my = b1 ? (double)b1[c] : 0.0, eyy = 0;
             for (int i = 0; i < Ci; ++i) {
-                const double wi = w1[c * Ci + i], mi = mom[i] / n;
+                const double wi = w1[c * Ci + i], mi = mom[i];
                 my += wi * mi;
                 double row = 0;
-                for (int j = 0; j < Ci; ++j) row += (double)w1[c * Ci + j] * (mom[Ci + i * Ci + j] / n - mi * (mom[j] / n));
+                for (int j = 0; j < Ci; ++j) row += (double)w1[c * Ci + j] * (mom[Ci + i * Ci + j] - mi * mom[j]);
                 eyy += wi * row;
             }
             if (eyy < 0) eyy = 0;
@@ -387,9 +387,17 @@ __global__ void __launch_bounds__(256) tail_gb2_kernel(const float* __restrict__
     __shared__ double sm[4];
     const int o = blockIdx.y;
     double acc = 0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)N * hw; i += (size_t)gridDim.x * 256) {
-        const size_t n = i / hw, p = i - n * hw;
-        acc += gout[(n * Co + o) * hw + p];
+    // one (image, channel) plane per workgroup pass: contiguous, no per-element division
+    for (int n = blockIdx.x; n < N; n += gridDim.x) {
+        const float* pl = gout + ((size_t)n * Co + o) * hw;
+        if ((hw & 3) == 0) {
+            for (int p = threadIdx.x * 4; p < hw; p += 1024) {
+                const float4 v = *reinterpret_cast<const float4*>(pl + p);
+                acc += (double)((v.x + v.y) + (v.z + v.w));
+            }
+        } else {
+            for (int p = threadIdx.x; p < hw; p += 256) acc += pl[p];
+        }
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
@@ -469,7 +477,8 @@ int bh_tail_bwd(const float* gout, const float* x, const float* w1, const float*
     if (Ci == 16) TAIL_BWD(16); else if (Ci == 32) TAIL_BWD(32); else TAIL_BWD(8);
 #undef TAIL_BWD
     if (gb2) {
-        hipLaunchKernelGGL(tail_gb2_kernel, dim3(64, Co), dim3(256), 0, s, gout, groups * rows / hw, Co, hw, gb2);
+        const int nimg = groups * rows / hw;
+        hipLaunchKernelGGL(tail_gb2_kernel, dim3(nimg < 256 ? nimg : 256, Co), dim3(256), 0, s, gout, nimg, Co, hw, gb2);
         BH_LAUNCH_CHECK();
     }
     return BH_OK;
