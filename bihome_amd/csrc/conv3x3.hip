@@ -62,8 +62,7 @@ struct C3Args {
     double* bn_sums;       // optional [groups][Nn][2]: += per-channel (sum, sum of squares) of the output (forward only)
     int imgs_per_group, groups;
     int dbg_nch;           // ablation: number of channel chunks to run (-1 = all)
-    int stagger;           // 0 none; 1: workgroups with bit 8 of their launch index set start late; 2: odd ones
-    int stagger_sleeps;    // ... by this many s_sleep(127) (8128 cycles each)
+    int tpb, gx_total;     // tile positions per workgroup (see the loop in the kernel), total positions along x
     int dbg_noload;        // ablation bits: 1 no weight-slab DMA in the loop, 2 no halo DMA in the loop (wrong results, timing only)
 };
 
@@ -99,6 +98,27 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
     __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Src), 0, a.src_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wt), 0, a.w_bytes, 0x00020000);
 
+    // ---- weight slab slots ----
+    unsigned boff[2] = {0u, 0u};    // (fixed size: a template-dependent array type as a builtin operand silently drops
+                                    //  the host-side kernel stub with this compiler)
+#pragma unroll
+    for (int i = 0; i < BINS; ++i) {
+        const int idx = i * 4 + wave;                      // 1 KB wave instruction of the slab image
+        if (!FLIP) {            // B[k][n] = W[n][tap][c0 + k]: image [8 planes][BN n] x float4
+            const int plane = BN == 64 ? idx : idx * 2 + (lane >> 5), n = n0 + (BN == 64 ? lane : (lane & 31));
+            boff[i] = n < a.Nn ? ((unsigned)(n * 9) * (unsigned)a.Cw + (unsigned)(plane * 4)) * 4u : OOB;
+        } else {                // B[k][n] = W[c0 + k][8 - tap][n]: image [32 k][BN n] floats, BN/4 lanes x float4 per k row
+            constexpr int LPR = BN / 4;
+            const int k = idx * (64 / LPR) + lane / LPR, n = n0 + (lane % LPR) * 4;
+            boff[i] = n < a.Nn ? ((unsigned)(k * 9) * (unsigned)a.Cw + (unsigned)n) * 4u : OOB;
+        }
+    }
+    // A workgroup walks a.tpb consecutive tile positions (two on the launches that would otherwise be exactly two rounds of
+    // resident workgroups: the second tile starts whenever the first is done instead of waiting for a dispatch slot, and
+    // its prologue loads queue behind the first tile's stores without a launch-wide phase change)
+    for (int it = 0; it < a.tpb; ++it) {
+    const int bx = blockIdx.x * a.tpb + it;
+    if (bx >= a.gx_total) break;
     // ---- halo slots of this lane: slot q = (j*4 + wave)*64 + lane of the [8][SUBT][100] image ----
     // (written for instruction count - VALU work does not overlap the other workgroup's MFMAs: the per-sub-tile origin
     //  is computed once, with shifts when the tile grid is a power of two, and the slot -> (plane, sub-tile, hy, hx)
@@ -107,7 +127,7 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
     int oy0[SUBT], ox0[SUBT];
 #pragma unroll
     for (int s = 0; s < SUBT; ++s) {
-        const int g = blockIdx.x * SUBT + s;
+        const int g = bx * SUBT + s;
         int img, ty, tx;
         if (a.tpi_shift >= 0) { img = g >> a.tpi_shift; const int t = g & (a.tiles_per_img - 1); ty = t >> a.tx_shift; tx = t & (a.tiles_x - 1); }
         else { img = g / a.tiles_per_img; const int t = g - img * a.tiles_per_img; ty = t / a.tiles_x; tx = t - ty * a.tiles_x; }
@@ -130,21 +150,6 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
                 off = ((unsigned)(o + hy * a.W + hx) * (unsigned)a.Kc + (unsigned)(plane * 4)) * 4u;
         }
         hoff[j] = off;
-    }
-    // ---- weight slab slots ----
-    unsigned boff[2] = {0u, 0u};    // (fixed size: a template-dependent array type as a builtin operand silently drops
-                                    //  the host-side kernel stub with this compiler)
-#pragma unroll
-    for (int i = 0; i < BINS; ++i) {
-        const int idx = i * 4 + wave;                      // 1 KB wave instruction of the slab image
-        if (!FLIP) {            // B[k][n] = W[n][tap][c0 + k]: image [8 planes][BN n] x float4
-            const int plane = BN == 64 ? idx : idx * 2 + (lane >> 5), n = n0 + (BN == 64 ? lane : (lane & 31));
-            boff[i] = n < a.Nn ? ((unsigned)(n * 9) * (unsigned)a.Cw + (unsigned)(plane * 4)) * 4u : OOB;
-        } else {                // B[k][n] = W[c0 + k][8 - tap][n]: image [32 k][BN n] floats, BN/4 lanes x float4 per k row
-            constexpr int LPR = BN / 4;
-            const int k = idx * (64 / LPR) + lane / LPR, n = n0 + (lane % LPR) * 4;
-            boff[i] = n < a.Nn ? ((unsigned)(k * 9) * (unsigned)a.Cw + (unsigned)n) * 4u : OOB;
-        }
     }
 #define issue_B(c, tap, bs)                                                                                             \
     do {                                                                                                                \
@@ -170,15 +175,6 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
-    // Stagger: the two workgroups of a CU start together and stay in lockstep, so their memory phases (prologue loads,
-    // epilogue stores) coincide and the matrix pipe idles; delaying every second first-round workgroup by about one
-    // memory phase makes each of them compute alone (at twice the rate) while its neighbour loads / stores.
-    if (a.stagger) {
-        const unsigned lid = blockIdx.x + gridDim.x * blockIdx.y;
-        const bool late = a.stagger == 1 ? ((lid >> 8) & 1) && lid < 512 : (lid & 1) && lid < 512;
-        if (late)
-            for (int i = 0; i < a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     const int nch = a.dbg_nch >= 0 ? a.dbg_nch : a.Kc / 32;     // (ablation hook: bh_debug_force_tile(-8, n) caps the chunk loop)
     // a single chunk (32 source channels) never touches the second halo stage: the host then launches with one stage less
     // of LDS (41.6 instead of 67.2 KB: three workgroups per CU for the 32-channel layers) and the slabs move down
@@ -263,7 +259,7 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
     // Element (i, r) of a lane is pixel (c3_strip_row(2*(r>>2) + kh2), 4*(i + wh) + (r&3)) of the sub-tile: the row part of
     // its address is one of four per-lane VGPRs, the column part (4*(i + wh) + (r&3)) * Nn is workgroup-uniform and rides in
     // the scalar offset of the buffer instruction - no per-element address arithmetic.
-    const int g = blockIdx.x * SUBT + wm;
+    const int g = bx * SUBT + wm;
     const int n = n0 + wn * 32 + l31;
     const bool valid = g < a.subtiles && n < a.Nn;
     const int gg = g < a.subtiles ? g : 0;
@@ -415,20 +411,21 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
                         const int wv1 = BN == 64 ? (w1 + 2 * cr) : w1;
                         if (grp_of[wv1] == g0) { tot += red[(wv1 * 32 + col) * 2 + mom]; done |= 1 << w1; }
                     }
-                    atomicAdd(&a.bn_sums[bn_sum_index(blockIdx.x % BH_BN_SUM_SLOTS, a.groups, g0, a.Nn, nn, mom)], tot);
+                    atomicAdd(&a.bn_sums[bn_sum_index(bx % BH_BN_SUM_SLOTS, a.groups, g0, a.Nn, nn, mom)], tot);
                 }
             }
         }
     }
+    __syncthreads();            // the next tile's DMA overwrites the LDS this tile's statistics merge just read
+    }
 }
 
 static int g_c3_noload = 0;
-static int g_c3_disable = 0, g_c3_min_blocks = 256, g_c3_dbg_nch = -1, g_c3_subt = 2, g_c3_stagger = -1, g_c3_stagger_sleeps = 1;
+static int g_c3_disable = 0, g_c3_min_blocks = 256, g_c3_dbg_nch = -1, g_c3_subt = 2, g_c3_tpb = 2;
 void bh_conv3x3_tune(int disable, int min_blocks) {
     if (disable <= -100) { g_c3_dbg_nch = -100 - disable - 1; return; }
     if (disable >= 60 && disable < 64) { g_c3_noload = disable - 60; return; }
-    if (disable >= 19 && disable < 23) { g_c3_stagger = disable - 20; return; }            // stagger mode -1 (automatic) / 0 / 1 / 2
-    if (disable >= 30 && disable < 60) { g_c3_stagger_sleeps = disable - 30; return; }      // ... number of sleeps
+    if (disable >= 20 && disable < 24) { g_c3_tpb = disable - 20; return; }                // tile positions per workgroup on two-round launches (1 / 2)
     if (disable >= 11 && disable <= 13) { g_c3_subt = disable - 10; return; }      // 1 / 2 (automatic) / 3 (always two) sub-tiles per workgroup     // -100 -> -1 (all), -101 -> 0 chunks, -102 -> 1 ...
     g_c3_disable = disable;
     if (min_blocks > 0) g_c3_min_blocks = min_blocks;
@@ -473,6 +470,11 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
     const bool few = (long long)((a.subtiles + 1) / 2) * (Nn / bn_tile) <= 256;
     const int subt = (bn_tile == 64 && (g_c3_subt == 1 || (g_c3_subt == 2 && few))) ? 1 : 2;
     dim3 grid((a.subtiles + subt - 1) / subt, Nn / bn_tile);
+    a.gx_total = (int)grid.x; a.tpb = 1;
+    {   // exactly-two-rounds launches (two resident workgroups per CU with two sub-tiles, 512 slots): one round of two tiles
+        const long long wgs = (long long)grid.x * grid.y;
+        if (g_c3_tpb >= 2 && subt == 2 && Kc / 32 > 1 && wgs > 512 && wgs <= 1024) { a.tpb = 2; grid.x = (grid.x + 1) / 2; }
+    }
     if ((int)(((a.subtiles + 1) / 2) * grid.y) < g_c3_min_blocks) return 0;
     static bool attr_set = false;
     typedef void (*kern_t)(C3Args);
@@ -493,10 +495,6 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
     }
     const kern_t fn = subt == 1 ? fns[8 + (d->precision == 1 ? 2 : 0) + (dgrad ? 1 : 0)]
                                 : fns[(d->precision == 1 ? 4 : 0) + (bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0)];
-    // start stagger (experiment hook, off: in a back-to-back micro-benchmark it takes 128x32x32x64 from 101 to 93 us, in the
-    // training step - where other kernels sit between these launches - it changes nothing; tools/conv3x3_stagger.py)
-    a.stagger = g_c3_stagger > 0 ? g_c3_stagger : 0;
-    a.stagger_sleeps = g_c3_stagger_sleeps;
     a.dbg_noload = g_c3_noload;
     const int lds = (subt == 1 ? LDS1 : C3_LDS_BYTES) - (Kc / 32 > 1 ? 0 : 8 * 100 * subt * 16);      // single chunk: one halo stage
     hipLaunchKernelGGL(fn, grid, dim3(256), lds, stream, a);

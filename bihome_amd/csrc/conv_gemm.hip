@@ -956,8 +956,7 @@ int bh_debug_force_tile(int bm, int bn) {
     if (bm == -18) { bh_conv3x3_tune(60 + bn, 0); return BH_OK; }       // (-18, bits): 3x3 kernel ablation - 1 no weight DMA, 2 no halo DMA in the loop
     if (bm == -14) { bh_warp_tune(0, bn); return BH_OK; }               // (-14, 1|2): warp forward rows per thread
     if (bm == -15) { bh_warp_tune(1, bn); return BH_OK; }               // (-15, 1|2|4): warp adjoint rows per thread
-    if (bm == -12) { bh_conv3x3_tune(20 + bn, 0); return BH_OK; }      // (-12, 0|1|2): 3x3 kernel start stagger mode
-    if (bm == -13) { bh_conv3x3_tune(30 + bn, 0); return BH_OK; }      // (-13, n): ... delay in s_sleep(127) units
+    if (bm == -12) { bh_conv3x3_tune(20 + bn, 0); return BH_OK; }      // (-12, 1|2): 3x3 kernel tile positions per workgroup on two-round launches
     if (bm == -9) { bh_conv3x3_tune(10 + bn, 0); return BH_OK; }     // (-9, 1|2): 3x3 kernel sub-tiles per workgroup (64-channel tile)
     if (bm == -8) { bh_conv3x3_tune(-101 - bn, 0); return BH_OK; }  // (-8, n): ablation - 3x3 kernel runs n channel chunks only (-1: all)   // (-7, 1): ablation - wgrad without its atomic flush      // (-6, 1): disable the dedicated 7x7 stem forward kernel
     g_force_bm = bm; g_force_bn = bn; return BH_OK;

@@ -397,6 +397,29 @@ def test_wgrad_stride1_fast_path_matches_generic_kernel(K, N, H, Ci, Co, k):
         assert float((out[mode].double() - ref64).abs().max()) < 2e-5 * scale + 1e-5, mode
 
 
+def test_conv3x3_two_tile_positions_per_workgroup(K):
+    """Launches of 513-1024 workgroups run as one round of workgroups that each walk two tile positions (conv3x3.hip, a.tpb):
+    forward with BatchNorm sums and dgrad against the generic kernel, odd position count."""
+    from bihome_amd._lib import lib
+    N, H, C = 65, 32, 64                                  # 65 * 16 sub-tiles / 2 = 520 workgroups -> 260 x 2
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, H, H, C, generator=g).cuda()
+    w = (torch.randn(C, 3, 3, C, generator=g) * 0.05).cuda()
+    gy = torch.randn(N, H, H, C, generator=g).cuda()
+    d = K.conv_desc(N, H, H, C, C, 3, 1, 1)
+    res = {}
+    try:
+        for mode in (1, 0):                               # 1: generic kernel, 0: halo kernel
+            lib.bh_debug_force_tile(-4, mode)
+            sums = K.bn_stats_buffer(1, C, "cuda")
+            res[mode] = (K.conv_fwd(x, w, None, d, bn_sums=sums, groups=1), K.conv_dgrad(gy, w, d), sums)
+    finally:
+        lib.bh_debug_force_tile(-4, 0)
+    assert float((res[0][0] - res[1][0]).abs().max()) < 5e-5
+    assert float((res[0][1] - res[1][1]).abs().max()) < 5e-5
+    assert float((res[0][2] - res[1][2]).abs().max() / res[1][2].abs().max()) < 1e-6
+
+
 @pytest.mark.parametrize("N,H,Ci,relu", [(4, 128, 1, False), (4, 128, 2, False), (2, 256, 3, False), (1, 256, 6, True)])
 def test_stem7_forward_kernel(K, N, H, Ci, relu):
     """csrc/stem7.hip (7x7 / stride 2 / pad 3 stems, NCHW planes -> NHWC) against torch float64 and the generic kernel."""
