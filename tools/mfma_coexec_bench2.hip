@@ -1,5 +1,5 @@
 // What issues under a running MFMA on gfx950?  32 v_mfma_f32_32x32x2_f32 per iteration (two accumulators) with, per
-// MFMA pair: MODE 0 nothing, 1: 4 v_fma_f32, 2: 4 s_add_u32, 3: 1 ds_read_b128 (result unused until the end),
+// MFMA pair: MODE 0 nothing, 1: 4 v_fma_f32, 3: 1 ds_read_b128 (result used at the end of the iteration),
 // 4: 2 ds_read_b32, 5: 1 workgroup barrier per 32 MFMAs, 6: 1 buffer_load_dwordx4 (L2-resident) per 4 MFMAs.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -68,7 +68,6 @@ int main() {
     for (int w = 1; w <= 2; ++w) {
         run<0>("MFMA only", w, d_out, d_src);
         run<1>("+ 2 v_fma_f32 per MFMA", w, d_out, d_src);
-        run<2>("+ 2 s_add_u32 per MFMA", w, d_out, d_src);
         run<3>("+ 0.5 ds_read_b128 (+ 0.5 v_add) per MFMA", w, d_out, d_src);
         run<4>("+ 1 ds_read_b32 (+ 1 v_add) per MFMA", w, d_out, d_src);
         run<5>("+ 1 s_barrier per 32 MFMA", w, d_out, d_src);
