@@ -237,14 +237,14 @@ __global__ void __launch_bounds__(256) wgrad_s1_kernel(WgradArgs a) {
     const int tky = t0 / a.kw, dy = tky - a.pad, dx0 = t0 - tky * a.kw - a.pad;       // taps (dy, dx0 + j), j < NT
     const int hw = a.Ho * a.Wo;
     // validity windows: (unsigned)(t - lo_t) < n_t  and  (unsigned)(x - lo_x[j]) < n_x[j]
-    const unsigned lo_t = dy < 0 ? (unsigned)(-dy * a.Wo) : 0u, n_t = (unsigned)(hw - (dy < 0 ? -dy : dy) * a.Wo);
+    const unsigned lo_t = dy < 0 ? (unsigned)(-dy * a.Wo) : 0u, n_t = (unsigned)max(0, hw - (dy < 0 ? -dy : dy) * a.Wo);   // (0: kernel taller than the map)
     unsigned lo_x[NT], n_x[NT];
     __amdgpu_buffer_rsrc_t rsQ[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int dx = dx0 + j;
         lo_x[j] = dx < 0 ? (unsigned)(-dx) : 0u;
-        n_x[j] = (unsigned)(a.Wo - (dx < 0 ? -dx : dx));
+        n_x[j] = (unsigned)max(0, a.Wo - (dx < 0 ? -dx : dx));
         const long long shift = (long long)(dy * a.Wo + dx) * a.Cq;      // elements: the tap shift is folded into the base
         rsQ[j] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Q + shift), 0, 0x80000000u, 0x00020000);
     }

@@ -369,7 +369,7 @@ def test_dgrad_epilogue_accumulates_batchnorm_backward_sums(K, N, H, C, Co, grou
 
 
 @pytest.mark.parametrize("N,H,Ci,Co,k", [(2, 8, 64, 64, 3), (1, 32, 64, 128, 3), (3, 16, 128, 64, 3), (2, 4, 64, 64, 3),
-                                         (2, 16, 64, 128, 1), (1, 16, 64, 64, 5)])
+                                         (2, 16, 64, 128, 1), (1, 16, 64, 64, 5), (8, 2, 64, 64, 7)])
 def test_wgrad_stride1_fast_path_matches_generic_kernel(K, N, H, Ci, Co, k):
     """wgrad_s1_kernel<1> / <3> (tap shift folded into the buffer base, window tests for the borders) against the generic
     split-K kernel and torch float64, including maps narrower than the tile step and a 5x5 kernel."""
