@@ -100,6 +100,34 @@ __device__ __forceinline__ void bn_coeffs(const double* __restrict__ stats, cons
     shift = (beta ? beta[c] : 0.f) - mean * scale;
 }
 
+// The same in two phases, so that a streaming kernel can put its first data loads BETWEEN the (tiny) table loads and the
+// arithmetic: VALU work is not hidden by other waves on this chip, and with eight waves per SIMD starting together the
+// ~300 instructions of four channels' coefficients used to delay the first load of every wave by microseconds.
+struct BnRaw { double s1, s2; float gm, bt; };
+__device__ __forceinline__ BnRaw bn_raw(const double* __restrict__ stats, const float* __restrict__ gamma,
+                                        const float* __restrict__ beta, const float* __restrict__ rmean,
+                                        const float* __restrict__ rvar, int use_running, int groups, int grp, int C, int c) {
+    BnRaw r;
+    if (use_running) { r.s1 = rmean[c]; r.s2 = rvar[c]; }
+    else { r.s1 = bn_sum_total(stats, groups, grp, C, c, 0); r.s2 = bn_sum_total(stats, groups, grp, C, c, 1); }
+    r.gm = gamma ? gamma[c] : 1.f;
+    r.bt = beta ? beta[c] : 0.f;
+    return r;
+}
+__device__ __forceinline__ void bn_coeffs_from_raw(const BnRaw& r, int use_running, float eps, double inv_rows, float& mean,
+                                                   float& invstd, float& scale, float& shift) {
+    if (use_running) { mean = (float)r.s1; invstd = 1.0f / sqrtf((float)r.s2 + eps); }
+    else {
+        const double m = r.s1 * inv_rows;
+        double var = r.s2 * inv_rows - m * m;
+        if (var < 0) var = 0;
+        mean = (float)m;
+        invstd = 1.0f / sqrtf((float)var + eps);
+    }
+    scale = r.gm * invstd;
+    shift = r.bt - mean * scale;
+}
+
 // grid (nblk, groups)
 __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ rmean,
@@ -109,25 +137,47 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__
                                                        float* __restrict__ upd_mean, float* __restrict__ upd_var) {
     const int cq = threadIdx.x % g.LPR, r0 = threadIdx.x / g.LPR;
     const int grp = blockIdx.y;
+    BnRaw raw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) raw[i] = bn_raw(stats, gamma, beta, rmean, rvar, use_running, g.groups, grp, g.C, cq * 4 + i);
+    const size_t gbase = ((size_t)grp * g.rows) * g.C + cq * 4;
+    const bool relu = flags & 1, addres = (flags & 2) && res;
+    // four rows per lane and pass; the loads of the first pass are issued before the coefficient arithmetic
+    const int stride = gridDim.x * g.RPP;
+    int r = blockIdx.x * g.RPP + r0;
+    float4 a[4], q[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int rr = r + u * stride;
+        a[u] = rr < g.rows ? *reinterpret_cast<const float4*>(x + gbase + (size_t)rr * g.C) : make_float4(0.f, 0.f, 0.f, 0.f);
+        q[u] = (addres && rr < g.rows) ? *reinterpret_cast<const float4*>(res + gbase + (size_t)rr * g.C) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     float sc[4], sh[4];
+    const double inv_rows = 1.0 / (double)g.rows;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float m, is;
-        bn_coeffs(stats, gamma, beta, rmean, rvar, use_running, g.groups, grp, g.C, cq * 4 + i, eps, (double)g.rows, m, is, sc[i], sh[i]);
+        bn_coeffs_from_raw(raw[i], use_running, eps, inv_rows, m, is, sc[i], sh[i]);
     }
     if (upd_mean && blockIdx.x == 0 && blockIdx.y == 0) bn_update_running(stats, g, momentum, upd_mean, upd_var);
-    const size_t gbase = ((size_t)grp * g.rows) * g.C + cq * 4;
-    const bool relu = flags & 1, addres = (flags & 2) && res;
-    for (int r = blockIdx.x * g.RPP + r0; r < g.rows; r += gridDim.x * g.RPP) {
-        const size_t off = gbase + (size_t)r * g.C;
-        float4 a = *reinterpret_cast<const float4*>(x + off);
-        float4 o = make_float4(a.x * sc[0] + sh[0], a.y * sc[1] + sh[1], a.z * sc[2] + sh[2], a.w * sc[3] + sh[3]);
-        if (addres) {
-            float4 q = *reinterpret_cast<const float4*>(res + off);
-            o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
+    while (true) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r + u * stride;
+            if (rr >= g.rows) break;
+            float4 o = make_float4(a[u].x * sc[0] + sh[0], a[u].y * sc[1] + sh[1], a[u].z * sc[2] + sh[2], a[u].w * sc[3] + sh[3]);
+            if (addres) { o.x += q[u].x; o.y += q[u].y; o.z += q[u].z; o.w += q[u].w; }
+            if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            *reinterpret_cast<float4*>(y + gbase + (size_t)rr * g.C) = o;
         }
-        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-        *reinterpret_cast<float4*>(y + off) = o;
+        r += 4 * stride;
+        if (r >= g.rows) break;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r + u * stride;
+            a[u] = rr < g.rows ? *reinterpret_cast<const float4*>(x + gbase + (size_t)rr * g.C) : make_float4(0.f, 0.f, 0.f, 0.f);
+            q[u] = (addres && rr < g.rows) ? *reinterpret_cast<const float4*>(res + gbase + (size_t)rr * g.C) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
 }
 
@@ -217,23 +267,56 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
                                                            float* __restrict__ ggamma, float* __restrict__ gbeta) {
     const int cq = threadIdx.x % g.LPR, r0 = threadIdx.x / g.LPR;
     const int grp = blockIdx.y;
-    float mean[4], invstd[4], sc[4], sh[4], k1[4], k2[4];
+    // table loads first, then the data loads of the first pass, then the coefficient arithmetic (see bn_raw)
+    BnRaw raw[4];
+    float4 cf4[4];
+    double rs1[4], rs2[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = cq * 4 + i;
+        cf4[i] = make_float4(0.f, 0.f, 0.f, 0.f); rs1[i] = 0; rs2[i] = 0;
         if (coef) {
-            const float4 q = coef[(size_t)grp * g.C + c];        // (mean, invstd, mean dy, mean dy*xhat) from the finalize kernel
-            mean[i] = q.x; invstd[i] = q.y; k1[i] = q.z; k2[i] = q.w;
-            sc[i] = (gamma ? gamma[c] : 1.f) * q.y;
-            sh[i] = (beta ? beta[c] : 0.f) - q.x * sc[i];
+            cf4[i] = coef[(size_t)grp * g.C + c];        // (mean, invstd, mean dy, mean dy*xhat) from the finalize kernel
+            raw[i].gm = gamma ? gamma[c] : 1.f; raw[i].bt = beta ? beta[c] : 0.f; raw[i].s1 = 0; raw[i].s2 = 0;
         } else {
             // the gradient sums were accumulated by the dgrad that produced gy (bh_conv_dgrad_bnreduce): no reduce /
             // finalize launches, the coefficients come straight from the two padded sums tables
-            bn_coeffs(stats, gamma, beta, nullptr, nullptr, 0, g.groups, grp, g.C, c, eps, (double)g.rows, mean[i], invstd[i],
-                      sc[i], sh[i]);
-            const float invn = 1.0f / (float)g.rows;
-            k1[i] = (float)bn_sum_total(sums, g.groups, grp, g.C, c, 0) * invn;
-            k2[i] = (float)bn_sum_total(sums, g.groups, grp, g.C, c, 1) * invn;
+            raw[i] = bn_raw(stats, gamma, beta, nullptr, nullptr, 0, g.groups, grp, g.C, c);
+            rs1[i] = bn_sum_total(sums, g.groups, grp, g.C, c, 0);
+            rs2[i] = bn_sum_total(sums, g.groups, grp, g.C, c, 1);
+        }
+    }
+    const size_t gbase = ((size_t)grp * g.rows) * g.C + cq * 4;
+    const bool relu = flags & 1, mask_from_x = flags & 4;
+    const bool rd_y = relu && !mask_from_x;
+    const int stride = gridDim.x * g.RPP;
+    int r = blockIdx.x * g.RPP + r0;
+    float4 dv[4], av[4], yv[4];
+    auto issue = [&](int rb) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = rb + u * stride;
+            const size_t off = gbase + (size_t)rr * g.C;
+            const bool ok = rr < g.rows;
+            dv[u] = ok ? *reinterpret_cast<const float4*>(gy + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            av[u] = ok ? *reinterpret_cast<const float4*>(x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            yv[u] = (ok && rd_y) ? *reinterpret_cast<const float4*>(y + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    issue(r);
+    float mean[4], invstd[4], sc[4], sh[4], k1[4], k2[4];
+    const double inv_rows = 1.0 / (double)g.rows;
+    const float invn = 1.0f / (float)g.rows;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (coef) {
+            mean[i] = cf4[i].x; invstd[i] = cf4[i].y; k1[i] = cf4[i].z; k2[i] = cf4[i].w;
+            sc[i] = raw[i].gm * cf4[i].y;
+            sh[i] = raw[i].bt - cf4[i].x * sc[i];
+        } else {
+            bn_coeffs_from_raw(raw[i], 0, eps, inv_rows, mean[i], invstd[i], sc[i], sh[i]);
+            k1[i] = (float)rs1[i] * invn;
+            k2[i] = (float)rs2[i] * invn;
         }
     }
     if (!coef && (ggamma || gbeta) && blockIdx.x == 0 && blockIdx.y == 0) {       // dgamma / dbeta: totals over the groups
@@ -247,28 +330,34 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
             if (gbeta) gbeta[c] += (float)tb;
         }
     }
-    const size_t gbase = ((size_t)grp * g.rows) * g.C + cq * 4;
-    const bool relu = flags & 1, mask_from_x = flags & 4;
-    for (int r = blockIdx.x * g.RPP + r0; r < g.rows; r += gridDim.x * g.RPP) {
-        const size_t off = gbase + (size_t)r * g.C;
-        float4 d = *reinterpret_cast<const float4*>(gy + off);
-        float4 a = *reinterpret_cast<const float4*>(x + off);
-        if (relu) {
+    while (true) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r + u * stride;
+            if (rr >= g.rows) break;
+            const size_t off = gbase + (size_t)rr * g.C;
+            float4 d = dv[u];
+            const float4 a = av[u];
+            if (relu) {
+                float4 o;
+                if (mask_from_x) o = make_float4(a.x * sc[0] + sh[0], a.y * sc[1] + sh[1], a.z * sc[2] + sh[2], a.w * sc[3] + sh[3]);
+                else o = yv[u];
+                if (!(o.x > 0.f)) d.x = 0.f;
+                if (!(o.y > 0.f)) d.y = 0.f;
+                if (!(o.z > 0.f)) d.z = 0.f;
+                if (!(o.w > 0.f)) d.w = 0.f;
+            }
+            if (gres) *reinterpret_cast<float4*>(gres + off) = d;
             float4 o;
-            if (mask_from_x) o = make_float4(a.x * sc[0] + sh[0], a.y * sc[1] + sh[1], a.z * sc[2] + sh[2], a.w * sc[3] + sh[3]);
-            else o = *reinterpret_cast<const float4*>(y + off);
-            if (!(o.x > 0.f)) d.x = 0.f;
-            if (!(o.y > 0.f)) d.y = 0.f;
-            if (!(o.z > 0.f)) d.z = 0.f;
-            if (!(o.w > 0.f)) d.w = 0.f;
+            o.x = sc[0] * (d.x - k1[0] - (a.x - mean[0]) * invstd[0] * k2[0]);
+            o.y = sc[1] * (d.y - k1[1] - (a.y - mean[1]) * invstd[1] * k2[1]);
+            o.z = sc[2] * (d.z - k1[2] - (a.z - mean[2]) * invstd[2] * k2[2]);
+            o.w = sc[3] * (d.w - k1[3] - (a.w - mean[3]) * invstd[3] * k2[3]);
+            *reinterpret_cast<float4*>(gx + off) = o;
         }
-        if (gres) *reinterpret_cast<float4*>(gres + off) = d;
-        float4 o;
-        o.x = sc[0] * (d.x - k1[0] - (a.x - mean[0]) * invstd[0] * k2[0]);
-        o.y = sc[1] * (d.y - k1[1] - (a.y - mean[1]) * invstd[1] * k2[1]);
-        o.z = sc[2] * (d.z - k1[2] - (a.z - mean[2]) * invstd[2] * k2[2]);
-        o.w = sc[3] * (d.w - k1[3] - (a.w - mean[3]) * invstd[3] * k2[3]);
-        *reinterpret_cast<float4*>(gx + off) = o;
+        r += 4 * stride;
+        if (r >= g.rows) break;
+        issue(r);
     }
 }
 
