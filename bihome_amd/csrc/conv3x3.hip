@@ -113,6 +113,28 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
             boff[i] = n < a.Nn ? ((unsigned)(k * 9) * (unsigned)a.Cw + (unsigned)n) * 4u : OOB;
         }
     }
+    const int nch = a.dbg_nch >= 0 ? a.dbg_nch : a.Kc / 32;     // (ablation hook: bh_debug_force_tile(-8, n) caps the chunk loop)
+    // a single chunk (32 source channels) never touches the second halo stage: the host then launches with one stage less
+    // of LDS (41.6 instead of 67.2 KB: three workgroups per CU for the 32-channel layers) and the slabs move down
+    const int slab0 = (a.Kc / 32 > 1 ? 2 : 1) * HALO_B;
+#define issue_B(c, tap, bs)                                                                                             \
+    do {                                                                                                                \
+        const unsigned soff_ = FLIP ? (unsigned)(((c) * 32 * 9 + (8 - (tap))) * a.Cw) * 4u                             \
+                                    : (unsigned)((tap) * a.Cw + (c) * 32) * 4u;                                        \
+        char* base_ = smem + slab0 + (bs) * C3_B_BYTES + wave * 1024;                                              \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_ptr)(base_), 16, boff[0], soff_, 0, 0);                 \
+        if (BINS == 2)                                                                                                  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_ptr)(base_ + 4096), 16, boff[1], soff_, 0, 0); \
+    } while (0)
+    // (the last wave instruction of a stage is partial - 64 resp. 32 of its lanes: the others are masked off, an
+    //  out-of-range lane would still write zeros past the stage)
+#define C3_ISSUE_HALO(j, c, hs)                                                                                         \
+    do {                                                                                                                \
+        if ((j) < HJ && (j) * 4 + wave < HINS && (((j) * 4 + wave) * 64 + lane) < 8 * HPL)                              \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_ptr)(smem + (hs) * HALO_B + ((j) * 4 + wave) * 1024), \
+                                                     16, hoff[(j) < HJ ? (j) : 0], (unsigned)((c) * 32) * 4u, 0, 0);    \
+    } while (0)
+
     // A workgroup walks a.tpb consecutive tile positions (two on the launches that would otherwise be exactly two rounds of
     // resident workgroups: the second tile starts whenever the first is done instead of waiting for a dispatch slot, and
     // its prologue loads queue behind the first tile's stores without a launch-wide phase change)
@@ -134,6 +156,7 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
         oy0[s] = ty * 8 - 1; ox0[s] = tx * 8 - 1;
         org[s] = g < a.subtiles ? (img * a.H + oy0[s]) * a.W + ox0[s] : (int)0x80000000;
     }
+    issue_B(0, 0, 0);                            // the first weight slab goes out before any of the slot arithmetic
     unsigned hoff[7] = {OOB, OOB, OOB, OOB, OOB, OOB, OOB};   // (fixed size, first HJ used: see the note at boff)
 #pragma unroll
     for (int j = 0; j < HJ; ++j) {
@@ -150,35 +173,14 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
                 off = ((unsigned)(o + hy * a.W + hx) * (unsigned)a.Kc + (unsigned)(plane * 4)) * 4u;
         }
         hoff[j] = off;
+        C3_ISSUE_HALO(j, 0, 0);              // in flight while the next slot's offset is computed
     }
-#define issue_B(c, tap, bs)                                                                                             \
-    do {                                                                                                                \
-        const unsigned soff_ = FLIP ? (unsigned)(((c) * 32 * 9 + (8 - (tap))) * a.Cw) * 4u                             \
-                                    : (unsigned)((tap) * a.Cw + (c) * 32) * 4u;                                        \
-        char* base_ = smem + slab0 + (bs) * C3_B_BYTES + wave * 1024;                                              \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_ptr)(base_), 16, boff[0], soff_, 0, 0);                 \
-        if (BINS == 2)                                                                                                  \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_ptr)(base_ + 4096), 16, boff[1], soff_, 0, 0); \
-    } while (0)
-    // (the last wave instruction of a stage is partial - 64 resp. 32 of its lanes: the others are masked off, an
-    //  out-of-range lane would still write zeros past the stage)
-#define C3_ISSUE_HALO(j, c, hs)                                                                                         \
-    do {                                                                                                                \
-        if ((j) < HJ && (j) * 4 + wave < HINS && (((j) * 4 + wave) * 64 + lane) < 8 * HPL)                              \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_ptr)(smem + (hs) * HALO_B + ((j) * 4 + wave) * 1024), \
-                                                     16, hoff[(j) < HJ ? (j) : 0], (unsigned)((c) * 32) * 4u, 0, 0);    \
-    } while (0)
-
     f32x16 acc[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
-    const int nch = a.dbg_nch >= 0 ? a.dbg_nch : a.Kc / 32;     // (ablation hook: bh_debug_force_tile(-8, n) caps the chunk loop)
-    // a single chunk (32 source channels) never touches the second halo stage: the host then launches with one stage less
-    // of LDS (41.6 instead of 67.2 KB: three workgroups per CU for the 32-channel layers) and the slabs move down
-    const int slab0 = (a.Kc / 32 > 1 ? 2 : 1) * HALO_B;
     // lane-constant parts of the fragment addresses (bytes)
     // GEMM row l31 of a wave's 32-row fragment <-> pixel (c3_strip_row(l31 >> 2), 4 * strip + (l31 & 3)) of the 8x8 sub-tile:
     // an 8-row x 4-column strip, strip = wh for the 32-row waves, = the fragment index i for the 64-row waves.
@@ -189,9 +191,6 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
     const int a_lane = (kh2 * HPL + wm * 100 + c3_strip_row(l31 >> 2) * 10 + wh * 4 + (l31 & 3)) * 16;
     const int b_lane = FLIP ? (kh2 * 4 * BN + wn * 32 + l31) * 4 : (kh2 * BN + wn * 32 + l31) * 16;
 
-#pragma unroll
-    for (int j = 0; j < HJ; ++j) C3_ISSUE_HALO(j, 0, 0);
-    issue_B(0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
