@@ -50,9 +50,10 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, seed=42, batch=8, steps=3, warmup=1):
+def cpu_baseline(cfg, seed=42, batch=8, steps=20, warmup=1):
     """The oracle (plain PyTorch-CPU restatement of the same modules, oracle/bihome_oracle.py) timed on this
-    box's host cores: a bounded sample (bs=8, `steps` full train steps) of the same workload."""
+    box's host cores: a bounded sample (bs=8, `steps` full train steps, ~10 s of CPU work, capped at 40 s) of the same
+    workload."""
     from bihome_amd import synth
     from bihome_amd.weights import load_synthetic
     from oracle import bihome_oracle as O
