@@ -59,6 +59,7 @@ class Model(nn.Module):
             load_imagenet_resnet34(self, pre)
             net.to_kernel_layout_(self)
         self._runner = None
+        net.install_counter_hooks(self)
 
     def _build(self):
         r = self.resnet34

@@ -79,6 +79,7 @@ class Model(nn.Module):
         self.precision = kwargs.get('PRECISION', os.environ.get('BIHOME_PRECISION', 'f32'))
         net.to_kernel_layout_(self)
         self._runner = None
+        net.install_counter_hooks(self)
         self.fuse_tail = os.environ.get("BIHOME_FUSE_TAIL", "1") != "0"
         if isinstance(pre, str) and pre:           # path of the torchvision resnet34 ImageNet state dict (Rethinking.py:158-282)
             from ..weights import load_imagenet_resnet34

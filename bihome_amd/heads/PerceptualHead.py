@@ -64,6 +64,8 @@ class AuxiliaryResnet(nn.Module):
         self.precision = kwargs.get('PRECISION', os.environ.get('BIHOME_PRECISION', 'f32'))
         net.to_kernel_layout_(self)
         self._runners = {}
+        self._fold = {}             # one BatchNorm-folding cache for every program over these modules
+        net.install_counter_hooks(self)
 
     @staticmethod
     def _gray_weight(w):
@@ -80,7 +82,7 @@ class AuxiliaryResnet(nn.Module):
             s = prog.maxpool(s)
             for blk in r.layer1:
                 s = prog.basic_block(s, blk)
-            self._runners[in_ch] = net.Runner(self, prog, trainable=False, precision=self.precision)
+            self._runners[in_ch] = net.Runner(self, prog, trainable=False, precision=self.precision, fold_cache=self._fold)
         return self._runners[in_ch]
 
     def forward(self, x, groups=1):
@@ -296,7 +298,13 @@ class Model(nn.Module):
 
     def _choices(self, data, key, B, N, device):
         if key in data:                                         # test hook: indices supplied (bit-exact pin)
-            return data[key].to(device=device, dtype=torch.int64).reshape(B, -1).contiguous()
+            c = data[key].to(device=device, dtype=torch.int64).reshape(B, -1).contiguous()
+            # the DLT kernels gather pf[id] and scatter-add into g_pf[id]: caller-supplied indices must lie in [0, N).
+            # (Host check with a device sync: this hook is the test / replay path; indices drawn by `sample_choice` are in
+            # range by construction.  A device-side assert would abort the process on ROCm instead of raising.)
+            if c.numel() and not bool(((c >= 0) & (c < N)).all()):
+                raise ValueError("bihome_amd: data['%s'] holds indices outside [0, %d)" % (key, N))
+            return c
         n, P = self.hypothesis_no, self.point_per_hypothesis
         return self.sample_choice(N, B * P * n, device).reshape(B, -1)
 

@@ -365,18 +365,22 @@ def conv_fwd(x, w, bias, d, bn_sums=None, groups=1, res=None, relu=False):
 _STEM_WT = {}
 
 
-def _stem_dgrad_two_step(gy, w, d):
+def _stem_dgrad_two_step(gy, w, d, wkey=None):
     """dgrad of the 1- or 3-input-channel 7x7/2 stem as (1x1 MFMA GEMM gy x w^T -> per-source-pixel tap table) + col2im.
-    w is the kernel-layout weight [Co][7][7][Ci]; the result is NCHW [N,Ci,Hi,Wi] (== NHWC for Ci = 1)."""
-    key = (w.data_ptr(), w._version, str(w.device), d.Ci)
+    w is the kernel-layout weight [Co][7][7][Ci]; the result is NCHW [N,Ci,Hi,Wi] (== NHWC for Ci = 1).
+    wkey: identity of the SOURCE parameter, (id(param), param._version) - `w` itself may be a per-forward temporary (the
+    extractor's channel-summed stem weight) whose address and version repeat although the parameter changed; without a
+    key the transposed table is rebuilt on every call (64 x 52 floats)."""
+    key = None if wkey is None else (wkey, str(w.device), d.Ci)
     cols = 49 * d.Ci
     ld = (cols + 3) // 4 * 4                                                          # 52 / 148
-    wt = _STEM_WT.get(key)
+    wt = _STEM_WT.get(key) if key is not None else None
     if wt is None:
-        _STEM_WT.clear()
         wt = torch.zeros(ld, 1, 1, d.Co, dtype=torch.float32, device=w.device)        # [tap*Ci + c, padded][Co]
         wt[:cols, 0, 0, :] = w.reshape(d.Co, cols).t()
-        _STEM_WT[key] = wt
+        if key is not None:
+            _STEM_WT.clear()
+            _STEM_WT[key] = wt
     d1 = conv_desc(d.N, d.Ho, d.Wo, d.Co, ld, 1, 1, 0, precision=d.precision)
     tm = conv_fwd(gy, wt, None, d1)                                                   # [N,Ho,Wo,ld]
     shape = (d.N, d.Hi, d.Wi, 1) if d.Ci == 1 else (d.N, d.Ci, d.Hi, d.Wi)
@@ -391,8 +395,9 @@ def dgrad_bn_reduce_ok(d):
     return _c3_variant(d, True) is not None
 
 
-def conv_dgrad(gy, w, d, out=None, bn_reduce=None):
-    """bn_reduce (only when dgrad_bn_reduce_ok(d)): dict(z, y, stats, gamma, beta, eps, relu, sums, groups) of the
+def conv_dgrad(gy, w, d, out=None, bn_reduce=None, wkey=None):
+    """wkey: (id(param), param._version) of the parameter `w` was derived from (cache key of derived weight tables).
+    bn_reduce (only when dgrad_bn_reduce_ok(d)): dict(z, y, stats, gamma, beta, eps, relu, sums, groups) of the
     BatchNorm whose output gradient this call completes - its backward sums are accumulated into `sums` (zeroed
     bn_stats_buffer) in the conv epilogue; pass them to bn_bwd(..., sums_ready=sums)."""
     _chk(gy); _chk(w)
@@ -409,7 +414,7 @@ def conv_dgrad(gy, w, d, out=None, bn_reduce=None):
         return out
     if (out is None and not d.transposed and d.kh == 7 and d.stride == 2 and not d.out_nchw
             and (d.Ci == 1 or (d.Ci == 3 and d.in_nchw)) and d.Co % 4 == 0 and d.N * d.Ho * d.Wo >= 4096):
-        return _stem_dgrad_two_step(gy, w, d)
+        return _stem_dgrad_two_step(gy, w, d, wkey)
     acc = out is not None
     if (not d.transposed and d.stride == 2 and not d.in_nchw and not d.out_nchw and d.Co % 4 == 0 and d.Ci % 4 == 0
             and d.Hi % 2 == 0 and d.Wi % 2 == 0 and d.Ho * 2 == d.Hi and d.Wo * 2 == d.Wi

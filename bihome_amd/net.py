@@ -179,10 +179,10 @@ class Program:
 
 class Ctx:
     """Saved tensors of one forward pass."""
-    __slots__ = ("slots", "stats", "descs", "groups", "training", "weights")
+    __slots__ = ("slots", "stats", "descs", "groups", "training", "weights", "wkeys")
 
     def __init__(self):
-        self.slots, self.stats, self.descs, self.weights = {}, {}, {}, {}
+        self.slots, self.stats, self.descs, self.weights, self.wkeys = {}, {}, {}, {}, {}
 
 
 def _conv_geometry(mod, x_shape, in_nchw, out_nchw, precision=0):
@@ -225,6 +225,14 @@ def _folded(cache, conv, bn, weight_fn):
         bf = bf.contiguous()
     cache[key] = (vers, wf, bf)
     return wf, bf
+
+
+def _momentum(bn):
+    """torch's momentum=None (cumulative moving average) is not built: the kernels replay one exponential update per
+    statistics group.  No reference module uses it (every BatchNorm2d upstream keeps the default 0.1)."""
+    if bn.momentum is None:
+        raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative average) is not supported by bihome_amd")
+    return bn.momentum
 
 
 def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None):
@@ -296,11 +304,12 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None):
                 out = K.conv_fwd(src, wk, op.mod.bias, d)
             if save:
                 ctx.descs[i], ctx.weights[i] = d, wk
+                ctx.wkeys[i] = (id(op.mod.weight), op.mod.weight._version)
         elif op.kind == "bn":
             m = op.mod
             res = slots[op.res] if op.res is not None else None
             out, st = K.bn_fwd(src, m.weight, m.bias, m.running_mean, m.running_var, res, groups, m.eps,
-                               m.momentum if m.momentum is not None else 0.1, op.relu, training,
+                               _momentum(m), op.relu, training,
                                stats=arena[bn_off[i]:bn_off[i] + K.bn_stats_doubles(groups, m.num_features)],
                                stats_ready=i in ready)
             if training:        # flushed to the `num_batches_tracked` buffer lazily (flush_counters): no per-layer launch
@@ -312,7 +321,7 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None):
             N, h, w, _ = src.shape
             out, ws = K.tail_fwd(src, kview(c1.weight), c1.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                  kview(c2.weight), c2.bias, groups, h * w, bn.eps,
-                                 bn.momentum if bn.momentum is not None else 0.1, training)
+                                 _momentum(bn), training)
             if training:
                 bn._bh_pending_batches = getattr(bn, "_bh_pending_batches", 0) + groups
             if save:
@@ -428,9 +437,9 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
                                groups=ctx.groups)
                     bn_reduced[b] = sums
                 if op.src in grads:
-                    K.conv_dgrad(g, wk, d, out=grads[op.src], bn_reduce=red)
+                    K.conv_dgrad(g, wk, d, out=grads[op.src], bn_reduce=red, wkey=ctx.wkeys[i])
                 else:
-                    grads[op.src] = K.conv_dgrad(g, wk, d, bn_reduce=red)
+                    grads[op.src] = K.conv_dgrad(g, wk, d, bn_reduce=red, wkey=ctx.wkeys[i])
         elif op.kind == "bn":
             m = op.mod
             train_w = want_wgrad and m.weight is not None and m.weight.requires_grad
@@ -449,11 +458,18 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
             c1, bn, c2 = op.mod
             tr = want_wgrad and c1.weight.requires_grad
             N, h, w, _ = x.shape
+            eval_b1 = tr and not ctx.training and c1.bias is not None and c1.bias.requires_grad
+            gbeta0 = bn.bias.grad.clone() if eval_b1 else None
             gx = K.tail_bwd(g, x, kview(c1.weight), c1.bias, bn.weight, bn.bias, kview(c2.weight), ctx.stats[i],
                             bn.running_mean, bn.running_var, ctx.groups, h * w, bn.eps, ctx.training, need_src_grad,
                             kview(c1.weight.grad) if tr else None, bn.weight.grad if tr else None,
                             bn.bias.grad if tr else None, kview(c2.weight.grad) if tr else None,
                             c2.bias.grad if (tr and c2.bias is not None) else None)
+            if eval_b1:
+                # eval-mode BatchNorm is a fixed affine map, so layer8.0.bias has a gradient (with batch statistics it is
+                # exactly zero and the fused kernel never forms it): g_b1 = g_beta * gamma / sqrt(running_var + eps)
+                with torch.no_grad():
+                    c1.bias.grad.add_((bn.bias.grad - gbeta0) * bn.weight * torch.rsqrt(bn.running_var + bn.eps))
             if tr and on_param_grad is not None:
                 for p_ in (c2.weight, c2.bias, bn.weight, bn.bias, c1.weight, c1.bias):
                     if p_ is not None:
@@ -469,6 +485,19 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
     if wgrad_stream is not None:
         main.wait_stream(wgrad_stream)          # the optimiser (and the release of the activations) follows
     return grads.get(0)
+
+
+def _drop_pending_counters(module, *unused):
+    for m in module.modules():
+        if getattr(m, "_bh_pending_batches", 0):
+            m._bh_pending_batches = 0
+
+
+def install_counter_hooks(module):
+    """load_state_dict replaces `num_batches_tracked`: calls counted on the host before the load must not be added on
+    top of the loaded value at the next state_dict()."""
+    module.register_load_state_dict_pre_hook(lambda *a, **k: _drop_pending_counters(module))
+    return module
 
 
 def flush_counters(module):
@@ -516,7 +545,7 @@ class NetFunction(torch.autograd.Function):
 class Runner:
     """Binds a Program to its nn.Module (parameter container) and, if trainable, a FlatGrads buffer."""
 
-    def __init__(self, module, prog, trainable, precision="f32"):
+    def __init__(self, module, prog, trainable, precision="f32", fold_cache=None):
         self.module, self.prog = module, prog
         self.precision = K.PRECISION[str(precision).lower()]     # conv operand precision (0 fp32, 1 bf16 operands)
         params = [p for p in module.parameters() if p.requires_grad]
@@ -524,7 +553,9 @@ class Runner:
         self.anchor = params[0] if (trainable and params) else None
         self._dummy = None
         self.reducer = None        # bihome_amd.ddp.FlatGradReducer when training data-parallel
-        self._fold = {}            # eval-mode BatchNorm folding cache (run_forward / _folded)
+        # eval-mode BatchNorm folding cache (run_forward / _folded); Runners over the SAME modules (the extractor's
+        # 1- and 3-channel programs) share one dict so that a training forward through either invalidates both
+        self._fold = fold_cache if fold_cache is not None else {}
         self.fold_bn = os.environ.get("BIHOME_FOLD_BN", "1") != "0"
         # opt-in (BIHOME_OVERLAP=1 or bench.py --overlap): +3% step throughput, but kernels of the two streams share the
         # GPU, so per-kernel durations (rocprof, the roofline leg) are no longer those of the kernel alone

@@ -105,4 +105,32 @@ def attach_reducer(model, bucket_bytes=8 << 20):
     r = backbone._runner
     r.flat.ensure(next(backbone.parameters()).device)
     r.reducer = FlatGradReducer(r.flat, bucket_bytes=bucket_bytes)
+    broadcast_model(model)
     return r.reducer
+
+
+def broadcast_model(model, src=0):
+    """What torch's DistributedDataParallel does at construction: every parameter and buffer (BatchNorm running
+    statistics, counters) of the replica is overwritten with rank `src`'s, so that replicas start identical whatever
+    each rank initialised or loaded.  No-op outside a process group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    from . import net
+    net.flush_counters(model)
+    seen = set()
+    with torch.no_grad():
+        for t in list(model.parameters()) + list(model.buffers()):
+            if id(t) in seen:
+                continue
+            seen.add(id(t))
+            if t.is_contiguous():
+                dist.broadcast(t.data, src)
+            else:                               # channels_last conv weights: broadcast the dense kernel-layout view
+                v = t.data.permute(0, 2, 3, 1) if t.dim() == 4 else None
+                if v is not None and v.is_contiguous():
+                    dist.broadcast(v, src)
+                else:
+                    c = t.data.contiguous()
+                    dist.broadcast(c, src)
+                    t.data.copy_(c)

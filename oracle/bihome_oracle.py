@@ -226,15 +226,19 @@ class ResNet34Backbone(nn.Module):
 # --------------------------------------------------------------------------------------------
 
 class AuxiliaryResnet(nn.Module):
-    """PerceptualHead.py:15-76 with AUXILIARY_RESNET='resnet34', OUTPUT_LAYER=1, frozen:
-    gray->3ch repeat (:52-53), conv1, bn1, relu, maxpool, layer1.  Weights frozen (:36-39) but the
-    BatchNorms still follow module.train()/eval() (batch statistics in training)."""
+    """PerceptualHead.py:15-76 with AUXILIARY_RESNET='resnet34', frozen: gray->3ch repeat (:52-53), conv1, bn1, relu,
+    maxpool, layer1 and - for AUXILIARY_RESNET_OUTPUT_LAYER 2/3/4 - layer2/3/4 (:62-67; the unused layers are Identity
+    upstream, so they own no state-dict keys).  Weights frozen (:36-39) but the BatchNorms still follow
+    module.train()/eval() (batch statistics in training)."""
 
-    def __init__(self):
+    def __init__(self, output_layer=1):
         super().__init__()
         full = _TVResNet34()
+        self.output_layer = int(output_layer)
         self.resnet = nn.Module()
         self.resnet.conv1, self.resnet.bn1, self.resnet.layer1 = full.conv1, full.bn1, full.layer1
+        for i in range(2, self.output_layer + 1):
+            setattr(self.resnet, "layer%d" % i, getattr(full, "layer%d" % i))
         for p in self.parameters():
             p.requires_grad = False
 
@@ -242,7 +246,10 @@ class AuxiliaryResnet(nn.Module):
         if x.shape[1] == 1:
             x = x.repeat(1, 3, 1, 1)
         r = self.resnet
-        return r.layer1(F.max_pool2d(F.relu(r.bn1(r.conv1(x))), 3, 2, 1))
+        x = r.layer1(F.max_pool2d(F.relu(r.bn1(r.conv1(x))), 3, 2, 1))
+        for i in range(2, self.output_layer + 1):
+            x = getattr(r, "layer%d" % i)(x)
+        return x
 
 
 def sample_choice(n_points, count, generator=None):
@@ -268,15 +275,17 @@ class BiHomEHead(nn.Module):
             self.hypothesis_no = kw["RANSAC_HYPOTHESIS_NO"]
             self.points_per_hypothesis = kw["POINTS_PER_HYPOTHESIS"]
         self.one_line = "one-line" in kw["TRIPLET_LOSS"]                                 # iHomE (:465-538)
-        assert kw["TRIPLET_DISTANCE"] == "l1" and not len(kw["MASK_KEYS"]) and not kw.get("MASK_CRD", False)
-        if self.one_line:
-            assert isinstance(kw["TRIPLET_MARGIN"], (int, float))
-        else:
-            assert "double-line" in kw["TRIPLET_LOSS"]
-            assert kw["TRIPLET_AGGREGATION"] == "channel-agnostic" and isinstance(kw["TRIPLET_MARGIN"], str)
-        self.triplet_margin = kw["TRIPLET_MARGIN"]
+        self.multihead = kw["TRIPLET_LOSS"] == ""                                        # :108,:230-235 -> multihead_resnet_loss
+        if not self.multihead:
+            assert kw["TRIPLET_DISTANCE"] == "l1" and not len(kw["MASK_KEYS"]) and not kw.get("MASK_CRD", False)
+            if self.one_line:
+                assert isinstance(kw["TRIPLET_MARGIN"], (int, float))
+            else:
+                assert "double-line" in kw["TRIPLET_LOSS"]
+                assert kw["TRIPLET_AGGREGATION"] == "channel-agnostic" and isinstance(kw["TRIPLET_MARGIN"], str)
+        self.triplet_margin = kw.get("TRIPLET_MARGIN")
         self.triplet_mu = kw.get("TRIPLET_MU", 0.0)
-        self.auxiliary_resnet = AuxiliaryResnet()
+        self.auxiliary_resnet = AuxiliaryResnet(kw.get("AUXILIARY_RESNET_OUTPUT_LAYER", 1))
         self.last = {}
 
     # -- DSAC ---------------------------------------------------------------------------------
@@ -318,13 +327,13 @@ class BiHomEHead(nn.Module):
         return warp_image(image, H), H
 
     def forward(self, data, choice_12=None, choice_21=None):                              # :148-235
-        if self.one_line:
+        if self.one_line or self.multihead:
             if not len(self.delta_hat_keys):
                 d12, H12, scores = self._delta_from_pf(data[self.pf_keys[0]], choice_12)
                 self.last.update(H_dlt_12=H12)
             else:
                 d12, scores = data[self.delta_hat_keys[0]], None
-            return self.one_line_loss(data, d12, scores)
+            return self.multihead_loss(data, d12, scores) if self.multihead else self.one_line_loss(data, d12, scores)
         if not len(self.delta_hat_keys):
             d12, H12, _ = self._delta_from_pf(data[self.pf_keys[0]], choice_12)
             d21, H21, _ = self._delta_from_pf(data[self.pf_keys[1]], choice_21)
@@ -361,6 +370,16 @@ class BiHomEHead(nn.Module):
         eye = torch.eye(3, dtype=h1.dtype).unsqueeze(0)
         ln3 = ((h1 @ h2 - eye) ** 2).sum()                                                # :660-662
         loss = ln1.sum() + ln2.sum() + self.triplet_mu * ln3                              # :656-665
+        if "summary_writer" in data:                                                      # :678-697 (log steps)
+            sw, step = data["summary_writer"], data["summary_writer_step"]
+            sw.add_scalars("feature_space", {"patch_1_f": f1.mean().item()}, step)
+            sw.add_scalars("feature_space", {"patch_2_f": f2.mean().item()}, step)
+            sw.add_scalars("feature_space", {"patch_1_f_prime": f1w.mean().item()}, step)
+            sw.add_scalars("loss_comp", {"l1": (f2 - f1w).abs().mean().item()}, step)
+            sw.add_scalars("loss_comp", {"l3": (f2 - f1).abs().mean().item()}, step)
+            sw.add_scalars("h", {"h1": ((h1 - eye) ** 2).sum().item()}, step)
+            sw.add_scalars("loss_den", {"l1_den": den1.min().item()}, step)
+            sw.add_scalars("loss_den", {"l2_den": den2.min().item()}, step)
         self.last.update(ln1=ln1.sum(), ln2=ln2.sum(), ln3=ln3, H_4pt_12=h1, H_4pt_21=h2, warp_12=p1w, warp_21=p2w,
                          mask_pooled_12=m1w, mask_pooled_21=m2w, f1=f1, f2=f2, f1w=f1w, f2w=f2w,
                          delta_hat_12=d12, delta_hat_21=d21)
@@ -369,7 +388,9 @@ class BiHomEHead(nn.Module):
     def one_line_loss(self, data, d12, scores=None):                                      # :320-538 ('one-line', 'l1')
         p1, p2 = data[self.patch_keys[0]], data[self.patch_keys[1]]
         B, n, i = d12.shape[0], self.hypothesis_no, self.patch_size
-        assert n == 1
+        if n > 1:                                                                         # :352,:361 (one copy per hypothesis)
+            p1 = p1.reshape(B, 1, i, i).repeat(1, n, 1, 1).reshape(B * n, 1, i, i)
+            p2 = p2.reshape(B, 1, i, i).repeat(1, n, 1, 1).reshape(B * n, 1, i, i)
         aux = self.auxiliary_resnet
         f1 = aux(p1)                                                                      # :358
         f2 = aux(p2)                                                                      # :367
@@ -387,10 +408,46 @@ class BiHomEHead(nn.Module):
             loss_mat = loss_mat * scores.reshape(B * n, 1, 1)                             # :508-511
         den = (m1w * m2).sum((-1, -2))                                                    # :523
         loss = ((m1w * m2 * loss_mat).sum((-1, -2)) / torch.max(den, torch.ones_like(den))).sum()   # :524-538
+        if "summary_writer" in data:                                                      # :678-692
+            sw, step = data["summary_writer"], data["summary_writer_step"]
+            eye = torch.eye(3, dtype=h1.dtype).unsqueeze(0)
+            sw.add_scalars("feature_space", {"patch_1_f": f1.mean().item()}, step)
+            sw.add_scalars("feature_space", {"patch_2_f": f2.mean().item()}, step)
+            sw.add_scalars("feature_space", {"patch_1_f_prime": f1w.mean().item()}, step)
+            sw.add_scalars("loss_comp", {"l1": (f2 - f1w).abs().mean().item()}, step)
+            sw.add_scalars("loss_comp", {"l3": (f2 - f1).abs().mean().item()}, step)
+            sw.add_scalars("h", {"h1": ((h1 - eye) ** 2).sum().item()}, step)
         self.last.update(H_4pt_12=h1, warp_12=p1w, mask_pooled_12=m1w, f1=f1, f2=f2, f1w=f1w, delta_hat_12=d12)
         if scores is not None:
             d12 = (d12 * scores.reshape(B * n, 1, 1)).reshape(B, n, 4, 2).sum(1)          # :708-710
         return loss, data.get("delta"), d12
+
+    def multihead_loss(self, data, d12, scores=None):                                     # :245-315 (TRIPLET_LOSS == '')
+        """Returns (ground_truth, network_output, delta_gt, delta_hat) = (features of patch_2, features of the warped
+        patch_1, ...): the driver applies a torch loss to the first two (train.py:318-322)."""
+        p1, p2 = data[self.patch_keys[0]], data[self.patch_keys[1]]
+        B, n, i = d12.shape[0], self.hypothesis_no, self.patch_size
+        p1 = p1.reshape(B, 1, i, i).repeat(1, n, 1, 1).reshape(B * n, 1, i, i)           # :265
+        p2 = p2.reshape(B, 1, i, i).repeat(1, n, 1, 1).reshape(B * n, 1, i, i)           # :268
+        aux = self.auxiliary_resnet
+        f2 = aux(p2)                                                                      # :269
+        d12 = d12.reshape(B * n, 4, 2)
+        p1w, h1 = self._warp(p1, d12)                                                     # :272
+        f1w = aux(p1w)                                                                    # :273
+        if scores is not None:                                                            # :276-280
+            sc = scores.reshape(B * n, 1, 1, 1)
+            f1w, f2 = f1w * sc, f2 * sc
+        if "summary_writer" in data:                                                      # :286-298
+            sw, step = data["summary_writer"], data["summary_writer_step"]
+            eye = torch.eye(3, dtype=h1.dtype).unsqueeze(0)
+            sw.add_scalars("feature_space", {"patch_2_f": f2.mean().item()}, step)
+            sw.add_scalars("feature_space", {"patch_1_f_prime": f1w.mean().item()}, step)
+            sw.add_scalars("loss_comp", {"l1": (f2 - f1w).abs().mean().item()}, step)
+            sw.add_scalars("h", {"h1": ((h1 - eye) ** 2).sum().item()}, step)
+        self.last.update(H_4pt_12=h1, warp_12=p1w, f2=f2, f1w=f1w)
+        if scores is not None:                                                            # :309-312
+            d12 = (d12 * scores.reshape(B * n, 1, 1)).reshape(B, n, 4, 2).sum(1)
+        return f2, f1w, data.get("delta"), d12                                            # :315
 
     def predict_homography(self, data, choice=None):                                      # :716-767
         if len(self.delta_hat_keys):
@@ -458,7 +515,7 @@ def train_step(bb, head, opt, sched, data, choice_12=None, choice_21=None, clip=
     bb.train(); head.train()
     opt.zero_grad()
     if loss_fn is not None:
-        ground_truth, network_output, delta_gt, delta_hat = head(bb(data))
+        ground_truth, network_output, delta_gt, delta_hat = head(bb(data), choice_12, choice_21)
         loss = loss_fn(ground_truth, network_output)
     else:
         loss, delta_gt, delta_hat = head(bb(data), choice_12, choice_21)

@@ -1,0 +1,120 @@
+"""Regression tests for host-side state bugs found in review (round-1 ADVICE.md): derived-weight caches, BatchNorm call
+counters, eval-mode gradients of the fused tail, index validation of caller-supplied DSAC samples."""
+import numpy as np
+import pytest
+import torch
+
+from bihome_amd import configs, synth
+from bihome_amd.weights import load_synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def cuda(a, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(a)).to(dtype).cuda()
+
+
+def relerr(a, ref):
+    a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    return np.abs(a - ref).max() / (np.abs(ref).max() + 1e-30)
+
+
+def _head_grad(head, d, ch):
+    data = {k: cuda(d[k]) for k in ("patch_1", "patch_2", "delta", "pf_hat_12", "pf_hat_21")}
+    data["pf_hat_12"].requires_grad_(True)
+    data["pf_hat_21"].requires_grad_(True)
+    data["choice_12"], data["choice_21"] = ch[0].cuda(), ch[1].cuda()
+    loss, _, _ = head(data)
+    loss.backward()
+    return loss.item(), data["pf_hat_12"].grad.cpu().numpy()
+
+
+def test_extractor_stem_dgrad_follows_weight_reload():
+    """The 1-channel extractor stem's dgrad uses a transposed tap table derived from a per-forward temporary (the
+    channel-summed weight); reloading the frozen extractor's weights after a step must change the gradient that reaches
+    the perspective field exactly as a fresh model with those weights does."""
+    from bihome_amd.step import build_model
+    cfg = configs.get("zeng-bihome")
+    d = synth.make_head_inputs(4, 3)
+    g = torch.Generator().manual_seed(1)
+    ch = [torch.randint(1, 128 * 128, (4, 128), generator=g) for _ in range(2)]
+    headA = build_model(cfg)[1].train()
+    load_synthetic(headA.auxiliary_resnet, 0)
+    l0, g0 = _head_grad(headA, d, ch)
+    load_synthetic(headA.auxiliary_resnet, 5)              # same tensors, new values (copy_ into the parameters)
+    l1, g1 = _head_grad(headA, d, ch)
+    headB = build_model(cfg)[1].train()
+    load_synthetic(headB.auxiliary_resnet, 5)
+    l2, g2 = _head_grad(headB, d, ch)
+    assert abs(l1 - l2) <= 1e-6 * abs(l2)
+    assert relerr(g1, g2) < 1e-5
+    assert relerr(g0, g2) > 1e-2                           # the two weight sets really differ
+
+
+def test_fused_tail_eval_mode_bias_gradient():
+    """With BatchNorm on running statistics (model.eval(), gradients enabled: fine-tuning with frozen BN) layer8.0.bias
+    has a non-zero gradient; the fused tail must deliver the same one as the unfused conv / bn / conv program."""
+    import importlib
+    bcfg = configs.get("zeng-bihome")["MODEL"]["BACKBONE"]
+    Model = importlib.import_module("src.backbones.Rethinking").Model
+    d = synth.make_pairs(2, seed=4)
+    grads = {}
+    for fuse in (True, False):
+        bb = Model(**bcfg).cuda()
+        load_synthetic(bb, 0)
+        with torch.no_grad():                              # non-trivial running statistics
+            for m in bb.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.running_var.mul_(1.7)
+                    m.running_mean.add_(0.05)
+        bb.fuse_tail = fuse
+        bb.eval()
+        out = bb({k: cuda(d[k]) for k in ("patch_1", "patch_2")})
+        (out["pf_hat_12"].square().sum() + out["pf_hat_21"].sum()).backward()
+        grads[fuse] = {n: p.grad.detach().cpu().numpy().copy() for n, p in bb.named_parameters()}
+    gb = grads[False]["layer8.0.bias"]
+    assert np.abs(gb).max() > 0
+    assert relerr(grads[True]["layer8.0.bias"], gb) < 1e-4
+    for n in ("layer8.0.weight", "layer8.1.weight", "layer8.3.weight", "layer7.0.upper_branch.0.weight"):
+        assert relerr(grads[True][n], grads[False][n]) < 2e-4, n
+
+
+def test_choice_out_of_range_is_rejected():
+    from bihome_amd.step import build_model
+    cfg = configs.get("zeng-bihome")
+    head = build_model(cfg)[1].train()
+    load_synthetic(head.auxiliary_resnet, 0)
+    d = synth.make_head_inputs(2, 3)
+    data = {k: cuda(d[k]) for k in ("patch_1", "patch_2", "delta", "pf_hat_12", "pf_hat_21")}
+    bad = torch.randint(0, 128 * 128, (2, 128))
+    bad[1, 7] = 128 * 128                                  # one past the end
+    data["choice_12"], data["choice_21"] = bad.cuda(), bad.clamp(max=128 * 128 - 1).cuda()
+    with pytest.raises(ValueError, match="outside"):
+        head(data)
+
+
+def test_batchnorm_counters_after_load_state_dict():
+    """num_batches_tracked: calls counted on the host before load_state_dict are dropped, calls after it are added to the
+    loaded value (2 statistics groups per stacked forward)."""
+    from bihome_amd.step import build_model
+    cfg = configs.get("zeng-bihome")
+    model = build_model(cfg)
+    load_synthetic(model[0], 0)
+    d = synth.make_pairs(2, seed=4)
+    data = {k: cuda(d[k]) for k in ("patch_1", "patch_2")}
+    model.train()
+    model[0](dict(data))
+    sd = model.state_dict()
+    key = "0.layer1.1.num_batches_tracked"
+    assert int(sd[key]) == 2
+    model[0](dict(data))                                   # pending +2, not flushed
+    sd7 = {k: (torch.full_like(v, 7) if k.endswith("num_batches_tracked") else v.clone()) for k, v in sd.items()}
+    model.load_state_dict(sd7)
+    assert int(model.state_dict()[key]) == 7
+    model[0](dict(data))
+    assert int(model.state_dict()[key]) == 9
+    bn = torch.nn.BatchNorm2d(64, momentum=None)
+    model[0].layer1[1].momentum = None
+    with pytest.raises(NotImplementedError):
+        model[0](dict(data))
+    model[0].layer1[1].momentum = bn.momentum if bn.momentum is not None else 0.1
