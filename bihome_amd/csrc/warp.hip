@@ -78,6 +78,16 @@ __global__ void __launch_bounds__(256) warp_fwd_kernel(const float* __restrict__
             float s = window_sum_16x4(cv, pool);
             if ((tx % pool) == 0 && (ty % pool) == 0)
                 cov[(size_t)b * (h / pool) * pw + (size_t)(y / pool) * pw + x / pool] = s / (float)(pool * pool);
+        } else if (pool > 16) {
+            // pool 32 (extractor output layer 4): the 16x16 tile is a quarter of one window - tile sum, one atomic add
+            // into the coverage the host zeroed before the launch
+            float s = window_sum_16x4(cv, 16);             // 16 x 4 strip of this wave
+            const int wave = threadIdx.x >> 6;
+            if ((threadIdx.x & 63) == 0) covrows[wave][0] = s;
+            __syncthreads();
+            if (threadIdx.x == 0)
+                atomicAdd(&cov[(size_t)b * (h / pool) * pw + (size_t)(y / pool) * pw + x / pool],
+                          (covrows[0][0] + covrows[1][0] + covrows[2][0] + covrows[3][0]) / (float)(pool * pool));
         } else {
             // pool 8 or 16: reduce 16x4 strip per wave to per-window-column sums, combine via LDS
             float s = window_sum_16x4(cv, pool);           // x: full pool (<=16) ; y: 4 rows
@@ -335,7 +345,7 @@ extern "C" {
 int bh_warp_fwd(const float* img, const double* H64, int B, int C, int h, int w, int pool, float* out, float* cov,
                 void* stream) {
     if (!H64 || B < 0 || (img && !out) || (!img && !cov)) return BH_E_BADARG;
-    if ((h % 16) || (w % 16) || (pool != 1 && pool != 2 && pool != 4 && pool != 8 && pool != 16)) return BH_E_UNSUPPORTED;
+    if ((h % 16) || (w % 16) || (pool != 1 && pool != 2 && pool != 4 && pool != 8 && pool != 16 && pool != 32) || (h % pool) || (w % pool)) return BH_E_UNSUPPORTED;
     if (B == 0) return BH_OK;
     if (pool == 4 && (w % 64) == 0) {
         const int rpt = (g_warp_rpt_fwd == 2 && h % 32 == 0) ? 2 : 1;
@@ -343,6 +353,10 @@ int bh_warp_fwd(const float* img, const double* H64, int B, int C, int h, int w,
         else hipLaunchKernelGGL(warp_fwd4_kernel<1>, dim3(w / 64, h / 16, B), dim3(256), 0, bh_stream(stream), img, H64, C, h, w, out, cov);
         BH_LAUNCH_CHECK();
         return BH_OK;
+    }
+    if (pool > 16 && cov) {       // quarter-window partial sums are added with atomics
+        hipError_t e = hipMemsetAsync(cov, 0, (size_t)B * (h / pool) * (w / pool) * sizeof(float), bh_stream(stream));
+        if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(warp_fwd_kernel, dim3(w / 16, h / 16, B), dim3(256), 0, bh_stream(stream), img, H64, C, h, w, pool,
                        out, cov);
@@ -353,7 +367,7 @@ int bh_warp_fwd(const float* img, const double* H64, int B, int C, int h, int w,
 int bh_warp_bwd(const float* img, const double* H64, const float* g_out, const float* g_cov, int B, int C, int h, int w,
                 int pool, double* gH, void* stream) {
     if (!H64 || !gH || B < 0 || (g_out && !img)) return BH_E_BADARG;
-    if ((h % 16) || (w % 16) || (pool != 1 && pool != 2 && pool != 4 && pool != 8 && pool != 16)) return BH_E_UNSUPPORTED;
+    if ((h % 16) || (w % 16) || (pool != 1 && pool != 2 && pool != 4 && pool != 8 && pool != 16 && pool != 32) || (h % pool) || (w % pool)) return BH_E_UNSUPPORTED;
     if (B == 0) return BH_OK;
     if (pool == 4 && (w % 64) == 0) {
         int rpt = g_warp_rpt_bwd;

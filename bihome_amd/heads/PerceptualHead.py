@@ -28,34 +28,52 @@ from .. import net
 # frozen ResNet-34 stem + layer1 (parameter container with torchvision's names)
 # -----------------------------------------------------------------------------------------------
 class _BasicBlock(nn.Module):
-    def __init__(self, c):
+    def __init__(self, cin, cout=None, stride=1):
         super().__init__()
-        self.conv1 = nn.Conv2d(c, c, 3, 1, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(c)
-        self.conv2 = nn.Conv2d(c, c, 3, 1, 1, bias=False)
-        self.bn2 = nn.BatchNorm2d(c)
+        cout = cin if cout is None else cout
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
         self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
 
 
 class _ResNetStem(nn.Module):
-    def __init__(self):
+    """conv1, bn1, layer1 .. layer<output_layer> of a torchvision resnet34 (the later layers are Identity upstream and own
+    no parameters: PerceptualHead.py:26-33)."""
+
+    def __init__(self, output_layer=1):
         super().__init__()
         self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
-        self.layer1 = nn.Sequential(_BasicBlock(64), _BasicBlock(64), _BasicBlock(64))
+        cin = 64
+        for i, (n, c) in enumerate(zip((3, 4, 6, 3), (64, 128, 256, 512))):
+            if i + 1 > output_layer:
+                break
+            blocks = []
+            for j in range(n):
+                blocks.append(_BasicBlock(cin, c, 2 if (j == 0 and i > 0) else 1))
+                cin = c
+            setattr(self, 'layer%d' % (i + 1), nn.Sequential(*blocks))
+        self.out_channels = cin
 
 
 class AuxiliaryResnet(nn.Module):
-    """PerceptualHead.py:15-76 for AUXILIARY_RESNET='resnet34', AUXILIARY_RESNET_OUTPUT_LAYER=1.
-    Output is NHWC [N, h/4, w/4, 64] (the layout the triplet kernel reads)."""
+    """PerceptualHead.py:15-76 for AUXILIARY_RESNET='resnet34', AUXILIARY_RESNET_OUTPUT_LAYER 1..4 (:24-33,:62-67).
+    Output is NHWC [N, h/s, w/s, C] with (s, C) = (4, 64), (8, 128), (16, 256), (32, 512) - the layout the triplet
+    kernel reads."""
 
     def __init__(self, **kwargs):
         super().__init__()
-        if kwargs.get('AUXILIARY_RESNET', 'resnet34') != 'resnet34' or kwargs.get('AUXILIARY_RESNET_OUTPUT_LAYER', 1) != 1:
-            raise NotImplementedError("only AUXILIARY_RESNET='resnet34' with OUTPUT_LAYER=1 is built")
+        self.output_layer = int(kwargs.get('AUXILIARY_RESNET_OUTPUT_LAYER', 1))
+        if kwargs.get('AUXILIARY_RESNET', 'resnet34') != 'resnet34' or not 1 <= self.output_layer <= 4:
+            raise NotImplementedError("only AUXILIARY_RESNET='resnet34' with OUTPUT_LAYER 1..4 is built")
         if kwargs.get('WITH_PROJECTION_HEAD') is not None:
             raise NotImplementedError("WITH_PROJECTION_HEAD is not used by any shipped config")
-        self.resnet = _ResNetStem()
+        self.resnet = _ResNetStem(self.output_layer)
+        self.stride = 4 << (self.output_layer - 1)      # feature-map stride = the mask downsample factor (:450)
         self.freeze = kwargs.get('AUXILIARY_RESNET_FREEZE', True)
         if not self.freeze:
             raise NotImplementedError("AUXILIARY_RESNET_FREEZE=False is not used by any shipped config")
@@ -80,8 +98,9 @@ class AuxiliaryResnet(nn.Module):
             s = prog.conv(0, r.conv1, in_nchw=(in_ch != 1), weight_fn=self._gray_weight if in_ch == 1 else None)
             s = prog.bn(s, r.bn1, relu=True)
             s = prog.maxpool(s)
-            for blk in r.layer1:
-                s = prog.basic_block(s, blk)
+            for li in range(1, self.output_layer + 1):
+                for blk in getattr(r, 'layer%d' % li):
+                    s = prog.basic_block(s, blk)
             self._runners[in_ch] = net.Runner(self, prog, trainable=False, precision=self.precision, fold_cache=self._fold)
         return self._runners[in_ch]
 
@@ -142,7 +161,7 @@ class _BiHomELoss(torch.autograd.Function):
             with torch.no_grad():
                 feat = aux(patches, groups=2)                   # :358,:367  (patch_1 then patch_2 statistics)
         H64, H32 = K.h4pt_fwd(delta, h)                          # _warp -> four_point_to_homography :237-243
-        pool = 4
+        pool = aux.stride                                        # :450 downsample_factor = mask size // feature size
         warped, cov = K.warp_fwd(patches, H64, pool)             # :371,:382,:392,:401,:447-459
         with torch.enable_grad():
             wl = warped.detach().requires_grad_(True)
@@ -153,7 +172,8 @@ class _BiHomELoss(torch.autograd.Function):
         loss4 = K.bihome_loss_fwd(numden, H64[:B], H64[B:], head.triplet_mu)   # :656-665
         ctx.head, ctx.B, ctx.pool = head, B, pool
         ctx.saved = (delta, patches, H64, feat, featw, wl, cov, M1, M2, numden)
-        head.last = {"loss4": loss4, "H_4pt": H32, "warped": warped, "coverage": cov}
+        head.last = {"loss4": loss4, "H_4pt": H32, "warped": warped, "coverage": cov, "numden": numden,
+                     "f1": f1, "f2": f2, "f1w": f1w}
         return loss4[0]
 
     @staticmethod
@@ -193,7 +213,7 @@ class _IHomELoss(torch.autograd.Function):
             with torch.no_grad():
                 feat = aux(patches, groups=2)                   # :358,:367 (patch_1, then patch_2)
         H64, H32 = K.h4pt_fwd(delta, h)                          # :371 -> four_point_to_homography
-        pool = 4
+        pool = aux.stride
         p1 = patches[:B].contiguous()
         warped, cov = K.warp_fwd(p1, H64, pool)                  # :371,:382 + downsample (:447-451)
         with torch.enable_grad():
@@ -202,7 +222,8 @@ class _IHomELoss(torch.autograd.Function):
         loss, T, numden = K.oneline_loss_fwd(feat[:B], feat[B:], featw.detach(), cov, head.triplet_margin)   # :474-533
         ctx.head, ctx.pool = head, pool
         ctx.saved = (delta, p1, H64, feat[B:], featw, wl, cov, T, numden)
-        head.last = {"loss4": loss, "H_4pt": H32, "warped": warped, "coverage": cov}
+        head.last = {"loss4": loss, "H_4pt": H32, "warped": warped, "coverage": cov, "f1": feat[:B], "f2": feat[B:],
+                     "f1w": featw.detach()}
         return loss[0]
 
     @staticmethod
@@ -217,6 +238,43 @@ class _IHomELoss(torch.autograd.Function):
         K.warp_bwd(p1, H64, gwarp.contiguous(), gcov, ctx.pool, gH=gH)
         gdelta = K.h4pt_bwd(delta, H64, gH, h)
         return gdelta, None, None
+
+
+class _WarpFeatures(torch.autograd.Function):
+    """multihead_resnet_loss (PerceptualHead.py:245-315): features of the warped patch_1 as a differentiable function
+    of delta_hat.  p1[B,1,h,w], delta[B,4,2] -> NHWC features [B,h/s,w/s,C]."""
+
+    @staticmethod
+    def forward(ctx, delta, p1, head):
+        aux = head.auxiliary_resnet
+        delta = delta.contiguous()
+        h = p1.shape[-1]
+        H64, H32 = K.h4pt_fwd(delta, h)                          # _warp :237-243
+        warped, _ = K.warp_fwd(p1, H64, aux.stride, want_cov=False)   # :272
+        with torch.enable_grad():
+            wl = warped.detach().requires_grad_(True)
+            featw = aux(wl, groups=1)                            # :273
+        ctx.saved = (delta, p1, H64, featw, wl)
+        ctx.pool = aux.stride
+        head.last = {"H_4pt": H32, "warped": warped}
+        return featw.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        delta, p1, H64, featw, wl = ctx.saved
+        ctx.saved = None
+        (gwarp,) = torch.autograd.grad(featw, wl, g.contiguous())
+        gH = torch.zeros_like(H64)
+        K.warp_bwd(p1, H64, gwarp.contiguous(), None, ctx.pool, gH=gH)
+        return K.h4pt_bwd(delta, H64, gH, p1.shape[-1]), None, None
+
+
+def _tb_scalars(data, groups):
+    """The head's TensorBoard side channel (PerceptualHead.py:286-298,678-697): only when the driver injected
+    data['summary_writer'] (log steps, train.py:312-314).  Each value is a device sync, as upstream."""
+    sw, step = data['summary_writer'], data['summary_writer_step']
+    for tag, key, val in groups:
+        sw.add_scalars(tag, {key: float(val)}, step)
 
 
 # -----------------------------------------------------------------------------------------------
@@ -237,18 +295,21 @@ class Model(nn.Module):
             if kwargs.get('SCORING_METHOD', 'repr_error') != 'repr_error':
                 raise NotImplementedError("only SCORING_METHOD='repr_error' is built")
         self.triplet_version = kwargs['TRIPLET_LOSS']
+        self.multihead = self.triplet_version == ''           # PerceptualHead.py:108,:230-235 -> multihead_resnet_loss
         common = ('dual' not in self.triplet_version and kwargs.get('TRIPLET_DISTANCE') == 'l1'
                   and not len(kwargs.get('MASK_KEYS', [])) and 'upsample' not in str(kwargs.get('SAMPLING_STRATEGY', ''))
                   and not kwargs.get('MASK_CRD', False))
         self.one_line = 'one-line' in self.triplet_version
-        if self.one_line:                  # iHomE: PerceptualHead.py:465-538, hinge with a numeric margin
+        if self.multihead:                 # features out, a torch loss is applied by the driver (train.py:318-322)
+            ok = True
+        elif self.one_line:                # iHomE: PerceptualHead.py:465-538, hinge with a numeric margin
             ok = common and isinstance(kwargs.get('TRIPLET_MARGIN'), (int, float))
         else:                              # biHomE: PerceptualHead.py:540-665
             ok = (common and 'double-line' in self.triplet_version and isinstance(kwargs.get('TRIPLET_MARGIN'), str)
                   and kwargs.get('TRIPLET_AGGREGATION') == 'channel-agnostic')
         if not ok:
-            raise NotImplementedError("built: biHomE (double-line / l1 / channel-agnostic / str margin) and iHomE (one-line / l1 / "
-                                      "numeric margin), no MASK_KEYS / MASK_CRD, downsample-mask - see SURVEY.md 2 for what is out of "
+            raise NotImplementedError("built: biHomE (double-line / l1 / channel-agnostic / str margin), iHomE (one-line / l1 / "
+                                      "numeric margin) and the multihead feature loss (TRIPLET_LOSS ''), no MASK_KEYS / MASK_CRD, downsample-mask - see SURVEY.md 2 for what is out of "
                                       "scope")
         self.triplet_mu = kwargs.get('TRIPLET_MU', 0.0)
         self.triplet_margin = kwargs.get('TRIPLET_MARGIN')
@@ -323,6 +384,8 @@ class Model(nn.Module):
         if not p1.is_cuda:
             raise RuntimeError("bihome_amd heads run on the MI355X only; no CPU fallback (use oracle/ for CPU checks)")
         B = p1.shape[0]
+        if self.multihead:
+            return self._forward_multihead(data, p1, p2, B)
         if self.one_line:
             return self._forward_one_line(data, p1, p2, B)
         if not len(self.delta_hat_keys):
@@ -345,14 +408,19 @@ class Model(nn.Module):
         loss = _BiHomELoss.apply(delta, patches, self)
         self._feat_ready = None
         if 'summary_writer' in data:                            # PerceptualHead.py:678-697 (syncs; log steps only)
-            step = data['summary_writer_step']
-            l4 = self.last["loss4"].tolist()
-            data['summary_writer'].add_scalars('loss_comp', {'ln1': l4[1], 'ln2': l4[2], 'ln3': l4[3]}, step)
+            f1, f2, f1w = self.last["f1"], self.last["f2"], self.last["f1w"]
+            nd = self.last["numden"]                            # [B, (num1, den1, num2, den2)]
+            eye = torch.eye(3, device=p1.device, dtype=torch.float32)
+            _tb_scalars(data, [('feature_space', 'patch_1_f', f1.mean()), ('feature_space', 'patch_2_f', f2.mean()),
+                               ('feature_space', 'patch_1_f_prime', f1w.mean()),
+                               ('loss_comp', 'l1', (f2 - f1w).abs().mean()), ('loss_comp', 'l3', (f2 - f1).abs().mean()),
+                               ('h', 'h1', ((self.last["H_4pt"][:B] - eye) ** 2).sum()),
+                               ('loss_den', 'l1_den', nd[:, 1].min()), ('loss_den', 'l2_den', nd[:, 3].min())])
         delta_gt = data['delta'] if 'delta' in data else None
         return loss, delta_gt, delta[:B]
 
-    def _forward_one_line(self, data, p1, p2, B):
-        """One direction only (PerceptualHead.py:154-176,222-223): delta_hat_12 from the DLT on pf_hat_12 (or given)."""
+    def _delta_12(self, data, B):
+        """delta_hat_12 [B,4,2]: from the DLT on pf_hat_12 (:154-178) or as given by the backbone (:211-214)."""
         if not len(self.delta_hat_keys):
             pf = data[self.pf_keys[0]].contiguous()
             N = pf.shape[-1] * pf.shape[-2]
@@ -360,10 +428,30 @@ class Model(nn.Module):
             if self.hypothesis_no != 1:
                 raise NotImplementedError("training with RANSAC_HYPOTHESIS_NO > 1 is not used by any shipped config")
             dh, Hd = _DltFunction.apply(pf, c12, self.hypothesis_no, self.point_per_hypothesis)
-            delta = dh.reshape(B, 4, 2)           # (the softmax score of a single hypothesis is 1: :505-511,:708-710)
             self.last_dlt = Hd
-        else:
-            delta = data[self.delta_hat_keys[0]].reshape(B, 4, 2)
+            return dh.reshape(B, 4, 2)    # (the softmax score of a single hypothesis is exactly 1: :276-280,:505-511,:708-710)
+        return data[self.delta_hat_keys[0]].reshape(B, 4, 2)
+
+    def _forward_multihead(self, data, p1, p2, B):
+        """multihead_resnet_loss (PerceptualHead.py:245-315): returns (features of patch_2, features of the warped patch_1,
+        delta_gt, delta_hat) - ground truth first, the driver applies its torch loss (train.py:318-322).  The feature
+        tensors are handed over in the reference's NCHW shape (views of the kernels' NHWC maps)."""
+        delta = self._delta_12(data, B)
+        P = self.patch_size
+        aux = self.auxiliary_resnet
+        f2 = aux(p2.reshape(B, -1, P, P), groups=1).detach()      # :269 (frozen weights: no gradient path)
+        f1w = _WarpFeatures.apply(delta, p1.reshape(B, -1, P, P).contiguous(), self)     # :272-273
+        if 'summary_writer' in data:                            # :286-298
+            eye = torch.eye(3, device=p1.device, dtype=torch.float32)
+            _tb_scalars(data, [('feature_space', 'patch_2_f', f2.mean()), ('feature_space', 'patch_1_f_prime', f1w.mean()),
+                               ('loss_comp', 'l1', (f2 - f1w).abs().mean()),
+                               ('h', 'h1', ((self.last["H_4pt"] - eye) ** 2).sum())])
+        delta_gt = data['delta'] if 'delta' in data else None
+        return f2.permute(0, 3, 1, 2), f1w.permute(0, 3, 1, 2), delta_gt, delta
+
+    def _forward_one_line(self, data, p1, p2, B):
+        """One direction only (PerceptualHead.py:154-176,222-223): delta_hat_12 from the DLT on pf_hat_12 (or given)."""
+        delta = self._delta_12(data, B)
         pre, self._prefetched = self._prefetched, None
         if pre is not None and pre[0] is p1 and pre[1] is p2:
             patches, self._feat_ready = pre[2], (pre[3], pre[4])
@@ -371,6 +459,13 @@ class Model(nn.Module):
             patches, self._feat_ready = self._stack_patches(data), None
         loss = _IHomELoss.apply(delta, patches, self)
         self._feat_ready = None
+        if 'summary_writer' in data:                            # :678-692
+            f1, f2, f1w = self.last["f1"], self.last["f2"], self.last["f1w"]
+            eye = torch.eye(3, device=p1.device, dtype=torch.float32)
+            _tb_scalars(data, [('feature_space', 'patch_1_f', f1.mean()), ('feature_space', 'patch_2_f', f2.mean()),
+                               ('feature_space', 'patch_1_f_prime', f1w.mean()),
+                               ('loss_comp', 'l1', (f2 - f1w).abs().mean()), ('loss_comp', 'l3', (f2 - f1).abs().mean()),
+                               ('h', 'h1', ((self.last["H_4pt"] - eye) ** 2).sum())])
         delta_gt = data['delta'] if 'delta' in data else None
         return loss, delta_gt, delta
 

@@ -252,7 +252,7 @@ def warp_bwd(img, H64, g_out, g_cov, pool=4, gH=None):
     B, C, h, w = img.shape
     if gH is None:
         gH = torch.zeros(B, 9, dtype=torch.float64, device=img.device)
-    with _Timed("warp_bwd_kernel", 0.0, 4.0 * (img.numel() + g_out.numel() + g_cov.numel())):
+    with _Timed("warp_bwd_kernel", 0.0, 4.0 * (img.numel() + g_out.numel() + (g_cov.numel() if g_cov is not None else 0))):
         check(lib.bh_warp_bwd(_p(img), _p(H64), _p(g_out), _p(g_cov), B, C, h, w, pool, _p(gH), _stream()), "bh_warp_bwd")
     return gH
 

@@ -46,27 +46,29 @@ def _oracle_step(cfg, d, dtype, choices=None, keys=("patch_1", "patch_2", "delta
     return dict(loss=loss.item(), mace=O.mace(dgt, dh), dh=dh.detach().double(), grads=grads, fields=fields)
 
 
-def _check_grads(model_params, g64, g32, per_tensor_floor=1e-3, max_bad=4):
-    """Per-tensor gradient norms within 5x the oracle's own f32/f64 spread; whole-gradient relative L2 error within 3x the
-    oracle's f32-vs-f64 error."""
+def _check_grads(model_params, g64, g32, max_bad=4):
+    """Gradients against the float64 oracle, calibrated by the oracle's own float32 run.  At 64 pairs the reference
+    arithmetic in float32 sits 0.5-1 % (relative L2, per tensor) from float64: a float32 SVD of the 9x9 normal matrix and
+    ReLU / max-pool decisions within rounding of a tie move the whole backward pass (tools/grad_parity_report.py prints
+    the table).  Required: whole-gradient relative L2 error <= 1.5x the float32 oracle's, and per tensor
+    relL2(hip) <= max(2.5 x relL2(f32 oracle, same tensor), 2 x the float32 oracle's whole-gradient error), with at most
+    `max_bad` tensors up to 2x beyond that."""
     gscale = max(g.abs().max().item() for g in g64.values())
     num = num32 = den = 0.0
-    bad = []
+    rows = []
     for name, p in model_params:
         r = g64[name]
         if r.abs().max().item() < 1e-9 * gscale:           # mathematically zero (conv bias in front of a BatchNorm)
             assert p.grad.abs().max().item() < 1e-5 * gscale, name
             continue
         got = p.grad.detach().cpu().double()
-        num += (got - r).pow(2).sum().item()
-        num32 += (g32[name] - r).pow(2).sum().item()
-        den += r.pow(2).sum().item()
-        gn, rn, sn = got.norm().item(), r.norm().item(), abs(g32[name].norm().item() - r.norm().item())
-        if abs(gn - rn) > max(5 * sn, per_tensor_floor * rn):
-            bad.append((name, gn, rn, sn))
+        n_, n32, d_ = (got - r).pow(2).sum().item(), (g32[name] - r).pow(2).sum().item(), r.pow(2).sum().item()
+        num += n_; num32 += n32; den += d_
+        rows.append((name, (n_ / d_) ** 0.5, (n32 / d_) ** 0.5))
     e, e32 = (num / den) ** 0.5, (num32 / den) ** 0.5
-    assert e <= max(3 * e32, 1e-4), (e, e32)
-    assert len(bad) <= max_bad and all(abs(a - b) < 0.05 * b for _, a, b, _ in bad), bad[:10]
+    assert e <= max(1.5 * e32, 1e-4), (e, e32)
+    bad = [(n, a, b) for n, a, b in rows if a > max(2.5 * b, 2 * e32, 1e-4)]
+    assert len(bad) <= max_bad and all(a <= 2 * max(2.5 * b, 2 * e32, 1e-4) for _, a, b in bad), (bad[:10], e, e32)
     return e, e32
 
 
