@@ -98,6 +98,17 @@ def _ihome(base):
     return cfg
 
 
+def _multihead(base):
+    """multihead_resnet_loss variant (PerceptualHead.py:230-235,245-315): TRIPLET_LOSS '' - the head returns the extractor
+    features of patch_2 and of the warped patch_1 and the driver applies a torch loss to them (train.py:318-322).  No
+    yaml for it ships upstream; one direction, kwargs as in the biHomE configs."""
+    cfg = _ihome(base)
+    cfg["MODEL"]["HEAD"]["TRIPLET_LOSS"] = ""
+    cfg["MODEL"]["HEAD"]["TRIPLET_MARGIN"] = "inf"
+    cfg["SOLVER"]["LOSS"] = "L1Loss"
+    return cfg
+
+
 def get(name):
     """'zeng-bihome' / 'detone-bihome' = config/s-coco/*; the '-pds' variants = config/pds-coco/* (the two trees differ
     only in HomographyNetPrep's photometric max_delta, 0 vs 32, and the log dir).  'zeng-bihome-rgb256' is the
@@ -109,6 +120,8 @@ def get(name):
         cfg["MODEL"]["HEAD"].update(PATCH_SIZE=256)
         cfg["DATA"].update(BATCH_SIZE=32, RHO=64, PATCH_SIZE=256, PATCH_CHANNELS=3)
         return cfg
+    if name in ("zeng-multihead", "detone-multihead"):
+        return _multihead(ZENG_BIHOME if name == "zeng-multihead" else DETONE_BIHOME)
     if name in ("zeng-ihome", "detone-ihome"):
         return _ihome(ZENG_BIHOME if name == "zeng-ihome" else DETONE_BIHOME)
     base = name[:-4] if name.endswith("-pds") else name

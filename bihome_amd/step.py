@@ -48,6 +48,9 @@ def train_step(model, data, opt, sched, clip=-1.0, reducer=None, loss_fn="biHomE
     if isinstance(loss_fn, torch.nn.Module):                        # train.py:318-322 (ground truth first, as upstream)
         ground_truth, network_output, delta_gt, delta_hat = model(data)
         loss = loss_fn(ground_truth, network_output)
+    elif loss_fn == "CosineDistance":                               # train.py:324-326 (multihead features)
+        ground_truth, network_output, delta_gt, delta_hat = model(data)
+        loss = torch.sum(1 - torch.cosine_similarity(ground_truth, network_output, dim=1))
     else:
         loss, delta_gt, delta_hat = model(data)                     # train.py:357
     loss.backward()                                                 # train.py:379

@@ -2,8 +2,9 @@
 
 Mirrors the distribution of the reference's data pipeline without COCO, cv2 or a network
 (SURVEY.md §8(d)): `HomographyNetPrep` (src/data/transforms.py:441-725), `DictToGrayscale`
-(:344-354), `DictStandardize` (:369-378) and, for pds-coco, the brightness/contrast part of
-`PhotometricDistortSimple` (:296-330).  Base images stand in for the offline-preprocessed
+(:344-354), `DictStandardize` (:369-378) and `PhotometricDistortSimple` (:296-330: brightness, contrast,
+HSV saturation / hue, channel permutation).  `homography_net_prep` reproduces one reference sample draw for draw
+(checked against the reference's own classes through tests/golden/datagen_*.npz).  Base images stand in for the offline-preprocessed
 240x320 COCO crops (src/data/coco/preprocess_offline.py:22).  Deterministic: numpy PCG64.
 """
 import numpy as np
@@ -65,15 +66,130 @@ def warp_bilinear(img, H, out_h, out_w):
     return out
 
 
+_EPS32 = np.float32(1.1920929e-07)
+_PERMS = ((0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0))        # transforms.py:235-237
+_SECTOR = np.array([[1, 3, 0], [1, 0, 2], [3, 0, 1], [0, 2, 1], [0, 1, 3], [2, 1, 0]])   # HSV->RGB: tab index of (b, g, r)
+
+
+def rgb_to_hsv(img):
+    """float32 RGB -> HSV the way the reference's cv2.cvtColor(COLOR_RGB2HSV) call does for CV_32F (transforms.py:167-168):
+    V = max, S = (V - min) / (|V| + eps), H in degrees from the channel holding the max; inputs are not clipped."""
+    img = np.asarray(img, np.float32)
+    r, g, b = img[..., 0], img[..., 1], img[..., 2]
+    v = np.maximum(np.maximum(r, g), b)
+    diff = (v - np.minimum(np.minimum(r, g), b)).astype(np.float32)
+    sat = diff / (np.abs(v) + _EPS32)
+    d = (np.float32(60.0) / (diff + _EPS32)).astype(np.float32)
+    h = np.where(v == r, (g - b) * d, np.where(v == g, (b - r) * d + np.float32(120.0), (r - g) * d + np.float32(240.0)))
+    h = np.where(h < 0, h + np.float32(360.0), h)
+    return np.stack([h, sat, v], -1).astype(np.float32)
+
+
+def hsv_to_rgb(img):
+    """float32 HSV -> RGB, sector-table form (the reference's cv2.cvtColor(COLOR_HSV2RGB), transforms.py:173-174)."""
+    img = np.asarray(img, np.float32)
+    h, sat, v = img[..., 0], img[..., 1], img[..., 2]
+    hh = (h * np.float32(6.0 / 360.0)).astype(np.float32)
+    hh = (hh - np.floor(hh / 6.0) * 6.0 * ((hh < 0) | (hh >= 6))).astype(np.float32)
+    sector = np.floor(hh).astype(np.int64)
+    frac = (hh - sector).astype(np.float32)
+    bad = (sector < 0) | (sector >= 6)
+    sector, frac = np.where(bad, 0, sector), np.where(bad, np.float32(0), frac)
+    one = np.float32(1.0)
+    tab = np.stack([v, v * (one - sat), v * (one - sat * frac), v * (one - sat * (one - frac))], -1).astype(np.float32)
+    idx = _SECTOR[sector]
+    b, g, r = (np.take_along_axis(tab, idx[..., i:i + 1], -1)[..., 0] for i in range(3))
+    grey = sat == 0
+    return np.stack([np.where(grey, v, r), np.where(grey, v, g), np.where(grey, v, b)], -1).astype(np.float32)
+
+
+def draw_photometric(rs, max_delta):
+    """The random decisions of one PhotometricDistortSimple call (transforms.py:296-330, classes :141-245) in the
+    reference's draw order, as a parameter record the host and device generators both apply:
+    (brightness delta, contrast-first alpha, saturation alpha, hue delta, contrast-last alpha, channel permutation index).
+    `rs`: numpy RandomState-like (randint / uniform)."""
+    lower, upper = 1.0 - max_delta / 32 * 0.5, 1.0 + max_delta / 32 * 0.5            # :301-302
+    br = rs.uniform(-max_delta, max_delta) if rs.randint(2) else 0.0                  # :152-155
+    first = bool(rs.randint(2))                                                       # :322 (pd[:-1] or pd[1:])
+    c1 = c2 = 1.0
+    if first and rs.randint(2):                                                       # contrast before HSV (:167-169)
+        c1 = rs.uniform(lower, upper)
+    sat = rs.uniform(lower, upper) if rs.randint(2) else 1.0                          # :194-196
+    hue = rs.uniform(-max_delta / 2, max_delta / 2) if rs.randint(2) else 0.0         # :206-210
+    if not first and rs.randint(2):                                                   # contrast after HSV
+        c2 = rs.uniform(lower, upper)
+    perm = 0
+    if max_delta > 0 and rs.randint(2):                                               # :327-328, :241-245
+        perm = int(rs.randint(len(_PERMS)))
+    return np.array([br, c1, sat, hue, c2, perm], np.float64)
+
+
+def apply_photometric(img, p):
+    """Apply one parameter record of `draw_photometric` to an HxWx3 image (float32 arithmetic, as upstream)."""
+    br, c1, sat, hue, c2, perm = p
+    im = np.asarray(img).astype(np.float32)                                           # ImageConvertFromInts :125-127
+    im = im + np.float32(br)
+    im = im * np.float32(c1)
+    hsv = rgb_to_hsv(im)
+    hsv[..., 1] *= np.float32(sat)
+    if hue != 0.0:
+        hch = hsv[..., 0] + np.float32(hue)
+        hch = np.where(hch > 360.0, hch - np.float32(360.0), hch)
+        hsv[..., 0] = np.where(hch < 0.0, hch + np.float32(360.0), hch)
+    im = hsv_to_rgb(hsv) * np.float32(c2)
+    return im[..., list(_PERMS[int(perm)])]
+
+
+class _RandomStateAdapter:
+    """numpy Generator (PCG64) behind the two RandomState calls the reference's transforms use."""
+
+    def __init__(self, gen):
+        self.gen = gen
+
+    def randint(self, low, high=None, size=None):
+        if high is None:
+            low, high = 0, low
+        return self.gen.integers(low, high, size)
+
+    def uniform(self, low, high):
+        return self.gen.uniform(low, high)
+
+
 def _photometric(rng, img, max_delta):
-    """Brightness +-max_delta and contrast x[1-d/64, 1+d/64], each with p=0.5 (transforms.py:296-330,
-    RGB part; the HSV hue/saturation jitter does not survive the grayscale conversion materially)."""
-    img = img.copy()
-    if rng.integers(2):
-        img += rng.uniform(-max_delta, max_delta)
-    if rng.integers(2):
-        img *= rng.uniform(1.0 - max_delta / 64.0, 1.0 + max_delta / 64.0)
-    return img
+    """PhotometricDistortSimple (transforms.py:296-330): brightness, contrast, HSV saturation / hue, channel permutation,
+    each with p = 0.5, contrast either before or after the HSV part."""
+    return apply_photometric(img, draw_photometric(_RandomStateAdapter(rng), max_delta)).astype(np.float64)
+
+
+def homography_net_prep(rs, image, rho=32, patch=128, max_delta=0, photometric_keys=("image_1", "image_2")):
+    """One sample exactly in the reference's order of operations and random draws (HomographyNetPrep.__call__,
+    transforms.py:458-725, '4_points'): photometric distortion of both copies (applied even for max_delta 0, where it only
+    consumes draws and a float32 HSV round trip), patch centre, corner offsets, homography, warp of image_2, crops.
+    `rs`: numpy RandomState (the reference seeds one per transform, :451-454).  Returns the reference's dict (numpy)."""
+    h, w = image.shape[:2]
+    im1 = apply_photometric(image, draw_photometric(rs, max_delta)) if "image_1" in photometric_keys else np.copy(image)
+    im2 = apply_photometric(image, draw_photometric(rs, max_delta)) if "image_2" in photometric_keys else np.copy(image)
+    half = patch // 2
+    if patch != w:                                                                    # :504-509
+        px = int(rs.randint(rho + half, w - rho - half + 1))
+        py = int(rs.randint(rho + half, h - rho - half + 1))
+    else:
+        px, py = w // 2, h // 2
+    corners = np.array([(px - half, py - half), (px + half, py - half), (px + half, py + half), (px - half, py + half)])
+    p1 = im1[corners[0, 1]:corners[3, 1], corners[0, 0]:corners[1, 0]]               # :521
+    delta = rs.randint(-rho, rho, 8).reshape(4, 2)                                    # :538
+    H = four_point_homography(corners.astype(np.float64), (corners + delta).astype(np.float64))       # :569-570
+    # warp_image(image_2, H) = cv2.warpPerspective(image_2, inv(H)): image_2'(x) = image_2(H x)    (:571, utils.py:61-64)
+    im2w = warp_bilinear(im2.astype(np.float64), H, h, w).astype(im2.dtype if im2.dtype.kind == "f" else np.float64)
+    p2 = im2w[corners[0, 1]:corners[3, 1], corners[0, 0]:corners[1, 0]]               # :576
+    return {"image_1": im1, "image_2": im2w, "patch_1": p1, "patch_2": p2, "corners": corners, "target": delta,
+            "delta": delta, "homography": H}
+
+
+def gray_standardize(patch, mean=0.443, std=0.129):
+    """DictToGrayscale (:344-354) + DictStandardize (:369-378) + DictToTensor's HWC->CHW (:728-743) for one patch."""
+    g = patch[:, :, 0] * 0.299 + patch[:, :, 1] * 0.587 + patch[:, :, 2] * 0.114
+    return ((g[None].astype(np.float32) / 255) - mean) / std
 
 
 def make_pairs(batch, patch=128, rho=32, seed=42, photometric_max_delta=0, channels=1, pool=4, target=False):

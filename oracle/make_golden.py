@@ -30,7 +30,8 @@ def install_standins():
     tv.models = torchvision_standin
     sys.modules["torchvision"] = tv
     sys.modules["torchvision.models"] = torchvision_standin
-    sys.modules["cv2"] = types.ModuleType("cv2")
+    from oracle.refshim import cv2_standin
+    sys.modules["cv2"] = cv2_standin      # (the torch hot path never calls it; the numpy data-generation path does)
     # the reference package is `src`; the build's drop-in shims are ALSO `src.*`, so make sure the
     # reference's is the one imported in this process
     if REF in sys.path:
@@ -309,6 +310,188 @@ def run_ihome_scenario(ref_bb_cls, ref_head_cls, cfg, dtype, batch=4, seed=31, s
     return out
 
 
+class RecordingWriter:
+    """Stands in for the driver's SummaryWriter (train.py:312-314, 507): records what the head writes."""
+
+    def __init__(self):
+        self.scalars = {}
+
+    def add_scalars(self, tag, values, step):
+        for k, v in values.items():
+            self.scalars["tb/%s/%s" % (tag, k)] = np.float64(v)
+
+
+def run_detone_steps(ref_bb_cls, ref_head_cls, cfg, dtype, batch=8, seed=5, steps=3):
+    """configs[3]'s model (ResNet-34 regressor + biHomE head): `steps` Adam steps on one batch (train.py:296-387)."""
+    from bihome_amd import synth
+    from bihome_amd.weights import load_synthetic
+    bb = ref_bb_cls(**cfg["MODEL"]["BACKBONE"])
+    head = ref_head_cls(bb, **cfg["MODEL"]["HEAD"])
+    load_synthetic(bb, seed=0)
+    load_synthetic(head.auxiliary_resnet, seed=0)
+    model = torch.nn.Sequential(bb, head).to(dtype)
+    s = cfg["SOLVER"]
+    opt = torch.optim.Adam(model.parameters(), lr=s["LR"], betas=(s["MOMENTUM_1"], s["MOMENTUM_2"]), weight_decay=0)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=s["MILESTONES"], gamma=s["LR_DECAY"])
+    d = synth.make_pairs(batch, seed=seed)
+    out = {"loss": [], "mace": [], "delta_hat_12": []}
+    model.train()
+    for it in range(steps):
+        opt.zero_grad()
+        data = {k: t(d[k], dtype) for k in ("patch_1", "patch_2", "delta")}
+        loss, delta_gt, delta_hat = model(data)
+        loss.backward()
+        if it == 0:
+            for name in ("resnet34.conv1.weight", "resnet34.layer2.0.downsample.0.weight", "resnet34.fc.weight", "resnet34.fc.bias"):
+                out["gradnorm/" + name] = np.float64(dict(bb.named_parameters())[name].grad.double().norm().item())
+        opt.step()
+        sched.step()
+        out["loss"].append(loss.item())
+        out["mace"].append(float(np.mean(np.linalg.norm(delta_gt.numpy().reshape(-1, 2) -
+                                                        delta_hat.detach().numpy().reshape(-1, 2), axis=-1))))
+        out["delta_hat_12"].append(delta_hat.detach().double().numpy().copy())
+    for k in ("loss", "mace", "delta_hat_12"):
+        out[k] = np.asarray(out[k])
+    return out
+
+
+def run_bihome_variant(ref_bb_cls, ref_head_cls, cfg, dtype, batch=4, seed=17, steps=1, photometric=0, loss_name=None):
+    """Reference Rethinking + PerceptualHead with modified HEAD kwargs (extractor output layer, TRIPLET_LOSS '' ...) or
+    data (photometric distortion): `steps` Adam steps on one batch with the driver's log-step side channel on
+    (train.py:312-314), multinomial draws recorded.  loss_name: torch.nn loss applied by the driver (train.py:318-322)
+    for the multihead branch, None for the head's own loss (train.py:330)."""
+    from bihome_amd import synth
+    from bihome_amd.weights import load_synthetic
+    bb = ref_bb_cls(**cfg["MODEL"]["BACKBONE"])
+    head = ref_head_cls(bb, **cfg["MODEL"]["HEAD"])
+    load_synthetic(bb, seed=0)
+    load_synthetic(head.auxiliary_resnet, seed=0)
+    model = torch.nn.Sequential(bb, head).to(dtype)
+    s = cfg["SOLVER"]
+    opt = torch.optim.Adam(model.parameters(), lr=s["LR"], betas=(s["MOMENTUM_1"], s["MOMENTUM_2"]), weight_decay=0)
+    loss_fn = getattr(torch.nn, loss_name)() if loss_name else None
+    d = synth.make_pairs(batch, seed=seed, photometric_max_delta=photometric)
+    double = "double-line" in cfg["MODEL"]["HEAD"]["TRIPLET_LOSS"]
+    out = {"loss": [], "mace": [], "choice_12": [], "choice_21": []}
+    model.train()
+    for it in range(steps):
+        opt.zero_grad()
+        data = {k: t(d[k], dtype) for k in ("patch_1", "patch_2", "delta")}
+        rw = RecordingWriter()
+        if it == 0:
+            data["summary_writer"], data["summary_writer_step"] = rw, 1
+        torch.manual_seed(4000 + it)
+        with RecordMultinomial() as rec:
+            if loss_fn is not None:
+                ground_truth, network_output, delta_gt, delta_hat = model(data)
+                loss = loss_fn(ground_truth, network_output)
+            else:
+                loss, delta_gt, delta_hat = model(data)
+        loss.backward()
+        if it == 0:
+            out.update(rw.scalars)
+            out["pf_hat_12_sub"] = sub(data["pf_hat_12"], 8)
+            out["delta_hat_12"] = delta_hat.detach().double().numpy().copy()
+            if loss_fn is not None:
+                out["ground_truth_csum"] = csum(ground_truth)
+                out["network_output_csum"] = csum(network_output)
+                out["network_output_sub"] = network_output[:, ::8, ::2, ::2].detach().double().numpy().copy()
+            for name in ("layer1.0.weight", "layer4.6.upper_branch.0.weight", "layer8.3.weight", "layer8.3.bias"):
+                out["gradnorm/" + name] = np.float64(dict(bb.named_parameters())[name].grad.double().norm().item())
+            out["aux_bn1_running_mean"] = head.auxiliary_resnet.resnet.bn1.running_mean.double().numpy().copy()
+        opt.step()
+        out["loss"].append(loss.item())
+        out["mace"].append(float(np.mean(np.linalg.norm(delta_gt.numpy().reshape(-1, 2) -
+                                                        delta_hat.detach().numpy().reshape(-1, 2), axis=-1))))
+        out["choice_12"].append(rec.calls[0].reshape(batch, -1).numpy())
+        if double:
+            out["choice_21"].append(rec.calls[1].reshape(batch, -1).numpy())
+    for k in ("loss", "mace", "choice_12", "choice_21"):
+        out[k] = np.asarray(out[k])
+    return out
+
+
+def run_datagen(outdir):
+    """The reference's own data-generation classes (src/data/transforms.py PhotometricDistortSimple :296-330,
+    HomographyNetPrep :421-725, DictToGrayscale :344-354, DictStandardize :369-378) on seeded inputs, with the OpenCV
+    calls served by oracle/refshim/cv2_standin.py.  Pins bihome_amd/synth.py (host generator) draw for draw."""
+    import importlib
+    from bihome_amd import synth
+    T = importlib.import_module("src.data.transforms")
+    assert os.path.realpath(T.__file__).startswith(os.path.realpath(REF)), T.__file__
+    out = {}
+    # (1) photometric distortion alone: 16 seeds x {32, 0} on a small uint8 image (+ one float image with out-of-range values)
+    rng = np.random.Generator(np.random.PCG64(5))
+    small = np.clip(synth.texture_image(rng, 16, 24), 0, 255).astype(np.uint8)
+    out["photo_input"] = small
+    for md in (32, 0):
+        res = []
+        for seed in range(16):
+            rs = np.random.RandomState(seed)
+            res.append(T.PhotometricDistortSimple(keys=["im"], max_delta=md, random_state=rs)({"im": small})["im"])
+        out["photo_out_md%d" % md] = np.stack(res).astype(np.float32)
+    # (2) whole samples: HomographyNetPrep -> DictToGrayscale -> DictStandardize on 240x320 uint8 images
+    rng = np.random.Generator(np.random.PCG64(6))
+    image = np.clip(synth.texture_image(rng, 240, 320), 0, 255).astype(np.uint8)
+    out["prep_image_seed"] = np.int64(6)
+    for md in (0, 32):
+        recs = {"corners": [], "delta": [], "homography": [], "patch_1_sub": [], "patch_2_sub": [], "patch_1_csum": [],
+                "patch_2_csum": [], "p1_std": [], "p2_std": []}
+        for seed in range(4):
+            prep = T.HomographyNetPrep(32, 128, ["image_1", "image_2"], md, "4_points", seed)
+            d = prep(([image], None))
+            recs["corners"].append(d["corners"]); recs["delta"].append(d["delta"]); recs["homography"].append(d["homography"])
+            recs["patch_1_sub"].append(d["patch_1"][::4, ::4].astype(np.float32))
+            recs["patch_2_sub"].append(d["patch_2"][::4, ::4].astype(np.float32))
+            for k in ("patch_1", "patch_2"):
+                a = d[k].astype(np.float64)
+                recs[k + "_csum"].append([a.sum(), np.abs(a).sum(), (a * a).sum()])
+            d = T.DictToGrayscale(["patch_1", "patch_2"])(d)
+            d = T.DictStandardize([0.443], [0.129], ["patch_1", "patch_2"])(d)
+            recs["p1_std"].append(d["patch_1"][::4, ::4, 0].astype(np.float32))
+            recs["p2_std"].append(d["patch_2"][::4, ::4, 0].astype(np.float32))
+        for k, v in recs.items():
+            out["prep_md%d_%s" % (md, k)] = np.asarray(v)
+    np.savez_compressed(os.path.join(outdir, "datagen_ref.npz"), **out)
+    print("datagen: photo", out["photo_out_md32"].shape, "prep corners", out["prep_md32_corners"][0].tolist())
+
+
+def _round2(importlib, Rethinking, ResNet34, configs, dtype, tag, outdir, which):
+    """Fixtures added in round 2 (each file independent of the round-1 ones above)."""
+    import copy
+    PerceptualHead = importlib.import_module("src.heads.PerceptualHead")
+    assert os.path.realpath(PerceptualHead.__file__).startswith(os.path.realpath(REF)), PerceptualHead.__file__
+
+    def want(name):
+        return not which or name in which
+
+    if want("detone_b8"):
+        r = run_detone_steps(ResNet34.Model, PerceptualHead.Model, configs.get("detone-bihome"), dtype)
+        np.savez_compressed(os.path.join(outdir, "detone_b8_%s.npz" % tag), **r)
+        print("detone_b8", tag, "loss", r["loss"], "mace", r["mace"])
+    for layer in (2, 3, 4):
+        if want("zeng_aux%d_b4" % layer):
+            cfg = configs.get("zeng-bihome")
+            cfg["MODEL"]["HEAD"]["AUXILIARY_RESNET_OUTPUT_LAYER"] = layer
+            r = run_bihome_variant(Rethinking.Model, PerceptualHead.Model, cfg, dtype)
+            np.savez_compressed(os.path.join(outdir, "zeng_aux%d_b4_%s.npz" % (layer, tag)), **r)
+            print("zeng_aux%d" % layer, tag, "loss", r["loss"], "mace", r["mace"])
+    if want("zeng_tb_b4"):
+        r = run_bihome_variant(Rethinking.Model, PerceptualHead.Model, configs.get("zeng-bihome"), dtype, steps=2)
+        np.savez_compressed(os.path.join(outdir, "zeng_tb_b4_%s.npz" % tag), **r)
+        print("zeng_tb", tag, "loss", r["loss"], {k: float(v) for k, v in r.items() if k.startswith("tb/")})
+    if want("zeng_multihead_b4"):
+        cfg = configs.get("zeng-multihead")
+        r = run_bihome_variant(Rethinking.Model, PerceptualHead.Model, cfg, dtype, steps=2, loss_name=cfg["SOLVER"]["LOSS"])
+        np.savez_compressed(os.path.join(outdir, "zeng_multihead_b4_%s.npz" % tag), **r)
+        print("zeng_multihead", tag, "loss", r["loss"], "mace", r["mace"])
+    if want("zeng_pds_b8"):
+        r = run_bihome_variant(Rethinking.Model, PerceptualHead.Model, configs.get("zeng-bihome-pds"), dtype, batch=8, seed=8,
+                               steps=3, photometric=32)
+        np.savez_compressed(os.path.join(outdir, "zeng_pds_b8_%s.npz" % tag), **r)
+        print("zeng_pds", tag, "loss", r["loss"], "mace", r["mace"])
+
+
 def _orig(importlib, Rethinking, ResNet34, configs, dtype, tag, outdir):
     NoOpHead = importlib.import_module("src.heads.NoOpHead")
     assert os.path.realpath(NoOpHead.__file__).startswith(os.path.realpath(REF)), NoOpHead.__file__
@@ -339,7 +522,14 @@ def main():
     import warnings
     warnings.filterwarnings("ignore")
     orig_only = "--orig-only" in sys.argv          # regenerate just the supervised "-orig" fixtures
+    round2 = [a for a in sys.argv[1:] if a.startswith("--round2")]      # --round2 or --round2=name1,name2
     for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        if round2:
+            names = round2[0].split("=", 1)[1].split(",") if "=" in round2[0] else []
+            if tag == "f32" and (not names or "datagen" in names):
+                run_datagen(outdir)
+            _round2(importlib, Rethinking, ResNet34, configs, dtype, tag, outdir, names)
+            continue
         if orig_only:
             _orig(importlib, Rethinking, ResNet34, configs, dtype, tag, outdir)
             continue
@@ -356,6 +546,9 @@ def main():
         np.savez_compressed(os.path.join(outdir, "detone_b4_%s.npz" % tag), **r)
         print("detone", tag, "loss", r["loss"])
         _orig(importlib, Rethinking, ResNet34, configs, dtype, tag, outdir)
+        _round2(importlib, Rethinking, ResNet34, configs, dtype, tag, outdir, [])
+        if tag == "f32":
+            run_datagen(outdir)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,149 @@
+"""SURVEY.md 8(f4) branches of the head on the HIP path against fixtures from the reference's own PerceptualHead.py:
+deeper extractor outputs (AUXILIARY_RESNET_OUTPUT_LAYER 2-4), the multihead feature loss (TRIPLET_LOSS ''), the
+TensorBoard side channel, and configs[3] (ResNet-34 regressor) through three Adam steps in float32 and in the bf16 mode."""
+import numpy as np
+import pytest
+import torch
+
+from bihome_amd import configs, synth
+from bihome_amd.weights import load_synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def cuda(a, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(a)).to(dtype).cuda()
+
+
+def relerr(a, ref):
+    a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    return np.abs(a - ref).max() / (np.abs(ref).max() + 1e-30)
+
+
+class _Rec:
+    def __init__(self):
+        self.scalars = {}
+
+    def add_scalars(self, tag, values, step):
+        for k, v in values.items():
+            self.scalars["tb/%s/%s" % (tag, k)] = float(v)
+
+
+def _model(cfg):
+    from bihome_amd.step import build_model
+    model = build_model(cfg)
+    load_synthetic(model[0], 0)
+    load_synthetic(model[1].auxiliary_resnet, 0)
+    return model
+
+
+@pytest.mark.parametrize("layer", [1, 2, 3, 4])
+def test_extractor_output_layers_vs_golden(golden, layer):
+    """Loss, delta_hat, MACE, gradient norms and every TensorBoard scalar of the reference head for extractor outputs
+    layer1..layer4 (feature strides 4 / 8 / 16 / 32 = mask pooling factors; 64 / 128 / 256 / 512 channels)."""
+    from bihome_amd.step import mace
+    name = "zeng_tb_b4" if layer == 1 else "zeng_aux%d_b4" % layer
+    g32, g64 = golden(name + "_f32"), golden(name + "_f64")
+    cfg = configs.get("zeng-bihome")
+    cfg["MODEL"]["HEAD"]["AUXILIARY_RESNET_OUTPUT_LAYER"] = layer
+    model = _model(cfg)
+    assert set(k for k in model[1].auxiliary_resnet.state_dict() if "layer" in k) == \
+        set(k for k in model[1].auxiliary_resnet.state_dict() if any("layer%d." % i in k for i in range(1, layer + 1)))
+    model.train()
+    d = synth.make_pairs(4, seed=17)
+    data = {k: cuda(d[k]) for k in ("patch_1", "patch_2", "delta")}
+    data["choice_12"], data["choice_21"] = cuda(g64["choice_12"][0], torch.int64), cuda(g64["choice_21"][0], torch.int64)
+    rec = _Rec()
+    data["summary_writer"], data["summary_writer_step"] = rec, 1
+    loss, dgt, dh = model(data)
+    loss.backward()
+    spread = abs(g32["loss"][0] - g64["loss"][0])
+    assert abs(loss.item() - g64["loss"][0]) <= max(3 * spread, 2e-4 * abs(g64["loss"][0])), (loss.item(), g64["loss"][0], g32["loss"][0])
+    assert relerr(dh.detach().cpu(), g64["delta_hat_12"]) < 1e-3
+    assert abs(mace(dgt, dh) - g64["mace"][0]) < 1e-3
+    params = dict(model[0].named_parameters())
+    for n in ("layer1.0.weight", "layer4.6.upper_branch.0.weight", "layer8.3.weight", "layer8.3.bias"):
+        gn, ref, sp = params[n].grad.double().norm().item(), g64["gradnorm/" + n], abs(g64["gradnorm/" + n] - g32["gradnorm/" + n])
+        assert abs(gn - ref) <= max(5 * sp, 5e-3 * ref), (n, gn, ref, sp)
+    tb = {k for k in g64 if k.startswith("tb/")}
+    assert set(rec.scalars) == tb and len(tb) == 8
+    for k in tb:
+        tol = max(3 * abs(g32[k] - g64[k]), 2e-4 * abs(g64[k]))
+        assert abs(rec.scalars[k] - g64[k]) <= tol, (k, rec.scalars[k], g64[k], g32[k])
+    np.testing.assert_allclose(model[1].auxiliary_resnet.resnet.bn1.running_mean.cpu().numpy(), g64["aux_bn1_running_mean"],
+                               rtol=1e-4, atol=1e-5)
+
+
+def test_multihead_feature_loss_vs_golden(golden):
+    """TRIPLET_LOSS '' (multihead_resnet_loss, PerceptualHead.py:245-315) with the driver's L1Loss (train.py:318-322): the
+    returned feature tensors (NCHW as upstream), two Adam steps, TensorBoard scalars."""
+    from bihome_amd.step import build_loss, build_optimizer, mace, train_step
+    g32, g64 = golden("zeng_multihead_b4_f32"), golden("zeng_multihead_b4_f64")
+    cfg = configs.get("zeng-multihead")
+    model = _model(cfg)
+    opt, sched = build_optimizer(model, cfg["SOLVER"])
+    loss_fn = build_loss(cfg["SOLVER"])
+    assert isinstance(loss_fn, torch.nn.L1Loss)
+    d = synth.make_pairs(4, seed=17)
+    losses, maces = [], []
+    for it in range(2):
+        data = {k: cuda(d[k]) for k in ("patch_1", "patch_2", "delta")}
+        data["choice_12"] = cuda(g64["choice_12"][it], torch.int64)
+        rec = _Rec()
+        if it == 0:
+            data["summary_writer"], data["summary_writer_step"] = rec, 1
+            model.train()
+            gt, out, dgt, dh = model(data)
+            assert gt.shape == out.shape == (4, 64, 32, 32)
+            o = out.detach().double().cpu()
+            cs = np.array([o.sum().item(), o.abs().sum().item(), (o * o).sum().item()])
+            np.testing.assert_allclose(cs, g64["network_output_csum"], rtol=2e-4)
+            assert relerr(o[:, ::8, ::2, ::2], g64["network_output_sub"]) < 1e-3
+            for k in (k for k in g64 if k.startswith("tb/")):
+                assert abs(rec.scalars[k] - g64[k]) <= max(3 * abs(g32[k] - g64[k]), 2e-4 * abs(g64[k])), k
+        loss, dgt, dh = train_step(model, data, opt, sched, loss_fn=loss_fn)
+        losses.append(loss.item()); maces.append(mace(dgt, dh))
+    assert abs(losses[0] - g64["loss"][0]) <= 1e-4 * abs(g64["loss"][0]), (losses, g64["loss"])
+    assert abs(maces[0] - g64["mace"][0]) < 1e-3
+    assert abs(losses[1] - g64["loss"][1]) <= max(20 * abs(g32["loss"][1] - g64["loss"][1]), 2e-3 * abs(g64["loss"][1]))
+
+
+@pytest.mark.parametrize("precision,head_precision", [("f32", "f32"), ("bf16", "bf16"), ("bf16", "f32")])
+def test_detone_three_steps_vs_golden(golden, precision, head_precision):
+    """configs[3] (ResNet-34 regressor + biHomE, B = 8, three Adam steps, lr 5e-3) against the reference fixture.
+    float32: first step tight, later steps within a multiple of the reference's own float32-vs-float64 spread (loss 86.0
+    vs 81.8 at step 2: training from random weights at this learning rate amplifies rounding).
+    bf16 (bf16 MFMA operands, float32 accumulate; backbone only, or backbone and extractor): delta_hat is a direct
+    network output, so 2^-9 operand rounding through 36 conv layers shows up directly in MACE (measured 0.0105 px at
+    step 0), and the loss is a difference of two nearly equal feature distances (|f1w-f2| - |f1-f2|), which amplifies
+    the extractor's rounding (measured 3.4 % at step 0 with a bf16 extractor).  Stated tolerances: step 0 loss within
+    5 % (bf16 extractor) / 1 % (f32 extractor), MACE within 0.02 px; later steps loss within 25 %, MACE within 15x the
+    float32 reference's own f32-vs-f64 spread.  north_star's "MACE within 1e-3" is NOT met in bf16 - DESIGN.md 8."""
+    from bihome_amd.step import build_optimizer, mace, train_step
+    g32, g64 = golden("detone_b8_f32"), golden("detone_b8_f64")
+    cfg = configs.get("detone-bihome")
+    cfg["MODEL"]["BACKBONE"]["PRECISION"] = precision
+    cfg["MODEL"]["HEAD"]["PRECISION"] = head_precision
+    model = _model(cfg)
+    opt, sched = build_optimizer(model, cfg["SOLVER"])
+    d = synth.make_pairs(8, seed=5)
+    losses, maces = [], []
+    for it in range(3):
+        data = {k: cuda(d[k]) for k in ("patch_1", "patch_2", "delta")}
+        loss, dgt, dh = train_step(model, data, opt, sched)
+        losses.append(loss.item()); maces.append(mace(dgt, dh))
+        if it == 0 and precision == "f32":
+            assert relerr(dh.cpu(), g64["delta_hat_12"][0]) < 1e-3
+    print(precision, head_precision, "loss", losses, "mace", maces, "ref", g64["loss"], g64["mace"])
+    if precision == "f32":
+        assert abs(losses[0] - g64["loss"][0]) <= max(3 * abs(g32["loss"][0] - g64["loss"][0]), 1e-4 * abs(g64["loss"][0]))
+        assert abs(maces[0] - g64["mace"][0]) < 1e-3
+        mult, lrel = 5.0, 0.05
+    else:
+        assert abs(losses[0] - g64["loss"][0]) <= (5e-2 if head_precision == "bf16" else 1e-2) * abs(g64["loss"][0])
+        assert abs(maces[0] - g64["mace"][0]) < 2e-2
+        mult, lrel = 15.0, 0.25
+    for it in (1, 2):
+        sp_l, sp_m = abs(g32["loss"][it] - g64["loss"][it]), abs(g32["mace"][it] - g64["mace"][it])
+        assert abs(losses[it] - g64["loss"][it]) <= max(mult * sp_l, lrel * abs(g64["loss"][it])), (it, losses, g64["loss"])
+        assert abs(maces[it] - g64["mace"][it]) <= max(mult * sp_m, 0.05), (it, maces, g64["mace"])

@@ -143,3 +143,102 @@ def test_ihome_one_line(golden):
         np.testing.assert_allclose(O.mace(dgt, dh), g["mace"][it], rtol=1e-7)
         if it == 0:
             np.testing.assert_allclose(dh.numpy(), g["delta_hat_12"], atol=1e-7)
+
+
+class _Rec:
+    def __init__(self):
+        self.scalars = {}
+
+    def add_scalars(self, tag, values, step):
+        for k, v in values.items():
+            self.scalars["tb/%s/%s" % (tag, k)] = float(v)
+
+
+def test_detone_three_steps(golden):
+    """configs[3]'s model, three Adam steps at B=8 (fixture: reference ResNet34.py + PerceptualHead.py), float64."""
+    g = golden("detone_b8_f64")
+    cfg = configs.get("detone-bihome")
+    bb, head = O.build(cfg)
+    load_synthetic(bb, 0)
+    load_synthetic(head.auxiliary_resnet, 0)
+    bb.double(); head.double()
+    opt, sched = O.make_optimizer(torch.nn.Sequential(bb, head), cfg["SOLVER"])
+    d = synth.make_pairs(8, seed=5)
+    for it in range(3):
+        data = {k: _t(d[k], torch.float64) for k in ("patch_1", "patch_2", "delta")}
+        loss, dgt, dh = O.train_step(bb, head, opt, sched, data)
+        assert abs(loss.item() - g["loss"][it]) <= 1e-7 * abs(g["loss"][it]), it
+        np.testing.assert_allclose(O.mace(dgt, dh), g["mace"][it], rtol=1e-7)
+        np.testing.assert_allclose(dh.numpy(), g["delta_hat_12"][it], atol=1e-6)
+
+
+@pytest.mark.parametrize("layer", [2, 3, 4])
+def test_extractor_output_layers(golden, layer):
+    """AUXILIARY_RESNET_OUTPUT_LAYER 2/3/4 (PerceptualHead.py:24-33,62-67; mask downsample factor 8/16/32 :450): first
+    step loss, delta_hat, gradient norms and the head's TensorBoard side channel (:678-697) against the reference."""
+    g = golden("zeng_aux%d_b4_f64" % layer)
+    cfg = configs.get("zeng-bihome")
+    cfg["MODEL"]["HEAD"]["AUXILIARY_RESNET_OUTPUT_LAYER"] = layer
+    bb, head = O.build(cfg)
+    load_synthetic(bb, 0)
+    load_synthetic(head.auxiliary_resnet, 0)
+    bb.double(); head.double()
+    opt, sched = O.make_optimizer(torch.nn.Sequential(bb, head), cfg["SOLVER"])
+    d = synth.make_pairs(4, seed=17)
+    data = {k: _t(d[k], torch.float64) for k in ("patch_1", "patch_2", "delta")}
+    rec = _Rec()
+    data["summary_writer"], data["summary_writer_step"] = rec, 1
+    loss, dgt, dh = O.train_step(bb, head, opt, sched, data, _t(g["choice_12"][0], torch.int64), _t(g["choice_21"][0], torch.int64))
+    assert abs(loss.item() - g["loss"][0]) <= 1e-8 * abs(g["loss"][0])
+    np.testing.assert_allclose(dh.numpy(), g["delta_hat_12"], atol=1e-7)
+    for k in g:
+        if k.startswith("tb/"):
+            np.testing.assert_allclose(rec.scalars[k], g[k], rtol=1e-7, err_msg=k)
+    assert set(rec.scalars) == {k for k in g if k.startswith("tb/")}
+
+
+def test_multihead_feature_loss(golden):
+    """TRIPLET_LOSS '' -> multihead_resnet_loss (PerceptualHead.py:245-315) + the driver's torch loss (train.py:318-322)."""
+    g = golden("zeng_multihead_b4_f64")
+    cfg = configs.get("zeng-multihead")
+    bb, head = O.build(cfg)
+    assert head.multihead
+    load_synthetic(bb, 0)
+    load_synthetic(head.auxiliary_resnet, 0)
+    bb.double(); head.double()
+    opt, sched = O.make_optimizer(torch.nn.Sequential(bb, head), cfg["SOLVER"])
+    loss_fn = getattr(torch.nn, cfg["SOLVER"]["LOSS"])()
+    d = synth.make_pairs(4, seed=17)
+    for it in range(2):
+        data = {k: _t(d[k], torch.float64) for k in ("patch_1", "patch_2", "delta")}
+        rec = _Rec()
+        if it == 0:
+            data["summary_writer"], data["summary_writer_step"] = rec, 1
+        loss, dgt, dh = O.train_step(bb, head, opt, sched, data, _t(g["choice_12"][it], torch.int64), loss_fn=loss_fn)
+        assert abs(loss.item() - g["loss"][it]) <= 1e-8 * abs(g["loss"][it])
+        np.testing.assert_allclose(O.mace(dgt, dh), g["mace"][it], rtol=1e-7)
+        if it == 0:
+            for k in g:
+                if k.startswith("tb/"):
+                    np.testing.assert_allclose(rec.scalars[k], g[k], rtol=1e-7, err_msg=k)
+
+
+def test_bihome_tensorboard_keys(golden):
+    """The shipped biHomE config with the driver's log-step side channel on: every key / value the reference head writes."""
+    g = golden("zeng_tb_b4_f64")
+    cfg = configs.get("zeng-bihome")
+    bb, head = O.build(cfg)
+    load_synthetic(bb, 0)
+    load_synthetic(head.auxiliary_resnet, 0)
+    bb.double(); head.double()
+    opt, sched = O.make_optimizer(torch.nn.Sequential(bb, head), cfg["SOLVER"])
+    d = synth.make_pairs(4, seed=17)
+    data = {k: _t(d[k], torch.float64) for k in ("patch_1", "patch_2", "delta")}
+    rec = _Rec()
+    data["summary_writer"], data["summary_writer_step"] = rec, 1
+    loss, _, _ = O.train_step(bb, head, opt, sched, data, _t(g["choice_12"][0], torch.int64), _t(g["choice_21"][0], torch.int64))
+    assert abs(loss.item() - g["loss"][0]) <= 1e-8 * abs(g["loss"][0])
+    tb = {k for k in g if k.startswith("tb/")}
+    assert tb == set(rec.scalars) and len(tb) == 8
+    for k in tb:
+        np.testing.assert_allclose(rec.scalars[k], g[k], rtol=1e-7, err_msg=k)
