@@ -97,8 +97,8 @@ def pmc_traffic(kernel):
         except Exception:
             continue
         if key in ks:
-            return ks[key]["traffic_bytes_per_launch"]
-    return None
+            return ks[key]["traffic_bytes_per_launch"], os.path.relpath(path, ROOT)
+    return None, None
 
 
 def roofline_leg(model, data, opt, sched, reducer, nsteps=2):
@@ -120,7 +120,7 @@ def roofline_leg(model, data, opt, sched, reducer, nsteps=2):
     K.TIMING = None
     rows.sort(key=lambda r: -r["ms_per_step"])
     top = rows[0]
-    traffic = pmc_traffic(top["kernel"])
+    traffic, traffic_src = pmc_traffic(top["kernel"])
     # BASELINE.json's HBM-bound part: homography warp + perceptual-feature L1 / triplet reduction (SURVEY.md 8(d) bytes)
     hp = [r for r in rows if r["kernel"] in ("warp_fwd_kernel", "warp_bwd_kernel", "triplet_fwd_kernel", "triplet_bwd_kernel")]
     hbm_path = None
@@ -158,13 +158,13 @@ def roofline_leg(model, data, opt, sched, reducer, nsteps=2):
     if top["tflops"] > 0:
         roof = {"kernel": top["kernel"], "bound": "mfma", "achieved": top["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": top["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": top["bytes_per_launch"],
+                "traffic_source": traffic_src, "algorithmic_bytes_per_launch": top["bytes_per_launch"],
                 "avg_launch_us": top["avg_us"], "flops_per_launch": top["flops_per_launch"],
                 "launches_per_step": top["launches_per_step"], "by_kernel_template": families,
                 "warp_perceptual_path": hbm_path}
     else:
         roof = {"kernel": top["kernel"], "bound": "hbm", "achieved": top["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "frac": top["gbs"] / PEAK_HBM_GBS, "traffic": traffic, "avg_launch_us": top["avg_us"],
+                "frac": top["gbs"] / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": top["avg_us"],
                 "bytes_per_launch": top["bytes_per_launch"], "launches_per_step": top["launches_per_step"]}
     return roof, rows
 
@@ -208,7 +208,10 @@ def main():
     if args.overlap:
         os.environ["BIHOME_OVERLAP"] = "1"
     if args.hook:
-        from bihome_amd._lib import lib
+        from bihome_amd._lib import TUNING, lib
+        if not TUNING:
+            raise SystemExit("--hook needs the -DBH_TUNING library: `make -C bihome_amd/csrc tuning` and BIHOME_TUNING=1 "
+                             "(the product library has no process-global tuning state)")
         for h in args.hook:
             a_, b_ = (int(v) for v in h.split(","))
             lib.bh_debug_force_tile(a_, b_)

@@ -8,12 +8,18 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbihome_hip.so")
+# BIHOME_TUNING=1 (tools/ only): the -DBH_TUNING build with the bh_debug_force_tile ablation hooks (`make -C csrc tuning`)
+TUNING = os.environ.get("BIHOME_TUNING") == "1"
+LIB_PATH = os.path.join(_HERE, "libbihome_hip_tuning.so" if TUNING else "libbihome_hip.so")
 
 
 class BhConvDesc(Structure):
     _fields_ = [(n, c_int) for n in ("N", "Hi", "Wi", "Ci", "Ho", "Wo", "Co", "kh", "kw", "stride", "pad",
-                                     "transposed", "in_nchw", "out_nchw", "precision")]
+                                     "transposed", "in_nchw", "out_nchw", "precision", "route")]
+
+
+# bh_conv_desc.route bits (include/bihome.h): explicit per-call kernel routing for tests / benchmarks; 0 = automatic
+ROUTE_GENERIC_CONV, ROUTE_HALO_SMALL, ROUTE_NO_STEM7, ROUTE_WGRAD_GENERIC, ROUTE_WGRAD_3TAP = 1, 2, 4, 8, 16
 
 
 class BhBnReduce(Structure):
@@ -38,7 +44,7 @@ SIGNATURES = {
     "bh_bihome_loss_bwd": [P] * 14 + [c_int, c_int, c_int, c_float] + [P] * 6 + [P],
     "bh_oneline_loss_fwd": [P, P, P, P, P, c_int, c_int, c_int, c_float, P, P, P, P],
     "bh_oneline_loss_bwd": [P, P, P, P, P, P, P, c_int, c_int, c_int, P, P, P],
-    "bh_debug_force_tile": [c_int, c_int],
+    "bh_conv_variant": [POINTER(BhConvDesc), c_int, c_int, c_int, c_char_p, c_int],
     "bh_conv_fwd": [P, P, P, P, POINTER(BhConvDesc), P],
     "bh_conv_fwd_act": [P, P, P, P, P, POINTER(BhConvDesc), c_int, P],
     "bh_conv_fwd_bnstats": [P, P, P, P, POINTER(BhConvDesc), P, c_int, P],
@@ -84,6 +90,9 @@ def _load():
             raise BihomeLibError("bihome_amd: %s does not export %s (stale build?)" % (LIB_PATH, name)) from e
         fn.argtypes = argtypes
         fn.restype = c_int
+    if TUNING:
+        lib.bh_debug_force_tile.argtypes = [c_int, c_int]
+        lib.bh_debug_force_tile.restype = c_int
     return lib
 
 

@@ -1,6 +1,23 @@
 // Library probe entry points.
 #include "common.h"
+#include <stdarg.h>
+#include <stdio.h>
 #include <string.h>
+
+thread_local BhQuery* bh_query_ctx = nullptr;
+
+bool bh_query(const char* fmt, ...) {
+    BhQuery* q = bh_query_ctx;
+    if (!q) return false;
+    if (q->len && q->len < (int)sizeof(q->name) - 1) q->name[q->len++] = '+';
+    va_list ap;
+    va_start(ap, fmt);
+    const int room = (int)sizeof(q->name) - q->len;
+    const int w = vsnprintf(q->name + q->len, (size_t)room, fmt, ap);
+    va_end(ap);
+    if (w > 0) q->len += w < room ? w : room - 1;
+    return true;
+}
 
 extern "C" {
 
@@ -14,6 +31,25 @@ int bh_device_arch(char* buf, int buflen) {
         strncpy(buf, prop.gcnArchName, (size_t)buflen - 1);
         buf[buflen - 1] = 0;
     }
+    return BH_OK;
+}
+
+int bh_conv_variant(const bh_conv_desc* d, int which, int accumulate, int with_bnstats, char* buf, int n) {
+    if (!d || !buf || n < 2 || which < 0 || which > 2) return BH_E_BADARG;
+    BhQuery q;
+    q.name[0] = 0; q.len = 0;
+    // non-null placeholders: in query mode no kernel is launched and no pointer is dereferenced
+    float* p = reinterpret_cast<float*>(static_cast<uintptr_t>(256));
+    double* pd = reinterpret_cast<double*>(static_cast<uintptr_t>(256));
+    bh_query_ctx = &q;
+    int rc;
+    if (which == 0) rc = with_bnstats ? bh_conv_fwd_bnstats(p, p, nullptr, p, d, pd, 1, nullptr) : bh_conv_fwd(p, p, nullptr, p, d, nullptr);
+    else if (which == 1) rc = bh_conv_dgrad(p, p, p, d, accumulate, nullptr);
+    else rc = bh_conv_wgrad(p, p, p, nullptr, d, nullptr);
+    bh_query_ctx = nullptr;
+    if (rc) return rc;
+    strncpy(buf, q.name, (size_t)n - 1);
+    buf[n - 1] = 0;
     return BH_OK;
 }
 

@@ -21,6 +21,29 @@
 
 static inline hipStream_t bh_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Tuning knobs: compile-time constants in the product library, process-global variables only under -DBH_TUNING
+#ifdef BH_TUNING
+#define BH_KNOB(name, val) int name = val
+#define BH_KNOB_EXTERN(name) extern int name
+#else
+#define BH_KNOB(name, val) static constexpr int name = val
+#define BH_KNOB_EXTERN(name) static_assert(true, "")
+#endif
+
+// bh_conv_variant: while a query is active on this thread, dispatchers record the kernel they would launch and return
+struct BhQuery { char name[256]; int len; };
+extern thread_local BhQuery* bh_query_ctx;
+bool bh_query(const char* fmt, ...);       // true (and the name appended) when a query is active: the caller skips its launch
+
+// per-device one-time flags (hipFuncSetAttribute is per device)
+static inline bool bh_device_once(unsigned long long& mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+    if (mask & (1ull << dev)) return false;
+    mask |= 1ull << dev;
+    return true;
+}
+
 __device__ __forceinline__ size_t bn_sum_index(int slot, int groups, int grp, int C, int c, int mom) {
     return ((((size_t)slot * groups + grp) * C + c) * 2 + mom) * BH_BN_SUM_STRIDE;
 }

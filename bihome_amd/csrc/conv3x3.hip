@@ -113,7 +113,13 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
             boff[i] = n < a.Nn ? ((unsigned)(k * 9) * (unsigned)a.Cw + (unsigned)n) * 4u : OOB;
         }
     }
+#ifdef BH_TUNING
     const int nch = a.dbg_nch >= 0 ? a.dbg_nch : a.Kc / 32;     // (ablation hook: bh_debug_force_tile(-8, n) caps the chunk loop)
+    const int dbg_noload = a.dbg_noload;
+#else
+    const int nch = a.Kc / 32;
+    constexpr int dbg_noload = 0;
+#endif
     // a single chunk (32 source channels) never touches the second halo stage: the host then launches with one stage less
     // of LDS (41.6 instead of 67.2 KB: three workgroups per CU for the 32-channel layers) and the slabs move down
     const int slab0 = (a.Kc / 32 > 1 ? 2 : 1) * HALO_B;
@@ -219,11 +225,11 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
                     b[q].w = *reinterpret_cast<const float*>(bp + (q * 8 + 3) * (BN * 4));
                 }
             }
-            if (!(a.dbg_noload & 1)) {
+            if (!(dbg_noload & 1)) {
                 if (tap < 8) issue_B(c, tap + 1, bs ^ 1);
                 else if (more) issue_B(c + 1, 0, bs ^ 1);
             }
-            if (tap < HJ && more && !(a.dbg_noload & 2)) C3_ISSUE_HALO(tap, c + 1, hs ^ 1);
+            if (tap < HJ && more && !(dbg_noload & 2)) C3_ISSUE_HALO(tap, c + 1, hs ^ 1);
             if constexpr (BF16) {
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
@@ -419,23 +425,24 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
     }
 }
 
-static int g_c3_noload = 0;
-static int g_c3_disable = 0, g_c3_min_blocks = 256, g_c3_dbg_nch = -1, g_c3_subt = 2, g_c3_tpb = 2;
+constexpr int C3_MIN_BLOCKS = 256;      // below this many workgroups the generic kernel's finer tiles fill the chip better
+BH_KNOB(g_c3_noload, 0); BH_KNOB(g_c3_dbg_nch, -1); BH_KNOB(g_c3_subt, 2); BH_KNOB(g_c3_tpb, 2);
+#ifdef BH_TUNING
 void bh_conv3x3_tune(int disable, int min_blocks) {
-    if (disable <= -100) { g_c3_dbg_nch = -100 - disable - 1; return; }
+    (void)min_blocks;
+    if (disable <= -100) { g_c3_dbg_nch = -100 - disable - 1; return; }            // -100 -> -1 (all), -101 -> 0 chunks, -102 -> 1 ...
     if (disable >= 60 && disable < 64) { g_c3_noload = disable - 60; return; }
-    if (disable >= 20 && disable < 24) { g_c3_tpb = disable - 20; return; }                // tile positions per workgroup on two-round launches (1 / 2)
-    if (disable >= 11 && disable <= 13) { g_c3_subt = disable - 10; return; }      // 1 / 2 (automatic) / 3 (always two) sub-tiles per workgroup     // -100 -> -1 (all), -101 -> 0 chunks, -102 -> 1 ...
-    g_c3_disable = disable;
-    if (min_blocks > 0) g_c3_min_blocks = min_blocks;
+    if (disable >= 20 && disable < 24) { g_c3_tpb = disable - 20; return; }        // tile positions per workgroup on two-round launches (1 / 2)
+    if (disable >= 11 && disable <= 13) { g_c3_subt = disable - 10; return; }      // 1 / 2 (automatic) / 3 (always two) sub-tiles per workgroup
 }
+#endif
 
 // *taken = 1 when the shape is eligible and the launch was made; returns BH_OK or a hipError_t
 int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* out, const bh_conv_desc* d, int dgrad,
                    int accumulate, hipStream_t stream, int* taken, double* bn_sums, int groups, const float* res, int relu,
                    const bh_bn_reduce* bnr) {
     *taken = 0;
-    if (g_c3_disable || d->transposed || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->in_nchw ||
+    if ((d->route & BH_ROUTE_GENERIC_CONV) || d->transposed || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->in_nchw ||
         d->out_nchw || (d->precision != 0 && d->precision != 1))
         return 0;
     if (d->Hi % 8 || d->Wi % 8 || d->Ho != d->Hi || d->Wo != d->Wi) return 0;
@@ -474,8 +481,12 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
         const long long wgs = (long long)grid.x * grid.y;
         if (g_c3_tpb >= 2 && subt == 2 && Kc / 32 > 1 && wgs > 512 && wgs <= 1024) { a.tpb = 2; grid.x = (grid.x + 1) / 2; }
     }
-    if ((int)(((a.subtiles + 1) / 2) * grid.y) < g_c3_min_blocks) return 0;
-    static bool attr_set = false;
+    if (!(d->route & BH_ROUTE_HALO_SMALL) && (int)(((a.subtiles + 1) / 2) * grid.y) < C3_MIN_BLOCKS) return 0;
+    if (bh_query("conv3x3_halo_kernel<%s,%d,%s,%d>", dgrad ? "true" : "false", bn_tile, d->precision == 1 ? "true" : "false", subt)) {
+        *taken = 1;
+        return BH_OK;
+    }
+    static unsigned long long attr_devs = 0;             // devices on which the dynamic-LDS attributes have been set
     typedef void (*kern_t)(C3Args);
     static const kern_t fns[12] = {conv3x3_halo_kernel<false, 64, false>, conv3x3_halo_kernel<true, 64, false>,
                                    conv3x3_halo_kernel<false, 32, false>, conv3x3_halo_kernel<true, 32, false>,
@@ -484,13 +495,12 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
                                    conv3x3_halo_kernel<false, 64, false, 1>, conv3x3_halo_kernel<true, 64, false, 1>,
                                    conv3x3_halo_kernel<false, 64, true, 1>,  conv3x3_halo_kernel<true, 64, true, 1>};
     constexpr int LDS1 = 2 * (8 * 100 * 16) + 2 * C3_B_BYTES;           // one sub-tile per workgroup: 41,984 B
-    if (!attr_set) {
+    if (bh_device_once(attr_devs)) {
         for (int i = 0; i < 12; ++i) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[i]), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                i < 8 ? C3_LDS_BYTES : LDS1);
             if (e != hipSuccess) return (int)e;
         }
-        attr_set = true;
     }
     const kern_t fn = subt == 1 ? fns[8 + (d->precision == 1 ? 2 : 0) + (dgrad ? 1 : 0)]
                                 : fns[(d->precision == 1 ? 4 : 0) + (bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0)];

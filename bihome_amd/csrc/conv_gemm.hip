@@ -704,6 +704,9 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
 
 template <int BM, int BN, int BK, bool VEC, bool BF16 = false>
 static int launch(const GemmArgs& a, hipStream_t s) {
+    if (bh_query("conv_gemm_kernel<%d,%d,%d,%s,%s,%s>", BM, BN, BK, VEC ? "true" : "false", BF16 ? "true" : "false",
+                 (VEC && a.use_buf) ? "true" : "false"))
+        return BH_OK;
     dim3 grid((a.M + BM - 1) / BM, (a.Nn + BN - 1) / BN);
     if constexpr (VEC) {
         if (a.use_buf) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, VEC, BF16, true>), grid, dim3(256), 0, s, a);
@@ -717,8 +720,12 @@ static int launch(const GemmArgs& a, hipStream_t s) {
 
 // Tile choice: the largest tile that still gives the 256 CUs about two workgroups each; the small-spatial
 // layers (8x8x256ch, 16x16x128ch at 2B = 128) otherwise launch only 128-256 workgroups.
+#ifdef BH_TUNING
 extern int g_wgrad_target, g_wgrad_noflush, g_wgrad_xcd_map, g_wgrad_s1, g_wgrad_s1_target, g_wgrad_s3_target;
 static int g_force_bm = 0, g_force_bn = 0, g_prio = 0, g_no_buf = 0;     // tuning hook (bh_debug_force_tile), 0 = automatic
+#else
+static constexpr int g_force_bm = 0, g_force_bn = 0, g_prio = 0, g_no_buf = 0;
+#endif
 
 static int dispatch(const GemmArgs& a_in, hipStream_t s) {
     GemmArgs a = a_in;
@@ -901,13 +908,15 @@ __global__ void __launch_bounds__(256) col2im_c1_kernel(const float* __restrict_
     }
 }
 
+#ifdef BH_TUNING
 void bh_conv3x3_tune(int disable, int min_blocks);
+void bh_stem7_tune(int disable);
+void bh_warp_tune(int which, int n);
+#endif
 int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* out, const bh_conv_desc* d, int dgrad,
                    int accumulate, hipStream_t stream, int* taken, double* bn_sums, int groups, const float* res = nullptr,
                    int relu = 0, const bh_bn_reduce* bnr = nullptr);
 int bn_launch_stats(const float* x, int groups, int rows, int C, double* sums, hipStream_t s);
-void bh_stem7_tune(int disable);
-void bh_warp_tune(int which, int n);
 int bh_stem7_try(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, int relu,
                  hipStream_t stream, int* taken);
 
@@ -941,16 +950,14 @@ int bh_col2im_c1(const float* Tm, float* gx, const bh_conv_desc* d, int ldT, voi
     return BH_OK;
 }
 
+#ifdef BH_TUNING
 int bh_debug_force_tile(int bm, int bn) {
     if (bm == -1) { g_prio = bn; return BH_OK; }            // (-1, bits): 1 s_setprio, 2 no global reloads, 4 no LDS restaging (ablations)
     if (bm == -2) { g_no_buf = bn; return BH_OK; }          // (-2, 1): disable the buffer-load fast path
     if (bm == -3) { g_wgrad_target = bn; return BH_OK; }    // (-3, n): wgrad split-K work items per launch
-    if (bm == -4) { bh_conv3x3_tune(bn, 0); return BH_OK; } // (-4, 1): disable the halo-tiled 3x3 kernel
-    if (bm == -5) { bh_conv3x3_tune(0, bn); return BH_OK; } // (-5, n): minimum workgroups for the halo-tiled 3x3 kernel
-    if (bm == -6) { bh_stem7_tune(bn); return BH_OK; }
+    // (-4 / -5 / -6 / -16 of round 1 - kernel routing - are now per-call bits of bh_conv_desc.route)
     if (bm == -7) { g_wgrad_noflush = bn; return BH_OK; }
     if (bm == -10) { g_wgrad_xcd_map = bn; return BH_OK; }              // (-10, 0|1): XCD-aware wgrad work order off / on
-    if (bm == -16) { g_wgrad_s1 = bn; return BH_OK; }                    // (-16, 0|1|3): stride-1 wgrad fast path off / one tap / three taps per workgroup
     if (bm == -19) { g_wgrad_s3_target = bn; return BH_OK; }             // (-19, n): workgroups per launch of the three-tap wgrad variant
     if (bm == -17) { g_wgrad_s1_target = bn; return BH_OK; }             // (-17, n): its split-K work items per launch
     if (bm == -18) { bh_conv3x3_tune(60 + bn, 0); return BH_OK; }       // (-18, bits): 3x3 kernel ablation - 1 no weight DMA, 2 no halo DMA in the loop
@@ -961,6 +968,7 @@ int bh_debug_force_tile(int bm, int bn) {
     if (bm == -8) { bh_conv3x3_tune(-101 - bn, 0); return BH_OK; }  // (-8, n): ablation - 3x3 kernel runs n channel chunks only (-1: all)   // (-7, 1): ablation - wgrad without its atomic flush      // (-6, 1): disable the dedicated 7x7 stem forward kernel
     g_force_bm = bm; g_force_bn = bn; return BH_OK;
 }
+#endif
 
 static int conv_fwd_impl(const float* x, const float* w, const float* bias, const float* res, float* y, const bh_conv_desc* d,
                          int relu, void* stream, double* bn_sums = nullptr, int groups = 1) {
@@ -1035,6 +1043,7 @@ int bh_conv_fwd_bnstats(const float* x, const float* w, const float* bias, float
         rc = bh_conv_fwd(x, w, bias, y, d, stream);
         if (rc) return rc;
     }
+    if (bh_query("bn_stats_kernel")) return BH_OK;
     return bn_launch_stats(y, groups, (d->N / groups) * d->Ho * d->Wo, d->Co, sums, bh_stream(stream));
 }
 
@@ -1081,10 +1090,12 @@ int bh_conv_dgrad_s2(const float* gy, const float* w, float* gx, const bh_conv_d
     hipStream_t s = bh_stream(stream);
     const int k = d->kh, pad = d->pad;
     const int total = d->Co * k * k * d->Ci;
-    hipLaunchKernelGGL(pack_s2_dgrad_weights_kernel, dim3((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256), dim3(256), 0, s,
-                       w, wpack, d->Co, d->Ci, k, pad);
-    BH_LAUNCH_CHECK();
-    if (k1 && !accumulate) {                       // three of the four classes have no tap: their gradient is zero
+    if (!bh_query("pack_s2_dgrad_weights_kernel")) {
+        hipLaunchKernelGGL(pack_s2_dgrad_weights_kernel, dim3((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256), dim3(256), 0, s,
+                           w, wpack, d->Co, d->Ci, k, pad);
+        BH_LAUNCH_CHECK();
+    }
+    if (k1 && !accumulate && !bh_query_ctx) {                       // three of the four classes have no tap: their gradient is zero
         hipError_t e = hipMemsetAsync(gx, 0, sizeof(float) * (size_t)d->N * d->Hi * d->Wi * d->Ci, s);
         if (e != hipSuccess) return (int)e;
     }
@@ -1143,6 +1154,7 @@ int bh_conv_dgrad(const float* gy, const float* w, float* gx, const bh_conv_desc
         (64 % (d->Co / 4)) == 0 && d->kh == 7 && d->kw == 7 && d->stride == 2) {
         const size_t lds = sizeof(float) * d->kh * d->kw * d->Co;
         dim3 grid(1024, d->stride * d->stride);
+        if (bh_query("stem_dgrad_c1_kernel<7,2>")) return BH_OK;
         hipLaunchKernelGGL((stem_dgrad_c1_kernel<7, 2>), grid, dim3(256), lds, bh_stream(stream), gy, w, gx, d->N, d->Hi,
                            d->Wi, d->Ho, d->Wo, d->Co, d->pad);
         BH_LAUNCH_CHECK();

@@ -90,12 +90,12 @@ template <int CIN>
 static int stem7_launch(const Stem7Args& a, hipStream_t s) {
     constexpr int KP = (49 * CIN + 3) / 4 * 4;
     const size_t lds = sizeof(float) * (KP * 64 + CIN * 21 * 21);
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (bh_query("stem7_fwd_kernel<%d>", CIN)) return BH_OK;
+    static unsigned long long attr_devs = 0;             // devices on which the dynamic-LDS attribute has been set
+    if (bh_device_once(attr_devs)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem7_fwd_kernel<CIN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
     }
     const int per_cu = lds > 40 * 1024 ? (lds > 80 * 1024 ? 1 : 2) : 4;
     int blocks = 256 * per_cu;
@@ -105,14 +105,12 @@ static int stem7_launch(const Stem7Args& a, hipStream_t s) {
     return BH_OK;
 }
 
-static int g_stem7_disable = 0;
-void bh_stem7_tune(int disable) { g_stem7_disable = disable; }
 
 // *taken = 1 when the shape is a stem this kernel takes and the launch was made
 int bh_stem7_try(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, int relu,
                  hipStream_t stream, int* taken) {
     *taken = 0;
-    if (g_stem7_disable || d->transposed || d->kh != 7 || d->kw != 7 || d->stride != 2 || d->pad != 3 || d->Co != 64 ||
+    if ((d->route & BH_ROUTE_NO_STEM7) || d->transposed || d->kh != 7 || d->kw != 7 || d->stride != 2 || d->pad != 3 || d->Co != 64 ||
         d->out_nchw)
         return BH_OK;
     if (!(d->Ci == 1 || ((d->Ci == 2 || d->Ci == 3 || d->Ci == 6) && d->in_nchw))) return BH_OK;

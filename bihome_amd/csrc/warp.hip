@@ -334,11 +334,13 @@ __global__ void __launch_bounds__(256) warp_bwd4_kernel(const float* __restrict_
 }
 
 // rows per thread of the pool = 4 kernels (tuning hook: bh_debug_force_tile(-14 / -15, n))
-static int g_warp_rpt_fwd = 1, g_warp_rpt_bwd = 2;       // measured (tools/hbm_path_bench.py): fwd 11.6 / 12.0 us, adjoint 14.7 / 13.4 / 15.4 us
+BH_KNOB(g_warp_rpt_fwd, 1); BH_KNOB(g_warp_rpt_bwd, 2);       // measured (tools/hbm_path_bench.py): fwd 11.6 / 12.0 us, adjoint 14.7 / 13.4 / 15.4 us
+#ifdef BH_TUNING
 void bh_warp_tune(int which, int n) {
     if (which == 0) g_warp_rpt_fwd = n;
     else g_warp_rpt_bwd = n;
 }
+#endif
 
 extern "C" {
 

@@ -632,11 +632,11 @@ __global__ void __launch_bounds__(256) plane_sum_kernel(const float* __restrict_
     if (threadIdx.x == 0) atomicAdd(out, sm[0] + sm[1] + sm[2] + sm[3]);
 }
 
-int g_wgrad_noflush = 0, g_wgrad_xcd_map = 0, g_wgrad_s1 = 1;          // stride-1 fast path: 0 off, 1 one tap per workgroup, 3 a kernel row of taps (bh_debug_force_tile(-16, n); 3 is faster
+BH_KNOB(g_wgrad_noflush, 0); BH_KNOB(g_wgrad_xcd_map, 0);          // stride-1 fast path: 0 off, 1 one tap per workgroup, 3 a kernel row of taps (bh_debug_force_tile(-16, n); 3 is faster
                                               // back to back on the 64-channel layers - 97 vs 105 us - and 3 % slower in the training step)
-int g_wgrad_s3_target = 768;   // workgroups per launch of the three-tap variant (bh_debug_force_tile(-19, n))   // (XCD-aware order: measured 7-18 % slower)
-int g_wgrad_s1_target = 2048;  // split-K work items per launch of the stride-1 kernel (bh_debug_force_tile(-17, n))
-int g_wgrad_target = 4096;      // split-K work items per launch (tuning hook: bh_debug_force_tile(-3, n))
+BH_KNOB(g_wgrad_s3_target, 768);  // workgroups per launch of the three-tap variant (bh_debug_force_tile(-19, n))   // (XCD-aware order: measured 7-18 % slower)
+BH_KNOB(g_wgrad_s1_target, 2048);  // split-K work items per launch of the stride-1 kernel (bh_debug_force_tile(-17, n))
+BH_KNOB(g_wgrad_target, 4096);     // split-K work items per launch (tuning hook: bh_debug_force_tile(-3, n))
 
 extern "C" {
 
@@ -733,27 +733,31 @@ int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, cons
         a.rows_per_block = (((a.M + sp - 1) / sp) + 4 * WBK - 1) / (4 * WBK) * (4 * WBK);
         sp = (a.M + a.rows_per_block - 1) / a.rows_per_block;
         dim3 g2(tiles, groups_y, sp);
+        if (bh_query("wgrad_small_taps_kernel<%d>", a.T == 9 ? 3 : 2)) return BH_OK;
         if (a.T == 9) hipLaunchKernelGGL((wgrad_small_taps_kernel<3>), g2, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((wgrad_small_taps_kernel<2>), g2, dim3(256), 0, s, a);
     } else if (small) {
+        if (bh_query("wgrad_small_kernel<%s>", vec ? "true" : "false")) return BH_OK;
         if (vec) hipLaunchKernelGGL((wgrad_small_kernel<true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((wgrad_small_kernel<false>), grid, dim3(256), 0, s, a);
-    } else if (g_wgrad_s1 && vec && a.use_buf && (d->precision == 0 || d->precision == 1) && !d->transposed && d->stride == 1 && d->Ho == d->Hi &&
+    } else if (!(d->route & BH_ROUTE_WGRAD_GENERIC) && vec && a.use_buf && (d->precision == 0 || d->precision == 1) && !d->transposed && d->stride == 1 && d->Ho == d->Hi &&
                d->Wo == d->Wi && a.hwshift >= 0 && a.M % WBK == 0 && a.Np % 64 == 0 && a.Nq % 64 == 0 && !a.xcd_map) {
         // taps per workgroup: in bf16 mode the loop is so short that the launch is bound by its operand traffic (each tap
         // re-reads x and gy: 320 MB per launch) - three taps per workgroup share gy and a third of it goes away
-        const int nt = (a.kw == 3 && (g_wgrad_s1 >= 3 || d->precision == 1)) ? 3 : 1;
+        const int nt = (a.kw == 3 && ((d->route & BH_ROUTE_WGRAD_3TAP) || d->precision == 1)) ? 3 : 1;
         const int gy = ty / nt;
         int sp = (nt == 3 ? g_wgrad_s3_target : g_wgrad_s1_target) / (tiles * gy);        // round DOWN: at most `target` workgroups
         if (sp > maxsplit) sp = maxsplit;
         if (sp < 1) sp = 1;
         a.rows_per_block = (((a.M + sp - 1) / sp) + WBK - 1) / WBK * WBK;
         sp = (a.M + a.rows_per_block - 1) / a.rows_per_block;
+        if (bh_query("wgrad_s1_kernel<%d,%s>", nt, d->precision == 1 ? "true" : "false")) return BH_OK;
         if (d->precision == 1 && nt == 3) hipLaunchKernelGGL((wgrad_s1_kernel<3, true>), dim3(tiles, gy, sp), dim3(256), 0, s, a);
         else if (d->precision == 1) hipLaunchKernelGGL((wgrad_s1_kernel<1, true>), dim3(tiles, gy, sp), dim3(256), 0, s, a);
         else if (nt == 3) hipLaunchKernelGGL((wgrad_s1_kernel<3, false>), dim3(tiles, gy, sp), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((wgrad_s1_kernel<1, false>), dim3(tiles, gy, sp), dim3(256), 0, s, a);
     } else {
+        if (bh_query("wgrad_kernel<%s,%s>", vec ? "true" : "false", (vec && d->precision == 1) ? "true" : "false")) return BH_OK;
         if (vec && d->precision == 1) hipLaunchKernelGGL((wgrad_kernel<true, true>), grid, dim3(256), 0, s, a);
         else if (vec) hipLaunchKernelGGL((wgrad_kernel<true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((wgrad_kernel<false>), grid, dim3(256), 0, s, a);

@@ -44,117 +44,30 @@ class _Timed:
             r["n"] += 1
 
 
-def gemm_variant(M, Nn, Kc, vec, bf16=False, buf_ok=True, src_elems=1, bw_elems=1, T=1):
-    """Mirror of conv_gemm.hip's dispatch(): which template instantiation a launch uses (the kernel
-    symbol rocprofv3 reports: conv_gemm_kernel<BM, BN, BK, VEC, BF16, BUF>).  buf_ok: not a strided adjoint."""
-    buf = (vec and buf_ok and Nn % 4 == 0 and T <= 64 and 0 < src_elems < (1 << 29) and 0 < bw_elems < (1 << 29)
-           and Kc % 32 == 0)
-    fmt = ("conv_gemm_kernel<%d,%d,%d,%s," + ("true," if (bf16 and vec and Kc % 32 == 0) else "false,")
-           + ("true>" if buf else "false>"))
-    if bf16 and vec and Kc % 32 == 0:
-        if Nn <= 32:
-            return fmt % (128, 32, 32, "true")
-        return fmt % (64 if ((M + 127) // 128) * ((Nn + 63) // 64) < 1024 else 128, 64, 32, "true")
-    if not vec:
-        return fmt % (128, 128 if Nn > 64 else (64 if Nn > 32 else 32), 32, "false")
-    k16 = (Kc % 32) != 0 and Kc <= 16
-    mt64 = (M + 63) // 64
-    k64 = Kc % 64 == 0 and Kc >= 256
-    if Nn > 64:
-        if k16:
-            return fmt % (128, 128, 16, "true")
-        nt = (Nn + 127) // 128
-        if Nn >= 256 and mt64 * nt >= 512:
-            return fmt % (64, 128, 32, "true")
-        return fmt % (64, 64, 64 if k64 else 32, "true")
-    if Nn > 32:
-        if k16:
-            return fmt % (128, 64, 16, "true")
-        return fmt % (64, 64, 32, "true")
-    return fmt % (128, 32, 16 if k16 else 32, "true")
+_VARIANT_CACHE = {}
 
 
-def _conv_variant(d, which):
-    v = _conv_variant0(d, which)
-    if TIMING_DETAIL:
-        v += " %s N%d %dx%d C%d->%d k%d s%d%s" % (which, d.N, d.Hi, d.Wi, d.Ci, d.Co, d.kh, d.stride, " T" if d.transposed else "")
+def conv_variant(d, which, accumulate=False, bn_groups=0):
+    """Kernel symbol(s) a launch described by `d` runs, as the LIBRARY reports it (bh_conv_variant executes the real
+    dispatch code with the launches replaced by a name record): 'fwd' / 'dgrad' / 'wgrad'.  Used for the roofline
+    attribution in bench.py and the per-launch timing tables; several launches are joined by '+'."""
+    key = (tuple(getattr(d, f) for f, _ in BhConvDesc._fields_), which, bool(accumulate), int(bn_groups))
+    v = _VARIANT_CACHE.get(key)
+    if v is None:
+        buf = ctypes.create_string_buffer(256)
+        check(lib.bh_conv_variant(ctypes.byref(d), {"fwd": 0, "dgrad": 1, "wgrad": 2}[which], int(bool(accumulate)), int(bn_groups),
+                                  buf, 256), "bh_conv_variant")
+        v = _VARIANT_CACHE[key] = buf.value.decode()
     return v
 
 
-C3_MIN_BLOCKS = 256          # mirror of conv3x3.hip g_c3_min_blocks
-
-
-def _c3_variant(d, dgrad):
-    """Mirror of bh_conv3x3_try: the halo-tiled 3x3 kernel's symbol when the launch is eligible, else None."""
-    if (d.transposed or d.kh != 3 or d.kw != 3 or d.stride != 1 or d.pad != 1 or d.in_nchw or d.out_nchw
-            or d.precision not in (0, 1) or d.Hi % 8 or d.Wi % 8):
-        return None
-    Kc, Nn = (d.Co, d.Ci) if dgrad else (d.Ci, d.Co)
-    if Kc % 32 or Nn % 32 or d.N * d.Hi * d.Wi * max(Kc, Nn) * 4 >= 2 ** 31:
-        return None
-    bn = 32 if Nn % 64 else 64
-    pairs = ((d.N * (d.Hi // 8) * (d.Wi // 8) + 1) // 2) * (Nn // bn)
-    if pairs < C3_MIN_BLOCKS:
-        return None
-    subt = 1 if (bn == 64 and pairs <= 256) else 2          # one 8x8 sub-tile per workgroup on the small grids
-    return "conv3x3_halo_kernel<%s,%d,%s,%d>" % ("true" if dgrad else "false", bn, "true" if d.precision == 1 else "false", subt)
-
-
-def _stem7_variant(d):
-    """Mirror of bh_stem7_try (csrc/stem7.hip)."""
-    if (d.transposed or d.kh != 7 or d.kw != 7 or d.stride != 2 or d.pad != 3 or d.Co != 64 or d.out_nchw
-            or not (d.Ci == 1 or (d.Ci in (2, 3, 6) and d.in_nchw)) or d.Ho % 8 or d.Wo % 8 or d.Ho * 2 != d.Hi
-            or d.Wo * 2 != d.Wi or d.N * (d.Ho // 8) * (d.Wo // 8) < 256):
-        return None
-    return "stem7_fwd_kernel<%d>" % d.Ci
-
-
-def _conv_variant0(d, which):
-    if which == "fwd":
-        st = _stem7_variant(d)
-        if st is not None:
-            return st
-    c3 = _c3_variant(d, which != "fwd")
-    if c3 is not None:
-        return c3
-    if which == "fwd":
-        vec = (not d.in_nchw) and d.Ci % 4 == 0
-        src, bw = d.N * d.Hi * d.Wi * d.Ci, d.Co * d.kh * d.kw * d.Ci
-        if d.transposed:
-            return gemm_variant(d.N * d.Hi * d.Wi, d.kh * d.kw * d.Co, d.Ci, vec, d.precision == 1, True, src, bw, 1)
-        return gemm_variant(d.N * d.Ho * d.Wo, d.Co, d.Ci, vec, d.precision == 1, True, src, bw, d.kh * d.kw)
-    if (not d.transposed) and d.Ci == 1 and not d.out_nchw:
-        return "stem_dgrad_c1_kernel"
-    vec = (not d.out_nchw) and d.Co % 4 == 0
-    src, bw = d.N * d.Ho * d.Wo * d.Co, d.Co * d.kh * d.kw * d.Ci
-    return gemm_variant(d.N * d.Hi * d.Wi, d.Ci, d.Co, vec, d.precision == 1, d.transposed or d.stride == 1, src, bw,
-                        d.kh * d.kw)
-
-
-WGRAD_S1 = 1             # mirrors g_wgrad_s1 (bh_debug_force_tile(-16, n)): 0 off, 1 one tap, 3 three taps per workgroup
-
-
-def _wgrad_variant(d):
-    """Mirror of wgrad.hip's dispatch: kernel symbol of a weight-gradient launch."""
-    if d.transposed:
-        Np, Nq, vec = d.Ci, d.Co, d.Co % 4 == 0
-    else:
-        Np, Nq, vec = d.Co, d.Ci, (not d.in_nchw) and d.Ci % 4 == 0
-    ncols = Nq if vec else d.kh * d.kw * Nq
-    small = Np <= 32 or ncols <= 32
-    if small and vec and d.precision == 0 and d.kh * d.kw in (9, 4) and not d.out_nchw:
-        return "wgrad_small_taps_kernel<%d>" % (3 if d.kh * d.kw == 9 else 2)
-    if small:
-        return "wgrad_small_kernel<%s>" % ("true" if vec else "false")
-    M = d.N * d.Ho * d.Wo
-    pow2 = lambda v: v > 0 and (v & (v - 1)) == 0
-    if (WGRAD_S1 and vec and d.precision in (0, 1) and not d.transposed and d.stride == 1 and d.Ho == d.Hi and d.Wo == d.Wi
-            and not d.out_nchw and pow2(d.Wo) and pow2(d.Ho * d.Wo) and M % 32 == 0 and Np % 64 == 0 and Nq % 64 == 0
-            and Np % 4 == 0 and M * Np < (1 << 29) and d.N * d.Hi * d.Wi * d.Ci < (1 << 29)):
-        if d.precision == 1:
-            return "wgrad_s1_kernel<%d,true>" % (3 if d.kw == 3 else 1)
-        return "wgrad_s1_kernel<%d,false>" % (3 if (WGRAD_S1 >= 3 and d.kw == 3) else 1)
-    return "wgrad_kernel<%s,%s>" % ("true" if vec else "false", "true" if (vec and d.precision == 1) else "false")
+def _conv_variant(d, which, accumulate=False, bn_groups=0):
+    if TIMING is None:
+        return ""
+    v = conv_variant(d, which, accumulate, bn_groups)
+    if TIMING_DETAIL:
+        v += " %s N%d %dx%d C%d->%d k%d s%d%s" % (which, d.N, d.Hi, d.Wi, d.Ci, d.Co, d.kh, d.stride, " T" if d.transposed else "")
+    return v
 
 
 def conv_flops(d):
@@ -325,9 +238,10 @@ def bihome_loss_bwd(g_loss, f1, f2, f1w, f2w, m1w, m2w, m1, m2, M1, M2, numden, 
 PRECISION = {"f32": 0, "fp32": 0, "bf16": 1}
 
 
-def conv_desc(N, Hi, Wi, Ci, Co, k, stride, pad, transposed=False, in_nchw=False, out_nchw=False, precision=0):
+def conv_desc(N, Hi, Wi, Ci, Co, k, stride, pad, transposed=False, in_nchw=False, out_nchw=False, precision=0, route=0):
     d = BhConvDesc()
     d.precision = int(precision)
+    d.route = int(route)
     d.N, d.Hi, d.Wi, d.Ci, d.Co = N, Hi, Wi, Ci, Co
     d.kh = d.kw = k
     d.stride, d.pad = stride, pad
@@ -349,7 +263,8 @@ def conv_fwd(x, w, bias, d, bn_sums=None, groups=1, res=None, relu=False):
     y = act(conv + bias + res) (BatchNorm folded into w, bias by the caller)."""
     _chk(x); _chk(w); _chk(bias); _chk(res)
     y = torch.empty(conv_out_shape(d), dtype=torch.float32, device=x.device)
-    with _Timed(_conv_variant(d, "fwd"), conv_flops(d), 4.0 * (x.numel() + y.numel() + w.numel())):
+    with _Timed(_conv_variant(d, "fwd", bn_groups=groups if bn_sums is not None else 0), conv_flops(d),
+                4.0 * (x.numel() + y.numel() + w.numel())):
         if res is not None or relu:
             check(lib.bh_conv_fwd_act(_p(x), _p(w), _p(bias), _p(res), _p(y), ctypes.byref(d), int(bool(relu)), _stream()),
                   "bh_conv_fwd_act")
@@ -392,7 +307,7 @@ def _stem_dgrad_two_step(gy, w, d, wkey=None):
 
 def dgrad_bn_reduce_ok(d):
     """True when conv_dgrad(..., bn_reduce=...) is available for this conv (the halo-tiled 3x3 kernel takes its dgrad)."""
-    return _c3_variant(d, True) is not None
+    return conv_variant(d, "dgrad").startswith("conv3x3_halo_kernel")
 
 
 def conv_dgrad(gy, w, d, out=None, bn_reduce=None, wkey=None):
@@ -408,7 +323,7 @@ def conv_dgrad(gy, w, d, out=None, bn_reduce=None, wkey=None):
         b = bn_reduce
         _chk(b["z"]); _chk(b["y"]); _chk(b["stats"], torch.float64); _chk(b["sums"], torch.float64)
         st = BhBnReduce(_p(b["z"]), _p(b["y"]), _p(b["stats"]), _p(b["gamma"]), _p(b["beta"]), float(b["eps"]), int(bool(b["relu"])))
-        with _Timed(_conv_variant(d, "dgrad"), conv_flops(d), 4.0 * (gy.numel() + out.numel() * (3 if acc else 2) + w.numel())):
+        with _Timed(_conv_variant(d, "dgrad", acc), conv_flops(d), 4.0 * (gy.numel() + out.numel() * (3 if acc else 2) + w.numel())):
             check(lib.bh_conv_dgrad_bnreduce(_p(gy), _p(w), _p(out), ctypes.byref(d), int(acc), ctypes.byref(st), _p(b["sums"]),
                                              int(b["groups"]), _stream()), "bh_conv_dgrad_bnreduce")
         return out
@@ -431,7 +346,7 @@ def conv_dgrad(gy, w, d, out=None, bn_reduce=None, wkey=None):
     if out is None:
         shape = (d.N, d.Ci, d.Hi, d.Wi) if d.in_nchw else (d.N, d.Hi, d.Wi, d.Ci)
         out = torch.empty(shape, dtype=torch.float32, device=gy.device)
-    with _Timed(_conv_variant(d, "dgrad"), conv_flops(d), 4.0 * (gy.numel() + out.numel() * (2 if acc else 1) + w.numel())):
+    with _Timed(_conv_variant(d, "dgrad", acc), conv_flops(d), 4.0 * (gy.numel() + out.numel() * (2 if acc else 1) + w.numel())):
         check(lib.bh_conv_dgrad(_p(gy), _p(w), _p(out), ctypes.byref(d), int(acc), _stream()), "bh_conv_dgrad")
     return out
 
@@ -440,7 +355,7 @@ def conv_wgrad(x, gy, gw, gbias, d):
     """gw += x^T gy (split-K MFMA kernel, fp32 atomics); gbias += column sums of gy (separate launch, own timing entry so
     that the wgrad entry is the kernel rocprofv3 lists under the same name)."""
     _chk(x); _chk(gy); _chk(gw); _chk(gbias)
-    with _Timed(_wgrad_variant(d) + (" N%d %dx%d C%d->%d k%d s%d%s" % (d.N, d.Hi, d.Wi, d.Ci, d.Co, d.kh, d.stride, " T" if d.transposed else "") if TIMING_DETAIL else ""), conv_flops(d), 4.0 * (x.numel() + gy.numel() + gw.numel())):
+    with _Timed((conv_variant(d, "wgrad") if TIMING is not None else "") + (" N%d %dx%d C%d->%d k%d s%d%s" % (d.N, d.Hi, d.Wi, d.Ci, d.Co, d.kh, d.stride, " T" if d.transposed else "") if TIMING_DETAIL else ""), conv_flops(d), 4.0 * (x.numel() + gy.numel() + gw.numel())):
         check(lib.bh_conv_wgrad(_p(x), _p(gy), _p(gw), None, ctypes.byref(d), _stream()), "bh_conv_wgrad")
     if gbias is not None:
         with _Timed("bias_grad(colsum)", 0.0, 4.0 * gy.numel()):

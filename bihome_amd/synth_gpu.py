@@ -24,6 +24,7 @@ class GpuPairGenerator:
         self.patch, self.rho, self.pmd = patch, rho, photometric_max_delta
         self.gen = torch.Generator(device=device)
         self.gen.manual_seed(seed)
+        self._rs = np.random.RandomState(seed)            # photometric decisions (host draws, reference order)
         self.device = device
 
     def draw(self, B):
@@ -37,11 +38,11 @@ class GpuPairGenerator:
         delta = torch.randint(-self.rho, self.rho, (B, 4, 2), generator=g, device=dev).to(torch.float32).contiguous()
         photo = None
         if self.pmd > 0:
-            on = torch.randint(0, 2, (B, 4), generator=g, device=dev).to(torch.float32)
-            u = torch.rand(B, 4, generator=g, device=dev)
-            br = (2 * u[:, [0, 2]] - 1) * self.pmd * on[:, [0, 2]]
-            ct = 1 + (2 * u[:, [1, 3]] - 1) * (self.pmd / 64.0) * on[:, [1, 3]]
-            photo = torch.stack([br[:, 0], ct[:, 0], br[:, 1], ct[:, 1]], 1).contiguous()
+            # PhotometricDistortSimple's decisions (transforms.py:296-330) for both images of every pair: the same record
+            # layout and draw order as the host generator (synth.draw_photometric), drawn on the host - 12 floats per pair
+            recs = np.stack([np.concatenate([synth.draw_photometric(self._rs, self.pmd), synth.draw_photometric(self._rs, self.pmd)])
+                             for _ in range(B)])
+            photo = torch.tensor(recs, dtype=torch.float32, device=dev).contiguous()
         return idx, origin, delta, photo
 
     def make(self, idx, origin, delta, photo=None):

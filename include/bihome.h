@@ -2,8 +2,10 @@
  * bihome.h - C ABI of libbihome_hip.so: the MI355X (gfx950) kernels behind the biHomE training hot path.
  *
  * Boundary contract: plain device pointers + sizes + a hipStream_t passed as void*,
- * int status return (0 = ok, >0 = hipError_t, <0 = BH_E_*), no allocation, no global state, re-entrant
- * per stream.  The reference has no FFI of its own (it is pure Python over ATen); each entry point
+ * int status return (0 = ok, >0 = hipError_t, <0 = BH_E_*), no allocation, no global mutable state (kernel routing is
+ * a pure function of the arguments; the only process state is the per-device "dynamic LDS attribute set" flags),
+ * re-entrant per stream.  Builds with -DBH_TUNING (tools/ only, `make tuning`) add the bh_debug_force_tile ablation
+ * hook, which IS global state; the default library does not contain it.  The reference has no FFI of its own (it is pure Python over ATen); each entry point
  * below names the reference call site (path:line under the upstream repository) whose arithmetic it
  * replaces.  The host-side mirror of the reference's plugin API (src/backbones/<Name>.Model,
  * src/heads/<Name>.Model) lives in bihome_amd/ and calls these through ctypes.
@@ -124,10 +126,25 @@ typedef struct {
     int out_nchw;           /* 1: y is NCHW (only for the network output, Co <= 4) */
     int precision;          /* 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1: operands rounded to bf16 while staging,
                              * fp32 accumulate (v_mfma_f32_32x32x16_bf16), tensors stay fp32 in HBM */
+    int route;              /* 0: automatic kernel choice (production).  BH_ROUTE_* bits: explicit per-call routing for
+                             * tests and benchmarks (e.g. drive the halo-tiled 3x3 kernel on a grid it would decline) */
 } bh_conv_desc;
+#define BH_ROUTE_GENERIC_CONV 1   /* fwd / dgrad: never the halo-tiled 3x3 kernel (generic implicit GEMM) */
+#define BH_ROUTE_HALO_SMALL 2     /* fwd / dgrad: let the halo-tiled 3x3 kernel take grids below its workgroup minimum */
+#define BH_ROUTE_NO_STEM7 4       /* fwd: never the dedicated 7x7/2 stem kernel */
+#define BH_ROUTE_WGRAD_GENERIC 8  /* wgrad: generic split-K kernel instead of the stride-1 fast path */
+#define BH_ROUTE_WGRAD_3TAP 16    /* wgrad: three taps per workgroup in the stride-1 fast path */
 
-/* tuning hook (benchmarks only): force the implicit-GEMM tile (BM,BN) for vectorised launches; (0,0) = automatic */
+/* Which kernel a launch described by d would run: which = 0 forward, 1 dgrad, 2 wgrad.  Writes the kernel template
+ * instantiation (the symbol rocprofv3 lists, e.g. "conv3x3_halo_kernel<false,64,false,2>"; several launches joined by
+ * '+') into buf[n].  Runs the real dispatch code with the launches replaced by a name record, so it cannot drift from it.
+ * accumulate / with_bnstats mirror the arguments of the call being described (they influence routing). */
+int bh_conv_variant(const bh_conv_desc* d, int which, int accumulate, int with_bnstats, char* buf, int n);
+
+#ifdef BH_TUNING
+/* ablation / tuning hook of the -DBH_TUNING build (tools/ only; process-global state) */
 int bh_debug_force_tile(int bm, int bn);
+#endif
 /* y = conv(x, w) (+ bias[Co] if bias != NULL) */
 int bh_conv_fwd(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, void* stream);
 /* y = act(conv(x, w) + bias + res): res (NULL ok) has the layout of y, relu != 0 applies max(.,0).  The inference path:
@@ -220,12 +237,15 @@ int bh_tail_bwd(const float* gout, const float* x, const float* w1, const float*
                 float* scratch, int groups, int rows, int hw, int Ci, int Cm, int Co, float eps, int use_running,
                 void* stream);
 
-/* Synthetic pair generator (next-row f1): HomographyNetPrep + DictToGrayscale + DictStandardize (+ brightness/contrast
- * of PhotometricDistortSimple) of src/data/transforms.py:296-330,344-378,441-725 for B samples in one launch.
+/* Synthetic pair generator (next-row f1): HomographyNetPrep + PhotometricDistortSimple + DictToGrayscale +
+ * DictStandardize of src/data/transforms.py:296-330,344-378,441-725 for B samples in one launch.
  * images[n_images,3,Hs,Ws] float RGB 0..255 (resident); img_idx[B]; origin[B,2] = top-left corner (x0,y0) of the
- * patch; Hpatch[B,9] double = bh_h4pt_fwd(delta) in patch coordinates; photo[B,4] = {brightness1, contrast1,
- * brightness2, contrast2} or NULL.  patch1 = crop, patch2(x) = image(origin + Hpatch.x) bilinear; both
- * standardised ((g/255 - mean)/std), [B,1,P,P]. */
+ * patch; Hpatch[B,9] double = bh_h4pt_fwd(delta) in patch coordinates; photo[B,2,6] = per image of the pair
+ * {brightness delta, contrast factor applied before the HSV part, saturation factor, hue delta (degrees), contrast factor
+ * applied after the HSV part, channel-permutation index 0..5 into ((0,1,2),(0,2,1),(1,0,2),(1,2,0),(2,0,1),(2,1,0))}
+ * (transforms.py:141-245; OpenCV float HSV), or NULL for no distortion.  The distortion is applied to the image before
+ * it is warped, as upstream.  patch1 = crop, patch2(x) = image(origin + Hpatch.x) bilinear; both standardised
+ * ((gray/255 - mean)/std), [B,1,P,P]. */
 int bh_synth_pairs(const float* images, const int* img_idx, const float* origin, const double* Hpatch, const float* photo,
                    int B, int n_images, int Hs, int Ws, int P, float mean, float std, float* patch1, float* patch2,
                    void* stream);

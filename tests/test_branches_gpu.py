@@ -116,8 +116,8 @@ def test_detone_three_steps_vs_golden(golden, precision, head_precision):
     bf16 (bf16 MFMA operands, float32 accumulate; backbone only, or backbone and extractor): delta_hat is a direct
     network output, so 2^-9 operand rounding through 36 conv layers shows up directly in MACE (measured 0.0105 px at
     step 0), and the loss is a difference of two nearly equal feature distances (|f1w-f2| - |f1-f2|), which amplifies
-    the extractor's rounding (measured 3.4 % at step 0 with a bf16 extractor).  Stated tolerances: step 0 loss within
-    5 % (bf16 extractor) / 1 % (f32 extractor), MACE within 0.02 px; later steps loss within 25 %, MACE within 15x the
+    the 0.01 px error of delta_hat (measured 3.4 % at step 0 with a bf16 extractor, 3.1 % with a float32 extractor: the
+    backbone's operand rounding dominates).  Stated tolerances: step 0 loss within 5 %, MACE within 0.02 px; later steps loss within 25 %, MACE within 15x the
     float32 reference's own f32-vs-f64 spread.  north_star's "MACE within 1e-3" is NOT met in bf16 - DESIGN.md 8."""
     from bihome_amd.step import build_optimizer, mace, train_step
     g32, g64 = golden("detone_b8_f32"), golden("detone_b8_f64")
@@ -140,10 +140,41 @@ def test_detone_three_steps_vs_golden(golden, precision, head_precision):
         assert abs(maces[0] - g64["mace"][0]) < 1e-3
         mult, lrel = 5.0, 0.05
     else:
-        assert abs(losses[0] - g64["loss"][0]) <= (5e-2 if head_precision == "bf16" else 1e-2) * abs(g64["loss"][0])
+        assert abs(losses[0] - g64["loss"][0]) <= 5e-2 * abs(g64["loss"][0])
         assert abs(maces[0] - g64["mace"][0]) < 2e-2
         mult, lrel = 15.0, 0.25
     for it in (1, 2):
         sp_l, sp_m = abs(g32["loss"][it] - g64["loss"][it]), abs(g32["mace"][it] - g64["mace"][it])
         assert abs(losses[it] - g64["loss"][it]) <= max(mult * sp_l, lrel * abs(g64["loss"][it])), (it, losses, g64["loss"])
         assert abs(maces[it] - g64["mace"][it]) <= max(mult * sp_m, 0.05), (it, maces, g64["mace"])
+
+
+def test_pds_coco_three_steps_vs_golden(golden):
+    """BASELINE.json configs[2] (pds-coco: both images of a pair independently photometrically distorted,
+    config/pds-coco/zeng-bihome-lr-1e-3.yaml:62-67) at B = 8 through three Adam steps against the reference's own modules on
+    the same distorted inputs and DSAC draws: first step tight (north_star tolerances), later steps within a multiple of
+    the reference's own float32-vs-float64 spread."""
+    from bihome_amd.step import build_optimizer, mace, train_step
+    g32, g64 = golden("zeng_pds_b8_f32"), golden("zeng_pds_b8_f64")
+    cfg = configs.get("zeng-bihome-pds")
+    assert cfg["DATA"]["PHOTOMETRIC_MAX_DELTA"] == 32
+    model = _model(cfg)
+    opt, sched = build_optimizer(model, cfg["SOLVER"])
+    d = synth.make_pairs(8, seed=8, photometric_max_delta=32)
+    losses, maces = [], []
+    for it in range(3):
+        data = {k: cuda(d[k]) for k in ("patch_1", "patch_2", "delta")}
+        data["choice_12"], data["choice_21"] = cuda(g64["choice_12"][it], torch.int64), cuda(g64["choice_21"][it], torch.int64)
+        loss, dgt, dh = train_step(model, data, opt, sched)
+        losses.append(loss.item()); maces.append(mace(dgt, dh))
+        if it == 0:
+            assert relerr(data["pf_hat_12"].detach().cpu()[..., ::8, ::8], g64["pf_hat_12_sub"]) < 2e-4
+            assert relerr(dh.cpu(), g64["delta_hat_12"]) < 1e-3
+    print("pds loss", losses, "mace", maces, "ref", g64["loss"], g64["mace"], g32["loss"])
+    # the loss is a difference of feature distances and sits near zero here (0.354 against ~55 per term): absolute floor
+    assert abs(losses[0] - g64["loss"][0]) <= max(3 * abs(g32["loss"][0] - g64["loss"][0]), 1e-4 * abs(g64["loss"][0]))
+    assert abs(maces[0] - g64["mace"][0]) < 1e-3
+    for it in (1, 2):
+        sp_l, sp_m = abs(g32["loss"][it] - g64["loss"][it]), abs(g32["mace"][it] - g64["mace"][it])
+        assert abs(losses[it] - g64["loss"][it]) <= max(5 * sp_l, 0.05 * abs(g64["loss"][it])), (it, losses, g64["loss"])
+        assert abs(maces[it] - g64["mace"][it]) <= max(10 * sp_m, 0.05), (it, maces, g64["mace"])

@@ -13,6 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def header_symbols():
     text = open(os.path.join(ROOT, "include", "bihome.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"#ifdef BH_TUNING.*?#endif", "", text, flags=re.S)      # the ablation hook exists in the -DBH_TUNING build only
     return sorted(set(re.findall(r"\bint\s+(bh_\w+)\s*\(", text)))
 
 
@@ -25,6 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(raw, s), "libbihome_hip.so does not export %s" % s
     assert sorted(_lib.SIGNATURES) == syms, (set(_lib.SIGNATURES) ^ set(syms))
     assert _lib.lib.bh_version() >= 1
+    assert not hasattr(raw, "bh_debug_force_tile")      # no process-global tuning state in the product library
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
@@ -84,11 +86,39 @@ def test_conv_desc_and_variant():
     d = K.conv_desc(4, 8, 8, 256, 128, 2, 2, 0, transposed=True)
     assert (d.Ho, d.Wo) == (16, 16)
     assert K.conv_flops(d) == 2.0 * 4 * 64 * 256 * 128 * 4
-    assert K.gemm_variant(1 << 20, 256, 256, True) == "conv_gemm_kernel<64,128,32,true,false,true>"
-    assert K.gemm_variant(8192, 256, 256, True) == "conv_gemm_kernel<64,64,64,true,false,true>"
-    assert K.gemm_variant(1 << 21, 2, 128, True) == "conv_gemm_kernel<128,32,32,true,false,false>"      # Nn % 4 != 0: pointer loader
-    assert K.gemm_variant(1 << 21, 128, 16, True) == "conv_gemm_kernel<128,128,16,true,false,false>"    # Kc % 32 != 0
-    assert K.gemm_variant(1 << 19, 64, 2, False) == "conv_gemm_kernel<128,64,32,false,false,false>"
+
+
+def test_conv_variant_query_reports_the_dispatch():
+    """bh_conv_variant runs the library's own dispatch with the launches replaced by a name record (no GPU needed): the
+    kernel symbols of the BENCH shapes (BASELINE.json configs[1], 128 stacked images) and of the routing bits."""
+    from bihome_amd import kernels as K
+    from bihome_amd._lib import ROUTE_GENERIC_CONV, ROUTE_HALO_SMALL, ROUTE_NO_STEM7, ROUTE_WGRAD_3TAP, ROUTE_WGRAD_GENERIC
+    d = K.conv_desc(128, 32, 32, 64, 64, 3, 1, 1)
+    assert K.conv_variant(d, "fwd") == "conv3x3_halo_kernel<false,64,false,2>"
+    assert K.conv_variant(d, "fwd", bn_groups=2) == "conv3x3_halo_kernel<false,64,false,2>"
+    assert K.conv_variant(d, "dgrad") == "conv3x3_halo_kernel<true,64,false,2>"
+    assert K.conv_variant(d, "wgrad") == "wgrad_s1_kernel<1,false>"
+    assert K.dgrad_bn_reduce_ok(d)
+    d8 = K.conv_desc(128, 8, 8, 256, 256, 3, 1, 1)
+    assert K.conv_variant(d8, "fwd") == "conv3x3_halo_kernel<false,64,false,1>"          # one sub-tile per workgroup
+    assert K.conv_variant(K.conv_desc(128, 128, 128, 32, 32, 3, 1, 1), "fwd") == "conv3x3_halo_kernel<false,32,false,2>"
+    assert K.conv_variant(K.conv_desc(128, 32, 32, 64, 64, 3, 1, 1, precision=1), "wgrad") == "wgrad_s1_kernel<3,true>"
+    # per-call routing bits (tests / benchmarks)
+    assert K.conv_variant(K.conv_desc(128, 32, 32, 64, 64, 3, 1, 1, route=ROUTE_GENERIC_CONV), "fwd").startswith("conv_gemm_kernel<64,64,")
+    small = K.conv_desc(2, 8, 8, 64, 64, 3, 1, 1)
+    assert K.conv_variant(small, "fwd").startswith("conv_gemm_kernel") and not K.dgrad_bn_reduce_ok(small)
+    assert K.conv_variant(K.conv_desc(2, 8, 8, 64, 64, 3, 1, 1, route=ROUTE_HALO_SMALL), "fwd").startswith("conv3x3_halo_kernel")
+    assert K.conv_variant(K.conv_desc(128, 32, 32, 64, 64, 3, 1, 1, route=ROUTE_WGRAD_GENERIC), "wgrad") == "wgrad_kernel<true,false>"
+    assert K.conv_variant(K.conv_desc(128, 32, 32, 64, 64, 3, 1, 1, route=ROUTE_WGRAD_3TAP), "wgrad") == "wgrad_s1_kernel<3,false>"
+    stem = K.conv_desc(128, 128, 128, 2, 64, 7, 2, 3, in_nchw=True)
+    assert K.conv_variant(stem, "fwd") == "stem7_fwd_kernel<2>"
+    assert K.conv_variant(K.conv_desc(128, 128, 128, 2, 64, 7, 2, 3, in_nchw=True, route=ROUTE_NO_STEM7), "fwd").startswith("conv_gemm_kernel<128,")
+    assert K.conv_variant(stem, "wgrad") == "wgrad_kernel<false,false>"                 # joint (tap, channel) columns: N = 98
+    # generic implicit GEMM: 1x1, transposed, stride 2
+    assert K.conv_variant(K.conv_desc(128, 16, 16, 256, 128, 1, 1, 0), "fwd") == "conv_gemm_kernel<64,64,64,true,false,true>"
+    assert K.conv_variant(K.conv_desc(128, 8, 8, 256, 256, 2, 2, 0, transposed=True), "fwd") == "conv_gemm_kernel<64,128,32,true,false,true>"
+    assert K.conv_variant(K.conv_desc(128, 128, 128, 128, 2, 1, 1, 0, out_nchw=True), "fwd") == "conv_gemm_kernel<128,32,32,true,false,false>"
+    assert "conv_gemm_kernel" in K.conv_variant(K.conv_desc(128, 32, 32, 64, 128, 3, 2, 1), "dgrad")
 
 
 def test_synthetic_pairs_are_consistent():

@@ -301,13 +301,12 @@ def test_bf16_operand_mode(K, N, Hi, Ci, Co, k, s, p):
 ])
 def test_conv_fwd_with_batchnorm_sums(K, N, H, Ci, Co, k, groups):
     """bh_conv_fwd_bnstats: per-group, per-channel (sum y, sum y^2) of the conv output, as BatchNorm consumes them."""
-    from bihome_amd._lib import lib
-    lib.bh_debug_force_tile(-5, 1)          # let the halo kernel take these small grids
-    try:
+    from bihome_amd._lib import ROUTE_HALO_SMALL
+    if True:
         x = torch.tensor(rnd((N, H, H, Ci), 70)).cuda()
         w = torch.tensor(rnd((Co, k, k, Ci), 71) * 0.1).cuda()
         b = torch.tensor(rnd((Co,), 72)).cuda()
-        d = K.conv_desc(N, H, H, Ci, Co, k, 1, k // 2)
+        d = K.conv_desc(N, H, H, Ci, Co, k, 1, k // 2, route=ROUTE_HALO_SMALL)   # let the halo kernel take these small grids
         sums = K.bn_stats_buffer(groups, Co, "cuda")
         y = K.conv_fwd(x, w, b, d, bn_sums=sums, groups=groups)
         y0 = K.conv_fwd(x, w, b, d)
@@ -321,8 +320,6 @@ def test_conv_fwd_with_batchnorm_sums(K, N, H, Ci, Co, k, groups):
         o1, _ = K.bn_fwd(y, gm, bt, rm.clone(), rv.clone(), None, groups, 1e-5, 0.1, True, True, stats=sums, stats_ready=True)
         o2, _ = K.bn_fwd(y, gm, bt, rm.clone(), rv.clone(), None, groups, 1e-5, 0.1, True, True)
         close(o1.cpu(), o2.cpu(), 1e-5)
-    finally:
-        lib.bh_debug_force_tile(-5, 256)
 
 
 @pytest.mark.parametrize("N,H,C,Co,groups,relu,res,acc", [
@@ -332,17 +329,15 @@ def test_conv_fwd_with_batchnorm_sums(K, N, H, Ci, Co, k, groups):
 ])
 def test_dgrad_epilogue_accumulates_batchnorm_backward_sums(K, N, H, C, Co, groups, relu, res, acc):
     """bh_conv_dgrad_bnreduce + bh_bn_bwd(flags bit4) against the three-launch BatchNorm adjoint on the same gradient."""
-    from bihome_amd._lib import lib
-    lib.bh_debug_force_tile(-5, 1)
-    K.C3_MIN_BLOCKS = 1                      # (the Python mirror of the same threshold)
-    try:
+    from bihome_amd._lib import ROUTE_HALO_SMALL
+    if True:
         z = torch.tensor(rnd((N, H, H, C), 80) * 1.5 + 0.3).cuda()
         r = torch.tensor(rnd((N, H, H, C), 81)).cuda() if res else None
         gm, bt = torch.tensor(1 + 0.3 * rnd((C,), 82)).cuda(), torch.tensor(0.2 * rnd((C,), 83)).cuda()
         rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
         y, st = K.bn_fwd(z, gm, bt, rm, rv, r, groups, 1e-5, 0.1, relu, True)
         # the conv that consumes y: 3x3, C -> Co
-        d = K.conv_desc(N, H, H, C, Co, 3, 1, 1)
+        d = K.conv_desc(N, H, H, C, Co, 3, 1, 1, route=ROUTE_HALO_SMALL)
         w = torch.tensor(rnd((Co, 3, 3, C), 84) * 0.1).cuda()
         gy = torch.tensor(rnd((N, H, H, Co), 85)).cuda()
         part = torch.tensor(rnd((N, H, H, C), 86)).cuda() if acc else None      # gradient already joined from another branch
@@ -363,9 +358,6 @@ def test_dgrad_epilogue_accumulates_batchnorm_backward_sums(K, N, H, C, Co, grou
         close(gb1.cpu(), gb0.cpu(), 2e-5)
         if res:
             assert torch.equal(gr1, gr0)
-    finally:
-        lib.bh_debug_force_tile(-5, 256)
-        K.C3_MIN_BLOCKS = 256
 
 
 @pytest.mark.parametrize("N,H,Ci,Co,k", [(2, 8, 64, 64, 3), (1, 32, 64, 128, 3), (3, 16, 128, 64, 3), (2, 4, 64, 64, 3),
@@ -373,7 +365,7 @@ def test_dgrad_epilogue_accumulates_batchnorm_backward_sums(K, N, H, C, Co, grou
 def test_wgrad_stride1_fast_path_matches_generic_kernel(K, N, H, Ci, Co, k):
     """wgrad_s1_kernel<1> / <3> (tap shift folded into the buffer base, window tests for the borders) against the generic
     split-K kernel and torch float64, including maps narrower than the tile step and a 5x5 kernel."""
-    from bihome_amd._lib import lib
+    from bihome_amd._lib import ROUTE_WGRAD_3TAP, ROUTE_WGRAD_GENERIC
     g = torch.Generator().manual_seed(11)
     x = torch.randn(N, H, H, Ci, generator=g).cuda()
     gy = torch.randn(N, H, H, Co, generator=g).cuda()
@@ -381,17 +373,13 @@ def test_wgrad_stride1_fast_path_matches_generic_kernel(K, N, H, Ci, Co, k):
     ref64 = torch.nn.grad.conv2d_weight(x.double().cpu().permute(0, 3, 1, 2), (Co, Ci, k, k), gy.double().cpu().permute(0, 3, 1, 2),
                                         stride=1, padding=k // 2).permute(0, 2, 3, 1)
     out = {}
-    try:
-        for mode in (0, 1, 3):
-            lib.bh_debug_force_tile(-16, mode)
-            K.WGRAD_S1 = mode
-            gw = torch.zeros(Co, k, k, Ci, device="cuda")
-            K.conv_wgrad(x, gy, gw, None, d)
-            out[mode] = gw.cpu()
-    finally:
-        lib.bh_debug_force_tile(-16, 1)
-        K.WGRAD_S1 = 1
-    assert K._wgrad_variant(d) == "wgrad_s1_kernel<1,false>"
+    for mode, route in ((0, ROUTE_WGRAD_GENERIC), (1, 0), (3, ROUTE_WGRAD_3TAP)):
+        dm = K.conv_desc(N, H, H, Ci, Co, k, 1, k // 2, route=route)
+        gw = torch.zeros(Co, k, k, Ci, device="cuda")
+        K.conv_wgrad(x, gy, gw, None, dm)
+        out[mode] = gw.cpu()
+    assert K.conv_variant(d, "wgrad") == "wgrad_s1_kernel<1,false>"
+    assert K.conv_variant(K.conv_desc(N, H, H, Ci, Co, k, 1, k // 2, route=ROUTE_WGRAD_GENERIC), "wgrad") == "wgrad_kernel<true,false>"
     scale = float(ref64.abs().max())
     for mode in (0, 1, 3):
         assert float((out[mode].double() - ref64).abs().max()) < 2e-5 * scale + 1e-5, mode
@@ -400,21 +388,18 @@ def test_wgrad_stride1_fast_path_matches_generic_kernel(K, N, H, Ci, Co, k):
 def test_conv3x3_two_tile_positions_per_workgroup(K):
     """Launches of 513-1024 workgroups run as one round of workgroups that each walk two tile positions (conv3x3.hip, a.tpb):
     forward with BatchNorm sums and dgrad against the generic kernel, odd position count."""
-    from bihome_amd._lib import lib
+    from bihome_amd._lib import ROUTE_GENERIC_CONV
     N, H, C = 65, 32, 64                                  # 65 * 16 sub-tiles / 2 = 520 workgroups -> 260 x 2
     g = torch.Generator().manual_seed(3)
     x = torch.randn(N, H, H, C, generator=g).cuda()
     w = (torch.randn(C, 3, 3, C, generator=g) * 0.05).cuda()
     gy = torch.randn(N, H, H, C, generator=g).cuda()
-    d = K.conv_desc(N, H, H, C, C, 3, 1, 1)
     res = {}
-    try:
-        for mode in (1, 0):                               # 1: generic kernel, 0: halo kernel
-            lib.bh_debug_force_tile(-4, mode)
-            sums = K.bn_stats_buffer(1, C, "cuda")
-            res[mode] = (K.conv_fwd(x, w, None, d, bn_sums=sums, groups=1), K.conv_dgrad(gy, w, d), sums)
-    finally:
-        lib.bh_debug_force_tile(-4, 0)
+    for mode in (1, 0):                                   # 1: generic kernel, 0: halo kernel
+        d = K.conv_desc(N, H, H, C, C, 3, 1, 1, route=ROUTE_GENERIC_CONV if mode else 0)
+        assert K.conv_variant(d, "fwd").startswith("conv_gemm_kernel" if mode else "conv3x3_halo_kernel<false,64,false,2>")
+        sums = K.bn_stats_buffer(1, C, "cuda")
+        res[mode] = (K.conv_fwd(x, w, None, d, bn_sums=sums, groups=1), K.conv_dgrad(gy, w, d), sums)
     assert float((res[0][0] - res[1][0]).abs().max()) < 5e-5
     assert float((res[0][1] - res[1][1]).abs().max()) < 5e-5
     assert float((res[0][2] - res[1][2]).abs().max() / res[1][2].abs().max()) < 1e-6
@@ -423,7 +408,7 @@ def test_conv3x3_two_tile_positions_per_workgroup(K):
 @pytest.mark.parametrize("N,H,Ci,relu", [(4, 128, 1, False), (4, 128, 2, False), (2, 256, 3, False), (1, 256, 6, True)])
 def test_stem7_forward_kernel(K, N, H, Ci, relu):
     """csrc/stem7.hip (7x7 / stride 2 / pad 3 stems, NCHW planes -> NHWC) against torch float64 and the generic kernel."""
-    from bihome_amd._lib import lib
+    from bihome_amd._lib import ROUTE_NO_STEM7
     g = torch.Generator().manual_seed(5)
     x = torch.randn(N, Ci, H, H, generator=g, dtype=torch.float64)
     w = torch.randn(64, Ci, 7, 7, generator=g, dtype=torch.float64) * 0.1
@@ -432,18 +417,16 @@ def test_stem7_forward_kernel(K, N, H, Ci, relu):
     if relu:
         ref = F.relu(ref)
     d = K.conv_desc(N, H, H, Ci, 64, 7, 2, 3, in_nchw=Ci != 1)
-    assert K._conv_variant(d, "fwd") == "stem7_fwd_kernel<%d>" % Ci
+    assert K.conv_variant(d, "fwd") == "stem7_fwd_kernel<%d>" % Ci
     xk = x.float().cuda().contiguous()
     if Ci == 1:
         xk = xk.view(N, H, H, 1)
     wk = w.float().cuda().permute(0, 2, 3, 1).contiguous()
     y = K.conv_fwd(xk, wk, b.float().cuda(), d, relu=relu)
     close(y.permute(0, 3, 1, 2).cpu(), ref, 2e-5)
-    lib.bh_debug_force_tile(-6, 1)
-    try:
-        y0 = K.conv_fwd(xk, wk, b.float().cuda(), d, relu=relu)
-    finally:
-        lib.bh_debug_force_tile(-6, 0)
+    d0 = K.conv_desc(N, H, H, Ci, 64, 7, 2, 3, in_nchw=Ci != 1, route=ROUTE_NO_STEM7)
+    assert K.conv_variant(d0, "fwd").startswith("conv_gemm_kernel")
+    y0 = K.conv_fwd(xk, wk, b.float().cuda(), d0, relu=relu)
     close(y.cpu(), y0.cpu(), 2e-5)
 
 

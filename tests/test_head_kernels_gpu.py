@@ -209,10 +209,27 @@ def test_gpu_pair_generator_matches_host_generator(K):
             ref = (g / 255 - 0.443) / 0.129
             np.testing.assert_allclose(got.cpu().numpy(), ref, atol=2e-3)
     assert delta.min() >= -32 and delta.max() <= 31 and origin[:, 0].min() >= 32
-    # photometric variant runs and changes the statistics
+    # pds-coco: the full PhotometricDistortSimple (brightness, contrast before / after, HSV saturation and hue, channel
+    # permutation) on the device against synth.apply_photometric - which tests/test_datagen_cpu.py pins against the
+    # reference's own transforms.py classes - on the same parameter records, images, positions and offsets
     gen2 = GpuPairGenerator(n_images=2, seed=6, photometric_max_delta=32)
-    o2 = gen2.next(8)
-    assert torch.isfinite(o2["patch_1"]).all() and torch.isfinite(o2["patch_2"]).all()
+    idx, origin, delta, photo = gen2.draw(12)
+    assert photo.shape == (12, 12)
+    o2 = gen2.make(idx, origin, delta, photo)
+    imgs = gen2.images.cpu().numpy()
+    rec = photo.cpu().numpy().astype(np.float64)
+    assert (rec[:, 5] > 0).any() and (rec[:, 3] != 0).any() and (rec[:, 2] != 1).any() and (rec[:, [1, 4]] != 1).any()
+    for b in range(12):
+        img = imgs[int(idx[b])].transpose(1, 2, 0)
+        x0, y0 = int(origin[b, 0]), int(origin[b, 1])
+        H = synth.four_point_homography(c, c + delta[b].cpu().numpy().astype(np.float64))
+        T = np.array([[1, 0, x0], [0, 1, y0], [0, 0, 1.0]])
+        im1 = synth.apply_photometric(img, rec[b, :6]).astype(np.float64)
+        im2 = synth.apply_photometric(img, rec[b, 6:]).astype(np.float64)
+        ref1 = synth.gray_standardize(im1[y0:y0 + 128, x0:x0 + 128])[0]
+        ref2 = synth.gray_standardize(synth.warp_bilinear(im2, T @ H, 128, 128))[0]
+        np.testing.assert_allclose(o2["patch_1"][b, 0].cpu().numpy(), ref1, atol=3e-3)
+        np.testing.assert_allclose(o2["patch_2"][b, 0].cpu().numpy(), ref2, atol=3e-3)
 
 
 @pytest.mark.parametrize("B,hf,C,margin", [(3, 32, 64, 1.0), (2, 8, 128, 0.0), (1, 16, 64, 25.0)])

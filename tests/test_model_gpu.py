@@ -274,20 +274,6 @@ def test_checkpoint_compatibility_and_multi_hypothesis_eval(zeng, golden):
     np.testing.assert_allclose(dh.cpu().numpy(), g["delta_hat"], atol=5e-2)
 
 
-def test_pds_config_trains():
-    """pds-coco variant (photometric distortion of both images): one step runs and gives a finite loss/MACE."""
-    from bihome_amd.step import build_model, build_optimizer, mace, train_step
-    cfg = configs.get("zeng-bihome-pds")
-    assert cfg["DATA"]["PHOTOMETRIC_MAX_DELTA"] == 32
-    model = build_model(cfg)
-    load_synthetic(model[0], 0)
-    load_synthetic(model[1].auxiliary_resnet, 0)
-    opt, sched = build_optimizer(model, cfg["SOLVER"])
-    d = synth.make_pairs(4, seed=8, photometric_max_delta=32)
-    loss, dgt, dh = train_step(model, {k: cuda(d[k]) for k in ("patch_1", "patch_2", "delta")}, opt, sched)
-    assert np.isfinite(loss.item()) and np.isfinite(mace(dgt, dh))
-
-
 def test_eval_batchnorm_folding_matches_unfolded(zeng):
     """Inference path: every eval-mode BatchNorm folded into the conv before it (ReLU / residual add in the
     conv epilogue) gives the same perspective field and delta_hat as the unfolded eval pass, after the running
