@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--overlap", action="store_true",
                     help="second HIP stream: wgrad GEMMs under the dgrad/BatchNorm chain, extractor prefetch under the backbone "
                          "(+3%% pairs/s; off by default so that per-kernel durations are those of each kernel alone)")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the whole training step in a HIP graph (bihome_amd.graph.GraphedStep) and time replays")
     ap.add_argument("--hook", action="append", default=[], metavar="A,B",
                     help="tuning experiments: call bh_debug_force_tile(A, B) before the run (see csrc/conv_gemm.hip)")
     return ap.parse_args()
@@ -222,7 +224,8 @@ def main():
     load_synthetic(model[0], 0)                       # identical replicas on every rank
     if hasattr(model[1], "auxiliary_resnet"):
         load_synthetic(model[1].auxiliary_resnet, 0)
-    opt, sched = build_optimizer(model, cfg["SOLVER"])
+    use_graph = args.graph and world == 1 and not args.gpu_datagen
+    opt, sched = build_optimizer(model, cfg["SOLVER"], capturable=use_graph)
     reducer = attach_reducer(model) if world > 1 else None
 
     B = args.batch or cfg["DATA"]["BATCH_SIZE"]
@@ -252,12 +255,21 @@ def main():
     def batch():
         return gen.next(B) if gen is not None else dict(data)
 
+    if use_graph:
+        from bihome_amd.graph import GraphedStep
+        gs = GraphedStep(model, opt, sched, dict(data), loss_fn=loss_fn, warmup=3)
+
+        def one_step():
+            return gs(batch())
+    else:
+        def one_step():
+            return train_step(model, batch(), opt, sched, reducer=reducer, loss_fn=loss_fn)
     for _ in range(args.warmup):
-        loss, dgt, dh = train_step(model, batch(), opt, sched, reducer=reducer, loss_fn=loss_fn)
+        loss, dgt, dh = one_step()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, dgt, dh = train_step(model, batch(), opt, sched, reducer=reducer, loss_fn=loss_fn)
+        loss, dgt, dh = one_step()
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -296,6 +308,7 @@ def main():
                                        cfg["MODEL"]["HEAD"]["NAME"], B, P, P,
                                        "RGB" if CH == 3 else "grayscale", args.precision),
                        "stream_overlap": bool(args.overlap or os.environ.get("BIHOME_OVERLAP") == "1"),
+                       "hip_graph": bool(use_graph),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "optimizer": "Adam lr 1e-3"},
             "final_loss": final_loss, "final_mace": final_mace,
             "eval": {"mace": eval_mace, "ms_per_batch": eval_ms, "pairs_per_s_per_gpu": 1e3 * B / eval_ms,

