@@ -15,7 +15,11 @@ LIB_PATH = os.path.join(_HERE, "libbihome_hip_tuning.so" if TUNING else "libbiho
 
 class BhConvDesc(Structure):
     _fields_ = [(n, c_int) for n in ("N", "Hi", "Wi", "Ci", "Ho", "Wo", "Co", "kh", "kw", "stride", "pad",
-                                     "transposed", "in_nchw", "out_nchw", "precision", "route")]
+                                     "transposed", "in_nchw", "out_nchw", "precision", "w_layout", "route")]
+
+
+class BhPack3x3Job(Structure):
+    _fields_ = [("w", c_void_p), ("pf", c_void_p), ("pd", c_void_p), ("Co", c_int), ("Ci", c_int)]
 
 
 # bh_conv_desc.route bits (include/bihome.h): explicit per-call kernel routing for tests / benchmarks; 0 = automatic
@@ -44,6 +48,7 @@ SIGNATURES = {
     "bh_bihome_loss_bwd": [P] * 14 + [c_int, c_int, c_int, c_float] + [P] * 6 + [P],
     "bh_oneline_loss_fwd": [P, P, P, P, P, c_int, c_int, c_int, c_float, P, P, P, P],
     "bh_oneline_loss_bwd": [P, P, P, P, P, P, P, c_int, c_int, c_int, P, P, P],
+    "bh_conv3x3_pack": [P, c_int, P],
     "bh_conv_variant": [POINTER(BhConvDesc), c_int, c_int, c_int, c_char_p, c_int],
     "bh_conv_fwd": [P, P, P, P, POINTER(BhConvDesc), P],
     "bh_conv_fwd_act": [P, P, P, P, P, POINTER(BhConvDesc), c_int, P],

@@ -34,7 +34,7 @@ int bh_device_arch(char* buf, int buflen) {
     return BH_OK;
 }
 
-int bh_conv_variant(const bh_conv_desc* d, int which, int accumulate, int with_bnstats, char* buf, int n) {
+int bh_conv_variant(const bh_conv_desc* d, int which, int accumulate, int with_bnstats /* = bn_groups */, char* buf, int n) {
     if (!d || !buf || n < 2 || which < 0 || which > 2) return BH_E_BADARG;
     BhQuery q;
     q.name[0] = 0; q.len = 0;
@@ -43,7 +43,7 @@ int bh_conv_variant(const bh_conv_desc* d, int which, int accumulate, int with_b
     double* pd = reinterpret_cast<double*>(static_cast<uintptr_t>(256));
     bh_query_ctx = &q;
     int rc;
-    if (which == 0) rc = with_bnstats ? bh_conv_fwd_bnstats(p, p, nullptr, p, d, pd, 1, nullptr) : bh_conv_fwd(p, p, nullptr, p, d, nullptr);
+    if (which == 0) rc = with_bnstats ? bh_conv_fwd_bnstats(p, p, nullptr, p, d, pd, with_bnstats, nullptr) : bh_conv_fwd(p, p, nullptr, p, d, nullptr);
     else if (which == 1) rc = bh_conv_dgrad(p, p, p, d, accumulate, nullptr);
     else rc = bh_conv_wgrad(p, p, p, nullptr, d, nullptr);
     bh_query_ctx = nullptr;

@@ -17,6 +17,13 @@
 // step j contracts channel 8q+j with 8q+4+j - any pairing is valid inside a sum over k).
 // Double-buffered: the weight slab of step t+1 and (one wave instruction per tap step) the halo of the next
 // chunk are in flight while the 32 MFMAs per wave of step t run; one barrier per step.
+//
+// PACKED variant (training path, round 2): the weights arrive pre-packed in MFMA-fragment order (bh_conv3x3_pack, one
+// batched launch per optimizer step for all layers: [chunk][tap][32-wide n tile][q][lane] x float4), so a wave fetches the
+// B fragments of a tap with four fully coalesced 1 KB buffer_load_dwordx4 straight into registers, one tap ahead.  No
+// weight slab in LDS, no slab DMA, no B fragment ds_reads, and - because nothing in LDS changes inside a chunk - ONE
+// workgroup barrier per 32-channel chunk instead of nine: the four waves of a workgroup (and the two workgroups of a
+// CU) drift freely through the taps.  Forward and dgrad are the same loop (the flip / transpose lives in the pack).
 #include "common.h"
 #include <type_traits>
 
@@ -63,6 +70,7 @@ struct C3Args {
     int imgs_per_group, groups;
     int dbg_nch;           // ablation: number of channel chunks to run (-1 = all)
     int tpb, gx_total;     // tile positions per workgroup (see the loop in the kernel), total positions along x
+    int NW;                // PACKED: number of 32-wide output-channel tiles (Nn / 32)
     int dbg_noload;        // ablation bits: 1 no weight-slab DMA in the loop, 2 no halo DMA in the loop (wrong results, timing only)
 };
 
@@ -78,7 +86,7 @@ constexpr int C3_LDS_BYTES = 2 * C3_HALO_BYTES + 2 * C3_B_BYTES;      // 67584
 // SUBT = 8x8 sub-tiles per workgroup.  2 (default): 128 GEMM rows, 67.5 KB of LDS, two workgroups per CU.  1 (BN = 64
 // only): 64 rows, a wave owns 32 rows x 32 channels, 41.6 KB of LDS, three workgroups per CU - more weight-slab traffic
 // and LDS reads per MFMA, but three workgroups drift out of lockstep and cover each other's prologue / epilogue.
-template <bool FLIP, int BN, bool BF16 = false, int SUBT = 2>
+template <bool FLIP, int BN, bool BF16 = false, int SUBT = 2, bool PACKED = false>
 __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
     static_assert(SUBT == 2 || BN == 64, "one sub-tile per workgroup is built for the 64-channel tile only");
     constexpr int TM = (BN == 64 && SUBT == 2) ? 2 : 1;
@@ -120,6 +128,17 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
     const int nch = a.Kc / 32;
     constexpr int dbg_noload = 0;
 #endif
+    // PACKED: B fragments straight from the fragment-ordered weight buffer; soffset = ((chunk*9 + tap)*NW + n tile) * 4 KB
+    const int wnG = blockIdx.y * (BN / 32) + (BN == 64 ? (wave >> 1) : 0);
+    const unsigned pb_voff = (unsigned)lane * 16u;
+#define C3_LOAD_B(dst, c, tap)                                                                                          \
+    do {                                                                                                                \
+        const unsigned so_ = (unsigned)(((c) * 9 + (tap)) * a.NW + wnG) * 4096u;                                        \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                              \
+            const auto v_ = __builtin_amdgcn_raw_buffer_load_b128(rsB, pb_voff + (unsigned)q_ * 1024u, so_, 0);         \
+            dst[q_] = __builtin_bit_cast(float4, v_);                                                                   \
+        }                                                                                                               \
+    } while (0)
     // a single chunk (32 source channels) never touches the second halo stage: the host then launches with one stage less
     // of LDS (41.6 instead of 67.2 KB: three workgroups per CU for the 32-channel layers) and the slabs move down
     const int slab0 = (a.Kc / 32 > 1 ? 2 : 1) * HALO_B;
@@ -162,7 +181,9 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
         oy0[s] = ty * 8 - 1; ox0[s] = tx * 8 - 1;
         org[s] = g < a.subtiles ? (img * a.H + oy0[s]) * a.W + ox0[s] : (int)0x80000000;
     }
-    issue_B(0, 0, 0);                            // the first weight slab goes out before any of the slot arithmetic
+    float4 bcur[4], bnext[4];
+    if constexpr (PACKED) C3_LOAD_B(bcur, 0, 0);
+    else issue_B(0, 0, 0);                       // the first weight slab goes out before any of the slot arithmetic
     unsigned hoff[7] = {OOB, OOB, OOB, OOB, OOB, OOB, OOB};   // (fixed size, first HJ used: see the note at boff)
 #pragma unroll
     for (int j = 0; j < HJ; ++j) {
@@ -201,6 +222,59 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
     __syncthreads();
 
     int bs = 0;
+    if constexpr (PACKED) {
+        for (int c = 0; c < nch; ++c) {
+            const int hs = c & 1;
+            const char* hbase = smem + hs * HALO_B + a_lane;
+            const bool more = c + 1 < nch;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3, dx = tap - dy * 3;
+                const char* ap = hbase + (dy * 10 + dx) * 16;
+                float4 af[TM][4];
+                // A fragments first: the compiler puts a vmcnt(0) in front of LDS reads that follow an LDS-DMA, and at
+                // this point everything in flight (B of this tap, the previous tap's halo piece) is a whole tap old
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af[i][q] = *reinterpret_cast<const float4*>(ap + q * (2 * HPL * 16) + i * 64);
+                __builtin_amdgcn_sched_barrier(0);
+                if (tap < 8) C3_LOAD_B(bnext, c, tap + 1);
+                else if (more) C3_LOAD_B(bnext, c + 1, 0);
+                if (tap < HJ && more) C3_ISSUE_HALO(tap, c + 1, hs ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (BF16) {
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const bf16x8 bb = c3_pack_bf16(bcur[2 * s2], bcur[2 * s2 + 1]);
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c3_pack_bf16(af[i][2 * s2], af[i][2 * s2 + 1]), bb, acc[i], 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q].x, bcur[q].x, acc[i], 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q].y, bcur[q].y, acc[i], 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q].z, bcur[q].z, acc[i], 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q].w, bcur[q].w, acc[i], 0, 0, 0);
+                    }
+                }
+                if (tap == 8) {
+                    // chunk boundary: every wave's halo pieces of the next chunk have landed and nobody still reads this stage
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bcur[q] = bnext[q];
+            }
+        }
+    } else {
     for (int c = 0; c < nch; ++c) {
         const int hs = c & 1;
         const char* hbase = smem + hs * HALO_B + a_lane;
@@ -257,8 +331,10 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
             bs ^= 1;
         }
     }
+    }
 #undef C3_ISSUE_HALO
 #undef issue_B
+#undef C3_LOAD_B
 
     // ---- epilogue: C/D layout col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m) ----
     // Element (i, r) of a lane is pixel (c3_strip_row(2*(r>>2) + kh2), 4*(i + wh) + (r&3)) of the sub-tile: the row part of
@@ -442,13 +518,15 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
                    int accumulate, hipStream_t stream, int* taken, double* bn_sums, int groups, const float* res, int relu,
                    const bh_bn_reduce* bnr) {
     *taken = 0;
+    // (packed weights only make sense to this kernel: a caller that passes them must have asked bh_conv_variant first)
     if ((d->route & BH_ROUTE_GENERIC_CONV) || d->transposed || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->in_nchw ||
         d->out_nchw || (d->precision != 0 && d->precision != 1))
-        return 0;
-    if (d->Hi % 8 || d->Wi % 8 || d->Ho != d->Hi || d->Wo != d->Wi) return 0;
+        return d->w_layout ? BH_E_UNSUPPORTED : 0;
+    if (d->Hi % 8 || d->Wi % 8 || d->Ho != d->Hi || d->Wo != d->Wi) return d->w_layout ? BH_E_UNSUPPORTED : 0;
     const int Kc = dgrad ? d->Co : d->Ci, Nn = dgrad ? d->Ci : d->Co;
-    if (Kc % 32 || Nn % 32) return 0;
+    if (Kc % 32 || Nn % 32) return d->w_layout ? BH_E_UNSUPPORTED : 0;
     const int bn_tile = (Nn % 64) ? 32 : 64;
+    const bool packed = d->w_layout == 1;              // weights in bh_conv3x3_pack fragment order (this direction's buffer)
     const long long src_bytes = (long long)d->N * d->Hi * d->Wi * Kc * 4, w_bytes = (long long)d->Co * 9 * d->Ci * 4;
     const long long out_bytes = (long long)d->N * d->Hi * d->Wi * Nn * 4;
     if (src_bytes >= (1ll << 31) || w_bytes >= (1ll << 31) || out_bytes >= (1ll << 31)) return 0;
@@ -481,33 +559,83 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
         const long long wgs = (long long)grid.x * grid.y;
         if (g_c3_tpb >= 2 && subt == 2 && Kc / 32 > 1 && wgs > 512 && wgs <= 1024) { a.tpb = 2; grid.x = (grid.x + 1) / 2; }
     }
-    if (!(d->route & BH_ROUTE_HALO_SMALL) && (int)(((a.subtiles + 1) / 2) * grid.y) < C3_MIN_BLOCKS) return 0;
-    if (bh_query("conv3x3_halo_kernel<%s,%d,%s,%d>", dgrad ? "true" : "false", bn_tile, d->precision == 1 ? "true" : "false", subt)) {
+    if (!(d->route & BH_ROUTE_HALO_SMALL) && (int)(((a.subtiles + 1) / 2) * grid.y) < C3_MIN_BLOCKS) return d->w_layout ? BH_E_UNSUPPORTED : 0;
+    a.NW = Nn / 32;
+    if (bh_query(packed ? "conv3x3_halo_kernel<%s,%d,%s,%d,true>" : "conv3x3_halo_kernel<%s,%d,%s,%d>", dgrad ? "true" : "false", bn_tile,
+                 d->precision == 1 ? "true" : "false", subt)) {
         *taken = 1;
         return BH_OK;
     }
     static unsigned long long attr_devs = 0;             // devices on which the dynamic-LDS attributes have been set
     typedef void (*kern_t)(C3Args);
-    static const kern_t fns[12] = {conv3x3_halo_kernel<false, 64, false>, conv3x3_halo_kernel<true, 64, false>,
-                                   conv3x3_halo_kernel<false, 32, false>, conv3x3_halo_kernel<true, 32, false>,
-                                   conv3x3_halo_kernel<false, 64, true>,  conv3x3_halo_kernel<true, 64, true>,
-                                   conv3x3_halo_kernel<false, 32, true>,  conv3x3_halo_kernel<true, 32, true>,
-                                   conv3x3_halo_kernel<false, 64, false, 1>, conv3x3_halo_kernel<true, 64, false, 1>,
-                                   conv3x3_halo_kernel<false, 64, true, 1>,  conv3x3_halo_kernel<true, 64, true, 1>};
-    constexpr int LDS1 = 2 * (8 * 100 * 16) + 2 * C3_B_BYTES;           // one sub-tile per workgroup: 41,984 B
+#define C3_ROW(P) conv3x3_halo_kernel<false, 64, false, 2, P>, conv3x3_halo_kernel<true, 64, false, 2, P>,   \
+                  conv3x3_halo_kernel<false, 32, false, 2, P>, conv3x3_halo_kernel<true, 32, false, 2, P>,   \
+                  conv3x3_halo_kernel<false, 64, true, 2, P>,  conv3x3_halo_kernel<true, 64, true, 2, P>,    \
+                  conv3x3_halo_kernel<false, 32, true, 2, P>,  conv3x3_halo_kernel<true, 32, true, 2, P>,    \
+                  conv3x3_halo_kernel<false, 64, false, 1, P>, conv3x3_halo_kernel<true, 64, false, 1, P>,   \
+                  conv3x3_halo_kernel<false, 64, true, 1, P>,  conv3x3_halo_kernel<true, 64, true, 1, P>
+    static const kern_t fns[24] = {C3_ROW(false), C3_ROW(true)};
+#undef C3_ROW
+    constexpr int HALO2 = 8 * 200 * 16, HALO1 = 8 * 100 * 16;          // one halo stage: two / one sub-tile per workgroup
+    constexpr int LDS1 = 2 * HALO1 + 2 * C3_B_BYTES;                   // one sub-tile per workgroup: 41,984 B
     if (bh_device_once(attr_devs)) {
-        for (int i = 0; i < 12; ++i) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[i]), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               i < 8 ? C3_LDS_BYTES : LDS1);
+        for (int i = 0; i < 24; ++i) {
+            const int j = i % 12;
+            const int full = i < 12 ? (j < 8 ? C3_LDS_BYTES : LDS1) : 2 * (j < 8 ? HALO2 : HALO1);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[i]), hipFuncAttributeMaxDynamicSharedMemorySize, full);
             if (e != hipSuccess) return (int)e;
         }
     }
-    const kern_t fn = subt == 1 ? fns[8 + (d->precision == 1 ? 2 : 0) + (dgrad ? 1 : 0)]
-                                : fns[(d->precision == 1 ? 4 : 0) + (bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0)];
+    const kern_t fn = fns[(packed ? 12 : 0) + (subt == 1 ? 8 + (d->precision == 1 ? 2 : 0) + (dgrad ? 1 : 0)
+                                                         : (d->precision == 1 ? 4 : 0) + (bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0))];
     a.dbg_noload = g_c3_noload;
-    const int lds = (subt == 1 ? LDS1 : C3_LDS_BYTES) - (Kc / 32 > 1 ? 0 : 8 * 100 * subt * 16);      // single chunk: one halo stage
+    const int stage = subt == 1 ? HALO1 : HALO2;
+    const int lds = packed ? (Kc / 32 > 1 ? 2 : 1) * stage                                    // halo stages only
+                           : (subt == 1 ? LDS1 : C3_LDS_BYTES) - (Kc / 32 > 1 ? 0 : stage);   // single chunk: one halo stage
     hipLaunchKernelGGL(fn, grid, dim3(256), lds, stream, a);
     BH_LAUNCH_CHECK();
     *taken = 1;
+    return BH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight packing for the PACKED kernels: [Co][9][Ci] -> MFMA-fragment order, for the forward (K = Ci, N = Co) and for the
+// dgrad (K = Co, N = Ci, taps flipped) of every 3x3 layer of a network in ONE launch (grid.y = layer).
+//   packed[(((chunk*9 + tap)*NW + n_tile)*4 + q)*64 + lane] (float4) = B[k = chunk*32 + (2q + lane/32)*4 + e][n = n_tile*32 + lane%32]
+//   forward: B[k][n] = W[n][tap][k]            dgrad: B[k][n] = W[k][8 - tap][n]
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pack_conv3x3_weights_kernel(const bh_pack3x3_job* __restrict__ jobs) {
+    const bh_pack3x3_job j = jobs[blockIdx.y];
+    const int Co = j.Co, Ci = j.Ci;
+    const long long n4 = (long long)Co * 9 * Ci / 4;
+    const float4* __restrict__ w4 = reinterpret_cast<const float4*>(j.w);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const int lane = (int)(i & 63), q = (int)((i >> 6) & 3);
+        const int l31 = lane & 31, kh2 = lane >> 5;
+        long long r = i >> 8;
+        if (j.pf) {
+            const int NW = Co / 32;
+            const int nt = (int)(r % NW); long long r2 = r / NW;
+            const int tap = (int)(r2 % 9), c = (int)(r2 / 9);
+            const int n = nt * 32 + l31, k0 = c * 32 + (2 * q + kh2) * 4;
+            reinterpret_cast<float4*>(j.pf)[i] = w4[((long long)(n * 9 + tap) * Ci + k0) >> 2];
+        }
+        if (j.pd) {
+            const int NW = Ci / 32;
+            const int nt = (int)(r % NW); long long r2 = r / NW;
+            const int tap = (int)(r2 % 9), c = (int)(r2 / 9);
+            const int n = nt * 32 + l31, k0 = c * 32 + (2 * q + kh2) * 4;
+            const float* src = j.w + ((long long)k0 * 9 + (8 - tap)) * Ci + n;
+            const long long ks = 9ll * Ci;
+            reinterpret_cast<float4*>(j.pd)[i] = make_float4(src[0], src[ks], src[2 * ks], src[3 * ks]);
+        }
+    }
+}
+
+extern "C" int bh_conv3x3_pack(const bh_pack3x3_job* jobs_dev, int njobs, void* stream) {
+    if (!jobs_dev || njobs < 0) return BH_E_BADARG;
+    if (njobs == 0) return BH_OK;
+    hipLaunchKernelGGL(pack_conv3x3_weights_kernel, dim3(64, njobs), dim3(256), 0, bh_stream(stream), jobs_dev);
+    BH_LAUNCH_CHECK();
     return BH_OK;
 }

@@ -363,7 +363,8 @@ class Model(nn.Module):
             # the DLT kernels gather pf[id] and scatter-add into g_pf[id]: caller-supplied indices must lie in [0, N).
             # (Host check with a device sync: this hook is the test / replay path; indices drawn by `sample_choice` are in
             # range by construction.  A device-side assert would abort the process on ROCm instead of raising.)
-            if c.numel() and not bool(((c >= 0) & (c < N)).all()):
+            capturing = torch.cuda.is_current_stream_capturing()     # (no host sync inside a HIP-graph capture)
+            if c.numel() and not capturing and not bool(((c >= 0) & (c < N)).all()):
                 raise ValueError("bihome_amd: data['%s'] holds indices outside [0, %d)" % (key, N))
             return c
         n, P = self.hypothesis_no, self.point_per_hypothesis

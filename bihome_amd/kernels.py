@@ -4,7 +4,7 @@ import ctypes
 
 import torch
 
-from ._lib import BhBnReduce, BhConvDesc, check, lib
+from ._lib import BhBnReduce, BhConvDesc, BhPack3x3Job, check, lib
 
 
 def _p(t):
@@ -257,12 +257,69 @@ def conv_out_shape(d):
     return (d.N, d.Co, d.Ho, d.Wo) if d.out_nchw else (d.N, d.Ho, d.Wo, d.Co)
 
 
-def conv_fwd(x, w, bias, d, bn_sums=None, groups=1, res=None, relu=False):
-    """bn_sums: zeroed float64 sums buffer - the conv also accumulates the batch statistics of its output for the
+def _with_layout(d, w_layout):
+    d2 = BhConvDesc()
+    ctypes.memmove(ctypes.byref(d2), ctypes.byref(d), ctypes.sizeof(BhConvDesc))
+    d2.w_layout = w_layout
+    return d2
+
+
+def packs_3x3(d):
+    """True when the halo-tiled 3x3 kernel takes both the forward and the dgrad of this conv (then the fragment-ordered
+    weight copies of bh_conv3x3_pack can be used for it)."""
+    return (conv_variant(d, "fwd").startswith("conv3x3_halo_kernel") and conv_variant(d, "dgrad").startswith("conv3x3_halo_kernel"))
+
+
+class WeightPacker:
+    """Fragment-ordered copies (forward and dgrad operand order) of the 3x3 conv weights of one module tree, refreshed by
+    ONE bh_conv3x3_pack launch whenever a parameter version changed (every optimizer step in training, once for frozen
+    weights).  Buffers and the device job table are allocated once (addresses stay fixed: HIP-graph safe)."""
+
+    def __init__(self):
+        self.entries = {}          # id(weight) -> (weight, pf, pd)
+        self.table = None
+        self.versions = None
+
+    def get(self, weight, need_dgrad=True):
+        e = self.entries.get(id(weight))
+        if e is None:
+            Co, Ci = weight.shape[0], weight.shape[1]
+            pf = torch.empty(weight.numel(), dtype=torch.float32, device=weight.device)
+            pd = torch.empty(weight.numel(), dtype=torch.float32, device=weight.device) if need_dgrad else None
+            e = self.entries[id(weight)] = (weight, pf, pd)
+            self.table = None
+        return e[1], e[2]
+
+    def refresh(self):
+        if not self.entries:
+            return
+        vers = tuple((w._version, w.data_ptr()) for w, _, _ in self.entries.values())
+        if self.table is not None and vers == self.versions:
+            return
+        if self.table is None or any(p != q[1] for p, q in zip(self._ptrs, vers)):
+            jobs = (BhPack3x3Job * len(self.entries))()
+            for j, (w, pf, pd) in zip(jobs, self.entries.values()):
+                if not w.permute(0, 2, 3, 1).is_contiguous():
+                    raise RuntimeError("conv weight is not in kernel (channels_last) layout")
+                j.w, j.pf, j.pd = w.data_ptr(), pf.data_ptr(), (pd.data_ptr() if pd is not None else None)
+                j.Co, j.Ci = w.shape[0], w.shape[1]
+            raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8)
+            dev = next(iter(self.entries.values()))[0].device
+            self.table = raw.to(dev)
+            self._ptrs = [v[1] for v in vers]
+        check(lib.bh_conv3x3_pack(_p(self.table), len(self.entries), _stream()), "bh_conv3x3_pack")
+        self.versions = vers
+
+
+def conv_fwd(x, w, bias, d, bn_sums=None, groups=1, res=None, relu=False, wpacked=None):
+    """wpacked: the forward buffer of WeightPacker for this conv (then `w` is only used for the byte count).
+    bn_sums: zeroed float64 sums buffer - the conv also accumulates the batch statistics of its output for the
     BatchNorm that follows (bn_fwd(..., stats=bn_sums, stats_ready=True)).  res / relu: inference epilogue
     y = act(conv + bias + res) (BatchNorm folded into w, bias by the caller)."""
     _chk(x); _chk(w); _chk(bias); _chk(res)
     y = torch.empty(conv_out_shape(d), dtype=torch.float32, device=x.device)
+    if wpacked is not None:
+        d, w = _with_layout(d, 1), wpacked
     with _Timed(_conv_variant(d, "fwd", bn_groups=groups if bn_sums is not None else 0), conv_flops(d),
                 4.0 * (x.numel() + y.numel() + w.numel())):
         if res is not None or relu:
@@ -310,12 +367,15 @@ def dgrad_bn_reduce_ok(d):
     return conv_variant(d, "dgrad").startswith("conv3x3_halo_kernel")
 
 
-def conv_dgrad(gy, w, d, out=None, bn_reduce=None, wkey=None):
-    """wkey: (id(param), param._version) of the parameter `w` was derived from (cache key of derived weight tables).
+def conv_dgrad(gy, w, d, out=None, bn_reduce=None, wkey=None, wpacked=None):
+    """wpacked: the dgrad buffer of WeightPacker for this conv.
+    wkey: (id(param), param._version) of the parameter `w` was derived from (cache key of derived weight tables).
     bn_reduce (only when dgrad_bn_reduce_ok(d)): dict(z, y, stats, gamma, beta, eps, relu, sums, groups) of the
     BatchNorm whose output gradient this call completes - its backward sums are accumulated into `sums` (zeroed
     bn_stats_buffer) in the conv epilogue; pass them to bn_bwd(..., sums_ready=sums)."""
     _chk(gy); _chk(w)
+    if wpacked is not None:
+        d, w = _with_layout(d, 1), wpacked
     if bn_reduce is not None:
         acc = out is not None
         if out is None:

@@ -179,10 +179,10 @@ class Program:
 
 class Ctx:
     """Saved tensors of one forward pass."""
-    __slots__ = ("slots", "stats", "descs", "groups", "training", "weights", "wkeys")
+    __slots__ = ("slots", "stats", "descs", "groups", "training", "weights", "wkeys", "wpacked")
 
     def __init__(self):
-        self.slots, self.stats, self.descs, self.weights, self.wkeys = {}, {}, {}, {}, {}
+        self.slots, self.stats, self.descs, self.weights, self.wkeys, self.wpacked = {}, {}, {}, {}, {}, {}
 
 
 def _conv_geometry(mod, x_shape, in_nchw, out_nchw, precision=0):
@@ -235,11 +235,15 @@ def _momentum(bn):
     return bn.momentum
 
 
-def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None):
-    """x: NHWC (or NCHW when the first conv is flagged in_nchw). Returns (out, ctx|None).
+def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, packer=None):
+    """packer: kernels.WeightPacker holding fragment-ordered copies of the 3x3 weights (refreshed here, one launch, when
+    a parameter changed): the halo-tiled 3x3 kernel then streams its B operand straight into registers.
+    x: NHWC (or NCHW when the first conv is flagged in_nchw). Returns (out, ctx|None).
     fold_cache (inference only: not training, nothing saved): a dict - every conv whose only consumer is a BatchNorm
     runs with that BatchNorm folded into its weights and the ReLU / residual add fused into its epilogue."""
     ctx = Ctx() if save else None
+    if packer is not None:
+        packer.refresh()
     slots = {0: x}
     if save:
         ctx.groups, ctx.training = groups, training
@@ -295,15 +299,20 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None):
             d = _conv_geometry(op.mod, src.shape, e["in_nchw"], e["out_nchw"], precision)
             w = e["weight_fn"](op.mod.weight) if e["weight_fn"] else op.mod.weight
             wk = kview(w)
+            pk = None
+            if packer is not None and e["weight_fn"] is None and id(op.mod.weight) in packer.entries and K.packs_3x3(d):
+                pk = packer.entries[id(op.mod.weight)]
             if i in fused_stats and d.N % groups == 0:
                 b = fused_stats[i]
                 out = K.conv_fwd(src, wk, op.mod.bias, d,
-                                 bn_sums=arena[bn_off[b]:bn_off[b] + K.bn_stats_doubles(groups, d.Co)], groups=groups)
+                                 bn_sums=arena[bn_off[b]:bn_off[b] + K.bn_stats_doubles(groups, d.Co)], groups=groups,
+                                 wpacked=pk[1] if pk else None)
                 ready.add(b)
             else:
-                out = K.conv_fwd(src, wk, op.mod.bias, d)
+                out = K.conv_fwd(src, wk, op.mod.bias, d, wpacked=pk[1] if pk else None)
             if save:
                 ctx.descs[i], ctx.weights[i] = d, wk
+                ctx.wpacked[i] = pk[2] if pk else None
                 ctx.wkeys[i] = (id(op.mod.weight), op.mod.weight._version)
         elif op.kind == "bn":
             m = op.mod
@@ -437,9 +446,9 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
                                groups=ctx.groups)
                     bn_reduced[b] = sums
                 if op.src in grads:
-                    K.conv_dgrad(g, wk, d, out=grads[op.src], bn_reduce=red, wkey=ctx.wkeys[i])
+                    K.conv_dgrad(g, wk, d, out=grads[op.src], bn_reduce=red, wkey=ctx.wkeys[i], wpacked=ctx.wpacked.get(i))
                 else:
-                    grads[op.src] = K.conv_dgrad(g, wk, d, bn_reduce=red, wkey=ctx.wkeys[i])
+                    grads[op.src] = K.conv_dgrad(g, wk, d, bn_reduce=red, wkey=ctx.wkeys[i], wpacked=ctx.wpacked.get(i))
         elif op.kind == "bn":
             m = op.mod
             train_w = want_wgrad and m.weight is not None and m.weight.requires_grad
@@ -522,8 +531,9 @@ class NetFunction(torch.autograd.Function):
         training = runner.module.training
         if training:
             runner._fold.clear()            # running statistics are about to change (the kernels write them in place)
-        out, saved = run_forward(runner.prog, x, groups, training, save=need, precision=runner.precision,
-                                 fold_cache=runner._fold if (runner.fold_bn and not training and not need) else None)
+        fold = runner._fold if (runner.fold_bn and not training and not need) else None
+        out, saved = run_forward(runner.prog, x, groups, training, save=need, precision=runner.precision, fold_cache=fold,
+                                 packer=runner.packer_for(x.device) if fold is None else None)
         ctx.runner, ctx.saved, ctx.want_x = runner, saved, ctx.needs_input_grad[0]
         return out
 
@@ -560,6 +570,23 @@ class Runner:
         # opt-in (BIHOME_OVERLAP=1 or bench.py --overlap): +3% step throughput, but kernels of the two streams share the
         # GPU, so per-kernel durations (rocprof, the roofline leg) are no longer those of the kernel alone
         self.wgrad_on_side_stream = os.environ.get("BIHOME_OVERLAP", "0") == "1"
+        # fragment-ordered weight copies for the halo-tiled 3x3 kernel (csrc/conv3x3.hip PACKED; BIHOME_PACK_WEIGHTS=0: off)
+        self.use_packer = os.environ.get("BIHOME_PACK_WEIGHTS", "1") != "0"
+        self._packer = None
+
+    def packer_for(self, device):
+        if not self.use_packer:
+            return None
+        if self._packer is None or self._packer_dev != device:
+            pk = K.WeightPacker()
+            for op in self.prog.ops:
+                m = op.mod
+                if (op.kind == "conv" and isinstance(m, nn.Conv2d) and op.extra["weight_fn"] is None and m.kernel_size == (3, 3)
+                        and m.stride == (1, 1) and m.padding == (1, 1) and m.in_channels % 32 == 0 and m.out_channels % 32 == 0
+                        and m.weight.device == device):
+                    pk.get(m.weight)
+            self._packer, self._packer_dev = pk, device
+        return self._packer
 
     def __call__(self, x, groups):
         if not x.is_cuda:

@@ -126,6 +126,10 @@ typedef struct {
     int out_nchw;           /* 1: y is NCHW (only for the network output, Co <= 4) */
     int precision;          /* 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1: operands rounded to bf16 while staging,
                              * fp32 accumulate (v_mfma_f32_32x32x16_bf16), tensors stay fp32 in HBM */
+    int w_layout;           /* 0: w is [Co][kh][kw][Ci].  1 (3x3 / stride 1 / pad 1 only): w is the fragment-ordered copy made
+                             * by bh_conv3x3_pack - its `pf` buffer for bh_conv_fwd*, its `pd` buffer for bh_conv_dgrad* -
+                             * which the halo-tiled 3x3 kernel streams straight into registers; BH_E_UNSUPPORTED when
+                             * that kernel does not take the launch (ask bh_conv_variant first) */
     int route;              /* 0: automatic kernel choice (production).  BH_ROUTE_* bits: explicit per-call routing for
                              * tests and benchmarks (e.g. drive the halo-tiled 3x3 kernel on a grid it would decline) */
 } bh_conv_desc;
@@ -135,11 +139,24 @@ typedef struct {
 #define BH_ROUTE_WGRAD_GENERIC 8  /* wgrad: generic split-K kernel instead of the stride-1 fast path */
 #define BH_ROUTE_WGRAD_3TAP 16    /* wgrad: three taps per workgroup in the stride-1 fast path */
 
+/* One 3x3 layer's weights for bh_conv3x3_pack: w[Co][3][3][Ci] (Co, Ci multiples of 32) -> pf (forward operand order) and
+ * pd (dgrad operand order: transposed, taps flipped), Co*9*Ci floats each; either may be NULL. */
+typedef struct {
+    const float* w;
+    float* pf;
+    float* pd;
+    int Co, Ci;
+} bh_pack3x3_job;
+/* Packs the weights of njobs layers in one launch (jobs_dev: device array).  Call after every optimizer step (the
+ * parameters changed) before the next forward; frozen layers need it once. */
+int bh_conv3x3_pack(const bh_pack3x3_job* jobs_dev, int njobs, void* stream);
+
 /* Which kernel a launch described by d would run: which = 0 forward, 1 dgrad, 2 wgrad.  Writes the kernel template
  * instantiation (the symbol rocprofv3 lists, e.g. "conv3x3_halo_kernel<false,64,false,2>"; several launches joined by
  * '+') into buf[n].  Runs the real dispatch code with the launches replaced by a name record, so it cannot drift from it.
- * accumulate / with_bnstats mirror the arguments of the call being described (they influence routing). */
-int bh_conv_variant(const bh_conv_desc* d, int which, int accumulate, int with_bnstats, char* buf, int n);
+ * accumulate / bn_groups (0: plain bh_conv_fwd, > 0: bh_conv_fwd_bnstats with that many groups) mirror the arguments of
+ * the call being described (they influence routing). */
+int bh_conv_variant(const bh_conv_desc* d, int which, int accumulate, int bn_groups, char* buf, int n);
 
 #ifdef BH_TUNING
 /* ablation / tuning hook of the -DBH_TUNING build (tools/ only; process-global state) */

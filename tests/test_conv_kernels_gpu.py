@@ -470,3 +470,56 @@ def test_c_abi_error_codes(K):
         K.warp_fwd(img, H)
     with pytest.raises(RuntimeError, match="no CPU"):
         K.conv_fwd(x.cpu(), w, None, d)
+
+
+@pytest.mark.parametrize("N,H,Ci,Co,prec", [
+    (128, 32, 64, 64, 0),       # the bench shape: two tile positions per workgroup, two chunks
+    (8, 16, 128, 128, 0),       # four chunks, two n tiles
+    (8, 8, 256, 256, 0),        # one sub-tile per workgroup
+    (4, 64, 32, 32, 0),         # 32-channel tile, single chunk (one halo stage)
+    (3, 24, 64, 32, 0),         # odd sub-tile count, 64 -> 32
+    (5, 16, 32, 64, 0),         # single chunk, 64-wide tile, odd image count
+    (8, 16, 64, 128, 1),        # bf16 operand mode
+])
+def test_conv3x3_packed_weights_match_lds_slab_path(K, N, H, Ci, Co, prec):
+    """bh_conv3x3_pack + w_layout = 1 (B fragments streamed from the fragment-ordered copy into registers, one barrier per
+    chunk) against the LDS-slab form of the same kernel: same MFMA order, so forward, forward + BatchNorm sums, dgrad and
+    accumulating dgrad must be BIT-identical; and against torch float64."""
+    from bihome_amd._lib import ROUTE_HALO_SMALL
+    g = torch.Generator().manual_seed(N * 7 + H)
+    x = torch.randn(N, H, H, Ci, generator=g).cuda()
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * 0.05).cuda().contiguous(memory_format=torch.channels_last)
+    wk = w.permute(0, 2, 3, 1)
+    b = torch.randn(Co, generator=g).cuda()
+    gy = torch.randn(N, H, H, Co, generator=g).cuda()
+    d = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=prec, route=ROUTE_HALO_SMALL)
+    assert K.packs_3x3(d)
+    pk = K.WeightPacker()
+    pf, pd = pk.get(w)
+    pk.refresh()
+    dp = K._with_layout(d, 1)
+    assert K.conv_variant(dp, "fwd").endswith(",true>") and K.conv_variant(dp, "dgrad").endswith(",true>")
+    y0 = K.conv_fwd(x, wk, b, d)
+    y1 = K.conv_fwd(x, wk, b, d, wpacked=pf)
+    assert torch.equal(y0, y1)
+    s0, s1 = K.bn_stats_buffer(1, Co, "cuda"), K.bn_stats_buffer(1, Co, "cuda")
+    assert torch.equal(K.conv_fwd(x, wk, b, d, bn_sums=s0, groups=1), K.conv_fwd(x, wk, b, d, bn_sums=s1, groups=1, wpacked=pf))
+    close(s1.cpu(), s0.cpu(), 1e-12)
+    g0 = K.conv_dgrad(gy, wk, d)
+    g1 = K.conv_dgrad(gy, wk, d, wpacked=pd)
+    assert torch.equal(g0, g1)
+    acc0, acc1 = x.clone(), x.clone()
+    K.conv_dgrad(gy, wk, d, out=acc0)
+    K.conv_dgrad(gy, wk, d, out=acc1, wpacked=pd)
+    assert torch.equal(acc0, acc1)
+    if prec == 0:
+        ref = F.conv2d(x.double().cpu().permute(0, 3, 1, 2), w.double().cpu(), b.double().cpu(), 1, 1).permute(0, 2, 3, 1)
+        close(y1.cpu(), ref, 3e-5)
+    # a parameter update is picked up by the next refresh (version counter), without reallocating the buffers
+    p0 = pf.data_ptr()
+    with torch.no_grad():
+        w.mul_(0.5)
+    pk.refresh()
+    assert pf.data_ptr() == p0
+    y2 = K.conv_fwd(x, wk, None, d, wpacked=pf)
+    assert torch.equal(y2, K.conv_fwd(x, wk, None, d))
