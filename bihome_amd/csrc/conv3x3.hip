@@ -552,12 +552,14 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
     // one sub-tile per workgroup where two would leave half of the 512 workgroup slots empty (the 8x8x256-channel layers:
     // +6 %); elsewhere the 128-row tile is as fast or faster (measured, tools/conv3x3_check.py --subt1)
     const bool few = (long long)((a.subtiles + 1) / 2) * (Nn / bn_tile) <= 256;
-    const int subt = (bn_tile == 64 && (g_c3_subt == 1 || (g_c3_subt == 2 && few))) ? 1 : 2;
+    const int subt = (bn_tile == 64 && (g_c3_subt == 1 || (d->route & BH_ROUTE_C3_ONE_SUBTILE) || (g_c3_subt == 2 && few))) ? 1 : 2;
     dim3 grid((a.subtiles + subt - 1) / subt, Nn / bn_tile);
     a.gx_total = (int)grid.x; a.tpb = 1;
     {   // exactly-two-rounds launches (two resident workgroups per CU with two sub-tiles, 512 slots): one round of two tiles
         const long long wgs = (long long)grid.x * grid.y;
-        if (g_c3_tpb >= 2 && subt == 2 && Kc / 32 > 1 && wgs > 512 && wgs <= 1024) { a.tpb = 2; grid.x = (grid.x + 1) / 2; }
+        if (g_c3_tpb >= 2 && !(d->route & BH_ROUTE_C3_ONE_POSITION) && subt == 2 && Kc / 32 > 1 && wgs > 512 && wgs <= 1024) {
+            a.tpb = 2; grid.x = (grid.x + 1) / 2;
+        }
     }
     if (!(d->route & BH_ROUTE_HALO_SMALL) && (int)(((a.subtiles + 1) / 2) * grid.y) < C3_MIN_BLOCKS) return d->w_layout ? BH_E_UNSUPPORTED : 0;
     a.NW = Nn / 32;

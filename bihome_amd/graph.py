@@ -38,7 +38,7 @@ class GraphedStep:
             self.out = train_step(model, dict(self.static), opt, None, clip=clip, loss_fn=loss_fn)
         # host-side BatchNorm call counters advance once per replay by what one captured step added
         self._bn_inc = [getattr(m, "_bh_pending_batches", 0) - b for m, b in zip(self._bns, before)]
-        self.warmup_steps = warmup + 1                     # optimizer steps already taken on the example batch
+        self.warmup_steps = warmup                         # optimizer steps already taken on the example batch (the capture records, it does not run)
 
     def __call__(self, data):
         for k in self.keys:

@@ -1,6 +1,7 @@
 """Thin tensor-level wrappers over the C ABI (include/bihome.h): argument checking, raw device
 pointers and the current HIP stream.  No arithmetic happens here."""
 import ctypes
+import os
 
 import torch
 
@@ -236,12 +237,13 @@ def bihome_loss_bwd(g_loss, f1, f2, f1w, f2w, m1w, m2w, m1, m2, M1, M2, numden, 
 # conv stacks
 # ------------------------------------------------------------------------------------------------
 PRECISION = {"f32": 0, "fp32": 0, "bf16": 1}
+_ENV_ROUTE = int(os.environ.get("BIHOME_ROUTE", "0"))     # benchmarks: OR these BH_ROUTE_* bits into every conv descriptor
 
 
 def conv_desc(N, Hi, Wi, Ci, Co, k, stride, pad, transposed=False, in_nchw=False, out_nchw=False, precision=0, route=0):
     d = BhConvDesc()
     d.precision = int(precision)
-    d.route = int(route)
+    d.route = int(route) | _ENV_ROUTE
     d.N, d.Hi, d.Wi, d.Ci, d.Co = N, Hi, Wi, Ci, Co
     d.kh = d.kw = k
     d.stride, d.pad = stride, pad
@@ -279,6 +281,7 @@ class WeightPacker:
         self.entries = {}          # id(weight) -> (weight, pf, pd)
         self.table = None
         self.versions = None
+        self.dirty = False         # a training forward ran since the last pack: the optimizer has (probably) moved the weights
 
     def get(self, weight, need_dgrad=True):
         e = self.entries.get(id(weight))
@@ -290,11 +293,17 @@ class WeightPacker:
             self.table = None
         return e[1], e[2]
 
-    def refresh(self):
+    def refresh(self, training=False):
+        """Repack when a parameter changed.  Version counters catch load_state_dict / copy_ / the default optimizers, but
+        torch's FUSED optimizers update parameters without bumping them - so trainable weights are repacked on every
+        training forward, and on the first inference forward after one."""
         if not self.entries:
             return
         vers = tuple((w._version, w.data_ptr()) for w, _, _ in self.entries.values())
-        if self.table is not None and vers == self.versions:
+        trainable = any(w.requires_grad for w, _, _ in self.entries.values())
+        force = trainable and (training or self.dirty)
+        self.dirty = bool(training and trainable)
+        if self.table is not None and vers == self.versions and not force:
             return
         if self.table is None or any(p != q[1] for p, q in zip(self._ptrs, vers)):
             jobs = (BhPack3x3Job * len(self.entries))()

@@ -243,7 +243,7 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, p
     runs with that BatchNorm folded into its weights and the ReLU / residual add fused into its epilogue."""
     ctx = Ctx() if save else None
     if packer is not None:
-        packer.refresh()
+        packer.refresh(training)
     slots = {0: x}
     if save:
         ctx.groups, ctx.training = groups, training

@@ -138,6 +138,8 @@ typedef struct {
 #define BH_ROUTE_NO_STEM7 4       /* fwd: never the dedicated 7x7/2 stem kernel */
 #define BH_ROUTE_WGRAD_GENERIC 8  /* wgrad: generic split-K kernel instead of the stride-1 fast path */
 #define BH_ROUTE_WGRAD_3TAP 16    /* wgrad: three taps per workgroup in the stride-1 fast path */
+#define BH_ROUTE_C3_ONE_SUBTILE 32  /* fwd / dgrad: halo-tiled 3x3 kernel with one 8x8 sub-tile per workgroup (64-channel tile) */
+#define BH_ROUTE_C3_ONE_POSITION 64 /* fwd / dgrad: halo-tiled 3x3 kernel never walks two tile positions per workgroup */
 
 /* One 3x3 layer's weights for bh_conv3x3_pack: w[Co][3][3][Ci] (Co, Ci multiples of 32) -> pf (forward operand order) and
  * pd (dgrad operand order: transposed, taps flipped), Co*9*Ci floats each; either may be NULL. */
