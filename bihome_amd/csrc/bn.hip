@@ -48,11 +48,19 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const float* __restrict__
     const int rbeg = chunk * g.rows_per_chunk, rend = min(g.rows, rbeg + g.rows_per_chunk);
     const float* base = x + ((size_t)grp * g.rows) * g.C + cq * 4;
     double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int r = rbeg + r0; r < rend; r += g.RPP) {
-        float4 a = *reinterpret_cast<const float4*>(base + (size_t)r * g.C);
+    auto accumulate = [&](const float4& a) {
         v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
         v[4] += (double)a.x * a.x; v[5] += (double)a.y * a.y; v[6] += (double)a.z * a.z; v[7] += (double)a.w * a.w;
+    };
+    int r = rbeg + r0;
+    for (; r + 7 * g.RPP < rend; r += 8 * g.RPP) {          // eight rows per lane in flight
+        float4 a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = *reinterpret_cast<const float4*>(base + (size_t)(r + u * g.RPP) * g.C);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) accumulate(a[u]);
     }
+    for (; r < rend; r += g.RPP) accumulate(*reinterpret_cast<const float4*>(base + (size_t)r * g.C));
     reduce_rows<8>(v, g.LPR, g.RPP, sm);
     if ((int)threadIdx.x < g.LPR) {
         const int slot = blockIdx.x % BH_BN_SUM_SLOTS;
@@ -199,14 +207,12 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restr
     const size_t gbase = ((size_t)grp * g.rows) * g.C + cq * 4;
     const bool relu = flags & 1, mask_from_x = flags & 4;     // bit 2: no residual -> y = relu(x*sc+sh), recompute the mask
     double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int r = rbeg + r0; r < rend; r += g.RPP) {
-        const size_t off = gbase + (size_t)r * g.C;
-        float4 d = *reinterpret_cast<const float4*>(gy + off);
-        float4 a = *reinterpret_cast<const float4*>(x + off);
+    const bool need_y = relu && !mask_from_x;
+    auto accumulate = [&](float4 d, const float4& a, const float4& yv) {
         if (relu) {
             float4 o;
             if (mask_from_x) o = make_float4(a.x * sc[0] + sh[0], a.y * sc[1] + sh[1], a.z * sc[2] + sh[2], a.w * sc[3] + sh[3]);
-            else o = *reinterpret_cast<const float4*>(y + off);
+            else o = yv;
             if (!(o.x > 0.f)) d.x = 0.f;
             if (!(o.y > 0.f)) d.y = 0.f;
             if (!(o.z > 0.f)) d.z = 0.f;
@@ -217,6 +223,28 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restr
         v[5] += (double)(d.y * ((a.y - mean[1]) * invstd[1]));
         v[6] += (double)(d.z * ((a.z - mean[2]) * invstd[2]));
         v[7] += (double)(d.w * ((a.w - mean[3]) * invstd[3]));
+    };
+    // four rows per lane in flight (a one-row loop keeps 2-3 loads outstanding per lane and runs at HBM latency, not
+    // bandwidth: 37 us for two 33.5 MB tensors)
+    int r = rbeg + r0;
+    for (; r + 3 * g.RPP < rend; r += 4 * g.RPP) {
+        float4 d[4], a[4], yv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t off = gbase + (size_t)(r + u * g.RPP) * g.C;
+            d[u] = *reinterpret_cast<const float4*>(gy + off);
+            a[u] = *reinterpret_cast<const float4*>(x + off);
+            yv[u] = need_y ? *reinterpret_cast<const float4*>(y + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) accumulate(d[u], a[u], yv[u]);
+    }
+    for (; r < rend; r += g.RPP) {
+        const size_t off = gbase + (size_t)r * g.C;
+        const float4 d = *reinterpret_cast<const float4*>(gy + off);
+        const float4 a = *reinterpret_cast<const float4*>(x + off);
+        const float4 yv = need_y ? *reinterpret_cast<const float4*>(y + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        accumulate(d, a, yv);
     }
     reduce_rows<8>(v, g.LPR, g.RPP, sm);
     if ((int)threadIdx.x < g.LPR) {
@@ -361,9 +389,13 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
     }
 }
 
+BH_KNOB(g_bn_apply_cap, 512);        // workgroups per apply launch: two per CU that loop beat a one-shot grid of 2048 by 15-30 % (tools/bn_apply_sweep.py; tuning: bh_debug_force_tile(-20, n))
+#ifdef BH_TUNING
+void bh_bn_tune(int cap) { g_bn_apply_cap = cap; }
+#endif
 static int apply_blocks(const BnGeom& g) {
     int nb = (g.rows + g.RPP * 4 - 1) / (g.RPP * 4);
-    int cap = 2048 / g.groups;
+    int cap = g_bn_apply_cap / g.groups;
     if (cap < 1) cap = 1;
     if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
