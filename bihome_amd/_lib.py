@@ -54,10 +54,13 @@ SIGNATURES = {
     "bh_conv_fwd_act": [P, P, P, P, P, POINTER(BhConvDesc), c_int, P],
     "bh_conv_fwd_bnstats": [P, P, P, P, POINTER(BhConvDesc), P, c_int, P],
     "bh_conv_dgrad": [P, P, P, POINTER(BhConvDesc), c_int, P],
+    "bh_conv_dgrad_colsum": [P, P, P, POINTER(BhConvDesc), P, P],
+    "bh_bias_grad_from_sums": [P, P, c_int, c_int, P],
     "bh_conv_dgrad_s2": [P, P, P, POINTER(BhConvDesc), c_int, P, P],
     "bh_conv_dgrad_bnreduce": [P, P, P, POINTER(BhConvDesc), c_int, POINTER(BhBnReduce), P, c_int, P],
     "bh_col2im_c1": [P, P, POINTER(BhConvDesc), c_int, P],
     "bh_conv_wgrad": [P, P, P, P, POINTER(BhConvDesc), P],
+    "bh_conv_wgrad_det": [P, P, P, P, POINTER(BhConvDesc), P, c_int64, P],
     "bh_conv_bias_grad": [P, P, POINTER(BhConvDesc), P],
     "bh_bn_stats_doubles": [c_int, c_int],
     "bh_bn_scratch_doubles": [c_int, c_int],
@@ -95,6 +98,8 @@ def _load():
             raise BihomeLibError("bihome_amd: %s does not export %s (stale build?)" % (LIB_PATH, name)) from e
         fn.argtypes = argtypes
         fn.restype = c_int
+    lib.bh_conv_wgrad_det_bytes.argtypes = [POINTER(BhConvDesc)]      # (the one entry point that does not return a status)
+    lib.bh_conv_wgrad_det_bytes.restype = c_int64
     if TUNING:
         lib.bh_debug_force_tile.argtypes = [c_int, c_int]
         lib.bh_debug_force_tile.restype = c_int

@@ -534,7 +534,10 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
     a.Src = src; a.Wt = w; a.bias = bias; a.Out = out;
     a.N = d->N; a.H = d->Hi; a.W = d->Wi; a.Kc = Kc; a.Nn = Nn; a.Cw = d->Ci; a.accumulate = accumulate;
     a.src_bytes = (unsigned)src_bytes; a.w_bytes = (unsigned)w_bytes; a.out_bytes = (unsigned)out_bytes;
-    if (bn_sums && ((dgrad != 0) != (bnr != nullptr) || groups < 1 || d->N % groups)) return BH_E_BADARG;
+    // sums: forward -> BatchNorm statistics of the output; dgrad + bnr -> that BatchNorm's backward sums; dgrad without
+    // bnr -> plain per-channel (sum, sum of squares) of the gradient written (its column sums = the bias gradient of the
+    // layer that produced this conv's input: bh_conv_dgrad_colsum), only on the non-accumulating store path
+    if (bn_sums && (groups < 1 || d->N % groups || (!dgrad && bnr) || (dgrad && !bnr && accumulate))) return BH_E_BADARG;
     if (bnr) {
         if (!bnr->z || !bnr->stats) return BH_E_BADARG;
         a.bnr_z = bnr->z; a.bnr_y = bnr->y; a.bnr_stats = bnr->stats; a.bnr_gamma = bnr->gamma; a.bnr_beta = bnr->beta;

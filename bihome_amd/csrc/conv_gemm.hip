@@ -1142,6 +1142,31 @@ int bh_conv_dgrad_bnreduce(const float* gy, const float* w, float* gx, const bh_
     return taken ? BH_OK : BH_E_UNSUPPORTED;       // only where the halo-tiled 3x3 kernel applies: the caller checks
 }
 
+int bh_conv_dgrad_colsum(const float* gy, const float* w, float* gx, const bh_conv_desc* d, double* sums, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!gy || !w || !gx || !sums) return BH_E_BADARG;
+    int taken = 0;
+    rc = bh_conv3x3_try(gy, w, nullptr, gx, d, 1, 0, bh_stream(stream), &taken, sums, 1, nullptr, 0, nullptr);
+    if (rc) return rc;
+    return taken ? BH_OK : BH_E_UNSUPPORTED;
+}
+
+__global__ void bias_grad_from_sums_kernel(const double* __restrict__ sums, float* __restrict__ gbias, int groups, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double t = 0;
+    for (int g = 0; g < groups; ++g) t += bn_sum_total(sums, groups, g, C, c, 0);
+    gbias[c] += (float)t;
+}
+
+int bh_bias_grad_from_sums(const double* sums, float* gbias, int groups, int C, void* stream) {
+    if (!sums || !gbias || groups < 1 || C < 1) return BH_E_BADARG;
+    hipLaunchKernelGGL(bias_grad_from_sums_kernel, dim3((C + 63) / 64), dim3(64), 0, bh_stream(stream), sums, gbias, groups, C);
+    BH_LAUNCH_CHECK();
+    return BH_OK;
+}
+
 int bh_conv_dgrad(const float* gy, const float* w, float* gx, const bh_conv_desc* d, int accumulate, void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;

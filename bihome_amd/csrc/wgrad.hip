@@ -29,6 +29,7 @@ struct WgradArgs {
     int rows_per_block;
     int xcd_map;             // XCD-aware (tile, tap, split) order, see wgrad_kernel
     int noflush;             // ablation (bh_debug_force_tile(-7, 1)): skip the atomic flush
+    float* partials;         // deterministic mode (wgrad_s1): per-workgroup partial tiles go here instead of into atomics
 };
 
 #define WBK 32
@@ -334,6 +335,17 @@ __global__ void __launch_bounds__(256) wgrad_s1_kernel(WgradArgs a) {
         __syncthreads();
     }
     if (a.noflush) return;
+    if (a.partials) {
+        // deterministic mode: partial[split][tap][tile][wave][r][lane] (1 KB per wave and accumulator register: coalesced);
+        // wgrad_s1_reduce_kernel adds the splits in index order
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float* const o = a.partials + ((((size_t)blockIdx.z * a.T + (t0 + j)) * gridDim.x + blockIdx.x) * 4 + wave) * 1024 + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r * 64] = acc[j][r];
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         float* const o = a.Out + (long long)(p0 + wm * 32 + 4 * kh2) * a.sOp + (long long)(t0 + j) * a.sOt + q0 + wn * 32 + l31;
@@ -632,6 +644,25 @@ __global__ void __launch_bounds__(256) plane_sum_kernel(const float* __restrict_
     if (threadIdx.x == 0) atomicAdd(out, sm[0] + sm[1] + sm[2] + sm[3]);
 }
 
+// Second pass of the deterministic mode: Out[p][t][q] += sum over the pixel splits, in split order (fixed), of the partial
+// tiles written by wgrad_s1_kernel.  One thread per output element in partial-tile order (coalesced reads and, per
+// accumulator register, 128-byte coalesced writes).
+__global__ void __launch_bounds__(256) wgrad_s1_reduce_kernel(const float* __restrict__ partials, float* __restrict__ out, int nsplit,
+                                                              int T, int ntiles, int qtiles, long long sOp, long long sOt) {
+    const size_t per_split = (size_t)T * ntiles * 4096;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= per_split) return;
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += partials[(size_t)z * per_split + i];
+    const int lane = (int)(i & 63), r = (int)((i >> 6) & 15), wave = (int)((i >> 10) & 3);
+    const size_t tt = i >> 12;
+    const int tile = (int)(tt % ntiles), t = (int)(tt / ntiles);
+    const int p0 = (tile / qtiles) * 64, q0 = (tile % qtiles) * 64;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, kh2 = lane >> 5;
+    const int p = p0 + wm * 32 + 4 * kh2 + (r & 3) + 8 * (r >> 2), q = q0 + wn * 32 + l31;
+    out[(long long)p * sOp + (long long)t * sOt + q] += s;
+}
+
 BH_KNOB(g_wgrad_noflush, 0); BH_KNOB(g_wgrad_xcd_map, 0);          // stride-1 fast path: 0 off, 1 one tap per workgroup, 3 a kernel row of taps (bh_debug_force_tile(-16, n); 3 is faster
                                               // back to back on the 64-channel layers - 97 vs 105 us - and 3 % slower in the training step)
 BH_KNOB(g_wgrad_s3_target, 768);  // workgroups per launch of the three-tap variant (bh_debug_force_tile(-19, n))   // (XCD-aware order: measured 7-18 % slower)
@@ -668,7 +699,34 @@ int bh_conv_bias_grad(const float* gy, float* gbias, const bh_conv_desc* d, void
     return BH_OK;
 }
 
+static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gbias, const bh_conv_desc* d, void* stream,
+                           float* ws, long long ws_bytes, long long* ws_need);
+
 int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, const bh_conv_desc* d, void* stream) {
+    return conv_wgrad_impl(x, gy, gw, gbias, d, stream, nullptr, 0, nullptr);
+}
+
+long long bh_conv_wgrad_det_bytes(const bh_conv_desc* d) {
+    long long need = 0;
+    float* p = reinterpret_cast<float*>(static_cast<uintptr_t>(256));
+    BhQuery q; q.name[0] = 0; q.len = 0;
+    BhQuery* saved = bh_query_ctx;
+    bh_query_ctx = &q;                      // dry run: nothing is launched
+    const int rc = conv_wgrad_impl(p, p, p, nullptr, d, nullptr, p, 0, &need);
+    bh_query_ctx = saved;
+    return rc == BH_OK ? need : 0;
+}
+
+int bh_conv_wgrad_det(const float* x, const float* gy, float* gw, float* gbias, const bh_conv_desc* d, float* ws, long long ws_bytes,
+                      void* stream) {
+    if (!ws) return BH_E_BADARG;
+    return conv_wgrad_impl(x, gy, gw, gbias, d, stream, ws, ws_bytes, nullptr);
+}
+
+}  // extern "C"
+
+static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gbias, const bh_conv_desc* d, void* stream,
+                           float* ws, long long ws_bytes, long long* ws_need) {
     if (!d || !x || !gy || !gw) return BH_E_BADARG;
     if (d->out_nchw && (d->Co > 4 || d->transposed)) return BH_E_UNSUPPORTED;
     hipStream_t s = bh_stream(stream);
@@ -723,6 +781,7 @@ int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, cons
         a.xcd_map = 1;
     }
     dim3 grid(tiles, ty, split);
+    if (ws && small) return BH_E_UNSUPPORTED;
     if (small && vec && !a.p_nchw && (a.T == 9 || a.T == 4) && d->precision == 0) {
         // taps-fused: one launch dimension less, pixel ranges sized for ~2048 wave-level work items
         const int groups_y = (a.T == 9) ? 3 : 2;        // 3 taps (T = 9) or 2 taps (T = 4) per wave: 48 / 32 accumulator regs
@@ -751,11 +810,26 @@ int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, cons
         if (sp < 1) sp = 1;
         a.rows_per_block = (((a.M + sp - 1) / sp) + WBK - 1) / WBK * WBK;
         sp = (a.M + a.rows_per_block - 1) / a.rows_per_block;
-        if (bh_query("wgrad_s1_kernel<%d,%s>", nt, d->precision == 1 ? "true" : "false")) return BH_OK;
+        if (ws) {                           // deterministic mode: partial tiles + fixed-order second pass
+            const long long need = (long long)sp * a.T * tiles * 4096 * 4;
+            if (ws_need) *ws_need = need;
+            if (!ws_need && ws_bytes < need) return BH_E_BADARG;
+            a.partials = ws;
+        }
+        if (bh_query(ws ? "wgrad_s1_kernel<%d,%s>+wgrad_s1_reduce_kernel" : "wgrad_s1_kernel<%d,%s>", nt, d->precision == 1 ? "true" : "false"))
+            return BH_OK;
         if (d->precision == 1 && nt == 3) hipLaunchKernelGGL((wgrad_s1_kernel<3, true>), dim3(tiles, gy, sp), dim3(256), 0, s, a);
         else if (d->precision == 1) hipLaunchKernelGGL((wgrad_s1_kernel<1, true>), dim3(tiles, gy, sp), dim3(256), 0, s, a);
         else if (nt == 3) hipLaunchKernelGGL((wgrad_s1_kernel<3, false>), dim3(tiles, gy, sp), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((wgrad_s1_kernel<1, false>), dim3(tiles, gy, sp), dim3(256), 0, s, a);
+        if (ws) {
+            BH_LAUNCH_CHECK();
+            const long long per_split = (long long)a.T * tiles * 4096;
+            hipLaunchKernelGGL(wgrad_s1_reduce_kernel, dim3((unsigned)((per_split + 255) / 256)), dim3(256), 0, s, ws, gw, sp, a.T, tiles,
+                               a.Nq >> 6, a.sOp, a.sOt);
+        }
+    } else if (ws) {
+        return BH_E_UNSUPPORTED;            // deterministic mode exists for the stride-1 fast path only
     } else {
         if (bh_query("wgrad_kernel<%s,%s>", vec ? "true" : "false", (vec && d->precision == 1) ? "true" : "false")) return BH_OK;
         if (vec && d->precision == 1) hipLaunchKernelGGL((wgrad_kernel<true, true>), grid, dim3(256), 0, s, a);
@@ -766,5 +840,3 @@ int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, cons
     if (gbias) return bh_conv_bias_grad(gy, gbias, d, stream);
     return BH_OK;
 }
-
-}  // extern "C"

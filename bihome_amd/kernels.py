@@ -376,8 +376,16 @@ def dgrad_bn_reduce_ok(d):
     return conv_variant(d, "dgrad").startswith("conv3x3_halo_kernel")
 
 
-def conv_dgrad(gy, w, d, out=None, bn_reduce=None, wkey=None, wpacked=None):
-    """wpacked: the dgrad buffer of WeightPacker for this conv.
+def bias_grad_from_sums(sums, gbias, groups, C):
+    """gbias[C] += column sums accumulated by conv_dgrad(..., colsum=sums)."""
+    _chk(sums, torch.float64); _chk(gbias)
+    check(lib.bh_bias_grad_from_sums(_p(sums), _p(gbias), groups, C, _stream()), "bh_bias_grad_from_sums")
+
+
+def conv_dgrad(gy, w, d, out=None, bn_reduce=None, wkey=None, wpacked=None, colsum=None):
+    """colsum (only when dgrad_bn_reduce_ok(d), no `out`, no bn_reduce): zeroed bn_stats_buffer(1, Ci) - the per-channel sums
+    of the gradient written are accumulated in the epilogue (bias gradient of the producer of this conv's input).
+    wpacked: the dgrad buffer of WeightPacker for this conv.
     wkey: (id(param), param._version) of the parameter `w` was derived from (cache key of derived weight tables).
     bn_reduce (only when dgrad_bn_reduce_ok(d)): dict(z, y, stats, gamma, beta, eps, relu, sums, groups) of the
     BatchNorm whose output gradient this call completes - its backward sums are accumulated into `sums` (zeroed
@@ -385,6 +393,13 @@ def conv_dgrad(gy, w, d, out=None, bn_reduce=None, wkey=None, wpacked=None):
     _chk(gy); _chk(w)
     if wpacked is not None:
         d, w = _with_layout(d, 1), wpacked
+    if colsum is not None:
+        assert out is None and bn_reduce is None
+        _chk(colsum, torch.float64)
+        out = torch.empty((d.N, d.Hi, d.Wi, d.Ci), dtype=torch.float32, device=gy.device)
+        with _Timed(_conv_variant(d, "dgrad"), conv_flops(d), 4.0 * (gy.numel() + out.numel() + w.numel())):
+            check(lib.bh_conv_dgrad_colsum(_p(gy), _p(w), _p(out), ctypes.byref(d), _p(colsum), _stream()), "bh_conv_dgrad_colsum")
+        return out
     if bn_reduce is not None:
         acc = out is not None
         if out is None:
@@ -420,10 +435,26 @@ def conv_dgrad(gy, w, d, out=None, bn_reduce=None, wkey=None, wpacked=None):
     return out
 
 
-def conv_wgrad(x, gy, gw, gbias, d):
+def wgrad_det_bytes(d):
+    """Workspace bytes of the deterministic weight-gradient form for this conv (0: not available for the shape)."""
+    return int(lib.bh_conv_wgrad_det_bytes(ctypes.byref(d)))
+
+
+def conv_wgrad(x, gy, gw, gbias, d, det_ws=None):
     """gw += x^T gy (split-K MFMA kernel, fp32 atomics); gbias += column sums of gy (separate launch, own timing entry so
-    that the wgrad entry is the kernel rocprofv3 lists under the same name)."""
+    that the wgrad entry is the kernel rocprofv3 lists under the same name).
+    det_ws: float32 workspace of >= wgrad_det_bytes(d) bytes - the split-K partial tiles are stored there and added in a
+    fixed order by a second launch (bitwise repeatable, no atomics); ignored where the shape has no deterministic form."""
     _chk(x); _chk(gy); _chk(gw); _chk(gbias)
+    if det_ws is not None:
+        need = wgrad_det_bytes(d)
+        if 0 < need <= det_ws.numel() * 4:
+            with _Timed((conv_variant(d, "wgrad") + "+det" if TIMING is not None else ""), conv_flops(d), 4.0 * (x.numel() + gy.numel() + gw.numel())):
+                check(lib.bh_conv_wgrad_det(_p(x), _p(gy), _p(gw), None, ctypes.byref(d), _p(det_ws), det_ws.numel() * 4, _stream()),
+                      "bh_conv_wgrad_det")
+            if gbias is not None:
+                check(lib.bh_conv_bias_grad(_p(gy), _p(gbias), ctypes.byref(d), _stream()), "bh_conv_bias_grad")
+            return
     with _Timed((conv_variant(d, "wgrad") if TIMING is not None else "") + (" N%d %dx%d C%d->%d k%d s%d%s" % (d.N, d.Hi, d.Wi, d.Ci, d.Co, d.kh, d.stride, " T" if d.transposed else "") if TIMING_DETAIL else ""), conv_flops(d), 4.0 * (x.numel() + gy.numel() + gw.numel())):
         check(lib.bh_conv_wgrad(_p(x), _p(gy), _p(gw), None, ctypes.byref(d), _stream()), "bh_conv_wgrad")
     if gbias is not None:

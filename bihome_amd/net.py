@@ -361,7 +361,7 @@ def side_stream(device):
     return _SIDE_STREAMS[key]
 
 
-def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=None, wgrad_stream=None):
+def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=None, wgrad_stream=None, det_ws=None):
     """Adjoint of run_forward. Parameter gradients are accumulated (+=) into each parameter's `.grad`
     tensor (which must already exist, see FlatGrads). Returns the input gradient or None.
     wgrad_stream: a second HIP stream for the conv weight-gradient launches.  The backward chain on the main stream is
@@ -402,7 +402,23 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
             if (op.kind == "conv" and b is not None and prog.ops[b].kind == "bn" and last_consumer.get(op.src) == j
                     and j in ctx.descs and K.dgrad_bn_reduce_ok(ctx.descs[j]) and ctx.descs[j].N % ctx.groups == 0):
                 fuse_bn[j] = b
+    # A 3x3 conv that is the ONLY consumer of a biased (transposed) conv's output: the column sums of its input gradient
+    # are that layer's bias gradient - accumulated in the dgrad epilogue instead of a streaming pass over the gradient
+    fuse_bias = {}                                        # conv op index -> producer op index
+    if want_wgrad and os.environ.get("BIHOME_FUSE_BIAS_GRAD", "1") != "0":
+        producer = {op.dst: j for j, op in enumerate(prog.ops)}
+        for j, op in enumerate(prog.ops):
+            p = producer.get(op.src)
+            if (op.kind == "conv" and j not in fuse_bn and p is not None and prog.ops[p].kind == "conv" and consumed_by.get(op.src, 0) == 1
+                    and j in ctx.descs and p in ctx.descs and K.dgrad_bn_reduce_ok(ctx.descs[j])):
+                pm = prog.ops[p].mod
+                if pm.bias is not None and pm.bias.requires_grad and pm.weight.requires_grad and prog.ops[p].extra["weight_fn"] is None:
+                    fuse_bias[j] = p
     red_off, total = {}, 0
+    bias_off = {}
+    for j, p in fuse_bias.items():
+        bias_off[p] = total
+        total += K.bn_stats_doubles(1, ctx.descs[j].Ci)
     for b in fuse_bn.values():
         red_off[b] = total
         total += K.bn_stats_doubles(ctx.groups, prog.ops[b].mod.num_features)
@@ -422,8 +438,12 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
             if want_wgrad and m.weight.requires_grad and op.extra["weight_fn"] is None:
                 gw = m.weight.grad if m.weight.dim() == 2 else kview(m.weight.grad)
                 gb = m.bias.grad if (m.bias is not None and m.bias.requires_grad) else None
+                has_gb = gb is not None
+                if i in bias_off and has_gb:              # column sums already taken by the consumer's dgrad epilogue
+                    K.bias_grad_from_sums(red_arena[bias_off[i]:bias_off[i] + K.bn_stats_doubles(1, d.Co)], gb, 1, d.Co)
+                    gb = None
                 if wgrad_stream is None:
-                    K.conv_wgrad(x, g, gw, gb, d)
+                    K.conv_wgrad(x, g, gw, gb, d, det_ws=det_ws)
                 else:
                     ev = torch.cuda.Event()
                     ev.record(main)                                   # g is final here
@@ -433,7 +453,7 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
                         K.conv_wgrad(x, g, gw, gb, d)
                 if on_param_grad is not None:       # gradient of this layer is final: its bucket may leave
                     on_param_grad(m.weight)
-                    if gb is not None:
+                    if has_gb:
                         on_param_grad(m.bias)
             if need_src_grad:
                 red = None
@@ -445,7 +465,11 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
                                stats=ctx.stats[b], gamma=bm.weight, beta=bm.bias, eps=bm.eps, relu=bop.relu, sums=sums,
                                groups=ctx.groups)
                     bn_reduced[b] = sums
-                if op.src in grads:
+                if i in fuse_bias and op.src not in grads and red is None:
+                    p = fuse_bias[i]
+                    grads[op.src] = K.conv_dgrad(g, wk, d, wpacked=ctx.wpacked.get(i),
+                                                 colsum=red_arena[bias_off[p]:bias_off[p] + K.bn_stats_doubles(1, d.Ci)])
+                elif op.src in grads:
                     K.conv_dgrad(g, wk, d, out=grads[op.src], bn_reduce=red, wkey=ctx.wkeys[i], wpacked=ctx.wpacked.get(i))
                 else:
                     grads[op.src] = K.conv_dgrad(g, wk, d, bn_reduce=red, wkey=ctx.wkeys[i], wpacked=ctx.wpacked.get(i))
@@ -547,7 +571,7 @@ class NetFunction(torch.autograd.Function):
         if r.reducer is not None:
             r.reducer.wait_streams = [side] if side is not None else []
         gin = run_backward(r.prog, ctx.saved, g.contiguous(), want_wgrad=r.flat is not None, want_input_grad=ctx.want_x,
-                           on_param_grad=hook, wgrad_stream=side)
+                           on_param_grad=hook, wgrad_stream=side, det_ws=r.det_workspace(g.device) if side is None else None)
         ctx.saved = None
         return gin, None, None, None, None
 
@@ -573,6 +597,17 @@ class Runner:
         # fragment-ordered weight copies for the halo-tiled 3x3 kernel (csrc/conv3x3.hip PACKED; BIHOME_PACK_WEIGHTS=0: off)
         self.use_packer = os.environ.get("BIHOME_PACK_WEIGHTS", "1") != "0"
         self._packer = None
+        self.deterministic_wgrad = os.environ.get("BIHOME_DETERMINISTIC_WGRAD", "0") == "1"
+        self._det_ws = None
+
+    def det_workspace(self, device):
+        """BIHOME_DETERMINISTIC_WGRAD=1: one 40 MB workspace for the fixed-order split-K reduction of the 3x3 weight
+        gradients (every launch of the stride-1 fast path stores 2048 x 16 KB partial tiles)."""
+        if not self.deterministic_wgrad or self.flat is None:
+            return None
+        if self._det_ws is None or self._det_ws.device != device:
+            self._det_ws = torch.empty(10 << 20, dtype=torch.float32, device=device)
+        return self._det_ws
 
     def packer_for(self, device):
         if not self.use_packer:

@@ -202,12 +202,26 @@ typedef struct bh_bn_reduce {
  * Co % 32 == 0, Ci % 32 == 0, fp32 or bf16 operands); BH_E_UNSUPPORTED otherwise and nothing is written. */
 int bh_conv_dgrad_bnreduce(const float* gy, const float* w, float* gx, const bh_conv_desc* d, int accumulate,
                            const bh_bn_reduce* bnr, double* sums, int groups, void* stream);
+/* bh_conv_dgrad (no accumulate) that also adds, in its epilogue, the per-channel sums of the gradient it writes into
+ * `sums` (bh_bn_stats_doubles(1, Ci) doubles, caller-zeroed; entry (0, c, 0) = column sum).  The column sums of a conv's
+ * input gradient ARE the bias gradient of the layer that produced that input (ConvTranspose2d + bias in the decoder
+ * units, src/backbones/utils.py:60-82): bh_bias_grad_from_sums adds them to gbias[C] and the separate streaming pass of
+ * bh_conv_bias_grad over that gradient disappears.  Only where the halo-tiled 3x3 kernel applies (else BH_E_UNSUPPORTED). */
+int bh_conv_dgrad_colsum(const float* gy, const float* w, float* gx, const bh_conv_desc* d, double* sums, void* stream);
+int bh_bias_grad_from_sums(const double* sums, float* gbias, int groups, int C, void* stream);
 /* Second half of the two-step dgrad of the extractor's 7x7/2 stem on a grayscale (Ci = 1) or RGB (Ci = 3, in_nchw) patch:
  * Tm[N*Ho*Wo][ldT] = gy x w^T (one 1x1 bh_conv_fwd launch; column = tap*Ci + c, ldT >= 49*Ci padded)
  * -> gx[N,Ci,Hi,Wi] = col2im(Tm). */
 int bh_col2im_c1(const float* Tm, float* gx, const bh_conv_desc* d, int ldT, void* stream);
 /* gw += x^T * gy ; gbias += sum gy  (accumulated: caller zeroes; gbias NULL ok) */
 int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, const bh_conv_desc* d, void* stream);
+/* Deterministic form of bh_conv_wgrad for the stride-1 "same" 3x3 / 5x5 / 7x7 layers its fast path takes (Co, Ci multiples
+ * of 64, power-of-two maps): the split-K workgroups store their partial tiles into ws (bh_conv_wgrad_det_bytes(d) bytes, 0 =
+ * shape not supported) and a second launch adds them in a fixed order - bitwise repeatable gw, no fp32 atomics.
+ * BH_E_UNSUPPORTED for other shapes (use bh_conv_wgrad). */
+long long bh_conv_wgrad_det_bytes(const bh_conv_desc* d);
+int bh_conv_wgrad_det(const float* x, const float* gy, float* gw, float* gbias, const bh_conv_desc* d, float* ws, long long ws_bytes,
+                      void* stream);
 /* the bias part alone: gbias[Co] += sum of gy over all output pixels (what bh_conv_wgrad does when gbias != NULL) */
 int bh_conv_bias_grad(const float* gy, float* gbias, const bh_conv_desc* d, void* stream);
 

@@ -14,7 +14,7 @@ def header_symbols():
     text = open(os.path.join(ROOT, "include", "bihome.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     text = re.sub(r"#ifdef BH_TUNING.*?#endif", "", text, flags=re.S)      # the ablation hook exists in the -DBH_TUNING build only
-    return sorted(set(re.findall(r"\bint\s+(bh_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\bint\s+(bh_\w+)\s*\(", text)))      # (status-returning entry points; bh_conv_wgrad_det_bytes returns a size)
 
 
 def test_library_exports_every_declared_symbol():

@@ -523,3 +523,34 @@ def test_conv3x3_packed_weights_match_lds_slab_path(K, N, H, Ci, Co, prec):
     assert pf.data_ptr() == p0
     y2 = K.conv_fwd(x, wk, None, d, wpacked=pf)
     assert torch.equal(y2, K.conv_fwd(x, wk, None, d))
+
+
+@pytest.mark.parametrize("N,H,Ci,Co", [(128, 32, 64, 64), (16, 16, 128, 128), (8, 8, 256, 256)])
+def test_wgrad_deterministic_mode_is_bitwise_repeatable(K, N, H, Ci, Co):
+    """bh_conv_wgrad_det: split-K partial tiles + a fixed-order second pass instead of fp32 atomics.  Two runs give
+    bit-identical weight gradients (the default atomics path does not), the values match torch float64, and the result
+    accumulates onto what gw already holds."""
+    g = torch.Generator().manual_seed(N + H)
+    x = torch.randn(N, H, H, Ci, generator=g).cuda()
+    gy = torch.randn(N, H, H, Co, generator=g).cuda()
+    d = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1)
+    need = K.wgrad_det_bytes(d)
+    assert 0 < need <= 40 << 20
+    ws = torch.empty(need // 4, dtype=torch.float32, device="cuda")
+    runs = []
+    for _ in range(3):
+        gw = torch.zeros(Co, 3, 3, Ci, device="cuda")
+        K.conv_wgrad(x, gy, gw, None, d, det_ws=ws)
+        runs.append(gw.clone())
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+    if N * H * H <= 8192:
+        ref = torch.nn.grad.conv2d_weight(x.double().cpu().permute(0, 3, 1, 2), (Co, Ci, 3, 3), gy.double().cpu().permute(0, 3, 1, 2),
+                                          stride=1, padding=1).permute(0, 2, 3, 1)
+        close(runs[0].cpu(), ref, 2e-5)
+    a = torch.zeros(Co, 3, 3, Ci, device="cuda")
+    K.conv_wgrad(x, gy, a, None, d)                          # default (atomics) path: same values up to summation order
+    close(runs[0].cpu(), a.cpu(), 2e-5)
+    gw2 = runs[0].clone()
+    K.conv_wgrad(x, gy, gw2, None, d, det_ws=ws)             # accumulates
+    close(gw2.cpu(), 2 * runs[0].cpu(), 1e-6)
+    assert K.wgrad_det_bytes(K.conv_desc(8, 64, 64, 32, 32, 3, 1, 1)) == 0      # small-channel layers: no deterministic form
