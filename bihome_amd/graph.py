@@ -36,8 +36,12 @@ class GraphedStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = train_step(model, dict(self.static), opt, None, clip=clip, loss_fn=loss_fn)
-        # host-side BatchNorm call counters advance once per replay by what one captured step added
+        # host-side BatchNorm call counters advance once per replay by what one captured step added; the capture itself
+        # recorded the step without running it, so its own increment is taken back
         self._bn_inc = [getattr(m, "_bh_pending_batches", 0) - b for m, b in zip(self._bns, before)]
+        for m, b in zip(self._bns, before):
+            if hasattr(m, "_bh_pending_batches"):
+                m._bh_pending_batches = b
         self.warmup_steps = warmup                         # optimizer steps already taken on the example batch (the capture records, it does not run)
 
     def __call__(self, data):

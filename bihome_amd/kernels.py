@@ -328,7 +328,7 @@ def conv_fwd(x, w, bias, d, bn_sums=None, groups=1, res=None, relu=False, wpacke
     _chk(x); _chk(w); _chk(bias); _chk(res)
     y = torch.empty(conv_out_shape(d), dtype=torch.float32, device=x.device)
     if wpacked is not None:
-        d, w = _with_layout(d, 1), wpacked
+        d, w = (getattr(d, "bh_packed", None) or _with_layout(d, 1)), wpacked
     with _Timed(_conv_variant(d, "fwd", bn_groups=groups if bn_sums is not None else 0), conv_flops(d),
                 4.0 * (x.numel() + y.numel() + w.numel())):
         if res is not None or relu:
@@ -392,7 +392,7 @@ def conv_dgrad(gy, w, d, out=None, bn_reduce=None, wkey=None, wpacked=None, cols
     bn_stats_buffer) in the conv epilogue; pass them to bn_bwd(..., sums_ready=sums)."""
     _chk(gy); _chk(w)
     if wpacked is not None:
-        d, w = _with_layout(d, 1), wpacked
+        d, w = (getattr(d, "bh_packed", None) or _with_layout(d, 1)), wpacked
     if colsum is not None:
         assert out is None and bn_reduce is None
         _chk(colsum, torch.float64)

@@ -185,7 +185,27 @@ class Ctx:
         self.slots, self.stats, self.descs, self.weights, self.wkeys, self.wpacked = {}, {}, {}, {}, {}, {}
 
 
+_GEOM_CACHE = {}
+
+
 def _conv_geometry(mod, x_shape, in_nchw, out_nchw, precision=0):
+    """Conv descriptor for `mod` on an input of `x_shape`, memoised together with what the library reports for it (halo
+    3x3 kernel eligible for packed weights / for the fused BatchNorm reduce) and its packed-layout twin: building the
+    ctypes struct and asking bh_conv_variant costs ~20 us of host time per launch otherwise, which is what bounds the
+    shorter models (ResNet-34 regressor: 13.1 -> 15-17 ms/step when it was done per call)."""
+    key = (id(mod), tuple(x_shape), bool(in_nchw), bool(out_nchw), int(precision))
+    hit = _GEOM_CACHE.get(key)
+    if hit is not None and hit[0] is mod:
+        return hit[1]
+    d = _conv_geometry_uncached(mod, x_shape, in_nchw, out_nchw, precision)
+    d.bh_packs = bool(isinstance(mod, nn.Conv2d) and K.packs_3x3(d))
+    d.bh_reduce_ok = bool(isinstance(mod, nn.Conv2d) and K.dgrad_bn_reduce_ok(d))
+    d.bh_packed = K._with_layout(d, 1) if d.bh_packs else None
+    _GEOM_CACHE[key] = (mod, d)
+    return d
+
+
+def _conv_geometry_uncached(mod, x_shape, in_nchw, out_nchw, precision=0):
     if in_nchw:
         N, Ci, Hi, Wi = x_shape
     else:
@@ -300,7 +320,7 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, p
             w = e["weight_fn"](op.mod.weight) if e["weight_fn"] else op.mod.weight
             wk = kview(w)
             pk = None
-            if packer is not None and e["weight_fn"] is None and id(op.mod.weight) in packer.entries and K.packs_3x3(d):
+            if packer is not None and e["weight_fn"] is None and d.bh_packs and id(op.mod.weight) in packer.entries:
                 pk = packer.entries[id(op.mod.weight)]
             if i in fused_stats and d.N % groups == 0:
                 b = fused_stats[i]
@@ -400,7 +420,7 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
         for j, op in enumerate(prog.ops):
             b = producer.get(op.src)
             if (op.kind == "conv" and b is not None and prog.ops[b].kind == "bn" and last_consumer.get(op.src) == j
-                    and j in ctx.descs and K.dgrad_bn_reduce_ok(ctx.descs[j]) and ctx.descs[j].N % ctx.groups == 0):
+                    and j in ctx.descs and ctx.descs[j].bh_reduce_ok and ctx.descs[j].N % ctx.groups == 0):
                 fuse_bn[j] = b
     # A 3x3 conv that is the ONLY consumer of a biased (transposed) conv's output: the column sums of its input gradient
     # are that layer's bias gradient - accumulated in the dgrad epilogue instead of a streaming pass over the gradient
@@ -410,7 +430,7 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
         for j, op in enumerate(prog.ops):
             p = producer.get(op.src)
             if (op.kind == "conv" and j not in fuse_bn and p is not None and prog.ops[p].kind == "conv" and consumed_by.get(op.src, 0) == 1
-                    and j in ctx.descs and p in ctx.descs and K.dgrad_bn_reduce_ok(ctx.descs[j])):
+                    and j in ctx.descs and p in ctx.descs and ctx.descs[j].bh_reduce_ok):
                 pm = prog.ops[p].mod
                 if pm.bias is not None and pm.bias.requires_grad and pm.weight.requires_grad and prog.ops[p].extra["weight_fn"] is None:
                     fuse_bias[j] = p
