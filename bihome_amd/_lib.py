@@ -39,15 +39,19 @@ SIGNATURES = {
     "bh_h4pt_fwd": [P, c_int, c_float, c_float, P, P, P],
     "bh_h4pt_bwd": [P, P, P, c_int, c_float, c_float, P, P],
     "bh_dlt_fwd": [P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P],
-    "bh_dlt_bwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P],
+    "bh_dlt_bwd": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P],
+    "bh_dsac_scores_fwd": [P, c_int, c_int, P, P],
+    "bh_dsac_scores_bwd": [P, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P],
+    "bh_scale_samples_fwd": [P, P, c_int, c_int64, c_int, P, P],
+    "bh_scale_samples_bwd": [P, P, P, c_int, c_int64, c_int, P, P, P],
     "bh_dsac_score": [P, P, c_int, c_int, c_int, c_int, P, P, P],
     "bh_warp_fwd": [P, P, c_int, c_int, c_int, c_int, c_int, P, P, P],
     "bh_warp_bwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P],
     "bh_triplet_l1_fwd": [P] * 8 + [c_int, c_int, c_int, P, P, P, P],
     "bh_bihome_loss_fwd": [P, P, P, c_int, c_float, P, P],
     "bh_bihome_loss_bwd": [P] * 14 + [c_int, c_int, c_int, c_float] + [P] * 6 + [P],
-    "bh_oneline_loss_fwd": [P, P, P, P, P, c_int, c_int, c_int, c_float, P, P, P, P],
-    "bh_oneline_loss_bwd": [P, P, P, P, P, P, P, c_int, c_int, c_int, P, P, P],
+    "bh_oneline_loss_fwd": [P, P, P, P, P, c_int, c_int, c_int, c_float, c_int, P, P, P, P, P, P],
+    "bh_oneline_loss_bwd": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P],
     "bh_conv3x3_pack": [P, c_int, P],
     "bh_conv_variant": [POINTER(BhConvDesc), c_int, c_int, c_int, c_char_p, c_int],
     "bh_conv_fwd": [P, P, P, P, POINTER(BhConvDesc), P],

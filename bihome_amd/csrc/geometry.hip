@@ -253,7 +253,8 @@ __global__ void __launch_bounds__(64) dlt_fwd_kernel(const float* __restrict__ p
 
 __global__ void __launch_bounds__(64) dlt_bwd_kernel(const float* __restrict__ pf, const int64_t* __restrict__ choice,
                                                      const double* __restrict__ eig, const float* __restrict__ g_delta,
-                                                     int P, int h, int w, float* __restrict__ g_pf) {
+                                                     const double* __restrict__ g_Hd, int P, int h, int w,
+                                                     float* __restrict__ g_pf) {
     __shared__ double Gs[81];
     __shared__ double sc[8];   // g(1/s2), g m2x, g m2y
     const int b = blockIdx.x, j = blockIdx.y, n = gridDim.y, lane = threadIdx.x;
@@ -294,6 +295,9 @@ __global__ void __launch_bounds__(64) dlt_bwd_kernel(const float* __restrict__ p
                 gHn[3] += gy * x; gHn[4] += gy * y; gHn[5] += gy;
             }
         }
+        // gradient that reaches the homography itself (hypothesis scoring, ransac_utils.py:76-128)
+        if (g_Hd)
+            for (int i = 0; i < 9; ++i) gHn[i] += g_Hd[(size_t)prob * 9 + i];
         // Hn = Hu / (Hu22 + eps)
         double gHu[9], dot = 0;
         for (int i = 0; i < 9; ++i) { gHu[i] = gHn[i] * inv; dot += gHn[i] * Hu[i]; }
@@ -399,6 +403,67 @@ __global__ void __launch_bounds__(256) dsac_score_kernel(const float* __restrict
     if (threadIdx.x == 0) err[b * n + j] = (float)(part[0] + part[1] + part[2] + part[3]);
 }
 
+// scores = softmax(-err) over the hypotheses of a sample (ransac_utils.py:126)
+__global__ void dsac_softmax_kernel(const float* __restrict__ err, int B, int n, float* __restrict__ scores) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float mn = err[b * n];
+    for (int j = 1; j < n; ++j) mn = fminf(mn, err[b * n + j]);
+    float z = 0.f;
+    for (int j = 0; j < n; ++j) z += expf(-(err[b * n + j] - mn));
+    for (int j = 0; j < n; ++j) scores[b * n + j] = expf(-(err[b * n + j] - mn)) / z;
+}
+
+// g_scores -> g_err:  s = softmax(-e)  =>  de_j = -s_j (g_j - sum_k g_k s_k)
+__global__ void dsac_softmax_bwd_kernel(const float* __restrict__ scores, const float* __restrict__ g_scores, int B, int n,
+                                        float* __restrict__ g_err) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float dot = 0.f;
+    for (int j = 0; j < n; ++j) dot += g_scores[b * n + j] * scores[b * n + j];
+    for (int j = 0; j < n; ++j) g_err[b * n + j] = -scores[b * n + j] * (g_scores[b * n + j] - dot);
+}
+
+// adjoint of dsac_score_kernel: g_err[B,n] -> g_Hd[B*n,9] (double, overwritten) and g_pf[B,2,h,w] += (atomics: the n
+// hypotheses of a sample and the DLT adjoint write the same field).  grid (B, n), block 256.
+__global__ void __launch_bounds__(256) dsac_score_bwd_kernel(const float* __restrict__ pf, const float* __restrict__ Hd,
+                                                             const float* __restrict__ g_err, int h, int w,
+                                                             double* __restrict__ g_Hd, float* __restrict__ g_pf) {
+    __shared__ double part[4][9];
+    const int b = blockIdx.x, j = blockIdx.y, n = gridDim.y;
+    const float* Hm = Hd + (size_t)(b * n + j) * 9;
+    const float H0 = Hm[0], H1 = Hm[1], H2 = Hm[2], H3 = Hm[3], H4 = Hm[4], H5 = Hm[5], H6 = Hm[6], H7 = Hm[7], H8 = Hm[8];
+    const float ge = g_err[b * n + j];
+    const float* pfx = pf + (size_t)b * 2 * h * w;
+    const float* pfy = pfx + (size_t)h * w;
+    float* gx = g_pf + (size_t)b * 2 * h * w;
+    float* gy = gx + (size_t)h * w;
+    double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < h * w; i += 256) {
+        const float x = (float)(i % w), y = (float)(i / w);
+        const float qx = H0 * x + H1 * y + H2, qy = H3 * x + H4 * y + H5, qz = H6 * x + H7 * y + H8;
+        const bool ok = fabsf(qz) > 1e-8f;
+        const float sc = ok ? 1.0f / qz : 1.0f;
+        const float tx = qx * sc, ty = qy * sc;
+        const float rx = tx - (x + pfx[i]), ry = ty - (y + pfy[i]);
+        const float gtx = ge * (float)((rx > 0.f) - (rx < 0.f)), gty = ge * (float)((ry > 0.f) - (ry < 0.f));   // d|r| = sign(r), 0 at 0
+        if (gtx != 0.f) atomicAdd(gx + i, -gtx);
+        if (gty != 0.f) atomicAdd(gy + i, -gty);
+        const double gqx = (double)(gtx * sc), gqy = (double)(gty * sc);
+        const double gqz = ok ? -(double)(gtx * tx + gty * ty) * (double)sc : 0.0;
+        s[0] += gqx * x; s[1] += gqx * y; s[2] += gqx;
+        s[3] += gqy * x; s[4] += gqy * y; s[5] += gqy;
+        s[6] += gqz * x; s[7] += gqz * y; s[8] += gqz;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s[k] = wave_sum(s[k]);
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 9; ++k) part[threadIdx.x >> 6][k] = s[k];
+    __syncthreads();
+    if (threadIdx.x < 9)
+        g_Hd[(size_t)(b * n + j) * 9 + threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+}
+
 __global__ void dsac_best_kernel(const float* __restrict__ err, int B, int n, int64_t* __restrict__ best) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -443,12 +508,13 @@ int bh_dlt_fwd(const float* pf, const int64_t* choice, int B, int n, int P, int 
     return BH_OK;
 }
 
-int bh_dlt_bwd(const float* pf, const int64_t* choice, const double* eig, const float* g_delta, int B, int n, int P,
-               int h, int w, float* g_pf, void* stream) {
+int bh_dlt_bwd(const float* pf, const int64_t* choice, const double* eig, const float* g_delta, const double* g_Hdlt, int B,
+               int n, int P, int h, int w, float* g_pf, void* stream) {
     if (!pf || !choice || !eig || !g_delta || !g_pf || B < 0 || n < 1 || P < 4) return BH_E_BADARG;
     if (P > 64 * DLT_MAXPTS) return BH_E_UNSUPPORTED;
     if (B == 0) return BH_OK;
-    hipLaunchKernelGGL(dlt_bwd_kernel, dim3(B, n), dim3(64), 0, bh_stream(stream), pf, choice, eig, g_delta, P, h, w, g_pf);
+    hipLaunchKernelGGL(dlt_bwd_kernel, dim3(B, n), dim3(64), 0, bh_stream(stream), pf, choice, eig, g_delta, g_Hdlt, P, h, w,
+                       g_pf);
     BH_LAUNCH_CHECK();
     return BH_OK;
 }
@@ -463,6 +529,25 @@ int bh_dsac_score(const float* pf, const float* Hdlt, int B, int n, int h, int w
         hipLaunchKernelGGL(dsac_best_kernel, dim3((B + 63) / 64), dim3(64), 0, bh_stream(stream), err, B, n, best);
         BH_LAUNCH_CHECK();
     }
+    return BH_OK;
+}
+
+int bh_dsac_scores_fwd(const float* err, int B, int n, float* scores, void* stream) {
+    if (!err || !scores || B < 0 || n < 1) return BH_E_BADARG;
+    if (B == 0) return BH_OK;
+    hipLaunchKernelGGL(dsac_softmax_kernel, dim3((B + 63) / 64), dim3(64), 0, bh_stream(stream), err, B, n, scores);
+    BH_LAUNCH_CHECK();
+    return BH_OK;
+}
+
+int bh_dsac_scores_bwd(const float* pf, const float* Hdlt, const float* scores, const float* g_scores, int B, int n, int h,
+                       int w, float* g_err, double* g_Hdlt, float* g_pf, void* stream) {
+    if (!pf || !Hdlt || !scores || !g_scores || !g_err || !g_Hdlt || !g_pf || B < 0 || n < 1) return BH_E_BADARG;
+    if (B == 0) return BH_OK;
+    hipLaunchKernelGGL(dsac_softmax_bwd_kernel, dim3((B + 63) / 64), dim3(64), 0, bh_stream(stream), scores, g_scores, B, n, g_err);
+    BH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dsac_score_bwd_kernel, dim3(B, n), dim3(256), 0, bh_stream(stream), pf, Hdlt, g_err, h, w, g_Hdlt, g_pf);
+    BH_LAUNCH_CHECK();
     return BH_OK;
 }
 

@@ -157,10 +157,11 @@ __global__ void __launch_bounds__(256) triplet_bwd_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) oneline_fwd_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                           const float* __restrict__ f1w, const float* __restrict__ m1w,
-                                                          const float* __restrict__ m2, int hw, int C, float margin,
+                                                          const float* __restrict__ m2, int hw, int C, float margin, int rep,
                                                           float* __restrict__ T, double* __restrict__ numden) {
+    // rep: hypotheses per sample - f1 / f2 / m2 hold one entry per SAMPLE (index b / rep), f1w / m1w one per hypothesis
     __shared__ double part[4][2];
-    const int b = blockIdx.y;
+    const int b = blockIdx.y, bs = b / rep;
     const int LP = min(64, C / 4), PPW = 64 / LP;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane / LP, cl = lane % LP;
@@ -170,9 +171,9 @@ __global__ void __launch_bounds__(256) oneline_fwd_kernel(const float* __restric
         const int p = p0 + sub;
         float s1 = 0, s3 = 0;
         if (p < hw) {
-            const size_t base = ((size_t)b * hw + p) * C;
+            const size_t base = ((size_t)b * hw + p) * C, bases = ((size_t)bs * hw + p) * C;
             for (int c = cl * 4; c < C; c += LP * 4) {
-                const float4 a1 = ld4(f1 + base + c), a2 = ld4(f2 + base + c), a1w = ld4(f1w + base + c);
+                const float4 a1 = ld4(f1 + bases + c), a2 = ld4(f2 + bases + c), a1w = ld4(f1w + base + c);
                 s1 += l1_4(a1w, a2);
                 s3 += l1_4(a1, a2);
             }
@@ -182,7 +183,7 @@ __global__ void __launch_bounds__(256) oneline_fwd_kernel(const float* __restric
             const size_t q = (size_t)b * hw + p;
             const float t = s1 - s3 + margin;
             T[q] = t;
-            const float w = m1w[q] * (m2 ? m2[q] : 1.0f);
+            const float w = m1w[q] * (m2 ? m2[(size_t)bs * hw + p] : 1.0f);
             a_n += (double)(w * fmaxf(t, 0.0f)); a_d += (double)w;
         }
     }
@@ -193,10 +194,16 @@ __global__ void __launch_bounds__(256) oneline_fwd_kernel(const float* __restric
         atomicAdd(numden + (size_t)b * 2 + threadIdx.x, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
-__global__ void __launch_bounds__(256) oneline_loss_kernel(const double* __restrict__ numden, int B, float* __restrict__ loss) {
+__global__ void __launch_bounds__(256) oneline_loss_kernel(const double* __restrict__ numden, int B, const float* __restrict__ sample_w,
+                                                           float* __restrict__ per_sample, float* __restrict__ loss) {
+    // sample_w (NULL = 1): the DSAC score of the hypothesis (PerceptualHead.py:505-511); per_sample (NULL ok): unweighted value
     __shared__ double part[4];
     double l = 0;
-    for (int b = threadIdx.x; b < B; b += 256) l += (double)((float)numden[b * 2] / fmaxf((float)numden[b * 2 + 1], 1.0f));
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float v = (float)numden[b * 2] / fmaxf((float)numden[b * 2 + 1], 1.0f);
+        if (per_sample) per_sample[b] = v;
+        l += (double)(sample_w ? sample_w[b] * v : v);
+    }
     l = wave_sum(l);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = l;
     __syncthreads();
@@ -206,10 +213,11 @@ __global__ void __launch_bounds__(256) oneline_loss_kernel(const double* __restr
 __global__ void __launch_bounds__(256) oneline_bwd_kernel(const float* __restrict__ g_loss, const float* __restrict__ f2,
                                                           const float* __restrict__ f1w, const float* __restrict__ m1w,
                                                           const float* __restrict__ m2, const float* __restrict__ T,
-                                                          const double* __restrict__ numden, int hw, int C,
+                                                          const double* __restrict__ numden, int hw, int C, int rep,
+                                                          const float* __restrict__ sample_w,
                                                           float* __restrict__ g_f1w, float* __restrict__ g_m1w) {
-    const int b = blockIdx.y;
-    const float g = g_loss[0];
+    const int b = blockIdx.y, bs = b / rep;
+    const float g = g_loss[0] * (sample_w ? sample_w[b] : 1.0f);
     const float N = (float)numden[b * 2], D = (float)numden[b * 2 + 1];
     const float den = fmaxf(D, 1.0f);
     const float dd = (D > 1.0f) ? -N / (den * den) : 0.0f;
@@ -221,11 +229,11 @@ __global__ void __launch_bounds__(256) oneline_bwd_kernel(const float* __restric
         const int p = p0 + sub;
         if (p >= hw) continue;
         const size_t q = (size_t)b * hw + p;
-        const float mm2 = m2 ? m2[q] : 1.0f, t = T[q];
+        const float mm2 = m2 ? m2[(size_t)bs * hw + p] : 1.0f, t = T[q];
         const float k = (t > 0.0f) ? g * m1w[q] * mm2 / den : 0.0f;         // hinge: no gradient where it is inactive
-        const size_t base = q * C;
+        const size_t base = q * C, bases = ((size_t)bs * hw + p) * C;
         for (int c = cl * 4; c < C; c += LP * 4) {
-            const float4 a2 = ld4(f2 + base + c), a1w = ld4(f1w + base + c);
+            const float4 a2 = ld4(f2 + bases + c), a1w = ld4(f1w + base + c);
             *reinterpret_cast<float4*>(g_f1w + base + c) =
                 make_float4(k * sgn(a1w.x - a2.x), k * sgn(a1w.y - a2.y), k * sgn(a1w.z - a2.z), k * sgn(a1w.w - a2.w));
         }
@@ -233,33 +241,67 @@ __global__ void __launch_bounds__(256) oneline_bwd_kernel(const float* __restric
     }
 }
 
+__global__ void __launch_bounds__(256) scale_samples_fwd_kernel(const float* __restrict__ x, const float* __restrict__ sc, long long L,
+                                                                int rep, float* __restrict__ y) {
+    const int b = blockIdx.y;
+    const float k = sc[b];
+    const float4* xs = reinterpret_cast<const float4*>(x + (size_t)(b / rep) * L);
+    float4* ys = reinterpret_cast<float4*>(y + (size_t)b * L);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < L / 4; i += (long long)gridDim.x * 256) {
+        const float4 v = xs[i];
+        ys[i] = make_float4(v.x * k, v.y * k, v.z * k, v.w * k);
+    }
+}
+
+__global__ void __launch_bounds__(256) scale_samples_bwd_kernel(const float* __restrict__ g_y, const float* __restrict__ x,
+                                                                const float* __restrict__ sc, long long L, int rep,
+                                                                float* __restrict__ g_x, float* __restrict__ g_s) {
+    __shared__ double part[4];
+    const int b = blockIdx.y;
+    const float k = sc[b];
+    const float4* gs = reinterpret_cast<const float4*>(g_y + (size_t)b * L);
+    const float4* xs = reinterpret_cast<const float4*>(x + (size_t)(b / rep) * L);
+    float4* gx = g_x ? reinterpret_cast<float4*>(g_x + (size_t)b * L) : nullptr;
+    double acc = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < L / 4; i += (long long)gridDim.x * 256) {
+        const float4 g = gs[i], v = xs[i];
+        acc += (double)(g.x * v.x + g.y * v.y + g.z * v.z + g.w * v.w);
+        if (gx) gx[i] = make_float4(g.x * k, g.y * k, g.z * k, g.w * k);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(g_s + b, (float)(part[0] + part[1] + part[2] + part[3]));
+}
+
 extern "C" {
 
 int bh_oneline_loss_fwd(const float* f1, const float* f2, const float* f1w, const float* m1w, const float* m2, int B, int hw,
-                        int C, float margin, float* T, double* numden, float* loss, void* stream) {
-    if (!f1 || !f2 || !f1w || !m1w || !T || !numden || !loss || B < 0) return BH_E_BADARG;
+                        int C, float margin, int rep, const float* sample_w, float* T, double* numden, float* per_sample,
+                        float* loss, void* stream) {
+    if (!f1 || !f2 || !f1w || !m1w || !T || !numden || !loss || B < 0 || rep < 1 || B % rep) return BH_E_BADARG;
     if (C % 4 || C < 4 || (C / 4 < 64 && (64 % (C / 4)))) return BH_E_UNSUPPORTED;
     hipStream_t s = bh_stream(stream);
     if (B > 0) {
         hipError_t e = hipMemsetAsync(numden, 0, sizeof(double) * 2 * (size_t)B, s);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(oneline_fwd_kernel, dim3(TRIP_BLOCKS_PER_SAMPLE, B), dim3(256), 0, s, f1, f2, f1w, m1w, m2, hw, C,
-                           margin, T, numden);
+                           margin, rep, T, numden);
         BH_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(oneline_loss_kernel, dim3(1), dim3(256), 0, s, numden, B, loss);
+    hipLaunchKernelGGL(oneline_loss_kernel, dim3(1), dim3(256), 0, s, numden, B, sample_w, per_sample, loss);
     BH_LAUNCH_CHECK();
     return BH_OK;
 }
 
 int bh_oneline_loss_bwd(const float* g_loss, const float* f2, const float* f1w, const float* m1w, const float* m2,
-                        const float* T, const double* numden, int B, int hw, int C, float* g_f1w, float* g_m1w,
-                        void* stream) {
-    if (!g_loss || !f2 || !f1w || !m1w || !T || !numden || !g_f1w || !g_m1w || B < 0) return BH_E_BADARG;
+                        const float* T, const double* numden, int B, int hw, int C, int rep, const float* sample_w,
+                        float* g_f1w, float* g_m1w, void* stream) {
+    if (!g_loss || !f2 || !f1w || !m1w || !T || !numden || !g_f1w || !g_m1w || B < 0 || rep < 1 || B % rep) return BH_E_BADARG;
     if (C % 4 || C < 4 || (C / 4 < 64 && (64 % (C / 4)))) return BH_E_UNSUPPORTED;
     if (B == 0) return BH_OK;
     hipLaunchKernelGGL(oneline_bwd_kernel, dim3(TRIP_BLOCKS_PER_SAMPLE, B), dim3(256), 0, bh_stream(stream), g_loss, f2, f1w,
-                       m1w, m2, T, numden, hw, C, g_f1w, g_m1w);
+                       m1w, m2, T, numden, hw, C, rep, sample_w, g_f1w, g_m1w);
     BH_LAUNCH_CHECK();
     return BH_OK;
 }
@@ -299,6 +341,28 @@ int bh_bihome_loss_bwd(const float* g_loss, const float* f1, const float* f2, co
     hipLaunchKernelGGL(triplet_bwd_kernel, dim3(TRIP_BLOCKS_PER_SAMPLE, B), dim3(256), 0, bh_stream(stream), g_loss, f1,
                        f2, f1w, f2w, m1w, m2w, m1, m2, M1, M2, numden, H1, H2, hw, C, mu, g_f1w, g_f2w, g_m1w, g_m2w,
                        gH1, gH2);
+    BH_LAUNCH_CHECK();
+    return BH_OK;
+}
+
+// Per-hypothesis score weighting of a feature map (multihead_resnet_loss, PerceptualHead.py:276-280):
+//   y[b, :] = x[b / rep, :] * s[b]     (x holds one row of L floats per sample, y one per hypothesis)
+// adjoint: g_x[b, :] = g_y[b, :] * s[b] (rep == 1 only), g_s[b] = sum_l g_y[b, l] x[b / rep, l].   grid (blocks, Bn)
+int bh_scale_samples_fwd(const float* x, const float* s, int Bn, long long L, int rep, float* y, void* stream) {
+    if (!x || !s || !y || Bn < 0 || rep < 1 || L % 4) return BH_E_BADARG;
+    if (Bn == 0) return BH_OK;
+    hipLaunchKernelGGL(scale_samples_fwd_kernel, dim3(32, Bn), dim3(256), 0, bh_stream(stream), x, s, L, rep, y);
+    BH_LAUNCH_CHECK();
+    return BH_OK;
+}
+
+int bh_scale_samples_bwd(const float* g_y, const float* x, const float* s, int Bn, long long L, int rep, float* g_x, float* g_s,
+                         void* stream) {
+    if (!g_y || !x || !s || !g_s || Bn < 0 || rep < 1 || L % 4 || (g_x && rep != 1)) return BH_E_BADARG;
+    if (Bn == 0) return BH_OK;
+    hipError_t e = hipMemsetAsync(g_s, 0, sizeof(float) * (size_t)Bn, bh_stream(stream));
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(scale_samples_bwd_kernel, dim3(32, Bn), dim3(256), 0, bh_stream(stream), g_y, x, s, L, rep, g_x, g_s);
     BH_LAUNCH_CHECK();
     return BH_OK;
 }

@@ -132,15 +132,59 @@ class _DltFunction(torch.autograd.Function):
         Hd, dh, eig = K.dlt_fwd(pf, choice, n, P)
         ctx.save_for_backward(pf, choice, eig)
         ctx.n, ctx.P = n, P
+        ctx.set_materialize_grads(False)            # an unused output (Hdlt when nothing scores the hypotheses) stays None
         N = pf.shape[0]
-        ctx.mark_non_differentiable(Hd)
         return dh.view(N, n, 4, 2), Hd.view(N, n, 3, 3)
 
     @staticmethod
-    def backward(ctx, g_dh, _g_H):
+    def backward(ctx, g_dh, g_H):
         pf, choice, eig = ctx.saved_tensors
-        g = g_dh.contiguous().view(-1, 4, 2)
-        return K.dlt_bwd(pf, choice, eig, g, ctx.n, ctx.P), None, None, None
+        N = pf.shape[0]
+        g = (g_dh.contiguous().view(-1, 4, 2) if g_dh is not None
+             else torch.zeros(N * ctx.n, 4, 2, dtype=torch.float32, device=pf.device))
+        gH = g_H.reshape(-1, 9).to(torch.float64).contiguous() if g_H is not None else None   # from the hypothesis scores
+        return K.dlt_bwd(pf, choice, eig, g, ctx.n, ctx.P, g_H=gH), None, None, None
+
+
+class _DsacScores(torch.autograd.Function):
+    """DSACSoftmax.__score_hypotheses (ransac_utils.py:76-128): scores[N,n] = softmax(-sum_points |H.coord - map|_1), with
+    its adjoint w.r.t. the perspective field (every point) and the hypotheses' homographies."""
+
+    @staticmethod
+    def forward(ctx, pf, Hd):
+        pf = pf.contiguous()
+        N, n = Hd.shape[0], Hd.shape[1]
+        Hflat = Hd.reshape(N * n, 9).contiguous()
+        scores, _ = K.dsac_scores_fwd(pf, Hflat, n)
+        ctx.save_for_backward(pf, Hflat, scores)
+        ctx.n = n
+        return scores
+
+    @staticmethod
+    def backward(ctx, g_scores):
+        pf, Hflat, scores = ctx.saved_tensors
+        g_pf, g_Hd = K.dsac_scores_bwd(pf, Hflat, scores, g_scores.contiguous(), ctx.n)
+        return g_pf, g_Hd.to(torch.float32).view(-1, ctx.n, 3, 3)
+
+
+class _ScaleSamples(torch.autograd.Function):
+    """y[b] = x[b // rep] * s[b] (multihead_resnet_loss' score weighting, PerceptualHead.py:276-280)."""
+
+    @staticmethod
+    def forward(ctx, x, s, rep):
+        x, s = x.contiguous(), s.contiguous()
+        ctx.save_for_backward(x, s)
+        ctx.rep = rep
+        return K.scale_samples_fwd(x, s, rep)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, s = ctx.saved_tensors
+        want_gx = ctx.needs_input_grad[0]
+        if want_gx and ctx.rep != 1:
+            raise NotImplementedError("gradient w.r.t. a repeated feature map is not needed by any branch")
+        g_x, g_s = K.scale_samples_bwd(g.contiguous(), x, s, ctx.rep, want_gx)
+        return g_x, g_s, None
 
 
 class _BiHomELoss(torch.autograd.Function):
@@ -200,7 +244,8 @@ class _IHomELoss(torch.autograd.Function):
     numeric margin.  patches[2B,1,h,w] = cat(patch_1, patch_2); delta[B,4,2] = delta_hat_12."""
 
     @staticmethod
-    def forward(ctx, delta, patches, head):
+    def forward(ctx, delta, patches, head, scores=None, n=1):
+        """delta [B*n,4,2] (n hypotheses per sample, :352-361), scores [B*n] or None (:505-511)."""
         B2, _, h, w = patches.shape
         B = B2 // 2
         aux = head.auxiliary_resnet
@@ -211,33 +256,37 @@ class _IHomELoss(torch.autograd.Function):
             torch.cuda.current_stream().wait_event(ready[1])
         else:
             with torch.no_grad():
+                # (upstream extracts the features of the n-fold repeated patches: identical batch statistics, so one copy)
                 feat = aux(patches, groups=2)                   # :358,:367 (patch_1, then patch_2)
         H64, H32 = K.h4pt_fwd(delta, h)                          # :371 -> four_point_to_homography
         pool = aux.stride
-        p1 = patches[:B].contiguous()
+        p1 = patches[:B].contiguous() if n == 1 else patches[:B].repeat_interleave(n, 0)   # :352 one copy per hypothesis
         warped, cov = K.warp_fwd(p1, H64, pool)                  # :371,:382 + downsample (:447-451)
         with torch.enable_grad():
             wl = warped.detach().requires_grad_(True)
             featw = aux(wl, groups=1)                            # :377
-        loss, T, numden = K.oneline_loss_fwd(feat[:B], feat[B:], featw.detach(), cov, head.triplet_margin)   # :474-533
-        ctx.head, ctx.pool = head, pool
-        ctx.saved = (delta, p1, H64, feat[B:], featw, wl, cov, T, numden)
+        sw = scores.contiguous() if scores is not None else None
+        loss, T, numden, per = K.oneline_loss_fwd(feat[:B], feat[B:], featw.detach(), cov, head.triplet_margin, rep=n,
+                                                  sample_w=sw)    # :474-533
+        ctx.head, ctx.pool, ctx.n = head, pool, n
+        ctx.saved = (delta, p1, H64, feat[B:], featw, wl, cov, T, numden, sw, per)
         head.last = {"loss4": loss, "H_4pt": H32, "warped": warped, "coverage": cov, "f1": feat[:B], "f2": feat[B:],
                      "f1w": featw.detach()}
         return loss[0]
 
     @staticmethod
     def backward(ctx, g_loss):
-        delta, p1, H64, f2, featw, wl, cov, T, numden = ctx.saved
+        delta, p1, H64, f2, featw, wl, cov, T, numden, sw, per = ctx.saved
         ctx.saved = None
         h = p1.shape[-1]
         g = g_loss.reshape(1).to(torch.float32).contiguous()
-        gfw, gcov = K.oneline_loss_bwd(g, f2, featw.detach(), cov, T, numden)
+        gfw, gcov = K.oneline_loss_bwd(g, f2, featw.detach(), cov, T, numden, rep=ctx.n, sample_w=sw)
         (gwarp,) = torch.autograd.grad(featw, wl, gfw)
         gH = torch.zeros_like(H64)
         K.warp_bwd(p1, H64, gwarp.contiguous(), gcov, ctx.pool, gH=gH)
         gdelta = K.h4pt_bwd(delta, H64, gH, h)
-        return gdelta, None, None
+        g_scores = per * g if sw is not None else None           # d loss / d score_b = loss_b
+        return gdelta, None, None, g_scores, None
 
 
 class _WarpFeatures(torch.autograd.Function):
@@ -396,7 +445,9 @@ class Model(nn.Module):
             c21 = self._choices(data, 'choice_21', B, N, pf.device)
             dh, Hd = _DltFunction.apply(pf, torch.cat([c12, c21], 0), self.hypothesis_no, self.point_per_hypothesis)
             if self.hypothesis_no != 1:
-                raise NotImplementedError("training with RANSAC_HYPOTHESIS_NO > 1 is not used by any shipped config")
+                # (upstream's double-line branch cannot run with n > 1 either: `eye` is built for B samples, h1 h2 for B*n,
+                #  PerceptualHead.py:660-662; the one-line and multihead branches do take several hypotheses - built below)
+                raise NotImplementedError("double-line training with RANSAC_HYPOTHESIS_NO > 1 is not defined upstream")
             delta = dh.reshape(2 * B, 4, 2)
             self.last_dlt = Hd
         else:
@@ -421,54 +472,70 @@ class Model(nn.Module):
         return loss, delta_gt, delta[:B]
 
     def _delta_12(self, data, B):
-        """delta_hat_12 [B,4,2]: from the DLT on pf_hat_12 (:154-178) or as given by the backbone (:211-214)."""
+        """(delta_hat_12 [B*n,4,2], scores [B*n] | None): n hypotheses per sample from the DLT on pf_hat_12 with their
+        softmax(-reprojection error) scores (:154-178, ransac_utils.py:147-161), or the backbone's own delta_hat (:211-214).
+        A single hypothesis has score exactly 1 (and no gradient through it): scores = None."""
         if not len(self.delta_hat_keys):
             pf = data[self.pf_keys[0]].contiguous()
             N = pf.shape[-1] * pf.shape[-2]
+            n = self.hypothesis_no
             c12 = self._choices(data, 'choice_12', B, N, pf.device)
-            if self.hypothesis_no != 1:
-                raise NotImplementedError("training with RANSAC_HYPOTHESIS_NO > 1 is not used by any shipped config")
-            dh, Hd = _DltFunction.apply(pf, c12, self.hypothesis_no, self.point_per_hypothesis)
+            dh, Hd = _DltFunction.apply(pf, c12, n, self.point_per_hypothesis)
             self.last_dlt = Hd
-            return dh.reshape(B, 4, 2)    # (the softmax score of a single hypothesis is exactly 1: :276-280,:505-511,:708-710)
-        return data[self.delta_hat_keys[0]].reshape(B, 4, 2)
+            scores = _DsacScores.apply(pf, Hd).reshape(B * n) if n > 1 else None
+            return dh.reshape(B * n, 4, 2), scores
+        return data[self.delta_hat_keys[0]].reshape(B, 4, 2), None
+
+    def _expected_delta(self, delta, scores, B):
+        """:309-312,:708-710: the returned delta_hat is the score-weighted mean over the hypotheses."""
+        if scores is None:
+            return delta
+        n = self.hypothesis_no
+        return (delta.reshape(B, n, 4, 2) * scores.reshape(B, n, 1, 1)).sum(1)
 
     def _forward_multihead(self, data, p1, p2, B):
         """multihead_resnet_loss (PerceptualHead.py:245-315): returns (features of patch_2, features of the warped patch_1,
         delta_gt, delta_hat) - ground truth first, the driver applies its torch loss (train.py:318-322).  The feature
         tensors are handed over in the reference's NCHW shape (views of the kernels' NHWC maps)."""
-        delta = self._delta_12(data, B)
+        delta, scores = self._delta_12(data, B)
         P = self.patch_size
+        n = 1 if scores is None else self.hypothesis_no
         aux = self.auxiliary_resnet
         f2 = aux(p2.reshape(B, -1, P, P), groups=1).detach()      # :269 (frozen weights: no gradient path)
-        f1w = _WarpFeatures.apply(delta, p1.reshape(B, -1, P, P).contiguous(), self)     # :272-273
+        p1r = p1.reshape(B, -1, P, P).contiguous()
+        f1w = _WarpFeatures.apply(delta, p1r if n == 1 else p1r.repeat_interleave(n, 0), self)     # :265,:272-273
+        if scores is not None:                                  # :276-280 both feature maps times the hypothesis score
+            f1w = _ScaleSamples.apply(f1w, scores, 1)
+            f2 = _ScaleSamples.apply(f2, scores, n)
         if 'summary_writer' in data:                            # :286-298
             eye = torch.eye(3, device=p1.device, dtype=torch.float32)
             _tb_scalars(data, [('feature_space', 'patch_2_f', f2.mean()), ('feature_space', 'patch_1_f_prime', f1w.mean()),
                                ('loss_comp', 'l1', (f2 - f1w).abs().mean()),
                                ('h', 'h1', ((self.last["H_4pt"] - eye) ** 2).sum())])
         delta_gt = data['delta'] if 'delta' in data else None
-        return f2.permute(0, 3, 1, 2), f1w.permute(0, 3, 1, 2), delta_gt, delta
+        return f2.permute(0, 3, 1, 2), f1w.permute(0, 3, 1, 2), delta_gt, self._expected_delta(delta, scores, B)
 
     def _forward_one_line(self, data, p1, p2, B):
         """One direction only (PerceptualHead.py:154-176,222-223): delta_hat_12 from the DLT on pf_hat_12 (or given)."""
-        delta = self._delta_12(data, B)
+        delta, scores = self._delta_12(data, B)
         pre, self._prefetched = self._prefetched, None
         if pre is not None and pre[0] is p1 and pre[1] is p2:
             patches, self._feat_ready = pre[2], (pre[3], pre[4])
         else:
             patches, self._feat_ready = self._stack_patches(data), None
-        loss = _IHomELoss.apply(delta, patches, self)
+        loss = _IHomELoss.apply(delta, patches, self, scores, 1 if scores is None else self.hypothesis_no)
         self._feat_ready = None
         if 'summary_writer' in data:                            # :678-692
             f1, f2, f1w = self.last["f1"], self.last["f2"], self.last["f1w"]
+            if scores is not None:                              # (upstream logs the n-fold repeated maps)
+                f1, f2 = (t.repeat_interleave(self.hypothesis_no, 0) for t in (f1, f2))
             eye = torch.eye(3, device=p1.device, dtype=torch.float32)
             _tb_scalars(data, [('feature_space', 'patch_1_f', f1.mean()), ('feature_space', 'patch_2_f', f2.mean()),
                                ('feature_space', 'patch_1_f_prime', f1w.mean()),
                                ('loss_comp', 'l1', (f2 - f1w).abs().mean()), ('loss_comp', 'l3', (f2 - f1).abs().mean()),
                                ('h', 'h1', ((self.last["H_4pt"] - eye) ** 2).sum())])
         delta_gt = data['delta'] if 'delta' in data else None
-        return loss, delta_gt, delta
+        return loss, delta_gt, self._expected_delta(delta, scores, B)
 
     def predict_homography(self, data):
         if len(self.delta_hat_keys):

@@ -122,12 +122,56 @@ def dlt_fwd(pf, choice, n, P):
     return Hd, dh, eig
 
 
-def dlt_bwd(pf, choice, eig, g_delta, n, P):
-    _chk(pf); _chk(choice, torch.int64); _chk(eig, torch.float64); _chk(g_delta)
+def dlt_bwd(pf, choice, eig, g_delta, n, P, g_H=None):
+    """g_H [B*n,9] float64 (optional): gradient reaching the homography itself (hypothesis scoring)."""
+    _chk(pf); _chk(choice, torch.int64); _chk(eig, torch.float64); _chk(g_delta); _chk(g_H, torch.float64)
     B, _, h, w = pf.shape
     g_pf = torch.zeros_like(pf)
-    check(lib.bh_dlt_bwd(_p(pf), _p(choice), _p(eig), _p(g_delta), B, n, P, h, w, _p(g_pf), _stream()), "bh_dlt_bwd")
+    check(lib.bh_dlt_bwd(_p(pf), _p(choice), _p(eig), _p(g_delta), _p(g_H), B, n, P, h, w, _p(g_pf), _stream()), "bh_dlt_bwd")
     return g_pf
+
+
+def dsac_scores_fwd(pf, Hd, n):
+    """scores[B,n] = softmax(-reprojection error) (ransac_utils.py:76-128); returns (scores, err)."""
+    _chk(pf); _chk(Hd)
+    B, _, h, w = pf.shape
+    err = torch.empty(B, n, dtype=torch.float32, device=pf.device)
+    scores = torch.empty_like(err)
+    check(lib.bh_dsac_score(_p(pf), _p(Hd), B, n, h, w, _p(err), None, _stream()), "bh_dsac_score")
+    check(lib.bh_dsac_scores_fwd(_p(err), B, n, _p(scores), _stream()), "bh_dsac_scores_fwd")
+    return scores, err
+
+
+def dsac_scores_bwd(pf, Hd, scores, g_scores, n):
+    """-> (g_pf [B,2,h,w], g_Hd [B*n,9] float64)."""
+    _chk(pf); _chk(Hd); _chk(scores); _chk(g_scores)
+    B, _, h, w = pf.shape
+    g_err = torch.empty_like(scores)
+    g_Hd = torch.empty(B * n, 9, dtype=torch.float64, device=pf.device)
+    g_pf = torch.zeros_like(pf)
+    check(lib.bh_dsac_scores_bwd(_p(pf), _p(Hd), _p(scores), _p(g_scores), B, n, h, w, _p(g_err), _p(g_Hd), _p(g_pf), _stream()),
+          "bh_dsac_scores_bwd")
+    return g_pf, g_Hd
+
+
+def scale_samples_fwd(x, s, rep):
+    """y[b] = x[b // rep] * s[b]: x [Bx, ...] (one row per sample), s [Bx * rep] -> y [Bx * rep, ...]."""
+    _chk(x); _chk(s)
+    Bn = s.numel()
+    L = x.numel() // x.shape[0]
+    y = torch.empty((Bn,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+    check(lib.bh_scale_samples_fwd(_p(x), _p(s), Bn, L, rep, _p(y), _stream()), "bh_scale_samples_fwd")
+    return y
+
+
+def scale_samples_bwd(g_y, x, s, rep, want_gx):
+    _chk(g_y); _chk(x); _chk(s)
+    Bn = s.numel()
+    L = x.numel() // x.shape[0]
+    g_x = torch.empty_like(g_y) if want_gx else None
+    g_s = torch.empty(Bn, dtype=torch.float32, device=x.device)
+    check(lib.bh_scale_samples_bwd(_p(g_y), _p(x), _p(s), Bn, L, rep, _p(g_x), _p(g_s), _stream()), "bh_scale_samples_bwd")
+    return g_x, g_s
 
 
 def dsac_score(pf, Hd, n):
@@ -188,26 +232,28 @@ def triplet_l1_fwd(f1, f2, f1w, f2w, m1w, m2w, m1=None, m2=None):
     return M1, M2, numden
 
 
-def oneline_loss_fwd(f1, f2, f1w, m1w, margin, m2=None):
-    """iHomE one-line hinge loss (PerceptualHead.py:465-538): returns (loss[1], T[B,hf,wf], numden[B,2])."""
-    for t in (f1, f2, f1w, m1w, m2):
+def oneline_loss_fwd(f1, f2, f1w, m1w, margin, m2=None, rep=1, sample_w=None):
+    """iHomE one-line hinge loss (PerceptualHead.py:465-538): returns (loss[1], T[B,hf,wf], numden[B,2], per_sample[B]).
+    rep > 1: B = samples * rep hypotheses; f1 / f2 / m2 hold one entry per sample; sample_w[B] = DSAC scores."""
+    for t in (f1, f2, f1w, m1w, m2, sample_w):
         _chk(t)
-    B, hf, wf, C = f1.shape
+    B, hf, wf, C = f1w.shape
     T = torch.empty(B, hf, wf, dtype=torch.float32, device=f1.device)
     numden = torch.empty(B, 2, dtype=torch.float64, device=f1.device)
+    per = torch.empty(B, dtype=torch.float32, device=f1.device)
     loss = torch.empty(1, dtype=torch.float32, device=f1.device)
-    check(lib.bh_oneline_loss_fwd(_p(f1), _p(f2), _p(f1w), _p(m1w), _p(m2), B, hf * wf, C, float(margin), _p(T), _p(numden),
-                                  _p(loss), _stream()), "bh_oneline_loss_fwd")
-    return loss, T, numden
+    check(lib.bh_oneline_loss_fwd(_p(f1), _p(f2), _p(f1w), _p(m1w), _p(m2), B, hf * wf, C, float(margin), rep, _p(sample_w), _p(T),
+                                  _p(numden), _p(per), _p(loss), _stream()), "bh_oneline_loss_fwd")
+    return loss, T, numden, per
 
 
-def oneline_loss_bwd(g_loss, f2, f1w, m1w, T, numden, m2=None):
-    _chk(g_loss)
+def oneline_loss_bwd(g_loss, f2, f1w, m1w, T, numden, m2=None, rep=1, sample_w=None):
+    _chk(g_loss); _chk(sample_w)
     B, hf, wf, C = f1w.shape
     g_f1w = torch.empty_like(f1w)
     g_m1w = torch.empty(B, hf, wf, dtype=torch.float32, device=f1w.device)
-    check(lib.bh_oneline_loss_bwd(_p(g_loss), _p(f2), _p(f1w), _p(m1w), _p(m2), _p(T), _p(numden), B, hf * wf, C, _p(g_f1w),
-                                  _p(g_m1w), _stream()), "bh_oneline_loss_bwd")
+    check(lib.bh_oneline_loss_bwd(_p(g_loss), _p(f2), _p(f1w), _p(m1w), _p(m2), _p(T), _p(numden), B, hf * wf, C, rep, _p(sample_w),
+                                  _p(g_f1w), _p(g_m1w), _stream()), "bh_oneline_loss_bwd")
     return g_f1w, g_m1w
 
 

@@ -55,7 +55,9 @@ int bh_h4pt_bwd(const float* delta, const double* H64, const double* gH, int B, 
 int bh_dlt_fwd(const float* pf, const int64_t* choice, int B, int n, int P, int h, int w,
                float* Hdlt, float* delta_hat, double* eig, void* stream);
 /* adjoint: g_delta[B*n,4,2] -> g_pf[B,2,h,w] += (scatter-add at the sampled indices; caller zeroes) */
-int bh_dlt_bwd(const float* pf, const int64_t* choice, const double* eig, const float* g_delta,
+/* g_Hdlt[B*n,9] (double, NULL ok): gradient that reaches the normalised homography itself (from the hypothesis scores,
+ * bh_dsac_scores_bwd), added to the one that arrives through delta_hat */
+int bh_dlt_bwd(const float* pf, const int64_t* choice, const double* eig, const float* g_delta, const double* g_Hdlt,
                int B, int n, int P, int h, int w, float* g_pf, void* stream);
 
 /* DSACSoftmax.__score_hypotheses ('repr_error'), src/heads/ransac_utils.py:76-128, and the
@@ -63,6 +65,14 @@ int bh_dlt_bwd(const float* pf, const int64_t* choice, const double* eig, const 
  * err[B,n] = sum over all h*w points of |H.coord - (coord + pf)|_1 ; best[B] int64 (first minimum). */
 int bh_dsac_score(const float* pf, const float* Hdlt, int B, int n, int h, int w,
                   float* err, int64_t* best, void* stream);
+
+/* scores[B,n] = softmax(-err) over the hypotheses (ransac_utils.py:126): the weights of the score-weighted multi-hypothesis
+ * losses (PerceptualHead.py:276-280,505-511,708-710).  Adjoint of scoring + softmax: g_scores[B,n] -> g_err[B,n] (scratch,
+ * overwritten), g_Hdlt[B*n,9] (double, overwritten; feed to bh_dlt_bwd) and g_pf[B,2,h,w] += (atomics; the reprojection
+ * error sees every point of the field: sign(H.coord - map) per point). */
+int bh_dsac_scores_fwd(const float* err, int B, int n, float* scores, void* stream);
+int bh_dsac_scores_bwd(const float* pf, const float* Hdlt, const float* scores, const float* g_scores, int B, int n, int h,
+                       int w, float* g_err, double* g_Hdlt, float* g_pf, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Homography warp (warp_image, src/data/utils.py:54-59 -> kornia.warp_perspective(bilinear, zeros,
@@ -103,12 +113,21 @@ int bh_bihome_loss_bwd(const float* g_loss, const float* f1, const float* f2, co
 /* One-line variant (iHomE; triplet_resnet_loss 'one-line' / l1 / numeric margin: PerceptualHead.py:465-538):
  *   loss = sum_b [ sum_p w max(|f1w-f2|_1 - |f1-f2|_1 + margin, 0) / max(sum_p w, 1) ],  w = m1w * m2 (m2 NULL => ones)
  * T[B,hw] = pre-hinge value (kept for the adjoint), numden[B,2] double, loss[1]. */
+/* Multi-hypothesis form (RANSAC_HYPOTHESIS_NO = rep > 1, PerceptualHead.py:352-361,505-511): B counts hypotheses
+ * (samples * rep); f1, f2, m2 hold one entry per SAMPLE (row b / rep), f1w / m1w / T one per hypothesis; sample_w[B]
+ * (NULL = 1) = DSAC score of the hypothesis, loss = sum_b sample_w[b] * loss_b; per_sample[B] (NULL ok) = loss_b. */
 int bh_oneline_loss_fwd(const float* f1, const float* f2, const float* f1w, const float* m1w, const float* m2, int B, int hw,
-                        int C, float margin, float* T, double* numden, float* loss, void* stream);
-/* adjoint: g_loss[1] -> g_f1w[B,hw,C], g_m1w[B,hw] (overwritten) */
+                        int C, float margin, int rep, const float* sample_w, float* T, double* numden, float* per_sample,
+                        float* loss, void* stream);
+/* adjoint: g_loss[1] -> g_f1w[B,hw,C], g_m1w[B,hw] (overwritten); d loss / d sample_w[b] = g_loss * per_sample[b] */
 int bh_oneline_loss_bwd(const float* g_loss, const float* f2, const float* f1w, const float* m1w, const float* m2,
-                        const float* T, const double* numden, int B, int hw, int C, float* g_f1w, float* g_m1w,
-                        void* stream);
+                        const float* T, const double* numden, int B, int hw, int C, int rep, const float* sample_w,
+                        float* g_f1w, float* g_m1w, void* stream);
+/* y[b,:] = x[b / rep,:] * s[b] over Bn hypotheses of L floats (the score weighting of multihead_resnet_loss,
+ * PerceptualHead.py:276-280) and its adjoint (g_x only for rep = 1, may be NULL; g_s[Bn] overwritten). */
+int bh_scale_samples_fwd(const float* x, const float* s, int Bn, long long L, int rep, float* y, void* stream);
+int bh_scale_samples_bwd(const float* g_y, const float* x, const float* s, int Bn, long long L, int rep, float* g_x, float* g_s,
+                         void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Conv stacks (Rethinking._forward src/backbones/Rethinking.py:284-294 with blocks

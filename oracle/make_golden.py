@@ -485,6 +485,14 @@ def _round2(importlib, Rethinking, ResNet34, configs, dtype, tag, outdir, which)
         r = run_bihome_variant(Rethinking.Model, PerceptualHead.Model, cfg, dtype, steps=2, loss_name=cfg["SOLVER"]["LOSS"])
         np.savez_compressed(os.path.join(outdir, "zeng_multihead_b4_%s.npz" % tag), **r)
         print("zeng_multihead", tag, "loss", r["loss"], "mace", r["mace"])
+    for base, loss_name in (("zeng-ihome", None), ("zeng-multihead", "L1Loss")):
+        name = base.replace("-", "_") + "_n4_b4"
+        if want(name):              # score-weighted multi-hypothesis training (PerceptualHead.py:276-280,505-511,708-710)
+            cfg = configs.get(base)
+            cfg["MODEL"]["HEAD"].update(RANSAC_HYPOTHESIS_NO=4, POINTS_PER_HYPOTHESIS=16)
+            r = run_bihome_variant(Rethinking.Model, PerceptualHead.Model, cfg, dtype, batch=4, seed=19, steps=2, loss_name=loss_name)
+            np.savez_compressed(os.path.join(outdir, "%s_%s.npz" % (name, tag)), **r)
+            print(name, tag, "loss", r["loss"], "mace", r["mace"])
     if want("zeng_pds_b8"):
         r = run_bihome_variant(Rethinking.Model, PerceptualHead.Model, configs.get("zeng-bihome-pds"), dtype, batch=8, seed=8,
                                steps=3, photometric=32)

@@ -178,3 +178,38 @@ def test_pds_coco_three_steps_vs_golden(golden):
         sp_l, sp_m = abs(g32["loss"][it] - g64["loss"][it]), abs(g32["mace"][it] - g64["mace"][it])
         assert abs(losses[it] - g64["loss"][it]) <= max(5 * sp_l, 0.05 * abs(g64["loss"][it])), (it, losses, g64["loss"])
         assert abs(maces[it] - g64["mace"][it]) <= max(10 * sp_m, 0.05), (it, maces, g64["mace"])
+
+
+@pytest.mark.parametrize("base,loss_name", [("zeng-ihome", None), ("zeng-multihead", "L1Loss")])
+def test_score_weighted_multi_hypothesis_training_vs_golden(golden, base, loss_name):
+    """Training with RANSAC_HYPOTHESIS_NO = 4 (16 points per hypothesis): softmax(-reprojection error) scores weight the
+    hinge loss (one-line, PerceptualHead.py:505-511) or both feature maps (multihead, :276-280), delta_hat is the
+    score-weighted mean (:309-312,:708-710), and the gradient reaches the perspective field through the DLT of every
+    hypothesis AND through the scores (bh_dsac_scores_bwd: every point of the field).  Against the reference's own
+    modules on the recorded draws: step 0 tight, step 1 (after one Adam update - it sees the gradients) within the
+    reference's float32-vs-float64 spread."""
+    from bihome_amd.step import build_loss, build_optimizer, mace, train_step
+    name = base.replace("-", "_") + "_n4_b4"
+    g32, g64 = golden(name + "_f32"), golden(name + "_f64")
+    cfg = configs.get(base)
+    cfg["MODEL"]["HEAD"].update(RANSAC_HYPOTHESIS_NO=4, POINTS_PER_HYPOTHESIS=16)
+    model = _model(cfg)
+    opt, sched = build_optimizer(model, cfg["SOLVER"])
+    loss_fn = build_loss(cfg["SOLVER"])
+    assert isinstance(loss_fn, torch.nn.Module) == (loss_name is not None)
+    d = synth.make_pairs(4, seed=19)
+    losses, maces = [], []
+    for it in range(2):
+        data = {k: cuda(d[k]) for k in ("patch_1", "patch_2", "delta")}
+        data["choice_12"] = cuda(g64["choice_12"][it], torch.int64)
+        loss, dgt, dh = train_step(model, data, opt, sched, loss_fn=loss_fn)
+        losses.append(loss.item()); maces.append(mace(dgt, dh))
+        if it == 0:
+            assert dh.shape == (4, 4, 2)
+            assert relerr(dh.cpu(), g64["delta_hat_12"]) < 2e-3
+    print(base, "loss", losses, "mace", maces, "ref", g64["loss"], g64["mace"], g32["loss"])
+    assert abs(losses[0] - g64["loss"][0]) <= max(3 * abs(g32["loss"][0] - g64["loss"][0]), 2e-4 * abs(g64["loss"][0]))
+    assert abs(maces[0] - g64["mace"][0]) < 2e-3
+    sp_l, sp_m = abs(g32["loss"][1] - g64["loss"][1]), abs(g32["mace"][1] - g64["mace"][1])
+    assert abs(losses[1] - g64["loss"][1]) <= max(5 * sp_l, 2e-3 * abs(g64["loss"][1])), (losses, g64["loss"], g32["loss"])
+    assert abs(maces[1] - g64["mace"][1]) <= max(5 * sp_m, 5e-3), (maces, g64["mace"], g32["mace"])

@@ -254,3 +254,32 @@ def test_oneline_hinge_loss_fwd_bwd(B, hf, C, margin):
     gf, gm = K.oneline_loss_bwd(torch.ones(1, device="cuda"), f2.cuda(), f1w.cuda(), m1w.cuda(), T, numden)
     assert (gf.cpu().double() - c.grad).abs().max().item() <= 2e-5 * c.grad.abs().max().item() + 1e-7
     assert (gm.cpu().double() - m.grad).abs().max().item() <= 2e-4 * m.grad.abs().max().item() + 1e-6
+
+
+def test_dsac_scores_fwd_bwd_vs_torch64():
+    """bh_dsac_score + bh_dsac_scores_fwd / _bwd (softmax(-reprojection error) and its adjoint w.r.t. the field and the
+    hypotheses' homographies) against torch float64 autograd of ransac_utils.py:76-128."""
+    from bihome_amd import kernels as K
+    B, n, h = 3, 4, 32
+    g = torch.Generator().manual_seed(4)
+    pf = torch.randn(B, 2, h, h, generator=g) * 2.0
+    Hd = torch.eye(3).repeat(B * n, 1, 1) + 0.01 * torch.randn(B * n, 3, 3, generator=g)
+    Hd[:, 2, :2] *= 0.01
+    gs = torch.randn(B, n, generator=g)
+    pf64, H64 = pf.double().requires_grad_(True), Hd.double().requires_grad_(True)
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float64), torch.arange(h, dtype=torch.float64), indexing="ij")
+    coord = torch.stack([xs.reshape(-1), ys.reshape(-1)], -1)
+    mapf = coord[None] + pf64.reshape(B, 2, -1).permute(0, 2, 1)
+    ph = torch.cat([coord, torch.ones_like(coord[:, :1])], -1)
+    q = torch.einsum("bnij,pj->bnpi", H64.reshape(B, n, 3, 3), ph)
+    t = q[..., :2] / q[..., 2:3]
+    err = (t - mapf[:, None]).abs().sum(-1).sum(-1)
+    scores = torch.softmax(-err, -1)
+    (scores * gs.double()).sum().backward()
+    s, e = K.dsac_scores_fwd(pf.cuda(), Hd.reshape(-1, 9).cuda().contiguous(), n)
+    assert (e.cpu().double() - err.detach()).abs().max() <= 1e-5 * err.detach().abs().max()
+    assert (s.cpu().double() - scores.detach()).abs().max() < 2e-4
+    g_pf, g_H = K.dsac_scores_bwd(pf.cuda(), Hd.reshape(-1, 9).cuda().contiguous(), s, gs.cuda().contiguous(), n)
+    rp, rh = pf64.grad, H64.grad.reshape(-1, 9)
+    assert (g_pf.cpu().double() - rp).abs().max() <= 2e-3 * rp.abs().max() + 1e-9
+    assert (g_H.cpu() - rh).abs().max() <= 2e-3 * rh.abs().max() + 1e-9

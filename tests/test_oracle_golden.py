@@ -242,3 +242,26 @@ def test_bihome_tensorboard_keys(golden):
     assert tb == set(rec.scalars) and len(tb) == 8
     for k in tb:
         np.testing.assert_allclose(rec.scalars[k], g[k], rtol=1e-7, err_msg=k)
+
+
+@pytest.mark.parametrize("base,loss_name", [("zeng-ihome", None), ("zeng-multihead", "L1Loss")])
+def test_score_weighted_multi_hypothesis_training(golden, base, loss_name):
+    """RANSAC_HYPOTHESIS_NO = 4, 16 points each: the hinge loss (one-line) / the feature maps (multihead) are weighted by
+    softmax(-reprojection error) and delta_hat is the score-weighted mean (PerceptualHead.py:276-280,505-511,708-710)."""
+    g = golden(base.replace("-", "_") + "_n4_b4_f64")
+    cfg = configs.get(base)
+    cfg["MODEL"]["HEAD"].update(RANSAC_HYPOTHESIS_NO=4, POINTS_PER_HYPOTHESIS=16)
+    bb, head = O.build(cfg)
+    load_synthetic(bb, 0)
+    load_synthetic(head.auxiliary_resnet, 0)
+    bb.double(); head.double()
+    opt, sched = O.make_optimizer(torch.nn.Sequential(bb, head), cfg["SOLVER"])
+    loss_fn = getattr(torch.nn, loss_name)() if loss_name else None
+    d = synth.make_pairs(4, seed=19)
+    for it in range(2):
+        data = {k: _t(d[k], torch.float64) for k in ("patch_1", "patch_2", "delta")}
+        loss, dgt, dh = O.train_step(bb, head, opt, sched, data, _t(g["choice_12"][it], torch.int64), loss_fn=loss_fn)
+        assert abs(loss.item() - g["loss"][it]) <= 1e-7 * abs(g["loss"][it]), (it, loss.item(), g["loss"])
+        np.testing.assert_allclose(O.mace(dgt, dh), g["mace"][it], rtol=1e-7)
+        if it == 0:
+            np.testing.assert_allclose(dh.numpy(), g["delta_hat_12"], atol=1e-6)
