@@ -249,7 +249,7 @@ def test_oneline_hinge_loss_fwd_bwd(B, hf, C, margin):
     den = m.sum((-1, -2))
     ref = ((m * torch.clamp(t, min=0)).sum((-1, -2)) / torch.max(den, torch.ones_like(den))).sum()
     ref.backward()
-    loss, T, numden = K.oneline_loss_fwd(f1.cuda(), f2.cuda(), f1w.cuda(), m1w.cuda(), margin)
+    loss, T, numden, per = K.oneline_loss_fwd(f1.cuda(), f2.cuda(), f1w.cuda(), m1w.cuda(), margin)
     assert abs(loss.item() - ref.item()) <= 2e-5 * abs(ref.item()) + 1e-6
     gf, gm = K.oneline_loss_bwd(torch.ones(1, device="cuda"), f2.cuda(), f1w.cuda(), m1w.cuda(), T, numden)
     assert (gf.cpu().double() - c.grad).abs().max().item() <= 2e-5 * c.grad.abs().max().item() + 1e-7
@@ -283,3 +283,41 @@ def test_dsac_scores_fwd_bwd_vs_torch64():
     rp, rh = pf64.grad, H64.grad.reshape(-1, 9)
     assert (g_pf.cpu().double() - rp).abs().max() <= 2e-3 * rp.abs().max() + 1e-9
     assert (g_H.cpu() - rh).abs().max() <= 2e-3 * rh.abs().max() + 1e-9
+
+
+def test_scale_samples_and_scored_hinge_vs_torch64():
+    """bh_scale_samples_fwd/bwd (rep = 1 with g_x, rep = 3 without) and the multi-hypothesis form of the one-line loss
+    (rep = 3, per-hypothesis scores) against torch float64 autograd."""
+    from bihome_amd import kernels as K
+    g = torch.Generator().manual_seed(9)
+    B, n, hf, C = 2, 3, 8, 64
+    x1 = torch.randn(B * n, hf, hf, C, generator=g)
+    x2 = torch.randn(B, hf, hf, C, generator=g)
+    s = torch.rand(B * n, generator=g) + 0.1
+    gy = torch.randn(B * n, hf, hf, C, generator=g)
+    for x, rep in ((x1, 1), (x2, n)):
+        xd, sd = x.double().requires_grad_(True), s.double().requires_grad_(True)
+        y = xd.repeat_interleave(rep, 0) * sd.view(-1, 1, 1, 1)
+        (y * gy.double()).sum().backward()
+        yk = K.scale_samples_fwd(x.cuda(), s.cuda(), rep)
+        assert (yk.cpu().double() - y.detach()).abs().max() < 1e-6
+        gx, gs = K.scale_samples_bwd(gy.cuda(), x.cuda(), s.cuda(), rep, rep == 1)
+        assert (gs.cpu().double() - sd.grad).abs().max() <= 1e-5 * sd.grad.abs().max()
+        if rep == 1:
+            assert (gx.cpu().double() - xd.grad).abs().max() < 1e-6
+    # scored hinge
+    f1, f2 = torch.randn(B, hf, hf, C, generator=g), torch.randn(B, hf, hf, C, generator=g)
+    f1w = f2.repeat_interleave(n, 0) + 0.7 * torch.randn(B * n, hf, hf, C, generator=g)
+    m1w = torch.rand(B * n, hf, hf, generator=g)
+    a, b, c, m, sc = (t.double().requires_grad_(rq) for t, rq in ((f1, False), (f2, False), (f1w, True), (m1w, True), (s, True)))
+    t = (c - b.repeat_interleave(n, 0)).abs().sum(-1) - (a - b).abs().sum(-1).repeat_interleave(n, 0) + 1.0
+    den = m.sum((-1, -2))
+    per = (m * torch.clamp(t, min=0)).sum((-1, -2)) / torch.max(den, torch.ones_like(den))
+    ref = (per * sc).sum()
+    ref.backward()
+    loss, T, numden, perk = K.oneline_loss_fwd(f1.cuda(), f2.cuda(), f1w.cuda(), m1w.cuda(), 1.0, rep=n, sample_w=s.cuda())
+    assert abs(loss.item() - ref.item()) <= 2e-5 * abs(ref.item())
+    assert (perk.cpu().double() - per.detach()).abs().max() <= 2e-5 * per.detach().abs().max()
+    gf, gm = K.oneline_loss_bwd(torch.ones(1, device="cuda"), f2.cuda(), f1w.cuda(), m1w.cuda(), T, numden, rep=n, sample_w=s.cuda())
+    assert (gf.cpu().double() - c.grad).abs().max() <= 2e-5 * c.grad.abs().max() + 1e-8
+    assert (gm.cpu().double() - m.grad).abs().max() <= 2e-4 * m.grad.abs().max() + 1e-7
