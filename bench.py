@@ -108,6 +108,11 @@ def roofline_leg(model, data, opt, sched, reducer, nsteps=2):
     extra steps; returns the roofline object of the kernel with the largest total time plus a breakdown."""
     from bihome_amd import kernels as K
     from bihome_amd.step import train_step
+    # one untimed pass in timing mode first: the first event pairs / variant queries of a process stall the host for
+    # milliseconds, and an event pair also measures the time the GPU waits for the host between its two markers
+    K.TIMING = {}
+    train_step(model, dict(data), opt, sched, reducer=reducer, loss_fn=LOSS_FN[0])
+    torch.cuda.synchronize()
     K.TIMING = {}
     for _ in range(nsteps):
         train_step(model, dict(data), opt, sched, reducer=reducer, loss_fn=LOSS_FN[0])
