@@ -160,4 +160,5 @@ def test_packed_weights_follow_fused_optimizer_updates():
             assert not torch.equal(stale, pf)               # the last optimizer step moved the weights; refresh saw it
     l1, l0 = res[True], res[False]
     assert abs(l1[0] - l0[0]) <= 1e-5 * abs(l0[0])
-    assert abs(l1[2] - l0[2]) <= 2e-3 * abs(l0[2]) + 1e-3, (l1, l0)       # stale packed weights are ~20 % off by step 2
+    assert abs(l1[1] - l0[1]) <= 1e-3 * abs(l0[1]) + 1e-3, (l1, l0)       # the first forward after an update: stale copies are ~20 % off here
+    assert abs(l1[2] - l0[2]) <= 5e-2 * abs(l0[2]) + 1e-2, (l1, l0)       # (two eager runs differ by ~0.5 % by now: atomics order)
