@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=None, help="image pairs per GPU (default: the config's DATA.BATCH_SIZE)")
     ap.add_argument("--config", default="zeng-bihome")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
+    ap.add_argument("--precision", default="f32", choices=["f32", "f32-mfma", "bf16"],
                     help="conv operand precision; the headline config (BASELINE.json configs[1]) is f32")
     ap.add_argument("--gpu-datagen", action="store_true",
                     help="draw a fresh batch every step with the device-side pair generator (bh_synth_pairs) inside the "
@@ -304,7 +304,8 @@ def main():
         out = {
             "metric": "training image-pairs/s (%dx%d patch, bs=%d per GPU, full step: fwd+bwd+Adam)" % (P, P, B),
             "value": value, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"f32": "f32", "f32-mfma": "f32", "bf16": "bf16"}[args.precision],
             "data": "synthetic (seeded COCO-style texture pairs, random-init weights%s)" % (
                 "; fresh batch per step from the device-side generator" if args.gpu_datagen else "; one resident batch"),
             "config": {"workload": "%s: %s backbone + %s head, %d pairs/GPU, %dx%d %s, %s MFMA conv + HIP "
@@ -312,6 +313,12 @@ def main():
                                        WORKLOADS.get(args.config, args.config), cfg["MODEL"]["BACKBONE"]["NAME"],
                                        cfg["MODEL"]["HEAD"]["NAME"], B, P, P,
                                        "RGB" if CH == 3 else "grayscale", args.precision),
+                       "arithmetic": {"f32": "fp32 tensors, fp32 accumulate; packed 3x3 convs (fwd, dgrad): each fp32 operand cut exactly "
+                                             "into 3 bf16 pieces, 6 partial products per product on v_mfma_f32_32x32x16_bf16 "
+                                             "(error vs float64 <= the fp32-input MFMA form: tests/test_conv_kernels_gpu.py); all "
+                                             "other convs and the weight gradients: v_mfma_f32_32x32x2_f32",
+                                      "f32-mfma": "fp32 tensors, v_mfma_f32_32x32x2_f32 everywhere",
+                                      "bf16": "fp32 tensors, conv operands rounded to bf16, fp32 accumulate"}[args.precision],
                        "stream_overlap": bool(args.overlap or os.environ.get("BIHOME_OVERLAP") == "1"),
                        "hip_graph": bool(use_graph),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "optimizer": "Adam lr 1e-3"},

@@ -19,7 +19,8 @@ class BhConvDesc(Structure):
 
 
 class BhPack3x3Job(Structure):
-    _fields_ = [("w", c_void_p), ("pf", c_void_p), ("pd", c_void_p), ("Co", c_int), ("Ci", c_int)]
+    _fields_ = [("w", c_void_p), ("pf", c_void_p), ("pd", c_void_p), ("Co", c_int), ("Ci", c_int), ("split", c_int),
+                ("reserved", c_int)]
 
 
 # bh_conv_desc.route bits (include/bihome.h): explicit per-call kernel routing for tests / benchmarks; 0 = automatic

@@ -50,7 +50,7 @@ class Model(nn.Module):
         self.resnet34 = _ResNet34(2, 8)
         self.variant = str.lower(kwargs['VARIANT']) if 'VARIANT' in kwargs else 'oneline'
         assert 'oneline' in self.variant or 'doubleline' in self.variant, 'Only OneLine or DoubleLine variant is supported'
-        # optional extra kwarg (ignored upstream): conv operand precision 'f32' (default, exact) or 'bf16' (bf16 MFMA operands,
+        # optional extra kwarg (ignored upstream): conv arithmetic 'f32' (default: fp32 accuracy, kernels.PRECISION), 'f32-mfma' (fp32-input MFMA only) or 'bf16' (bf16 MFMA operands,
         # fp32 accumulate/storage - BASELINE.json configs[3])
         self.precision = kwargs.get('PRECISION', os.environ.get('BIHOME_PRECISION', 'f32'))
         net.to_kernel_layout_(self)

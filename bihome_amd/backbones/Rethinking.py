@@ -74,7 +74,7 @@ class Model(nn.Module):
         self.layer6 = S(U(64, 64), U(64, 64), D(64))
         self.layer7 = S(U(32, 32), D(32))
         self.layer8 = S(nn.Conv2d(16, 128, 1), nn.BatchNorm2d(128), nn.ReLU(), nn.Conv2d(128, 2, 1))
-        # optional extra kwarg (ignored upstream): conv operand precision 'f32' (default, exact) or 'bf16' (bf16 MFMA operands,
+        # optional extra kwarg (ignored upstream): conv arithmetic 'f32' (default: fp32 accuracy, kernels.PRECISION), 'f32-mfma' (fp32-input MFMA only) or 'bf16' (bf16 MFMA operands,
         # fp32 accumulate/storage - BASELINE.json configs[3])
         self.precision = kwargs.get('PRECISION', os.environ.get('BIHOME_PRECISION', 'f32'))
         net.to_kernel_layout_(self)

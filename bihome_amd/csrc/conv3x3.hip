@@ -38,6 +38,32 @@ __device__ __forceinline__ bf16x8 c3_pack_bf16(const float4& lo, const float4& h
     return __builtin_convertvector(v, bf16x8);
 }
 
+// X3 ("f32x3": fp32 result accuracy on the bf16 matrix pipe): every fp32 operand x is cut into three bf16 pieces
+// x = hi + mid + lo (truncation: 8 + 8 + 8 significand bits, so the sum is EXACT), and a product a*b is evaluated as the six
+// partial products of total order <= 2 (hi*hi, hi*mid, mid*hi, hi*lo, mid*mid, lo*hi) on v_mfma_f32_32x32x16_bf16 with fp32
+// accumulate; the three dropped ones are below 2^-23 |a*b| - the size of one fp32 rounding of the product.  Six 32-cycle
+// MFMAs contract 16 channels that cost eight 64-cycle v_mfma_f32_32x32x2_f32: 2.67x less matrix-pipe time.
+// c3_split8: 8 floats -> the 8 bf16 of each piece, element e in the low / high half of dword e/2 (5.5 VALU per element).
+__device__ __forceinline__ void c3_split8(const float4& u, const float4& v, uint4& hi, uint4& mid, uint4& lo) {
+    const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+    unsigned xb[8], rb[8], sb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        xb[e] = __builtin_bit_cast(unsigned, x[e]);
+        const float r = x[e] - __builtin_bit_cast(float, xb[e] & 0xFFFF0000u);        // exact
+        rb[e] = __builtin_bit_cast(unsigned, r);
+        const float t = r - __builtin_bit_cast(float, rb[e] & 0xFFFF0000u);           // exact, <= 8 significant bits
+        sb[e] = __builtin_bit_cast(unsigned, t);
+    }
+    // v_perm_b32: bytes 7,6 of {S0,S1} = high half of S0, bytes 3,2 = high half of S1
+    hi = make_uint4(__builtin_amdgcn_perm(xb[1], xb[0], 0x07060302u), __builtin_amdgcn_perm(xb[3], xb[2], 0x07060302u),
+                    __builtin_amdgcn_perm(xb[5], xb[4], 0x07060302u), __builtin_amdgcn_perm(xb[7], xb[6], 0x07060302u));
+    mid = make_uint4(__builtin_amdgcn_perm(rb[1], rb[0], 0x07060302u), __builtin_amdgcn_perm(rb[3], rb[2], 0x07060302u),
+                     __builtin_amdgcn_perm(rb[5], rb[4], 0x07060302u), __builtin_amdgcn_perm(rb[7], rb[6], 0x07060302u));
+    lo = make_uint4(__builtin_amdgcn_perm(sb[1], sb[0], 0x07060302u), __builtin_amdgcn_perm(sb[3], sb[2], 0x07060302u),
+                    __builtin_amdgcn_perm(sb[5], sb[4], 0x07060302u), __builtin_amdgcn_perm(sb[7], sb[6], 0x07060302u));
+}
+
 // pixel row (0..7) of the 8x4 strip held by lane quad q = l31 >> 2: 0 1 3 2 5 4 6 7 (see a_lane in the kernel)
 __device__ __forceinline__ int c3_strip_row(int q) { return q ^ (((q >> 1) ^ (q >> 2)) & 1); }
 
@@ -86,12 +112,19 @@ constexpr int C3_LDS_BYTES = 2 * C3_HALO_BYTES + 2 * C3_B_BYTES;      // 67584
 // SUBT = 8x8 sub-tiles per workgroup.  2 (default): 128 GEMM rows, 67.5 KB of LDS, two workgroups per CU.  1 (BN = 64
 // only): 64 rows, a wave owns 32 rows x 32 channels, 41.6 KB of LDS, three workgroups per CU - more weight-slab traffic
 // and LDS reads per MFMA, but three workgroups drift out of lockstep and cover each other's prologue / epilogue.
-template <bool FLIP, int BN, bool BF16 = false, int SUBT = 2, bool PACKED = false>
-__global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
+// X3 (PACKED only, bh_conv_desc.precision = 2): the LDS image of a halo stage is [3 pieces][4 k-planes of 8 bf16 channels]
+// [SUBT][100 halo pixels] x 16 B - the same slot geometry with 12 instead of 8 plane images (38.4 KB per stage, two stages,
+// two workgroups per CU).  The halo goes through registers (two dwordx4 per slot, cut into the three pieces, three
+// ds_write_b128) two taps after it was requested: no LDS-DMA, one bare s_barrier per chunk.  Per tap and 32x32 accumulator:
+// 6 ds_read_b128 and 12 MFMAs of 32 cycles (fp32 form: 4 reads, 16 MFMAs of 64 cycles).
+template <bool FLIP, int BN, bool BF16 = false, int SUBT = 2, bool PACKED = false, bool X3 = false>
+__global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a) {
     static_assert(SUBT == 2 || BN == 64, "one sub-tile per workgroup is built for the 64-channel tile only");
+    static_assert(!X3 || (PACKED && !BF16), "the split form exists for packed weights only");
     constexpr int TM = (BN == 64 && SUBT == 2) ? 2 : 1;
     constexpr int HPL = 100 * SUBT;                        // halo slots per k-plane
-    constexpr int HALO_B = 8 * HPL * 16;                   // bytes of one halo stage
+    constexpr int HALO_B = (X3 ? 12 : 8) * HPL * 16;       // bytes of one halo stage
+    constexpr int XJ = (4 * HPL + 255) / 256;              // X3: halo slots (of 8 channels) per thread and chunk (4 / 2)
     constexpr int HINS = (8 * HPL + 63) / 64;              // wave instructions per halo stage (25 / 13)
     constexpr int HJ = (HINS + 3) / 4;                     // ... per wave (7 / 4)
     constexpr int BINS = BN == 64 ? 2 : 1;                 // weight-slab wave instructions per wave and step
@@ -139,6 +172,15 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
             dst[q_] = __builtin_bit_cast(float4, v_);                                                                   \
         }                                                                                                               \
     } while (0)
+    // X3: [chunk][tap][n tile][piece][16-channel step][lane] x (8 bf16): six 1 KB loads per tap, dst index = piece * 2 + step
+#define C3_LOAD_BX(dst, c, tap)                                                                                         \
+    do {                                                                                                                \
+        const unsigned so_ = (unsigned)(((c) * 9 + (tap)) * a.NW + wnG) * 6144u;                                        \
+        _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) {                                                              \
+            const auto v_ = __builtin_amdgcn_raw_buffer_load_b128(rsB, pb_voff + (unsigned)q_ * 1024u, so_, 0);         \
+            dst[q_] = __builtin_bit_cast(uint4, v_);                                                                    \
+        }                                                                                                               \
+    } while (0)
     // a single chunk (32 source channels) never touches the second halo stage: the host then launches with one stage less
     // of LDS (41.6 instead of 67.2 KB: three workgroups per CU for the 32-channel layers) and the slabs move down
     const int slab0 = (a.Kc / 32 > 1 ? 2 : 1) * HALO_B;
@@ -181,6 +223,109 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
         oy0[s] = ty * 8 - 1; ox0[s] = tx * 8 - 1;
         org[s] = g < a.subtiles ? (img * a.H + oy0[s]) * a.W + ox0[s] : (int)0x80000000;
     }
+    f32x16 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    if constexpr (X3) {
+        // ---- halo slots of this thread: slot q = j*256 + tid of the [4 k-planes][SUBT][100] image (8 channels = 32 B each) ----
+        constexpr unsigned XOOB = 0x80000000u;           // (tensor sizes are below 2^31: stays out of range with the +16 / chunk offsets added)
+        uint4 bcur[6], bnext[6];
+        C3_LOAD_BX(bcur, 0, 0);
+        unsigned xoff[XJ];
+#pragma unroll
+        for (int j = 0; j < XJ; ++j) {
+            const int q = j * 256 + tid;
+            unsigned off = XOOB;
+            if (q < 4 * HPL) {
+                const int plane = SUBT == 2 ? (q * 5243) >> 20 : (q * 10486) >> 20;      // q / 200, q / 100
+                const int rem = q - plane * HPL;
+                const int s = SUBT == 2 ? (rem >= 100 ? 1 : 0) : 0, hp = rem - s * 100;
+                const int hy = (hp * 205) >> 11, hx = hp - hy * 10;
+                const int y = (s ? oy0[SUBT - 1] : oy0[0]) + hy, x = (s ? ox0[SUBT - 1] : ox0[0]) + hx;
+                const int o = s ? org[SUBT - 1] : org[0];
+                if (o != (int)0x80000000 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
+                    off = ((unsigned)(o + hy * a.W + hx) * (unsigned)a.Kc + (unsigned)(plane * 8)) * 4u;
+            }
+            xoff[j] = off;
+        }
+        // (rounds whose first slot of this wave is past the image are skipped wave-uniformly: 800 = 3 x 256 + 32 slots)
+#define X3_ISSUE(j, c, h)                                                                                               \
+    do {                                                                                                                \
+        if ((j) * 256 + wave * 64 < 4 * HPL) {                                                                          \
+            h[0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, xoff[j], (unsigned)((c) * 128), 0));       \
+            h[1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, xoff[j] + 16u, (unsigned)((c) * 128), 0)); \
+        }                                                                                                               \
+    } while (0)
+#define X3_STORE(j, hs, h)                                                                                              \
+    do {                                                                                                                \
+        if ((j) * 256 + wave * 64 < 4 * HPL && (j) * 256 + tid < 4 * HPL) {                                             \
+            uint4 p0_, p1_, p2_;                                                                                        \
+            c3_split8(h[0], h[1], p0_, p1_, p2_);                                                                       \
+            char* d_ = smem + (hs) * HALO_B + ((j) * 256 + tid) * 16;                                                   \
+            *reinterpret_cast<uint4*>(d_) = p0_;                                                                        \
+            *reinterpret_cast<uint4*>(d_ + 4 * HPL * 16) = p1_;                                                         \
+            *reinterpret_cast<uint4*>(d_ + 8 * HPL * 16) = p2_;                                                         \
+        }                                                                                                               \
+    } while (0)
+        {
+            float4 hp[XJ][2];
+#pragma unroll
+            for (int j = 0; j < XJ; ++j) X3_ISSUE(j, 0, hp[j]);
+#pragma unroll
+            for (int j = 0; j < XJ; ++j) X3_STORE(j, 0, hp[j]);
+        }
+        const int a_lane = (kh2 * HPL + wm * 100 + c3_strip_row(l31 >> 2) * 10 + wh * 4 + (l31 & 3)) * 16;
+        __syncthreads();
+        float4 hb[2][2];
+        uint4 af[TM][2][3];                            // [fragment][16-channel step][piece]
+        for (int c = 0; c < nch; ++c) {
+            const int hs = c & 1;
+            const char* hbase = smem + hs * HALO_B + a_lane;
+            const bool more = c + 1 < nch;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3, dx = tap - dy * 3;
+                const char* ap = hbase + (dy * 10 + dx) * 16;
+                if (!(dbg_noload & 4) || (tap == 0 && c == 0)) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+                            af[i][s2][pc] = *reinterpret_cast<const uint4*>(ap + (pc * 4 + 2 * s2) * (HPL * 16) + i * 64);
+                }
+                if (!(dbg_noload & 1)) {
+                if (tap < 8) C3_LOAD_BX(bnext, c, tap + 1);
+                else if (more) C3_LOAD_BX(bnext, c + 1, 0);
+                }
+                if (more && !(dbg_noload & 2)) {
+                    // the next chunk's halo: slot round j is requested at tap 2j and cut / written two taps later
+                    if ((tap & 1) == 0 && tap >= 2 && tap / 2 - 1 < XJ) X3_STORE(tap / 2 - 1, hs ^ 1, hb[(tap / 2 - 1) & 1]);
+                    if ((tap & 1) == 0 && tap / 2 < XJ) X3_ISSUE(tap / 2, c + 1, hb[(tap / 2) & 1]);
+                }
+#define X3_MFMA(s2, PA, PB)                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                      \
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i][s2][PA]),                      \
+                                                         __builtin_bit_cast(bf16x8, bcur[(PB) * 2 + (s2)]), acc[i], 0, 0, 0)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {       // small partial products first
+                    X3_MFMA(s2, 2, 0); X3_MFMA(s2, 0, 2); X3_MFMA(s2, 1, 1);
+                    X3_MFMA(s2, 1, 0); X3_MFMA(s2, 0, 1); X3_MFMA(s2, 0, 0);
+                }
+#undef X3_MFMA
+                if (tap == 8) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (!(dbg_noload & 1)) {
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) bcur[q] = bnext[q];
+                }
+            }
+        }
+#undef X3_ISSUE
+#undef X3_STORE
+    } else {
     float4 bcur[4], bnext[4];
     if constexpr (PACKED) C3_LOAD_B(bcur, 0, 0);
     else issue_B(0, 0, 0);                       // the first weight slab goes out before any of the slot arithmetic
@@ -202,12 +347,6 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
         hoff[j] = off;
         C3_ISSUE_HALO(j, 0, 0);              // in flight while the next slot's offset is computed
     }
-    f32x16 acc[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
-
     // lane-constant parts of the fragment addresses (bytes)
     // GEMM row l31 of a wave's 32-row fragment <-> pixel (c3_strip_row(l31 >> 2), 4 * strip + (l31 & 3)) of the 8x8 sub-tile:
     // an 8-row x 4-column strip, strip = wh for the 32-row waves, = the fragment index i for the 64-row waves.
@@ -332,9 +471,11 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(C3Args a) {
         }
     }
     }
+    }
 #undef C3_ISSUE_HALO
 #undef issue_B
 #undef C3_LOAD_B
+#undef C3_LOAD_BX
 
     // ---- epilogue: C/D layout col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m) ----
     // Element (i, r) of a lane is pixel (c3_strip_row(2*(r>>2) + kh2), 4*(i + wh) + (r&3)) of the sub-tile: the row part of
@@ -507,7 +648,7 @@ BH_KNOB(g_c3_noload, 0); BH_KNOB(g_c3_dbg_nch, -1); BH_KNOB(g_c3_subt, 2); BH_KN
 void bh_conv3x3_tune(int disable, int min_blocks) {
     (void)min_blocks;
     if (disable <= -100) { g_c3_dbg_nch = -100 - disable - 1; return; }            // -100 -> -1 (all), -101 -> 0 chunks, -102 -> 1 ...
-    if (disable >= 60 && disable < 64) { g_c3_noload = disable - 60; return; }
+    if (disable >= 60 && disable < 68) { g_c3_noload = disable - 60; return; }
     if (disable >= 20 && disable < 24) { g_c3_tpb = disable - 20; return; }        // tile positions per workgroup on two-round launches (1 / 2)
     if (disable >= 11 && disable <= 13) { g_c3_subt = disable - 10; return; }      // 1 / 2 (automatic) / 3 (always two) sub-tiles per workgroup
 }
@@ -520,14 +661,17 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
     *taken = 0;
     // (packed weights only make sense to this kernel: a caller that passes them must have asked bh_conv_variant first)
     if ((d->route & BH_ROUTE_GENERIC_CONV) || d->transposed || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->in_nchw ||
-        d->out_nchw || (d->precision != 0 && d->precision != 1))
+        d->out_nchw || d->precision < 0 || d->precision > 2)
         return d->w_layout ? BH_E_UNSUPPORTED : 0;
+    if ((d->w_layout == 2) != (d->precision == 2 && d->w_layout != 0)) return BH_E_BADARG;      // split weights <-> precision 2
     if (d->Hi % 8 || d->Wi % 8 || d->Ho != d->Hi || d->Wo != d->Wi) return d->w_layout ? BH_E_UNSUPPORTED : 0;
     const int Kc = dgrad ? d->Co : d->Ci, Nn = dgrad ? d->Ci : d->Co;
     if (Kc % 32 || Nn % 32) return d->w_layout ? BH_E_UNSUPPORTED : 0;
     const int bn_tile = (Nn % 64) ? 32 : 64;
-    const bool packed = d->w_layout == 1;              // weights in bh_conv3x3_pack fragment order (this direction's buffer)
-    const long long src_bytes = (long long)d->N * d->Hi * d->Wi * Kc * 4, w_bytes = (long long)d->Co * 9 * d->Ci * 4;
+    const bool packed = d->w_layout != 0;              // weights in bh_conv3x3_pack fragment order (this direction's buffer)
+    const bool x3 = d->w_layout == 2;                  // ... cut into three bf16 pieces (6 bytes per weight)
+    const bool bf16 = d->precision == 1;               // (precision 2 without split weights runs the exact fp32 form)
+    const long long src_bytes = (long long)d->N * d->Hi * d->Wi * Kc * 4, w_bytes = (long long)d->Co * 9 * d->Ci * (x3 ? 6 : 4);
     const long long out_bytes = (long long)d->N * d->Hi * d->Wi * Nn * 4;
     if (src_bytes >= (1ll << 31) || w_bytes >= (1ll << 31) || out_bytes >= (1ll << 31)) return 0;
     C3Args a = {};
@@ -566,8 +710,8 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
     }
     if (!(d->route & BH_ROUTE_HALO_SMALL) && (int)(((a.subtiles + 1) / 2) * grid.y) < C3_MIN_BLOCKS) return d->w_layout ? BH_E_UNSUPPORTED : 0;
     a.NW = Nn / 32;
-    if (bh_query(packed ? "conv3x3_halo_kernel<%s,%d,%s,%d,true>" : "conv3x3_halo_kernel<%s,%d,%s,%d>", dgrad ? "true" : "false", bn_tile,
-                 d->precision == 1 ? "true" : "false", subt)) {
+    if (bh_query(x3 ? "conv3x3_halo_kernel<%s,%d,%s,%d,true,true>" : packed ? "conv3x3_halo_kernel<%s,%d,%s,%d,true>" : "conv3x3_halo_kernel<%s,%d,%s,%d>",
+                 dgrad ? "true" : "false", bn_tile, bf16 ? "true" : "false", subt)) {
         *taken = 1;
         return BH_OK;
     }
@@ -579,22 +723,27 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
                   conv3x3_halo_kernel<false, 32, true, 2, P>,  conv3x3_halo_kernel<true, 32, true, 2, P>,    \
                   conv3x3_halo_kernel<false, 64, false, 1, P>, conv3x3_halo_kernel<true, 64, false, 1, P>,   \
                   conv3x3_halo_kernel<false, 64, true, 1, P>,  conv3x3_halo_kernel<true, 64, true, 1, P>
-    static const kern_t fns[24] = {C3_ROW(false), C3_ROW(true)};
+    static const kern_t fns[30] = {C3_ROW(false), C3_ROW(true),
+                                   conv3x3_halo_kernel<false, 64, false, 2, true, true>, conv3x3_halo_kernel<true, 64, false, 2, true, true>,
+                                   conv3x3_halo_kernel<false, 32, false, 2, true, true>, conv3x3_halo_kernel<true, 32, false, 2, true, true>,
+                                   conv3x3_halo_kernel<false, 64, false, 1, true, true>, conv3x3_halo_kernel<true, 64, false, 1, true, true>};
 #undef C3_ROW
     constexpr int HALO2 = 8 * 200 * 16, HALO1 = 8 * 100 * 16;          // one halo stage: two / one sub-tile per workgroup
     constexpr int LDS1 = 2 * HALO1 + 2 * C3_B_BYTES;                   // one sub-tile per workgroup: 41,984 B
+    constexpr int XHALO2 = 12 * 200 * 16, XHALO1 = 12 * 100 * 16;      // split form: 12 plane images per stage
     if (bh_device_once(attr_devs)) {
-        for (int i = 0; i < 24; ++i) {
+        for (int i = 0; i < 30; ++i) {
             const int j = i % 12;
-            const int full = i < 12 ? (j < 8 ? C3_LDS_BYTES : LDS1) : 2 * (j < 8 ? HALO2 : HALO1);
+            const int full = i >= 24 ? 2 * (i < 28 ? XHALO2 : XHALO1) : i < 12 ? (j < 8 ? C3_LDS_BYTES : LDS1) : 2 * (j < 8 ? HALO2 : HALO1);
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[i]), hipFuncAttributeMaxDynamicSharedMemorySize, full);
             if (e != hipSuccess) return (int)e;
         }
     }
-    const kern_t fn = fns[(packed ? 12 : 0) + (subt == 1 ? 8 + (d->precision == 1 ? 2 : 0) + (dgrad ? 1 : 0)
-                                                         : (d->precision == 1 ? 4 : 0) + (bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0))];
+    const kern_t fn = x3 ? fns[24 + (subt == 1 ? 4 : bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0)]
+                         : fns[(packed ? 12 : 0) + (subt == 1 ? 8 + (bf16 ? 2 : 0) + (dgrad ? 1 : 0)
+                                                              : (bf16 ? 4 : 0) + (bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0))];
     a.dbg_noload = g_c3_noload;
-    const int stage = subt == 1 ? HALO1 : HALO2;
+    const int stage = x3 ? (subt == 1 ? XHALO1 : XHALO2) : subt == 1 ? HALO1 : HALO2;
     const int lds = packed ? (Kc / 32 > 1 ? 2 : 1) * stage                                    // halo stages only
                            : (subt == 1 ? LDS1 : C3_LDS_BYTES) - (Kc / 32 > 1 ? 0 : stage);   // single chunk: one halo stage
     hipLaunchKernelGGL(fn, grid, dim3(256), lds, stream, a);
@@ -614,6 +763,38 @@ __global__ void __launch_bounds__(256) pack_conv3x3_weights_kernel(const bh_pack
     const int Co = j.Co, Ci = j.Ci;
     const long long n4 = (long long)Co * 9 * Ci / 4;
     const float4* __restrict__ w4 = reinterpret_cast<const float4*>(j.w);
+    if (j.split) {
+        // [chunk][tap][n tile][piece][16-channel step s2][lane] x (8 bf16): lane (l31, kh2) holds k = chunk*32 + (2*s2 + kh2)*8 + e
+        const long long n8 = (long long)Co * 9 * Ci / 8;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+            const int lane = (int)(i & 63), s2 = (int)((i >> 6) & 1);
+            const int l31 = lane & 31, kh2 = lane >> 5;
+            const long long r = i >> 7;
+            for (int dir = 0; dir < 2; ++dir) {
+                float* const dst = dir ? j.pd : j.pf;
+                if (!dst) continue;
+                const int NW = (dir ? Ci : Co) / 32;
+                const int nt = (int)(r % NW); const long long r2 = r / NW;
+                const int tap = (int)(r2 % 9), c = (int)(r2 / 9);
+                const int n = nt * 32 + l31, k0 = c * 32 + (2 * s2 + kh2) * 8;
+                float4 u, v;
+                if (!dir) {
+                    const float4* src = reinterpret_cast<const float4*>(j.w + ((long long)(n * 9 + tap) * Ci + k0));
+                    u = src[0]; v = src[1];
+                } else {
+                    const float* src = j.w + ((long long)k0 * 9 + (8 - tap)) * Ci + n;
+                    const long long ks = 9ll * Ci;
+                    u = make_float4(src[0], src[ks], src[2 * ks], src[3 * ks]);
+                    v = make_float4(src[4 * ks], src[5 * ks], src[6 * ks], src[7 * ks]);
+                }
+                uint4 p0, p1, p2;
+                c3_split8(u, v, p0, p1, p2);
+                uint4* const o = reinterpret_cast<uint4*>(dst) + (r * 6 + s2) * 64 + lane;
+                o[0] = p0; o[2 * 64] = p1; o[4 * 64] = p2;
+            }
+        }
+        return;
+    }
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         const int lane = (int)(i & 63), q = (int)((i >> 6) & 3);
         const int l31 = lane & 31, kh2 = lane >> 5;

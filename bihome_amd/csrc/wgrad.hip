@@ -782,7 +782,7 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
     }
     dim3 grid(tiles, ty, split);
     if (ws && small) return BH_E_UNSUPPORTED;
-    if (small && vec && !a.p_nchw && (a.T == 9 || a.T == 4) && d->precision == 0) {
+    if (small && vec && !a.p_nchw && (a.T == 9 || a.T == 4) && d->precision != 1) {
         // taps-fused: one launch dimension less, pixel ranges sized for ~2048 wave-level work items
         const int groups_y = (a.T == 9) ? 3 : 2;        // 3 taps (T = 9) or 2 taps (T = 4) per wave: 48 / 32 accumulator regs
         int sp = (2048 + tiles * groups_y - 1) / (tiles * groups_y);
@@ -799,7 +799,7 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
         if (bh_query("wgrad_small_kernel<%s>", vec ? "true" : "false")) return BH_OK;
         if (vec) hipLaunchKernelGGL((wgrad_small_kernel<true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((wgrad_small_kernel<false>), grid, dim3(256), 0, s, a);
-    } else if (!(d->route & BH_ROUTE_WGRAD_GENERIC) && vec && a.use_buf && (d->precision == 0 || d->precision == 1) && !d->transposed && d->stride == 1 && d->Ho == d->Hi &&
+    } else if (!(d->route & BH_ROUTE_WGRAD_GENERIC) && vec && a.use_buf && d->precision >= 0 && d->precision <= 2 && !d->transposed && d->stride == 1 && d->Ho == d->Hi &&
                d->Wo == d->Wi && a.hwshift >= 0 && a.M % WBK == 0 && a.Np % 64 == 0 && a.Nq % 64 == 0 && !a.xcd_map) {
         // taps per workgroup: in bf16 mode the loop is so short that the launch is bound by its operand traffic (each tap
         // re-reads x and gy: 320 MB per launch) - three taps per workgroup share gy and a third of it goes away

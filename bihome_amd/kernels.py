@@ -282,7 +282,12 @@ def bihome_loss_bwd(g_loss, f1, f2, f1w, f2w, m1w, m2w, m1, m2, M1, M2, numden, 
 # ------------------------------------------------------------------------------------------------
 # conv stacks
 # ------------------------------------------------------------------------------------------------
-PRECISION = {"f32": 0, "fp32": 0, "bf16": 1}
+# conv arithmetic (bh_conv_desc.precision).  'f32' (default) asks for fp32 ACCURACY and lets the library pick the evaluation:
+# the packed 3x3 kernels cut every fp32 operand exactly into three bf16 pieces and accumulate the six partial products of
+# order <= 2 in fp32 on the bf16 matrix pipe (precision 2, "f32x3": error against float64 at or below that of the fp32-input
+# MFMA form, tests/test_conv_kernels_gpu.py::test_conv3x3_f32x3_*), everything else runs v_mfma_f32_32x32x2_f32.
+# 'f32-mfma' forces the fp32-input MFMA everywhere (precision 0); 'bf16' rounds the operands to bf16 (precision 1).
+PRECISION = {"f32": 2, "fp32": 2, "f32x3": 2, "f32-mfma": 0, "bf16": 1}
 _ENV_ROUTE = int(os.environ.get("BIHOME_ROUTE", "0"))     # benchmarks: OR these BH_ROUTE_* bits into every conv descriptor
 
 
@@ -323,7 +328,9 @@ class WeightPacker:
     ONE bh_conv3x3_pack launch whenever a parameter version changed (every optimizer step in training, once for frozen
     weights).  Buffers and the device job table are allocated once (addresses stay fixed: HIP-graph safe)."""
 
-    def __init__(self):
+    def __init__(self, split=False):
+        self.split = bool(split)   # three bf16 pieces per weight (bh_conv_desc.w_layout 2) instead of fp32 fragments (1)
+        self.layout = 2 if split else 1
         self.entries = {}          # id(weight) -> (weight, pf, pd)
         self.table = None
         self.versions = None
@@ -333,8 +340,9 @@ class WeightPacker:
         e = self.entries.get(id(weight))
         if e is None:
             Co, Ci = weight.shape[0], weight.shape[1]
-            pf = torch.empty(weight.numel(), dtype=torch.float32, device=weight.device)
-            pd = torch.empty(weight.numel(), dtype=torch.float32, device=weight.device) if need_dgrad else None
+            n = weight.numel() * 3 // 2 if self.split else weight.numel()
+            pf = torch.empty(n, dtype=torch.float32, device=weight.device)
+            pd = torch.empty(n, dtype=torch.float32, device=weight.device) if need_dgrad else None
             e = self.entries[id(weight)] = (weight, pf, pd)
             self.table = None
         return e[1], e[2]
@@ -357,7 +365,7 @@ class WeightPacker:
                 if not w.permute(0, 2, 3, 1).is_contiguous():
                     raise RuntimeError("conv weight is not in kernel (channels_last) layout")
                 j.w, j.pf, j.pd = w.data_ptr(), pf.data_ptr(), (pd.data_ptr() if pd is not None else None)
-                j.Co, j.Ci = w.shape[0], w.shape[1]
+                j.Co, j.Ci, j.split = w.shape[0], w.shape[1], int(self.split)
             raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8)
             dev = next(iter(self.entries.values()))[0].device
             self.table = raw.to(dev)
@@ -374,7 +382,7 @@ def conv_fwd(x, w, bias, d, bn_sums=None, groups=1, res=None, relu=False, wpacke
     _chk(x); _chk(w); _chk(bias); _chk(res)
     y = torch.empty(conv_out_shape(d), dtype=torch.float32, device=x.device)
     if wpacked is not None:
-        d, w = (getattr(d, "bh_packed", None) or _with_layout(d, 1)), wpacked
+        d, w = (getattr(d, "bh_packed", None) or _with_layout(d, 2 if d.precision == 2 else 1)), wpacked
     with _Timed(_conv_variant(d, "fwd", bn_groups=groups if bn_sums is not None else 0), conv_flops(d),
                 4.0 * (x.numel() + y.numel() + w.numel())):
         if res is not None or relu:
@@ -438,7 +446,7 @@ def conv_dgrad(gy, w, d, out=None, bn_reduce=None, wkey=None, wpacked=None, cols
     bn_stats_buffer) in the conv epilogue; pass them to bn_bwd(..., sums_ready=sums)."""
     _chk(gy); _chk(w)
     if wpacked is not None:
-        d, w = (getattr(d, "bh_packed", None) or _with_layout(d, 1)), wpacked
+        d, w = (getattr(d, "bh_packed", None) or _with_layout(d, 2 if d.precision == 2 else 1)), wpacked
     if colsum is not None:
         assert out is None and bn_reduce is None
         _chk(colsum, torch.float64)

@@ -200,7 +200,7 @@ def _conv_geometry(mod, x_shape, in_nchw, out_nchw, precision=0):
     d = _conv_geometry_uncached(mod, x_shape, in_nchw, out_nchw, precision)
     d.bh_packs = bool(isinstance(mod, nn.Conv2d) and K.packs_3x3(d))
     d.bh_reduce_ok = bool(isinstance(mod, nn.Conv2d) and K.dgrad_bn_reduce_ok(d))
-    d.bh_packed = K._with_layout(d, 1) if d.bh_packs else None
+    d.bh_packed = K._with_layout(d, 2 if int(precision) == 2 else 1) if d.bh_packs else None
     _GEOM_CACHE[key] = (mod, d)
     return d
 
@@ -601,7 +601,7 @@ class Runner:
 
     def __init__(self, module, prog, trainable, precision="f32", fold_cache=None):
         self.module, self.prog = module, prog
-        self.precision = K.PRECISION[str(precision).lower()]     # conv operand precision (0 fp32, 1 bf16 operands)
+        self.precision = K.PRECISION[str(precision).lower()]     # conv operand precision (0 fp32, 1 bf16 operands, 2 f32x3)
         params = [p for p in module.parameters() if p.requires_grad]
         self.flat = FlatGrads(params) if (trainable and params) else None
         self.anchor = params[0] if (trainable and params) else None
@@ -633,7 +633,7 @@ class Runner:
         if not self.use_packer:
             return None
         if self._packer is None or self._packer_dev != device:
-            pk = K.WeightPacker()
+            pk = K.WeightPacker(split=self.precision == 2)
             for op in self.prog.ops:
                 m = op.mod
                 if (op.kind == "conv" and isinstance(m, nn.Conv2d) and op.extra["weight_fn"] is None and m.kernel_size == (3, 3)

@@ -144,8 +144,13 @@ typedef struct {
     int in_nchw;            /* 1: x is NCHW (only for the network inputs, Ci <= 4) */
     int out_nchw;           /* 1: y is NCHW (only for the network output, Co <= 4) */
     int precision;          /* 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1: operands rounded to bf16 while staging,
-                             * fp32 accumulate (v_mfma_f32_32x32x16_bf16), tensors stay fp32 in HBM */
-    int w_layout;           /* 0: w is [Co][kh][kw][Ci].  1 (3x3 / stride 1 / pad 1 only): w is the fragment-ordered copy made
+                             * fp32 accumulate (v_mfma_f32_32x32x16_bf16), tensors stay fp32 in HBM; 2 ("f32x3"): fp32
+                             * accuracy on the bf16 matrix pipe - every fp32 operand is cut EXACTLY into three bf16 pieces
+                             * and the six partial products of order <= 2 are accumulated in fp32 (what is dropped is
+                             * below 2^-23 of a product, one fp32 rounding); taken by the halo-tiled 3x3 kernel with
+                             * w_layout 2, every other kernel computes precision 2 as precision 0 */
+    int w_layout;           /* 0: w is [Co][kh][kw][Ci].  2: as 1, made with bh_pack3x3_job.split = 1 (three bf16 pieces, 6 bytes
+                             * per weight; requires precision 2).  1 (3x3 / stride 1 / pad 1 only): w is the fragment-ordered copy made
                              * by bh_conv3x3_pack - its `pf` buffer for bh_conv_fwd*, its `pd` buffer for bh_conv_dgrad* -
                              * which the halo-tiled 3x3 kernel streams straight into registers; BH_E_UNSUPPORTED when
                              * that kernel does not take the launch (ask bh_conv_variant first) */
@@ -161,12 +166,15 @@ typedef struct {
 #define BH_ROUTE_C3_ONE_POSITION 64 /* fwd / dgrad: halo-tiled 3x3 kernel never walks two tile positions per workgroup */
 
 /* One 3x3 layer's weights for bh_conv3x3_pack: w[Co][3][3][Ci] (Co, Ci multiples of 32) -> pf (forward operand order) and
- * pd (dgrad operand order: transposed, taps flipped), Co*9*Ci floats each; either may be NULL. */
+ * pd (dgrad operand order: transposed, taps flipped), Co*9*Ci floats each (split: 1.5x that); either may be NULL. */
 typedef struct {
     const float* w;
     float* pf;
     float* pd;
     int Co, Ci;
+    int split;              /* 0: fp32 fragments (w_layout 1).  1: three bf16 pieces per weight (w_layout 2): pf / pd then hold
+                             * Co*9*Ci*6 bytes each */
+    int reserved;
 } bh_pack3x3_job;
 /* Packs the weights of njobs layers in one launch (jobs_dev: device array).  Call after every optimizer step (the
  * parameters changed) before the next forward; frozen layers need it once. */

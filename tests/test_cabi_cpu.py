@@ -103,6 +103,15 @@ def test_conv_variant_query_reports_the_dispatch():
     assert K.conv_variant(d8, "fwd") == "conv3x3_halo_kernel<false,64,false,1>"          # one sub-tile per workgroup
     assert K.conv_variant(K.conv_desc(128, 128, 128, 32, 32, 3, 1, 1), "fwd") == "conv3x3_halo_kernel<false,32,false,2>"
     assert K.conv_variant(K.conv_desc(128, 32, 32, 64, 64, 3, 1, 1, precision=1), "wgrad") == "wgrad_s1_kernel<3,true>"
+    # packed weights (w_layout 1: fp32 fragments, 2: three bf16 pieces with precision 2 = the default 'f32' arithmetic of the models)
+    assert K.conv_variant(K._with_layout(d, 1), "fwd") == "conv3x3_halo_kernel<false,64,false,2,true>"
+    dx = K.conv_desc(128, 32, 32, 64, 64, 3, 1, 1, precision=K.PRECISION["f32"])
+    assert dx.precision == 2 and K.PRECISION["f32-mfma"] == 0
+    assert K.conv_variant(K._with_layout(dx, 2), "fwd") == "conv3x3_halo_kernel<false,64,false,2,true,true>"
+    assert K.conv_variant(K._with_layout(dx, 2), "dgrad") == "conv3x3_halo_kernel<true,64,false,2,true,true>"
+    assert K.conv_variant(dx, "fwd") == "conv3x3_halo_kernel<false,64,false,2>" and K.conv_variant(dx, "wgrad") == "wgrad_s1_kernel<1,false>"
+    with pytest.raises(RuntimeError):
+        K.conv_variant(K._with_layout(d, 2), "fwd")                  # split weights need precision 2
     # per-call routing bits (tests / benchmarks)
     assert K.conv_variant(K.conv_desc(128, 32, 32, 64, 64, 3, 1, 1, route=ROUTE_GENERIC_CONV), "fwd").startswith("conv_gemm_kernel<64,64,")
     small = K.conv_desc(2, 8, 8, 64, 64, 3, 1, 1)

@@ -525,6 +525,90 @@ def test_conv3x3_packed_weights_match_lds_slab_path(K, N, H, Ci, Co, prec):
     assert torch.equal(y2, K.conv_fwd(x, wk, None, d))
 
 
+@pytest.mark.parametrize("N,H,Ci,Co,wide", [
+    (128, 32, 64, 64, False),    # the bench shape: two tile positions per workgroup, two chunks
+    (8, 16, 128, 128, False),    # four chunks, two n tiles
+    (8, 8, 256, 256, False),     # one sub-tile per workgroup, eight chunks
+    (4, 64, 32, 32, False),      # 32-channel tile, single chunk (one halo stage)
+    (3, 24, 96, 160, False),     # odd sub-tile count, three chunks, 64- and 32-wide n tiles
+    (5, 16, 32, 64, False),      # single chunk, odd image count
+    (8, 16, 64, 64, True),       # operands spread over 24 binades
+])
+def test_conv3x3_f32x3_is_fp32_accurate(K, N, H, Ci, Co, wide):
+    """precision 2 / w_layout 2 of the packed 3x3 kernel: every fp32 operand is cut exactly into three bf16 pieces and six
+    partial products per product run on the bf16 MFMA with fp32 accumulate.  Claim under test: this is fp32 arithmetic - the
+    error against torch float64 is no larger than that of the fp32-input MFMA kernel on the same data (measured 0.85x), for
+    forward, forward + BatchNorm sums, dgrad and accumulating dgrad; the piece split itself is exact (pack -> sum of pieces
+    = weight, bit for bit)."""
+    from bihome_amd._lib import ROUTE_HALO_SMALL
+    g = torch.Generator().manual_seed(N * 7 + H)
+    x = torch.randn(N, H, H, Ci, generator=g)
+    gy = torch.randn(N, H, H, Co, generator=g)
+    if wide:
+        x = x * torch.exp2(torch.randint(-12, 12, x.shape, generator=g).float())
+        gy = gy * torch.exp2(torch.randint(-12, 12, gy.shape, generator=g).float())
+    x, gy = x.cuda(), gy.cuda()
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * 0.05).cuda().contiguous(memory_format=torch.channels_last)
+    wk = w.permute(0, 2, 3, 1)
+    b = torch.randn(Co, generator=g).cuda()
+    xd, wd = x.double().cpu().permute(0, 3, 1, 2), w.double().cpu()
+    ref = F.conv2d(xd, wd, b.double().cpu(), 1, 1).permute(0, 2, 3, 1)
+    refd = F.conv_transpose2d(gy.double().cpu().permute(0, 3, 1, 2), wd, None, 1, 1).permute(0, 2, 3, 1)
+    err = {}
+    for prec in (0, 2):
+        d = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=prec, route=ROUTE_HALO_SMALL)
+        pk = K.WeightPacker(split=prec == 2)
+        pf, pd = pk.get(w)
+        pk.refresh()
+        dp = K._with_layout(d, 2 if prec == 2 else 1)
+        assert K.conv_variant(dp, "fwd").endswith(",true,true>" if prec == 2 else ",true>")
+        assert K.conv_variant(dp, "dgrad").endswith(",true,true>" if prec == 2 else ",true>")
+        y = K.conv_fwd(x, wk, b, d, wpacked=pf)
+        s = K.bn_stats_buffer(1, Co, "cuda")
+        assert torch.equal(y, K.conv_fwd(x, wk, b, d, bn_sums=s, groups=1, wpacked=pf))
+        yd = y.double()
+        tot = torch.stack([yd.sum((0, 1, 2)), (yd * yd).sum((0, 1, 2))], 1).cpu()
+        got = s.view(K.BN_SUM_SLOTS, 1, Co, 2, K.BN_SUM_STRIDE)[..., 0].sum(0).reshape(Co, 2).cpu()
+        close(got, tot, 1e-6)                      # (the kernel sums float partials of 4 elements in double)
+        gx = K.conv_dgrad(gy, wk, d, wpacked=pd)
+        acc = x.clone()
+        K.conv_dgrad(gy, wk, d, out=acc, wpacked=pd)
+        close(acc.cpu(), (x + gx).cpu(), 1e-6)
+        err[prec] = (((y.cpu().double() - ref).norm() / ref.norm()).item(), ((gx.cpu().double() - refd).norm() / refd.norm()).item())
+        if prec == 2:
+            # the three pieces of every packed weight add up to the weight exactly
+            pieces = pf.view(torch.int16).view(-1, 3, 2, 64, 8).to(torch.int32) << 16        # [chunk*tap*ntile][piece][step][lane][e]
+            total = pieces.view(torch.float32).double().sum(1)                               # exact in float64
+            NW = Co // 32
+            back = torch.empty(Co, 9, Ci, dtype=torch.float64, device="cuda")
+            t = total.view(Ci // 32, 9, NW, 2, 2, 32, 8)                                     # [c][tap][nt][s2][kh2][l31][e]
+            back.view(NW, 32, 9, Ci // 32, 2, 2, 8).copy_(t.permute(2, 5, 1, 0, 3, 4, 6))    # n = nt*32 + l31, k = c*32 + (2*s2 + kh2)*8 + e
+            assert torch.equal(back.float(), wk.reshape(Co, 9, Ci)) and torch.equal(back, wk.reshape(Co, 9, Ci).double())
+    assert err[2][0] <= 1.1 * err[0][0] + 1e-9 and err[2][1] <= 1.1 * err[0][1] + 1e-9, err
+    assert err[2][0] < 2e-6 and err[2][1] < 2e-6
+
+
+def test_conv3x3_f32x3_layout_and_precision_must_agree(K):
+    """w_layout 2 (split weights) <-> precision 2: a mismatch is a caller error, not a silently wrong operand format; precision 2
+    without packed weights computes as precision 0 (bit-identical to the fp32-input MFMA kernel)."""
+    x = torch.randn(8, 16, 16, 64, device="cuda")
+    w = (torch.randn(64, 64, 3, 3, device="cuda") * 0.05).contiguous(memory_format=torch.channels_last)
+    wk = w.permute(0, 2, 3, 1)
+    d0, d2 = K.conv_desc(8, 16, 16, 64, 64, 3, 1, 1, precision=0), K.conv_desc(8, 16, 16, 64, 64, 3, 1, 1, precision=2)
+    assert torch.equal(K.conv_fwd(x, wk, None, d0), K.conv_fwd(x, wk, None, d2))
+    pk = K.WeightPacker(split=True)
+    pf, _ = pk.get(w)
+    pk.refresh()
+    from bihome_amd._lib import lib, ROUTE_HALO_SMALL
+    import ctypes
+    y = torch.empty(8, 16, 16, 64, device="cuda")
+    for prec, lay in ((0, 2), (2, 1), (1, 2)):
+        d = K._with_layout(K.conv_desc(8, 16, 16, 64, 64, 3, 1, 1, precision=prec, route=ROUTE_HALO_SMALL), lay)
+        rc = lib.bh_conv_fwd(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(pf.data_ptr()), None, ctypes.c_void_p(y.data_ptr()),
+                             ctypes.byref(d), None)
+        assert rc == -1, (prec, lay, rc)            # BH_E_BADARG
+
+
 @pytest.mark.parametrize("N,H,Ci,Co", [(128, 32, 64, 64), (16, 16, 128, 128), (8, 8, 256, 256)])
 def test_wgrad_deterministic_mode_is_bitwise_repeatable(K, N, H, Ci, Co):
     """bh_conv_wgrad_det: split-K partial tiles + a fixed-order second pass instead of fp32 atomics.  Two runs give
