@@ -78,3 +78,29 @@ __device__ __forceinline__ void mat3_mul(const double* a, const double* b, doubl
 #pragma unroll
         for (int j = 0; j < 3; ++j) c[i * 3 + j] = a[i * 3] * b[j] + a[i * 3 + 1] * b[3 + j] + a[i * 3 + 2] * b[6 + j];
 }
+
+// X3 ("f32x3": fp32 result accuracy on the bf16 matrix pipe): every fp32 operand x is cut into three bf16 pieces
+// x = hi + mid + lo (truncation: 8 + 8 + 8 significand bits, so the sum is EXACT), and a product a*b is evaluated as the six
+// partial products of total order <= 2 (hi*hi, hi*mid, mid*hi, hi*lo, mid*mid, lo*hi) on v_mfma_f32_32x32x16_bf16 with fp32
+// accumulate; the three dropped ones are below 2^-23 |a*b| - the size of one fp32 rounding of the product.  Six 32-cycle
+// MFMAs contract 16 channels that cost eight 64-cycle v_mfma_f32_32x32x2_f32: 2.67x less matrix-pipe time.
+// bh_split8: 8 floats -> the 8 bf16 of each piece, element e in the low / high half of dword e/2 (5.5 VALU per element).
+__device__ __forceinline__ void bh_split8(const float4& u, const float4& v, uint4& hi, uint4& mid, uint4& lo) {
+    const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+    unsigned xb[8], rb[8], sb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        xb[e] = __builtin_bit_cast(unsigned, x[e]);
+        const float r = x[e] - __builtin_bit_cast(float, xb[e] & 0xFFFF0000u);        // exact
+        rb[e] = __builtin_bit_cast(unsigned, r);
+        const float t = r - __builtin_bit_cast(float, rb[e] & 0xFFFF0000u);           // exact, <= 8 significant bits
+        sb[e] = __builtin_bit_cast(unsigned, t);
+    }
+    // v_perm_b32: bytes 7,6 of {S0,S1} = high half of S0, bytes 3,2 = high half of S1
+    hi = make_uint4(__builtin_amdgcn_perm(xb[1], xb[0], 0x07060302u), __builtin_amdgcn_perm(xb[3], xb[2], 0x07060302u),
+                    __builtin_amdgcn_perm(xb[5], xb[4], 0x07060302u), __builtin_amdgcn_perm(xb[7], xb[6], 0x07060302u));
+    mid = make_uint4(__builtin_amdgcn_perm(rb[1], rb[0], 0x07060302u), __builtin_amdgcn_perm(rb[3], rb[2], 0x07060302u),
+                     __builtin_amdgcn_perm(rb[5], rb[4], 0x07060302u), __builtin_amdgcn_perm(rb[7], rb[6], 0x07060302u));
+    lo = make_uint4(__builtin_amdgcn_perm(sb[1], sb[0], 0x07060302u), __builtin_amdgcn_perm(sb[3], sb[2], 0x07060302u),
+                    __builtin_amdgcn_perm(sb[5], sb[4], 0x07060302u), __builtin_amdgcn_perm(sb[7], sb[6], 0x07060302u));
+}

@@ -38,32 +38,6 @@ __device__ __forceinline__ bf16x8 c3_pack_bf16(const float4& lo, const float4& h
     return __builtin_convertvector(v, bf16x8);
 }
 
-// X3 ("f32x3": fp32 result accuracy on the bf16 matrix pipe): every fp32 operand x is cut into three bf16 pieces
-// x = hi + mid + lo (truncation: 8 + 8 + 8 significand bits, so the sum is EXACT), and a product a*b is evaluated as the six
-// partial products of total order <= 2 (hi*hi, hi*mid, mid*hi, hi*lo, mid*mid, lo*hi) on v_mfma_f32_32x32x16_bf16 with fp32
-// accumulate; the three dropped ones are below 2^-23 |a*b| - the size of one fp32 rounding of the product.  Six 32-cycle
-// MFMAs contract 16 channels that cost eight 64-cycle v_mfma_f32_32x32x2_f32: 2.67x less matrix-pipe time.
-// c3_split8: 8 floats -> the 8 bf16 of each piece, element e in the low / high half of dword e/2 (5.5 VALU per element).
-__device__ __forceinline__ void c3_split8(const float4& u, const float4& v, uint4& hi, uint4& mid, uint4& lo) {
-    const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
-    unsigned xb[8], rb[8], sb[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        xb[e] = __builtin_bit_cast(unsigned, x[e]);
-        const float r = x[e] - __builtin_bit_cast(float, xb[e] & 0xFFFF0000u);        // exact
-        rb[e] = __builtin_bit_cast(unsigned, r);
-        const float t = r - __builtin_bit_cast(float, rb[e] & 0xFFFF0000u);           // exact, <= 8 significant bits
-        sb[e] = __builtin_bit_cast(unsigned, t);
-    }
-    // v_perm_b32: bytes 7,6 of {S0,S1} = high half of S0, bytes 3,2 = high half of S1
-    hi = make_uint4(__builtin_amdgcn_perm(xb[1], xb[0], 0x07060302u), __builtin_amdgcn_perm(xb[3], xb[2], 0x07060302u),
-                    __builtin_amdgcn_perm(xb[5], xb[4], 0x07060302u), __builtin_amdgcn_perm(xb[7], xb[6], 0x07060302u));
-    mid = make_uint4(__builtin_amdgcn_perm(rb[1], rb[0], 0x07060302u), __builtin_amdgcn_perm(rb[3], rb[2], 0x07060302u),
-                     __builtin_amdgcn_perm(rb[5], rb[4], 0x07060302u), __builtin_amdgcn_perm(rb[7], rb[6], 0x07060302u));
-    lo = make_uint4(__builtin_amdgcn_perm(sb[1], sb[0], 0x07060302u), __builtin_amdgcn_perm(sb[3], sb[2], 0x07060302u),
-                    __builtin_amdgcn_perm(sb[5], sb[4], 0x07060302u), __builtin_amdgcn_perm(sb[7], sb[6], 0x07060302u));
-}
-
 // pixel row (0..7) of the 8x4 strip held by lane quad q = l31 >> 2: 0 1 3 2 5 4 6 7 (see a_lane in the kernel)
 __device__ __forceinline__ int c3_strip_row(int q) { return q ^ (((q >> 1) ^ (q >> 2)) & 1); }
 
@@ -262,7 +236,7 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
     do {                                                                                                                \
         if ((j) * 256 + wave * 64 < 4 * HPL && (j) * 256 + tid < 4 * HPL) {                                             \
             uint4 p0_, p1_, p2_;                                                                                        \
-            c3_split8(h[0], h[1], p0_, p1_, p2_);                                                                       \
+            bh_split8(h[0], h[1], p0_, p1_, p2_);                                                                       \
             char* d_ = smem + (hs) * HALO_B + ((j) * 256 + tid) * 16;                                                   \
             *reinterpret_cast<uint4*>(d_) = p0_;                                                                        \
             *reinterpret_cast<uint4*>(d_ + 4 * HPL * 16) = p1_;                                                         \
@@ -788,7 +762,7 @@ __global__ void __launch_bounds__(256) pack_conv3x3_weights_kernel(const bh_pack
                     v = make_float4(src[4 * ks], src[5 * ks], src[6 * ks], src[7 * ks]);
                 }
                 uint4 p0, p1, p2;
-                c3_split8(u, v, p0, p1, p2);
+                bh_split8(u, v, p0, p1, p2);
                 uint4* const o = reinterpret_cast<uint4*>(dst) + (r * 6 + s2) * 64 + lane;
                 o[0] = p0; o[2 * 64] = p1; o[4 * 64] = p2;
             }

@@ -913,6 +913,7 @@ void bh_conv3x3_tune(int disable, int min_blocks);
 void bh_stem7_tune(int disable);
 void bh_warp_tune(int which, int n);
 void bh_bn_tune(int cap);
+void bh_wgrad_x3_tune(int what, int v);
 #endif
 int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* out, const bh_conv_desc* d, int dgrad,
                    int accumulate, hipStream_t stream, int* taken, double* bn_sums, int groups, const float* res = nullptr,
@@ -962,6 +963,9 @@ int bh_debug_force_tile(int bm, int bn) {
     if (bm == -19) { g_wgrad_s3_target = bn; return BH_OK; }             // (-19, n): workgroups per launch of the three-tap wgrad variant
     if (bm == -17) { g_wgrad_s1_target = bn; return BH_OK; }             // (-17, n): its split-K work items per launch
     if (bm == -18) { bh_conv3x3_tune(60 + bn, 0); return BH_OK; }       // (-18, bits): 3x3 kernel ablation - 1 no weight DMA, 2 no halo DMA in the loop
+    if (bm == -30) { bh_wgrad_x3_tune(0, bn); return BH_OK; }            // (-30, n): workgroups per launch of the f32x3 wgrad kernel
+    if (bm == -31) { bh_wgrad_x3_tune(1, bn); return BH_OK; }            // (-31, 1): ablation - that kernel without its atomic flush
+    if (bm == -32) { bh_wgrad_x3_tune(2, bn); return BH_OK; }            // (-32, 1|2): wave sets per workgroup
     if (bm == -20) { bh_bn_tune(bn); return BH_OK; }                     // (-20, n): workgroups per BatchNorm apply launch
     if (bm == -14) { bh_warp_tune(0, bn); return BH_OK; }               // (-14, 1|2): warp forward rows per thread
     if (bm == -15) { bh_warp_tune(1, bn); return BH_OK; }               // (-15, 1|2|4): warp adjoint rows per thread

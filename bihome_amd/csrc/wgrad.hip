@@ -8,6 +8,9 @@
 // Tile 64 (p) x 64 (q) x 32 pixels, 4 waves as 2x2, one 32x32 accumulator each.
 #include "common.h"
 
+int bh_wgrad_x3_try(const float* x, const float* gy, float* gw, const bh_conv_desc* d, hipStream_t stream, int* taken, float* ws,
+                    long long ws_bytes, long long* ws_need);    // wgrad_x3.hip
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int v4i32 __attribute__((ext_vector_type(4)));
@@ -730,6 +733,13 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
     if (!d || !x || !gy || !gw) return BH_E_BADARG;
     if (d->out_nchw && (d->Co > 4 || d->transposed)) return BH_E_UNSUPPORTED;
     hipStream_t s = bh_stream(stream);
+    if (d->precision == 2 && !(d->route & BH_ROUTE_WGRAD_GENERIC)) {
+        // f32x3 arithmetic: the halo-tiled split-operand kernel (wgrad_x3.hip) takes the 3x3 layers with channels % 64 == 0
+        int taken = 0;
+        const int rc = bh_wgrad_x3_try(x, gy, gw, d, s, &taken, ws, ws_bytes, ws_need);
+        if (rc != BH_OK) return rc;
+        if (taken) return (gbias && !bh_query_ctx) ? bh_conv_bias_grad(gy, gbias, d, stream) : BH_OK;
+    }
     WgradArgs a = {};
     a.Out = gw;
     a.T = d->kh * d->kw; a.kw = d->kw;

@@ -201,6 +201,8 @@ def _conv_geometry(mod, x_shape, in_nchw, out_nchw, precision=0):
     d.bh_packs = bool(isinstance(mod, nn.Conv2d) and K.packs_3x3(d))
     d.bh_reduce_ok = bool(isinstance(mod, nn.Conv2d) and K.dgrad_bn_reduce_ok(d))
     d.bh_packed = K._with_layout(d, 2 if int(precision) == 2 else 1) if d.bh_packs else None
+    # f32x3 weight gradient (csrc/wgrad_x3.hip): reduces its split-K partial blocks through a workspace (fixed order, cheaper than atomics)
+    d.bh_wx3 = bool(int(precision) == 2 and isinstance(mod, nn.Conv2d) and K.conv_variant(d, "wgrad").startswith("wgrad_x3"))
     _GEOM_CACHE[key] = (mod, d)
     return d
 
@@ -381,7 +383,7 @@ def side_stream(device):
     return _SIDE_STREAMS[key]
 
 
-def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=None, wgrad_stream=None, det_ws=None):
+def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=None, wgrad_stream=None, det_ws=None, x3_ws=None):
     """Adjoint of run_forward. Parameter gradients are accumulated (+=) into each parameter's `.grad`
     tensor (which must already exist, see FlatGrads). Returns the input gradient or None.
     wgrad_stream: a second HIP stream for the conv weight-gradient launches.  The backward chain on the main stream is
@@ -462,15 +464,16 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
                 if i in bias_off and has_gb:              # column sums already taken by the consumer's dgrad epilogue
                     K.bias_grad_from_sums(red_arena[bias_off[i]:bias_off[i] + K.bn_stats_doubles(1, d.Co)], gb, 1, d.Co)
                     gb = None
+                ws = det_ws if det_ws is not None else (x3_ws if getattr(d, "bh_wx3", False) else None)
                 if wgrad_stream is None:
-                    K.conv_wgrad(x, g, gw, gb, d, det_ws=det_ws)
+                    K.conv_wgrad(x, g, gw, gb, d, det_ws=ws)
                 else:
                     ev = torch.cuda.Event()
                     ev.record(main)                                   # g is final here
                     g.record_stream(wgrad_stream)
                     with torch.cuda.stream(wgrad_stream):
                         wgrad_stream.wait_event(ev)
-                        K.conv_wgrad(x, g, gw, gb, d)
+                        K.conv_wgrad(x, g, gw, gb, d, det_ws=ws if getattr(d, "bh_wx3", False) else None)     # (one stream: launches serialise on the workspace)
                 if on_param_grad is not None:       # gradient of this layer is final: its bucket may leave
                     on_param_grad(m.weight)
                     if has_gb:
@@ -591,7 +594,8 @@ class NetFunction(torch.autograd.Function):
         if r.reducer is not None:
             r.reducer.wait_streams = [side] if side is not None else []
         gin = run_backward(r.prog, ctx.saved, g.contiguous(), want_wgrad=r.flat is not None, want_input_grad=ctx.want_x,
-                           on_param_grad=hook, wgrad_stream=side, det_ws=r.det_workspace(g.device) if side is None else None)
+                           on_param_grad=hook, wgrad_stream=side, det_ws=r.det_workspace(g.device) if side is None else None,
+                           x3_ws=r.x3_workspace(g.device))
         ctx.saved = None
         return gin, None, None, None, None
 
@@ -624,6 +628,15 @@ class Runner:
         """BIHOME_DETERMINISTIC_WGRAD=1: one 40 MB workspace for the fixed-order split-K reduction of the 3x3 weight
         gradients (every launch of the stride-1 fast path stores 2048 x 16 KB partial tiles)."""
         if not self.deterministic_wgrad or self.flat is None:
+            return None
+        if self._det_ws is None or self._det_ws.device != device:
+            self._det_ws = torch.empty(10 << 20, dtype=torch.float32, device=device)
+        return self._det_ws
+
+    def x3_workspace(self, device):
+        """'f32' arithmetic (precision 2): the 40 MB workspace the f32x3 weight-gradient kernel stores its <= 256 partial blocks
+        of 147 KB in (wgrad_x3_reduce_kernel adds them in split order: those layers' gradients are bitwise reproducible)."""
+        if self.precision != 2 or self.flat is None:
             return None
         if self._det_ws is None or self._det_ws.device != device:
             self._det_ws = torch.empty(10 << 20, dtype=torch.float32, device=device)

@@ -588,6 +588,50 @@ def test_conv3x3_f32x3_is_fp32_accurate(K, N, H, Ci, Co, wide):
     assert err[2][0] < 2e-6 and err[2][1] < 2e-6
 
 
+@pytest.mark.parametrize("N,H,Ci,Co", [
+    (128, 32, 64, 64),      # the bench shape: 8 tiles per workgroup, 256 partial blocks
+    (2, 8, 64, 64),         # one tile per image (image = tile: the whole halo ring is padding), fewer tiles than CUs
+    (3, 24, 64, 128),       # non-power-of-two tile grid, two output-channel blocks
+    (8, 8, 256, 128),       # 4 x 2 channel blocks
+    (16, 16, 128, 128),
+    (5, 40, 64, 64),        # odd image count, 5 x 5 tiles
+])
+def test_wgrad_f32x3_kernel(K, N, H, Ci, Co):
+    """csrc/wgrad_x3.hip (precision 2: halo-tiled, all nine taps per workgroup, three exact bf16 pieces per operand, transposing
+    LDS reads): against torch float64 with an error no larger than the fp32-input MFMA kernel's on the same data; accumulates
+    onto gw; with a workspace the split-K reduction runs in fixed order - bitwise repeatable - and agrees with the atomics
+    form to fp32 rounding."""
+    g = torch.Generator().manual_seed(N + H + Ci)
+    x = torch.randn(N, H, H, Ci, generator=g).cuda()
+    gy = torch.randn(N, H, H, Co, generator=g).cuda()
+    w = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x.double().cpu().permute(0, 3, 1, 2), w, None, 1, 1)
+    ref = torch.autograd.grad(y, w, gy.double().cpu().permute(0, 3, 1, 2))[0].permute(0, 2, 3, 1)       # [Co][3][3][Ci]
+    err = {}
+    for prec in (0, 2):
+        d = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=prec)
+        assert K.conv_variant(d, "wgrad").startswith("wgrad_x3_kernel") == (prec == 2)
+        gw = torch.ones(Co, 3, 3, Ci, device="cuda")
+        K.conv_wgrad(x, gy, gw, None, d)
+        err[prec] = ((gw.cpu().double() - 1.0 - ref).norm() / ref.norm()).item()
+    # (both errors are fp32 ACCUMULATION rounding over N*H*W terms - the products are exact in either form; the f32x3 kernel adds
+    #  up to 512 pixels per accumulator before the split-K reduction, the fp32-MFMA one 64, hence up to ~1.2x at the bench shape)
+    assert err[2] <= 1.5 * err[0] + 1e-8 and err[2] < 2e-6, err
+    d = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=2)
+    need = K.wgrad_det_bytes(d)
+    assert 0 < need <= 40 << 20
+    ws = torch.empty(need // 4, dtype=torch.float32, device="cuda")
+    runs = []
+    for _ in range(3):
+        gw = torch.zeros(Co, 3, 3, Ci, device="cuda")
+        gb = torch.zeros(Co, device="cuda")
+        K.conv_wgrad(x, gy, gw, gb, d, det_ws=ws)
+        runs.append(gw)
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+    assert ((runs[0].cpu().double() - ref).norm() / ref.norm()).item() <= 1.5 * err[0] + 1e-8
+    close(gb.cpu(), gy.double().sum((0, 1, 2)).cpu(), 1e-5)
+
+
 def test_conv3x3_f32x3_layout_and_precision_must_agree(K):
     """w_layout 2 (split weights) <-> precision 2: a mismatch is a caller error, not a silently wrong operand format; precision 2
     without packed weights computes as precision 0 (bit-identical to the fp32-input MFMA kernel)."""
