@@ -163,7 +163,8 @@ def test_packed_weights_follow_fused_optimizer_updates(precision):
             assert not torch.equal(stale, pf)               # the last optimizer step moved the weights; refresh saw it
     l1, l0 = res[True], res[False]
     assert abs(l1[0] - l0[0]) <= (1e-5 if precision == "f32-mfma" else 1e-4) * abs(l0[0])
-    # the first forward after an update: stale copies are ~20 % off here ('f32': two different fp32-accurate evaluations have
-    # drifted apart by one optimizer step from random weights)
-    assert abs(l1[1] - l0[1]) <= (1e-3 if precision == "f32-mfma" else 1e-2) * abs(l0[1]) + 1e-3, (l1, l0)
-    assert abs(l1[2] - l0[2]) <= 5e-2 * abs(l0[2]) + 1e-2, (l1, l0)       # (two eager runs differ by ~0.5 % by now: atomics order)
+    # the first forward after an update: stale copies are ~20 % off here.  'f32': two different fp32-accurate evaluations (their
+    # step-0 losses agree to 3e-5); Adam's first update is lr * sign(g) for every parameter, so the near-zero gradient entries
+    # whose sign differs between the two move apart by 2 lr each - 3 % in the next loss from these random weights
+    assert abs(l1[1] - l0[1]) <= (1e-3 if precision == "f32-mfma" else 8e-2) * abs(l0[1]) + 1e-3, (l1, l0)
+    assert abs(l1[2] - l0[2]) <= (5e-2 if precision == "f32-mfma" else 1e-1) * abs(l0[2]) + 1e-2, (l1, l0)       # (two eager runs differ by ~0.5 % by now: atomics order)
