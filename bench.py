@@ -105,6 +105,8 @@ def pmc_traffic(kernel):
             ks = json.load(open(path))["kernels"]
         except Exception:
             continue
+        if "+" in key and all(p in ks for p in key.split("+")):        # an entry of several launches (e.g. kernel + its reduce pass)
+            return sum(ks[p]["traffic_bytes_per_launch"] for p in key.split("+")), os.path.relpath(path, ROOT)
         if key in ks:
             return ks[key]["traffic_bytes_per_launch"], os.path.relpath(path, ROOT)
     return None, None

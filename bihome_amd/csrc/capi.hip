@@ -35,7 +35,7 @@ int bh_device_arch(char* buf, int buflen) {
 }
 
 int bh_conv_variant(const bh_conv_desc* d, int which, int accumulate, int with_bnstats /* = bn_groups */, char* buf, int n) {
-    if (!d || !buf || n < 2 || which < 0 || which > 2) return BH_E_BADARG;
+    if (!d || !buf || n < 2 || which < 0 || which > 3) return BH_E_BADARG;
     BhQuery q;
     q.name[0] = 0; q.len = 0;
     // non-null placeholders: in query mode no kernel is launched and no pointer is dereferenced
@@ -45,7 +45,8 @@ int bh_conv_variant(const bh_conv_desc* d, int which, int accumulate, int with_b
     int rc;
     if (which == 0) rc = with_bnstats ? bh_conv_fwd_bnstats(p, p, nullptr, p, d, pd, with_bnstats, nullptr) : bh_conv_fwd(p, p, nullptr, p, d, nullptr);
     else if (which == 1) rc = bh_conv_dgrad(p, p, p, d, accumulate, nullptr);
-    else rc = bh_conv_wgrad(p, p, p, nullptr, d, nullptr);
+    else if (which == 2) rc = bh_conv_wgrad(p, p, p, nullptr, d, nullptr);
+    else rc = bh_conv_wgrad_det(p, p, p, nullptr, d, p, 1ll << 40, nullptr);      // 3: the workspace form
     bh_query_ctx = nullptr;
     if (rc) return rc;
     strncpy(buf, q.name, (size_t)n - 1);

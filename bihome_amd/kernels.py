@@ -56,7 +56,7 @@ def conv_variant(d, which, accumulate=False, bn_groups=0):
     v = _VARIANT_CACHE.get(key)
     if v is None:
         buf = ctypes.create_string_buffer(256)
-        check(lib.bh_conv_variant(ctypes.byref(d), {"fwd": 0, "dgrad": 1, "wgrad": 2}[which], int(bool(accumulate)), int(bn_groups),
+        check(lib.bh_conv_variant(ctypes.byref(d), {"fwd": 0, "dgrad": 1, "wgrad": 2, "wgrad_det": 3}[which], int(bool(accumulate)), int(bn_groups),
                                   buf, 256), "bh_conv_variant")
         v = _VARIANT_CACHE[key] = buf.value.decode()
     return v
@@ -503,7 +503,7 @@ def conv_wgrad(x, gy, gw, gbias, d, det_ws=None):
     if det_ws is not None:
         need = wgrad_det_bytes(d)
         if 0 < need <= det_ws.numel() * 4:
-            with _Timed((conv_variant(d, "wgrad") + "+det" if TIMING is not None else ""), conv_flops(d), 4.0 * (x.numel() + gy.numel() + gw.numel())):
+            with _Timed((conv_variant(d, "wgrad_det") if TIMING is not None else ""), conv_flops(d), 4.0 * (x.numel() + gy.numel() + gw.numel())):
                 check(lib.bh_conv_wgrad_det(_p(x), _p(gy), _p(gw), None, ctypes.byref(d), _p(det_ws), det_ws.numel() * 4, _stream()),
                       "bh_conv_wgrad_det")
             if gbias is not None:

@@ -180,7 +180,7 @@ typedef struct {
  * parameters changed) before the next forward; frozen layers need it once. */
 int bh_conv3x3_pack(const bh_pack3x3_job* jobs_dev, int njobs, void* stream);
 
-/* Which kernel a launch described by d would run: which = 0 forward, 1 dgrad, 2 wgrad.  Writes the kernel template
+/* Which kernel a launch described by d would run: which = 0 forward, 1 dgrad, 2 wgrad, 3 wgrad through a workspace (bh_conv_wgrad_det).  Writes the kernel template
  * instantiation (the symbol rocprofv3 lists, e.g. "conv3x3_halo_kernel<false,64,false,2>"; several launches joined by
  * '+') into buf[n].  Runs the real dispatch code with the launches replaced by a name record, so it cannot drift from it.
  * accumulate / bn_groups (0: plain bh_conv_fwd, > 0: bh_conv_fwd_bnstats with that many groups) mirror the arguments of
@@ -245,6 +245,8 @@ int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, cons
 /* Deterministic form of bh_conv_wgrad for the stride-1 "same" 3x3 / 5x5 / 7x7 layers its fast path takes (Co, Ci multiples
  * of 64, power-of-two maps): the split-K workgroups store their partial tiles into ws (bh_conv_wgrad_det_bytes(d) bytes, 0 =
  * shape not supported) and a second launch adds them in a fixed order - bitwise repeatable gw, no fp32 atomics.
+ * With precision 2 (f32x3: 3x3 layers, H and W multiples of 8, channels multiples of 64) this is the FAST form - the kernel
+ * keeps one 64 x 9 x 64 block per workgroup and storing + reducing <= 256 of them costs less than the atomics tail.
  * BH_E_UNSUPPORTED for other shapes (use bh_conv_wgrad). */
 long long bh_conv_wgrad_det_bytes(const bh_conv_desc* d);
 int bh_conv_wgrad_det(const float* x, const float* gy, float* gw, float* gbias, const bh_conv_desc* d, float* ws, long long ws_bytes,
