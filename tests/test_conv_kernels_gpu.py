@@ -632,6 +632,36 @@ def test_wgrad_f32x3_kernel(K, N, H, Ci, Co):
     close(gb.cpu(), gy.double().sum((0, 1, 2)).cpu(), 1e-5)
 
 
+def test_conv3x3_f32x3_error_bound_under_cancellation(K):
+    """Worst case for a split-operand scheme: dot products whose terms cancel (the result is ~1e-4 of sum |a||b|), operands with
+    all 24 significand bits set, and weights whose three pieces have mixed signs after the cut.  The ABSOLUTE error of every
+    output against float64, in units of sum_k |a_k||b_k| * 2^-24 (one fp32 ulp of the magnitude being accumulated), must stay
+    within a small constant for f32x3 - and does not exceed what the fp32-input MFMA kernel shows on the same data."""
+    from bihome_amd._lib import ROUTE_HALO_SMALL
+    N, H, Ci, Co = 8, 16, 64, 64
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(N, H, H, Ci, generator=g)
+    x = (x.view(torch.int32) | 0x7FF).view(torch.float32)                   # low mantissa bits all set
+    w = torch.randn(Co, Ci, 3, 3, generator=g) * 0.05
+    w[:, 1::2] = -w[:, 0::2] * (1.0 + 1e-4 * torch.randn(Co, Ci // 2, 3, 3, generator=g))     # channel pairs nearly cancel when x is smooth
+    x[..., 1::2] = x[..., 0::2] * (1.0 + 1e-4 * torch.randn(N, H, H, Ci // 2, generator=g))
+    x, w = x.cuda(), w.cuda().contiguous(memory_format=torch.channels_last)
+    wk = w.permute(0, 2, 3, 1)
+    xd, wd = x.double().cpu().permute(0, 3, 1, 2), w.double().cpu()
+    ref = F.conv2d(xd, wd, None, 1, 1).permute(0, 2, 3, 1)
+    mag = F.conv2d(xd.abs(), wd.abs(), None, 1, 1).permute(0, 2, 3, 1)      # sum |a||b| per output
+    assert (ref.abs() / mag).median() < 1e-3                                  # the case really cancels
+    ulps = {}
+    for prec in (0, 2):
+        d = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=prec, route=ROUTE_HALO_SMALL)
+        pk = K.WeightPacker(split=prec == 2)
+        pf, _ = pk.get(w)
+        pk.refresh()
+        y = K.conv_fwd(x, wk, None, d, wpacked=pf)
+        ulps[prec] = ((y.cpu().double() - ref).abs() / (mag * 2.0 ** -24)).max().item()
+    assert ulps[2] <= max(1.25 * ulps[0], 4.0) and ulps[2] < 16.0, ulps      # (K = 576 terms: a few ulps of the accumulated magnitude)
+
+
 def test_conv3x3_f32x3_layout_and_precision_must_agree(K):
     """w_layout 2 (split weights) <-> precision 2: a mismatch is a caller error, not a silently wrong operand format; precision 2
     without packed weights computes as precision 0 (bit-identical to the fp32-input MFMA kernel)."""
