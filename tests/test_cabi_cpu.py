@@ -109,9 +109,11 @@ def test_conv_variant_query_reports_the_dispatch():
     assert dx.precision == 2 and K.PRECISION["f32-mfma"] == 0
     assert K.conv_variant(K._with_layout(dx, 2), "fwd") == "conv3x3_halo_kernel<false,64,false,2,true,true>"
     assert K.conv_variant(K._with_layout(dx, 2), "dgrad") == "conv3x3_halo_kernel<true,64,false,2,true,true>"
-    assert K.conv_variant(dx, "fwd") == "conv3x3_halo_kernel<false,64,false,2>" and K.conv_variant(dx, "wgrad") == "wgrad_x3_kernel<0>"
+    assert K.conv_variant(dx, "fwd") == "conv3x3_halo_kernel<false,64,false,2>" and K.conv_variant(dx, "wgrad") == "wgrad_x3_kernel<64>"
     assert K.wgrad_det_bytes(dx) == 256 * 36864 * 4                       # 256 partial blocks of 64 x 9 x 64
-    assert K.conv_variant(K.conv_desc(128, 64, 64, 32, 32, 3, 1, 1, precision=2), "wgrad") == "wgrad_small_taps_kernel<3>"     # channels % 64
+    d32 = K.conv_desc(128, 64, 64, 32, 32, 3, 1, 1, precision=2)
+    assert K.conv_variant(d32, "wgrad") == "wgrad_x3_kernel<32>" and K.conv_variant(d32, "wgrad_det") == "wgrad_x3_kernel<32>+wgrad_x3_reduce_kernel<32>"
+    assert K.conv_variant(K.conv_desc(128, 128, 128, 16, 16, 3, 1, 1, precision=2), "wgrad").startswith("wgrad_small")           # channels % 32
     with pytest.raises(RuntimeError):
         K.conv_variant(K._with_layout(d, 2), "fwd")                  # split weights need precision 2
     # per-call routing bits (tests / benchmarks)

@@ -59,7 +59,7 @@ def run(N, H, Ci, Co, time_it=True):
 
 
 if __name__ == "__main__":
-    for shp in ((2, 8, 64, 64), (4, 16, 64, 64), (3, 24, 64, 128), (8, 8, 256, 128), (16, 16, 128, 128)):
+    for shp in ((2, 8, 64, 64), (3, 24, 64, 128), (8, 8, 256, 128), (4, 64, 32, 32), (3, 24, 32, 96)):
         run(*shp, time_it=False)
-    for shp in ((128, 32, 64, 64), (128, 16, 128, 128), (128, 8, 256, 256), (128, 64, 64, 64)):
+    for shp in ((128, 32, 64, 64), (128, 16, 128, 128), (128, 8, 256, 256), (128, 64, 64, 64), (128, 64, 32, 32), (128, 128, 32, 32)):
         run(*shp)
