@@ -14,9 +14,11 @@
 // tile (64 pixels) and the x halo (10x10 pixels) are loaded ONCE for the nine taps (the fp32-MFMA kernel wgrad_s1_kernel
 // re-reads both per tap: 320 MB per launch against 50 MB algorithmic), cut into the three pieces in registers and written
 // to LDS.  Two LDS images: while the MFMAs of tile k read image k & 1, the same waves cut tile k + 1 out of the registers
-// its loads arrived in and write it to the other image - in the MFMA stream, one scheduling region per tile (branch-free
-// staging, multiply-high tile decoding, fragments double-buffered in source, two accumulators alternating, a
-// sched_group_barrier pattern of one MFMA : one LDS read : three VALU) - then request tile k + 2; one barrier per tile.
+// its loads arrived in and write it to the other image - inside the MFMA stream (multiply-high tile decoding, fragments
+// double-buffered in source, two accumulators alternating) - then request tile k + 2; one barrier per tile.  (Spreading the
+// cut-and-write VALU work evenly between the MFMAs - branch-free tile step, sched_group_barrier pattern of one MFMA : one
+// LDS read : three VALU - measured 2-12 % SLOWER than leaving it in three bursts: an instruction between two MFMAs costs
+// more than its issue slot.)
 //   CB = 64: 36 accumulators of 32x32, nine per wave (wave = cout half x cin half), each wave runs the four 16-pixel steps
 //            of a tile: 216 MFMAs and ~170 transposing reads per wave and tile.
 //   CB = 32: 9 accumulators; the four waves split the PIXELS of a tile (wave w takes the w-th 16-pixel step) and each
@@ -228,17 +230,6 @@ __global__ void __launch_bounds__(256, 1) wgrad_x3_kernel(WX3Args a) {
             }
 #undef WX_MM0
         }
-        // desired issue order: one MFMA, then at most one fragment read, three VALU, and now and then a store / load
-#pragma unroll
-        for (int g = 0; g < NSTEP; ++g)
-#pragma unroll
-            for (int h = 0; h < 6; ++h) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);     // VALU
-                if (h == 5) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);    // DS write
-                if (h == 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // VMEM read
-            }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // (LDS only: the requested tile stays in flight)
     }
 #undef WX_LOAD_A
