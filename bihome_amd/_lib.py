@@ -32,6 +32,10 @@ class BhBnReduce(Structure):
                 ("eps", c_float), ("relu", c_int)]
 
 
+class BhBnIn(Structure):
+    _fields_ = [("table", c_void_p), ("groups", c_int), ("relu", c_int)]
+
+
 P = c_void_p
 # name -> argtypes (all return int).  Must list every symbol include/bihome.h declares.
 SIGNATURES = {
@@ -58,6 +62,9 @@ SIGNATURES = {
     "bh_conv_fwd": [P, P, P, P, POINTER(BhConvDesc), P],
     "bh_conv_fwd_act": [P, P, P, P, P, POINTER(BhConvDesc), c_int, P],
     "bh_conv_fwd_bnstats": [P, P, P, P, POINTER(BhConvDesc), P, c_int, P],
+    "bh_conv_fwd_bnin": [P, P, P, P, POINTER(BhConvDesc), P, c_int, POINTER(BhBnIn), P],
+    "bh_conv_wgrad_bnin": [P, P, P, P, POINTER(BhConvDesc), P, c_int64, POINTER(BhBnIn), P],
+    "bh_bn_fwd_coeffs": [P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, P, P],
     "bh_conv_dgrad": [P, P, P, POINTER(BhConvDesc), c_int, P],
     "bh_conv_dgrad_colsum": [P, P, P, POINTER(BhConvDesc), P, P],
     "bh_bias_grad_from_sums": [P, P, c_int, c_int, P],

@@ -402,6 +402,23 @@ static int apply_blocks(const BnGeom& g) {
     return nb;
 }
 
+// Coefficient table of a training-mode BatchNorm whose APPLY rides in its consumer (bh_conv_fwd_bnin / bh_conv_wgrad_bnin):
+// table[grp][c] = (scale, shift) with y = x * scale + shift, from the forward sums; workgroup 0 also makes the running-statistics
+// update that bh_bn_fwd would have made.  grid ceil(groups * C / 256).
+__global__ void __launch_bounds__(256) bn_fwd_coeffs_kernel(const double* __restrict__ stats, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, BnGeom g, float eps, float momentum,
+                                                            float* __restrict__ upd_mean, float* __restrict__ upd_var,
+                                                            float2* __restrict__ table) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < g.groups * g.C) {
+        const int grp = i / g.C, c = i - grp * g.C;
+        float mean, invstd, sc, sh;
+        bn_coeffs(stats, gamma, beta, nullptr, nullptr, 0, g.groups, grp, g.C, c, eps, (double)g.rows, mean, invstd, sc, sh);
+        table[i] = make_float2(sc, sh);
+    }
+    if (upd_mean && blockIdx.x == 0) bn_update_running(stats, g, momentum, upd_mean, upd_var);
+}
+
 // per-channel sums of an NHWC tensor into caller-zeroed sums[groups][C][2] (used by bh_bn_fwd and by the conv entry
 // point that hands the statistics to the BatchNorm that follows it)
 int bn_launch_stats(const float* x, int groups, int rows, int C, double* sums, hipStream_t s) {
@@ -432,6 +449,18 @@ int bh_bn_fwd(const float* x, const float* gamma, const float* beta, float* runn
     hipLaunchKernelGGL(bn_apply_kernel, dim3(apply_blocks(g), groups), dim3(256), 0, s, x, gamma, beta, running_mean,
                        running_var, res, y, stats, g, eps, flags, use_running, momentum, upd ? running_mean : nullptr,
                        upd ? running_var : nullptr);
+    BH_LAUNCH_CHECK();
+    return BH_OK;
+}
+
+int bh_bn_fwd_coeffs(const double* stats, const float* gamma, const float* beta, float* running_mean, float* running_var, int groups,
+                     int rows, int C, float eps, float momentum, float* table, void* stream) {
+    BnGeom g;
+    if (!stats || !table) return BH_E_BADARG;
+    if (!bn_geom(groups, rows, C, g)) return BH_E_UNSUPPORTED;
+    const bool upd = running_mean && running_var;
+    hipLaunchKernelGGL(bn_fwd_coeffs_kernel, dim3((groups * C + 255) / 256), dim3(256), 0, bh_stream(stream), stats, gamma, beta, g, eps,
+                       momentum, upd ? running_mean : nullptr, upd ? running_var : nullptr, reinterpret_cast<float2*>(table));
     BH_LAUNCH_CHECK();
     return BH_OK;
 }

@@ -71,6 +71,11 @@ struct C3Args {
     int dbg_nch;           // ablation: number of channel chunks to run (-1 = all)
     int tpb, gx_total;     // tile positions per workgroup (see the loop in the kernel), total positions along x
     int NW;                // PACKED: number of 32-wide output-channel tiles (Nn / 32)
+    // X3 forward with BNI: Src is the INPUT of a training-mode BatchNorm (+ReLU) whose output this convolution consumes; the halo
+    // staging applies y = max(x * scale + shift, lo) per channel on the way to LDS (padding stays zero), so that BatchNorm's
+    // output tensor never exists.  bni: table[groups][Kc] x (scale, shift) of bh_bn_fwd_coeffs, copied to LDS at bni_lds
+    const float* bni;
+    int bni_relu, bni_ipg, bni_groups, bni_lds;
     int dbg_noload;        // ablation bits: 1 no weight-slab DMA in the loop, 2 no halo DMA in the loop (wrong results, timing only)
 };
 
@@ -91,10 +96,11 @@ constexpr int C3_LDS_BYTES = 2 * C3_HALO_BYTES + 2 * C3_B_BYTES;      // 67584
 // two workgroups per CU).  The halo goes through registers (two dwordx4 per slot, cut into the three pieces, three
 // ds_write_b128) two taps after it was requested: no LDS-DMA, one bare s_barrier per chunk.  Per tap and 32x32 accumulator:
 // 6 ds_read_b128 and 12 MFMAs of 32 cycles (fp32 form: 4 reads, 16 MFMAs of 64 cycles).
-template <bool FLIP, int BN, bool BF16 = false, int SUBT = 2, bool PACKED = false, bool X3 = false>
+template <bool FLIP, int BN, bool BF16 = false, int SUBT = 2, bool PACKED = false, bool X3 = false, bool BNI = false>
 __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a) {
     static_assert(SUBT == 2 || BN == 64, "one sub-tile per workgroup is built for the 64-channel tile only");
     static_assert(!X3 || (PACKED && !BF16), "the split form exists for packed weights only");
+    static_assert(!BNI || (X3 && !FLIP), "the BatchNorm-on-load form is a forward f32x3 kernel");
     constexpr int TM = (BN == 64 && SUBT == 2) ? 2 : 1;
     constexpr int HPL = 100 * SUBT;                        // halo slots per k-plane
     constexpr int HALO_B = (X3 ? 12 : 8) * HPL * 16;       // bytes of one halo stage
@@ -179,6 +185,13 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
     // A workgroup walks a.tpb consecutive tile positions (two on the launches that would otherwise be exactly two rounds of
     // resident workgroups: the second tile starts whenever the first is done instead of waiting for a dispatch slot, and
     // its prologue loads queue behind the first tile's stores without a launch-wide phase change)
+    if constexpr (BNI) {
+        // the coefficient table of the fused BatchNorm: [groups][Kc] x (scale, shift), 8 bytes per channel
+        const int n4 = a.bni_groups * a.Kc / 2;
+        for (int i = tid; i < n4; i += 256)
+            reinterpret_cast<float4*>(smem + a.bni_lds)[i] = reinterpret_cast<const float4*>(a.bni)[i];
+        __syncthreads();
+    }
     for (int it = 0; it < a.tpb; ++it) {
     const int bx = blockIdx.x * a.tpb + it;
     if (bx >= a.gx_total) break;
@@ -188,6 +201,7 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
     //  decoding uses small-range multiply-shift divisions)
     int org[SUBT];                                   // pixel index of halo position (0, 0) of each sub-tile, or INT_MIN
     int oy0[SUBT], ox0[SUBT];
+    int bni_grp[SUBT];                               // BNI: statistics group of each sub-tile's image
 #pragma unroll
     for (int s = 0; s < SUBT; ++s) {
         const int g = bx * SUBT + s;
@@ -196,6 +210,7 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
         else { img = g / a.tiles_per_img; const int t = g - img * a.tiles_per_img; ty = t / a.tiles_x; tx = t - ty * a.tiles_x; }
         oy0[s] = ty * 8 - 1; ox0[s] = tx * 8 - 1;
         org[s] = g < a.subtiles ? (img * a.H + oy0[s]) * a.W + ox0[s] : (int)0x80000000;
+        if constexpr (BNI) bni_grp[s] = g < a.subtiles ? img / a.bni_ipg : 0;
     }
     f32x16 acc[TM];
 #pragma unroll
@@ -208,10 +223,12 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
         uint4 bcur[6], bnext[6];
         C3_LOAD_BX(bcur, 0, 0);
         unsigned xoff[XJ];
+        int xtb[XJ];                                     // BNI: byte offset of the slot's 8 coefficients pairs in the LDS table (chunk 0)
 #pragma unroll
         for (int j = 0; j < XJ; ++j) {
             const int q = j * 256 + tid;
             unsigned off = XOOB;
+            xtb[j] = 0;
             if (q < 4 * HPL) {
                 const int plane = SUBT == 2 ? (q * 5243) >> 20 : (q * 10486) >> 20;      // q / 200, q / 100
                 const int rem = q - plane * HPL;
@@ -221,9 +238,28 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
                 const int o = s ? org[SUBT - 1] : org[0];
                 if (o != (int)0x80000000 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
                     off = ((unsigned)(o + hy * a.W + hx) * (unsigned)a.Kc + (unsigned)(plane * 8)) * 4u;
+                if constexpr (BNI) xtb[j] = a.bni_lds + ((s ? bni_grp[SUBT - 1] : bni_grp[0]) * a.Kc + plane * 8) * 8;
             }
             xoff[j] = off;
         }
+        const float bni_lo = a.bni_relu ? 0.0f : -3.0e38f;
+        // y = max(x * scale + shift, lo) on the 8 channels of a slot; out-of-image slots stay zero
+#define X3_BNI(j, c, h)                                                                                                 \
+    do {                                                                                                                \
+        if constexpr (BNI) {                                                                                            \
+            const float4* tb_ = reinterpret_cast<const float4*>(smem + xtb[j] + (c) * 256);                             \
+            const float4 t0_ = tb_[0], t1_ = tb_[1], t2_ = tb_[2], t3_ = tb_[3];                                       \
+            const bool ok_ = xoff[j] != XOOB;                                                                           \
+            h[0].x = ok_ ? fmaxf(__builtin_fmaf(h[0].x, t0_.x, t0_.y), bni_lo) : 0.f;                                   \
+            h[0].y = ok_ ? fmaxf(__builtin_fmaf(h[0].y, t0_.z, t0_.w), bni_lo) : 0.f;                                   \
+            h[0].z = ok_ ? fmaxf(__builtin_fmaf(h[0].z, t1_.x, t1_.y), bni_lo) : 0.f;                                   \
+            h[0].w = ok_ ? fmaxf(__builtin_fmaf(h[0].w, t1_.z, t1_.w), bni_lo) : 0.f;                                   \
+            h[1].x = ok_ ? fmaxf(__builtin_fmaf(h[1].x, t2_.x, t2_.y), bni_lo) : 0.f;                                   \
+            h[1].y = ok_ ? fmaxf(__builtin_fmaf(h[1].y, t2_.z, t2_.w), bni_lo) : 0.f;                                   \
+            h[1].z = ok_ ? fmaxf(__builtin_fmaf(h[1].z, t3_.x, t3_.y), bni_lo) : 0.f;                                   \
+            h[1].w = ok_ ? fmaxf(__builtin_fmaf(h[1].w, t3_.z, t3_.w), bni_lo) : 0.f;                                   \
+        }                                                                                                               \
+    } while (0)
         // (rounds whose first slot of this wave is past the image are skipped wave-uniformly: 800 = 3 x 256 + 32 slots)
 #define X3_ISSUE(j, c, h)                                                                                               \
     do {                                                                                                                \
@@ -232,10 +268,11 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
             h[1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, xoff[j] + 16u, (unsigned)((c) * 128), 0)); \
         }                                                                                                               \
     } while (0)
-#define X3_STORE(j, hs, h)                                                                                              \
+#define X3_STORE(j, hs, c, h)                                                                                           \
     do {                                                                                                                \
         if ((j) * 256 + wave * 64 < 4 * HPL && (j) * 256 + tid < 4 * HPL) {                                             \
             uint4 p0_, p1_, p2_;                                                                                        \
+            X3_BNI(j, c, h);                                                                                            \
             bh_split8(h[0], h[1], p0_, p1_, p2_);                                                                       \
             char* d_ = smem + (hs) * HALO_B + ((j) * 256 + tid) * 16;                                                   \
             *reinterpret_cast<uint4*>(d_) = p0_;                                                                        \
@@ -248,7 +285,7 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
 #pragma unroll
             for (int j = 0; j < XJ; ++j) X3_ISSUE(j, 0, hp[j]);
 #pragma unroll
-            for (int j = 0; j < XJ; ++j) X3_STORE(j, 0, hp[j]);
+            for (int j = 0; j < XJ; ++j) X3_STORE(j, 0, 0, hp[j]);
         }
         const int a_lane = (kh2 * HPL + wm * 100 + c3_strip_row(l31 >> 2) * 10 + wh * 4 + (l31 & 3)) * 16;
         __syncthreads();
@@ -277,7 +314,7 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
                 }
                 if (more && !(dbg_noload & 2)) {
                     // the next chunk's halo: slot round j is requested at tap 2j and cut / written two taps later
-                    if ((tap & 1) == 0 && tap >= 2 && tap / 2 - 1 < XJ) X3_STORE(tap / 2 - 1, hs ^ 1, hb[(tap / 2 - 1) & 1]);
+                    if ((tap & 1) == 0 && tap >= 2 && tap / 2 - 1 < XJ) X3_STORE(tap / 2 - 1, hs ^ 1, c + 1, hb[(tap / 2 - 1) & 1]);
                     if ((tap & 1) == 0 && tap / 2 < XJ) X3_ISSUE(tap / 2, c + 1, hb[(tap / 2) & 1]);
                 }
 #define X3_MFMA(s2, PA, PB)                                                                                             \
@@ -299,6 +336,7 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
         }
 #undef X3_ISSUE
 #undef X3_STORE
+#undef X3_BNI
     } else {
     float4 bcur[4], bnext[4];
     if constexpr (PACKED) C3_LOAD_B(bcur, 0, 0);
@@ -631,7 +669,7 @@ void bh_conv3x3_tune(int disable, int min_blocks) {
 // *taken = 1 when the shape is eligible and the launch was made; returns BH_OK or a hipError_t
 int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* out, const bh_conv_desc* d, int dgrad,
                    int accumulate, hipStream_t stream, int* taken, double* bn_sums, int groups, const float* res, int relu,
-                   const bh_bn_reduce* bnr) {
+                   const bh_bn_reduce* bnr, const bh_bn_in* bni) {
     *taken = 0;
     // (packed weights only make sense to this kernel: a caller that passes them must have asked bh_conv_variant first)
     if ((d->route & BH_ROUTE_GENERIC_CONV) || d->transposed || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->in_nchw ||
@@ -684,7 +722,11 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
     }
     if (!(d->route & BH_ROUTE_HALO_SMALL) && (int)(((a.subtiles + 1) / 2) * grid.y) < C3_MIN_BLOCKS) return d->w_layout ? BH_E_UNSUPPORTED : 0;
     a.NW = Nn / 32;
-    if (bh_query(x3 ? "conv3x3_halo_kernel<%s,%d,%s,%d,true,true>" : packed ? "conv3x3_halo_kernel<%s,%d,%s,%d,true>" : "conv3x3_halo_kernel<%s,%d,%s,%d>",
+    if (bni) {      // BatchNorm-on-load: the f32x3 forward only, table of <= 4 KB (two groups x 256 channels) in LDS
+        if (!x3 || dgrad || !bni->table || bni->groups < 1 || d->N % bni->groups || (long long)bni->groups * Kc * 8 > 4096) return BH_E_UNSUPPORTED;
+        a.bni = bni->table; a.bni_relu = bni->relu; a.bni_groups = bni->groups; a.bni_ipg = d->N / bni->groups;
+    }
+    if (bh_query(bni ? "conv3x3_halo_kernel<%s,%d,%s,%d,true,true,true>" : x3 ? "conv3x3_halo_kernel<%s,%d,%s,%d,true,true>" : packed ? "conv3x3_halo_kernel<%s,%d,%s,%d,true>" : "conv3x3_halo_kernel<%s,%d,%s,%d>",
                  dgrad ? "true" : "false", bn_tile, bf16 ? "true" : "false", subt)) {
         *taken = 1;
         return BH_OK;
@@ -697,30 +739,33 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
                   conv3x3_halo_kernel<false, 32, true, 2, P>,  conv3x3_halo_kernel<true, 32, true, 2, P>,    \
                   conv3x3_halo_kernel<false, 64, false, 1, P>, conv3x3_halo_kernel<true, 64, false, 1, P>,   \
                   conv3x3_halo_kernel<false, 64, true, 1, P>,  conv3x3_halo_kernel<true, 64, true, 1, P>
-    static const kern_t fns[30] = {C3_ROW(false), C3_ROW(true),
+    static const kern_t fns[33] = {C3_ROW(false), C3_ROW(true),
                                    conv3x3_halo_kernel<false, 64, false, 2, true, true>, conv3x3_halo_kernel<true, 64, false, 2, true, true>,
                                    conv3x3_halo_kernel<false, 32, false, 2, true, true>, conv3x3_halo_kernel<true, 32, false, 2, true, true>,
-                                   conv3x3_halo_kernel<false, 64, false, 1, true, true>, conv3x3_halo_kernel<true, 64, false, 1, true, true>};
+                                   conv3x3_halo_kernel<false, 64, false, 1, true, true>, conv3x3_halo_kernel<true, 64, false, 1, true, true>,
+                                   conv3x3_halo_kernel<false, 64, false, 2, true, true, true>, conv3x3_halo_kernel<false, 32, false, 2, true, true, true>,
+                                   conv3x3_halo_kernel<false, 64, false, 1, true, true, true>};
 #undef C3_ROW
     constexpr int HALO2 = 8 * 200 * 16, HALO1 = 8 * 100 * 16;          // one halo stage: two / one sub-tile per workgroup
     constexpr int LDS1 = 2 * HALO1 + 2 * C3_B_BYTES;                   // one sub-tile per workgroup: 41,984 B
     constexpr int XHALO2 = 12 * 200 * 16, XHALO1 = 12 * 100 * 16;      // split form: 12 plane images per stage
     if (bh_device_once(attr_devs)) {
-        for (int i = 0; i < 30; ++i) {
+        for (int i = 0; i < 33; ++i) {
             const int j = i % 12;
-            const int full = i >= 24 ? 2 * (i < 28 ? XHALO2 : XHALO1) : i < 12 ? (j < 8 ? C3_LDS_BYTES : LDS1) : 2 * (j < 8 ? HALO2 : HALO1);
+            const int full = i >= 30 ? 2 * (i < 32 ? XHALO2 : XHALO1) + 4096 : i >= 24 ? 2 * (i < 28 ? XHALO2 : XHALO1) : i < 12 ? (j < 8 ? C3_LDS_BYTES : LDS1) : 2 * (j < 8 ? HALO2 : HALO1);
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[i]), hipFuncAttributeMaxDynamicSharedMemorySize, full);
             if (e != hipSuccess) return (int)e;
         }
     }
-    const kern_t fn = x3 ? fns[24 + (subt == 1 ? 4 : bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0)]
+    const kern_t fn = bni ? fns[30 + (subt == 1 ? 2 : bn_tile == 64 ? 0 : 1)] : x3 ? fns[24 + (subt == 1 ? 4 : bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0)]
                          : fns[(packed ? 12 : 0) + (subt == 1 ? 8 + (bf16 ? 2 : 0) + (dgrad ? 1 : 0)
                                                               : (bf16 ? 4 : 0) + (bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0))];
     a.dbg_noload = g_c3_noload;
     const int stage = x3 ? (subt == 1 ? XHALO1 : XHALO2) : subt == 1 ? HALO1 : HALO2;
     const int lds = packed ? (Kc / 32 > 1 ? 2 : 1) * stage                                    // halo stages only
                            : (subt == 1 ? LDS1 : C3_LDS_BYTES) - (Kc / 32 > 1 ? 0 : stage);   // single chunk: one halo stage
-    hipLaunchKernelGGL(fn, grid, dim3(256), lds, stream, a);
+    if (bni) a.bni_lds = lds;
+    hipLaunchKernelGGL(fn, grid, dim3(256), lds + (bni ? bni->groups * Kc * 8 : 0), stream, a);
     BH_LAUNCH_CHECK();
     *taken = 1;
     return BH_OK;

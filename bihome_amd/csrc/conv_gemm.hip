@@ -917,7 +917,7 @@ void bh_wgrad_x3_tune(int what, int v);
 #endif
 int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* out, const bh_conv_desc* d, int dgrad,
                    int accumulate, hipStream_t stream, int* taken, double* bn_sums, int groups, const float* res = nullptr,
-                   int relu = 0, const bh_bn_reduce* bnr = nullptr);
+                   int relu = 0, const bh_bn_reduce* bnr = nullptr, const bh_bn_in* bni = nullptr);
 int bn_launch_stats(const float* x, int groups, int rows, int C, double* sums, hipStream_t s);
 int bh_stem7_try(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, int relu,
                  hipStream_t stream, int* taken);
@@ -1030,6 +1030,17 @@ int bh_conv_fwd(const float* x, const float* w, const float* bias, float* y, con
 int bh_conv_fwd_act(const float* x, const float* w, const float* bias, const float* res, float* y, const bh_conv_desc* d,
                     int relu, void* stream) {
     return conv_fwd_impl(x, w, bias, res, y, d, relu, stream);
+}
+
+int bh_conv_fwd_bnin(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, double* sums, int groups,
+                     const bh_bn_in* bni, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!x || !w || !y || !bni || d->out_nchw || (sums && (groups < 1 || d->N % groups))) return BH_E_BADARG;
+    int taken = 0;
+    rc = bh_conv3x3_try(x, w, bias, y, d, 0, 0, bh_stream(stream), &taken, sums, sums ? groups : 1, nullptr, 0, nullptr, bni);
+    if (rc) return rc;
+    return taken ? BH_OK : BH_E_UNSUPPORTED;
 }
 
 int bh_conv_fwd_bnstats(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, double* sums,

@@ -9,7 +9,7 @@
 #include "common.h"
 
 int bh_wgrad_x3_try(const float* x, const float* gy, float* gw, const bh_conv_desc* d, hipStream_t stream, int* taken, float* ws,
-                    long long ws_bytes, long long* ws_need);    // wgrad_x3.hip
+                    long long ws_bytes, long long* ws_need, const bh_bn_in* bni = nullptr);    // wgrad_x3.hip
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -718,6 +718,17 @@ long long bh_conv_wgrad_det_bytes(const bh_conv_desc* d) {
     const int rc = conv_wgrad_impl(p, p, p, nullptr, d, nullptr, p, 0, &need);
     bh_query_ctx = saved;
     return rc == BH_OK ? need : 0;
+}
+
+int bh_conv_wgrad_bnin(const float* x, const float* gy, float* gw, float* gbias, const bh_conv_desc* d, float* ws, long long ws_bytes,
+                       const bh_bn_in* bni, void* stream) {
+    if (!d || !x || !gy || !gw || !bni || !ws) return BH_E_BADARG;
+    if (d->precision != 2) return BH_E_UNSUPPORTED;
+    int taken = 0;
+    const int rc = bh_wgrad_x3_try(x, gy, gw, d, bh_stream(stream), &taken, ws, ws_bytes, nullptr, bni);
+    if (rc != BH_OK) return rc;
+    if (!taken) return BH_E_UNSUPPORTED;
+    return gbias ? bh_conv_bias_grad(gy, gbias, d, stream) : BH_OK;
 }
 
 int bh_conv_wgrad_det(const float* x, const float* gy, float* gw, float* gbias, const bh_conv_desc* d, float* ws, long long ws_bytes,

@@ -48,6 +48,10 @@ struct WX3Args {
     unsigned x_bytes, gy_bytes;
     int noflush;
     float* partials;               // != NULL: partial[workgroup][tap][wave][r][lane] instead of atomics
+    // BNI: X is the INPUT of a training-mode BatchNorm(+ReLU) whose output the convolution consumed: the halo staging applies
+    // max(x * scale + shift, lo) per channel (zero padding stays zero).  bni: table[groups][Ci] x (scale, shift) (bh_bn_fwd_coeffs)
+    const float* bni;
+    int bni_relu, bni_ipg, bni_groups;
 };
 
 template <int CB>
@@ -65,7 +69,7 @@ struct WXGeom {
     static constexpr int HS = (100 * NG + 255) / 256;          // halo staging slots per thread (4 / 2)
 };
 
-template <int CB>
+template <int CB, bool BNI = false>
 __global__ void __launch_bounds__(256, 1) wgrad_x3_kernel(WX3Args a) {
     using G = WXGeom<CB>;
     constexpr int GS = G::GS, HS = G::HS, NG = G::NG;
@@ -101,6 +105,19 @@ __global__ void __launch_bounds__(256, 1) wgrad_x3_kernel(WX3Args a) {
     }
 
     float4 rg[GS][2], rx[HS][2];
+    bool h_ok[HS];                                                // BNI: slot inside the image / statistics group of its image,
+    int h_tb[HS];                                                 //      as byte offset of the slot's coefficients in the LDS table
+#pragma unroll
+    for (int j = 0; j < HS; ++j) { h_ok[j] = false; h_tb[j] = 0; }
+    constexpr int TB0 = 2 * G::LDS;                               // [groups][CB] x (scale, shift) of this workgroup's input-channel block
+    if constexpr (BNI) {
+        for (int i = tid; i < a.bni_groups * CB; i += 256) {
+            const int grp = i / CB, ch = i - grp * CB;
+            reinterpret_cast<float2*>(smem + TB0)[i] = reinterpret_cast<const float2*>(a.bni)[grp * a.Ci + ci0 + ch];
+        }
+    }
+    if constexpr (BNI) __syncthreads();
+    const float bni_lo = a.bni_relu ? 0.0f : -3.0e38f;
     // loads of tile t.  part -1: all; 0: the gy slots; 1 / 2: the first / second half of the halo slots (each register group is
     // re-requested as soon as its slots have been written out, so every load has most of a tile of MFMAs to arrive)
     auto issue_part = [&](int t, auto PART) {
@@ -122,7 +139,9 @@ __global__ void __launch_bounds__(256, 1) wgrad_x3_kernel(WX3Args a) {
             if (part >= 0 && (part == 0 || j / (HS / 2) != part - 1)) continue;
             const int y = ty * 8 + h_y[j], x = tx * 8 + h_x[j];
             const unsigned in = ((unsigned)(org + h_y[j] * a.W + h_x[j]) * (unsigned)a.Ci + (unsigned)(ci0 + h_cg[j])) * 4u;
-            const unsigned off = ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W) ? in : OOB;     // outside the image: zeros
+            const bool ok = (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+            const unsigned off = ok ? in : OOB;                   // outside the image: zeros
+            if constexpr (BNI) { h_ok[j] = ok; h_tb[j] = TB0 + ((img / a.bni_ipg) * CB + h_cg[j]) * 8; }
             rx[j][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0));
             rx[j][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsX, off + 16u, 0, 0));
         }
@@ -138,6 +157,17 @@ __global__ void __launch_bounds__(256, 1) wgrad_x3_kernel(WX3Args a) {
             *reinterpret_cast<uint4*>(img + g_lds[sl] + 2 * G::GP) = p2;
         } else if constexpr (sl < GS + HS) {
             constexpr int j = sl - GS;
+            if constexpr (BNI) {
+                const float4* tb = reinterpret_cast<const float4*>(smem + h_tb[j]);
+                const float4 t0 = tb[0], t1 = tb[1], t2 = tb[2], t3 = tb[3];
+                const bool ok = h_ok[j];
+                float4& u = rx[j][0];
+                float4& v = rx[j][1];
+                u.x = ok ? fmaxf(__builtin_fmaf(u.x, t0.x, t0.y), bni_lo) : 0.f; u.y = ok ? fmaxf(__builtin_fmaf(u.y, t0.z, t0.w), bni_lo) : 0.f;
+                u.z = ok ? fmaxf(__builtin_fmaf(u.z, t1.x, t1.y), bni_lo) : 0.f; u.w = ok ? fmaxf(__builtin_fmaf(u.w, t1.z, t1.w), bni_lo) : 0.f;
+                v.x = ok ? fmaxf(__builtin_fmaf(v.x, t2.x, t2.y), bni_lo) : 0.f; v.y = ok ? fmaxf(__builtin_fmaf(v.y, t2.z, t2.w), bni_lo) : 0.f;
+                v.z = ok ? fmaxf(__builtin_fmaf(v.z, t3.x, t3.y), bni_lo) : 0.f; v.w = ok ? fmaxf(__builtin_fmaf(v.w, t3.z, t3.w), bni_lo) : 0.f;
+            }
             bh_split8(rx[j][0], rx[j][1], p0, p1, p2);
             *reinterpret_cast<uint4*>(img + h_lds[j]) = p0;
             *reinterpret_cast<uint4*>(img + h_lds[j] + G::XP) = p1;
@@ -311,7 +341,7 @@ void bh_wgrad_x3_tune(int what, int v) { if (what == 0) g_wx3_target = v; else i
 // *taken = 1 when the shape is eligible (3x3 / stride 1 / pad 1, NHWC, H and W multiples of 8, channels multiples of 32).
 // ws != NULL: deterministic reduction through ws (ws_need != NULL: dry run that only reports the bytes needed)
 int bh_wgrad_x3_try(const float* x, const float* gy, float* gw, const bh_conv_desc* d, hipStream_t stream, int* taken, float* ws,
-                    long long ws_bytes, long long* ws_need) {
+                    long long ws_bytes, long long* ws_need, const bh_bn_in* bni) {
     *taken = 0;
     if (d->transposed || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->in_nchw || d->out_nchw) return BH_OK;
     if (d->Hi % 8 || d->Wi % 8 || d->Ho != d->Hi || d->Wo != d->Wi || d->Ci % 32 || d->Co % 32) return BH_OK;
@@ -334,13 +364,19 @@ int bh_wgrad_x3_try(const float* x, const float* gy, float* gw, const bh_conv_de
     a.nsplit = ns;
     a.x_bytes = (unsigned)(xe * 4); a.gy_bytes = (unsigned)(ge * 4);
     a.noflush = g_wx3_noflush;
+    if (bni) {
+        if (!bni->table || bni->groups < 1 || bni->groups > 4 || d->N % bni->groups) return BH_E_BADARG;
+        a.bni = bni->table; a.bni_relu = bni->relu; a.bni_groups = bni->groups; a.bni_ipg = d->N / bni->groups;
+    }
+    const int tb_bytes = bni ? bni->groups * cb * 8 : 0;
     const long long need = (long long)pairs * ns * 36864 * 4;
     if (ws) {
         if (ws_need) *ws_need = need;
         else if (ws_bytes < need) return BH_E_BADARG;
         a.partials = ws;
     }
-    if (bh_query(ws ? "wgrad_x3_kernel<%d>+wgrad_x3_reduce_kernel<%d>" : "wgrad_x3_kernel<%d>", cb, cb)) { *taken = 1; return BH_OK; }
+    if (bh_query(bni ? (ws ? "wgrad_x3_kernel<%d,true>+wgrad_x3_reduce_kernel<%d>" : "wgrad_x3_kernel<%d,true>")
+                     : (ws ? "wgrad_x3_kernel<%d>+wgrad_x3_reduce_kernel<%d>" : "wgrad_x3_kernel<%d>"), cb, cb)) { *taken = 1; return BH_OK; }
     static unsigned long long attr_devs = 0;
     if (bh_device_once(attr_devs)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -348,9 +384,17 @@ int bh_wgrad_x3_try(const float* x, const float* gy, float* gw, const bh_conv_de
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     2 * WXGeom<32>::LDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    2 * WXGeom<64>::LDS + 4 * 64 * 8);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_kernel<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    2 * WXGeom<32>::LDS + 4 * 32 * 8);
         if (e != hipSuccess) return (int)e;
     }
-    if (cb == 64) hipLaunchKernelGGL(wgrad_x3_kernel<64>, dim3(pairs * ns), dim3(256), 2 * WXGeom<64>::LDS, stream, a);
+    if (bni && cb == 64) hipLaunchKernelGGL((wgrad_x3_kernel<64, true>), dim3(pairs * ns), dim3(256), 2 * WXGeom<64>::LDS + tb_bytes, stream, a);
+    else if (bni) hipLaunchKernelGGL((wgrad_x3_kernel<32, true>), dim3(pairs * ns), dim3(256), 2 * WXGeom<32>::LDS + tb_bytes, stream, a);
+    else if (cb == 64) hipLaunchKernelGGL(wgrad_x3_kernel<64>, dim3(pairs * ns), dim3(256), 2 * WXGeom<64>::LDS, stream, a);
     else hipLaunchKernelGGL(wgrad_x3_kernel<32>, dim3(pairs * ns), dim3(256), 2 * WXGeom<32>::LDS, stream, a);
     BH_LAUNCH_CHECK();
     if (ws) {

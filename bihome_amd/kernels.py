@@ -5,7 +5,7 @@ import os
 
 import torch
 
-from ._lib import BhBnReduce, BhConvDesc, BhPack3x3Job, check, lib
+from ._lib import BhBnIn, BhBnReduce, BhConvDesc, BhPack3x3Job, check, lib
 
 
 def _p(t):
@@ -374,11 +374,52 @@ class WeightPacker:
         self.versions = vers
 
 
+class BnOnLoad:
+    """A training-mode BatchNorm(+ReLU) whose APPLY rides in its consumer: `z` is the BatchNorm's input, `table` the
+    [groups][C] x (scale, shift) coefficients made by bn_fwd_coeffs.  The f32x3 3x3 forward and weight-gradient kernels take
+    it as their input operand and transform it while staging (zero padding stays zero): the BatchNorm's output is never stored."""
+    __slots__ = ("z", "table", "groups", "relu")
+
+    def __init__(self, z, table, groups, relu):
+        self.z, self.table, self.groups, self.relu = z, table, groups, relu
+
+    @property
+    def shape(self):
+        return self.z.shape
+
+    def struct(self):
+        b = BhBnIn()
+        b.table, b.groups, b.relu = self.table.data_ptr(), int(self.groups), int(bool(self.relu))
+        return b
+
+
+def bn_fwd_coeffs(stats, gamma, beta, rmean, rvar, groups, rows, C, eps, momentum):
+    """(scale, shift) table of a training-mode BatchNorm from its forward sums (+ the running-statistics update)."""
+    table = torch.empty((groups, C, 2), dtype=torch.float32, device=stats.device)
+    check(lib.bh_bn_fwd_coeffs(_p(stats), _p(gamma), _p(beta), _p(rmean), _p(rvar), groups, rows, C, float(eps), float(momentum),
+                               _p(table), _stream()), "bh_bn_fwd_coeffs")
+    return table
+
+
 def conv_fwd(x, w, bias, d, bn_sums=None, groups=1, res=None, relu=False, wpacked=None):
     """wpacked: the forward buffer of WeightPacker for this conv (then `w` is only used for the byte count).
     bn_sums: zeroed float64 sums buffer - the conv also accumulates the batch statistics of its output for the
     BatchNorm that follows (bn_fwd(..., stats=bn_sums, stats_ready=True)).  res / relu: inference epilogue
     y = act(conv + bias + res) (BatchNorm folded into w, bias by the caller)."""
+    if isinstance(x, BnOnLoad):
+        # the BatchNorm in front of this conv is applied on load (packed f32x3 forward only)
+        bol, x = x, x.z
+        _chk(x); _chk(bias); _chk(bn_sums, torch.float64)
+        if wpacked is None or res is not None or relu:
+            raise RuntimeError("BatchNorm-on-load needs the packed f32x3 3x3 forward")
+        y = torch.empty(conv_out_shape(d), dtype=torch.float32, device=x.device)
+        dp = getattr(d, "bh_packed", None) or _with_layout(d, 2)
+        bs = bol.struct()
+        with _Timed(_conv_variant(dp, "fwd", bn_groups=groups if bn_sums is not None else 0) + "+bn_on_load" if TIMING is not None else "",
+                    conv_flops(d), 4.0 * (x.numel() + y.numel() + w.numel())):
+            check(lib.bh_conv_fwd_bnin(_p(x), _p(wpacked), _p(bias), _p(y), ctypes.byref(dp), _p(bn_sums), groups, ctypes.byref(bs),
+                                       _stream()), "bh_conv_fwd_bnin")
+        return y
     _chk(x); _chk(w); _chk(bias); _chk(res)
     y = torch.empty(conv_out_shape(d), dtype=torch.float32, device=x.device)
     if wpacked is not None:
@@ -499,6 +540,18 @@ def conv_wgrad(x, gy, gw, gbias, d, det_ws=None):
     that the wgrad entry is the kernel rocprofv3 lists under the same name).
     det_ws: float32 workspace of >= wgrad_det_bytes(d) bytes - the split-K partial tiles are stored there and added in a
     fixed order by a second launch (bitwise repeatable, no atomics); ignored where the shape has no deterministic form."""
+    if isinstance(x, BnOnLoad):
+        bol, x = x, x.z
+        _chk(x); _chk(gy); _chk(gw); _chk(gbias)
+        need = wgrad_det_bytes(d)
+        if det_ws is None or not (0 < need <= det_ws.numel() * 4):
+            raise RuntimeError("BatchNorm-on-load needs the f32x3 weight gradient and its workspace")
+        bs = bol.struct()
+        with _Timed((conv_variant(d, "wgrad_det") + "+bn_on_load" if TIMING is not None else ""), conv_flops(d),
+                    4.0 * (x.numel() + gy.numel() + gw.numel())):
+            check(lib.bh_conv_wgrad_bnin(_p(x), _p(gy), _p(gw), _p(gbias), ctypes.byref(d), _p(det_ws), det_ws.numel() * 4,
+                                         ctypes.byref(bs), _stream()), "bh_conv_wgrad_bnin")
+        return
     _chk(x); _chk(gy); _chk(gw); _chk(gbias)
     if det_ws is not None:
         need = wgrad_det_bytes(d)

@@ -290,6 +290,23 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, p
             if (op.kind == "bn" and j is not None and prog.ops[j].kind == "conv" and users.get(op.src, 0) == 1
                     and not prog.ops[j].extra["out_nchw"] and prog.ops[j].mod.weight.dim() == 4):
                 fused_stats[j] = i
+    # BatchNorm-on-load: a training-mode BatchNorm(+ReLU) without residual whose ONLY consumer is a 3x3 conv that runs the packed
+    # f32x3 forward and the f32x3 weight gradient is not applied at all - the consumer transforms the BatchNorm's INPUT while
+    # staging it (kernels.BnOnLoad): one launch and two tensor passes per such layer gone (the inner BatchNorm of every
+    # residual unit).  Needs the sums from the producer's epilogue (fused_stats) and a table of <= 4 KB.
+    bn_on_load = set()
+    if training and packer is not None and int(precision) == 2 and os.environ.get("BIHOME_BN_ON_LOAD", "1") != "0":
+        consumer = {}
+        for j, op in enumerate(prog.ops):
+            consumer.setdefault(op.src, j)
+        fused_bn = set(fused_stats.values())
+        for i, op in enumerate(prog.ops):
+            j = consumer.get(op.dst)
+            if (op.kind == "bn" and op.res is None and i in fused_bn and users.get(op.dst, 0) == 1 and j is not None
+                    and prog.ops[j].kind == "conv" and prog.ops[j].src == op.dst and prog.ops[j].extra["weight_fn"] is None
+                    and not prog.ops[j].extra["in_nchw"] and id(prog.ops[j].mod.weight) in packer.entries
+                    and groups * op.mod.num_features * 8 <= 4096):
+                bn_on_load.add(i)
     folded = {}                                           # bn op index -> conv op index (conv deferred to the bn's position)
     if fold_cache is not None and not training and not save:
         users = {}
@@ -339,10 +356,21 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, p
         elif op.kind == "bn":
             m = op.mod
             res = slots[op.res] if op.res is not None else None
-            out, st = K.bn_fwd(src, m.weight, m.bias, m.running_mean, m.running_var, res, groups, m.eps,
-                               _momentum(m), op.relu, training,
-                               stats=arena[bn_off[i]:bn_off[i] + K.bn_stats_doubles(groups, m.num_features)],
-                               stats_ready=i in ready)
+            lazy = False
+            if i in bn_on_load and i in ready and src.shape[0] % groups == 0:
+                cop = prog.ops[consumer[op.dst]]
+                cd = _conv_geometry(cop.mod, src.shape, False, cop.extra["out_nchw"], precision)
+                lazy = bool(cd.bh_packs and cd.bh_wx3)
+            if lazy:
+                st = arena[bn_off[i]:bn_off[i] + K.bn_stats_doubles(groups, m.num_features)]
+                table = K.bn_fwd_coeffs(st, m.weight, m.bias, m.running_mean, m.running_var, groups,
+                                        src.numel() // (m.num_features * groups), m.num_features, m.eps, _momentum(m))
+                out = K.BnOnLoad(src, table, groups, op.relu)
+            else:
+                out, st = K.bn_fwd(src, m.weight, m.bias, m.running_mean, m.running_var, res, groups, m.eps,
+                                   _momentum(m), op.relu, training,
+                                   stats=arena[bn_off[i]:bn_off[i] + K.bn_stats_doubles(groups, m.num_features)],
+                                   stats_ready=i in ready)
             if training:        # flushed to the `num_batches_tracked` buffer lazily (flush_counters): no per-layer launch
                 m._bh_pending_batches = getattr(m, "_bh_pending_batches", 0) + groups
             if save:
@@ -499,7 +527,10 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
         elif op.kind == "bn":
             m = op.mod
             train_w = want_wgrad and m.weight is not None and m.weight.requires_grad
-            gx, gres = K.bn_bwd(g, slots[op.dst], x, m.weight, ctx.stats[i], m.running_mean, m.running_var, ctx.groups,
+            yb = slots[op.dst]
+            if isinstance(yb, K.BnOnLoad):                # applied on load by its consumer: no output tensor (the mask comes from x)
+                yb = None
+            gx, gres = K.bn_bwd(g, yb, x, m.weight, ctx.stats[i], m.running_mean, m.running_var, ctx.groups,
                                 m.eps, op.relu, ctx.training, op.res is not None and ((op.res != 0) or want_input_grad),
                                 m.weight.grad if train_w else None, m.bias.grad if train_w else None, beta=m.bias,
                                 had_res=op.res is not None, sums_ready=bn_reduced.get(i))

@@ -197,6 +197,24 @@ int bh_conv_fwd(const float* x, const float* w, const float* bias, float* y, con
  * an eval-mode BatchNorm is folded into (w, bias) by the host and its ReLU / residual add ride in the conv epilogue. */
 int bh_conv_fwd_act(const float* x, const float* w, const float* bias, const float* res, float* y, const bh_conv_desc* d,
                     int relu, void* stream);
+/* BatchNorm-on-load (f32x3 3x3 layers, round 2): x is the INPUT of a training-mode BatchNorm(+ReLU) whose output this convolution
+ * is the only consumer of; the kernels apply y = max(x * scale + shift, relu ? 0 : -inf) per channel while staging their operand
+ * (zero padding stays zero), so the BatchNorm's output tensor is never written or read.  table[groups][C] x (scale, shift) comes from
+ * bh_bn_fwd_coeffs (which also makes the running-statistics update); the images of x are `groups` equal stacks along N.
+ * bh_conv_fwd_bnin: packed f32x3 forward (w_layout 2), optional BatchNorm sums of ITS output as in bh_conv_fwd_bnstats (sums NULL: none);
+ * bh_conv_wgrad_bnin: the f32x3 weight gradient (workspace form) with the same transform on x.  BH_E_UNSUPPORTED when the launch is
+ * not taken by those kernels (ask bh_conv_variant; table > 4 KB). */
+typedef struct {
+    const float* table;
+    int groups;
+    int relu;
+} bh_bn_in;
+int bh_bn_fwd_coeffs(const double* stats, const float* gamma, const float* beta, float* running_mean, float* running_var, int groups,
+                     int rows, int C, float eps, float momentum, float* table, void* stream);
+int bh_conv_fwd_bnin(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, double* sums, int groups,
+                     const bh_bn_in* bni, void* stream);
+int bh_conv_wgrad_bnin(const float* x, const float* gy, float* gw, float* gbias, const bh_conv_desc* d, float* ws, long long ws_bytes,
+                       const bh_bn_in* bni, void* stream);
 /* y = conv(x, w) + bias, and sums (bh_bn_stats_doubles(groups, Co) doubles, caller-zeroed) += per-channel (sum y, sum y^2) of each of the
  * `groups` sub-batches stacked along N: the batch statistics of the BatchNorm that follows, accumulated in the conv
  * epilogue (halo-tiled 3x3 kernel; generic implicit GEMM incl. ConvTranspose2d when the pixels of a group are a

@@ -670,6 +670,60 @@ def test_conv3x3_f32x3_error_bound_under_cancellation(K):
     assert ulps[2] <= max(1.25 * ulps[0], 4.0) and ulps[2] < 16.0, ulps      # (K = 576 terms: a few ulps of the accumulated magnitude)
 
 
+@pytest.mark.parametrize("N,H,Ci,Co,relu", [
+    (128, 32, 64, 64, True),     # bench shape, two statistics groups
+    (8, 16, 128, 64, True),      # four chunks
+    (8, 8, 256, 256, False),     # one sub-tile per workgroup, 4 KB table, no ReLU
+    (4, 64, 32, 32, True),       # 32-channel tile, single chunk
+    (6, 24, 64, 96, True),       # image borders inside every tile row, three images per group
+])
+def test_batchnorm_on_load_matches_materialised_batchnorm(K, N, H, Ci, Co, relu):
+    """bh_bn_fwd_coeffs + bh_conv_fwd_bnin / bh_conv_wgrad_bnin: the consumer conv applies the BatchNorm(+ReLU) in front of it
+    while staging its operand, so that BatchNorm's output is never stored.  Against the unfused sequence (bh_bn_fwd writes the
+    activation, the same f32x3 kernels read it): forward, forward + BatchNorm sums of the conv's own output, weight gradient
+    and the running-statistics update - equal up to the rounding of scale / shift arithmetic (fma vs separate ops), with the
+    zero padding ring intact (the transform of 0 is `shift`, not 0: a wrong border shows at 1e-1)."""
+    groups = 2
+    g = torch.Generator().manual_seed(N + H + Ci)
+    z = (torch.randn(N, H, H, Ci, generator=g) * 1.5 + 0.3).cuda()
+    gamma = (torch.rand(Ci, generator=g) + 0.5).cuda()
+    beta = (torch.randn(Ci, generator=g) * 0.2).cuda()
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * 0.05).cuda().contiguous(memory_format=torch.channels_last)
+    wk = w.permute(0, 2, 3, 1)
+    b = torch.randn(Co, generator=g).cuda()
+    gy = torch.randn(N, H, H, Co, generator=g).cuda()
+    rm0, rv0 = torch.randn(Ci, generator=g).cuda(), (torch.rand(Ci, generator=g) + 0.5).cuda()
+    rm1, rv1 = rm0.clone(), rv0.clone()
+    a, st = K.bn_fwd(z, gamma, beta, rm0, rv0, None, groups, 1e-5, 0.1, relu, True)
+    table = K.bn_fwd_coeffs(st, gamma, beta, rm1, rv1, groups, N * H * H // groups, Ci, 1e-5, 0.1)
+    assert torch.equal(rm0, rm1) and torch.equal(rv0, rv1)
+    d = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=2, route=0)
+    if not K.packs_3x3(d):
+        from bihome_amd._lib import ROUTE_HALO_SMALL
+        d = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=2, route=ROUTE_HALO_SMALL)
+    pk = K.WeightPacker(split=True)
+    pf, _ = pk.get(w)
+    pk.refresh()
+    lazy = K.BnOnLoad(z, table, groups, relu)
+    y_ref = K.conv_fwd(a, wk, b, d, wpacked=pf)
+    y = K.conv_fwd(lazy, wk, b, d, wpacked=pf)
+    close(y.cpu(), y_ref.cpu(), 2e-6)
+    s0, s1 = K.bn_stats_buffer(groups, Co, "cuda"), K.bn_stats_buffer(groups, Co, "cuda")
+    K.conv_fwd(a, wk, b, d, bn_sums=s0, groups=groups, wpacked=pf)
+    y2 = K.conv_fwd(lazy, wk, b, d, bn_sums=s1, groups=groups, wpacked=pf)
+    assert torch.equal(y2, y)
+    close(s1.cpu(), s0.cpu(), 1e-5)
+    need = K.wgrad_det_bytes(d)
+    assert need > 0
+    ws = torch.empty(need // 4, dtype=torch.float32, device="cuda")
+    g0, g1 = torch.zeros(Co, 3, 3, Ci, device="cuda"), torch.zeros(Co, 3, 3, Ci, device="cuda")
+    gb0, gb1 = torch.zeros(Co, device="cuda"), torch.zeros(Co, device="cuda")
+    K.conv_wgrad(a, gy, g0, gb0, d, det_ws=ws)
+    K.conv_wgrad(lazy, gy, g1, gb1, d, det_ws=ws)
+    close(g1.cpu(), g0.cpu(), 2e-6)
+    close(gb1.cpu(), gb0.cpu(), 1e-5)
+
+
 def test_conv3x3_f32x3_layout_and_precision_must_agree(K):
     """w_layout 2 (split weights) <-> precision 2: a mismatch is a caller error, not a silently wrong operand format; precision 2
     without packed weights computes as precision 0 (bit-identical to the fp32-input MFMA kernel)."""
