@@ -332,7 +332,18 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, p
             csrc = slots[cop.src]
             d = _conv_geometry(cop.mod, csrc.shape, e["in_nchw"], e["out_nchw"], precision)
             wf, bf = _folded(fold_cache, cop.mod, op.mod, e["weight_fn"])
-            out = K.conv_fwd(csrc, kview(wf), bf, d, res=slots[op.res] if op.res is not None else None, relu=op.relu)
+            pf = None
+            if int(precision) == 2 and d.bh_packs and e["weight_fn"] is None:
+                # f32x3 inference: the folded weights in cut fragment order (packed once per fold)
+                ent = fold_cache[(id(cop.mod), id(op.mod))]
+                if len(ent) < 4 or ent[3] is None:
+                    pk = K.WeightPacker(split=True)
+                    pf, _ = pk.get(wf, need_dgrad=False)
+                    pk.refresh()
+                    fold_cache[(id(cop.mod), id(op.mod))] = (ent[0], ent[1], ent[2], pf)
+                else:
+                    pf = ent[3]
+            out = K.conv_fwd(csrc, kview(wf), bf, d, res=slots[op.res] if op.res is not None else None, relu=op.relu, wpacked=pf)
         elif op.kind == "conv":
             e = op.extra
             d = _conv_geometry(op.mod, src.shape, e["in_nchw"], e["out_nchw"], precision)
