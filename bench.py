@@ -31,7 +31,12 @@ X3_PRODUCTS = 6                   # bf16 MFMA products per fp32 product in the f
 
 def is_x3(kernel):
     """f32x3 kernels: the algorithmic flops of a launch are executed as X3_PRODUCTS bf16 MFMA flops each."""
-    return kernel.startswith("wgrad_x3_kernel") or (kernel.startswith("conv3x3_halo_kernel") and kernel.endswith(",true,true>"))
+    if kernel.startswith("wgrad_x3_kernel"):
+        return True
+    if kernel.startswith("conv3x3_halo_kernel<"):                 # template arguments: FLIP, BN, BF16, SUBT, PACKED, X3, BNI
+        args = kernel[len("conv3x3_halo_kernel<"):].split(">")[0].split(",")
+        return len(args) >= 6 and args[5] == "true"
+    return False
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 
 
@@ -334,10 +339,10 @@ def main():
                                        WORKLOADS.get(args.config, args.config), cfg["MODEL"]["BACKBONE"]["NAME"],
                                        cfg["MODEL"]["HEAD"]["NAME"], B, P, P,
                                        "RGB" if CH == 3 else "grayscale", args.precision),
-                       "arithmetic": {"f32": "fp32 tensors, fp32 accumulate; packed 3x3 convs (fwd, dgrad): each fp32 operand cut exactly "
-                                             "into 3 bf16 pieces, 6 partial products per product on v_mfma_f32_32x32x16_bf16 "
+                       "arithmetic": {"f32": "fp32 tensors, fp32 accumulate; 3x3 / stride-1 convs (fwd, dgrad, wgrad): each fp32 operand cut "
+                                             "exactly into 3 bf16 pieces, 6 partial products per product on v_mfma_f32_32x32x16_bf16 "
                                              "(error vs float64 <= the fp32-input MFMA form: tests/test_conv_kernels_gpu.py); all "
-                                             "other convs and the weight gradients: v_mfma_f32_32x32x2_f32",
+                                             "other convs: v_mfma_f32_32x32x2_f32",
                                       "f32-mfma": "fp32 tensors, v_mfma_f32_32x32x2_f32 everywhere",
                                       "bf16": "fp32 tensors, conv operands rounded to bf16, fp32 accumulate"}[args.precision],
                        "stream_overlap": bool(args.overlap or os.environ.get("BIHOME_OVERLAP") == "1"),

@@ -726,8 +726,9 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
         if (!x3 || dgrad || !bni->table || bni->groups < 1 || d->N % bni->groups || (long long)bni->groups * Kc * 8 > 4096) return BH_E_UNSUPPORTED;
         a.bni = bni->table; a.bni_relu = bni->relu; a.bni_groups = bni->groups; a.bni_ipg = d->N / bni->groups;
     }
-    if (bh_query(bni ? "conv3x3_halo_kernel<%s,%d,%s,%d,true,true,true>" : x3 ? "conv3x3_halo_kernel<%s,%d,%s,%d,true,true>" : packed ? "conv3x3_halo_kernel<%s,%d,%s,%d,true>" : "conv3x3_halo_kernel<%s,%d,%s,%d>",
-                 dgrad ? "true" : "false", bn_tile, bf16 ? "true" : "false", subt)) {
+    // (all seven template arguments, as rocprofv3 prints the symbol: FLIP, BN, BF16, SUBT, PACKED, X3, BNI)
+    if (bh_query("conv3x3_halo_kernel<%s,%d,%s,%d,%s,%s,%s>", dgrad ? "true" : "false", bn_tile, bf16 ? "true" : "false", subt,
+                 packed ? "true" : "false", x3 ? "true" : "false", bni ? "true" : "false")) {
         *taken = 1;
         return BH_OK;
     }

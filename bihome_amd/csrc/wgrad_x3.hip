@@ -375,8 +375,7 @@ int bh_wgrad_x3_try(const float* x, const float* gy, float* gw, const bh_conv_de
         else if (ws_bytes < need) return BH_E_BADARG;
         a.partials = ws;
     }
-    if (bh_query(bni ? (ws ? "wgrad_x3_kernel<%d,true>+wgrad_x3_reduce_kernel<%d>" : "wgrad_x3_kernel<%d,true>")
-                     : (ws ? "wgrad_x3_kernel<%d>+wgrad_x3_reduce_kernel<%d>" : "wgrad_x3_kernel<%d>"), cb, cb)) { *taken = 1; return BH_OK; }
+    if (bh_query(ws ? "wgrad_x3_kernel<%d,%s>+wgrad_x3_reduce_kernel<%d>" : "wgrad_x3_kernel<%d,%s>", cb, bni ? "true" : "false", cb)) { *taken = 1; return BH_OK; }
     static unsigned long long attr_devs = 0;
     if (bh_device_once(attr_devs)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -415,7 +415,8 @@ def conv_fwd(x, w, bias, d, bn_sums=None, groups=1, res=None, relu=False, wpacke
         y = torch.empty(conv_out_shape(d), dtype=torch.float32, device=x.device)
         dp = getattr(d, "bh_packed", None) or _with_layout(d, 2)
         bs = bol.struct()
-        with _Timed(_conv_variant(dp, "fwd", bn_groups=groups if bn_sums is not None else 0) + "+bn_on_load" if TIMING is not None else "",
+        # (the library's name of the plain launch with the last template argument - BatchNorm-on-load - switched on)
+        with _Timed(_conv_variant(dp, "fwd", bn_groups=groups if bn_sums is not None else 0).replace(",false>", ",true>") if TIMING is not None else "",
                     conv_flops(d), 4.0 * (x.numel() + y.numel() + w.numel())):
             check(lib.bh_conv_fwd_bnin(_p(x), _p(wpacked), _p(bias), _p(y), ctypes.byref(dp), _p(bn_sums), groups, ctypes.byref(bs),
                                        _stream()), "bh_conv_fwd_bnin")
@@ -547,7 +548,7 @@ def conv_wgrad(x, gy, gw, gbias, d, det_ws=None):
         if det_ws is None or not (0 < need <= det_ws.numel() * 4):
             raise RuntimeError("BatchNorm-on-load needs the f32x3 weight gradient and its workspace")
         bs = bol.struct()
-        with _Timed((conv_variant(d, "wgrad_det") + "+bn_on_load" if TIMING is not None else ""), conv_flops(d),
+        with _Timed((conv_variant(d, "wgrad_det").replace(",false>", ",true>") if TIMING is not None else ""), conv_flops(d),
                     4.0 * (x.numel() + gy.numel() + gw.numel())):
             check(lib.bh_conv_wgrad_bnin(_p(x), _p(gy), _p(gw), _p(gbias), ctypes.byref(d), _p(det_ws), det_ws.numel() * 4,
                                          ctypes.byref(bs), _stream()), "bh_conv_wgrad_bnin")

@@ -397,7 +397,7 @@ def test_conv3x3_two_tile_positions_per_workgroup(K):
     res = {}
     for mode in (1, 0):                                   # 1: generic kernel, 0: halo kernel
         d = K.conv_desc(N, H, H, C, C, 3, 1, 1, route=ROUTE_GENERIC_CONV if mode else 0)
-        assert K.conv_variant(d, "fwd").startswith("conv_gemm_kernel" if mode else "conv3x3_halo_kernel<false,64,false,2>")
+        assert K.conv_variant(d, "fwd").startswith("conv_gemm_kernel" if mode else "conv3x3_halo_kernel<false,64,false,2,")
         sums = K.bn_stats_buffer(1, C, "cuda")
         res[mode] = (K.conv_fwd(x, w, None, d, bn_sums=sums, groups=1), K.conv_dgrad(gy, w, d), sums)
     assert float((res[0][0] - res[1][0]).abs().max()) < 5e-5
@@ -498,7 +498,7 @@ def test_conv3x3_packed_weights_match_lds_slab_path(K, N, H, Ci, Co, prec):
     pf, pd = pk.get(w)
     pk.refresh()
     dp = K._with_layout(d, 1)
-    assert K.conv_variant(dp, "fwd").endswith(",true>") and K.conv_variant(dp, "dgrad").endswith(",true>")
+    assert K.conv_variant(dp, "fwd").endswith(",true,false,false>") and K.conv_variant(dp, "dgrad").endswith(",true,false,false>")
     y0 = K.conv_fwd(x, wk, b, d)
     y1 = K.conv_fwd(x, wk, b, d, wpacked=pf)
     assert torch.equal(y0, y1)
@@ -561,8 +561,8 @@ def test_conv3x3_f32x3_is_fp32_accurate(K, N, H, Ci, Co, wide):
         pf, pd = pk.get(w)
         pk.refresh()
         dp = K._with_layout(d, 2 if prec == 2 else 1)
-        assert K.conv_variant(dp, "fwd").endswith(",true,true>" if prec == 2 else ",true>")
-        assert K.conv_variant(dp, "dgrad").endswith(",true,true>" if prec == 2 else ",true>")
+        assert K.conv_variant(dp, "fwd").endswith(",true,true,false>" if prec == 2 else ",true,false,false>")
+        assert K.conv_variant(dp, "dgrad").endswith(",true,true,false>" if prec == 2 else ",true,false,false>")
         y = K.conv_fwd(x, wk, b, d, wpacked=pf)
         s = K.bn_stats_buffer(1, Co, "cuda")
         assert torch.equal(y, K.conv_fwd(x, wk, b, d, bn_sums=s, groups=1, wpacked=pf))
