@@ -169,3 +169,32 @@ def test_imagenet_resnet34_key_placement():
         assert tuple(own[k].shape) == tuple(v.shape), k
     assert torch.equal(mapped["layer3.0.lower_branch.0.weight"], state["layer2.0.downsample.0.weight"])
     assert torch.equal(mapped["layer4.5.upper_branch.4.running_var"], state["layer3.5.bn2.running_var"])
+
+
+def test_ctypes_structs_mirror_the_header():
+    """The ctypes mirrors in bihome_amd/_lib.py (descriptor, pack job, BatchNorm reduce / on-load records) list the same fields,
+    in the same order and with the same C types, as the structs of include/bihome.h - a field added on one side only would
+    shift everything behind it silently."""
+    import ctypes
+    import re
+    from bihome_amd import _lib
+    src = open(os.path.join(os.path.dirname(__file__), "..", "include", "bihome.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    structs = {}
+    for body, name in re.findall(r"typedef\s+struct\s*\w*\s*\{(.*?)\}\s*(\w+)\s*;", src, flags=re.S):
+        fields = []
+        for decl in body.split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            m = re.match(r"(const\s+)?(\w+)\s*(\*?)\s*(.*)", decl)
+            ctype = "ptr" if m.group(3) or "*" in m.group(4) else m.group(2)
+            for nm in m.group(4).replace("*", "").split(","):
+                fields.append((nm.strip(), ctype))
+        structs[name] = fields
+    kinds = {ctypes.c_int: "int", ctypes.c_float: "float", ctypes.c_void_p: "ptr"}
+    for cname, cls in (("bh_conv_desc", _lib.BhConvDesc), ("bh_pack3x3_job", _lib.BhPack3x3Job), ("bh_bn_reduce", _lib.BhBnReduce),
+                       ("bh_bn_in", _lib.BhBnIn)):
+        assert cname in structs, cname
+        mirror = [(f, kinds[tp]) for f, tp in cls._fields_]
+        assert mirror == structs[cname], (cname, mirror, structs[cname])
