@@ -83,6 +83,184 @@ constexpr int C3_HALO_BYTES = 8 * 200 * 16;          // 25600
 constexpr int C3_B_BYTES = 8192;
 constexpr int C3_LDS_BYTES = 2 * C3_HALO_BYTES + 2 * C3_B_BYTES;      // 67584
 
+// ---- epilogue of one wave's accumulators: C/D layout col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m) ----
+// (shared by the halo kernels: the wave that holds - or was handed - the accumulators of tile position bx calls it with that
+//  wave's (wm, wn, wh) roles.  s1 / s2 return the tile's column sums for c3_stats_merge.)
+template <int BN, int SUBT, int TM>
+__device__ __forceinline__ void c3_epilogue(const C3Args& a, f32x16 (&acc)[TM], int bx, int n0, int wm, int wn, int wh, int l31, int kh2,
+                                            double& s1, double& s2, int& img, int& g) {
+    // ---- epilogue: C/D layout col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m) ----
+    // Element (i, r) of a lane is pixel (c3_strip_row(2*(r>>2) + kh2), 4*(i + wh) + (r&3)) of the sub-tile: the row part of
+    // its address is one of four per-lane VGPRs, the column part (4*(i + wh) + (r&3)) * Nn is workgroup-uniform and rides in
+    // the scalar offset of the buffer instruction - no per-element address arithmetic.
+    g = bx * SUBT + wm;
+    const int n = n0 + wn * 32 + l31;
+    const bool valid = g < a.subtiles && n < a.Nn;
+    const int gg = g < a.subtiles ? g : 0;
+    int ty, tx;
+    if (a.tpi_shift >= 0) { img = gg >> a.tpi_shift; const int t = gg & (a.tiles_per_img - 1); ty = t >> a.tx_shift; tx = t & (a.tiles_x - 1); }
+    else { img = gg / a.tiles_per_img; const int t = gg - img * a.tiles_per_img; ty = t / a.tiles_x; tx = t - ty * a.tiles_x; }
+    const float bv = (a.bias && n < a.Nn) ? a.bias[n] : 0.0f;
+    s1 = 0.0; s2 = 0.0;                            // BatchNorm statistics of the tile (a.bn_sums): sum y, sum y^2
+    float r_mean = 0.f, r_invstd = 0.f, r_sc = 0.f, r_sh = 0.f;
+    if (a.bnr_z && valid) {                        // coefficients of the BatchNorm whose output gradient this tile is
+        const int grp = img / a.imgs_per_group;
+        const double rows = (double)a.bnr_rows;
+        const double mu = a.bnr_stats[bn_sum_index(0, a.groups, grp, a.Nn, n, 0)] / rows;
+        double var = a.bnr_stats[bn_sum_index(0, a.groups, grp, a.Nn, n, 1)] / rows - mu * mu;
+        if (var < 0) var = 0;
+        r_mean = (float)mu;
+        r_invstd = 1.0f / sqrtf((float)var + a.bnr_eps);
+        r_sc = (a.bnr_gamma ? a.bnr_gamma[n] : 1.f) * r_invstd;
+        r_sh = (a.bnr_beta ? a.bnr_beta[n] : 0.f) - r_mean * r_sc;
+    }
+    if (valid) {
+        unsigned rowoff[4];                          // byte offsets (< 2^31: the host checks the tensor sizes)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq)
+            rowoff[rq] = ((unsigned)((img * a.H + ty * 8 + c3_strip_row(2 * rq + kh2)) * a.W + tx * 8) * (unsigned)a.Nn + (unsigned)n) * 4u;
+        const unsigned colstep = (unsigned)a.Nn * 4u;                                   // one pixel to the right
+        const unsigned col0 = (unsigned)(wh * 4) * colstep;
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(a.Out, 0, a.out_bytes, 0x00020000);
+#define C3_SOFF(i, r) (col0 + (unsigned)((i) * 4 + ((r) & 3)) * colstep)
+        if (!a.accumulate && !a.res && !a.bnr_z) {
+            // plain store (+ bias, ReLU) and the forward statistics: partial sums of a fragment quad in float, totals in double
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    float q1 = 0.f, q2 = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float v = acc[i][rq * 4 + c] + bv;
+                        if (a.relu) v = fmaxf(v, 0.0f);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsO, rowoff[rq], C3_SOFF(i, c), 0);
+                        q1 += v; q2 = __builtin_fmaf(v, v, q2);
+                    }
+                    s1 += (double)q1; s2 += (double)q2;
+                }
+        } else {
+            // Generic epilogue, instantiated per combination of (old gradient / residual present, BatchNorm reduce with or
+            // without a saved output) so that no variant carries the loads, zero fills and selects of the others.
+            // Phase 1 issues every global read (old gradient, residual, BatchNorm input / output) before the first store -
+            // a load behind a store would otherwise wait for that store (one vmcnt queue, in order).
+            const bool rd_old = a.accumulate, rd_res = a.res != nullptr, rd_z = a.bnr_z != nullptr;
+            const bool rd_y = rd_z && a.bnr_relu && a.bnr_y != nullptr;
+            const float c_x0 = -r_mean * r_invstd;                     // xhat = z * invstd + c_x0
+            auto body = [&](auto EXTRA, auto ZMODE) {                  // ZMODE 0: forward statistics, 1: reduce (mask from z), 2: reduce (mask from y)
+                constexpr bool HAS_EXTRA = decltype(EXTRA)::value;
+                constexpr int ZM = decltype(ZMODE)::value;
+                float ext[HAS_EXTRA ? TM : 1][16], zin[ZM > 0 ? TM : 1][16], yin[ZM == 2 ? TM : 1][16];
+                if constexpr (HAS_EXTRA) {
+                    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rd_res ? a.res : a.Out), 0, a.out_bytes, 0x00020000);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float o = 0.f;
+                            if (rd_old) o = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsO, rowoff[r >> 2], C3_SOFF(i, r), 0));
+                            if (rd_res) o += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, rowoff[r >> 2], C3_SOFF(i, r), 0));
+                            ext[i][r] = o;
+                        }
+                }
+                if constexpr (ZM > 0) {
+                    const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bnr_z), 0, a.out_bytes, 0x00020000);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            zin[i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsZ, rowoff[r >> 2], C3_SOFF(i, r), 0));
+                }
+                if constexpr (ZM == 2) {
+                    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bnr_y), 0, a.out_bytes, 0x00020000);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            yin[i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsY, rowoff[r >> 2], C3_SOFF(i, r), 0));
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        float q1 = 0.f, q2 = 0.f;                          // partial sums of a fragment quad in float, totals in double
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const int r = rq * 4 + c;
+                            float v = acc[i][r] + bv;
+                            if constexpr (HAS_EXTRA) v += ext[i][r];
+                            if (a.relu) v = fmaxf(v, 0.0f);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsO, rowoff[rq], C3_SOFF(i, r), 0);
+                            if constexpr (ZM > 0) {
+                                const float zv = zin[i][r];
+                                if (a.bnr_relu) {
+                                    const float yv = ZM == 2 ? yin[i][r] : __builtin_fmaf(zv, r_sc, r_sh);
+                                    if (!(yv > 0.f)) v = 0.f;
+                                }
+                                q1 += v; q2 = __builtin_fmaf(v, __builtin_fmaf(zv, r_invstd, c_x0), q2);
+                            } else {
+                                q1 += v; q2 = __builtin_fmaf(v, v, q2);
+                            }
+                        }
+                        s1 += (double)q1; s2 += (double)q2;
+                    }
+            };
+            using T_ = std::true_type; using F_ = std::false_type;
+            using Z0 = std::integral_constant<int, 0>; using Z1 = std::integral_constant<int, 1>; using Z2 = std::integral_constant<int, 2>;
+            if (rd_old || rd_res) {
+                if (!rd_z) body(T_{}, Z0{}); else if (!rd_y) body(T_{}, Z1{}); else body(T_{}, Z2{});
+            } else {
+                if (!rd_z) body(F_{}, Z0{}); else if (!rd_y) body(F_{}, Z1{}); else body(F_{}, Z2{});
+            }
+        }
+#undef C3_SOFF
+    }
+}
+
+// column sums of a tile -> the [groups][C][2] totals.  PHASE 0: both halves with a workgroup barrier in between (the halo
+// kernels); 1: the LDS writes only; 2: the merge + atomics only (the caller puts a barrier between the two).
+template <int BN, int PHASE>
+__device__ __forceinline__ void c3_stats_merge(const C3Args& a, char* redb, double s1, double s2, int img, int g, int bx, int n0, int wave,
+                                               int lane, int tid) {
+    const int l31 = lane & 31, kh2 = lane >> 5;
+    double* red = reinterpret_cast<double*>(redb);          // [4 waves][32 columns][2]
+    int* grp_of = reinterpret_cast<int*>(redb + 4 * 32 * 2 * 8);
+    if constexpr (PHASE != 2) {
+        // the two half-waves hold the two row halves of a column; the waves that share the channel range are merged through
+        // LDS when they belong to the same statistics group, then one f64 atomic per (channel, moment) goes to the totals
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        const int grp = img / a.imgs_per_group;
+        if (kh2 == 0) { red[(wave * 32 + l31) * 2] = s1; red[(wave * 32 + l31) * 2 + 1] = s2; }
+        if (lane == 0) grp_of[wave] = g < a.subtiles ? grp : -1;
+    }
+    if constexpr (PHASE == 0) __syncthreads();
+    if constexpr (PHASE != 1) {
+        constexpr int SHARE = BN == 64 ? 2 : 4;                  // waves per channel range
+        // thread -> (channel range cr, column, moment); waves of range cr: BN=64: wave = wm + 2*cr; BN=32: all four
+        if (tid < (4 / SHARE) * 64) {
+            const int cr = tid >> 6, col = (tid >> 1) & 31, mom = tid & 1;
+            const int nn = n0 + cr * 32 + col;
+            if (nn < a.Nn) {
+                int done = 0;                                    // bit w: wave already merged
+#pragma unroll
+                for (int w0 = 0; w0 < SHARE; ++w0) {
+                    const int wv0 = BN == 64 ? (w0 + 2 * cr) : w0;
+                    const int g0 = grp_of[wv0];
+                    if (g0 < 0 || (done >> w0) & 1) continue;
+                    double tot = red[(wv0 * 32 + col) * 2 + mom];
+#pragma unroll
+                    for (int w1 = w0 + 1; w1 < SHARE; ++w1) {
+                        const int wv1 = BN == 64 ? (w1 + 2 * cr) : w1;
+                        if (grp_of[wv1] == g0) { tot += red[(wv1 * 32 + col) * 2 + mom]; done |= 1 << w1; }
+                    }
+                    atomicAdd(&a.bn_sums[bn_sum_index(bx % BH_BN_SUM_SLOTS, a.groups, g0, a.Nn, nn, mom)], tot);
+                }
+            }
+        }
+    }
+}
+
 // BN = 64: wave (wm, wn) owns sub-tile wm x channels [32 wn, 32 wn + 32) (two A fragments per B fragment);
 // BN = 32: wave w owns rows [32 w, 32 w + 32) of the 128-row tile x all 32 channels (the 32-channel decoder layers).
 // BF16 (bh_conv_desc.precision = 1): same fp32 LDS image, the fragments are rounded to bf16 in registers and fed to
@@ -489,167 +667,10 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
 #undef C3_LOAD_B
 #undef C3_LOAD_BX
 
-    // ---- epilogue: C/D layout col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m) ----
-    // Element (i, r) of a lane is pixel (c3_strip_row(2*(r>>2) + kh2), 4*(i + wh) + (r&3)) of the sub-tile: the row part of
-    // its address is one of four per-lane VGPRs, the column part (4*(i + wh) + (r&3)) * Nn is workgroup-uniform and rides in
-    // the scalar offset of the buffer instruction - no per-element address arithmetic.
-    const int g = bx * SUBT + wm;
-    const int n = n0 + wn * 32 + l31;
-    const bool valid = g < a.subtiles && n < a.Nn;
-    const int gg = g < a.subtiles ? g : 0;
-    int img, ty, tx;
-    if (a.tpi_shift >= 0) { img = gg >> a.tpi_shift; const int t = gg & (a.tiles_per_img - 1); ty = t >> a.tx_shift; tx = t & (a.tiles_x - 1); }
-    else { img = gg / a.tiles_per_img; const int t = gg - img * a.tiles_per_img; ty = t / a.tiles_x; tx = t - ty * a.tiles_x; }
-    const float bv = (a.bias && n < a.Nn) ? a.bias[n] : 0.0f;
-    double s1 = 0.0, s2 = 0.0;                     // BatchNorm statistics of the tile (a.bn_sums): sum y, sum y^2
-    float r_mean = 0.f, r_invstd = 0.f, r_sc = 0.f, r_sh = 0.f;
-    if (a.bnr_z && valid) {                        // coefficients of the BatchNorm whose output gradient this tile is
-        const int grp = img / a.imgs_per_group;
-        const double rows = (double)a.bnr_rows;
-        const double mu = a.bnr_stats[bn_sum_index(0, a.groups, grp, a.Nn, n, 0)] / rows;
-        double var = a.bnr_stats[bn_sum_index(0, a.groups, grp, a.Nn, n, 1)] / rows - mu * mu;
-        if (var < 0) var = 0;
-        r_mean = (float)mu;
-        r_invstd = 1.0f / sqrtf((float)var + a.bnr_eps);
-        r_sc = (a.bnr_gamma ? a.bnr_gamma[n] : 1.f) * r_invstd;
-        r_sh = (a.bnr_beta ? a.bnr_beta[n] : 0.f) - r_mean * r_sc;
-    }
-    if (valid) {
-        unsigned rowoff[4];                          // byte offsets (< 2^31: the host checks the tensor sizes)
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq)
-            rowoff[rq] = ((unsigned)((img * a.H + ty * 8 + c3_strip_row(2 * rq + kh2)) * a.W + tx * 8) * (unsigned)a.Nn + (unsigned)n) * 4u;
-        const unsigned colstep = (unsigned)a.Nn * 4u;                                   // one pixel to the right
-        const unsigned col0 = (unsigned)(wh * 4) * colstep;
-        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(a.Out, 0, a.out_bytes, 0x00020000);
-#define C3_SOFF(i, r) (col0 + (unsigned)((i) * 4 + ((r) & 3)) * colstep)
-        if (!a.accumulate && !a.res && !a.bnr_z) {
-            // plain store (+ bias, ReLU) and the forward statistics: partial sums of a fragment quad in float, totals in double
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    float q1 = 0.f, q2 = 0.f;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        float v = acc[i][rq * 4 + c] + bv;
-                        if (a.relu) v = fmaxf(v, 0.0f);
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsO, rowoff[rq], C3_SOFF(i, c), 0);
-                        q1 += v; q2 = __builtin_fmaf(v, v, q2);
-                    }
-                    s1 += (double)q1; s2 += (double)q2;
-                }
-        } else {
-            // Generic epilogue, instantiated per combination of (old gradient / residual present, BatchNorm reduce with or
-            // without a saved output) so that no variant carries the loads, zero fills and selects of the others.
-            // Phase 1 issues every global read (old gradient, residual, BatchNorm input / output) before the first store -
-            // a load behind a store would otherwise wait for that store (one vmcnt queue, in order).
-            const bool rd_old = a.accumulate, rd_res = a.res != nullptr, rd_z = a.bnr_z != nullptr;
-            const bool rd_y = rd_z && a.bnr_relu && a.bnr_y != nullptr;
-            const float c_x0 = -r_mean * r_invstd;                     // xhat = z * invstd + c_x0
-            auto body = [&](auto EXTRA, auto ZMODE) {                  // ZMODE 0: forward statistics, 1: reduce (mask from z), 2: reduce (mask from y)
-                constexpr bool HAS_EXTRA = decltype(EXTRA)::value;
-                constexpr int ZM = decltype(ZMODE)::value;
-                float ext[HAS_EXTRA ? TM : 1][16], zin[ZM > 0 ? TM : 1][16], yin[ZM == 2 ? TM : 1][16];
-                if constexpr (HAS_EXTRA) {
-                    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rd_res ? a.res : a.Out), 0, a.out_bytes, 0x00020000);
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            float o = 0.f;
-                            if (rd_old) o = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsO, rowoff[r >> 2], C3_SOFF(i, r), 0));
-                            if (rd_res) o += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, rowoff[r >> 2], C3_SOFF(i, r), 0));
-                            ext[i][r] = o;
-                        }
-                }
-                if constexpr (ZM > 0) {
-                    const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bnr_z), 0, a.out_bytes, 0x00020000);
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            zin[i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsZ, rowoff[r >> 2], C3_SOFF(i, r), 0));
-                }
-                if constexpr (ZM == 2) {
-                    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bnr_y), 0, a.out_bytes, 0x00020000);
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            yin[i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsY, rowoff[r >> 2], C3_SOFF(i, r), 0));
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int rq = 0; rq < 4; ++rq) {
-                        float q1 = 0.f, q2 = 0.f;                          // partial sums of a fragment quad in float, totals in double
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const int r = rq * 4 + c;
-                            float v = acc[i][r] + bv;
-                            if constexpr (HAS_EXTRA) v += ext[i][r];
-                            if (a.relu) v = fmaxf(v, 0.0f);
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsO, rowoff[rq], C3_SOFF(i, r), 0);
-                            if constexpr (ZM > 0) {
-                                const float zv = zin[i][r];
-                                if (a.bnr_relu) {
-                                    const float yv = ZM == 2 ? yin[i][r] : __builtin_fmaf(zv, r_sc, r_sh);
-                                    if (!(yv > 0.f)) v = 0.f;
-                                }
-                                q1 += v; q2 = __builtin_fmaf(v, __builtin_fmaf(zv, r_invstd, c_x0), q2);
-                            } else {
-                                q1 += v; q2 = __builtin_fmaf(v, v, q2);
-                            }
-                        }
-                        s1 += (double)q1; s2 += (double)q2;
-                    }
-            };
-            using T_ = std::true_type; using F_ = std::false_type;
-            using Z0 = std::integral_constant<int, 0>; using Z1 = std::integral_constant<int, 1>; using Z2 = std::integral_constant<int, 2>;
-            if (rd_old || rd_res) {
-                if (!rd_z) body(T_{}, Z0{}); else if (!rd_y) body(T_{}, Z1{}); else body(T_{}, Z2{});
-            } else {
-                if (!rd_z) body(F_{}, Z0{}); else if (!rd_y) body(F_{}, Z1{}); else body(F_{}, Z2{});
-            }
-        }
-#undef C3_SOFF
-    }
-    if (a.bn_sums) {
-        // column sums: the two half-waves hold the two row halves of a column; the waves that share the channel range
-        // are merged through LDS (free after the last barrier of the main loop) when they belong to the same
-        // statistics group, then one f64 atomic per (channel, moment) goes to the [groups][C][2] totals
-        s1 += __shfl_xor(s1, 32, 64);
-        s2 += __shfl_xor(s2, 32, 64);
-        double* red = reinterpret_cast<double*>(smem);          // [4 waves][32 columns][2]
-        int* grp_of = reinterpret_cast<int*>(smem + 4 * 32 * 2 * 8);
-        const int grp = img / a.imgs_per_group;
-        if (kh2 == 0) { red[(wave * 32 + l31) * 2] = s1; red[(wave * 32 + l31) * 2 + 1] = s2; }
-        if (lane == 0) grp_of[wave] = g < a.subtiles ? grp : -1;
-        __syncthreads();
-        constexpr int SHARE = BN == 64 ? 2 : 4;                  // waves per channel range
-        // thread -> (channel range cr, column, moment); waves of range cr: BN=64: wave = wm + 2*cr; BN=32: all four
-        if (tid < (4 / SHARE) * 64) {
-            const int cr = tid >> 6, col = (tid >> 1) & 31, mom = tid & 1;
-            const int nn = n0 + cr * 32 + col;
-            if (nn < a.Nn) {
-                int done = 0;                                    // bit w: wave already merged
-#pragma unroll
-                for (int w0 = 0; w0 < SHARE; ++w0) {
-                    const int wv0 = BN == 64 ? (w0 + 2 * cr) : w0;
-                    const int g0 = grp_of[wv0];
-                    if (g0 < 0 || (done >> w0) & 1) continue;
-                    double tot = red[(wv0 * 32 + col) * 2 + mom];
-#pragma unroll
-                    for (int w1 = w0 + 1; w1 < SHARE; ++w1) {
-                        const int wv1 = BN == 64 ? (w1 + 2 * cr) : w1;
-                        if (grp_of[wv1] == g0) { tot += red[(wv1 * 32 + col) * 2 + mom]; done |= 1 << w1; }
-                    }
-                    atomicAdd(&a.bn_sums[bn_sum_index(bx % BH_BN_SUM_SLOTS, a.groups, g0, a.Nn, nn, mom)], tot);
-                }
-            }
-        }
-    }
+    double s1, s2;
+    int img, g;
+    c3_epilogue<BN, SUBT, TM>(a, acc, bx, n0, wm, wn, wh, l31, kh2, s1, s2, img, g);
+    if (a.bn_sums) c3_stats_merge<BN, 0>(a, smem, s1, s2, img, g, bx, n0, wave, lane, tid);
     __syncthreads();            // the next tile's DMA overwrites the LDS this tile's statistics merge just read
     }
 }
