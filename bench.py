@@ -214,25 +214,68 @@ WORKLOADS = {
 }
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start `python -m torch.distributed.run --nproc-per-node N
+    bench.py <same flags>` as a CHILD process - this process has made no GPU call yet (a process that has initialised the GPU
+    is never replaced or re-executed) - relay its output (rank 0's JSON line) and exit with its code.  A box with fewer than
+    N GPUs fails here, loudly, instead of reporting a one-rank number as an N-GPU one."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()                   # (counting devices does not initialise the GPU on this image)
+    gloo_dev = os.environ.get("BIHOME_DIST_BACKEND", "nccl") != "nccl"      # dev only: ranks may share a GPU over gloo
+    if ndev < args.gpus and not gloo_dev:
+        raise SystemExit("bench.py: --gpus %d but this node exposes %d GPU(s): refusing to report fewer ranks as %d "
+                         "(RCCL needs one device per rank)" % (args.gpus, ndev, args.gpus))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without a launcher: spawning %s" % (args.gpus, " ".join(cmd[1:9])), file=sys.stderr, flush=True)
+    r = subprocess.run(cmd, env=env)
+    raise SystemExit(r.returncode)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)                              # never returns
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or without a launcher)"
+                         % (args.gpus, world, args.gpus))
     ndev = torch.cuda.device_count()
+    backend = os.environ.get("BIHOME_DIST_BACKEND", "nccl")           # "nccl" IS RCCL on ROCm
+    if world > 1 and backend == "nccl" and ndev < world:
+        raise SystemExit("bench.py: %d ranks but %d GPU(s) visible: RCCL needs one device per rank" % (world, ndev))
     local = local % max(ndev, 1)          # (dev only: several ranks may share one GPU with BIHOME_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("BIHOME_DIST_BACKEND", "nccl")       # "nccl" IS RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
+        # every rank proves it is there: one all-reduce of ones over the data-path backend must count N
+        ones = torch.ones(1, device="cuda")
+        dist.all_reduce(ones)
+        torch.cuda.synchronize()
+        if int(ones.item()) != world:
+            raise SystemExit("bench.py: all-reduce counted %d ranks, expected %d" % (int(ones.item()), world))
+        if rank == 0:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else "-"
+            print("bench.py: process group up: backend=%s (RCCL %s) world_size=%d, all-reduce counted %d ranks, devices/node=%d"
+                  % (backend, ver, world, int(ones.item()), ndev), file=sys.stderr, flush=True)
 
     from bihome_amd import configs, synth
     from bihome_amd.step import attach_reducer, build_model, build_optimizer, mace, train_step

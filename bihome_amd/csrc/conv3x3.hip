@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
             }
             xoff[j] = off;
         }
-        const float bni_lo = a.bni_relu ? 0.0f : -3.0e38f;
+        const float bni_lo = a.bni_relu ? 0.0f : -__builtin_inff();   // v_maximum3_f32: NaN propagates (fmaxf would drop it), -inf passes everything
         // y = max(x * scale + shift, lo) on the 8 channels of a slot; out-of-image slots stay zero
 #define X3_BNI(j, c, h)                                                                                                 \
     do {                                                                                                                \
@@ -428,14 +428,14 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
             const float4* tb_ = reinterpret_cast<const float4*>(smem + xtb[j] + (c) * 256);                             \
             const float4 t0_ = tb_[0], t1_ = tb_[1], t2_ = tb_[2], t3_ = tb_[3];                                       \
             const bool ok_ = xoff[j] != XOOB;                                                                           \
-            h[0].x = ok_ ? fmaxf(__builtin_fmaf(h[0].x, t0_.x, t0_.y), bni_lo) : 0.f;                                   \
-            h[0].y = ok_ ? fmaxf(__builtin_fmaf(h[0].y, t0_.z, t0_.w), bni_lo) : 0.f;                                   \
-            h[0].z = ok_ ? fmaxf(__builtin_fmaf(h[0].z, t1_.x, t1_.y), bni_lo) : 0.f;                                   \
-            h[0].w = ok_ ? fmaxf(__builtin_fmaf(h[0].w, t1_.z, t1_.w), bni_lo) : 0.f;                                   \
-            h[1].x = ok_ ? fmaxf(__builtin_fmaf(h[1].x, t2_.x, t2_.y), bni_lo) : 0.f;                                   \
-            h[1].y = ok_ ? fmaxf(__builtin_fmaf(h[1].y, t2_.z, t2_.w), bni_lo) : 0.f;                                   \
-            h[1].z = ok_ ? fmaxf(__builtin_fmaf(h[1].z, t3_.x, t3_.y), bni_lo) : 0.f;                                   \
-            h[1].w = ok_ ? fmaxf(__builtin_fmaf(h[1].w, t3_.z, t3_.w), bni_lo) : 0.f;                                   \
+            h[0].x = ok_ ? __builtin_elementwise_maximum(__builtin_fmaf(h[0].x, t0_.x, t0_.y), bni_lo) : 0.f;                                   \
+            h[0].y = ok_ ? __builtin_elementwise_maximum(__builtin_fmaf(h[0].y, t0_.z, t0_.w), bni_lo) : 0.f;                                   \
+            h[0].z = ok_ ? __builtin_elementwise_maximum(__builtin_fmaf(h[0].z, t1_.x, t1_.y), bni_lo) : 0.f;                                   \
+            h[0].w = ok_ ? __builtin_elementwise_maximum(__builtin_fmaf(h[0].w, t1_.z, t1_.w), bni_lo) : 0.f;                                   \
+            h[1].x = ok_ ? __builtin_elementwise_maximum(__builtin_fmaf(h[1].x, t2_.x, t2_.y), bni_lo) : 0.f;                                   \
+            h[1].y = ok_ ? __builtin_elementwise_maximum(__builtin_fmaf(h[1].y, t2_.z, t2_.w), bni_lo) : 0.f;                                   \
+            h[1].z = ok_ ? __builtin_elementwise_maximum(__builtin_fmaf(h[1].z, t3_.x, t3_.y), bni_lo) : 0.f;                                   \
+            h[1].w = ok_ ? __builtin_elementwise_maximum(__builtin_fmaf(h[1].w, t3_.z, t3_.w), bni_lo) : 0.f;                                   \
         }                                                                                                               \
     } while (0)
         // (rounds whose first slot of this wave is past the image are skipped wave-uniformly: 800 = 3 x 256 + 32 slots)

@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_x3_kernel(WX3Args a) {
         }
     }
     if constexpr (BNI) __syncthreads();
-    const float bni_lo = a.bni_relu ? 0.0f : -3.0e38f;
+    const float bni_lo = a.bni_relu ? 0.0f : -__builtin_inff();   // v_maximum3_f32: NaN propagates (fmaxf would drop it), -inf passes everything
     // loads of tile t.  part -1: all; 0: the gy slots; 1 / 2: the first / second half of the halo slots (each register group is
     // re-requested as soon as its slots have been written out, so every load has most of a tile of MFMAs to arrive)
     auto issue_part = [&](int t, auto PART) {
@@ -163,10 +163,10 @@ __global__ void __launch_bounds__(256, 1) wgrad_x3_kernel(WX3Args a) {
                 const bool ok = h_ok[j];
                 float4& u = rx[j][0];
                 float4& v = rx[j][1];
-                u.x = ok ? fmaxf(__builtin_fmaf(u.x, t0.x, t0.y), bni_lo) : 0.f; u.y = ok ? fmaxf(__builtin_fmaf(u.y, t0.z, t0.w), bni_lo) : 0.f;
-                u.z = ok ? fmaxf(__builtin_fmaf(u.z, t1.x, t1.y), bni_lo) : 0.f; u.w = ok ? fmaxf(__builtin_fmaf(u.w, t1.z, t1.w), bni_lo) : 0.f;
-                v.x = ok ? fmaxf(__builtin_fmaf(v.x, t2.x, t2.y), bni_lo) : 0.f; v.y = ok ? fmaxf(__builtin_fmaf(v.y, t2.z, t2.w), bni_lo) : 0.f;
-                v.z = ok ? fmaxf(__builtin_fmaf(v.z, t3.x, t3.y), bni_lo) : 0.f; v.w = ok ? fmaxf(__builtin_fmaf(v.w, t3.z, t3.w), bni_lo) : 0.f;
+                u.x = ok ? __builtin_elementwise_maximum(__builtin_fmaf(u.x, t0.x, t0.y), bni_lo) : 0.f; u.y = ok ? __builtin_elementwise_maximum(__builtin_fmaf(u.y, t0.z, t0.w), bni_lo) : 0.f;
+                u.z = ok ? __builtin_elementwise_maximum(__builtin_fmaf(u.z, t1.x, t1.y), bni_lo) : 0.f; u.w = ok ? __builtin_elementwise_maximum(__builtin_fmaf(u.w, t1.z, t1.w), bni_lo) : 0.f;
+                v.x = ok ? __builtin_elementwise_maximum(__builtin_fmaf(v.x, t2.x, t2.y), bni_lo) : 0.f; v.y = ok ? __builtin_elementwise_maximum(__builtin_fmaf(v.y, t2.z, t2.w), bni_lo) : 0.f;
+                v.z = ok ? __builtin_elementwise_maximum(__builtin_fmaf(v.z, t3.x, t3.y), bni_lo) : 0.f; v.w = ok ? __builtin_elementwise_maximum(__builtin_fmaf(v.w, t3.z, t3.w), bni_lo) : 0.f;
             }
             bh_split8(rx[j][0], rx[j][1], p0, p1, p2);
             *reinterpret_cast<uint4*>(img + h_lds[j]) = p0;

@@ -48,6 +48,9 @@ class GraphedStep:
         for k in self.keys:
             self.static[k].copy_(data[k], non_blocking=True)
         self.graph.replay()
+        # the replay ran no Python: the captured fused Adam and BatchNorm kernels changed weights and running statistics
+        # without any of the eager forward's cache bookkeeping (version counters do not move either)
+        net.invalidate_caches(self.model)
         for m, inc in zip(self._bns, self._bn_inc):
             if inc:
                 m._bh_pending_batches = getattr(m, "_bh_pending_batches", 0) + inc

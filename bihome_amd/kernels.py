@@ -347,6 +347,11 @@ class WeightPacker:
             self.table = None
         return e[1], e[2]
 
+    def invalidate(self):
+        """The weights changed behind the version counters (graph replay, broadcast into .data): repack at the next refresh."""
+        self.versions = None
+        self.dirty = True
+
     def refresh(self, training=False):
         """Repack when a parameter changed.  Version counters catch load_state_dict / copy_ / the default optimizers, but
         torch's FUSED optimizers update parameters without bumping them - so trainable weights are repacked on every

@@ -14,6 +14,7 @@ MI355X-first choices:
     in a HIP graph.
 """
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -186,6 +187,7 @@ class Ctx:
 
 
 _GEOM_CACHE = {}
+X3_WS_BYTES = 40 << 20          # Runner.x3_workspace: partial blocks of the f32x3 weight gradient
 
 
 def _conv_geometry(mod, x_shape, in_nchw, out_nchw, precision=0):
@@ -203,6 +205,7 @@ def _conv_geometry(mod, x_shape, in_nchw, out_nchw, precision=0):
     d.bh_packed = K._with_layout(d, 2 if int(precision) == 2 else 1) if d.bh_packs else None
     # f32x3 weight gradient (csrc/wgrad_x3.hip): reduces its split-K partial blocks through a workspace (fixed order, cheaper than atomics)
     d.bh_wx3 = bool(int(precision) == 2 and isinstance(mod, nn.Conv2d) and K.conv_variant(d, "wgrad").startswith("wgrad_x3"))
+    d.bh_wx3_bytes = K.wgrad_det_bytes(d) if d.bh_wx3 else 0
     _GEOM_CACHE[key] = (mod, d)
     return d
 
@@ -265,7 +268,9 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, p
     runs with that BatchNorm folded into its weights and the ReLU / residual add fused into its epilogue."""
     ctx = Ctx() if save else None
     if packer is not None:
-        packer.refresh(training)
+        # a forward that saves for backward is (probably) followed by an optimizer step, whatever module.training says
+        # (frozen-BatchNorm fine-tuning runs the backbone in eval() mode): fused optimizers do not bump version counters
+        packer.refresh(training or save)
     slots = {0: x}
     if save:
         ctx.groups, ctx.training = groups, training
@@ -371,7 +376,9 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, p
             if i in bn_on_load and i in ready and src.shape[0] % groups == 0:
                 cop = prog.ops[consumer[op.dst]]
                 cd = _conv_geometry(cop.mod, src.shape, False, cop.extra["out_nchw"], precision)
-                lazy = bool(cd.bh_packs and cd.bh_wx3)
+                # (the consumer's weight gradient must fit the fixed f32x3 workspace, else its backward could not take the
+                #  un-materialised operand: decided here, before the BatchNorm output is elided)
+                lazy = bool(cd.bh_packs and cd.bh_wx3 and 0 < cd.bh_wx3_bytes <= X3_WS_BYTES)
             if lazy:
                 st = arena[bn_off[i]:bn_off[i] + K.bn_stats_doubles(groups, m.num_features)]
                 table = K.bn_fwd_coeffs(st, m.weight, m.bias, m.running_mean, m.running_var, groups,
@@ -618,8 +625,10 @@ class NetFunction(torch.autograd.Function):
         # (needs_input_grad reflects requires_grad of the inputs even under torch.no_grad(): the caller passes the mode)
         need = grad_mode and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         training = runner.module.training
-        if training:
-            runner._fold.clear()            # running statistics are about to change (the kernels write them in place)
+        if training or need:
+            # running statistics (training) or the weights (a backward + fused optimizer step follows: no version bump) are
+            # about to change under the folded copies
+            runner._fold.clear()
         fold = runner._fold if (runner.fold_bn and not training and not need) else None
         out, saved = run_forward(runner.prog, x, groups, training, save=need, precision=runner.precision, fold_cache=fold,
                                  packer=runner.packer_for(x.device) if fold is None else None)
@@ -642,10 +651,29 @@ class NetFunction(torch.autograd.Function):
         return gin, None, None, None, None
 
 
+_RUNNERS = weakref.WeakSet()
+
+
+def invalidate_caches(model=None):
+    """Drop every host-side copy derived from parameters / buffers (BatchNorm-folded weights, fragment-ordered packs, the
+    transposed stem table) of the Runners over `model`'s modules (all Runners when None).  Needed wherever weights or
+    running statistics change WITHOUT the eager forward's own bookkeeping seeing it: HIP-graph replays (no Python runs,
+    fused Adam and the BatchNorm kernels bump no version counter) and the parameter broadcast of attach_reducer."""
+    mods = None if model is None else {id(m) for m in model.modules()}
+    for r in list(_RUNNERS):
+        if mods is not None and id(r.module) not in mods:
+            continue
+        r._fold.clear()
+        if r._packer is not None:
+            r._packer.invalidate()
+    K._STEM_WT.clear()
+
+
 class Runner:
     """Binds a Program to its nn.Module (parameter container) and, if trainable, a FlatGrads buffer."""
 
     def __init__(self, module, prog, trainable, precision="f32", fold_cache=None):
+        _RUNNERS.add(self)
         self.module, self.prog = module, prog
         self.precision = K.PRECISION[str(precision).lower()]     # conv operand precision (0 fp32, 1 bf16 operands, 2 f32x3)
         params = [p for p in module.parameters() if p.requires_grad]
@@ -681,7 +709,7 @@ class Runner:
         if self.precision != 2 or self.flat is None:
             return None
         if self._det_ws is None or self._det_ws.device != device:
-            self._det_ws = torch.empty(10 << 20, dtype=torch.float32, device=device)
+            self._det_ws = torch.empty(X3_WS_BYTES // 4, dtype=torch.float32, device=device)
         return self._det_ws
 
     def packer_for(self, device):

@@ -119,12 +119,12 @@ def attach_reducer(model, bucket_bytes=8 << 20):
     return r.reducer
 
 
-def broadcast_model(model, src=0):
+def broadcast_model(model, src=0, force=False):
     """What torch's DistributedDataParallel does at construction: every parameter and buffer (BatchNorm running
     statistics, counters) of the replica is overwritten with rank `src`'s, so that replicas start identical whatever
-    each rank initialised or loaded.  No-op outside a process group."""
+    each rank initialised or loaded.  No-op outside a process group (and in a one-rank group unless `force`)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return
     from . import net
     net.flush_counters(model)
@@ -144,3 +144,6 @@ def broadcast_model(model, src=0):
                     c = t.data.contiguous()
                     dist.broadcast(c, src)
                     t.data.copy_(c)
+    # writes through .data bump no version counter: caches keyed on versions (folded BatchNorms, packed 3x3 weights of frozen
+    # layers, the extractor's transposed stem table) would keep this rank's pre-broadcast weights
+    net.invalidate_caches(model)

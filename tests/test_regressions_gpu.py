@@ -168,3 +168,89 @@ def test_packed_weights_follow_fused_optimizer_updates(precision):
     # whose sign differs between the two move apart by 2 lr each - 3 % in the next loss from these random weights
     assert abs(l1[1] - l0[1]) <= (1e-3 if precision == "f32-mfma" else 8e-2) * abs(l0[1]) + 1e-3, (l1, l0)
     assert abs(l1[2] - l0[2]) <= (5e-2 if precision == "f32-mfma" else 1e-1) * abs(l0[2]) + 1e-2, (l1, l0)       # (two eager runs differ by ~0.5 % by now: atomics order)
+
+
+def _set_running_stats_from_batch(model, data):
+    """One training-mode forward with momentum 1: running statistics = this batch's (a well-conditioned eval-mode network
+    from random weights)."""
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    old = [m.momentum for m in bns]
+    for m in bns:
+        m.momentum = 1.0
+    model.train()
+    with torch.no_grad():
+        model[0](dict(data))
+    for m, o in zip(bns, old):
+        m.momentum = o
+
+
+def test_packed_weights_follow_fused_adam_in_eval_mode():
+    """Round-2 ADVICE (medium): fine-tuning with frozen BatchNorm runs the module in eval() mode WITH gradients; fused Adam bumps
+    no version counter, so the packed 3x3 weights must be refreshed on every forward that saves for backward, not only when
+    module.training is set.  Three steps packer on vs off ('f32-mfma': the same MFMA order either way - stale copies show at 1e-1)."""
+    from bihome_amd.step import build_model, build_optimizer
+    cfg = configs.get("zeng-bihome")
+    cfg["MODEL"]["BACKBONE"]["PRECISION"] = cfg["MODEL"]["HEAD"]["PRECISION"] = "f32-mfma"
+    d = synth.make_pairs(8, seed=14)
+    g = torch.Generator().manual_seed(4)
+    ch = [torch.randint(1, 128 * 128, (8, 128), generator=g).cuda() for _ in range(2)]
+    res, evals = {}, {}
+    for use in (True, False):
+        model = build_model(cfg)
+        load_synthetic(model[0], 0)
+        load_synthetic(model[1].auxiliary_resnet, 0)
+        opt, sched = build_optimizer(model, cfg["SOLVER"])
+        data = {k: cuda(d[k]) for k in ("patch_1", "patch_2", "delta")}
+        data["choice_12"], data["choice_21"] = ch[0], ch[1]
+        _set_running_stats_from_batch(model, data)
+        model[0]._runner.use_packer = use
+        model[0]._runner._packer = None
+        for r in model[1].auxiliary_resnet._runners.values():
+            r.use_packer, r._packer = use, None
+        losses = []
+        for it in range(3):
+            model.eval()                                    # frozen BatchNorm statistics, gradients on
+            opt.zero_grad()
+            loss, _, _ = model(dict(data))
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        res[use] = losses
+        # ... and an inference forward afterwards sees the updated weights as well (folded BatchNorm cache)
+        from bihome_amd.step import predict
+        evals[use] = predict(model, dict(data)).cpu().numpy()
+    l1, l0 = res[True], res[False]
+    assert np.isfinite(l1).all() and np.isfinite(l0).all()
+    assert abs(l1[0] - l0[0]) <= 1e-5 * abs(l0[0])
+    assert abs(l1[1] - l0[1]) <= 2e-3 * abs(l0[1]) + 1e-3, (l1, l0)        # stale packs: the step-1 loss would be the step-0 one
+    assert abs(l1[1] - l1[0]) > 10 * abs(l1[1] - l0[1])                   # (the update moved the loss by far more than that)
+    assert abs(l1[2] - l0[2]) <= 5e-2 * abs(l0[2]) + 1e-2, (l1, l0)
+    assert relerr(evals[True], evals[False]) < 5e-2
+
+
+def test_graph_replays_invalidate_folded_and_packed_caches():
+    """Round-2 ADVICE (medium): replays run no Python, so the eager forward's cache bookkeeping never happens while the captured
+    fused Adam / BatchNorm kernels change weights and running statistics.  replays -> eval -> replays -> eval: the second
+    eval must see the CURRENT weights - compared with a fresh model loaded from the graphed model's state dict."""
+    from bihome_amd.graph import GraphedStep
+    from bihome_amd.step import build_model, build_optimizer, predict
+    cfg = configs.get("zeng-bihome")
+    d = synth.make_pairs(8, seed=15)
+    data = {k: cuda(d[k]) for k in ("patch_1", "patch_2", "delta")}
+    model = build_model(cfg)
+    load_synthetic(model[0], 0)
+    load_synthetic(model[1].auxiliary_resnet, 0)
+    opt, sched = build_optimizer(model, cfg["SOLVER"], capturable=True)
+    gs = GraphedStep(model, opt, sched, data)
+    gs(data)
+    e1 = predict(model, dict(data)).cpu().numpy()           # folds BatchNorms, packs folded weights
+    for _ in range(3):
+        gs(data)
+    e2 = predict(model, dict(data)).cpu().numpy()
+    fresh = build_model(cfg)
+    fresh.load_state_dict(model.state_dict())
+    e2_ref = predict(fresh, dict(data)).cpu().numpy()
+    assert relerr(e2, e2_ref) < 1e-5, relerr(e2, e2_ref)
+    assert relerr(e1, e2_ref) > 1e-3                        # three optimizer steps really moved the prediction
+    loss, _, _ = gs(data)                                   # and training continues on the graph after an eval
+    assert np.isfinite(loss.item())
