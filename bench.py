@@ -26,17 +26,20 @@ import torch
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (~2.5 PF)
-X3_PRODUCTS = 6                   # bf16 MFMA products per fp32 product in the f32x3 kernels (common.h bh_split8)
+X3_PRODUCTS = {3: 6, 2: 3}        # bf16 MFMA products per fp32 product by pieces per operand: f32x3 (common.h bh_split8), f32x2 (bh_split8_2)
 
 
-def is_x3(kernel):
-    """f32x3 kernels: the algorithmic flops of a launch are executed as X3_PRODUCTS bf16 MFMA flops each."""
-    if kernel.startswith("wgrad_x3_kernel"):
-        return True
-    if kernel.startswith("conv3x3_halo_kernel<"):                 # template arguments: FLIP, BN, BF16, SUBT, PACKED, X3, BNI
+def x3_pieces(kernel):
+    """Split-operand kernels: bf16 pieces per operand (3 = f32x3, 2 = f32x2; the algorithmic flops of a launch are executed as
+    X3_PRODUCTS[pieces] bf16 MFMA flops each), 0 for every other kernel."""
+    if kernel.startswith("wgrad_x3_kernel<"):                     # template arguments: CB, BNI, NP
+        args = kernel[len("wgrad_x3_kernel<"):].split(">")[0].split(",")
+        return int(args[2]) if len(args) >= 3 else 3
+    if kernel.startswith("conv3x3_halo_kernel<"):                 # template arguments: FLIP, BN, BF16, SUBT, PACKED, X3, BNI, NP
         args = kernel[len("conv3x3_halo_kernel<"):].split(">")[0].split(",")
-        return len(args) >= 6 and args[5] == "true"
-    return False
+        if len(args) >= 6 and args[5] == "true":
+            return int(args[7]) if len(args) >= 8 else 3
+    return 0
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 
 
@@ -47,7 +50,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=None, help="image pairs per GPU (default: the config's DATA.BATCH_SIZE)")
     ap.add_argument("--config", default="zeng-bihome")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f32-mfma", "bf16"],
+    ap.add_argument("--precision", default="f32", choices=["f32", "f32-mfma", "bf16", "f32x2"],
                     help="conv operand precision; the headline config (BASELINE.json configs[1]) is f32")
     ap.add_argument("--gpu-datagen", action="store_true",
                     help="draw a fresh batch every step with the device-side pair generator (bh_synth_pairs) inside the "
@@ -176,13 +179,15 @@ def roofline_leg(model, data, opt, sched, reducer, nsteps=2):
                  "frac_of_f32_mfma_peak": round(v["flops"] / (v["ms_per_step"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
                  if v["ms_per_step"] > 0 else 0.0}
                 for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms_per_step"])[:4]]
-    if top["tflops"] > 0 and is_x3(top["kernel"]):
-        # fp32 products evaluated as six bf16 MFMA products: the roofline is the bf16 matrix pipe, `achieved` counts the
-        # MFMA flops the launch executes (6 x algorithmic); fp32_equivalent_* relate the algorithmic flops to the fp32-input MFMA
-        ex = X3_PRODUCTS * top["tflops"]
+    if top["tflops"] > 0 and x3_pieces(top["kernel"]):
+        # fp32 products evaluated as six (f32x2: three) bf16 MFMA products: the roofline is the bf16 matrix pipe, `achieved` counts
+        # the MFMA flops the launch executes (6 x algorithmic); fp32_equivalent_* relate the algorithmic flops to the fp32-input MFMA
+        nprod = X3_PRODUCTS[x3_pieces(top["kernel"])]
+        ex = nprod * top["tflops"]
         roof = {"kernel": top["kernel"], "bound": "mfma", "achieved": ex, "peak": PEAK_BF16_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": ex / PEAK_BF16_MFMA_TFLOPS, "traffic": traffic,
-                "mfma": "v_mfma_f32_32x32x16_bf16, %d products per fp32 product (operands cut exactly into 3 bf16 pieces)" % X3_PRODUCTS,
+                "mfma": "v_mfma_f32_32x32x16_bf16, %d products per fp32 product (operands cut into %d bf16 pieces)"
+                        % (nprod, x3_pieces(top["kernel"])),
                 "algorithmic_tflops": top["tflops"], "fp32_equivalent_frac_of_f32_mfma_peak": top["tflops"] / PEAK_F32_MFMA_TFLOPS,
                 "traffic_source": traffic_src, "algorithmic_bytes_per_launch": top["bytes_per_launch"],
                 "avg_launch_us": top["avg_us"], "flops_per_launch": top["flops_per_launch"],
@@ -374,7 +379,7 @@ def main():
             "metric": "training image-pairs/s (%dx%d patch, bs=%d per GPU, full step: fwd+bwd+Adam)" % (P, P, B),
             "value": value, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"f32": "f32", "f32-mfma": "f32", "bf16": "bf16"}[args.precision],
+            "dtype": {"f32": "f32", "f32-mfma": "f32", "bf16": "bf16", "f32x2": "f32x2"}[args.precision],
             "data": "synthetic (seeded COCO-style texture pairs, random-init weights%s)" % (
                 "; fresh batch per step from the device-side generator" if args.gpu_datagen else "; one resident batch"),
             "config": {"workload": "%s: %s backbone + %s head, %d pairs/GPU, %dx%d %s, %s MFMA conv + HIP "
@@ -387,7 +392,11 @@ def main():
                                              "(error vs float64 <= the fp32-input MFMA form: tests/test_conv_kernels_gpu.py); all "
                                              "other convs: v_mfma_f32_32x32x2_f32",
                                       "f32-mfma": "fp32 tensors, v_mfma_f32_32x32x2_f32 everywhere",
-                                      "bf16": "fp32 tensors, conv operands rounded to bf16, fp32 accumulate"}[args.precision],
+                                      "bf16": "fp32 tensors, conv operands rounded to bf16, fp32 accumulate",
+                                      "f32x2": "REDUCED precision (not the headline): fp32 tensors, fp32 accumulate; 3x3 / stride-1 convs: each "
+                                               "operand as two bf16 pieces rounded to nearest (x = hi + mid + e, |e| <= 2^-18 |x|), 3 partial "
+                                               "products per product on v_mfma_f32_32x32x16_bf16 (~4e-6 per product); all other convs: "
+                                               "v_mfma_f32_32x32x2_f32"}[args.precision],
                        "stream_overlap": bool(args.overlap or os.environ.get("BIHOME_OVERLAP") == "1"),
                        "hip_graph": bool(use_graph),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "optimizer": "Adam lr 1e-3"},

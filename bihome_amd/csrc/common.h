@@ -104,3 +104,28 @@ __device__ __forceinline__ void bh_split8(const float4& u, const float4& v, uint
     lo = make_uint4(__builtin_amdgcn_perm(sb[1], sb[0], 0x07060302u), __builtin_amdgcn_perm(sb[3], sb[2], 0x07060302u),
                     __builtin_amdgcn_perm(sb[5], sb[4], 0x07060302u), __builtin_amdgcn_perm(sb[7], sb[6], 0x07060302u));
 }
+
+// X2 ("f32x2": bh_conv_desc.precision = 3): two bf16 pieces per operand, both ROUNDED to nearest even (v_cvt_pk_bf16_f32):
+// x = hi + mid + e with |e| <= 2^-18 |x| and zero mean, and a product a*b is evaluated as hi*hi + hi*mid + mid*hi (three MFMAs;
+// the dropped mid*mid is <= 2^-18 |a*b| as well).  Error ~4e-6 per product: ~13x the fp32 rounding, ~500x below the bf16-operand
+// mode - a separately reported arithmetic, never the default.  2.5 VALU per element.
+typedef __bf16 bh_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float bh_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void bh_split2_pair(float a, float b, unsigned& hi, unsigned& mid) {
+    const bh_f32x2 v = {a, b};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bh_bf16x2));
+    const bh_f32x2 r = {a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xFFFF0000u)};     // exact
+    mid = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bh_bf16x2));
+}
+__device__ __forceinline__ void bh_split8_2(const float4& u, const float4& v, uint4& hi, uint4& mid) {
+    bh_split2_pair(u.x, u.y, hi.x, mid.x);
+    bh_split2_pair(u.z, u.w, hi.y, mid.y);
+    bh_split2_pair(v.x, v.y, hi.z, mid.z);
+    bh_split2_pair(v.z, v.w, hi.w, mid.w);
+}
+// NP pieces of 8 floats: p[0] = hi, p[1] = mid (, p[2] = lo)
+template <int NP>
+__device__ __forceinline__ void bh_split8_np(const float4& u, const float4& v, uint4 (&p)[3]) {
+    if constexpr (NP == 3) bh_split8(u, v, p[0], p[1], p[2]);
+    else bh_split8_2(u, v, p[0], p[1]);
+}

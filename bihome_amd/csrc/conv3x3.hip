@@ -274,14 +274,17 @@ __device__ __forceinline__ void c3_stats_merge(const C3Args& a, char* redb, doub
 // two workgroups per CU).  The halo goes through registers (two dwordx4 per slot, cut into the three pieces, three
 // ds_write_b128) two taps after it was requested: no LDS-DMA, one bare s_barrier per chunk.  Per tap and 32x32 accumulator:
 // 6 ds_read_b128 and 12 MFMAs of 32 cycles (fp32 form: 4 reads, 16 MFMAs of 64 cycles).
-template <bool FLIP, int BN, bool BF16 = false, int SUBT = 2, bool PACKED = false, bool X3 = false, bool BNI = false>
+// NP (X3 only): bf16 pieces per operand.  3: the exact cut, six products ("f32x3", precision 2).  2: both pieces rounded to nearest,
+// three products ("f32x2", precision 3: common.h bh_split8_2) - 8 instead of 12 plane images, 4 instead of 6 weight loads per tap.
+template <bool FLIP, int BN, bool BF16 = false, int SUBT = 2, bool PACKED = false, bool X3 = false, bool BNI = false, int NP = 3>
 __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a) {
+    static_assert(NP == 3 || (NP == 2 && X3), "two pieces: split form only");
     static_assert(SUBT == 2 || BN == 64, "one sub-tile per workgroup is built for the 64-channel tile only");
     static_assert(!X3 || (PACKED && !BF16), "the split form exists for packed weights only");
     static_assert(!BNI || (X3 && !FLIP), "the BatchNorm-on-load form is a forward f32x3 kernel");
     constexpr int TM = (BN == 64 && SUBT == 2) ? 2 : 1;
     constexpr int HPL = 100 * SUBT;                        // halo slots per k-plane
-    constexpr int HALO_B = (X3 ? 12 : 8) * HPL * 16;       // bytes of one halo stage
+    constexpr int HALO_B = (X3 ? 4 * NP : 8) * HPL * 16;   // bytes of one halo stage
     constexpr int XJ = (4 * HPL + 255) / 256;              // X3: halo slots (of 8 channels) per thread and chunk (4 / 2)
     constexpr int HINS = (8 * HPL + 63) / 64;              // wave instructions per halo stage (25 / 13)
     constexpr int HJ = (HINS + 3) / 4;                     // ... per wave (7 / 4)
@@ -333,8 +336,8 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
     // X3: [chunk][tap][n tile][piece][16-channel step][lane] x (8 bf16): six 1 KB loads per tap, dst index = piece * 2 + step
 #define C3_LOAD_BX(dst, c, tap)                                                                                         \
     do {                                                                                                                \
-        const unsigned so_ = (unsigned)(((c) * 9 + (tap)) * a.NW + wnG) * 6144u;                                        \
-        _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) {                                                              \
+        const unsigned so_ = (unsigned)(((c) * 9 + (tap)) * a.NW + wnG) * (unsigned)(NP * 2048);                        \
+        _Pragma("unroll") for (int q_ = 0; q_ < 2 * NP; ++q_) {                                                              \
             const auto v_ = __builtin_amdgcn_raw_buffer_load_b128(rsB, pb_voff + (unsigned)q_ * 1024u, so_, 0);         \
             dst[q_] = __builtin_bit_cast(uint4, v_);                                                                    \
         }                                                                                                               \
@@ -398,7 +401,7 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
     if constexpr (X3) {
         // ---- halo slots of this thread: slot q = j*256 + tid of the [4 k-planes][SUBT][100] image (8 channels = 32 B each) ----
         constexpr unsigned XOOB = 0x80000000u;           // (tensor sizes are below 2^31: stays out of range with the +16 / chunk offsets added)
-        uint4 bcur[6], bnext[6];
+        uint4 bcur[2 * NP], bnext[2 * NP];
         C3_LOAD_BX(bcur, 0, 0);
         unsigned xoff[XJ];
         int xtb[XJ];                                     // BNI: byte offset of the slot's 8 coefficients pairs in the LDS table (chunk 0)
@@ -449,13 +452,12 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
 #define X3_STORE(j, hs, c, h)                                                                                           \
     do {                                                                                                                \
         if ((j) * 256 + wave * 64 < 4 * HPL && (j) * 256 + tid < 4 * HPL) {                                             \
-            uint4 p0_, p1_, p2_;                                                                                        \
+            uint4 p_[3];                                                                                                \
             X3_BNI(j, c, h);                                                                                            \
-            bh_split8(h[0], h[1], p0_, p1_, p2_);                                                                       \
+            bh_split8_np<NP>(h[0], h[1], p_);                                                                           \
             char* d_ = smem + (hs) * HALO_B + ((j) * 256 + tid) * 16;                                                   \
-            *reinterpret_cast<uint4*>(d_) = p0_;                                                                        \
-            *reinterpret_cast<uint4*>(d_ + 4 * HPL * 16) = p1_;                                                         \
-            *reinterpret_cast<uint4*>(d_ + 8 * HPL * 16) = p2_;                                                         \
+            _Pragma("unroll") for (int pc_ = 0; pc_ < NP; ++pc_)                                                        \
+                *reinterpret_cast<uint4*>(d_ + pc_ * 4 * HPL * 16) = p_[pc_];                                           \
         }                                                                                                               \
     } while (0)
         {
@@ -468,7 +470,7 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
         const int a_lane = (kh2 * HPL + wm * 100 + c3_strip_row(l31 >> 2) * 10 + wh * 4 + (l31 & 3)) * 16;
         __syncthreads();
         float4 hb[2][2];
-        uint4 af[TM][2][3];                            // [fragment][16-channel step][piece]
+        uint4 af[TM][2][NP];                           // [fragment][16-channel step][piece]
         for (int c = 0; c < nch; ++c) {
             const int hs = c & 1;
             const char* hbase = smem + hs * HALO_B + a_lane;
@@ -481,7 +483,7 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                    for (int pc = 0; pc < 3; ++pc)
+                    for (int pc = 0; pc < NP; ++pc)
 #pragma unroll
                         for (int i = 0; i < TM; ++i)
                             af[i][s2][pc] = *reinterpret_cast<const uint4*>(ap + (pc * 4 + 2 * s2) * (HPL * 16) + i * 64);
@@ -501,14 +503,14 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
                                                          __builtin_bit_cast(bf16x8, bcur[(PB) * 2 + (s2)]), acc[i], 0, 0, 0)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {       // small partial products first
-                    X3_MFMA(s2, 2, 0); X3_MFMA(s2, 0, 2); X3_MFMA(s2, 1, 1);
+                    if constexpr (NP == 3) { X3_MFMA(s2, 2, 0); X3_MFMA(s2, 0, 2); X3_MFMA(s2, 1, 1); }
                     X3_MFMA(s2, 1, 0); X3_MFMA(s2, 0, 1); X3_MFMA(s2, 0, 0);
                 }
 #undef X3_MFMA
                 if (tap == 8) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 if (!(dbg_noload & 1)) {
 #pragma unroll
-                    for (int q = 0; q < 6; ++q) bcur[q] = bnext[q];
+                    for (int q = 0; q < 2 * NP; ++q) bcur[q] = bnext[q];
                 }
             }
         }
@@ -694,17 +696,19 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
     *taken = 0;
     // (packed weights only make sense to this kernel: a caller that passes them must have asked bh_conv_variant first)
     if ((d->route & BH_ROUTE_GENERIC_CONV) || d->transposed || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->in_nchw ||
-        d->out_nchw || d->precision < 0 || d->precision > 2)
+        d->out_nchw || d->precision < 0 || d->precision > 3)
         return d->w_layout ? BH_E_UNSUPPORTED : 0;
-    if ((d->w_layout == 2) != (d->precision == 2 && d->w_layout != 0)) return BH_E_BADARG;      // split weights <-> precision 2
+    // split weights <-> their precision: w_layout 2 = three pieces (precision 2), w_layout 3 = two pieces (precision 3)
+    if (d->w_layout != 0 && ((d->w_layout == 2) != (d->precision == 2) || (d->w_layout == 3) != (d->precision == 3))) return BH_E_BADARG;
     if (d->Hi % 8 || d->Wi % 8 || d->Ho != d->Hi || d->Wo != d->Wi) return d->w_layout ? BH_E_UNSUPPORTED : 0;
     const int Kc = dgrad ? d->Co : d->Ci, Nn = dgrad ? d->Ci : d->Co;
     if (Kc % 32 || Nn % 32) return d->w_layout ? BH_E_UNSUPPORTED : 0;
     const int bn_tile = (Nn % 64) ? 32 : 64;
     const bool packed = d->w_layout != 0;              // weights in bh_conv3x3_pack fragment order (this direction's buffer)
-    const bool x3 = d->w_layout == 2;                  // ... cut into three bf16 pieces (6 bytes per weight)
-    const bool bf16 = d->precision == 1;               // (precision 2 without split weights runs the exact fp32 form)
-    const long long src_bytes = (long long)d->N * d->Hi * d->Wi * Kc * 4, w_bytes = (long long)d->Co * 9 * d->Ci * (x3 ? 6 : 4);
+    const bool x3 = d->w_layout == 2 || d->w_layout == 3;   // ... cut into three / two bf16 pieces (6 / 4 bytes per weight)
+    const int np = d->w_layout == 3 ? 2 : 3;
+    const bool bf16 = d->precision == 1;               // (precision 2 / 3 without split weights runs the exact fp32 form)
+    const long long src_bytes = (long long)d->N * d->Hi * d->Wi * Kc * 4, w_bytes = (long long)d->Co * 9 * d->Ci * (x3 ? 2 * np : 4);
     const long long out_bytes = (long long)d->N * d->Hi * d->Wi * Nn * 4;
     if (src_bytes >= (1ll << 31) || w_bytes >= (1ll << 31) || out_bytes >= (1ll << 31)) return 0;
     C3Args a = {};
@@ -747,9 +751,9 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
         if (!x3 || dgrad || !bni->table || bni->groups < 1 || d->N % bni->groups || (long long)bni->groups * Kc * 8 > 4096) return BH_E_UNSUPPORTED;
         a.bni = bni->table; a.bni_relu = bni->relu; a.bni_groups = bni->groups; a.bni_ipg = d->N / bni->groups;
     }
-    // (all seven template arguments, as rocprofv3 prints the symbol: FLIP, BN, BF16, SUBT, PACKED, X3, BNI)
-    if (bh_query("conv3x3_halo_kernel<%s,%d,%s,%d,%s,%s,%s>", dgrad ? "true" : "false", bn_tile, bf16 ? "true" : "false", subt,
-                 packed ? "true" : "false", x3 ? "true" : "false", bni ? "true" : "false")) {
+    // (all eight template arguments, as rocprofv3 prints the symbol: FLIP, BN, BF16, SUBT, PACKED, X3, BNI, NP)
+    if (bh_query("conv3x3_halo_kernel<%s,%d,%s,%d,%s,%s,%s,%d>", dgrad ? "true" : "false", bn_tile, bf16 ? "true" : "false", subt,
+                 packed ? "true" : "false", x3 ? "true" : "false", bni ? "true" : "false", np)) {
         *taken = 1;
         return BH_OK;
     }
@@ -761,25 +765,29 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
                   conv3x3_halo_kernel<false, 32, true, 2, P>,  conv3x3_halo_kernel<true, 32, true, 2, P>,    \
                   conv3x3_halo_kernel<false, 64, false, 1, P>, conv3x3_halo_kernel<true, 64, false, 1, P>,   \
                   conv3x3_halo_kernel<false, 64, true, 1, P>,  conv3x3_halo_kernel<true, 64, true, 1, P>
-    static const kern_t fns[33] = {C3_ROW(false), C3_ROW(true),
-                                   conv3x3_halo_kernel<false, 64, false, 2, true, true>, conv3x3_halo_kernel<true, 64, false, 2, true, true>,
-                                   conv3x3_halo_kernel<false, 32, false, 2, true, true>, conv3x3_halo_kernel<true, 32, false, 2, true, true>,
-                                   conv3x3_halo_kernel<false, 64, false, 1, true, true>, conv3x3_halo_kernel<true, 64, false, 1, true, true>,
-                                   conv3x3_halo_kernel<false, 64, false, 2, true, true, true>, conv3x3_halo_kernel<false, 32, false, 2, true, true, true>,
-                                   conv3x3_halo_kernel<false, 64, false, 1, true, true, true>};
+#define C3_XROW(NP_) conv3x3_halo_kernel<false, 64, false, 2, true, true, false, NP_>, conv3x3_halo_kernel<true, 64, false, 2, true, true, false, NP_>,  \
+                     conv3x3_halo_kernel<false, 32, false, 2, true, true, false, NP_>, conv3x3_halo_kernel<true, 32, false, 2, true, true, false, NP_>,  \
+                     conv3x3_halo_kernel<false, 64, false, 1, true, true, false, NP_>, conv3x3_halo_kernel<true, 64, false, 1, true, true, false, NP_>,  \
+                     conv3x3_halo_kernel<false, 64, false, 2, true, true, true, NP_>, conv3x3_halo_kernel<false, 32, false, 2, true, true, true, NP_>,   \
+                     conv3x3_halo_kernel<false, 64, false, 1, true, true, true, NP_>
+    static const kern_t fns[42] = {C3_ROW(false), C3_ROW(true), C3_XROW(3), C3_XROW(2)};
+#undef C3_XROW
 #undef C3_ROW
     constexpr int HALO2 = 8 * 200 * 16, HALO1 = 8 * 100 * 16;          // one halo stage: two / one sub-tile per workgroup
     constexpr int LDS1 = 2 * HALO1 + 2 * C3_B_BYTES;                   // one sub-tile per workgroup: 41,984 B
-    constexpr int XHALO2 = 12 * 200 * 16, XHALO1 = 12 * 100 * 16;      // split form: 12 plane images per stage
+    const int XHALO2 = 4 * np * 200 * 16, XHALO1 = 4 * np * 100 * 16;  // split form: 12 / 8 plane images per stage
     if (bh_device_once(attr_devs)) {
-        for (int i = 0; i < 33; ++i) {
+        for (int i = 0; i < 42; ++i) {
             const int j = i % 12;
-            const int full = i >= 30 ? 2 * (i < 32 ? XHALO2 : XHALO1) + 4096 : i >= 24 ? 2 * (i < 28 ? XHALO2 : XHALO1) : i < 12 ? (j < 8 ? C3_LDS_BYTES : LDS1) : 2 * (j < 8 ? HALO2 : HALO1);
+            const int xi = i >= 24 ? (i - 24) % 9 : 0, xh2 = (i >= 33 ? 8 : 12) * 200 * 16, xh1 = xh2 / 2;       // split rows: 0-5 plain, 6-8 BNI
+            const int full = i >= 24 ? 2 * ((xi == 4 || xi == 5 || xi == 8) ? xh1 : xh2) + (xi >= 6 ? 4096 : 0)
+                                     : i < 12 ? (j < 8 ? C3_LDS_BYTES : LDS1) : 2 * (j < 8 ? HALO2 : HALO1);
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[i]), hipFuncAttributeMaxDynamicSharedMemorySize, full);
             if (e != hipSuccess) return (int)e;
         }
     }
-    const kern_t fn = bni ? fns[30 + (subt == 1 ? 2 : bn_tile == 64 ? 0 : 1)] : x3 ? fns[24 + (subt == 1 ? 4 : bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0)]
+    const int xrow = 24 + (np == 2 ? 9 : 0);
+    const kern_t fn = bni ? fns[xrow + 6 + (subt == 1 ? 2 : bn_tile == 64 ? 0 : 1)] : x3 ? fns[xrow + (subt == 1 ? 4 : bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0)]
                          : fns[(packed ? 12 : 0) + (subt == 1 ? 8 + (bf16 ? 2 : 0) + (dgrad ? 1 : 0)
                                                               : (bf16 ? 4 : 0) + (bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0))];
     a.dbg_noload = g_c3_noload;
@@ -805,6 +813,7 @@ __global__ void __launch_bounds__(256) pack_conv3x3_weights_kernel(const bh_pack
     const long long n4 = (long long)Co * 9 * Ci / 4;
     const float4* __restrict__ w4 = reinterpret_cast<const float4*>(j.w);
     if (j.split) {
+        const int np = j.split == 2 ? 2 : 3;              // pieces per weight (split 1: the exact three-way cut; 2: two rounded pieces)
         // [chunk][tap][n tile][piece][16-channel step s2][lane] x (8 bf16): lane (l31, kh2) holds k = chunk*32 + (2*s2 + kh2)*8 + e
         const long long n8 = (long long)Co * 9 * Ci / 8;
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
@@ -829,9 +838,10 @@ __global__ void __launch_bounds__(256) pack_conv3x3_weights_kernel(const bh_pack
                     v = make_float4(src[4 * ks], src[5 * ks], src[6 * ks], src[7 * ks]);
                 }
                 uint4 p0, p1, p2;
-                bh_split8(u, v, p0, p1, p2);
-                uint4* const o = reinterpret_cast<uint4*>(dst) + (r * 6 + s2) * 64 + lane;
-                o[0] = p0; o[2 * 64] = p1; o[4 * 64] = p2;
+                uint4* const o = reinterpret_cast<uint4*>(dst) + (r * 2 * np + s2) * 64 + lane;
+                if (np == 3) { bh_split8(u, v, p0, p1, p2); o[4 * 64] = p2; }
+                else bh_split8_2(u, v, p0, p1);
+                o[0] = p0; o[2 * 64] = p1;
             }
         }
         return;

@@ -54,7 +54,7 @@ struct WX3Args {
     int bni_relu, bni_ipg, bni_groups;
 };
 
-template <int CB>
+template <int CB, int NP = 3>
 struct WXGeom {
     static constexpr int PIX = CB * 2;                        // bytes of a pixel record: CB bf16 channels
     // row skew: the four 64-byte segments of a transposing read (2x2 pixels) must start 16 banks apart
@@ -62,16 +62,18 @@ struct WXGeom {
     static constexpr int XROW = 10 * PIX + (CB == 64 ? 64 : 0);       // halo row:     1344 / 640 B
     static constexpr int GP = 8 * GROW;                        // one piece image of the gy tile
     static constexpr int XP = 10 * XROW;                       // one piece image of the halo
-    static constexpr int XBASE = 3 * GP;
-    static constexpr int LDS = 3 * (GP + XP);                  // one image of a tile: 66,432 / 34,560 B
+    static constexpr int XBASE = NP * GP;
+    static constexpr int LDS = NP * (GP + XP);                 // one image of a tile: 66,432 / 34,560 B (three pieces)
     static constexpr int NG = CB / 8;                          // 8-channel groups per pixel
     static constexpr int GS = 64 * NG / 256;                   // gy staging slots per thread (2 / 1)
     static constexpr int HS = (100 * NG + 255) / 256;          // halo staging slots per thread (4 / 2)
 };
 
-template <int CB, bool BNI = false>
+// NP: bf16 pieces per operand - 3: the exact cut, six products (precision 2); 2: two rounded pieces, three products ("f32x2",
+// precision 3, common.h bh_split8_2)
+template <int CB, bool BNI = false, int NP = 3>
 __global__ void __launch_bounds__(256, 1) wgrad_x3_kernel(WX3Args a) {
-    using G = WXGeom<CB>;
+    using G = WXGeom<CB, NP>;
     constexpr int GS = G::GS, HS = G::HS, NG = G::NG;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -149,12 +151,11 @@ __global__ void __launch_bounds__(256, 1) wgrad_x3_kernel(WX3Args a) {
     // slot 0 .. GS-1: gy; GS .. GS+HS-1: halo
     auto stage_slot = [&](auto SLOT, char* img) {
         constexpr int sl = decltype(SLOT)::value;
-        uint4 p0, p1, p2;
+        uint4 p[3];
         if constexpr (sl < GS) {
-            bh_split8(rg[sl][0], rg[sl][1], p0, p1, p2);
-            *reinterpret_cast<uint4*>(img + g_lds[sl]) = p0;
-            *reinterpret_cast<uint4*>(img + g_lds[sl] + G::GP) = p1;
-            *reinterpret_cast<uint4*>(img + g_lds[sl] + 2 * G::GP) = p2;
+            bh_split8_np<NP>(rg[sl][0], rg[sl][1], p);
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc) *reinterpret_cast<uint4*>(img + g_lds[sl] + pc * G::GP) = p[pc];
         } else if constexpr (sl < GS + HS) {
             constexpr int j = sl - GS;
             if constexpr (BNI) {
@@ -168,10 +169,9 @@ __global__ void __launch_bounds__(256, 1) wgrad_x3_kernel(WX3Args a) {
                 v.x = ok ? __builtin_elementwise_maximum(__builtin_fmaf(v.x, t2.x, t2.y), bni_lo) : 0.f; v.y = ok ? __builtin_elementwise_maximum(__builtin_fmaf(v.y, t2.z, t2.w), bni_lo) : 0.f;
                 v.z = ok ? __builtin_elementwise_maximum(__builtin_fmaf(v.z, t3.x, t3.y), bni_lo) : 0.f; v.w = ok ? __builtin_elementwise_maximum(__builtin_fmaf(v.w, t3.z, t3.w), bni_lo) : 0.f;
             }
-            bh_split8(rx[j][0], rx[j][1], p0, p1, p2);
-            *reinterpret_cast<uint4*>(img + h_lds[j]) = p0;
-            *reinterpret_cast<uint4*>(img + h_lds[j] + G::XP) = p1;
-            *reinterpret_cast<uint4*>(img + h_lds[j] + 2 * G::XP) = p2;
+            bh_split8_np<NP>(rx[j][0], rx[j][1], p);
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc) *reinterpret_cast<uint4*>(img + h_lds[j] + pc * G::XP) = p[pc];
         }
     };
 #define WX_SLOT(n, img) stage_slot(std::integral_constant<int, (n)>{}, img)
@@ -195,11 +195,11 @@ __global__ void __launch_bounds__(256, 1) wgrad_x3_kernel(WX3Args a) {
 
 #define WX_TR(base, off) __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4_ptr)(smem + (base) + (off)))
 #define WX_OPER(lo_, hi_) __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7))
-#define WX_LOAD_A(dst, ks) _Pragma("unroll") for (int pc = 0; pc < 3; ++pc) {                                          \
+#define WX_LOAD_A(dst, ks) _Pragma("unroll") for (int pc = 0; pc < NP; ++pc) {                                          \
         const i16x4 v0_ = WX_TR(la, pc * G::GP + 2 * (ks) * G::GROW);                                                   \
         const i16x4 v1_ = WX_TR(la, pc * G::GP + 2 * (ks) * G::GROW + 2 * G::PIX);                                      \
         dst[pc] = WX_OPER(v0_, v1_); }
-#define WX_LOAD_B(dst, ks, tap) _Pragma("unroll") for (int pc = 0; pc < 3; ++pc) {                                     \
+#define WX_LOAD_B(dst, ks, tap) _Pragma("unroll") for (int pc = 0; pc < NP; ++pc) {                                     \
         const i16x4 v0_ = WX_TR(lb, pc * G::XP + (2 * (ks) + (tap) / 3) * G::XROW + ((tap) % 3) * G::PIX);              \
         const i16x4 v1_ = WX_TR(lb, pc * G::XP + (2 * (ks) + (tap) / 3) * G::XROW + ((tap) % 3 + 2) * G::PIX);          \
         dst[pc] = WX_OPER(v0_, v1_); }
@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_x3_kernel(WX3Args a) {
         char* const nimg = smem + (G::LDS - cb);                   // the other image
         const int la = laneA + cb, lb = laneB + cb;
         const int tnext = split + min(k + 2, nt - 1) * a.nsplit;   // (past the end: re-request the last tile, never used)
-        bf16x8 af[2][3], bf[2][2][3];                              // A by ks parity; B by step-pair parity and step parity
+        bf16x8 af[2][NP], bf[2][2][NP];                            // A by ks parity; B by step-pair parity and step parity
         WX_LOAD_A(af[0], 0);
         WX_LOAD_B(bf[0][0], 0, 0);
         WX_LOAD_B(bf[0][1], 0, 1);
@@ -252,11 +252,12 @@ __global__ void __launch_bounds__(256, 1) wgrad_x3_kernel(WX3Args a) {
                 const int k1 = (s1 / 9) & 1, t1 = s1 % 9;
 #define WX_MM1(PA, PB) acc[t1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[k1][PA], bf[pb][1][PB], acc[t1], 0, 0, 0)
                 // small partial products first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
-                WX_MM0(2, 0); WX_MM1(2, 0); WX_MM0(0, 2); WX_MM1(0, 2); WX_MM0(1, 1); WX_MM1(1, 1);
+                if constexpr (NP == 3) { WX_MM0(2, 0); WX_MM1(2, 0); WX_MM0(0, 2); WX_MM1(0, 2); WX_MM0(1, 1); WX_MM1(1, 1); }
                 WX_MM0(1, 0); WX_MM1(1, 0); WX_MM0(0, 1); WX_MM1(0, 1); WX_MM0(0, 0); WX_MM1(0, 0);
 #undef WX_MM1
             } else {
-                WX_MM0(2, 0); WX_MM0(0, 2); WX_MM0(1, 1); WX_MM0(1, 0); WX_MM0(0, 1); WX_MM0(0, 0);
+                if constexpr (NP == 3) { WX_MM0(2, 0); WX_MM0(0, 2); WX_MM0(1, 1); }
+                WX_MM0(1, 0); WX_MM0(0, 1); WX_MM0(0, 0);
             }
 #undef WX_MM0
         }
@@ -375,26 +376,24 @@ int bh_wgrad_x3_try(const float* x, const float* gy, float* gw, const bh_conv_de
         else if (ws_bytes < need) return BH_E_BADARG;
         a.partials = ws;
     }
-    if (bh_query(ws ? "wgrad_x3_kernel<%d,%s>+wgrad_x3_reduce_kernel<%d>" : "wgrad_x3_kernel<%d,%s>", cb, bni ? "true" : "false", cb)) { *taken = 1; return BH_OK; }
+    const int np = d->precision == 3 ? 2 : 3;
+    // (all three template arguments, as rocprofv3 prints the symbol: CB, BNI, NP)
+    if (bh_query(ws ? "wgrad_x3_kernel<%d,%s,%d>+wgrad_x3_reduce_kernel<%d>" : "wgrad_x3_kernel<%d,%s,%d>", cb, bni ? "true" : "false", np, cb)) { *taken = 1; return BH_OK; }
+    typedef void (*kern_t)(WX3Args);
+    static const kern_t fns[8] = {wgrad_x3_kernel<64, false, 3>, wgrad_x3_kernel<32, false, 3>, wgrad_x3_kernel<64, true, 3>, wgrad_x3_kernel<32, true, 3>,
+                                  wgrad_x3_kernel<64, false, 2>, wgrad_x3_kernel<32, false, 2>, wgrad_x3_kernel<64, true, 2>, wgrad_x3_kernel<32, true, 2>};
+    static const int lds_of[8] = {2 * WXGeom<64, 3>::LDS, 2 * WXGeom<32, 3>::LDS, 2 * WXGeom<64, 3>::LDS, 2 * WXGeom<32, 3>::LDS,
+                                  2 * WXGeom<64, 2>::LDS, 2 * WXGeom<32, 2>::LDS, 2 * WXGeom<64, 2>::LDS, 2 * WXGeom<32, 2>::LDS};
     static unsigned long long attr_devs = 0;
     if (bh_device_once(attr_devs)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           2 * WXGeom<64>::LDS);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    2 * WXGeom<32>::LDS);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    2 * WXGeom<64>::LDS + 4 * 64 * 8);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_kernel<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    2 * WXGeom<32>::LDS + 4 * 32 * 8);
-        if (e != hipSuccess) return (int)e;
+        for (int i = 0; i < 8; ++i) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[i]), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     lds_of[i] + ((i & 2) ? 4 * ((i & 1) ? 32 : 64) * 8 : 0));
+            if (e != hipSuccess) return (int)e;
+        }
     }
-    if (bni && cb == 64) hipLaunchKernelGGL((wgrad_x3_kernel<64, true>), dim3(pairs * ns), dim3(256), 2 * WXGeom<64>::LDS + tb_bytes, stream, a);
-    else if (bni) hipLaunchKernelGGL((wgrad_x3_kernel<32, true>), dim3(pairs * ns), dim3(256), 2 * WXGeom<32>::LDS + tb_bytes, stream, a);
-    else if (cb == 64) hipLaunchKernelGGL(wgrad_x3_kernel<64>, dim3(pairs * ns), dim3(256), 2 * WXGeom<64>::LDS, stream, a);
-    else hipLaunchKernelGGL(wgrad_x3_kernel<32>, dim3(pairs * ns), dim3(256), 2 * WXGeom<32>::LDS, stream, a);
+    const int ki = (np == 2 ? 4 : 0) + (bni ? 2 : 0) + (cb == 64 ? 0 : 1);
+    hipLaunchKernelGGL(fns[ki], dim3(pairs * ns), dim3(256), lds_of[ki] + tb_bytes, stream, a);
     BH_LAUNCH_CHECK();
     if (ws) {
         if (cb == 64) hipLaunchKernelGGL(wgrad_x3_reduce_kernel<64>, dim3(36864 / 64, pairs), dim3(256), 0, stream, ws, gw, ns, a.cbi, d->Ci);

@@ -71,6 +71,12 @@ def _conv_variant(d, which, accumulate=False, bn_groups=0):
     return v
 
 
+def _bni_name(v):
+    """The library's name of a plain launch with the BatchNorm-on-load template argument (second to last) switched on."""
+    import re
+    return re.sub(r",false,(\d)>", r",true,\1>", v, count=1)
+
+
 def conv_flops(d):
     """Algorithmic flops of one conv launch: 2 * MACs (same count for fwd, dgrad and wgrad)."""
     if d.transposed:
@@ -287,7 +293,16 @@ def bihome_loss_bwd(g_loss, f1, f2, f1w, f2w, m1w, m2w, m1, m2, M1, M2, numden, 
 # order <= 2 in fp32 on the bf16 matrix pipe (precision 2, "f32x3": error against float64 at or below that of the fp32-input
 # MFMA form, tests/test_conv_kernels_gpu.py::test_conv3x3_f32x3_*), everything else runs v_mfma_f32_32x32x2_f32.
 # 'f32-mfma' forces the fp32-input MFMA everywhere (precision 0); 'bf16' rounds the operands to bf16 (precision 1).
-PRECISION = {"f32": 2, "fp32": 2, "f32x3": 2, "f32-mfma": 0, "bf16": 1}
+# 'f32x2' (precision 3): two bf16 pieces per operand, both rounded to nearest, three products - ~4e-6 per product (13x the fp32
+# rounding, 500x below 'bf16'); a separately reported reduced-precision arithmetic for the matrix-pipe-rate configurations.
+PRECISION = {"f32": 2, "fp32": 2, "f32x3": 2, "f32-mfma": 0, "bf16": 1, "f32x2": 3}
+SPLIT_PIECES = {2: 3, 3: 2}         # precision -> bf16 pieces per operand of the split-operand kernels
+SPLIT_LAYOUT = {2: 2, 3: 3}         # precision -> bh_conv_desc.w_layout of the packed split weights
+
+
+def packed_layout(precision):
+    """bh_conv_desc.w_layout of WeightPacker copies for this precision (1: fp32 fragments, 2 / 3: three / two bf16 pieces)."""
+    return SPLIT_LAYOUT.get(int(precision), 1)
 _ENV_ROUTE = int(os.environ.get("BIHOME_ROUTE", "0"))     # benchmarks: OR these BH_ROUTE_* bits into every conv descriptor
 
 
@@ -329,8 +344,11 @@ class WeightPacker:
     weights).  Buffers and the device job table are allocated once (addresses stay fixed: HIP-graph safe)."""
 
     def __init__(self, split=False):
-        self.split = bool(split)   # three bf16 pieces per weight (bh_conv_desc.w_layout 2) instead of fp32 fragments (1)
-        self.layout = 2 if split else 1
+        # split: False / 0 = fp32 fragments (w_layout 1); True / 3 = three exact bf16 pieces (w_layout 2, precision 2);
+        # 2 = two rounded bf16 pieces (w_layout 3, precision 3 "f32x2")
+        self.pieces = 0 if not split else (2 if (split == 2 and split is not True) else 3)
+        self.split = self.pieces > 0
+        self.layout = {0: 1, 3: 2, 2: 3}[self.pieces]
         self.entries = {}          # id(weight) -> (weight, pf, pd)
         self.table = None
         self.versions = None
@@ -340,7 +358,7 @@ class WeightPacker:
         e = self.entries.get(id(weight))
         if e is None:
             Co, Ci = weight.shape[0], weight.shape[1]
-            n = weight.numel() * 3 // 2 if self.split else weight.numel()
+            n = weight.numel() * self.pieces // 2 if self.split else weight.numel()
             pf = torch.empty(n, dtype=torch.float32, device=weight.device)
             pd = torch.empty(n, dtype=torch.float32, device=weight.device) if need_dgrad else None
             e = self.entries[id(weight)] = (weight, pf, pd)
@@ -370,7 +388,7 @@ class WeightPacker:
                 if not w.permute(0, 2, 3, 1).is_contiguous():
                     raise RuntimeError("conv weight is not in kernel (channels_last) layout")
                 j.w, j.pf, j.pd = w.data_ptr(), pf.data_ptr(), (pd.data_ptr() if pd is not None else None)
-                j.Co, j.Ci, j.split = w.shape[0], w.shape[1], int(self.split)
+                j.Co, j.Ci, j.split = w.shape[0], w.shape[1], {0: 0, 3: 1, 2: 2}[self.pieces]
             raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8)
             dev = next(iter(self.entries.values()))[0].device
             self.table = raw.to(dev)
@@ -418,10 +436,10 @@ def conv_fwd(x, w, bias, d, bn_sums=None, groups=1, res=None, relu=False, wpacke
         if wpacked is None or res is not None or relu:
             raise RuntimeError("BatchNorm-on-load needs the packed f32x3 3x3 forward")
         y = torch.empty(conv_out_shape(d), dtype=torch.float32, device=x.device)
-        dp = getattr(d, "bh_packed", None) or _with_layout(d, 2)
+        dp = getattr(d, "bh_packed", None) or _with_layout(d, packed_layout(d.precision))
         bs = bol.struct()
         # (the library's name of the plain launch with the last template argument - BatchNorm-on-load - switched on)
-        with _Timed(_conv_variant(dp, "fwd", bn_groups=groups if bn_sums is not None else 0).replace(",false>", ",true>") if TIMING is not None else "",
+        with _Timed(_bni_name(_conv_variant(dp, "fwd", bn_groups=groups if bn_sums is not None else 0)) if TIMING is not None else "",
                     conv_flops(d), 4.0 * (x.numel() + y.numel() + w.numel())):
             check(lib.bh_conv_fwd_bnin(_p(x), _p(wpacked), _p(bias), _p(y), ctypes.byref(dp), _p(bn_sums), groups, ctypes.byref(bs),
                                        _stream()), "bh_conv_fwd_bnin")
@@ -429,7 +447,7 @@ def conv_fwd(x, w, bias, d, bn_sums=None, groups=1, res=None, relu=False, wpacke
     _chk(x); _chk(w); _chk(bias); _chk(res)
     y = torch.empty(conv_out_shape(d), dtype=torch.float32, device=x.device)
     if wpacked is not None:
-        d, w = (getattr(d, "bh_packed", None) or _with_layout(d, 2 if d.precision == 2 else 1)), wpacked
+        d, w = (getattr(d, "bh_packed", None) or _with_layout(d, packed_layout(d.precision))), wpacked
     with _Timed(_conv_variant(d, "fwd", bn_groups=groups if bn_sums is not None else 0), conv_flops(d),
                 4.0 * (x.numel() + y.numel() + w.numel())):
         if res is not None or relu:
@@ -493,7 +511,7 @@ def conv_dgrad(gy, w, d, out=None, bn_reduce=None, wkey=None, wpacked=None, cols
     bn_stats_buffer) in the conv epilogue; pass them to bn_bwd(..., sums_ready=sums)."""
     _chk(gy); _chk(w)
     if wpacked is not None:
-        d, w = (getattr(d, "bh_packed", None) or _with_layout(d, 2 if d.precision == 2 else 1)), wpacked
+        d, w = (getattr(d, "bh_packed", None) or _with_layout(d, packed_layout(d.precision))), wpacked
     if colsum is not None:
         assert out is None and bn_reduce is None
         _chk(colsum, torch.float64)
@@ -553,7 +571,7 @@ def conv_wgrad(x, gy, gw, gbias, d, det_ws=None):
         if det_ws is None or not (0 < need <= det_ws.numel() * 4):
             raise RuntimeError("BatchNorm-on-load needs the f32x3 weight gradient and its workspace")
         bs = bol.struct()
-        with _Timed((conv_variant(d, "wgrad_det").replace(",false>", ",true>") if TIMING is not None else ""), conv_flops(d),
+        with _Timed((_bni_name(conv_variant(d, "wgrad_det")) if TIMING is not None else ""), conv_flops(d),
                     4.0 * (x.numel() + gy.numel() + gw.numel())):
             check(lib.bh_conv_wgrad_bnin(_p(x), _p(gy), _p(gw), _p(gbias), ctypes.byref(d), _p(det_ws), det_ws.numel() * 4,
                                          ctypes.byref(bs), _stream()), "bh_conv_wgrad_bnin")

@@ -202,9 +202,9 @@ def _conv_geometry(mod, x_shape, in_nchw, out_nchw, precision=0):
     d = _conv_geometry_uncached(mod, x_shape, in_nchw, out_nchw, precision)
     d.bh_packs = bool(isinstance(mod, nn.Conv2d) and K.packs_3x3(d))
     d.bh_reduce_ok = bool(isinstance(mod, nn.Conv2d) and K.dgrad_bn_reduce_ok(d))
-    d.bh_packed = K._with_layout(d, 2 if int(precision) == 2 else 1) if d.bh_packs else None
+    d.bh_packed = K._with_layout(d, K.packed_layout(precision)) if d.bh_packs else None
     # f32x3 weight gradient (csrc/wgrad_x3.hip): reduces its split-K partial blocks through a workspace (fixed order, cheaper than atomics)
-    d.bh_wx3 = bool(int(precision) == 2 and isinstance(mod, nn.Conv2d) and K.conv_variant(d, "wgrad").startswith("wgrad_x3"))
+    d.bh_wx3 = bool(int(precision) in K.SPLIT_PIECES and isinstance(mod, nn.Conv2d) and K.conv_variant(d, "wgrad").startswith("wgrad_x3"))
     d.bh_wx3_bytes = K.wgrad_det_bytes(d) if d.bh_wx3 else 0
     _GEOM_CACHE[key] = (mod, d)
     return d
@@ -300,7 +300,7 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, p
     # staging it (kernels.BnOnLoad): one launch and two tensor passes per such layer gone (the inner BatchNorm of every
     # residual unit).  Needs the sums from the producer's epilogue (fused_stats) and a table of <= 4 KB.
     bn_on_load = set()
-    if training and packer is not None and int(precision) == 2 and os.environ.get("BIHOME_BN_ON_LOAD", "1") != "0":
+    if training and packer is not None and int(precision) in K.SPLIT_PIECES and os.environ.get("BIHOME_BN_ON_LOAD", "1") != "0":
         consumer = {}
         for j, op in enumerate(prog.ops):
             consumer.setdefault(op.src, j)
@@ -338,11 +338,11 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, p
             d = _conv_geometry(cop.mod, csrc.shape, e["in_nchw"], e["out_nchw"], precision)
             wf, bf = _folded(fold_cache, cop.mod, op.mod, e["weight_fn"])
             pf = None
-            if int(precision) == 2 and d.bh_packs and e["weight_fn"] is None:
+            if int(precision) in K.SPLIT_PIECES and d.bh_packs and e["weight_fn"] is None:
                 # f32x3 inference: the folded weights in cut fragment order (packed once per fold)
                 ent = fold_cache[(id(cop.mod), id(op.mod))]
                 if len(ent) < 4 or ent[3] is None:
-                    pk = K.WeightPacker(split=True)
+                    pk = K.WeightPacker(split=K.SPLIT_PIECES[int(precision)])
                     pf, _ = pk.get(wf, need_dgrad=False)
                     pk.refresh()
                     fold_cache[(id(cop.mod), id(op.mod))] = (ent[0], ent[1], ent[2], pf)
@@ -706,7 +706,7 @@ class Runner:
     def x3_workspace(self, device):
         """'f32' arithmetic (precision 2): the 40 MB workspace the f32x3 weight-gradient kernel stores its <= 256 partial blocks
         of 147 KB in (wgrad_x3_reduce_kernel adds them in split order: those layers' gradients are bitwise reproducible)."""
-        if self.precision != 2 or self.flat is None:
+        if self.precision not in K.SPLIT_PIECES or self.flat is None:
             return None
         if self._det_ws is None or self._det_ws.device != device:
             self._det_ws = torch.empty(X3_WS_BYTES // 4, dtype=torch.float32, device=device)
@@ -716,7 +716,7 @@ class Runner:
         if not self.use_packer:
             return None
         if self._packer is None or self._packer_dev != device:
-            pk = K.WeightPacker(split=self.precision == 2)
+            pk = K.WeightPacker(split=K.SPLIT_PIECES.get(self.precision, 0))
             for op in self.prog.ops:
                 m = op.mod
                 if (op.kind == "conv" and isinstance(m, nn.Conv2d) and op.extra["weight_fn"] is None and m.kernel_size == (3, 3)

@@ -148,9 +148,13 @@ typedef struct {
                              * accuracy on the bf16 matrix pipe - every fp32 operand is cut EXACTLY into three bf16 pieces
                              * and the six partial products of order <= 2 are accumulated in fp32 (what is dropped is
                              * below 2^-23 of a product, one fp32 rounding); taken by the halo-tiled 3x3 kernel with
-                             * w_layout 2, every other kernel computes precision 2 as precision 0 */
+                             * w_layout 2, every other kernel computes precision 2 as precision 0;
+                             * 3 ("f32x2", REDUCED precision, reported separately): two bf16 pieces per operand, both rounded to
+                             * nearest (x = hi + mid + e, |e| <= 2^-18 |x|), products hi*hi + hi*mid + mid*hi (~4e-6 per
+                             * product: 13x the fp32 rounding, 500x below precision 1); same kernels as 2 with w_layout 3 */
     int w_layout;           /* 0: w is [Co][kh][kw][Ci].  2: as 1, made with bh_pack3x3_job.split = 1 (three bf16 pieces, 6 bytes
-                             * per weight; requires precision 2).  1 (3x3 / stride 1 / pad 1 only): w is the fragment-ordered copy made
+                             * per weight; requires precision 2).  3: as 1, made with split = 2 (two rounded bf16 pieces, 4 bytes
+                             * per weight; requires precision 3).  1 (3x3 / stride 1 / pad 1 only): w is the fragment-ordered copy made
                              * by bh_conv3x3_pack - its `pf` buffer for bh_conv_fwd*, its `pd` buffer for bh_conv_dgrad* -
                              * which the halo-tiled 3x3 kernel streams straight into registers; BH_E_UNSUPPORTED when
                              * that kernel does not take the launch (ask bh_conv_variant first) */
@@ -173,7 +177,7 @@ typedef struct {
     float* pd;
     int Co, Ci;
     int split;              /* 0: fp32 fragments (w_layout 1).  1: three bf16 pieces per weight (w_layout 2): pf / pd then hold
-                             * Co*9*Ci*6 bytes each */
+                             * Co*9*Ci*6 bytes each.  2: two rounded bf16 pieces (w_layout 3): Co*9*Ci*4 bytes each */
     int reserved;
 } bh_pack3x3_job;
 /* Packs the weights of njobs layers in one launch (jobs_dev: device array).  Call after every optimizer step (the

@@ -108,7 +108,7 @@ def test_multihead_feature_loss_vs_golden(golden):
     assert abs(losses[1] - g64["loss"][1]) <= max(20 * abs(g32["loss"][1] - g64["loss"][1]), 2e-3 * abs(g64["loss"][1]))
 
 
-@pytest.mark.parametrize("precision,head_precision", [("f32", "f32"), ("bf16", "bf16"), ("bf16", "f32")])
+@pytest.mark.parametrize("precision,head_precision", [("f32", "f32"), ("f32x2", "f32x2"), ("bf16", "bf16"), ("bf16", "f32")])
 def test_detone_three_steps_vs_golden(golden, precision, head_precision):
     """configs[3] (ResNet-34 regressor + biHomE, B = 8, three Adam steps, lr 5e-3) against the reference fixture.
     float32: first step tight, later steps within a multiple of the reference's own float32-vs-float64 spread (loss 86.0
@@ -135,7 +135,10 @@ def test_detone_three_steps_vs_golden(golden, precision, head_precision):
         if it == 0 and precision == "f32":
             assert relerr(dh.cpu(), g64["delta_hat_12"][0]) < 1e-3
     print(precision, head_precision, "loss", losses, "mace", maces, "ref", g64["loss"], g64["mace"])
-    if precision == "f32":
+    print("  step-0 margins: loss rel %.2e (f32 reference: %.2e), MACE diff %.2e"
+          % (abs(losses[0] - g64["loss"][0]) / abs(g64["loss"][0]), abs(g32["loss"][0] - g64["loss"][0]) / abs(g64["loss"][0]),
+             abs(maces[0] - g64["mace"][0])))
+    if precision in ("f32", "f32x2"):      # 'f32x2' (two rounded bf16 pieces, three products) is held to the float32 tolerances
         assert abs(losses[0] - g64["loss"][0]) <= max(3 * abs(g32["loss"][0] - g64["loss"][0]), 1e-4 * abs(g64["loss"][0]))
         assert abs(maces[0] - g64["mace"][0]) < 1e-3
         mult, lrel, mfloor = 5.0, 0.05, 0.05

@@ -498,7 +498,7 @@ def test_conv3x3_packed_weights_match_lds_slab_path(K, N, H, Ci, Co, prec):
     pf, pd = pk.get(w)
     pk.refresh()
     dp = K._with_layout(d, 1)
-    assert K.conv_variant(dp, "fwd").endswith(",true,false,false>") and K.conv_variant(dp, "dgrad").endswith(",true,false,false>")
+    assert K.conv_variant(dp, "fwd").endswith(",true,false,false,3>") and K.conv_variant(dp, "dgrad").endswith(",true,false,false,3>")
     y0 = K.conv_fwd(x, wk, b, d)
     y1 = K.conv_fwd(x, wk, b, d, wpacked=pf)
     assert torch.equal(y0, y1)
@@ -561,8 +561,8 @@ def test_conv3x3_f32x3_is_fp32_accurate(K, N, H, Ci, Co, wide):
         pf, pd = pk.get(w)
         pk.refresh()
         dp = K._with_layout(d, 2 if prec == 2 else 1)
-        assert K.conv_variant(dp, "fwd").endswith(",true,true,false>" if prec == 2 else ",true,false,false>")
-        assert K.conv_variant(dp, "dgrad").endswith(",true,true,false>" if prec == 2 else ",true,false,false>")
+        assert K.conv_variant(dp, "fwd").endswith(",true,true,false,3>" if prec == 2 else ",true,false,false,3>")
+        assert K.conv_variant(dp, "dgrad").endswith(",true,true,false,3>" if prec == 2 else ",true,false,false,3>")
         y = K.conv_fwd(x, wk, b, d, wpacked=pf)
         s = K.bn_stats_buffer(1, Co, "cuda")
         assert torch.equal(y, K.conv_fwd(x, wk, b, d, bn_sums=s, groups=1, wpacked=pf))
@@ -806,3 +806,62 @@ def test_batchnorm_on_load_propagates_nan(K, relu):
     K.conv_wgrad(K.BnOnLoad(z, table, groups, relu), torch.randn(N, H, H, Co, generator=g).cuda(), gw, None, d, det_ws=ws)
     nanc = torch.isnan(gw).any(dim=0).any(dim=0).any(dim=0).cpu()      # per input channel
     assert bool(nanc[13]) and int(nanc.sum()) == 1
+
+
+@pytest.mark.parametrize("N,H,Ci,Co", [(128, 32, 64, 64), (8, 16, 128, 128), (8, 8, 256, 256), (4, 64, 32, 32), (3, 24, 96, 160)])
+def test_conv3x3_f32x2_two_piece_mode(K, N, H, Ci, Co):
+    """precision 3 / w_layout 3 ("f32x2"): two bf16 pieces per operand, both rounded to nearest, three MFMA products.  Stated
+    accuracy: relative L2 error against torch float64 below 8e-6 for forward, dgrad and weight gradient (operand representation
+    2^-18 = 3.8e-6 worst case, zero mean), i.e. >= 100x below the bf16-operand mode (2.4e-3) and ~10x above fp32; the two
+    pieces of a packed weight reproduce it to 2^-17 relative."""
+    from bihome_amd._lib import ROUTE_HALO_SMALL
+    g = torch.Generator().manual_seed(N * 5 + H)
+    x = torch.randn(N, H, H, Ci, generator=g).cuda()
+    gy = torch.randn(N, H, H, Co, generator=g).cuda()
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * 0.05).cuda().contiguous(memory_format=torch.channels_last)
+    wk = w.permute(0, 2, 3, 1)
+    b = torch.randn(Co, generator=g).cuda()
+    xd, wd = x.double().cpu().permute(0, 3, 1, 2), w.double().cpu()
+    ref = F.conv2d(xd, wd, b.double().cpu(), 1, 1).permute(0, 2, 3, 1)
+    refd = F.conv_transpose2d(gy.double().cpu().permute(0, 3, 1, 2), wd, None, 1, 1).permute(0, 2, 3, 1)
+    refw = torch.einsum("nyxo,nyxtc->otc", gy.double().cpu(),
+                        F.unfold(xd, 3, padding=1).view(N, Ci, 9, H, H).permute(0, 3, 4, 2, 1)).reshape(Co, 3, 3, Ci)
+    errs = {}
+    for prec in (3, 2, 1):
+        d = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=prec, route=ROUTE_HALO_SMALL)
+        if prec == 1:
+            y, gx = K.conv_fwd(x, wk, b, d), K.conv_dgrad(gy, wk, d)
+        else:
+            pk = K.WeightPacker(split=K.SPLIT_PIECES[prec])
+            pf, pd = pk.get(w)
+            pk.refresh()
+            dp = K._with_layout(d, K.packed_layout(prec))
+            assert K.conv_variant(dp, "fwd").endswith(",true,true,false,%d>" % K.SPLIT_PIECES[prec])
+            y = K.conv_fwd(x, wk, b, d, wpacked=pf)
+            s = K.bn_stats_buffer(1, Co, "cuda")
+            assert torch.equal(y, K.conv_fwd(x, wk, b, d, bn_sums=s, groups=1, wpacked=pf))
+            gx = K.conv_dgrad(gy, wk, d, wpacked=pd)
+            acc = x.clone()
+            K.conv_dgrad(gy, wk, d, out=acc, wpacked=pd)
+            close(acc.cpu(), (x + gx).cpu(), 2e-5)
+        gw = torch.zeros(Co, 3, 3, Ci, device="cuda")
+        need = K.wgrad_det_bytes(d)
+        if prec != 1 and need > 0:
+            assert K.conv_variant(d, "wgrad_det").startswith("wgrad_x3_kernel<%d,false,%d>" % (64 if (Ci % 64 == 0 and Co % 64 == 0) else 32, K.SPLIT_PIECES[prec]))
+            K.conv_wgrad(x, gy, gw, None, d, det_ws=torch.empty(need // 4, dtype=torch.float32, device="cuda"))
+        else:
+            K.conv_wgrad(x, gy, gw, None, d)
+        errs[prec] = tuple(((a.cpu().double() - r).norm() / r.norm()).item() for a, r in ((y, ref), (gx, refd), (gw, refw)))
+        if prec == 3:
+            pieces = pf.view(torch.int16).view(-1, 2, 2, 64, 8).to(torch.int32) << 16        # [chunk*tap*ntile][piece][step][lane][e]
+            total = pieces.view(torch.float32).double().sum(1)
+            NW = Co // 32
+            back = torch.empty(Co, 9, Ci, dtype=torch.float64, device="cuda")
+            t = total.view(Ci // 32, 9, NW, 2, 2, 32, 8)
+            back.view(NW, 32, 9, Ci // 32, 2, 2, 8).copy_(t.permute(2, 5, 1, 0, 3, 4, 6))
+            wref = wk.reshape(Co, 9, Ci).double()
+            assert ((back - wref).abs() <= wref.abs() * 2.0 ** -17).all()
+            assert not torch.equal(back, wref)              # (it IS a reduced representation)
+    print("f32x2 / f32x3 / bf16 relative L2 error (fwd, dgrad, wgrad):", errs[3], errs[2], errs[1])
+    assert max(errs[3]) < 8e-6, errs
+    assert all(e3 < e1 / 100 for e3, e1 in zip(errs[3], errs[1])), errs
