@@ -10,7 +10,10 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_void
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # BIHOME_TUNING=1 (tools/ only): the -DBH_TUNING build with the bh_debug_force_tile ablation hooks (`make -C csrc tuning`)
 TUNING = os.environ.get("BIHOME_TUNING") == "1"
-LIB_PATH = os.path.join(_HERE, "libbihome_hip_tuning.so" if TUNING else "libbihome_hip.so")
+# BIHOME_LIB_VARIANT=ab (tools/ only): an A/B build of the same sources (`make -C csrc ab ABFLAGS=...` -> libbihome_hip_ab.so)
+_VARIANT = os.environ.get("BIHOME_LIB_VARIANT", "")
+LIB_PATH = os.path.join(_HERE, "libbihome_hip_tuning.so" if TUNING else
+                        ("libbihome_hip_%s.so" % _VARIANT if _VARIANT.isalnum() else "libbihome_hip.so"))
 
 
 class BhConvDesc(Structure):

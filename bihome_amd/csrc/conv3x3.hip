@@ -27,6 +27,25 @@
 #include "common.h"
 #include <type_traits>
 
+#ifndef C3_X3_PIPE
+// 1: the software-pipelined tap loop of round 3 (fragments half a tap, weights a full tap ahead; A/B builds: make ab
+// ABFLAGS=-DC3_X3_PIPE=1).  Measured: 70.5 vs 70.7 us (dgrad), 71.5 vs 72.5 us (forward) per launch, 18.07 vs 18.19 ms per step,
+// and the BatchNorm-on-load variant spills (58.8 vs 55.7 us) - the tap loop is NOT latency-bound: tools/x3_timeline.py shows the
+// CU's matrix pipe busy from the first stage-in to the last tile at the rate ONE wave per SIMD reaches alone, and
+// tools/mfma_clock_probe.hip shows why that rate is what it is (the chip sustains 1.6-1.9 PFLOP/s of bf16 MFMA on random-bit
+// operands whatever the pipe occupancy: a power limit, not an issue limit).  Default: the plain loop.
+#define C3_X3_PIPE 0
+#endif
+
+#ifdef BH_TUNING
+// phase time stamps (100 MHz wall clock) of the halo kernels: [workgroup tile][8] = start, first barrier, loop end, epilogue end, XCC / CU id
+__device__ unsigned long long g_c3_ts[8 * 16384];
+#define C3_STAMP(tile, k) do { if (a.dbg_ts && threadIdx.x == 0 && (tile) < 16384) { g_c3_ts[(tile) * 8 + (k)] = wall_clock64();          \
+        if ((k) == 1 || (k) == 2) g_c3_ts[(tile) * 8 + 4 + (k)] = __builtin_readcyclecounter(); } } while (0)
+#else
+#define C3_STAMP(tile, k) do { } while (0)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x8v __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -77,6 +96,7 @@ struct C3Args {
     const float* bni;
     int bni_relu, bni_ipg, bni_groups, bni_lds;
     int dbg_noload;        // ablation bits: 1 no weight-slab DMA in the loop, 2 no halo DMA in the loop (wrong results, timing only)
+    int dbg_ts;            // BH_TUNING: record phase time stamps into g_c3_ts
 };
 
 constexpr int C3_HALO_BYTES = 8 * 200 * 16;          // 25600
@@ -376,6 +396,15 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
     for (int it = 0; it < a.tpb; ++it) {
     const int bx = blockIdx.x * a.tpb + it;
     if (bx >= a.gx_total) break;
+    C3_STAMP(bx * gridDim.y + blockIdx.y, 0);
+#ifdef BH_TUNING
+    if (a.dbg_ts && threadIdx.x == 0 && bx * gridDim.y + blockIdx.y < 16384) {
+        unsigned hw_, xcc_;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
+        g_c3_ts[(bx * gridDim.y + blockIdx.y) * 8 + 4] = ((unsigned long long)xcc_ << 32) | hw_;
+    }
+#endif
     // ---- halo slots of this lane: slot q = (j*4 + wave)*64 + lane of the [8][SUBT][100] image ----
     // (written for instruction count - VALU work does not overlap the other workgroup's MFMAs: the per-sub-tile origin
     //  is computed once, with shifts when the tile grid is a power of two, and the slot -> (plane, sub-tile, hy, hx)
@@ -401,7 +430,10 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
     if constexpr (X3) {
         // ---- halo slots of this thread: slot q = j*256 + tid of the [4 k-planes][SUBT][100] image (8 channels = 32 B each) ----
         constexpr unsigned XOOB = 0x80000000u;           // (tensor sizes are below 2^31: stays out of range with the +16 / chunk offsets added)
-        uint4 bcur[2 * NP], bnext[2 * NP];
+        uint4 bcur[2 * NP];
+#if !C3_X3_PIPE
+        uint4 bnext[2 * NP];
+#endif
         C3_LOAD_BX(bcur, 0, 0);
         unsigned xoff[XJ];
         int xtb[XJ];                                     // BNI: byte offset of the slot's 8 coefficients pairs in the LDS table (chunk 0)
@@ -469,7 +501,87 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
         }
         const int a_lane = (kh2 * HPL + wm * 100 + c3_strip_row(l31 >> 2) * 10 + wh * 4 + (l31 & 3)) * 16;
         __syncthreads();
+        C3_STAMP(bx * gridDim.y + blockIdx.y, 1);
         float4 hb[2][2];
+#define X3_MFMA(afc, bc, s2, PA, PB)                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                      \
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afc[i][s2][PA]),                     \
+                                                         __builtin_bit_cast(bf16x8, bc[(PB) * 2 + (s2)]), acc[i], 0, 0, 0)
+        // A fragments of one tap: [fragment][16-channel step][piece], 4 * NP ds_read_b128 per wave (TM = 2)
+#define X3_LOAD_A(dst, ap)                                                                                              \
+    _Pragma("unroll") for (int s2_ = 0; s2_ < 2; ++s2_)                                                                 \
+        _Pragma("unroll") for (int pc_ = 0; pc_ < NP; ++pc_)                                                            \
+            _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_)                                                           \
+                dst[i_][s2_][pc_] = *reinterpret_cast<const uint4*>((ap) + (pc_ * 4 + 2 * s2_) * (HPL * 16) + i_ * 64)
+#if C3_X3_PIPE
+        // Software-pipelined tap loop (round 3).  The compiler's schedule of the plain loop below requested the fragments and the
+        // weights of tap t + 1 at the END of tap t and waited for them (lgkmcnt / vmcnt) one or two MFMAs into tap t + 1: LDS and
+        // L2 latency exposed once per tap and wave.  Here a tap is two halves of 4 * NP MFMAs (16-channel step s2 = 0 / 1):
+        //   weights of tap t + 1        -> requested at the start of tap t into the OTHER weight register set (a full tap ahead;
+        //                                  the sets alternate per tap, nine taps: the chunk loop is unrolled by two, no copies);
+        //   fragments, step 1 of tap t  -> requested at the start of tap t, into the registers its predecessor's second half freed;
+        //   fragments, step 0 of t + 1  -> requested between the halves of tap t, into the registers the first half just freed
+        // - every request has >= 4 * NP MFMAs (384 cycles) to arrive and no register is added.  sched_barriers pin the order.
+        // The halo of the next chunk is requested at taps 0 .. XJ-1 and cut / written at taps 2 .. XJ+1; ONE barrier per chunk
+        // between the halves of tap 8 (every wave has then read its last fragments of this stage and written its part of the
+        // next one), after which step 0 of the next chunk's tap 0 comes from the other stage.
+#define X3_LOAD_A_HALF(dst, ap, s2_)                                                                                    \
+    _Pragma("unroll") for (int pc_ = 0; pc_ < NP; ++pc_)                                                                \
+        _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_)                                                               \
+            dst[i_][s2_][pc_] = *reinterpret_cast<const uint4*>((ap) + (pc_ * 4 + 2 * (s2_)) * (HPL * 16) + i_ * 64)
+#define X3_MFMA_HALF(afc, bc, s2)                                                                                       \
+    do {                                                                                                                \
+        if constexpr (NP == 3) { X3_MFMA(afc, bc, s2, 2, 0); X3_MFMA(afc, bc, s2, 0, 2); X3_MFMA(afc, bc, s2, 1, 1); }  \
+        X3_MFMA(afc, bc, s2, 1, 0); X3_MFMA(afc, bc, s2, 0, 1); X3_MFMA(afc, bc, s2, 0, 0);                             \
+    } while (0)
+        uint4 af[TM][2][NP], bX[2 * NP], bY[2 * NP];
+#pragma unroll
+        for (int q = 0; q < 2 * NP; ++q) bX[q] = bcur[q];
+        X3_LOAD_A_HALF(af, smem + a_lane, 0);
+        auto tap_step = [&](auto TAP, const int c, const bool more, auto& bc, auto& bn) __attribute__((always_inline)) {
+            constexpr int tap = decltype(TAP)::value;
+            constexpr int dy = tap / 3, dx = tap - dy * 3, dy1 = (tap + 1) / 3, dx1 = (tap + 1) - dy1 * 3;
+            const int hs = c & 1;
+            const char* const hbase = smem + hs * HALO_B + a_lane;
+            if constexpr (tap < 8) C3_LOAD_BX(bn, c, tap + 1);
+            else if (more) C3_LOAD_BX(bn, c + 1, 0);
+            X3_LOAD_A_HALF(af, hbase + (dy * 10 + dx) * 16, 1);
+            if (more) {
+                if constexpr (tap >= 2 && tap - 2 < XJ) X3_STORE(tap - 2, hs ^ 1, c + 1, hb[(tap - 2) & 1]);
+                if constexpr (tap < XJ) X3_ISSUE(tap, c + 1, hb[tap & 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);         // requests first: nothing of the above sinks into the MFMA block
+            X3_MFMA_HALF(af, bc, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (tap < 8) X3_LOAD_A_HALF(af, hbase + (dy1 * 10 + dx1) * 16, 0);
+            else {
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (more) X3_LOAD_A_HALF(af, smem + (hs ^ 1) * HALO_B + a_lane, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            X3_MFMA_HALF(af, bc, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+#define X3_TAP(t, c, more, CUR, NXT) tap_step(std::integral_constant<int, t>{}, c, more, b##CUR, b##NXT)
+#define X3_CHUNK(c, more, P, Q)                                                                                         \
+    do {                                                                                                                \
+        X3_TAP(0, c, more, P, Q); X3_TAP(1, c, more, Q, P); X3_TAP(2, c, more, P, Q); X3_TAP(3, c, more, Q, P);         \
+        X3_TAP(4, c, more, P, Q); X3_TAP(5, c, more, Q, P); X3_TAP(6, c, more, P, Q); X3_TAP(7, c, more, Q, P);         \
+        X3_TAP(8, c, more, P, Q);                                                                                       \
+    } while (0)
+        {
+            int c = 0;
+            for (; c + 1 < nch; c += 2) {
+                X3_CHUNK(c, true, X, Y);
+                X3_CHUNK(c + 1, c + 2 < nch, Y, X);
+            }
+            if (c < nch) X3_CHUNK(c, false, X, Y);
+        }
+#undef X3_CHUNK
+#undef X3_TAP
+#undef X3_MFMA_HALF
+#undef X3_LOAD_A_HALF
+#else
         uint4 af[TM][2][NP];                           // [fragment][16-channel step][piece]
         for (int c = 0; c < nch; ++c) {
             const int hs = c & 1;
@@ -479,15 +591,7 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
             for (int tap = 0; tap < 9; ++tap) {
                 const int dy = tap / 3, dx = tap - dy * 3;
                 const char* ap = hbase + (dy * 10 + dx) * 16;
-                if (!(dbg_noload & 4) || (tap == 0 && c == 0)) {
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                    for (int pc = 0; pc < NP; ++pc)
-#pragma unroll
-                        for (int i = 0; i < TM; ++i)
-                            af[i][s2][pc] = *reinterpret_cast<const uint4*>(ap + (pc * 4 + 2 * s2) * (HPL * 16) + i * 64);
-                }
+                if (!(dbg_noload & 4) || (tap == 0 && c == 0)) X3_LOAD_A(af, ap);
                 if (!(dbg_noload & 1)) {
                 if (tap < 8) C3_LOAD_BX(bnext, c, tap + 1);
                 else if (more) C3_LOAD_BX(bnext, c + 1, 0);
@@ -497,16 +601,11 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
                     if ((tap & 1) == 0 && tap >= 2 && tap / 2 - 1 < XJ) X3_STORE(tap / 2 - 1, hs ^ 1, c + 1, hb[(tap / 2 - 1) & 1]);
                     if ((tap & 1) == 0 && tap / 2 < XJ) X3_ISSUE(tap / 2, c + 1, hb[(tap / 2) & 1]);
                 }
-#define X3_MFMA(s2, PA, PB)                                                                                             \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                      \
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i][s2][PA]),                      \
-                                                         __builtin_bit_cast(bf16x8, bcur[(PB) * 2 + (s2)]), acc[i], 0, 0, 0)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {       // small partial products first
-                    if constexpr (NP == 3) { X3_MFMA(s2, 2, 0); X3_MFMA(s2, 0, 2); X3_MFMA(s2, 1, 1); }
-                    X3_MFMA(s2, 1, 0); X3_MFMA(s2, 0, 1); X3_MFMA(s2, 0, 0);
+                    if constexpr (NP == 3) { X3_MFMA(af, bcur, s2, 2, 0); X3_MFMA(af, bcur, s2, 0, 2); X3_MFMA(af, bcur, s2, 1, 1); }
+                    X3_MFMA(af, bcur, s2, 1, 0); X3_MFMA(af, bcur, s2, 0, 1); X3_MFMA(af, bcur, s2, 0, 0);
                 }
-#undef X3_MFMA
                 if (tap == 8) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 if (!(dbg_noload & 1)) {
 #pragma unroll
@@ -514,6 +613,9 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
                 }
             }
         }
+#endif
+#undef X3_MFMA
+#undef X3_LOAD_A
 #undef X3_ISSUE
 #undef X3_STORE
 #undef X3_BNI
@@ -669,19 +771,30 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
 #undef C3_LOAD_B
 #undef C3_LOAD_BX
 
+    C3_STAMP(bx * gridDim.y + blockIdx.y, 2);
     double s1, s2;
     int img, g;
     c3_epilogue<BN, SUBT, TM>(a, acc, bx, n0, wm, wn, wh, l31, kh2, s1, s2, img, g);
     if (a.bn_sums) c3_stats_merge<BN, 0>(a, smem, s1, s2, img, g, bx, n0, wave, lane, tid);
+#ifdef BH_TUNING
+    if (a.dbg_ts) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (stores of the tile have left the wave)
+#endif
     __syncthreads();            // the next tile's DMA overwrites the LDS this tile's statistics merge just read
+    C3_STAMP(bx * gridDim.y + blockIdx.y, 3);
     }
 }
 
 constexpr int C3_MIN_BLOCKS = 256;      // below this many workgroups the generic kernel's finer tiles fill the chip better
-BH_KNOB(g_c3_noload, 0); BH_KNOB(g_c3_dbg_nch, -1); BH_KNOB(g_c3_subt, 2); BH_KNOB(g_c3_tpb, 2);
+BH_KNOB(g_c3_noload, 0); BH_KNOB(g_c3_dbg_nch, -1); BH_KNOB(g_c3_subt, 2); BH_KNOB(g_c3_tpb, 2); BH_KNOB(g_c3_stamp, 0);
 #ifdef BH_TUNING
+// copies the phase time stamps of the last instrumented launch to the host (n entries of 8 x u64)
+extern "C" int bh_debug_read_c3_stamps(unsigned long long* out, int n) {
+    if (n > 16384) n = 16384;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_c3_ts), (size_t)n * 8 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
 void bh_conv3x3_tune(int disable, int min_blocks) {
     (void)min_blocks;
+    if (disable == 70 || disable == 71) { g_c3_stamp = disable - 70; return; }        // phase time stamps off / on
     if (disable <= -100) { g_c3_dbg_nch = -100 - disable - 1; return; }            // -100 -> -1 (all), -101 -> 0 chunks, -102 -> 1 ...
     if (disable >= 60 && disable < 68) { g_c3_noload = disable - 60; return; }
     if (disable >= 20 && disable < 24) { g_c3_tpb = disable - 20; return; }        // tile positions per workgroup on two-round launches (1 / 2)
@@ -790,7 +903,7 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
     const kern_t fn = bni ? fns[xrow + 6 + (subt == 1 ? 2 : bn_tile == 64 ? 0 : 1)] : x3 ? fns[xrow + (subt == 1 ? 4 : bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0)]
                          : fns[(packed ? 12 : 0) + (subt == 1 ? 8 + (bf16 ? 2 : 0) + (dgrad ? 1 : 0)
                                                               : (bf16 ? 4 : 0) + (bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0))];
-    a.dbg_noload = g_c3_noload;
+    a.dbg_noload = g_c3_noload; a.dbg_ts = g_c3_stamp;
     const int stage = x3 ? (subt == 1 ? XHALO1 : XHALO2) : subt == 1 ? HALO1 : HALO2;
     const int lds = packed ? (Kc / 32 > 1 ? 2 : 1) * stage                                    // halo stages only
                            : (subt == 1 ? LDS1 : C3_LDS_BYTES) - (Kc / 32 > 1 ? 0 : stage);   // single chunk: one halo stage

@@ -864,4 +864,5 @@ def test_conv3x3_f32x2_two_piece_mode(K, N, H, Ci, Co):
             assert not torch.equal(back, wref)              # (it IS a reduced representation)
     print("f32x2 / f32x3 / bf16 relative L2 error (fwd, dgrad, wgrad):", errs[3], errs[2], errs[1])
     assert max(errs[3]) < 8e-6, errs
-    assert all(e3 < e1 / 100 for e3, e1 in zip(errs[3], errs[1])), errs
+    # (forward and dgrad; the bf16-operand weight gradient of some shapes runs the fp32 kernel)
+    assert all(e3 < e1 / 100 for e3, e1 in zip(errs[3][:2], errs[1][:2])), errs
