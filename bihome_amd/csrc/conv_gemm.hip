@@ -920,7 +920,7 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
                    int relu = 0, const bh_bn_reduce* bnr = nullptr, const bh_bn_in* bni = nullptr);
 int bn_launch_stats(const float* x, int groups, int rows, int C, double* sums, hipStream_t s);
 int bh_stem7_try(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, int relu,
-                 hipStream_t stream, int* taken);
+                 hipStream_t stream, int* taken, double* bn_sums = nullptr, int groups = 1);
 
 static int check_desc(const bh_conv_desc* d) {
     if (!d) return BH_E_BADARG;
@@ -1051,8 +1051,8 @@ int bh_conv_fwd_bnstats(const float* x, const float* w, const float* bias, float
     int taken = 0;
     rc = bh_conv3x3_try(x, w, bias, y, d, 0, 0, bh_stream(stream), &taken, sums, groups);
     if (rc || taken) return rc;
-    rc = bh_stem7_try(x, w, bias, y, d, 0, bh_stream(stream), &taken);        // (statistics by the separate kernel below)
-    if (rc) return rc;
+    rc = bh_stem7_try(x, w, bias, y, d, 0, bh_stream(stream), &taken, sums, groups);      // (statistics in its epilogue)
+    if (rc || taken) return rc;
     if (!taken) {
         rc = conv_fwd_impl(x, w, bias, nullptr, y, d, 0, stream, sums, groups);   // generic kernel, statistics in its epilogue
         if (rc == BH_OK) return rc;

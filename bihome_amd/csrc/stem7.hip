@@ -21,6 +21,12 @@ struct Stem7Args {
     int N, Hi, Wi, Ho, Wo;
     int tiles_x, tiles_per_img, ntiles;
     int relu;              // epilogue ReLU (inference: BatchNorm folded into w / bias)
+    // optional: per-channel (sum, sum of squares) of the output for the BatchNorm that follows, per statistics group (the images are
+    // `groups` equal stacks): the persistent workgroup keeps the column sums of its tiles in registers (tiles are walked in image
+    // order, so the group changes at most groups - 1 times) and adds them with one f64 atomic per channel and moment (round 3: the
+    // separate bn_stats pass over the 134 MB output is gone)
+    double* bn_sums;
+    int groups, imgs_per_group;
 };
 
 template <int CIN>
@@ -47,8 +53,28 @@ __global__ void __launch_bounds__(256) stem7_fwd_kernel(Stem7Args a) {
     const float* bbase = Wt + wn * 32 + l31;
     const float bv = a.bias ? a.bias[wn * 32 + l31] : 0.f;
 
+    double s1 = 0, s2 = 0;                             // column sums of this lane's channel over the tiles of statistics group cur_grp
+    int cur_grp = -1;
+    double* const red = reinterpret_cast<double*>(patch);      // [2 wm][64 n][2] (16-byte aligned: KP * 64 floats precede it)
+    auto flush_stats = [&]() {
+        // the two half-waves hold the two row halves of a column; the two wm waves of a channel range meet in LDS
+        __syncthreads();                                 // (patch is free: every wave is past its fragment reads)
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (kh2 == 0) { red[(wm * 64 + wn * 32 + l31) * 2] = s1; red[(wm * 64 + wn * 32 + l31) * 2 + 1] = s2; }
+        __syncthreads();
+        if (tid < 128 && cur_grp >= 0) {
+            const int n = tid >> 1, mom = tid & 1;
+            atomicAdd(&a.bn_sums[bn_sum_index(0, a.groups, cur_grp, 64, n, mom)], red[n * 2 + mom] + red[(64 + n) * 2 + mom]);
+        }
+        s1 = 0; s2 = 0;
+    };
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const int img = tile / a.tiles_per_img, t = tile - img * a.tiles_per_img;
+        if (a.bn_sums) {
+            const int grp = img / a.imgs_per_group;      // (workgroup-uniform)
+            if (grp != cur_grp) { if (cur_grp >= 0) flush_stats(); cur_grp = grp; }
+        }
         const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
         const int iy0 = ty * 16 - 3, ix0 = tx * 16 - 3;
         __syncthreads();                                 // previous tile's fragment reads are done (and Wt is complete)
@@ -82,14 +108,22 @@ __global__ void __launch_bounds__(256) stem7_fwd_kernel(Stem7Args a) {
             float v = acc[r] + bv;
             if (a.relu) v = fmaxf(v, 0.f);
             a.y[(((size_t)img * a.Ho + oy) * a.Wo + ox) * 64 + wn * 32 + l31] = v;
+            acc[r] = v;
+        }
+        if (a.bn_sums) {
+            float q1 = 0.f, q2 = 0.f;                    // 16 elements in float, totals in double
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { q1 += acc[r]; q2 = __builtin_fmaf(acc[r], acc[r], q2); }
+            s1 += (double)q1; s2 += (double)q2;
         }
     }
+    if (a.bn_sums && cur_grp >= 0) flush_stats();
 }
 
 template <int CIN>
 static int stem7_launch(const Stem7Args& a, hipStream_t s) {
     constexpr int KP = (49 * CIN + 3) / 4 * 4;
-    const size_t lds = sizeof(float) * (KP * 64 + CIN * 21 * 21);
+    const size_t lds = sizeof(float) * (KP * 64 + (CIN * 21 * 21 > 512 ? CIN * 21 * 21 : 512));     // (>= 2 KB behind Wt: the statistics merge)
     if (bh_query("stem7_fwd_kernel<%d>", CIN)) return BH_OK;
     static unsigned long long attr_devs = 0;             // devices on which the dynamic-LDS attribute has been set
     if (bh_device_once(attr_devs)) {
@@ -108,7 +142,7 @@ static int stem7_launch(const Stem7Args& a, hipStream_t s) {
 
 // *taken = 1 when the shape is a stem this kernel takes and the launch was made
 int bh_stem7_try(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, int relu,
-                 hipStream_t stream, int* taken) {
+                 hipStream_t stream, int* taken, double* bn_sums, int groups) {
     *taken = 0;
     if ((d->route & BH_ROUTE_NO_STEM7) || d->transposed || d->kh != 7 || d->kw != 7 || d->stride != 2 || d->pad != 3 || d->Co != 64 ||
         d->out_nchw)
@@ -117,6 +151,7 @@ int bh_stem7_try(const float* x, const float* w, const float* bias, float* y, co
     if (d->Ho % 8 || d->Wo % 8 || d->Ho * 2 != d->Hi || d->Wo * 2 != d->Wi) return BH_OK;
     Stem7Args a = {};
     a.x = x; a.w = w; a.bias = bias; a.y = y; a.relu = relu;
+    a.bn_sums = bn_sums; a.groups = groups > 0 ? groups : 1; a.imgs_per_group = d->N / a.groups;
     a.N = d->N; a.Hi = d->Hi; a.Wi = d->Wi; a.Ho = d->Ho; a.Wo = d->Wo;
     a.tiles_x = d->Wo / 8; a.tiles_per_img = (d->Ho / 8) * a.tiles_x; a.ntiles = d->N * a.tiles_per_img;
     if (a.ntiles < 256) return BH_OK;

@@ -249,13 +249,15 @@ def test_graph_replays_invalidate_folded_and_packed_caches():
     opt, sched = build_optimizer(model, cfg["SOLVER"], capturable=True)
     gs = GraphedStep(model, opt, sched, data)
     gs(data)
-    e1 = predict(model, dict(data)).cpu().numpy()           # folds BatchNorms, packs folded weights
+    g = torch.Generator().manual_seed(8)
+    ev = dict(data, choice=torch.randint(1, 128 * 128, (8, 128), generator=g).cuda())      # one fixed DSAC sample for every eval
+    e1 = predict(model, dict(ev)).cpu().numpy()             # folds BatchNorms, packs folded weights
     for _ in range(3):
         gs(data)
-    e2 = predict(model, dict(data)).cpu().numpy()
+    e2 = predict(model, dict(ev)).cpu().numpy()
     fresh = build_model(cfg)
     fresh.load_state_dict(model.state_dict())
-    e2_ref = predict(fresh, dict(data)).cpu().numpy()
+    e2_ref = predict(fresh, dict(ev)).cpu().numpy()
     assert relerr(e2, e2_ref) < 1e-5, relerr(e2, e2_ref)
     assert relerr(e1, e2_ref) > 1e-3                        # three optimizer steps really moved the prediction
     loss, _, _ = gs(data)                                   # and training continues on the graph after an eval
