@@ -43,6 +43,8 @@ P = c_void_p
 # name -> argtypes (all return int).  Must list every symbol include/bihome.h declares.
 SIGNATURES = {
     "bh_version": [],
+    "bh_set_deterministic": [c_int],
+    "bh_get_deterministic": [],
     "bh_device_arch": [c_char_p, c_int],
     "bh_h4pt_fwd": [P, c_int, c_float, c_float, P, P, P],
     "bh_h4pt_bwd": [P, P, P, c_int, c_float, c_float, P, P],
@@ -122,6 +124,10 @@ def _load():
 
 
 lib = _load()
+# BIHOME_DETERMINISTIC=1: order-independent reductions in every kernel (include/bihome.h bh_set_deterministic); kernels.set_deterministic
+# switches it at run time
+if os.environ.get("BIHOME_DETERMINISTIC", "0") == "1":
+    lib.bh_set_deterministic(1)
 
 
 def check(rc, what):

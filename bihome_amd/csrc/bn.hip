@@ -14,11 +14,12 @@
 
 struct BnGeom {
     int groups, rows, C, C4, LPR, RPP, nchunks, rows_per_chunk;
+    int det;               // deterministic mode: cross-workgroup sums through integer limbs (common.h bh_det_add)
 };
 
 static bool bn_geom(int groups, int rows, int C, BnGeom& g) {
     if (C % 4 || groups < 1 || rows < 1) return false;
-    g.groups = groups; g.rows = rows; g.C = C; g.C4 = C / 4;
+    g.groups = groups; g.rows = rows; g.C = C; g.C4 = C / 4; g.det = bh_deterministic() ? 1 : 0;
     if (g.C4 > 256 || (256 % g.C4)) return false;
     g.LPR = g.C4; g.RPP = 256 / g.LPR;
     int n = rows / (g.RPP * 4);          // >= 4 rows per lane per chunk; up to 256 chunks x groups workgroups
@@ -65,8 +66,8 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const float* __restrict__
     if ((int)threadIdx.x < g.LPR) {
         const int slot = blockIdx.x % BH_BN_SUM_SLOTS;
         for (int i = 0; i < 4; ++i) {
-            atomicAdd(&sums[bn_sum_index(slot, g.groups, grp, g.C, cq * 4 + i, 0)], v[i]);
-            atomicAdd(&sums[bn_sum_index(slot, g.groups, grp, g.C, cq * 4 + i, 1)], v[4 + i]);
+            bh_acc_add(&sums[bn_sum_index(slot, g.groups, grp, g.C, cq * 4 + i, 0)], v[i], g.det);
+            bh_acc_add(&sums[bn_sum_index(slot, g.groups, grp, g.C, cq * 4 + i, 1)], v[4 + i], g.det);
         }
     }
 }

@@ -44,13 +44,47 @@ static inline bool bh_device_once(unsigned long long& mask) {
     return true;
 }
 
+// ---- deterministic mode (bh_set_deterministic(1), include/bihome.h): every cross-workgroup accumulation becomes order-independent ----
+// A floating-point atomic add depends on the order in which the workgroups arrive.  In deterministic mode a sum lives in an ENTRY
+// of four 8-byte words: word 0 a plain double (the default mode's atomic target; in deterministic mode only the escape for
+// non-finite / huge addends), words 1-3 three int64 limbs on the grids 2^0, 2^-40, 2^-80.  An addend v is cut EXACTLY into
+// trunc(v), trunc(frac * 2^40), rint(rest * 2^40) and the three integers are added with integer atomics - integer addition is
+// associative, so the total is the same bit pattern whatever the arrival order (range 2^62, resolution 2^-80 ~ 8e-25; each
+// addend's own rounding onto that grid is a function of the addend alone).  Readers add word 0 and the limbs; a caller-zeroed
+// entry that was only written in the default mode has zero limbs, so one reader serves both modes.
+#define BH_ACC_WORDS 4
+bool bh_deterministic();                                       // host: the library-wide mode (capi.hip)
+__device__ __forceinline__ void bh_det_add(double* entry, double v) {
+    if (!(fabs(v) < 0x1p62)) { atomicAdd(entry, v); return; }  // inf / NaN / out of range: stays visible in word 0
+    const double hi = trunc(v);
+    const double r1 = (v - hi) * 0x1p40;                       // exact
+    const double mid = trunc(r1);
+    const double lo = rint((r1 - mid) * 0x1p40);
+    unsigned long long* const w = reinterpret_cast<unsigned long long*>(entry);
+    if (hi != 0.0) atomicAdd(w + 1, (unsigned long long)(long long)hi);
+    if (mid != 0.0) atomicAdd(w + 2, (unsigned long long)(long long)mid);
+    if (lo != 0.0) atomicAdd(w + 3, (unsigned long long)(long long)lo);
+}
+__device__ __forceinline__ double bh_acc_read(const double* __restrict__ entry) {
+    double t = entry[0];
+    const long long* const w = reinterpret_cast<const long long*>(entry);
+    const long long l0 = w[1], l1 = w[2], l2 = w[3];
+    if (l0 | l1 | l2) t += ((double)l2 * 0x1p-40 + (double)l1) * 0x1p-40 + (double)l0;      // smallest limb first
+    return t;
+}
+// accumulate into entry e of a sums buffer in either mode
+__device__ __forceinline__ void bh_acc_add(double* entry, double v, int det) {
+    if (det) bh_det_add(entry, v); else atomicAdd(entry, v);
+}
+
 __device__ __forceinline__ size_t bn_sum_index(int slot, int groups, int grp, int C, int c, int mom) {
     return ((((size_t)slot * groups + grp) * C + c) * 2 + mom) * BH_BN_SUM_STRIDE;
 }
+// (an entry of a BatchNorm sums buffer is the first BH_ACC_WORDS words of its 128-byte line)
 __device__ __forceinline__ double bn_sum_total(const double* __restrict__ buf, int groups, int grp, int C, int c, int mom) {
     double t = 0;
 #pragma unroll
-    for (int s = 0; s < BH_BN_SUM_SLOTS; ++s) t += buf[bn_sum_index(s, groups, grp, C, c, mom)];
+    for (int s = 0; s < BH_BN_SUM_SLOTS; ++s) t += bh_acc_read(buf + bn_sum_index(s, groups, grp, C, c, mom));
     return t;
 }
 

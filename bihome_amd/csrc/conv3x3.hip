@@ -97,6 +97,7 @@ struct C3Args {
     int bni_relu, bni_ipg, bni_groups, bni_lds;
     int dbg_noload;        // ablation bits: 1 no weight-slab DMA in the loop, 2 no halo DMA in the loop (wrong results, timing only)
     int dbg_ts;            // BH_TUNING: record phase time stamps into g_c3_ts
+    int det;               // deterministic mode: the statistics / backward sums go through integer limbs (common.h bh_det_add)
 };
 
 constexpr int C3_HALO_BYTES = 8 * 200 * 16;          // 25600
@@ -126,8 +127,8 @@ __device__ __forceinline__ void c3_epilogue(const C3Args& a, f32x16 (&acc)[TM], 
     if (a.bnr_z && valid) {                        // coefficients of the BatchNorm whose output gradient this tile is
         const int grp = img / a.imgs_per_group;
         const double rows = (double)a.bnr_rows;
-        const double mu = a.bnr_stats[bn_sum_index(0, a.groups, grp, a.Nn, n, 0)] / rows;
-        double var = a.bnr_stats[bn_sum_index(0, a.groups, grp, a.Nn, n, 1)] / rows - mu * mu;
+        const double mu = bn_sum_total(a.bnr_stats, a.groups, grp, a.Nn, n, 0) / rows;
+        double var = bn_sum_total(a.bnr_stats, a.groups, grp, a.Nn, n, 1) / rows - mu * mu;
         if (var < 0) var = 0;
         r_mean = (float)mu;
         r_invstd = 1.0f / sqrtf((float)var + a.bnr_eps);
@@ -274,7 +275,7 @@ __device__ __forceinline__ void c3_stats_merge(const C3Args& a, char* redb, doub
                         const int wv1 = BN == 64 ? (w1 + 2 * cr) : w1;
                         if (grp_of[wv1] == g0) { tot += red[(wv1 * 32 + col) * 2 + mom]; done |= 1 << w1; }
                     }
-                    atomicAdd(&a.bn_sums[bn_sum_index(bx % BH_BN_SUM_SLOTS, a.groups, g0, a.Nn, nn, mom)], tot);
+                    bh_acc_add(&a.bn_sums[bn_sum_index(bx % BH_BN_SUM_SLOTS, a.groups, g0, a.Nn, nn, mom)], tot, a.det);
                 }
             }
         }
@@ -903,7 +904,7 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
     const kern_t fn = bni ? fns[xrow + 6 + (subt == 1 ? 2 : bn_tile == 64 ? 0 : 1)] : x3 ? fns[xrow + (subt == 1 ? 4 : bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0)]
                          : fns[(packed ? 12 : 0) + (subt == 1 ? 8 + (bf16 ? 2 : 0) + (dgrad ? 1 : 0)
                                                               : (bf16 ? 4 : 0) + (bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0))];
-    a.dbg_noload = g_c3_noload; a.dbg_ts = g_c3_stamp;
+    a.dbg_noload = g_c3_noload; a.dbg_ts = g_c3_stamp; a.det = bh_deterministic() ? 1 : 0;
     const int stage = x3 ? (subt == 1 ? XHALO1 : XHALO2) : subt == 1 ? HALO1 : HALO2;
     const int lds = packed ? (Kc / 32 > 1 ? 2 : 1) * stage                                    // halo stages only
                            : (subt == 1 ? LDS1 : C3_LDS_BYTES) - (Kc / 32 > 1 ? 0 : stage);   // single chunk: one halo stage

@@ -51,6 +51,7 @@ struct GemmArgs {
     // (forward statistics of the BatchNorm that follows).  bn_rpg = GEMM rows per statistics group, a multiple of
     // every BM (host check), so a tile never straddles groups; bn_C = channels of the table (eC for the scatter epilogue)
     double* bn_sums;
+    int bn_det;              // deterministic mode: integer-limb accumulation (common.h bh_det_add)
     int bn_rpg, bn_groups, bn_C;
 };
 
@@ -696,7 +697,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
 #pragma unroll
                 for (int w = 0; w < WM; ++w) tot += red[(w * BN + col) * 2 + mom];
                 const int co = a.epi == 1 ? n % a.eC : n;
-                atomicAdd(&a.bn_sums[bn_sum_index(0, a.bn_groups, m0 / a.bn_rpg, a.bn_C, co, mom)], tot);
+                bh_acc_add(&a.bn_sums[bn_sum_index(0, a.bn_groups, m0 / a.bn_rpg, a.bn_C, co, mom)], tot, a.bn_det);
             }
         }
     }
@@ -1000,7 +1001,7 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, cons
         // every workgroup ends with one atomic per (channel, moment): beyond ~2k workgroups per address the atomic unit
         // (one same-address f64 atomic per ~30 ns) is slower than a separate statistics pass
         if (d->out_nchw || rpg % 128 || rpg * groups > 2048ll * 64) return BH_E_UNSUPPORTED;
-        a.bn_sums = bn_sums; a.bn_rpg = (int)rpg; a.bn_groups = groups; a.bn_C = d->Co;
+        a.bn_sums = bn_sums; a.bn_rpg = (int)rpg; a.bn_groups = groups; a.bn_C = d->Co; a.bn_det = bh_deterministic() ? 1 : 0;
     }
     a.Src = x; a.Bw = w; a.bias = bias; a.Out = y; a.bf16 = d->precision == 1;
     a.Hs = d->Hi; a.Ws = d->Wi; a.Cs = d->Ci; a.Kc = d->Ci;

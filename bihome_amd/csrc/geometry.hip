@@ -164,13 +164,13 @@ __device__ static void jacobi9(double* A, double* V, int lane) {
 }
 
 // loads this wave's points; returns count for this lane
-__device__ static int load_points(const float* pf, const int64_t* choice, int b, int j, int P, int h, int w, int lane,
+__device__ static int load_points(const float* pf, const int64_t* choice, int b, int j, int n, int P, int h, int w, int lane,
                                   double* x1, double* y1, double* x2, double* y2, int* idx) {
     int cnt = 0;
     const float* pfx = pf + (size_t)b * 2 * h * w;
     const float* pfy = pfx + (size_t)h * w;
     for (int p = lane; p < P && cnt < DLT_MAXPTS; p += 64, ++cnt) {
-        int id = (int)choice[(size_t)b * ((size_t)P * gridDim.y) + (size_t)j * P + p];
+        int id = (int)choice[(size_t)b * ((size_t)P * n) + (size_t)j * P + p];
         idx[cnt] = id;
         double cx = (double)(id % w), cy = (double)(id / w);
         x1[cnt] = cx; y1[cnt] = cy;
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(64) dlt_fwd_kernel(const float* __restrict__ p
     const int prob = b * n + j;
     double x1[DLT_MAXPTS], y1[DLT_MAXPTS], x2[DLT_MAXPTS], y2[DLT_MAXPTS];
     int idx[DLT_MAXPTS];
-    int cnt = load_points(pf, choice, b, j, P, h, w, lane, x1, y1, x2, y2, idx);
+    int cnt = load_points(pf, choice, b, j, n, P, h, w, lane, x1, y1, x2, y2, idx);
     Hartley t1 = hartley_stats(x1, y1, cnt, P);
     Hartley t2 = hartley_stats(x2, y2, cnt, P);
     // block sums: S0 = a a^T, Sx = x2 a a^T, Sy = y2 a a^T, Sr = (x2^2+y2^2) a a^T with a = [x1 y1 1] (normalised)
@@ -254,14 +254,19 @@ __global__ void __launch_bounds__(64) dlt_fwd_kernel(const float* __restrict__ p
 __global__ void __launch_bounds__(64) dlt_bwd_kernel(const float* __restrict__ pf, const int64_t* __restrict__ choice,
                                                      const double* __restrict__ eig, const float* __restrict__ g_delta,
                                                      const double* __restrict__ g_Hd, int P, int h, int w,
-                                                     float* __restrict__ g_pf) {
+                                                     float* __restrict__ g_pf, int n, int j0, int det) {
+    // n hypotheses per sample; this launch covers j0 + blockIdx.y.  det (deterministic mode: one launch per hypothesis, so the
+    // hypotheses of a sample add to its field in stream order): repeated sample indices inside the wave are added up in point
+    // order by the first of them and stored without atomics
     __shared__ double Gs[81];
     __shared__ double sc[8];   // g(1/s2), g m2x, g m2y
-    const int b = blockIdx.x, j = blockIdx.y, n = gridDim.y, lane = threadIdx.x;
+    __shared__ int d_idx[64 * DLT_MAXPTS];
+    __shared__ float d_vx[64 * DLT_MAXPTS], d_vy[64 * DLT_MAXPTS];
+    const int b = blockIdx.x, j = j0 + blockIdx.y, lane = threadIdx.x;
     const int prob = b * n + j;
     double x1[DLT_MAXPTS], y1[DLT_MAXPTS], x2[DLT_MAXPTS], y2[DLT_MAXPTS];
     int idx[DLT_MAXPTS];
-    int cnt = load_points(pf, choice, b, j, P, h, w, lane, x1, y1, x2, y2, idx);
+    int cnt = load_points(pf, choice, b, j, n, P, h, w, lane, x1, y1, x2, y2, idx);
     Hartley t1 = hartley_stats(x1, y1, cnt, P);
     Hartley t2 = hartley_stats(x2, y2, cnt, P);
     const double* e = eig + (size_t)prob * 96;
@@ -373,9 +378,30 @@ __global__ void __launch_bounds__(64) dlt_bwd_kernel(const float* __restrict__ p
     gmy += wave_sum(gm_from_d_y);
     float* gpfx = g_pf + (size_t)b * 2 * h * w;
     float* gpfy = gpfx + (size_t)h * w;
+    if (!det) {
+        for (int k = 0; k < cnt; ++k) {
+            atomicAdd(gpfx + idx[k], (float)(gpx[k] + gmx / P));
+            atomicAdd(gpfy + idx[k], (float)(gpy[k] + gmy / P));
+        }
+        return;
+    }
+    for (int k = 0; k < DLT_MAXPTS; ++k) {                  // point p = lane + 64 k lives in slot p
+        d_idx[k * 64 + lane] = k < cnt ? idx[k] : -1;
+        d_vx[k * 64 + lane] = k < cnt ? (float)(gpx[k] + gmx / P) : 0.f;
+        d_vy[k * 64 + lane] = k < cnt ? (float)(gpy[k] + gmy / P) : 0.f;
+    }
+    __syncthreads();
+    const int np = P < 64 * DLT_MAXPTS ? P : 64 * DLT_MAXPTS;
     for (int k = 0; k < cnt; ++k) {
-        atomicAdd(gpfx + idx[k], (float)(gpx[k] + gmx / P));
-        atomicAdd(gpfy + idx[k], (float)(gpy[k] + gmy / P));
+        const int me = k * 64 + lane, id = idx[k];
+        bool first = true;
+        float ax = 0.f, ay = 0.f;
+        for (int q = 0; q < np; ++q)
+            if (d_idx[q] == id) {
+                if (q < me) first = false;
+                ax += d_vx[q]; ay += d_vy[q];
+            }
+        if (first) { gpfx[id] += ax; gpfy[id] += ay; }
     }
 }
 
@@ -428,9 +454,10 @@ __global__ void dsac_softmax_bwd_kernel(const float* __restrict__ scores, const 
 // hypotheses of a sample and the DLT adjoint write the same field).  grid (B, n), block 256.
 __global__ void __launch_bounds__(256) dsac_score_bwd_kernel(const float* __restrict__ pf, const float* __restrict__ Hd,
                                                              const float* __restrict__ g_err, int h, int w,
-                                                             double* __restrict__ g_Hd, float* __restrict__ g_pf) {
+                                                             double* __restrict__ g_Hd, float* __restrict__ g_pf, int nhyp) {
     __shared__ double part[4][9];
-    const int b = blockIdx.x, j = blockIdx.y, n = gridDim.y;
+    const int b = blockIdx.x, n = nhyp;
+    for (int j = blockIdx.y; j < n; j += gridDim.y) {       // (deterministic mode: gridDim.y = 1 - one workgroup adds the hypotheses of a sample in order)
     const float* Hm = Hd + (size_t)(b * n + j) * 9;
     const float H0 = Hm[0], H1 = Hm[1], H2 = Hm[2], H3 = Hm[3], H4 = Hm[4], H5 = Hm[5], H6 = Hm[6], H7 = Hm[7], H8 = Hm[8];
     const float ge = g_err[b * n + j];
@@ -439,6 +466,8 @@ __global__ void __launch_bounds__(256) dsac_score_bwd_kernel(const float* __rest
     float* gx = g_pf + (size_t)b * 2 * h * w;
     float* gy = gx + (size_t)h * w;
     double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // (pixel i is always handled by thread i % 256 of the sample's workgroup: with one workgroup per sample its adds to g_pf[i]
+    //  follow the hypothesis order)
     for (int i = threadIdx.x; i < h * w; i += 256) {
         const float x = (float)(i % w), y = (float)(i / w);
         const float qx = H0 * x + H1 * y + H2, qy = H3 * x + H4 * y + H5, qz = H6 * x + H7 * y + H8;
@@ -462,6 +491,8 @@ __global__ void __launch_bounds__(256) dsac_score_bwd_kernel(const float* __rest
     __syncthreads();
     if (threadIdx.x < 9)
         g_Hd[(size_t)(b * n + j) * 9 + threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    __syncthreads();
+    }
 }
 
 __global__ void dsac_best_kernel(const float* __restrict__ err, int B, int n, int64_t* __restrict__ best) {
@@ -513,8 +544,16 @@ int bh_dlt_bwd(const float* pf, const int64_t* choice, const double* eig, const 
     if (!pf || !choice || !eig || !g_delta || !g_pf || B < 0 || n < 1 || P < 4) return BH_E_BADARG;
     if (P > 64 * DLT_MAXPTS) return BH_E_UNSUPPORTED;
     if (B == 0) return BH_OK;
+    if (bh_deterministic()) {
+        for (int j = 0; j < n; ++j) {
+            hipLaunchKernelGGL(dlt_bwd_kernel, dim3(B, 1), dim3(64), 0, bh_stream(stream), pf, choice, eig, g_delta, g_Hdlt, P, h, w,
+                               g_pf, n, j, 1);
+            BH_LAUNCH_CHECK();
+        }
+        return BH_OK;
+    }
     hipLaunchKernelGGL(dlt_bwd_kernel, dim3(B, n), dim3(64), 0, bh_stream(stream), pf, choice, eig, g_delta, g_Hdlt, P, h, w,
-                       g_pf);
+                       g_pf, n, 0, 0);
     BH_LAUNCH_CHECK();
     return BH_OK;
 }
@@ -546,7 +585,8 @@ int bh_dsac_scores_bwd(const float* pf, const float* Hdlt, const float* scores, 
     if (B == 0) return BH_OK;
     hipLaunchKernelGGL(dsac_softmax_bwd_kernel, dim3((B + 63) / 64), dim3(64), 0, bh_stream(stream), scores, g_scores, B, n, g_err);
     BH_LAUNCH_CHECK();
-    hipLaunchKernelGGL(dsac_score_bwd_kernel, dim3(B, n), dim3(256), 0, bh_stream(stream), pf, Hdlt, g_err, h, w, g_Hdlt, g_pf);
+    hipLaunchKernelGGL(dsac_score_bwd_kernel, dim3(B, bh_deterministic() ? 1 : n), dim3(256), 0, bh_stream(stream), pf, Hdlt, g_err, h, w,
+                       g_Hdlt, g_pf, n);
     BH_LAUNCH_CHECK();
     return BH_OK;
 }

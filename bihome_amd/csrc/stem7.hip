@@ -26,7 +26,7 @@ struct Stem7Args {
     // order, so the group changes at most groups - 1 times) and adds them with one f64 atomic per channel and moment (round 3: the
     // separate bn_stats pass over the 134 MB output is gone)
     double* bn_sums;
-    int groups, imgs_per_group;
+    int groups, imgs_per_group, det;
 };
 
 template <int CIN>
@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(256) stem7_fwd_kernel(Stem7Args a) {
         __syncthreads();
         if (tid < 128 && cur_grp >= 0) {
             const int n = tid >> 1, mom = tid & 1;
-            atomicAdd(&a.bn_sums[bn_sum_index(0, a.groups, cur_grp, 64, n, mom)], red[n * 2 + mom] + red[(64 + n) * 2 + mom]);
+            bh_acc_add(&a.bn_sums[bn_sum_index(0, a.groups, cur_grp, 64, n, mom)], red[n * 2 + mom] + red[(64 + n) * 2 + mom], a.det);
         }
         s1 = 0; s2 = 0;
     };
@@ -151,7 +151,7 @@ int bh_stem7_try(const float* x, const float* w, const float* bias, float* y, co
     if (d->Ho % 8 || d->Wo % 8 || d->Ho * 2 != d->Hi || d->Wo * 2 != d->Wi) return BH_OK;
     Stem7Args a = {};
     a.x = x; a.w = w; a.bias = bias; a.y = y; a.relu = relu;
-    a.bn_sums = bn_sums; a.groups = groups > 0 ? groups : 1; a.imgs_per_group = d->N / a.groups;
+    a.bn_sums = bn_sums; a.groups = groups > 0 ? groups : 1; a.imgs_per_group = d->N / a.groups; a.det = bh_deterministic() ? 1 : 0;
     a.N = d->N; a.Hi = d->Hi; a.Wi = d->Wi; a.Ho = d->Ho; a.Wo = d->Wo;
     a.tiles_x = d->Wo / 8; a.tiles_per_img = (d->Ho / 8) * a.tiles_x; a.ntiles = d->N * a.tiles_per_img;
     if (a.ntiles < 256) return BH_OK;

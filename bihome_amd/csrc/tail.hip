@@ -536,7 +536,7 @@ int bh_tail_bwd(const float* gout, const float* x, const float* w1, const float*
 #undef TAIL_BWD
     if (gb2) {
         const int nimg = groups * rows / hw;
-        hipLaunchKernelGGL(tail_gb2_kernel, dim3(nimg < 256 ? nimg : 256, Co), dim3(256), 0, s, gout, nimg, Co, hw, gb2);
+        hipLaunchKernelGGL(tail_gb2_kernel, dim3(bh_deterministic() ? 1 : (nimg < 256 ? nimg : 256), Co), dim3(256), 0, s, gout, nimg, Co, hw, gb2);
         BH_LAUNCH_CHECK();
     }
     return BH_OK;

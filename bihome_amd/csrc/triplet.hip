@@ -285,7 +285,7 @@ int bh_oneline_loss_fwd(const float* f1, const float* f2, const float* f1w, cons
     if (B > 0) {
         hipError_t e = hipMemsetAsync(numden, 0, sizeof(double) * 2 * (size_t)B, s);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(oneline_fwd_kernel, dim3(TRIP_BLOCKS_PER_SAMPLE, B), dim3(256), 0, s, f1, f2, f1w, m1w, m2, hw, C,
+        hipLaunchKernelGGL(oneline_fwd_kernel, dim3(bh_deterministic() ? 1 : TRIP_BLOCKS_PER_SAMPLE, B), dim3(256), 0, s, f1, f2, f1w, m1w, m2, hw, C,
                            margin, rep, T, numden);
         BH_LAUNCH_CHECK();
     }
@@ -314,7 +314,7 @@ int bh_triplet_l1_fwd(const float* f1, const float* f2, const float* f1w, const 
     if (B == 0) return BH_OK;
     hipError_t e = hipMemsetAsync(numden, 0, sizeof(double) * 4 * (size_t)B, bh_stream(stream));
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(triplet_fwd_kernel, dim3(TRIP_FWD_BLOCKS_PER_SAMPLE, B), dim3(256), 0, bh_stream(stream), f1, f2, f1w,
+    hipLaunchKernelGGL(triplet_fwd_kernel, dim3(bh_deterministic() ? 1 : TRIP_FWD_BLOCKS_PER_SAMPLE, B), dim3(256), 0, bh_stream(stream), f1, f2, f1w,
                        f2w, m1w, m2w, m1, m2, hw, C, M1, M2, numden);
     BH_LAUNCH_CHECK();
     return BH_OK;
@@ -362,7 +362,7 @@ int bh_scale_samples_bwd(const float* g_y, const float* x, const float* s, int B
     if (Bn == 0) return BH_OK;
     hipError_t e = hipMemsetAsync(g_s, 0, sizeof(float) * (size_t)Bn, bh_stream(stream));
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(scale_samples_bwd_kernel, dim3(32, Bn), dim3(256), 0, bh_stream(stream), g_y, x, s, L, rep, g_x, g_s);
+    hipLaunchKernelGGL(scale_samples_bwd_kernel, dim3(bh_deterministic() ? 1 : 32, Bn), dim3(256), 0, bh_stream(stream), g_y, x, s, L, rep, g_x, g_s);
     BH_LAUNCH_CHECK();
     return BH_OK;
 }

@@ -110,7 +110,11 @@ __global__ void __launch_bounds__(256) warp_bwd_kernel(const float* __restrict__
     __shared__ double part[4][9];
     const int b = blockIdx.z;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int x = blockIdx.x * 16 + tx, y = blockIdx.y * 16 + ty;
+    double acc9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // (deterministic mode: grid (1, 1, B) - one workgroup walks every tile of its sample and is the only writer of gH[b])
+    for (int by = blockIdx.y; by < h / 16; by += gridDim.y)
+    for (int bx = blockIdx.x; bx < w / 16; bx += gridDim.x) {
+    const int x = bx * 16 + tx, y = by * 16 + ty;
     float u, v, iz;
     bool guard;
     project(H64 + (size_t)b * 9, x, y, u, v, iz, guard);
@@ -138,13 +142,19 @@ __global__ void __launch_bounds__(256) warp_bwd_kernel(const float* __restrict__
     }
     // u = qx*iz, v = qy*iz, iz = 1/qz (or 1 under the guard)
     double s[9];
+    {
     const double fx = (double)x, fy = (double)y, dgu = (double)gu, dgv = (double)gv, diz = (double)iz;
     s[0] = dgu * diz * fx; s[1] = dgu * diz * fy; s[2] = dgu * diz;
     s[3] = dgv * diz * fx; s[4] = dgv * diz * fy; s[5] = dgv * diz;
     double gz = guard ? 0.0 : -(dgu * (double)u + dgv * (double)v) * diz;
     s[6] = gz * fx; s[7] = gz * fy; s[8] = gz;
+    }
 #pragma unroll
-    for (int i = 0; i < 9; ++i) s[i] = wave_sum(s[i]);
+    for (int i = 0; i < 9; ++i) acc9[i] += s[i];
+    }
+    double s[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) s[i] = wave_sum(acc9[i]);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane == 0)
         for (int i = 0; i < 9; ++i) part[wave][i] = s[i];
@@ -271,16 +281,19 @@ __global__ void __launch_bounds__(256) warp_bwd4_kernel(const float* __restrict_
     __shared__ double part[4][9];
     const int b = blockIdx.z;
     const int tq = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int xq = blockIdx.x * 64 + tq * 4;
     const Hf H = load_h(H64 + (size_t)b * 9);
     const unsigned plane = (unsigned)h * (unsigned)w;
     const bool have_img = img && g_out;
     double s[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) s[k] = 0.0;
+    // (deterministic mode: grid (1, 1, B) - one workgroup walks every tile position of its sample and is the only writer of gH[b])
+    for (int by = blockIdx.y; by < h / (16 * RPT); by += gridDim.y)
+    for (int bx = blockIdx.x; bx < w / 64; bx += gridDim.x) {
+    const int xq = bx * 64 + tq * 4;
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
-        const int y = (blockIdx.y * RPT + r) * 16 + ty;
+        const int y = (by * RPT + r) * 16 + ty;
         const unsigned pix = (unsigned)y * (unsigned)w + xq;
         const float gc = g_cov ? g_cov[(size_t)b * (h / 4) * (w / 4) + (size_t)(y / 4) * (w / 4) + xq / 4] * (1.0f / 16.0f) : 0.0f;
         float gu[4], gv[4];
@@ -322,6 +335,7 @@ __global__ void __launch_bounds__(256) warp_bwd4_kernel(const float* __restrict_
         s[0] += aux; s[1] += au * fy; s[2] += au;
         s[3] += avx; s[4] += av * fy; s[5] += av;
         s[6] += azx; s[7] += az * fy; s[8] += az;
+    }
     }
 #pragma unroll
     for (int k = 0; k < 9; ++k) s[k] = wave_sum(s[k]);
@@ -374,7 +388,7 @@ int bh_warp_bwd(const float* img, const double* H64, const float* g_out, const f
     if (pool == 4 && (w % 64) == 0) {
         int rpt = g_warp_rpt_bwd;
         while (rpt > 1 && h % (16 * rpt)) rpt >>= 1;
-        const dim3 grid(w / 64, h / (16 * rpt), B);
+        const dim3 grid = bh_deterministic() ? dim3(1, 1, B) : dim3(w / 64, h / (16 * rpt), B);
         hipStream_t s = bh_stream(stream);
         if (rpt >= 4) hipLaunchKernelGGL(warp_bwd4_kernel<4>, grid, dim3(256), 0, s, img, H64, g_out, g_cov, C, h, w, gH);
         else if (rpt == 2) hipLaunchKernelGGL(warp_bwd4_kernel<2>, grid, dim3(256), 0, s, img, H64, g_out, g_cov, C, h, w, gH);
@@ -382,8 +396,8 @@ int bh_warp_bwd(const float* img, const double* H64, const float* g_out, const f
         BH_LAUNCH_CHECK();
         return BH_OK;
     }
-    hipLaunchKernelGGL(warp_bwd_kernel, dim3(w / 16, h / 16, B), dim3(256), 0, bh_stream(stream), img, H64, g_out, g_cov,
-                       C, h, w, pool, gH);
+    hipLaunchKernelGGL(warp_bwd_kernel, bh_deterministic() ? dim3(1, 1, B) : dim3(w / 16, h / 16, B), dim3(256), 0, bh_stream(stream), img,
+                       H64, g_out, g_cov, C, h, w, pool, gH);
     BH_LAUNCH_CHECK();
     return BH_OK;
 }

@@ -33,7 +33,15 @@ struct WgradArgs {
     int xcd_map;             // XCD-aware (tile, tap, split) order, see wgrad_kernel
     int noflush;             // ablation (bh_debug_force_tile(-7, 1)): skip the atomic flush
     float* partials;         // deterministic mode (wgrad_s1): per-workgroup partial tiles go here instead of into atomics
+    double* shadow;          // deterministic mode (every other kernel): integer-limb entries (common.h bh_det_add), BH_ACC_WORDS words per
+                             // element of Out at the element's offset; wgrad_shadow_finalize_kernel adds them to Out
 };
+
+// one split-K contribution to Out[off]: fp32 atomic (order-dependent rounding) or, in deterministic mode, the integer limbs
+__device__ __forceinline__ void wg_acc(const WgradArgs& a, long long off, float v) {
+    if (a.shadow) bh_det_add(a.shadow + off * BH_ACC_WORDS, (double)v);
+    else atomicAdd(a.Out + off, v);
+}
 
 #define WBK 32
 #define WLD 68
@@ -204,7 +212,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int p = p0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh2;
-            if (p < a.Np && !a.noflush) atomicAdd(a.Out + (long long)p * a.sOp + (long long)t * a.sOt + q, acc[r]);
+            if (p < a.Np && !a.noflush) wg_acc(a, (long long)p * a.sOp + (long long)t * a.sOt + q, acc[r]);
         }
     }
 }
@@ -351,9 +359,9 @@ __global__ void __launch_bounds__(256) wgrad_s1_kernel(WgradArgs a) {
     }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        float* const o = a.Out + (long long)(p0 + wm * 32 + 4 * kh2) * a.sOp + (long long)(t0 + j) * a.sOt + q0 + wn * 32 + l31;
+        const long long o = (long long)(p0 + wm * 32 + 4 * kh2) * a.sOp + (long long)(t0 + j) * a.sOt + q0 + wn * 32 + l31;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) atomicAdd(o + (long long)((r & 3) + 8 * (r >> 2)) * a.sOp, acc[j][r]);
+        for (int r = 0; r < 16; ++r) wg_acc(a, o + (long long)((r & 3) + 8 * (r >> 2)) * a.sOp, acc[j][r]);
     }
 }
 
@@ -466,7 +474,7 @@ __global__ void __launch_bounds__(256) wgrad_small_kernel(WgradArgs a) {
         const int idx = tid + 256 * j, r = idx >> 6, ln = idx & 63;
         const float v = red[idx] + red[1024 + idx] + red[2048 + idx] + red[3072 + idx];
         const int p = p0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), q = q0 + (ln & 31);
-        if (p < a.Np && q < ncols) atomicAdd(a.Out + (long long)p * a.sOp + (long long)t * a.sOt + q, v);
+        if (p < a.Np && q < ncols) wg_acc(a, (long long)p * a.sOp + (long long)t * a.sOt + q, v);
     }
 }
 
@@ -579,14 +587,19 @@ __global__ void __launch_bounds__(256) wgrad_small_taps_kernel(WgradArgs a) {
             const int idx = tid + 256 * j, r = idx >> 6, ln = idx & 63;
             const float v = red[idx] + red[1024 + idx] + red[2048 + idx] + red[3072 + idx];
             const int p = p0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), q = q0 + (ln & 31);
-            if (p < a.Np && q < a.Nq) atomicAdd(a.Out + (long long)p * a.sOp + (long long)(t0 + t) * a.sOt + q, v);
+            if (p < a.Np && q < a.Nq) wg_acc(a, (long long)p * a.sOp + (long long)(t0 + t) * a.sOt + q, v);
         }
     }
 }
 
 // column sums of a [M][C] matrix accumulated into out[C] (bias gradients)
+// (shadow != NULL, here and in the two kernels below: deterministic mode - integer-limb entries instead of fp32 atomics)
+__device__ __forceinline__ void colsum_acc(float* out, double* shadow, int c, float v) {
+    if (shadow) bh_det_add(shadow + (size_t)c * BH_ACC_WORDS, (double)v);
+    else atomicAdd(out + c, v);
+}
 __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ x, int M, int C, int rows_per_block,
-                                                     float* __restrict__ out) {
+                                                     float* __restrict__ out, double* __restrict__ shadow) {
     __shared__ float sm[256];
     const int c = blockIdx.y * 64 + (threadIdx.x & 63);
     const int rsub = threadIdx.x >> 6;
@@ -596,12 +609,13 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ x
         for (int m = mbeg + rsub; m < mend; m += 4) acc += x[(size_t)m * C + c];
     sm[threadIdx.x] = acc;
     __syncthreads();
-    if (threadIdx.x < 64 && c < C) atomicAdd(out + c, sm[threadIdx.x] + sm[threadIdx.x + 64] + sm[threadIdx.x + 128] + sm[threadIdx.x + 192]);
+    if (threadIdx.x < 64 && c < C) colsum_acc(out, shadow, c, sm[threadIdx.x] + sm[threadIdx.x + 64] + sm[threadIdx.x + 128] + sm[threadIdx.x + 192]);
 }
 
 // same, float4 per lane (C % 4 == 0, C/4 divides 256): a lane keeps its four channels, 256/(C/4) rows per pass, four
 // independent loads in flight per lane; streams at HBM rate where the scalar version managed ~1.5 TB/s
-__global__ void __launch_bounds__(256) colsum4_kernel(const float* __restrict__ x, int M, int C, float* __restrict__ out) {
+__global__ void __launch_bounds__(256) colsum4_kernel(const float* __restrict__ x, int M, int C, float* __restrict__ out,
+                                                      double* __restrict__ shadow) {
     __shared__ float4 sm[256];
     const int LPR = C >> 2, RPP = 256 / LPR;
     const int cq = threadIdx.x % LPR, r0 = threadIdx.x / LPR;
@@ -624,16 +638,16 @@ __global__ void __launch_bounds__(256) colsum4_kernel(const float* __restrict__ 
             const float4 o = sm[threadIdx.x + r * LPR];
             acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
         }
-        atomicAdd(out + cq * 4 + 0, acc.x);
-        atomicAdd(out + cq * 4 + 1, acc.y);
-        atomicAdd(out + cq * 4 + 2, acc.z);
-        atomicAdd(out + cq * 4 + 3, acc.w);
+        colsum_acc(out, shadow, cq * 4 + 0, acc.x);
+        colsum_acc(out, shadow, cq * 4 + 1, acc.y);
+        colsum_acc(out, shadow, cq * 4 + 2, acc.z);
+        colsum_acc(out, shadow, cq * 4 + 3, acc.w);
     }
 }
 
 // sum of channel plane c of an NCHW tensor, accumulated into out[0]
 __global__ void __launch_bounds__(256) plane_sum_kernel(const float* __restrict__ x, int N, int C, int c, int hw,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, double* __restrict__ shadow) {
     __shared__ float sm[4];
     float acc = 0.f;
     const size_t total = (size_t)N * hw;
@@ -644,7 +658,13 @@ __global__ void __launch_bounds__(256) plane_sum_kernel(const float* __restrict_
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, sm[0] + sm[1] + sm[2] + sm[3]);
+    if (threadIdx.x == 0) colsum_acc(out, shadow, 0, sm[0] + sm[1] + sm[2] + sm[3]);
+}
+
+// deterministic mode, second pass: out[i] += (float)(value of shadow entry i)
+__global__ void __launch_bounds__(256) wgrad_shadow_finalize_kernel(const double* __restrict__ shadow, float* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        out[i] += (float)bh_acc_read(shadow + i * BH_ACC_WORDS);
 }
 
 // Second pass of the deterministic mode: Out[p][t][q] += sum over the pixel splits, in split order (fixed), of the partial
@@ -674,7 +694,8 @@ BH_KNOB(g_wgrad_target, 4096);     // split-K work items per launch (tuning hook
 
 extern "C" {
 
-int bh_conv_bias_grad(const float* gy, float* gbias, const bh_conv_desc* d, void* stream) {
+// shadow (deterministic mode): Co entries of BH_ACC_WORDS doubles, any content (zeroed here), or NULL (fp32 atomics)
+static int bias_grad_impl(const float* gy, float* gbias, const bh_conv_desc* d, void* stream, double* shadow) {
     if (!gy || !gbias || !d) return BH_E_BADARG;
     hipStream_t s = bh_stream(stream);
     // bias gradient = column sums of gy over all output pixels
@@ -682,24 +703,37 @@ int bh_conv_bias_grad(const float* gy, float* gbias, const bh_conv_desc* d, void
     int blocks = (M + 1023) / 1024;
     if (blocks > 1024) blocks = 1024;
     int rpb = (M + blocks - 1) / blocks;
+    if (shadow) {
+        const hipError_t e = hipMemsetAsync(shadow, 0, (size_t)C * BH_ACC_WORDS * sizeof(double), s);
+        if (e != hipSuccess) return (int)e;
+    }
     if (d->out_nchw) {
         // planes: treat each (n, c) plane as a [hw][1] matrix
         const int hwp = d->Ho * d->Wo;
         for (int c = 0; c < C; ++c) {
-            hipLaunchKernelGGL(plane_sum_kernel, dim3(64), dim3(256), 0, s, gy, d->N, C, c, hwp, gbias + c);
+            hipLaunchKernelGGL(plane_sum_kernel, dim3(64), dim3(256), 0, s, gy, d->N, C, c, hwp, gbias + c, shadow ? shadow + (size_t)c * BH_ACC_WORDS : nullptr);
             BH_LAUNCH_CHECK();
         }
     } else if (C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0) {
         const int rpp = 256 / (C / 4);
         int nb = (M + rpp * 8 - 1) / (rpp * 8);
         if (nb > 512) nb = 512;          // every workgroup ends with C same-address atomics (~28 ns each, serialised)
-        hipLaunchKernelGGL(colsum4_kernel, dim3(nb), dim3(256), 0, s, gy, M, C, gbias);
+        hipLaunchKernelGGL(colsum4_kernel, dim3(nb), dim3(256), 0, s, gy, M, C, gbias, shadow);
         BH_LAUNCH_CHECK();
     } else {
-        hipLaunchKernelGGL(colsum_kernel, dim3(blocks, (C + 63) / 64), dim3(256), 0, s, gy, M, C, rpb, gbias);
+        hipLaunchKernelGGL(colsum_kernel, dim3(blocks, (C + 63) / 64), dim3(256), 0, s, gy, M, C, rpb, gbias, shadow);
+        BH_LAUNCH_CHECK();
+    }
+    if (shadow) {
+        hipLaunchKernelGGL(wgrad_shadow_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, shadow, gbias, (long long)C);
         BH_LAUNCH_CHECK();
     }
     return BH_OK;
+}
+
+int bh_conv_bias_grad(const float* gy, float* gbias, const bh_conv_desc* d, void* stream) {
+    // (no workspace on this entry point: in deterministic mode callers take bh_conv_wgrad_det(..., gbias, ...), which has one)
+    return bias_grad_impl(gy, gbias, d, stream, nullptr);
 }
 
 static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gbias, const bh_conv_desc* d, void* stream,
@@ -744,12 +778,21 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
     if (!d || !x || !gy || !gw) return BH_E_BADARG;
     if (d->out_nchw && (d->Co > 4 || d->transposed)) return BH_E_UNSUPPORTED;
     hipStream_t s = bh_stream(stream);
+    // deterministic mode (bh_set_deterministic): with a workspace EVERY shape has an order-independent form - the f32x3 and
+    // stride-1 kernels store partial tiles, all others accumulate through integer-limb shadow entries; the last Co entries of
+    // the workspace serve the bias gradient
+    const bool det = ws && bh_deterministic();
+    const long long bias_bytes = det ? (long long)(d->transposed ? d->Co : d->Co) * BH_ACC_WORDS * 8 : 0;
     if ((d->precision == 2 || d->precision == 3) && !(d->route & BH_ROUTE_WGRAD_GENERIC)) {
         // f32x3 / f32x2 arithmetic: the halo-tiled split-operand kernel (wgrad_x3.hip) takes the 3x3 layers with channels % 64 == 0
         int taken = 0;
-        const int rc = bh_wgrad_x3_try(x, gy, gw, d, s, &taken, ws, ws_bytes, ws_need);
+        const int rc = bh_wgrad_x3_try(x, gy, gw, d, s, &taken, ws, ws_bytes > bias_bytes ? ws_bytes - bias_bytes : 0, ws_need);
         if (rc != BH_OK) return rc;
-        if (taken) return (gbias && !bh_query_ctx) ? bh_conv_bias_grad(gy, gbias, d, stream) : BH_OK;
+        if (taken) {
+            if (ws_need) { *ws_need += bias_bytes; return BH_OK; }
+            if (!gbias || bh_query_ctx) return BH_OK;
+            return bias_grad_impl(gy, gbias, d, stream, det ? reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + ws_bytes - bias_bytes) : nullptr);
+        }
     }
     WgradArgs a = {};
     a.Out = gw;
@@ -802,7 +845,21 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
         a.xcd_map = 1;
     }
     dim3 grid(tiles, ty, split);
-    if (ws && small) return BH_E_UNSUPPORTED;
+    if (ws && small && !det) return BH_E_UNSUPPORTED;
+    const long long numel = (long long)a.Np * a.sOp;                    // elements of gw
+    auto shadow_begin = [&]() -> int {                                  // the shapes without a partial-tile form
+        const long long need = numel * BH_ACC_WORDS * 8 + bias_bytes;
+        if (ws_need) { *ws_need = need; return 1; }
+        if (ws_bytes < need) return BH_E_BADARG;
+        if (!bh_query_ctx) {
+            const hipError_t e = hipMemsetAsync(ws, 0, (size_t)(numel * BH_ACC_WORDS * 8), s);
+            if (e != hipSuccess) return (int)e;
+        }
+        a.shadow = reinterpret_cast<double*>(ws);
+        return 0;
+    };
+    bool shadowed = false;
+    if (det && small) { const int r_ = shadow_begin(); if (r_ == 1) return BH_OK; if (r_) return r_; shadowed = true; }
     if (small && vec && !a.p_nchw && (a.T == 9 || a.T == 4) && d->precision != 1) {
         // taps-fused: one launch dimension less, pixel ranges sized for ~2048 wave-level work items
         const int groups_y = (a.T == 9) ? 3 : 2;        // 3 taps (T = 9) or 2 taps (T = 4) per wave: 48 / 32 accumulator regs
@@ -833,8 +890,8 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
         sp = (a.M + a.rows_per_block - 1) / a.rows_per_block;
         if (ws) {                           // deterministic mode: partial tiles + fixed-order second pass
             const long long need = (long long)sp * a.T * tiles * 4096 * 4;
-            if (ws_need) *ws_need = need;
-            if (!ws_need && ws_bytes < need) return BH_E_BADARG;
+            if (ws_need) *ws_need = need + bias_bytes;
+            if (!ws_need && ws_bytes < need + bias_bytes) return BH_E_BADARG;
             a.partials = ws;
         }
         if (bh_query(ws ? "wgrad_s1_kernel<%d,%s>+wgrad_s1_reduce_kernel" : "wgrad_s1_kernel<%d,%s>", nt, d->precision == 1 ? "true" : "false"))
@@ -849,15 +906,22 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
             hipLaunchKernelGGL(wgrad_s1_reduce_kernel, dim3((unsigned)((per_split + 255) / 256)), dim3(256), 0, s, ws, gw, sp, a.T, tiles,
                                a.Nq >> 6, a.sOp, a.sOt);
         }
-    } else if (ws) {
-        return BH_E_UNSUPPORTED;            // deterministic mode exists for the stride-1 fast path only
+    } else if (ws && !det) {
+        return BH_E_UNSUPPORTED;            // (outside deterministic mode the workspace form exists for the stride-1 fast path only)
     } else {
+        if (det) { const int r_ = shadow_begin(); if (r_ == 1) return BH_OK; if (r_) return r_; shadowed = true; }
         if (bh_query("wgrad_kernel<%s,%s>", vec ? "true" : "false", (vec && d->precision == 1) ? "true" : "false")) return BH_OK;
         if (vec && d->precision == 1) hipLaunchKernelGGL((wgrad_kernel<true, true>), grid, dim3(256), 0, s, a);
         else if (vec) hipLaunchKernelGGL((wgrad_kernel<true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((wgrad_kernel<false>), grid, dim3(256), 0, s, a);
     }
     BH_LAUNCH_CHECK();
-    if (gbias) return bh_conv_bias_grad(gy, gbias, d, stream);
+    if (shadowed) {
+        long long nb = (numel + 255) / 256;
+        if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(wgrad_shadow_finalize_kernel, dim3((unsigned)nb), dim3(256), 0, s, a.shadow, gw, numel);
+        BH_LAUNCH_CHECK();
+    }
+    if (gbias) return bias_grad_impl(gy, gbias, d, stream, det ? reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + ws_bytes - bias_bytes) : nullptr);
     return BH_OK;
 }

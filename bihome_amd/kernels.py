@@ -12,6 +12,17 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def set_deterministic(on=True):
+    """Library-wide deterministic mode (include/bihome.h bh_set_deterministic): every cross-workgroup sum becomes order-independent
+    - bit-identical training steps from run to run, and HIP-graph replays identical to eager steps.  Returns the previous setting.
+    (BIHOME_DETERMINISTIC=1 sets it at import.)  Must not change between the capture and the replays of a graph."""
+    return bool(lib.bh_set_deterministic(1 if on else 0))
+
+
+def deterministic():
+    return bool(lib.bh_get_deterministic())
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -577,13 +588,19 @@ def conv_wgrad(x, gy, gw, gbias, d, det_ws=None):
                                          ctypes.byref(bs), _stream()), "bh_conv_wgrad_bnin")
         return
     _chk(x); _chk(gy); _chk(gw); _chk(gbias)
+    det = deterministic()
+    if det and det_ws is None:
+        raise RuntimeError("deterministic mode: conv_wgrad needs a workspace (det_ws) - bh_conv_wgrad has only the atomic form")
     if det_ws is not None:
         need = wgrad_det_bytes(d)
+        if det and not (0 < need <= det_ws.numel() * 4):
+            raise RuntimeError("deterministic mode: workspace of %d bytes, %d needed" % (det_ws.numel() * 4, need))
         if 0 < need <= det_ws.numel() * 4:
             with _Timed((conv_variant(d, "wgrad_det") if TIMING is not None else ""), conv_flops(d), 4.0 * (x.numel() + gy.numel() + gw.numel())):
-                check(lib.bh_conv_wgrad_det(_p(x), _p(gy), _p(gw), None, ctypes.byref(d), _p(det_ws), det_ws.numel() * 4, _stream()),
-                      "bh_conv_wgrad_det")
-            if gbias is not None:
+                # (deterministic mode: the bias gradient rides in the same call - its limb entries are the tail of the workspace)
+                check(lib.bh_conv_wgrad_det(_p(x), _p(gy), _p(gw), _p(gbias) if det else None, ctypes.byref(d), _p(det_ws),
+                                            det_ws.numel() * 4, _stream()), "bh_conv_wgrad_det")
+            if gbias is not None and not det:
                 check(lib.bh_conv_bias_grad(_p(gy), _p(gbias), ctypes.byref(d), _stream()), "bh_conv_bias_grad")
             return
     with _Timed((conv_variant(d, "wgrad") if TIMING is not None else "") + (" N%d %dx%d C%d->%d k%d s%d%s" % (d.N, d.Hi, d.Wi, d.Ci, d.Co, d.kh, d.stride, " T" if d.transposed else "") if TIMING_DETAIL else ""), conv_flops(d), 4.0 * (x.numel() + gy.numel() + gw.numel())):

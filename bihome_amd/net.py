@@ -188,6 +188,8 @@ class Ctx:
 
 _GEOM_CACHE = {}
 X3_WS_BYTES = 40 << 20          # Runner.x3_workspace: partial blocks of the f32x3 weight gradient
+DET_WS_BYTES = 256 << 20        # deterministic mode: partial tiles / integer-limb shadow entries of ANY layer's weight gradient
+                                # (32 bytes per weight: 75.5 MB for a 512 x 512 x 3 x 3 layer)
 
 
 def _conv_geometry(mod, x_shape, in_nchw, out_nchw, precision=0):
@@ -378,7 +380,7 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, p
                 cd = _conv_geometry(cop.mod, src.shape, False, cop.extra["out_nchw"], precision)
                 # (the consumer's weight gradient must fit the fixed f32x3 workspace, else its backward could not take the
                 #  un-materialised operand: decided here, before the BatchNorm output is elided)
-                lazy = bool(cd.bh_packs and cd.bh_wx3 and 0 < cd.bh_wx3_bytes <= X3_WS_BYTES)
+                lazy = bool(cd.bh_packs and cd.bh_wx3 and 0 < cd.bh_wx3_bytes <= (DET_WS_BYTES if K.deterministic() else X3_WS_BYTES))
             if lazy:
                 st = arena[bn_off[i]:bn_off[i] + K.bn_stats_doubles(groups, m.num_features)]
                 table = K.bn_fwd_coeffs(st, m.weight, m.bias, m.running_mean, m.running_var, groups,
@@ -641,7 +643,8 @@ class NetFunction(torch.autograd.Function):
         if r.flat is not None:
             r.flat.attach(g.device)
         hook = r.reducer.param_ready if r.reducer is not None else None
-        side = side_stream(g.device) if (r.wgrad_on_side_stream and r.flat is not None) else None
+        # (deterministic mode: one stream - the weight-gradient launches share one workspace)
+        side = side_stream(g.device) if (r.wgrad_on_side_stream and r.flat is not None and not K.deterministic()) else None
         if r.reducer is not None:
             r.reducer.wait_streams = [side] if side is not None else []
         gin = run_backward(r.prog, ctx.saved, g.contiguous(), want_wgrad=r.flat is not None, want_input_grad=ctx.want_x,
@@ -697,15 +700,19 @@ class Runner:
     def det_workspace(self, device):
         """BIHOME_DETERMINISTIC_WGRAD=1: one 40 MB workspace for the fixed-order split-K reduction of the 3x3 weight
         gradients (every launch of the stride-1 fast path stores 2048 x 16 KB partial tiles)."""
-        if not self.deterministic_wgrad or self.flat is None:
+        det = K.deterministic()
+        if not (self.deterministic_wgrad or det) or self.flat is None:
             return None
-        if self._det_ws is None or self._det_ws.device != device:
-            self._det_ws = torch.empty(10 << 20, dtype=torch.float32, device=device)
+        size = DET_WS_BYTES if det else X3_WS_BYTES
+        if self._det_ws is None or self._det_ws.device != device or self._det_ws.numel() * 4 < size:
+            self._det_ws = torch.empty(size // 4, dtype=torch.float32, device=device)
         return self._det_ws
 
     def x3_workspace(self, device):
         """'f32' arithmetic (precision 2): the 40 MB workspace the f32x3 weight-gradient kernel stores its <= 256 partial blocks
         of 147 KB in (wgrad_x3_reduce_kernel adds them in split order: those layers' gradients are bitwise reproducible)."""
+        if K.deterministic():
+            return self.det_workspace(device)
         if self.precision not in K.SPLIT_PIECES or self.flat is None:
             return None
         if self._det_ws is None or self._det_ws.device != device:

@@ -32,6 +32,22 @@ extern "C" {
 int bh_version(void);
 int bh_device_arch(char* buf, int buflen);
 
+/* Deterministic mode (round 3; what torch.use_deterministic_algorithms is to the reference's ATen path, train.py:379-387).
+ * By default cross-workgroup sums use hardware floating-point atomics, whose rounding depends on arrival order: two runs of the
+ * same step differ in the last bits.  bh_set_deterministic(1) (process-wide, returns the previous setting; read at launch time,
+ * so it must not change between the capture and the replays of a HIP graph) makes every launch of this library order-independent:
+ *   - BatchNorm statistics / backward sums / bias column sums accumulated in conv epilogues: exact integer-limb accumulation inside
+ *     the padded sums entries (csrc/common.h bh_det_add; the readers understand both encodings);
+ *   - weight and bias gradients: bh_conv_wgrad_det with a workspace of bh_conv_wgrad_det_bytes(d) - partial tiles added in split
+ *     order (f32x3 / stride-1 kernels) or integer-limb shadow entries (every other shape).  bh_conv_wgrad / bh_conv_bias_grad have
+ *     no workspace and stay atomic;
+ *   - warp adjoint, triplet / one-line reductions, score weighting, the tail's bias gradient: one workgroup per sample / channel;
+ *   - DLT adjoint: duplicates of a sample's indices are added in point order inside the wave, hypotheses in launch order;
+ *   - not covered: the pooled coverage of bh_warp_fwd with pool = 32 (four quarter-window atomics per window).
+ * Same arithmetic otherwise: results differ from the default mode only by the order of additions. */
+int bh_set_deterministic(int on);
+int bh_get_deterministic(void);
+
 /* ---------------------------------------------------------------------------------------------
  * Geometry (per-sample small dense algebra, double precision inside)
  * ------------------------------------------------------------------------------------------- */
@@ -270,6 +286,8 @@ int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, cons
  * With precision 2 (f32x3: 3x3 layers, H and W multiples of 8, channels multiples of 64) this is the FAST form - the kernel
  * keeps one 64 x 9 x 64 block per workgroup and storing + reducing <= 256 of them costs less than the atomics tail.
  * BH_E_UNSUPPORTED for other shapes (use bh_conv_wgrad). */
+/* In deterministic mode (bh_set_deterministic) every shape has a workspace form (bh_conv_wgrad_det_bytes > 0) and gbias, when given,
+ * is accumulated deterministically as well (its entries are the last Co * 32 bytes of the workspace). */
 long long bh_conv_wgrad_det_bytes(const bh_conv_desc* d);
 int bh_conv_wgrad_det(const float* x, const float* gy, float* gw, float* gbias, const bh_conv_desc* d, float* ws, long long ws_bytes,
                       void* stream);
