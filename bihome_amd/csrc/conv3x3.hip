@@ -107,7 +107,7 @@ constexpr int C3_LDS_BYTES = 2 * C3_HALO_BYTES + 2 * C3_B_BYTES;      // 67584
 // ---- epilogue of one wave's accumulators: C/D layout col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m) ----
 // (shared by the halo kernels: the wave that holds - or was handed - the accumulators of tile position bx calls it with that
 //  wave's (wm, wn, wh) roles.  s1 / s2 return the tile's column sums for c3_stats_merge.)
-template <int BN, int SUBT, int TM>
+template <int BN, int SUBT, int TM, bool MAP4 = false>
 __device__ __forceinline__ void c3_epilogue(const C3Args& a, f32x16 (&acc)[TM], int bx, int n0, int wm, int wn, int wh, int l31, int kh2,
                                             double& s1, double& s2, int& img, int& g) {
     // ---- epilogue: C/D layout col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m) ----
@@ -119,7 +119,8 @@ __device__ __forceinline__ void c3_epilogue(const C3Args& a, f32x16 (&acc)[TM], 
     const bool valid = g < a.subtiles && n < a.Nn;
     const int gg = g < a.subtiles ? g : 0;
     int ty, tx;
-    if (a.tpi_shift >= 0) { img = gg >> a.tpi_shift; const int t = gg & (a.tiles_per_img - 1); ty = t >> a.tx_shift; tx = t & (a.tiles_x - 1); }
+    if constexpr (MAP4) { img = gg * 4; ty = 0; tx = 0; }       // a sub-tile = four 4x4 images (first image: the statistics group)
+    else if (a.tpi_shift >= 0) { img = gg >> a.tpi_shift; const int t = gg & (a.tiles_per_img - 1); ty = t >> a.tx_shift; tx = t & (a.tiles_x - 1); }
     else { img = gg / a.tiles_per_img; const int t = gg - img * a.tiles_per_img; ty = t / a.tiles_x; tx = t - ty * a.tiles_x; }
     const float bv = (a.bias && n < a.Nn) ? a.bias[n] : 0.0f;
     s1 = 0.0; s2 = 0.0;                            // BatchNorm statistics of the tile (a.bn_sums): sum y, sum y^2
@@ -138,10 +139,15 @@ __device__ __forceinline__ void c3_epilogue(const C3Args& a, f32x16 (&acc)[TM], 
     if (valid) {
         unsigned rowoff[4];                          // byte offsets (< 2^31: the host checks the tensor sizes)
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq)
-            rowoff[rq] = ((unsigned)((img * a.H + ty * 8 + c3_strip_row(2 * rq + kh2)) * a.W + tx * 8) * (unsigned)a.Nn + (unsigned)n) * 4u;
+        for (int rq = 0; rq < 4; ++rq) {
+            const int sr = c3_strip_row(2 * rq + kh2);
+            if constexpr (MAP4)      // strip row sr of the wave's 8x4 strip = row sr & 3 of image 2 wh + (sr >> 2) of the sub-tile
+                rowoff[rq] = ((unsigned)((img + 2 * wh + (sr >> 2)) * 16 + (sr & 3) * 4) * (unsigned)a.Nn + (unsigned)n) * 4u;
+            else
+                rowoff[rq] = ((unsigned)((img * a.H + ty * 8 + sr) * a.W + tx * 8) * (unsigned)a.Nn + (unsigned)n) * 4u;
+        }
         const unsigned colstep = (unsigned)a.Nn * 4u;                                   // one pixel to the right
-        const unsigned col0 = (unsigned)(wh * 4) * colstep;
+        const unsigned col0 = MAP4 ? 0u : (unsigned)(wh * 4) * colstep;
         const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(a.Out, 0, a.out_bytes, 0x00020000);
 #define C3_SOFF(i, r) (col0 + (unsigned)((i) * 4 + ((r) & 3)) * colstep)
         if (!a.accumulate && !a.res && !a.bnr_z) {
@@ -297,14 +303,20 @@ __device__ __forceinline__ void c3_stats_merge(const C3Args& a, char* redb, doub
 // 6 ds_read_b128 and 12 MFMAs of 32 cycles (fp32 form: 4 reads, 16 MFMAs of 64 cycles).
 // NP (X3 only): bf16 pieces per operand.  3: the exact cut, six products ("f32x3", precision 2).  2: both pieces rounded to nearest,
 // three products ("f32x2", precision 3: common.h bh_split8_2) - 8 instead of 12 plane images, 4 instead of 6 weight loads per tap.
-template <bool FLIP, int BN, bool BF16 = false, int SUBT = 2, bool PACKED = false, bool X3 = false, bool BNI = false, int NP = 3>
+// MAP4 (X3, SUBT = 1, BN = 64 only; round 3): 4 x 4 feature maps (the 512-channel layer4 of the ResNet-34 regressor) - a "sub-tile" of 64
+// GEMM rows is FOUR IMAGES, each with its own 6 x 6 zero-padded halo (144 halo slots instead of 100); a wave's 8 x 4 pixel strip is the
+// two images 2 wh, 2 wh + 1, a tap is the shift dy * 6 + dx.  Same loop, same fragment reads.
+template <bool FLIP, int BN, bool BF16 = false, int SUBT = 2, bool PACKED = false, bool X3 = false, bool BNI = false, int NP = 3, bool MAP4 = false>
 __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a) {
     static_assert(NP == 3 || (NP == 2 && X3), "two pieces: split form only");
+    static_assert(!MAP4 || (X3 && SUBT == 1 && BN == 64 && !BNI), "the 4 x 4 map form: split operands, one sub-tile, 64-channel tile");
+    constexpr int SLOTS = MAP4 ? 144 : 100;                // halo slots of a sub-tile per k-plane
+    constexpr int ROWP = MAP4 ? 6 : 10;                    // halo row pitch
     static_assert(SUBT == 2 || BN == 64, "one sub-tile per workgroup is built for the 64-channel tile only");
     static_assert(!X3 || (PACKED && !BF16), "the split form exists for packed weights only");
     static_assert(!BNI || (X3 && !FLIP), "the BatchNorm-on-load form is a forward f32x3 kernel");
     constexpr int TM = (BN == 64 && SUBT == 2) ? 2 : 1;
-    constexpr int HPL = 100 * SUBT;                        // halo slots per k-plane
+    constexpr int HPL = SLOTS * SUBT;                      // halo slots per k-plane
     constexpr int HALO_B = (X3 ? 4 * NP : 8) * HPL * 16;   // bytes of one halo stage
     constexpr int XJ = (4 * HPL + 255) / 256;              // X3: halo slots (of 8 channels) per thread and chunk (4 / 2)
     constexpr int HINS = (8 * HPL + 63) / 64;              // wave instructions per halo stage (25 / 13)
@@ -417,10 +429,11 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
     for (int s = 0; s < SUBT; ++s) {
         const int g = bx * SUBT + s;
         int img, ty, tx;
-        if (a.tpi_shift >= 0) { img = g >> a.tpi_shift; const int t = g & (a.tiles_per_img - 1); ty = t >> a.tx_shift; tx = t & (a.tiles_x - 1); }
+        if constexpr (MAP4) { img = g * 4; ty = 0; tx = 0; }
+        else if (a.tpi_shift >= 0) { img = g >> a.tpi_shift; const int t = g & (a.tiles_per_img - 1); ty = t >> a.tx_shift; tx = t & (a.tiles_x - 1); }
         else { img = g / a.tiles_per_img; const int t = g - img * a.tiles_per_img; ty = t / a.tiles_x; tx = t - ty * a.tiles_x; }
         oy0[s] = ty * 8 - 1; ox0[s] = tx * 8 - 1;
-        org[s] = g < a.subtiles ? (img * a.H + oy0[s]) * a.W + ox0[s] : (int)0x80000000;
+        org[s] = g < a.subtiles ? (MAP4 ? img * 16 : (img * a.H + oy0[s]) * a.W + ox0[s]) : (int)0x80000000;
         if constexpr (BNI) bni_grp[s] = g < a.subtiles ? img / a.bni_ipg : 0;
     }
     f32x16 acc[TM];
@@ -443,6 +456,14 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
             const int q = j * 256 + tid;
             unsigned off = XOOB;
             xtb[j] = 0;
+            if constexpr (MAP4) {
+                if (q < 4 * HPL) {
+                    const int plane = q / 144, hp = q - plane * 144;                        // slot = (plane, image of the sub-tile, 6 x 6 halo position)
+                    const int im = hp / 36, r = hp - im * 36, hy = r / 6, hx = r - hy * 6;
+                    if (org[0] != (int)0x80000000 && (unsigned)(hy - 1) < 4u && (unsigned)(hx - 1) < 4u)
+                        off = ((unsigned)(org[0] + im * 16 + (hy - 1) * 4 + (hx - 1)) * (unsigned)a.Kc + (unsigned)(plane * 8)) * 4u;
+                }
+            } else
             if (q < 4 * HPL) {
                 const int plane = SUBT == 2 ? (q * 5243) >> 20 : (q * 10486) >> 20;      // q / 200, q / 100
                 const int rem = q - plane * HPL;
@@ -500,7 +521,9 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
 #pragma unroll
             for (int j = 0; j < XJ; ++j) X3_STORE(j, 0, 0, hp[j]);
         }
-        const int a_lane = (kh2 * HPL + wm * 100 + c3_strip_row(l31 >> 2) * 10 + wh * 4 + (l31 & 3)) * 16;
+        const int sr_ = c3_strip_row(l31 >> 2);
+        const int a_lane = MAP4 ? (kh2 * HPL + (2 * wh + (sr_ >> 2)) * 36 + (sr_ & 3) * 6 + (l31 & 3)) * 16
+                                : (kh2 * HPL + wm * 100 + sr_ * 10 + wh * 4 + (l31 & 3)) * 16;
         __syncthreads();
         C3_STAMP(bx * gridDim.y + blockIdx.y, 1);
         float4 hb[2][2];
@@ -546,7 +569,7 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
             const char* const hbase = smem + hs * HALO_B + a_lane;
             if constexpr (tap < 8) C3_LOAD_BX(bn, c, tap + 1);
             else if (more) C3_LOAD_BX(bn, c + 1, 0);
-            X3_LOAD_A_HALF(af, hbase + (dy * 10 + dx) * 16, 1);
+            X3_LOAD_A_HALF(af, hbase + (dy * ROWP + dx) * 16, 1);
             if (more) {
                 if constexpr (tap >= 2 && tap - 2 < XJ) X3_STORE(tap - 2, hs ^ 1, c + 1, hb[(tap - 2) & 1]);
                 if constexpr (tap < XJ) X3_ISSUE(tap, c + 1, hb[tap & 1]);
@@ -554,7 +577,7 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
             __builtin_amdgcn_sched_barrier(0);         // requests first: nothing of the above sinks into the MFMA block
             X3_MFMA_HALF(af, bc, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (tap < 8) X3_LOAD_A_HALF(af, hbase + (dy1 * 10 + dx1) * 16, 0);
+            if constexpr (tap < 8) X3_LOAD_A_HALF(af, hbase + (dy1 * ROWP + dx1) * 16, 0);
             else {
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 if (more) X3_LOAD_A_HALF(af, smem + (hs ^ 1) * HALO_B + a_lane, 0);
@@ -591,7 +614,7 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int dy = tap / 3, dx = tap - dy * 3;
-                const char* ap = hbase + (dy * 10 + dx) * 16;
+                const char* ap = hbase + (dy * ROWP + dx) * 16;
                 if (!(dbg_noload & 4) || (tap == 0 && c == 0)) X3_LOAD_A(af, ap);
                 if (!(dbg_noload & 1)) {
                 if (tap < 8) C3_LOAD_BX(bnext, c, tap + 1);
@@ -775,7 +798,7 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
     C3_STAMP(bx * gridDim.y + blockIdx.y, 2);
     double s1, s2;
     int img, g;
-    c3_epilogue<BN, SUBT, TM>(a, acc, bx, n0, wm, wn, wh, l31, kh2, s1, s2, img, g);
+    c3_epilogue<BN, SUBT, TM, MAP4>(a, acc, bx, n0, wm, wn, wh, l31, kh2, s1, s2, img, g);
     if (a.bn_sums) c3_stats_merge<BN, 0>(a, smem, s1, s2, img, g, bx, n0, wave, lane, tid);
 #ifdef BH_TUNING
     if (a.dbg_ts) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (stores of the tile have left the wave)
@@ -814,7 +837,10 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
         return d->w_layout ? BH_E_UNSUPPORTED : 0;
     // split weights <-> their precision: w_layout 2 = three pieces (precision 2), w_layout 3 = two pieces (precision 3)
     if (d->w_layout != 0 && ((d->w_layout == 2) != (d->precision == 2) || (d->w_layout == 3) != (d->precision == 3))) return BH_E_BADARG;
-    if (d->Hi % 8 || d->Wi % 8 || d->Ho != d->Hi || d->Wo != d->Wi) return d->w_layout ? BH_E_UNSUPPORTED : 0;
+    // 4 x 4 maps (round 3: layer4 of the ResNet-34 regressor): split-operand form only, four images per sub-tile
+    const bool map4 = d->Hi == 4 && d->Wi == 4 && d->Ho == 4 && d->Wo == 4 && d->N % 4 == 0 && (d->w_layout == 2 || d->w_layout == 3) &&
+                      d->Co % 64 == 0 && d->Ci % 64 == 0 && !bni && (!bn_sums || (groups >= 1 && d->N % groups == 0 && (d->N / groups) % 4 == 0));
+    if (!map4 && (d->Hi % 8 || d->Wi % 8 || d->Ho != d->Hi || d->Wo != d->Wi)) return d->w_layout ? BH_E_UNSUPPORTED : 0;
     const int Kc = dgrad ? d->Co : d->Ci, Nn = dgrad ? d->Ci : d->Co;
     if (Kc % 32 || Nn % 32) return d->w_layout ? BH_E_UNSUPPORTED : 0;
     const int bn_tile = (Nn % 64) ? 32 : 64;
@@ -841,6 +867,7 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
     a.res = res; a.relu = relu; a.dbg_nch = g_c3_dbg_nch;
     a.bn_sums = bn_sums; a.imgs_per_group = bn_sums ? d->N / groups : 1; a.groups = groups;
     a.tiles_x = d->Wi / 8; a.tiles_per_img = (d->Hi / 8) * a.tiles_x; a.subtiles = d->N * a.tiles_per_img;
+    if (map4) { a.tiles_x = 1; a.tiles_per_img = 1; a.subtiles = d->N / 4; }
     a.tx_shift = a.tpi_shift = -1;
     for (int b = 0; b < 24; ++b) {
         if (a.tiles_x == (1 << b)) a.tx_shift = b;
@@ -850,7 +877,7 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
     // one sub-tile per workgroup where two would leave half of the 512 workgroup slots empty (the 8x8x256-channel layers:
     // +6 %); elsewhere the 128-row tile is as fast or faster (measured, tools/conv3x3_check.py --subt1)
     const bool few = (long long)((a.subtiles + 1) / 2) * (Nn / bn_tile) <= 256;
-    const int subt = (bn_tile == 64 && (g_c3_subt == 1 || (d->route & BH_ROUTE_C3_ONE_SUBTILE) || (g_c3_subt == 2 && few))) ? 1 : 2;
+    const int subt = map4 ? 1 : (bn_tile == 64 && (g_c3_subt == 1 || (d->route & BH_ROUTE_C3_ONE_SUBTILE) || (g_c3_subt == 2 && few))) ? 1 : 2;
     dim3 grid((a.subtiles + subt - 1) / subt, Nn / bn_tile);
     a.gx_total = (int)grid.x; a.tpb = 1;
     {   // exactly-two-rounds launches (two resident workgroups per CU with two sub-tiles, 512 slots): one round of two tiles
@@ -859,15 +886,17 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
             a.tpb = 2; grid.x = (grid.x + 1) / 2;
         }
     }
-    if (!(d->route & BH_ROUTE_HALO_SMALL) && (int)(((a.subtiles + 1) / 2) * grid.y) < C3_MIN_BLOCKS) return d->w_layout ? BH_E_UNSUPPORTED : 0;
+    if (!(d->route & BH_ROUTE_HALO_SMALL) && (int)((map4 ? a.subtiles : (a.subtiles + 1) / 2) * grid.y) < (map4 ? C3_MIN_BLOCKS / 2 : C3_MIN_BLOCKS))
+        return d->w_layout ? BH_E_UNSUPPORTED : 0;
     a.NW = Nn / 32;
     if (bni) {      // BatchNorm-on-load: the f32x3 forward only, table of <= 4 KB (two groups x 256 channels) in LDS
         if (!x3 || dgrad || !bni->table || bni->groups < 1 || d->N % bni->groups || (long long)bni->groups * Kc * 8 > 4096) return BH_E_UNSUPPORTED;
         a.bni = bni->table; a.bni_relu = bni->relu; a.bni_groups = bni->groups; a.bni_ipg = d->N / bni->groups;
     }
     // (all eight template arguments, as rocprofv3 prints the symbol: FLIP, BN, BF16, SUBT, PACKED, X3, BNI, NP)
-    if (bh_query("conv3x3_halo_kernel<%s,%d,%s,%d,%s,%s,%s,%d>", dgrad ? "true" : "false", bn_tile, bf16 ? "true" : "false", subt,
-                 packed ? "true" : "false", x3 ? "true" : "false", bni ? "true" : "false", np)) {
+    // (the 4 x 4 map form prints its ninth template argument; every other instantiation has it defaulted to false)
+    if (bh_query(map4 ? "conv3x3_halo_kernel<%s,%d,%s,%d,%s,%s,%s,%d,true>" : "conv3x3_halo_kernel<%s,%d,%s,%d,%s,%s,%s,%d>", dgrad ? "true" : "false",
+                 bn_tile, bf16 ? "true" : "false", subt, packed ? "true" : "false", x3 ? "true" : "false", bni ? "true" : "false", np)) {
         *taken = 1;
         return BH_OK;
     }
@@ -884,13 +913,19 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
                      conv3x3_halo_kernel<false, 64, false, 1, true, true, false, NP_>, conv3x3_halo_kernel<true, 64, false, 1, true, true, false, NP_>,  \
                      conv3x3_halo_kernel<false, 64, false, 2, true, true, true, NP_>, conv3x3_halo_kernel<false, 32, false, 2, true, true, true, NP_>,   \
                      conv3x3_halo_kernel<false, 64, false, 1, true, true, true, NP_>
-    static const kern_t fns[42] = {C3_ROW(false), C3_ROW(true), C3_XROW(3), C3_XROW(2)};
+    static const kern_t fns[46] = {C3_ROW(false), C3_ROW(true), C3_XROW(3), C3_XROW(2),
+                                   conv3x3_halo_kernel<false, 64, false, 1, true, true, false, 3, true>, conv3x3_halo_kernel<true, 64, false, 1, true, true, false, 3, true>,
+                                   conv3x3_halo_kernel<false, 64, false, 1, true, true, false, 2, true>, conv3x3_halo_kernel<true, 64, false, 1, true, true, false, 2, true>};
 #undef C3_XROW
 #undef C3_ROW
     constexpr int HALO2 = 8 * 200 * 16, HALO1 = 8 * 100 * 16;          // one halo stage: two / one sub-tile per workgroup
     constexpr int LDS1 = 2 * HALO1 + 2 * C3_B_BYTES;                   // one sub-tile per workgroup: 41,984 B
     const int XHALO2 = 4 * np * 200 * 16, XHALO1 = 4 * np * 100 * 16;  // split form: 12 / 8 plane images per stage
     if (bh_device_once(attr_devs)) {
+        for (int i = 42; i < 46; ++i) {          // 4 x 4 map form: 144 halo slots, 12 / 8 plane images, two stages
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[i]), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (i < 44 ? 12 : 8) * 144 * 16);
+            if (e != hipSuccess) return (int)e;
+        }
         for (int i = 0; i < 42; ++i) {
             const int j = i % 12;
             const int xi = i >= 24 ? (i - 24) % 9 : 0, xh2 = (i >= 33 ? 8 : 12) * 200 * 16, xh1 = xh2 / 2;       // split rows: 0-5 plain, 6-8 BNI
@@ -901,11 +936,11 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
         }
     }
     const int xrow = 24 + (np == 2 ? 9 : 0);
-    const kern_t fn = bni ? fns[xrow + 6 + (subt == 1 ? 2 : bn_tile == 64 ? 0 : 1)] : x3 ? fns[xrow + (subt == 1 ? 4 : bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0)]
+    const kern_t fn = map4 ? fns[42 + (np == 2 ? 2 : 0) + (dgrad ? 1 : 0)] : bni ? fns[xrow + 6 + (subt == 1 ? 2 : bn_tile == 64 ? 0 : 1)] : x3 ? fns[xrow + (subt == 1 ? 4 : bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0)]
                          : fns[(packed ? 12 : 0) + (subt == 1 ? 8 + (bf16 ? 2 : 0) + (dgrad ? 1 : 0)
                                                               : (bf16 ? 4 : 0) + (bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0))];
     a.dbg_noload = g_c3_noload; a.dbg_ts = g_c3_stamp; a.det = bh_deterministic() ? 1 : 0;
-    const int stage = x3 ? (subt == 1 ? XHALO1 : XHALO2) : subt == 1 ? HALO1 : HALO2;
+    const int stage = map4 ? 4 * np * 144 * 16 : x3 ? (subt == 1 ? XHALO1 : XHALO2) : subt == 1 ? HALO1 : HALO2;
     const int lds = packed ? (Kc / 32 > 1 ? 2 : 1) * stage                                    // halo stages only
                            : (subt == 1 ? LDS1 : C3_LDS_BYTES) - (Kc / 32 > 1 ? 0 : stage);   // single chunk: one halo stage
     if (bni) a.bni_lds = lds;

@@ -346,7 +346,12 @@ def _with_layout(d, w_layout):
 def packs_3x3(d):
     """True when the halo-tiled 3x3 kernel takes both the forward and the dgrad of this conv (then the fragment-ordered
     weight copies of bh_conv3x3_pack can be used for it)."""
-    return (conv_variant(d, "fwd").startswith("conv3x3_halo_kernel") and conv_variant(d, "dgrad").startswith("conv3x3_halo_kernel"))
+    # (asked with the layout the packed copies would have: the 4 x 4 map form of the halo kernel exists for split operands only)
+    q = _with_layout(d, packed_layout(d.precision)) if (d.w_layout == 0 and int(d.precision) in SPLIT_PIECES) else d
+    try:
+        return (conv_variant(q, "fwd").startswith("conv3x3_halo_kernel") and conv_variant(q, "dgrad").startswith("conv3x3_halo_kernel"))
+    except Exception:
+        return False
 
 
 class WeightPacker:

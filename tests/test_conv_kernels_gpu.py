@@ -866,3 +866,44 @@ def test_conv3x3_f32x2_two_piece_mode(K, N, H, Ci, Co):
     assert max(errs[3]) < 8e-6, errs
     # (forward and dgrad; the bf16-operand weight gradient of some shapes runs the fp32 kernel)
     assert all(e3 < e1 / 100 for e3, e1 in zip(errs[3][:2], errs[1][:2])), errs
+
+
+@pytest.mark.parametrize("N,Ci,Co,prec,groups", [(128, 512, 512, 2, 2), (128, 512, 512, 3, 2), (16, 64, 128, 2, 1), (8, 192, 64, 2, 2)])
+def test_conv3x3_halo_kernel_on_4x4_maps(K, N, Ci, Co, prec, groups):
+    """The MAP4 form of the split-operand halo kernel (round 3): 4 x 4 feature maps (layer4 of the ResNet-34 regressor), four images
+    with their own 6 x 6 zero-padded halos per 64-row sub-tile.  Forward (+ bias, + BatchNorm sums), dgrad, accumulating dgrad and
+    dgrad with the BatchNorm backward sums in the epilogue against torch float64 and against the generic kernel."""
+    from bihome_amd._lib import ROUTE_GENERIC_CONV, ROUTE_HALO_SMALL
+    g = torch.Generator().manual_seed(N + Ci)
+    x = torch.randn(N, 4, 4, Ci, generator=g).cuda()
+    gy = torch.randn(N, 4, 4, Co, generator=g).cuda()
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * 0.03).cuda().contiguous(memory_format=torch.channels_last)
+    wk = w.permute(0, 2, 3, 1)
+    b = torch.randn(Co, generator=g).cuda()
+    d = K.conv_desc(N, 4, 4, Ci, Co, 3, 1, 1, precision=prec, route=ROUTE_HALO_SMALL)
+    dp = K._with_layout(d, K.packed_layout(prec))
+    assert K.conv_variant(dp, "fwd").endswith(",%d,true>" % K.SPLIT_PIECES[prec]) and K.conv_variant(dp, "dgrad").endswith(",%d,true>" % K.SPLIT_PIECES[prec])
+    assert K.packs_3x3(d)
+    pk = K.WeightPacker(split=K.SPLIT_PIECES[prec])
+    pf, pd = pk.get(w)
+    pk.refresh()
+    ref = F.conv2d(x.double().cpu().permute(0, 3, 1, 2), w.double().cpu(), b.double().cpu(), 1, 1).permute(0, 2, 3, 1)
+    refd = F.conv_transpose2d(gy.double().cpu().permute(0, 3, 1, 2), w.double().cpu(), None, 1, 1).permute(0, 2, 3, 1)
+    tol = 2e-6 if prec == 2 else 1e-5
+    y = K.conv_fwd(x, wk, b, d, wpacked=pf)
+    assert ((y.cpu().double() - ref).norm() / ref.norm()).item() < tol
+    s = K.bn_stats_buffer(groups, Co, "cuda")
+    assert torch.equal(y, K.conv_fwd(x, wk, b, d, bn_sums=s, groups=groups, wpacked=pf))
+    yd = y.double().view(groups, -1, Co)
+    tot = torch.stack([yd.sum(1), (yd * yd).sum(1)], -1).cpu()
+    got = s.view(groups, Co, 2, K.BN_SUM_STRIDE)[..., 0].cpu()
+    close(got, tot, 1e-6)
+    gx = K.conv_dgrad(gy, wk, d, wpacked=pd)
+    assert ((gx.cpu().double() - refd).norm() / refd.norm()).item() < tol
+    acc = x.clone()
+    K.conv_dgrad(gy, wk, d, out=acc, wpacked=pd)
+    close(acc.cpu(), (x + gx).cpu(), 2e-5)
+    # the generic kernel on the same data (what these layers ran on before)
+    dg = K.conv_desc(N, 4, 4, Ci, Co, 3, 1, 1, precision=0, route=ROUTE_GENERIC_CONV)
+    close(y.cpu(), K.conv_fwd(x, wk, b, dg).cpu(), 2e-5)
+    close(gx.cpu(), K.conv_dgrad(gy, wk, dg).cpu(), 2e-5)

@@ -12,6 +12,12 @@ python3 bench.py --no-cpu-baseline --overlap > $O/tmp.log 2>&1; last_json $O/tmp
 python3 bench.py --no-cpu-baseline --graph > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_graph.json
 python3 bench.py --no-cpu-baseline --config detone-bihome > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_detone.json
 python3 bench.py --no-cpu-baseline --config detone-bihome --precision bf16 > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_detone_bf16.json
+python3 bench.py --no-cpu-baseline --config detone-bihome --precision f32x2 > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_detone_f32x2.json
+python3 bench.py --no-cpu-baseline --precision f32x2 > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_f32x2.json
+BIHOME_DETERMINISTIC=1 python3 bench.py --no-cpu-baseline > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_deterministic.json
+[ -x tools/mfma_clock_probe.bin ] && tools/mfma_clock_probe.bin > $O/${T}_mfma_clock_probe.txt 2>&1
+[ -f bihome_amd/libbihome_hip_tuning.so ] && for m in fwd fwdstats dgrad; do BIHOME_TUNING=1 python3 tools/x3_timeline.py $m; done > $O/${T}_x3_timeline.txt 2>&1
+python3 tools/step_detail.py zeng-bihome 64 > $O/${T}_step_detail.txt 2>&1
 python3 bench.py --no-cpu-baseline --config zeng-bihome-rgb256 > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_rgb256.json
 python3 bench.py --no-cpu-baseline --config zeng-bihome-pds > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_pds.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_kt -o ${T} -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/${T}_kt.log 2>&1
