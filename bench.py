@@ -405,6 +405,11 @@ def main():
                      "note": "predict_homography in eval mode (BatchNorm folded), held-out synthetic pairs, random-init "
                              "weights after the timed steps"},
             "roofline": roof, "cpu_baseline": cpu,
+            # (compact copy of roofline.warp_perceptual_path: BASELINE.json's HBM-bound part - homography warp + perceptual L1 / triplet -
+            #  as a fraction of the 8 TB/s HBM peak, by raw event pairs and net of the cost of an empty event pair)
+            "hbm_path_frac": ({"raw": roof["warp_perceptual_path"]["frac_of_hbm_peak"],
+                               "net_of_event_pairs": roof["warp_perceptual_path"]["frac_of_hbm_peak_net_of_event_pairs"]}
+                              if roof and roof.get("warp_perceptual_path") else None),
         }
         if rows:
             out["kernel_breakdown"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()
