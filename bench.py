@@ -216,6 +216,8 @@ WORKLOADS = {
     "zeng-bihome-pds": "BASELINE.json configs[2]: pds-coco Zeng (photometric-distorted)",
     "detone-bihome": "BASELINE.json configs[3]: s-coco ResNet-34 regressor",
     "zeng-bihome-rgb256": "BASELINE.json configs[4]: 256x256 RGB Zeng (build-side extension)",
+    "zhang-orig": "config/s-coco/zhang-orig (Zhang content-aware baseline: ContentAware backbone + TripletHead)",
+    "zhang-bihome": "config/s-coco/zhang-bihome (ContentAware backbone under the biHomE PerceptualHead)",
 }
 
 

@@ -62,6 +62,8 @@ SIGNATURES = {
     "bh_bihome_loss_bwd": [P] * 14 + [c_int, c_int, c_int, c_float] + [P] * 6 + [P],
     "bh_oneline_loss_fwd": [P, P, P, P, P, c_int, c_int, c_int, c_float, c_int, P, P, P, P, P, P],
     "bh_oneline_loss_bwd": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P],
+    "bh_zhang_triplet_fwd": [P] * 8 + [c_int, c_int, c_float, c_int, P, P, P, P],
+    "bh_zhang_triplet_bwd": [P] * 12 + [c_int, c_int, c_int] + [P] * 6 + [P],
     "bh_conv3x3_pack": [P, c_int, P],
     "bh_conv_variant": [POINTER(BhConvDesc), c_int, c_int, c_int, c_char_p, c_int],
     "bh_conv_fwd": [P, P, P, P, POINTER(BhConvDesc), P],

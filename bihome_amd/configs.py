@@ -85,6 +85,31 @@ DETONE_ORIG = {
 }
 
 
+# Zhang et al. "Content-Aware" baselines (config/s-coco/zhang-orig-lr-1e-2.yaml: ContentAware backbone + TripletHead;
+# zhang-bihome-lr-1e-2.yaml: the same backbone under the biHomE PerceptualHead with directly regressed offsets)
+ZHANG_ORIG = {
+    "MODEL": {
+        "BACKBONE": {
+            "NAME": "ContentAware", "VARIANT": "DoubleLine", "IMAGE_SIZE": 128, "PRETRAINED_RESNET": False,      # reference: True
+            "IMAGE_KEY": ["image"], "PATCH_KEYS": ["patch_1", "patch_2"], "MASK_KEYS": ["mask_1", "mask_2"], "FIX_MASK": True,
+            "FEATURE_KEYS": ["feature_1", "feature_2"], "TARGET_KEYS": ["delta_hat_12", "delta_hat_21"],
+        },
+        "HEAD": {
+            "NAME": "TripletHead", "VARIANT": "DoubleLine", "PATCH_SIZE": 128, "PATCH_KEYS": ["patch_1", "patch_2"],
+            "MASK_KEYS": ["mask_1", "mask_2"], "FEATURE_KEYS": ["feature_1", "feature_2"],
+            "TARGET_KEYS": ["delta_hat_12", "delta_hat_21"], "LD": 2, "MU": 0.01, "TRIPLET_MARGIN": 1.0,
+            "TRIPLET_AGGREGATION": "channel-agnostic",
+        },
+    },
+    "SOLVER": {"OPTIMIZER": "Adam", "MOMENTUM_1": 0.9, "MOMENTUM_2": 0.999, "LR": 0.01,
+               "MILESTONES": [30000, 60000, 90000], "LR_DECAY": 0.1, "LOSS": "TripletLoss"},
+    "DATA": {"BATCH_SIZE": 64, "RHO": 32, "PATCH_SIZE": 128, "PHOTOMETRIC_MAX_DELTA": 0},
+}
+ZHANG_BIHOME = copy.deepcopy(ZHANG_ORIG)
+ZHANG_BIHOME["MODEL"]["HEAD"] = copy.deepcopy(DETONE_BIHOME["MODEL"]["HEAD"])
+ZHANG_BIHOME["SOLVER"]["LOSS"] = "biHomE"
+
+
 def _ihome(base):
     """iHomE (one-line) variant of a biHomE config: one direction, hinge with a numeric margin (PerceptualHead.py:465-538).
     No yaml for it ships upstream (train.py:330 names the loss 'iHomE'); the kwargs follow the biHomE configs."""
@@ -126,7 +151,7 @@ def get(name):
         return _ihome(ZENG_BIHOME if name == "zeng-ihome" else DETONE_BIHOME)
     base = name[:-4] if name.endswith("-pds") else name
     cfg = copy.deepcopy({"zeng-bihome": ZENG_BIHOME, "detone-bihome": DETONE_BIHOME, "zeng-orig": ZENG_ORIG,
-                         "detone-orig": DETONE_ORIG}[base])
+                         "detone-orig": DETONE_ORIG, "zhang-orig": ZHANG_ORIG, "zhang-bihome": ZHANG_BIHOME}[base])
     if name.endswith("-pds"):
         cfg["DATA"]["PHOTOMETRIC_MAX_DELTA"] = 32
     return cfg

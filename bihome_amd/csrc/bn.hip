@@ -430,6 +430,13 @@ int bn_launch_stats(const float* x, int groups, int rows, int C, double* sums, h
     return BH_OK;
 }
 
+// C == 1 (bn1.hip)
+int bn1_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, const float* res, float* y,
+            double* stats, int groups, int rows, float eps, float momentum, int flags, int use_running, hipStream_t s);
+int bn1_bwd(const float* gy, const float* y, const float* x, const float* gamma, const float* beta, const double* stats, float* gx,
+            float* gres, float* ggamma, float* gbeta, double* scratch, int groups, int rows, float eps, int flags, int use_running,
+            const float* running_mean, const float* running_var, hipStream_t s);
+
 extern "C" {
 
 int bh_bn_stats_doubles(int groups, int C) { return (int)BH_BN_SUM_DOUBLES(groups, C); }
@@ -439,8 +446,9 @@ int bh_bn_fwd(const float* x, const float* gamma, const float* beta, float* runn
               int flags, int use_running, void* stream) {
     BnGeom g;
     if (!x || !y || !stats) return BH_E_BADARG;
-    if (!bn_geom(groups, rows, C, g)) return BH_E_UNSUPPORTED;
     if (use_running && (!running_mean || !running_var)) return BH_E_BADARG;
+    if (C == 1) return bn1_fwd(x, gamma, beta, running_mean, running_var, res, y, stats, groups, rows, eps, momentum, flags, use_running, bh_stream(stream));
+    if (!bn_geom(groups, rows, C, g)) return BH_E_UNSUPPORTED;
     hipStream_t s = bh_stream(stream);
     if (!use_running && !(flags & 8)) {                       // bit 3: the producer already accumulated the sums
         hipLaunchKernelGGL(bn_stats_kernel, dim3(g.nchunks, groups), dim3(256), 0, s, x, g, stats);
@@ -472,6 +480,8 @@ int bh_bn_bwd(const float* gy, const float* y, const float* x, const float* gamm
     BnGeom g;
     if (!gy || !x || !gx || !stats || !scratch || ((flags & 1) && !(flags & 4) && !y)) return BH_E_BADARG;
     if ((flags & 4) && (flags & 2)) return BH_E_BADARG;        // the mask can only be recomputed without a residual input
+    if (C == 1) return bn1_bwd(gy, y, x, gamma, beta, stats, gx, gres, ggamma, gbeta, scratch, groups, rows, eps, flags, use_running,
+                               running_mean, running_var, bh_stream(stream));
     if (!bn_geom(groups, rows, C, g)) return BH_E_UNSUPPORTED;
     hipStream_t s = bh_stream(stream);
     if (flags & 16) {            // scratch = padded sums accumulated by bh_conv_dgrad_bnreduce (training mode only)
@@ -503,6 +513,6 @@ int bh_bn_bwd(const float* gy, const float* y, const float* x, const float* gamm
     return BH_OK;
 }
 
-int bh_bn_scratch_doubles(int groups, int C) { return groups * C * 2 * (1 + BN_MAX_CHUNKS); }
+int bh_bn_scratch_doubles(int groups, int C) { return groups * C * 2 * (1 + (BN_MAX_CHUNKS > 256 ? BN_MAX_CHUNKS : 256)); }
 
 }  // extern "C"

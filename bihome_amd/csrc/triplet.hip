@@ -274,7 +274,118 @@ __global__ void __launch_bounds__(256) scale_samples_bwd_kernel(const float* __r
     if (threadIdx.x == 0) atomicAdd(g_s + b, (float)(part[0] + part[1] + part[2] + part[3]));
 }
 
+// ---------------------------------------------------------------------------------------------
+// Zhang et al. content-aware triplet loss on ONE-channel full-resolution features (TripletHead.forward, src/heads/TripletHead.py:75-152):
+//   ln1 = sum_b [ sum_p wa h(|f1w - f2| - |f1 - f2| + margin) / max(sum_p wa, 1) ],  wa = m1w * m2
+//   ln2 = the same with (f2w, f1, m2w * m1)                                            (double-line variant; f2w == NULL: one line)
+// h = max(., 0) for a numeric margin, identity (margin ignored) for a string margin (:92-107).  With one channel 'channel-aware' and
+// 'channel-agnostic' coincide.  T1 / T2[B,hw]: pre-hinge values (kept for the adjoint); numden[B,4] (double, overwritten) =
+// { num1, den1, num2, den2 } - bh_bihome_loss_fwd turns it into ln1 + ln2 + mu ln3 (:150-152).  One workgroup per sample: the
+// per-sample sums have a single writer (deterministic in every mode).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) zhang_triplet_fwd_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                                const float* __restrict__ f1w, const float* __restrict__ f2w,
+                                                                const float* __restrict__ m1w, const float* __restrict__ m2w,
+                                                                const float* __restrict__ m1, const float* __restrict__ m2, int hw,
+                                                                float margin, int hinge, float* __restrict__ T1, float* __restrict__ T2,
+                                                                double* __restrict__ numden) {
+    __shared__ double part[4][4];
+    const int b = blockIdx.x;
+    const size_t o = (size_t)b * hw;
+    double n1 = 0, d1 = 0, n2 = 0, d2 = 0;
+    for (int p = threadIdx.x; p < hw; p += 256) {
+        const float a = f1[o + p], c = f2[o + p];
+        const float s3 = fabsf(a - c);
+        const float t1 = fabsf(f1w[o + p] - c) - s3 + (hinge ? margin : 0.f);
+        T1[o + p] = t1;
+        const float wa = m1w[o + p] * (m2 ? m2[o + p] : 1.f);
+        n1 += (double)(wa * (hinge ? fmaxf(t1, 0.f) : t1)); d1 += (double)wa;
+        if (f2w) {
+            const float t2 = fabsf(f2w[o + p] - a) - s3 + (hinge ? margin : 0.f);
+            T2[o + p] = t2;
+            const float wb = m2w[o + p] * (m1 ? m1[o + p] : 1.f);
+            n2 += (double)(wb * (hinge ? fmaxf(t2, 0.f) : t2)); d2 += (double)wb;
+        }
+    }
+    n1 = wave_sum(n1); d1 = wave_sum(d1); n2 = wave_sum(n2); d2 = wave_sum(d2);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { part[wave][0] = n1; part[wave][1] = d1; part[wave][2] = n2; part[wave][3] = d2; }
+    __syncthreads();
+    if (threadIdx.x < 4) numden[(size_t)b * 4 + threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+}
+
+// adjoint: g_loss[1] -> g_f1, g_f2, g_f1w, g_f2w (the feature extractor is TRAINABLE here: all four feature maps carry gradients),
+// g_m1w, g_m2w (the warped masks; the unwarped masks m1 / m2 are treated as constants: FIX_MASK).  All overwritten.
+__global__ void __launch_bounds__(256) zhang_triplet_bwd_kernel(const float* __restrict__ g_loss, const float* __restrict__ f1,
+                                                                const float* __restrict__ f2, const float* __restrict__ f1w,
+                                                                const float* __restrict__ f2w, const float* __restrict__ m1w,
+                                                                const float* __restrict__ m2w, const float* __restrict__ m1,
+                                                                const float* __restrict__ m2, const float* __restrict__ T1,
+                                                                const float* __restrict__ T2, const double* __restrict__ numden, int hw,
+                                                                int hinge, float* __restrict__ g_f1, float* __restrict__ g_f2,
+                                                                float* __restrict__ g_f1w, float* __restrict__ g_f2w,
+                                                                float* __restrict__ g_m1w, float* __restrict__ g_m2w) {
+    const int b = blockIdx.y;
+    const size_t o = (size_t)b * hw;
+    const float g = g_loss[0];
+    const double N1 = numden[(size_t)b * 4], D1 = numden[(size_t)b * 4 + 1], N2 = numden[(size_t)b * 4 + 2], D2 = numden[(size_t)b * 4 + 3];
+    const float i1 = (float)(1.0 / fmax(D1, 1.0)), i2 = (float)(1.0 / fmax(D2, 1.0));
+    const float q1 = D1 > 1.0 ? (float)(N1 / (D1 * D1)) : 0.f, q2 = D2 > 1.0 ? (float)(N2 / (D2 * D2)) : 0.f;      // d(N / max(D,1)) / dD
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < hw; p += gridDim.x * 256) {
+        const float a = f1[o + p], c = f2[o + p], aw = f1w[o + p];
+        const float sc = (float)((a > c) - (a < c));                 // sign(f1 - f2): d|f1 - f2|
+        const float sa = (float)((aw > c) - (aw < c));               // sign(f1w - f2)
+        const float v2 = m2 ? m2[o + p] : 1.f;
+        const float wa = m1w[o + p] * v2;
+        const float t1 = T1[o + p];
+        const float on1 = hinge ? (t1 > 0.f ? 1.f : 0.f) : 1.f;
+        const float k1 = g * i1 * wa * on1;
+        float ga = -k1 * sc, gc = k1 * (sc - sa);
+        g_f1w[o + p] = k1 * sa;
+        g_m1w[o + p] = g * v2 * ((hinge ? fmaxf(t1, 0.f) : t1) * i1 - q1);
+        if (f2w) {
+            const float cw = f2w[o + p];
+            const float sb = (float)((cw > a) - (cw < a));           // sign(f2w - f1)
+            const float v1 = m1 ? m1[o + p] : 1.f;
+            const float wb = m2w[o + p] * v1;
+            const float t2 = T2[o + p];
+            const float on2 = hinge ? (t2 > 0.f ? 1.f : 0.f) : 1.f;
+            const float k2 = g * i2 * wb * on2;
+            ga += k2 * (-sb - sc); gc += k2 * sc;
+            g_f2w[o + p] = k2 * sb;
+            g_m2w[o + p] = g * v1 * ((hinge ? fmaxf(t2, 0.f) : t2) * i2 - q2);
+        }
+        g_f1[o + p] = ga; g_f2[o + p] = gc;
+    }
+}
+
 extern "C" {
+
+int bh_zhang_triplet_fwd(const float* f1, const float* f2, const float* f1w, const float* f2w, const float* m1w, const float* m2w,
+                         const float* m1, const float* m2, int B, int hw, float margin, int hinge, float* T1, float* T2, double* numden,
+                         void* stream) {
+    if (!f1 || !f2 || !f1w || !m1w || !T1 || !numden || (f2w && (!m2w || !T2)) || B < 0 || hw < 1) return BH_E_BADARG;
+    if (B == 0) return BH_OK;
+    hipLaunchKernelGGL(zhang_triplet_fwd_kernel, dim3(B), dim3(256), 0, bh_stream(stream), f1, f2, f1w, f2w, m1w, m2w, m1, m2, hw, margin,
+                       hinge, T1, T2, numden);
+    BH_LAUNCH_CHECK();
+    return BH_OK;
+}
+
+int bh_zhang_triplet_bwd(const float* g_loss, const float* f1, const float* f2, const float* f1w, const float* f2w, const float* m1w,
+                         const float* m2w, const float* m1, const float* m2, const float* T1, const float* T2, const double* numden, int B,
+                         int hw, int hinge, float* g_f1, float* g_f2, float* g_f1w, float* g_f2w, float* g_m1w, float* g_m2w, void* stream) {
+    if (!g_loss || !f1 || !f2 || !f1w || !m1w || !T1 || !numden || !g_f1 || !g_f2 || !g_f1w || !g_m1w ||
+        (f2w && (!m2w || !T2 || !g_f2w || !g_m2w)) || B < 0 || hw < 1)
+        return BH_E_BADARG;
+    if (B == 0) return BH_OK;
+    int nb = (hw + 1023) / 1024;
+    if (nb > 16) nb = 16;
+    hipLaunchKernelGGL(zhang_triplet_bwd_kernel, dim3(nb, B), dim3(256), 0, bh_stream(stream), g_loss, f1, f2, f1w, f2w, m1w, m2w, m1, m2, T1,
+                       T2, numden, hw, hinge, g_f1, g_f2, g_f1w, g_f2w, g_m1w, g_m2w);
+    BH_LAUNCH_CHECK();
+    return BH_OK;
+}
 
 int bh_oneline_loss_fwd(const float* f1, const float* f2, const float* f1w, const float* m1w, const float* m2, int B, int hw,
                         int C, float margin, int rep, const float* sample_w, float* T, double* numden, float* per_sample,

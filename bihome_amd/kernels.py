@@ -274,6 +274,34 @@ def oneline_loss_bwd(g_loss, f2, f1w, m1w, T, numden, m2=None, rep=1, sample_w=N
     return g_f1w, g_m1w
 
 
+def zhang_triplet_fwd(f1, f2, f1w, f2w, m1w, m2w, margin, hinge, m1=None, m2=None):
+    """Zhang content-aware triplet loss on one-channel full-resolution features [B,1,h,w] / masks [B,h,w] (TripletHead.py:75-152):
+    returns (T1, T2 | None, numden[B,4]).  f2w / m2w None: one line."""
+    for t in (f1, f2, f1w, f2w, m1w, m2w, m1, m2):
+        _chk(t)
+    B, hw = f1.shape[0], f1.numel() // f1.shape[0]
+    T1 = torch.empty(B, hw, dtype=torch.float32, device=f1.device)
+    T2 = torch.empty_like(T1) if f2w is not None else None
+    numden = torch.empty(B, 4, dtype=torch.float64, device=f1.device)
+    check(lib.bh_zhang_triplet_fwd(_p(f1), _p(f2), _p(f1w), _p(f2w), _p(m1w), _p(m2w), _p(m1), _p(m2), B, hw, float(margin), int(bool(hinge)),
+                                   _p(T1), _p(T2), _p(numden), _stream()), "bh_zhang_triplet_fwd")
+    return T1, T2, numden
+
+
+def zhang_triplet_bwd(g_loss, f1, f2, f1w, f2w, m1w, m2w, T1, T2, numden, hinge, m1=None, m2=None):
+    """-> (g_f1, g_f2, g_f1w, g_f2w | None, g_m1w, g_m2w | None), shaped like their tensors."""
+    _chk(g_loss)
+    B, hw = f1.shape[0], f1.numel() // f1.shape[0]
+    g_f1, g_f2, g_f1w = torch.empty_like(f1), torch.empty_like(f2), torch.empty_like(f1w)
+    g_m1w = torch.empty_like(m1w)
+    g_f2w = torch.empty_like(f2w) if f2w is not None else None
+    g_m2w = torch.empty_like(m2w) if f2w is not None else None
+    check(lib.bh_zhang_triplet_bwd(_p(g_loss), _p(f1), _p(f2), _p(f1w), _p(f2w), _p(m1w), _p(m2w), _p(m1), _p(m2), _p(T1), _p(T2), _p(numden),
+                                   B, hw, int(bool(hinge)), _p(g_f1), _p(g_f2), _p(g_f1w), _p(g_f2w), _p(g_m1w), _p(g_m2w), _stream()),
+          "bh_zhang_triplet_bwd")
+    return g_f1, g_f2, g_f1w, g_f2w, g_m1w, g_m2w
+
+
 def bihome_loss_fwd(numden, H1, H2, mu):
     _chk(numden, torch.float64); _chk(H1, torch.float64); _chk(H2, torch.float64)
     loss4 = torch.empty(4, dtype=torch.float32, device=numden.device)
@@ -633,7 +661,8 @@ def bn_fwd(x, gamma, beta, rmean, rvar, res, groups, eps, momentum, relu, traini
     """x [groups*rows..., C] NHWC (any leading shape); returns (y, stats).  stats: optional zeroed sums buffer (a slice of
     the caller's arena); stats_ready: the producing conv already accumulated the sums (conv_fwd(..., bn_sums=stats))."""
     _chk(x); _chk(res)
-    C = x.shape[-1]
+    # channels: the affine parameter's length (a one-channel NCHW tensor [N,1,h,w] IS its NHWC form: the Zhang extractor's last layer)
+    C = gamma.numel() if gamma is not None else x.shape[-1]
     rows = x.numel() // C // groups
     y = torch.empty_like(x)
     if stats is None:
@@ -651,7 +680,7 @@ def bn_bwd(gy, y, x, gamma, stats, rmean, rvar, groups, eps, relu, training, wan
            had_res=None, scratch=None, sums_ready=None):
     """sums_ready: the gradient sums buffer filled by conv_dgrad(..., bn_reduce=...) - reduce / finalize are skipped."""
     _chk(gy); _chk(x)
-    C = x.shape[-1]
+    C = gamma.numel() if gamma is not None else x.shape[-1]
     rows = x.numel() // C // groups
     gx = torch.empty_like(x)
     gres = torch.empty_like(x) if want_gres else None

@@ -110,6 +110,9 @@ def attach_reducer(model, bucket_bytes=8 << 20):
     flat gradient buffer, launched bucket by bucket from inside the backward pass)."""
     from .ddp import FlatGradReducer
     backbone = model[0]
+    if hasattr(backbone, "feature_extractor"):
+        raise NotImplementedError("data-parallel training of the ContentAware backbone is not built (two gradient buffers: the feature "
+                                  "extractor's and the resnet's); the BASELINE.json configs use Rethinking / ResNet34")
     if backbone._runner is None:
         backbone._runner = backbone._build()
     r = backbone._runner

@@ -139,6 +139,19 @@ int bh_oneline_loss_fwd(const float* f1, const float* f2, const float* f1w, cons
 int bh_oneline_loss_bwd(const float* g_loss, const float* f2, const float* f1w, const float* m1w, const float* m2,
                         const float* T, const double* numden, int B, int hw, int C, int rep, const float* sample_w,
                         float* g_f1w, float* g_m1w, void* stream);
+/* Zhang et al. content-aware triplet loss (TripletHead.forward, src/heads/TripletHead.py:75-152) on ONE-channel full-resolution feature
+ * maps f*[B,hw] (the ContentAware feature extractor, src/backbones/ContentAware.py:57-81) and masks m*[B,hw] (m1 / m2 NULL = ones: FIX_MASK):
+ *   num1 = sum_p m1w m2 h(|f1w - f2| - |f1 - f2| + margin), den1 = sum_p m1w m2; num2 / den2 with (f2w, f1, m2w m1); f2w NULL: one line.
+ * hinge != 0: h = max(., 0) (numeric margin, :98-107); hinge == 0: h = identity and margin is ignored (string margin, :92-97).
+ * T1 / T2[B,hw] = pre-hinge values (for the adjoint), numden[B,4] double (overwritten) -> bh_bihome_loss_fwd gives ln1 + ln2 + mu ln3
+ * (:150-152; one line: pass identity homographies and mu = 0).  The adjoint writes the gradients of ALL FOUR feature maps (the extractor
+ * is trainable here) and of the two warped masks (overwritten); the unwarped masks are constants. */
+int bh_zhang_triplet_fwd(const float* f1, const float* f2, const float* f1w, const float* f2w, const float* m1w, const float* m2w,
+                         const float* m1, const float* m2, int B, int hw, float margin, int hinge, float* T1, float* T2, double* numden,
+                         void* stream);
+int bh_zhang_triplet_bwd(const float* g_loss, const float* f1, const float* f2, const float* f1w, const float* f2w, const float* m1w,
+                         const float* m2w, const float* m1, const float* m2, const float* T1, const float* T2, const double* numden, int B,
+                         int hw, int hinge, float* g_f1, float* g_f2, float* g_f1w, float* g_f2w, float* g_m1w, float* g_m2w, void* stream);
 /* y[b,:] = x[b / rep,:] * s[b] over Bn hypotheses of L floats (the score weighting of multihead_resnet_loss,
  * PerceptualHead.py:276-280) and its adjoint (g_x only for rep = 1, may be NULL; g_s[Bn] overwritten). */
 int bh_scale_samples_fwd(const float* x, const float* s, int Bn, long long L, int rep, float* y, void* stream);
@@ -308,6 +321,8 @@ int bh_conv_bias_grad(const float* gy, float* gbias, const bh_conv_desc* d, void
  * per-chunk partial sums, reduced deterministically). */
 int bh_bn_stats_doubles(int groups, int C);
 int bh_bn_scratch_doubles(int groups, int C);
+/* C: a multiple of 4 (<= 1024, C/4 dividing 256), or 1 (round 3: the one-channel BatchNorms of the Zhang feature extractor /
+ * mask predictor, ContentAware.py:24-26,68-70 - csrc/bn1.hip, same contract). */
 int bh_bn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
               const float* res, float* y, double* stats, int groups, int rows, int C, float eps, float momentum,
               int flags, int use_running, void* stream);

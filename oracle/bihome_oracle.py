@@ -485,6 +485,139 @@ class NoOpHead(nn.Module):
         return ret
 
 
+# --------------------------------------------------------------------------------------------
+# Zhang et al. "Content-Aware" baseline (round 3): backbone src/backbones/ContentAware.py, head src/heads/TripletHead.py
+# --------------------------------------------------------------------------------------------
+
+def _cbr1(cin, cout, act=True):
+    return nn.Sequential(nn.Conv2d(cin, cout, 3, 1, 1, bias=False), nn.BatchNorm2d(cout), nn.ReLU() if act else nn.Sigmoid())
+
+
+class ZhangMaskPredictor(nn.Module):
+    """ContentAware.py:6-52.  fix_mask (every shipped config): all ones."""
+
+    def __init__(self, fix_mask=False, normalization_strength=-1):
+        super().__init__()
+        self.fix_mask, self.normalization_strength = fix_mask, normalization_strength
+        self.layer1, self.layer2, self.layer3, self.layer4 = _cbr1(1, 4), _cbr1(4, 8), _cbr1(8, 16), _cbr1(16, 32)
+        self.layer5 = _cbr1(32, 1, act=False)                                             # :24-26 (Sigmoid)
+
+    def forward(self, x):
+        if self.fix_mask:
+            return torch.ones_like(x)                                                     # :38-39
+        out = self.layer5(self.layer4(self.layer3(self.layer2(self.layer1(x)))))          # :41-45
+        if self.normalization_strength > 0:                                               # :28-35,49-50
+            mx = out.reshape(out.shape[0], -1).max(1)[0].reshape(-1, 1, 1, 1)
+            out = torch.clamp(out / (mx * self.normalization_strength), 0, 1)
+        return out
+
+
+class ZhangFeatureExtractor(nn.Module):
+    """ContentAware.py:55-74: 1 -> 4 -> 8 -> 1 channels, 3x3 conv + BatchNorm + ReLU each."""
+
+    def __init__(self):
+        super().__init__()
+        self.layer1, self.layer2, self.layer3 = _cbr1(1, 4), _cbr1(4, 8), _cbr1(8, 1)
+
+    def forward(self, x):
+        return self.layer3(self.layer2(self.layer1(x)))
+
+
+class ContentAwareBackbone(nn.Module):
+    """ContentAware.py:84-179: G = mask * features of each patch, resnet34 (2-channel stem, 8-way fc) on cat(G1, G2)."""
+
+    def __init__(self, **kw):
+        super().__init__()
+        self.patch_keys, self.mask_keys = kw["PATCH_KEYS"], kw["MASK_KEYS"]
+        self.feature_keys, self.target_keys = kw["FEATURE_KEYS"], kw["TARGET_KEYS"]
+        self.mask_predictor = ZhangMaskPredictor(kw["FIX_MASK"], kw.get("MASK_NORMALIZATION_STRENGTH", -1))   # :93-94
+        self.feature_extractor = ZhangFeatureExtractor()
+        self.variant = str.lower(kw["VARIANT"])
+        self.resnet34 = _TVResNet34(in_ch=2, num_out=8)                                   # :106-110
+
+    def _forward(self, x1, x2):                                                           # :124-144
+        m1, f1 = self.mask_predictor(x1), self.feature_extractor(x1)
+        m2, f2 = self.mask_predictor(x2), self.feature_extractor(x2)
+        g1, g2 = m1 * f1, m2 * f2
+        return m1, f1, m2, f2, g1, g2, self.resnet34(torch.cat([g1, g2], 1)).reshape(-1, 4, 2)
+
+    def forward(self, data):                                                              # :146-173
+        e1, e2 = self.patch_keys
+        (data[self.mask_keys[0]], data[self.feature_keys[0]], data[self.mask_keys[1]], data[self.feature_keys[1]], g1, g2,
+         data[self.target_keys[0]]) = self._forward(data[e1], data[e2])
+        if self.variant == "doubleline":
+            data[self.target_keys[1]] = self.resnet34(torch.cat([g2, g1], 1)).reshape(-1, 4, 2)
+        return data
+
+    def predict_homography(self, data):                                                   # :175-187
+        e1, e2 = self.patch_keys
+        data[self.mask_keys[0]], _, data[self.mask_keys[1]], _, _, _, data[self.target_keys[0]] = self._forward(data[e1], data[e2])
+        return data
+
+
+class ZhangTripletHead(nn.Module):
+    """src/heads/TripletHead.py:9-212."""
+
+    def __init__(self, backbone, **kw):
+        super().__init__()
+        self.backbone = backbone
+        self.patch_keys, self.mask_keys = kw["PATCH_KEYS"], kw["MASK_KEYS"]
+        self.feature_keys, self.target_keys = kw["FEATURE_KEYS"], kw["TARGET_KEYS"]
+        self.mu = kw["MU"]
+        self.variant = str.lower(kw["VARIANT"])
+        self.triplet_margin, self.aggregation = kw["TRIPLET_MARGIN"], kw["TRIPLET_AGGREGATION"]
+        self.last = {}
+
+    @staticmethod
+    def _warp(image, delta_hat):                                                          # :30-35
+        H = four_point_to_homography(image_shape_to_corners(image), delta_hat)
+        return warp_image(image, H), H
+
+    def _line(self, fw, f_other, f_same, mw, m_other):                                    # :75-114 (and :124-147 mirrored)
+        l1, l3 = torch.abs(fw - f_other), torch.abs(f_same - f_other)
+        mo, mw = m_other.squeeze(1), mw.squeeze(1)
+        den = (mw * mo).sum((-1, -2))
+        if isinstance(self.triplet_margin, str):
+            mat = (l1 - l3).sum(1) if self.aggregation == "channel-aware" else l1.sum(1) - l3.sum(1)
+        elif self.aggregation == "channel-aware":
+            mat = torch.clamp(l1 - l3 + self.triplet_margin, min=0).sum(1)
+        else:
+            # :104-105 (and :141-142) as written upstream: torch.max of the [B,h,w] channel sums with zeros_like(l1) = [B,1,h,w]
+            # BROADCASTS to [B,B,h,w] (entry [i,j] = hinge of sample j), and so do the mask product, the spatial sums ([B,B]) and
+            # the division by the [B] denominators: the final sum counts every sample B times.  A quirk of the numeric-margin /
+            # channel-agnostic branch (the shipped zhang-orig config); kept, because results must equal the reference's.
+            mat = torch.max(l1.sum(1) - l3.sum(1) + self.triplet_margin, torch.zeros_like(l1))
+        return ((mw * mo * mat).sum((-1, -2)) / torch.max(den, torch.ones_like(den))).sum()
+
+    def forward(self, data, *unused):                                                     # :37-199
+        e1, e2 = self.patch_keys
+        m1k, m2k = self.mask_keys
+        f1k, f2k = self.feature_keys
+        o1, o2 = (self.target_keys + [None])[:2]
+        p1, p2, m1, m2, f1, f2 = data[e1], data[e2], data[m1k], data[m2k], data[f1k], data[f2k]
+        p1w, _ = self._warp(p1, data[o1])
+        f1w = self.backbone.feature_extractor(p1w)                                        # :59
+        m1w, h1 = self._warp(m1, data[o1])
+        ln1 = self._line(f1w, f2, f1, m1w, m2)
+        loss = ln1
+        self.last = {"ln1": ln1.detach(), "h1": h1.detach(), "f1w": f1w.detach()}
+        if self.variant == "doubleline":
+            p2w, _ = self._warp(p2, data[o2])
+            f2w = self.backbone.feature_extractor(p2w)                                    # :68
+            m2w, h2 = self._warp(m2, data[o2])
+            ln2 = self._line(f2w, f1, f2, m2w, m1)
+            eye = torch.eye(3, dtype=h1.dtype).unsqueeze(0)
+            ln3 = ((torch.matmul(h1, h2) - eye) ** 2).sum()                               # :150-152
+            loss = ln1 + ln2 + self.mu * ln3
+            self.last.update(ln2=ln2.detach(), ln3=ln3.detach(), h2=h2.detach(), f2w=f2w.detach())
+        return loss, data.get("delta"), data[o1]
+
+    def predict_homography(self, data, *unused):                                          # :201-212
+        delta_hat = data[self.target_keys[0]]
+        _, H = self._warp(data[self.patch_keys[0]], delta_hat)
+        return delta_hat, H
+
+
 def mace(delta_gt, delta_hat):
     """train.py:402-403 / eval.py:133-134."""
     a = delta_gt.detach().cpu().numpy().reshape(-1, 2)
@@ -497,8 +630,8 @@ def build(cfg, dtype=torch.float32, seed=0):
     deterministic synthetic weights (weights are produced by the caller-supplied loader to keep
     this file free of product imports)."""
     bcfg, hcfg = cfg["MODEL"]["BACKBONE"], cfg["MODEL"]["HEAD"]
-    bb = (ZengBackbone if bcfg["NAME"] == "Rethinking" else ResNet34Backbone)(**bcfg)
-    head = (NoOpHead if hcfg["NAME"] == "NoOpHead" else BiHomEHead)(bb, **hcfg)
+    bb = {"Rethinking": ZengBackbone, "ResNet34": ResNet34Backbone, "ContentAware": ContentAwareBackbone}[bcfg["NAME"]](**bcfg)
+    head = {"NoOpHead": NoOpHead, "PerceptualHead": BiHomEHead, "TripletHead": ZhangTripletHead}[hcfg["NAME"]](bb, **hcfg)
     return bb, head
 
 

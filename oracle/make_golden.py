@@ -411,6 +411,76 @@ def run_bihome_variant(ref_bb_cls, ref_head_cls, cfg, dtype, batch=4, seed=17, s
     return out
 
 
+class _ScalarRecorder:
+    """Stand-in for the TensorBoard SummaryWriter the reference head writes to (TripletHead.py:158-186)."""
+
+    def __init__(self):
+        self.scalars = {}
+
+    def add_scalars(self, tag, values, step):
+        for k, v in values.items():
+            self.scalars["tb/%s/%s" % (tag, k)] = float(v)
+
+
+def run_zhang_scenario(ref_bb_cls, ref_head_cls, cfg, dtype, batch=4, seed=41, steps=2):
+    """Round 3: the Zhang "Content-Aware" baseline - the reference's ContentAware.Model (feature extractor + fixed all-ones mask +
+    resnet34) under its TripletHead.Model (config/s-coco/zhang-orig-lr-1e-2.yaml), `steps` Adam steps on one batch, then an eval
+    forward.  The feature extractor runs four times per step (two patches in the backbone, two warped patches in the head), each call
+    with its own BatchNorm batch statistics: the running statistics after the steps pin that order."""
+    from bihome_amd import synth
+    from bihome_amd.weights import load_synthetic
+    bb = ref_bb_cls(**cfg["MODEL"]["BACKBONE"])
+    head = ref_head_cls(bb, **cfg["MODEL"]["HEAD"])
+    load_synthetic(bb, seed=0)
+    model = torch.nn.Sequential(bb, head).to(dtype)
+    s = cfg["SOLVER"]
+    opt = torch.optim.Adam(model.parameters(), lr=s["LR"], betas=(s["MOMENTUM_1"], s["MOMENTUM_2"]), weight_decay=0)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=s["MILESTONES"], gamma=s["LR_DECAY"])
+    d = synth.make_pairs(batch, seed=seed)
+    out = {"loss": [], "mace": []}
+    grads_of = ("feature_extractor.layer1.0.weight", "feature_extractor.layer2.1.weight", "feature_extractor.layer3.0.weight",
+                "feature_extractor.layer3.1.weight", "feature_extractor.layer3.1.bias", "resnet34.conv1.weight",
+                "resnet34.layer4.2.conv2.weight", "resnet34.fc.bias")
+    model.train()
+    for it in range(steps):
+        opt.zero_grad()
+        data = {k: t(d[k], dtype) for k in ("patch_1", "patch_2", "delta")}
+        if it == 0:
+            rec = _ScalarRecorder()
+            data["summary_writer"], data["summary_writer_step"] = rec, 0
+        loss, delta_gt, delta_hat = model(data)
+        loss.backward()
+        if it == 0:
+            out.update({k: np.float64(v) for k, v in rec.scalars.items()})
+            out["delta_hat_12"] = data["delta_hat_12"].detach().double().numpy().copy()
+            out["delta_hat_21"] = data["delta_hat_21"].detach().double().numpy().copy()
+            out["feature_1_sub"] = sub(data["feature_1"], 8)
+            out["feature_2_csum"] = csum(data["feature_2"])
+            params = dict(bb.named_parameters())
+            for name in grads_of:
+                g = params[name].grad.double()
+                out["gradnorm/" + name] = np.float64(g.norm().item())
+            out["grad/feature_extractor.layer3.0.weight"] = params["feature_extractor.layer3.0.weight"].grad.double().numpy().copy()
+            out["grad/feature_extractor.layer1.0.weight"] = params["feature_extractor.layer1.0.weight"].grad.double().numpy().copy()
+        opt.step()
+        sched.step()
+        out["loss"].append(loss.item())
+        out["mace"].append(float(np.mean(np.linalg.norm(delta_gt.numpy().reshape(-1, 2) -
+                                                        delta_hat.detach().numpy().reshape(-1, 2), axis=-1))))
+    sd = bb.state_dict()
+    for k in ("feature_extractor.layer1.1.running_mean", "feature_extractor.layer1.1.running_var", "feature_extractor.layer3.1.running_mean",
+              "feature_extractor.layer3.1.running_var", "feature_extractor.layer3.1.num_batches_tracked", "resnet34.bn1.running_mean"):
+        out["state/" + k] = sd[k].double().numpy().copy()
+    model.eval()
+    with torch.no_grad():
+        data = {k: t(d[k], dtype) for k in ("patch_1", "patch_2", "delta")}
+        delta_hat, H = head.predict_homography(bb.predict_homography(data))
+    out["eval_delta_hat"] = delta_hat.double().numpy().copy()
+    out["eval_H"] = H.double().numpy().copy()
+    out["loss"], out["mace"] = np.asarray(out["loss"]), np.asarray(out["mace"])
+    return out
+
+
 def run_datagen(outdir):
     """The reference's own data-generation classes (src/data/transforms.py PhotometricDistortSimple :296-330,
     HomographyNetPrep :421-725, DictToGrayscale :344-354, DictStandardize :369-378) on seeded inputs, with the OpenCV
@@ -531,6 +601,16 @@ def main():
     warnings.filterwarnings("ignore")
     orig_only = "--orig-only" in sys.argv          # regenerate just the supervised "-orig" fixtures
     round2 = [a for a in sys.argv[1:] if a.startswith("--round2")]      # --round2 or --round2=name1,name2
+    if "--round3" in sys.argv:                     # the Zhang baseline (ContentAware + TripletHead): tests/golden/zhang_orig_b4_{f32,f64}.npz
+        ContentAware = importlib.import_module("src.backbones.ContentAware")
+        TripletHead = importlib.import_module("src.heads.TripletHead")
+        for m in (ContentAware, TripletHead):
+            assert os.path.realpath(m.__file__).startswith(os.path.realpath(REF)), m.__file__
+        for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+            r = run_zhang_scenario(ContentAware.Model, TripletHead.Model, configs.get("zhang-orig"), dtype)
+            np.savez_compressed(os.path.join(outdir, "zhang_orig_b4_%s.npz" % tag), **r)
+            print("zhang-orig", tag, "loss", r["loss"], "mace", r["mace"])
+        return
     for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
         if round2:
             names = round2[0].split("=", 1)[1].split(",") if "=" in round2[0] else []

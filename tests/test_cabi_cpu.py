@@ -207,3 +207,27 @@ def test_ctypes_structs_mirror_the_header():
         assert cname in structs, cname
         mirror = [(f, kinds[tp]) for f, tp in cls._fields_]
         assert mirror == structs[cname], (cname, mirror, structs[cname])
+
+
+def test_zhang_plugins_are_discoverable_and_share_the_reference_state_dict_schema():
+    """src.backbones.ContentAware / src.heads.TripletHead (round 3) resolve through the reference's importlib discovery (train.py:675-690)
+    and carry the state-dict keys of the oracle's module tree (which the reference fixture pins); FIX_MASK False is refused loudly."""
+    import importlib
+    import torch
+    from bihome_amd import configs
+    from bihome_amd.step import build_model
+    from oracle import bihome_oracle as O
+    cfg = configs.get("zhang-orig")
+    model = build_model(cfg, "cpu")
+    assert importlib.import_module("src.backbones.ContentAware").Model is type(model[0])
+    assert importlib.import_module("src.heads.TripletHead").Model is type(model[1])
+    bb, head = O.build(cfg)
+    assert set(torch.nn.Sequential(bb, head).state_dict().keys()) == set(model.state_dict().keys())
+    for k, v in bb.state_dict().items():
+        assert tuple(model[0].state_dict()[k].shape) == tuple(v.shape), k
+    bad = configs.get("zhang-orig")
+    bad["MODEL"]["BACKBONE"]["FIX_MASK"] = False
+    with pytest.raises(NotImplementedError):
+        build_model(bad, "cpu")
+    with pytest.raises(RuntimeError, match="no CPU"):
+        model[0]({"patch_1": torch.zeros(1, 1, 128, 128), "patch_2": torch.zeros(1, 1, 128, 128)})

@@ -265,3 +265,48 @@ def test_score_weighted_multi_hypothesis_training(golden, base, loss_name):
         np.testing.assert_allclose(O.mace(dgt, dh), g["mace"][it], rtol=1e-7)
         if it == 0:
             np.testing.assert_allclose(dh.numpy(), g["delta_hat_12"], atol=1e-6)
+
+
+def test_zhang_content_aware_triplet_head(golden):
+    """Round 3: the Zhang baseline - oracle ContentAwareBackbone + ZhangTripletHead against the fixture made by the reference's own
+    src/backbones/ContentAware.py + src/heads/TripletHead.py (oracle/make_golden.py --round3): two Adam steps at B = 4 in float64 -
+    losses, MACE, both regressed offsets, the feature maps, gradients of the feature extractor (which runs four times per step: two
+    patches in the backbone, two warped patches in the head), the running statistics after the steps (they pin the order of those
+    four calls) and the eval-mode prediction."""
+    g = golden("zhang_orig_b4_f64")
+    cfg = configs.get("zhang-orig")
+    bb, head = O.build(cfg)
+    load_synthetic(bb, 0)
+    bb.double(); head.double()
+    opt, sched = O.make_optimizer(torch.nn.Sequential(bb, head), cfg["SOLVER"])
+    d = synth.make_pairs(4, seed=41)
+    for it in range(2):
+        data = {k: _t(d[k], torch.float64) for k in ("patch_1", "patch_2", "delta")}
+        bb.train(); head.train()
+        opt.zero_grad()
+        loss, dgt, dh = head(bb(data))
+        loss.backward()
+        if it == 0:
+            np.testing.assert_allclose(data["delta_hat_12"].detach().numpy(), g["delta_hat_12"], atol=1e-8)
+            np.testing.assert_allclose(data["delta_hat_21"].detach().numpy(), g["delta_hat_21"], atol=1e-8)
+            np.testing.assert_allclose(data["feature_1"].detach().numpy()[..., ::8, ::8], g["feature_1_sub"], atol=1e-9)
+            params = dict(bb.named_parameters())
+            for k in (k for k in g if k.startswith("gradnorm/")):
+                np.testing.assert_allclose(params[k[9:]].grad.norm().item(), g[k], rtol=1e-6, err_msg=k)
+            for k in (k for k in g if k.startswith("grad/")):
+                np.testing.assert_allclose(params[k[5:]].grad.numpy(), g[k], rtol=1e-6, atol=1e-10, err_msg=k)
+            np.testing.assert_allclose(head.last["ln1"].item(), g["tb/loss_comp/ln1"], rtol=1e-8)
+            np.testing.assert_allclose(head.last["ln2"].item(), g["tb/loss_comp/ln2"], rtol=1e-8)
+            np.testing.assert_allclose(cfg["MODEL"]["HEAD"]["MU"] * head.last["ln3"].item(), g["tb/loss_comp/ln3"], rtol=1e-8)
+        opt.step(); sched.step()
+        assert abs(loss.item() - g["loss"][it]) <= 1e-7 * abs(g["loss"][it]), (it, loss.item(), g["loss"][it])
+        np.testing.assert_allclose(O.mace(dgt, dh), g["mace"][it], rtol=1e-7)
+    sd = bb.state_dict()
+    for k in (k for k in g if k.startswith("state/")):
+        np.testing.assert_allclose(sd[k[6:]].double().numpy(), g[k], rtol=1e-7, atol=1e-10, err_msg=k)
+    bb.eval(); head.eval()
+    with torch.no_grad():
+        data = {k: _t(d[k], torch.float64) for k in ("patch_1", "patch_2", "delta")}
+        dh, H = head.predict_homography(bb.predict_homography(data))
+    np.testing.assert_allclose(dh.numpy(), g["eval_delta_hat"], atol=1e-7)
+    np.testing.assert_allclose(H.numpy(), g["eval_H"], atol=1e-8)
