@@ -43,6 +43,7 @@ P = c_void_p
 # name -> argtypes (all return int).  Must list every symbol include/bihome.h declares.
 SIGNATURES = {
     "bh_version": [],
+    "bh_probe_mfma_bf16": [c_int, P, P, P],
     "bh_set_deterministic": [c_int],
     "bh_get_deterministic": [],
     "bh_device_arch": [c_char_p, c_int],

@@ -45,6 +45,11 @@ int bh_device_arch(char* buf, int buflen);
  *   - DLT adjoint: duplicates of a sample's indices are added in point order inside the wave, hypotheses in launch order;
  *   - not covered: the pooled coverage of bh_warp_fwd with pool = 32 (four quarter-window atomics per window).
  * Same arithmetic otherwise: results differ from the default mode only by the order of additions. */
+/* Measured matrix-pipe peak for the roofline: sustained TFLOP/s of a bare v_mfma_f32_32x32x16_bf16 stream on the whole
+ * chip (two workgroups of four waves per CU, ~5 ms), with constant operands (random_operands = 0) or random-bit operands (1: the data
+ * toggling of real tensors - on MI355X the power-limited rate, 25-35 % below the first).  Synchronises the stream.  sink_dev: 4 bytes of
+ * device memory (never written). */
+int bh_probe_mfma_bf16(int random_operands, float* sink_dev, double* tflops, void* stream);
 int bh_set_deterministic(int on);
 int bh_get_deterministic(void);
 
