@@ -80,8 +80,8 @@ __device__ __forceinline__ void bn_update_running(const double* __restrict__ sum
     for (int c = threadIdx.x; c < g.C; c += blockDim.x) {
         float rm = running_mean[c], rv = running_var[c];
         for (int grp = 0; grp < g.groups; ++grp) {
-            const double mean = bn_sum_total(sums, g.groups, grp, g.C, c, 0) / n;
-            double var = bn_sum_total(sums, g.groups, grp, g.C, c, 1) / n - mean * mean;
+            const double mean = bn_sum_total(sums, g.groups, grp, g.C, c, 0, g.det) / n;
+            double var = bn_sum_total(sums, g.groups, grp, g.C, c, 1, g.det) / n - mean * mean;
             if (var < 0) var = 0;
             const float unb = (float)(n > 1 ? var * n / (n - 1) : var);
             rm = (1.f - momentum) * rm + momentum * (float)mean;
@@ -95,11 +95,11 @@ __device__ __forceinline__ void bn_update_running(const double* __restrict__ sum
 __device__ __forceinline__ void bn_coeffs(const double* __restrict__ stats, const float* __restrict__ gamma,
                                           const float* __restrict__ beta, const float* __restrict__ rmean,
                                           const float* __restrict__ rvar, int use_running, int groups, int grp, int C, int c,
-                                          float eps, double rows, float& mean, float& invstd, float& scale, float& shift) {
+                                          float eps, double rows, float& mean, float& invstd, float& scale, float& shift, int det = -1) {
     if (use_running) { mean = rmean[c]; invstd = 1.0f / sqrtf(rvar[c] + eps); }
     else {                                                      // stats = [groups][C][2] sums (x, x^2) over `rows` rows
-        const double m = bn_sum_total(stats, groups, grp, C, c, 0) / rows;
-        double var = bn_sum_total(stats, groups, grp, C, c, 1) / rows - m * m;
+        const double m = bn_sum_total(stats, groups, grp, C, c, 0, det) / rows;
+        double var = bn_sum_total(stats, groups, grp, C, c, 1, det) / rows - m * m;
         if (var < 0) var = 0;
         mean = (float)m;
         invstd = 1.0f / sqrtf((float)var + eps);
@@ -115,10 +115,10 @@ __device__ __forceinline__ void bn_coeffs(const double* __restrict__ stats, cons
 struct BnRaw { double s1, s2; float gm, bt; };
 __device__ __forceinline__ BnRaw bn_raw(const double* __restrict__ stats, const float* __restrict__ gamma,
                                         const float* __restrict__ beta, const float* __restrict__ rmean,
-                                        const float* __restrict__ rvar, int use_running, int groups, int grp, int C, int c) {
+                                        const float* __restrict__ rvar, int use_running, int groups, int grp, int C, int c, int det = -1) {
     BnRaw r;
     if (use_running) { r.s1 = rmean[c]; r.s2 = rvar[c]; }
-    else { r.s1 = bn_sum_total(stats, groups, grp, C, c, 0); r.s2 = bn_sum_total(stats, groups, grp, C, c, 1); }
+    else { r.s1 = bn_sum_total(stats, groups, grp, C, c, 0, det); r.s2 = bn_sum_total(stats, groups, grp, C, c, 1, det); }
     r.gm = gamma ? gamma[c] : 1.f;
     r.bt = beta ? beta[c] : 0.f;
     return r;
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__
     const int grp = blockIdx.y;
     BnRaw raw[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) raw[i] = bn_raw(stats, gamma, beta, rmean, rvar, use_running, g.groups, grp, g.C, cq * 4 + i);
+    for (int i = 0; i < 4; ++i) raw[i] = bn_raw(stats, gamma, beta, rmean, rvar, use_running, g.groups, grp, g.C, cq * 4 + i, g.det);
     const size_t gbase = ((size_t)grp * g.rows) * g.C + cq * 4;
     const bool relu = flags & 1, addres = (flags & 2) && res;
     // four rows per lane and pass; the loads of the first pass are issued before the coefficient arithmetic
@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restr
     float mean[4], invstd[4], sc[4], sh[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-        bn_coeffs(stats, gamma, beta, rmean, rvar, use_running, g.groups, grp, g.C, cq * 4 + i, eps, (double)g.rows, mean[i], invstd[i], sc[i], sh[i]);
+        bn_coeffs(stats, gamma, beta, rmean, rvar, use_running, g.groups, grp, g.C, cq * 4 + i, eps, (double)g.rows, mean[i], invstd[i], sc[i], sh[i], g.det);
     const size_t gbase = ((size_t)grp * g.rows) * g.C + cq * 4;
     const bool relu = flags & 1, mask_from_x = flags & 4;     // bit 2: no residual -> y = relu(x*sc+sh), recompute the mask
     double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const double* __res
         s1 = wave_sum(s1); s2 = wave_sum(s2);
         if (lane == 0) {
             float mean, invstd, sc, sh;
-            bn_coeffs(stats, nullptr, nullptr, rmean, rvar, use_running, g.groups, grp, g.C, c, eps, (double)g.rows, mean, invstd, sc, sh);
+            bn_coeffs(stats, nullptr, nullptr, rmean, rvar, use_running, g.groups, grp, g.C, c, eps, (double)g.rows, mean, invstd, sc, sh, g.det);
             const float invn = 1.0f / (float)g.rows;
             coef[(size_t)grp * g.C + c] = use_running ? make_float4(mean, invstd, 0.f, 0.f)
                                                       : make_float4(mean, invstd, (float)s1 * invn, (float)s2 * invn);
@@ -310,9 +310,9 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
         } else {
             // the gradient sums were accumulated by the dgrad that produced gy (bh_conv_dgrad_bnreduce): no reduce /
             // finalize launches, the coefficients come straight from the two padded sums tables
-            raw[i] = bn_raw(stats, gamma, beta, nullptr, nullptr, 0, g.groups, grp, g.C, c);
-            rs1[i] = bn_sum_total(sums, g.groups, grp, g.C, c, 0);
-            rs2[i] = bn_sum_total(sums, g.groups, grp, g.C, c, 1);
+            raw[i] = bn_raw(stats, gamma, beta, nullptr, nullptr, 0, g.groups, grp, g.C, c, g.det);
+            rs1[i] = bn_sum_total(sums, g.groups, grp, g.C, c, 0, g.det);
+            rs2[i] = bn_sum_total(sums, g.groups, grp, g.C, c, 1, g.det);
         }
     }
     const size_t gbase = ((size_t)grp * g.rows) * g.C + cq * 4;
@@ -352,8 +352,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
         for (int c = threadIdx.x; c < g.C; c += blockDim.x) {
             double tb = 0, tg = 0;
             for (int q = 0; q < g.groups; ++q) {
-                tb += bn_sum_total(sums, g.groups, q, g.C, c, 0);
-                tg += bn_sum_total(sums, g.groups, q, g.C, c, 1);
+                tb += bn_sum_total(sums, g.groups, q, g.C, c, 0, g.det);
+                tg += bn_sum_total(sums, g.groups, q, g.C, c, 1, g.det);
             }
             if (ggamma) ggamma[c] += (float)tg;
             if (gbeta) gbeta[c] += (float)tb;
@@ -414,7 +414,7 @@ __global__ void __launch_bounds__(256) bn_fwd_coeffs_kernel(const double* __rest
     if (i < g.groups * g.C) {
         const int grp = i / g.C, c = i - grp * g.C;
         float mean, invstd, sc, sh;
-        bn_coeffs(stats, gamma, beta, nullptr, nullptr, 0, g.groups, grp, g.C, c, eps, (double)g.rows, mean, invstd, sc, sh);
+        bn_coeffs(stats, gamma, beta, nullptr, nullptr, 0, g.groups, grp, g.C, c, eps, (double)g.rows, mean, invstd, sc, sh, g.det);
         table[i] = make_float2(sc, sh);
     }
     if (upd_mean && blockIdx.x == 0) bn_update_running(stats, g, momentum, upd_mean, upd_var);

@@ -63,8 +63,8 @@ __device__ __forceinline__ void bn1_coeffs(const double* __restrict__ stats, con
                                            float& invstd, float& scale, float& shift) {
     if (use_running) { mean = rmean[0]; invstd = 1.0f / sqrtf(rvar[0] + eps); }
     else {
-        const double m = bn_sum_total(stats, g.groups, grp, 1, 0, 0) / (double)g.rows;
-        double var = bn_sum_total(stats, g.groups, grp, 1, 0, 1) / (double)g.rows - m * m;
+        const double m = bn_sum_total(stats, g.groups, grp, 1, 0, 0, g.det) / (double)g.rows;
+        double var = bn_sum_total(stats, g.groups, grp, 1, 0, 1, g.det) / (double)g.rows - m * m;
         if (var < 0) var = 0;
         mean = (float)m;
         invstd = 1.0f / sqrtf((float)var + eps);
@@ -96,8 +96,8 @@ __global__ void __launch_bounds__(256) bn1_apply_kernel(const float* __restrict_
         float rm = upd_mean[0], rv = upd_var[0];
         const double n = (double)g.rows;
         for (int q = 0; q < g.groups; ++q) {
-            const double m = bn_sum_total(stats, g.groups, q, 1, 0, 0) / n;
-            double var = bn_sum_total(stats, g.groups, q, 1, 0, 1) / n - m * m;
+            const double m = bn_sum_total(stats, g.groups, q, 1, 0, 0, g.det) / n;
+            double var = bn_sum_total(stats, g.groups, q, 1, 0, 1, g.det) / n - m * m;
             if (var < 0) var = 0;
             const float unb = (float)(n > 1 ? var * n / (n - 1) : var);
             rm = (1.f - momentum) * rm + momentum * (float)m;

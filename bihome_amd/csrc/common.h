@@ -65,8 +65,12 @@ __device__ __forceinline__ void bh_det_add(double* entry, double v) {
     if (mid != 0.0) atomicAdd(w + 2, (unsigned long long)(long long)mid);
     if (lo != 0.0) atomicAdd(w + 3, (unsigned long long)(long long)lo);
 }
-__device__ __forceinline__ double bh_acc_read(const double* __restrict__ entry) {
+// det: 1 = the limbs are in use, 0 = word 0 only (the writer's mode is known: no limb loads), -1 = look (cold paths)
+__device__ __forceinline__ double bh_acc_read(const double* __restrict__ entry, int det = -1) {
     double t = entry[0];
+#ifndef BH_ACC_LOOK                                             // (A/B builds: always look at the limbs, as the first version did)
+    if (det == 0) return t;
+#endif
     const long long* const w = reinterpret_cast<const long long*>(entry);
     const long long l0 = w[1], l1 = w[2], l2 = w[3];
     if (l0 | l1 | l2) t += ((double)l2 * 0x1p-40 + (double)l1) * 0x1p-40 + (double)l0;      // smallest limb first
@@ -81,10 +85,10 @@ __device__ __forceinline__ size_t bn_sum_index(int slot, int groups, int grp, in
     return ((((size_t)slot * groups + grp) * C + c) * 2 + mom) * BH_BN_SUM_STRIDE;
 }
 // (an entry of a BatchNorm sums buffer is the first BH_ACC_WORDS words of its 128-byte line)
-__device__ __forceinline__ double bn_sum_total(const double* __restrict__ buf, int groups, int grp, int C, int c, int mom) {
+__device__ __forceinline__ double bn_sum_total(const double* __restrict__ buf, int groups, int grp, int C, int c, int mom, int det = -1) {
     double t = 0;
 #pragma unroll
-    for (int s = 0; s < BH_BN_SUM_SLOTS; ++s) t += bh_acc_read(buf + bn_sum_index(s, groups, grp, C, c, mom));
+    for (int s = 0; s < BH_BN_SUM_SLOTS; ++s) t += bh_acc_read(buf + bn_sum_index(s, groups, grp, C, c, mom), det);
     return t;
 }
 

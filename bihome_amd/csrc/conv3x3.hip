@@ -128,8 +128,8 @@ __device__ __forceinline__ void c3_epilogue(const C3Args& a, f32x16 (&acc)[TM], 
     if (a.bnr_z && valid) {                        // coefficients of the BatchNorm whose output gradient this tile is
         const int grp = img / a.imgs_per_group;
         const double rows = (double)a.bnr_rows;
-        const double mu = bn_sum_total(a.bnr_stats, a.groups, grp, a.Nn, n, 0) / rows;
-        double var = bn_sum_total(a.bnr_stats, a.groups, grp, a.Nn, n, 1) / rows - mu * mu;
+        const double mu = bn_sum_total(a.bnr_stats, a.groups, grp, a.Nn, n, 0, a.det) / rows;
+        double var = bn_sum_total(a.bnr_stats, a.groups, grp, a.Nn, n, 1, a.det) / rows - mu * mu;
         if (var < 0) var = 0;
         r_mean = (float)mu;
         r_invstd = 1.0f / sqrtf((float)var + a.bnr_eps);
@@ -894,9 +894,9 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
         a.bni = bni->table; a.bni_relu = bni->relu; a.bni_groups = bni->groups; a.bni_ipg = d->N / bni->groups;
     }
     // (all eight template arguments, as rocprofv3 prints the symbol: FLIP, BN, BF16, SUBT, PACKED, X3, BNI, NP)
-    // (the 4 x 4 map form prints its ninth template argument; every other instantiation has it defaulted to false)
-    if (bh_query(map4 ? "conv3x3_halo_kernel<%s,%d,%s,%d,%s,%s,%s,%d,true>" : "conv3x3_halo_kernel<%s,%d,%s,%d,%s,%s,%s,%d>", dgrad ? "true" : "false",
-                 bn_tile, bf16 ? "true" : "false", subt, packed ? "true" : "false", x3 ? "true" : "false", bni ? "true" : "false", np)) {
+    // (all nine template arguments, as rocprofv3 prints the symbol: FLIP, BN, BF16, SUBT, PACKED, X3, BNI, NP, MAP4)
+    if (bh_query("conv3x3_halo_kernel<%s,%d,%s,%d,%s,%s,%s,%d,%s>", dgrad ? "true" : "false", bn_tile, bf16 ? "true" : "false", subt,
+                 packed ? "true" : "false", x3 ? "true" : "false", bni ? "true" : "false", np, map4 ? "true" : "false")) {
         *taken = 1;
         return BH_OK;
     }

@@ -85,7 +85,8 @@ def _conv_variant(d, which, accumulate=False, bn_groups=0):
 def _bni_name(v):
     """The library's name of a plain launch with the BatchNorm-on-load template argument (second to last) switched on."""
     import re
-    return re.sub(r",false,(\d)>", r",true,\1>", v, count=1)
+    # conv3x3_halo_kernel<..,BNI,NP,MAP4> / wgrad_x3_kernel<CB,BNI,NP>
+    return re.sub(r",false,(\d)(,false)?>", r",true,\1\2>", v, count=1)
 
 
 def conv_flops(d):

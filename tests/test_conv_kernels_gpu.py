@@ -498,7 +498,7 @@ def test_conv3x3_packed_weights_match_lds_slab_path(K, N, H, Ci, Co, prec):
     pf, pd = pk.get(w)
     pk.refresh()
     dp = K._with_layout(d, 1)
-    assert K.conv_variant(dp, "fwd").endswith(",true,false,false,3>") and K.conv_variant(dp, "dgrad").endswith(",true,false,false,3>")
+    assert K.conv_variant(dp, "fwd").endswith(",true,false,false,3,false>") and K.conv_variant(dp, "dgrad").endswith(",true,false,false,3,false>")
     y0 = K.conv_fwd(x, wk, b, d)
     y1 = K.conv_fwd(x, wk, b, d, wpacked=pf)
     assert torch.equal(y0, y1)
@@ -561,8 +561,8 @@ def test_conv3x3_f32x3_is_fp32_accurate(K, N, H, Ci, Co, wide):
         pf, pd = pk.get(w)
         pk.refresh()
         dp = K._with_layout(d, 2 if prec == 2 else 1)
-        assert K.conv_variant(dp, "fwd").endswith(",true,true,false,3>" if prec == 2 else ",true,false,false,3>")
-        assert K.conv_variant(dp, "dgrad").endswith(",true,true,false,3>" if prec == 2 else ",true,false,false,3>")
+        assert K.conv_variant(dp, "fwd").endswith(",true,true,false,3,false>" if prec == 2 else ",true,false,false,3,false>")
+        assert K.conv_variant(dp, "dgrad").endswith(",true,true,false,3,false>" if prec == 2 else ",true,false,false,3,false>")
         y = K.conv_fwd(x, wk, b, d, wpacked=pf)
         s = K.bn_stats_buffer(1, Co, "cuda")
         assert torch.equal(y, K.conv_fwd(x, wk, b, d, bn_sums=s, groups=1, wpacked=pf))
@@ -836,7 +836,7 @@ def test_conv3x3_f32x2_two_piece_mode(K, N, H, Ci, Co):
             pf, pd = pk.get(w)
             pk.refresh()
             dp = K._with_layout(d, K.packed_layout(prec))
-            assert K.conv_variant(dp, "fwd").endswith(",true,true,false,%d>" % K.SPLIT_PIECES[prec])
+            assert K.conv_variant(dp, "fwd").endswith(",true,true,false,%d,false>" % K.SPLIT_PIECES[prec])
             y = K.conv_fwd(x, wk, b, d, wpacked=pf)
             s = K.bn_stats_buffer(1, Co, "cuda")
             assert torch.equal(y, K.conv_fwd(x, wk, b, d, bn_sums=s, groups=1, wpacked=pf))
