@@ -782,6 +782,7 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
     // stride-1 kernels store partial tiles, all others accumulate through integer-limb shadow entries; the last Co entries of
     // the workspace serve the bias gradient
     const bool det = ws && bh_deterministic();
+    if (det) ws_bytes &= ~7ll;                                          // (the bias entries at the end of the workspace are doubles)
     const long long bias_bytes = det ? (long long)(d->transposed ? d->Co : d->Co) * BH_ACC_WORDS * 8 : 0;
     if ((d->precision == 2 || d->precision == 3) && !(d->route & BH_ROUTE_WGRAD_GENERIC)) {
         // f32x3 / f32x2 arithmetic: the halo-tiled split-operand kernel (wgrad_x3.hip) takes the 3x3 layers with channels % 64 == 0

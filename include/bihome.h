@@ -35,7 +35,8 @@ int bh_device_arch(char* buf, int buflen);
 /* Deterministic mode (round 3; what torch.use_deterministic_algorithms is to the reference's ATen path, train.py:379-387).
  * By default cross-workgroup sums use hardware floating-point atomics, whose rounding depends on arrival order: two runs of the
  * same step differ in the last bits.  bh_set_deterministic(1) (process-wide, returns the previous setting; read at launch time,
- * so it must not change between the capture and the replays of a HIP graph) makes every launch of this library order-independent:
+ * so it must not change between a forward pass and its backward - the sums a forward leaves for the backward are encoded per mode - nor between
+ * the capture and the replays of a HIP graph) makes every launch of this library order-independent:
  *   - BatchNorm statistics / backward sums / bias column sums accumulated in conv epilogues: exact integer-limb accumulation inside
  *     the padded sums entries (csrc/common.h bh_det_add; the readers understand both encodings);
  *   - weight and bias gradients: bh_conv_wgrad_det with a workspace of bh_conv_wgrad_det_bytes(d) - partial tiles added in split
