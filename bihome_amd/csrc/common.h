@@ -122,8 +122,12 @@ __device__ __forceinline__ void mat3_mul(const double* a, const double* b, doubl
 // partial products of total order <= 2 (hi*hi, hi*mid, mid*hi, hi*lo, mid*mid, lo*hi) on v_mfma_f32_32x32x16_bf16 with fp32
 // accumulate; the three dropped ones are below 2^-23 |a*b| - the size of one fp32 rounding of the product.  Six 32-cycle
 // MFMAs contract 16 channels that cost eight 64-cycle v_mfma_f32_32x32x2_f32: 2.67x less matrix-pipe time.
-// bh_split8: 8 floats -> the 8 bf16 of each piece, element e in the low / high half of dword e/2 (5.5 VALU per element).
+// bh_split8: 8 floats -> the 8 bf16 of each piece, element e in the low / high half of dword e/2 (4.5 VALU per element).
+typedef __bf16 bh_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float bh_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void bh_split8(const float4& u, const float4& v, uint4& hi, uint4& mid, uint4& lo) {
+#ifdef BH_SPLIT_TRUNC
+    // (round 2 form, A/B builds: all three pieces by truncation)
     const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
     unsigned xb[8], rb[8], sb[8];
 #pragma unroll
@@ -141,14 +145,32 @@ __device__ __forceinline__ void bh_split8(const float4& u, const float4& v, uint
                      __builtin_amdgcn_perm(rb[5], rb[4], 0x07060302u), __builtin_amdgcn_perm(rb[7], rb[6], 0x07060302u));
     lo = make_uint4(__builtin_amdgcn_perm(sb[1], sb[0], 0x07060302u), __builtin_amdgcn_perm(sb[3], sb[2], 0x07060302u),
                     __builtin_amdgcn_perm(sb[5], sb[4], 0x07060302u), __builtin_amdgcn_perm(sb[7], sb[6], 0x07060302u));
+#else
+    // Round 3: hi by truncation (no overflow near FLT_MAX), mid and lo by v_cvt_pk_bf16_f32 (round to nearest even, two elements per
+    // instruction) - 4.5 instead of 5.5 VALU per element, and STILL EXACT: r = x - hi has <= 16 significant bits below hi's last place;
+    // mid = RNE(r) keeps r's top 8, so t = r - mid is at most half a unit of mid's last place - <= 8 significant bits and a sign, a bf16
+    // number - and lo = RNE(t) = t.  (A carry in the rounding makes mid a power of two and t negative: still <= 8 bits.)
+    const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned b0 = __builtin_bit_cast(unsigned, x[2 * e]), b1 = __builtin_bit_cast(unsigned, x[2 * e + 1]);
+        h[e] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);       // high halves of (x[2e+1], x[2e]): element 2e in the low half
+        const bh_f32x2 r = {x[2 * e] - __builtin_bit_cast(float, b0 & 0xFFFF0000u), x[2 * e + 1] - __builtin_bit_cast(float, b1 & 0xFFFF0000u)};
+        m[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bh_bf16x2));
+        const bh_f32x2 t = {r[0] - __builtin_bit_cast(float, m[e] << 16), r[1] - __builtin_bit_cast(float, m[e] & 0xFFFF0000u)};      // exact
+        l[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bh_bf16x2));
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    mid = make_uint4(m[0], m[1], m[2], m[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+#endif
 }
 
 // X2 ("f32x2": bh_conv_desc.precision = 3): two bf16 pieces per operand, both ROUNDED to nearest even (v_cvt_pk_bf16_f32):
 // x = hi + mid + e with |e| <= 2^-18 |x| and zero mean, and a product a*b is evaluated as hi*hi + hi*mid + mid*hi (three MFMAs;
 // the dropped mid*mid is <= 2^-18 |a*b| as well).  Error ~4e-6 per product: ~13x the fp32 rounding, ~500x below the bf16-operand
 // mode - a separately reported arithmetic, never the default.  2.5 VALU per element.
-typedef __bf16 bh_bf16x2 __attribute__((ext_vector_type(2)));
-typedef float bh_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void bh_split2_pair(float a, float b, unsigned& hi, unsigned& mid) {
     const bh_f32x2 v = {a, b};
     hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bh_bf16x2));
