@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <vector>
 #include <algorithm>
+#include <cstdlib>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ unsigned mix(unsigned x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
@@ -45,12 +46,13 @@ __global__ void __launch_bounds__(256) probe(unsigned long long* out, float* sin
     if (threadIdx.x % 64 == 0) { const int w = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64; out[w * 2] = c1 - c0; out[w * 2 + 1] = w1 - w0; }
     if (s == 12345.678f) sink[0] = s;
 }
-int main() {
+int main(int argc, char** argv) {
     unsigned long long* d; float* sink; uint4* gsrc;
     hipMalloc(&d, 1 << 20); hipMalloc(&sink, 4); hipMalloc(&gsrc, 16 << 20); hipMemset(gsrc, 0x3c, 16 << 20);
     const char* names[4] = {"constant operands", "random-bit operands", "random + 0.5 ds_read_b128 / MFMA", "random + LDS + 0.25 buffer_load / MFMA"};
+    const int ncu = argc > 1 ? atoi(argv[1]) : 256;       // compute units to occupy (workgroups = ncu x workgroups per CU)
     for (int mode = 0; mode < 4; ++mode) for (int wg_per_cu : {1, 2}) {
-        const int iters = 2048, nwg = 256 * wg_per_cu, nw = nwg * 4;
+        const int iters = 2048, nwg = ncu * wg_per_cu, nw = nwg * 4;
         for (int rep = 0; rep < 3; ++rep) {
             if (mode == 0) hipLaunchKernelGGL(probe<0>, dim3(nwg), dim3(256), 0, 0, d, sink, gsrc, iters);
             if (mode == 1) hipLaunchKernelGGL(probe<1>, dim3(nwg), dim3(256), 0, 0, d, sink, gsrc, iters);
@@ -65,7 +67,7 @@ int main() {
         for (int w = 0; w < nw; ++w) { cyc.push_back(h[2 * w] / n); ns.push_back(h[2 * w + 1] * 10.0 / n); }
         std::sort(cyc.begin(), cyc.end()); std::sort(ns.begin(), ns.end());
         printf("%-40s %d WG/CU: ticks per MFMA per wave p50 %.2f; wall ns per MFMA per wave p50 %.2f; clock %.0f MHz; chip rate %.0f TFLOP/s\n",
-               names[mode], wg_per_cu, cyc[nw / 2], ns[nw / 2], 1e3 * cyc[nw / 2] / ns[nw / 2], 1024.0 * wg_per_cu * 32768.0 / ns[nw / 2] * 1e-3);
+               names[mode], wg_per_cu, cyc[nw / 2], ns[nw / 2], 1e3 * cyc[nw / 2] / ns[nw / 2], 4.0 * ncu * wg_per_cu * 32768.0 / ns[nw / 2] * 1e-3);
     }
     return 0;
 }
