@@ -67,3 +67,31 @@ def test_bench_refuses_more_ranks_than_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env2,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "n_gpus" not in r.stdout and "WORLD_SIZE=1" in r.stderr
+
+
+def test_bench_json_line_contract():
+    """`python bench.py` (N = 1, few steps): ONE JSON line with the fields the driver and the judge read - metric / value / unit / n_gpus /
+    steps / warmup / ms_per_step / scaling / dtype / config.workload, `roofline` (bound, achieved, peak, unit, frac, traffic, the measured
+    peaks of the same run) and `cpu_baseline` (value, unit, cores, kind, sample)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "hbm_path_frac"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["dtype"] == "f32"
+    assert d["unit"] == "image-pairs/s" and d["value"] > 1000 and "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "measured_peaks", "frac_of_measured_peak"):
+        assert k in rf, k
+    assert rf["bound"] in ("mfma", "hbm") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert rf["kernel"].startswith("conv3x3_halo_kernel<") and rf["kernel"].count(",") == 8        # all nine template arguments, as rocprofv3 prints them
+    assert 0.2 < rf["frac"] < 1.0 and rf["frac"] < rf["frac_of_measured_peak"] < 1.2
+    assert rf["measured_peaks"]["bf16_mfma_random_operands_TFLOPs"] < rf["measured_peaks"]["bf16_mfma_constant_operands_TFLOPs"] <= 2600
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
