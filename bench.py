@@ -40,6 +40,16 @@ def x3_pieces(kernel):
         if len(args) >= 6 and args[5] == "true":
             return int(args[7]) if len(args) >= 8 else 3
     return 0
+F16X2_TEXT = ("fp32 tensors, fp32 accumulate; 3x3 / stride-1 convs (fwd, dgrad, wgrad): each fp32 operand times a power-of-two scale per "
+              "tensor as two FP16 pieces (22 significand bits and a sign), 3 partial products per product on v_mfma_f32_32x32x16_f16 "
+              "(~2^-22 per product; error vs float64 <= the fp32-input MFMA form: tests/test_f16x2_gpu.py), results rescaled exactly; all "
+              "other convs: v_mfma_f32_32x32x2_f32")
+def x3_is_f16(kernel):
+    """fp16 pieces with per-tensor scales (the last template argument of both split-operand kernels; v_mfma_f32_32x32x16_f16)."""
+    args = kernel.split(">")[0].split(",")
+    return bool(x3_pieces(kernel)) and len(args) in (4, 10) and args[-1] == "true"
+
+
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 
 
@@ -50,7 +60,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=None, help="image pairs per GPU (default: the config's DATA.BATCH_SIZE)")
     ap.add_argument("--config", default="zeng-bihome")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f32-mfma", "bf16", "f32x2"],
+    ap.add_argument("--precision", default="f32", choices=["f32", "f32x3", "f32-mfma", "bf16", "f32x2", "f16x2"],
                     help="conv operand precision; the headline config (BASELINE.json configs[1]) is f32")
     ap.add_argument("--gpu-datagen", action="store_true",
                     help="draw a fresh batch every step with the device-side pair generator (bh_synth_pairs) inside the "
@@ -186,7 +196,9 @@ def roofline_leg(model, data, opt, sched, reducer, nsteps=2):
         ex = nprod * top["tflops"]
         roof = {"kernel": top["kernel"], "bound": "mfma", "achieved": ex, "peak": PEAK_BF16_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": ex / PEAK_BF16_MFMA_TFLOPS, "traffic": traffic,
-                "mfma": "v_mfma_f32_32x32x16_bf16, %d products per fp32 product (operands cut into %d bf16 pieces)"
+                "mfma": ("v_mfma_f32_32x32x16_f16, %d products per fp32 product (operands times a power-of-two scale per tensor as %d fp16 pieces)"
+                         if x3_is_f16(top["kernel"]) else
+                         "v_mfma_f32_32x32x16_bf16, %d products per fp32 product (operands cut into %d bf16 pieces)")
                         % (nprod, x3_pieces(top["kernel"])),
                 "algorithmic_tflops": top["tflops"], "fp32_equivalent_frac_of_f32_mfma_peak": top["tflops"] / PEAK_F32_MFMA_TFLOPS,
                 "traffic_source": traffic_src, "algorithmic_bytes_per_launch": top["bytes_per_launch"],
@@ -413,7 +425,7 @@ def main():
             "metric": "training image-pairs/s (%dx%d patch, bs=%d per GPU, full step: fwd+bwd+Adam)" % (P, P, B),
             "value": value, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"f32": "f32", "f32-mfma": "f32", "bf16": "bf16", "f32x2": "f32x2"}[args.precision],
+            "dtype": {"f32": "f32", "f32x3": "f32", "f16x2": "f32", "f32-mfma": "f32", "bf16": "bf16", "f32x2": "f32x2"}[args.precision],
             "data": "synthetic (seeded COCO-style texture pairs, random-init weights%s)" % (
                 "; fresh batch per step from the device-side generator" if args.gpu_datagen else "; one resident batch"),
             "config": {"workload": "%s: %s backbone + %s head, %d pairs/GPU, %dx%d %s, %s MFMA conv + HIP "
@@ -421,12 +433,12 @@ def main():
                                        WORKLOADS.get(args.config, args.config), cfg["MODEL"]["BACKBONE"]["NAME"],
                                        cfg["MODEL"]["HEAD"]["NAME"], B, P, P,
                                        "RGB" if CH == 3 else "grayscale", args.precision),
-                       "arithmetic": {"f32": "fp32 tensors, fp32 accumulate; 3x3 / stride-1 convs (fwd, dgrad, wgrad): each fp32 operand cut "
-                                             "exactly into 3 bf16 pieces, 6 partial products per product on v_mfma_f32_32x32x16_bf16 "
-                                             "(error vs float64 <= the fp32-input MFMA form: tests/test_conv_kernels_gpu.py); all "
-                                             "other convs: v_mfma_f32_32x32x2_f32",
+                       "arithmetic": {"f32": F16X2_TEXT,
+                                      "f32x3": "fp32 tensors, fp32 accumulate; 3x3 / stride-1 convs (fwd, dgrad, wgrad): each fp32 operand cut "
+                                               "exactly into 3 bf16 pieces, 6 partial products per product on v_mfma_f32_32x32x16_bf16; all "
+                                               "other convs: v_mfma_f32_32x32x2_f32 (the default arithmetic of rounds 2-3)",
                                       "f32-mfma": "fp32 tensors, v_mfma_f32_32x32x2_f32 everywhere",
-                                      "bf16": "fp32 tensors, conv operands rounded to bf16, fp32 accumulate",
+                                      "f16x2": F16X2_TEXT,
                                       "f32x2": "REDUCED precision (not the headline): fp32 tensors, fp32 accumulate; 3x3 / stride-1 convs: each "
                                                "operand as two bf16 pieces rounded to nearest (x = hi + mid + e, |e| <= 2^-18 |x|), 3 partial "
                                                "products per product on v_mfma_f32_32x32x16_bf16 (~4e-6 per product); all other convs: "

@@ -18,7 +18,12 @@ LIB_PATH = os.path.join(_HERE, "libbihome_hip_tuning.so" if TUNING else
 
 class BhConvDesc(Structure):
     _fields_ = [(n, c_int) for n in ("N", "Hi", "Wi", "Ci", "Ho", "Wo", "Co", "kh", "kw", "stride", "pad",
-                                     "transposed", "in_nchw", "out_nchw", "precision", "w_layout", "route")]
+                                     "transposed", "in_nchw", "out_nchw", "precision", "w_layout", "route")] + \
+               [("a_bound", c_void_p), ("b_bound", c_void_p)]      # per-call magnitude records (precision 4 only)
+
+
+GEOMETRY_FIELDS = tuple(n for n, _ in BhConvDesc._fields_[:17])       # what kernel routing depends on (cache keys)
+AMAX_FLOATS = 512                                                     # floats of a magnitude record (include/bihome.h BH_AMAX_FLOATS)
 
 
 class BhPack3x3Job(Structure):
@@ -66,6 +71,11 @@ SIGNATURES = {
     "bh_zhang_triplet_fwd": [P] * 8 + [c_int, c_int, c_float, c_int, P, P, P, P],
     "bh_zhang_triplet_bwd": [P] * 12 + [c_int, c_int, c_int] + [P] * 6 + [P],
     "bh_conv3x3_pack": [P, c_int, P],
+    "bh_conv3x3_pack_f16": [P, c_int, P],
+    "bh_absmax": [P, c_int64, P, P],
+    "bh_bn_fwd_coeffs_amax": [P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, P, P, P],
+    "bh_bn_fwd_amax": [P] * 8 + [c_int, c_int, c_int, c_float, c_float, c_int, c_int, P, P],
+    "bh_bn_bwd_amax": [P] * 11 + [c_int, c_int, c_int, c_float, c_int, c_int, P, P, P, P],
     "bh_conv_variant": [POINTER(BhConvDesc), c_int, c_int, c_int, c_char_p, c_int],
     "bh_conv_fwd": [P, P, P, P, POINTER(BhConvDesc), P],
     "bh_conv_fwd_act": [P, P, P, P, P, POINTER(BhConvDesc), c_int, P],

@@ -143,7 +143,10 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ rvar, const float* __restrict__ res,
                                                        float* __restrict__ y, const double* __restrict__ stats, BnGeom g,
                                                        float eps, int flags, int use_running, float momentum,
-                                                       float* __restrict__ upd_mean, float* __restrict__ upd_var) {
+                                                       float* __restrict__ upd_mean, float* __restrict__ upd_var,
+                                                       unsigned* __restrict__ amax) {
+    __shared__ float sm_amax[4];
+    float vmax = 0.f;                                         // amax != NULL: max |y| of this thread's elements (magnitude record, common.h F16X2)
     const int cq = threadIdx.x % g.LPR, r0 = threadIdx.x / g.LPR;
     const int grp = blockIdx.y;
     BnRaw raw[4];
@@ -178,6 +181,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__
             if (addres) { o.x += q[u].x; o.y += q[u].y; o.z += q[u].z; o.w += q[u].w; }
             if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
             *reinterpret_cast<float4*>(y + gbase + (size_t)rr * g.C) = o;
+            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         }
         r += 4 * stride;
         if (r >= g.rows) break;
@@ -188,6 +192,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__
             q[u] = (addres && rr < g.rows) ? *reinterpret_cast<const float4*>(res + gbase + (size_t)rr * g.C) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
+    if (amax) bh_amax_commit(amax, vmax, blockIdx.x + blockIdx.y * 7u, sm_amax);
 }
 
 // backward reduce: grid (nchunks, groups)
@@ -293,7 +298,10 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
                                                            float* __restrict__ gx, float* __restrict__ gres, BnGeom g,
                                                            int flags, const double* __restrict__ stats,
                                                            const double* __restrict__ sums, float eps,
-                                                           float* __restrict__ ggamma, float* __restrict__ gbeta) {
+                                                           float* __restrict__ ggamma, float* __restrict__ gbeta,
+                                                           unsigned* __restrict__ amax) {
+    __shared__ float sm_amax[4];
+    float vmax = 0.f;                                         // amax != NULL: max |gx| (magnitude record of the gradient, common.h F16X2)
     const int cq = threadIdx.x % g.LPR, r0 = threadIdx.x / g.LPR;
     const int grp = blockIdx.y;
     // table loads first, then the data loads of the first pass, then the coefficient arithmetic (see bn_raw)
@@ -383,11 +391,13 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
             o.z = sc[2] * (d.z - k1[2] - (a.z - mean[2]) * invstd[2] * k2[2]);
             o.w = sc[3] * (d.w - k1[3] - (a.w - mean[3]) * invstd[3] * k2[3]);
             *reinterpret_cast<float4*>(gx + off) = o;
+            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         }
         r += 4 * stride;
         if (r >= g.rows) break;
         issue(r);
     }
+    if (amax) bh_amax_commit(amax, vmax, blockIdx.x + blockIdx.y * 7u, sm_amax);
 }
 
 BH_KNOB(g_bn_apply_cap, 512);        // workgroups per apply launch: two per CU that loop beat a one-shot grid of 2048 by 15-30 % (tools/bn_apply_sweep.py; tuning: bh_debug_force_tile(-20, n))
@@ -409,14 +419,20 @@ static int apply_blocks(const BnGeom& g) {
 __global__ void __launch_bounds__(256) bn_fwd_coeffs_kernel(const double* __restrict__ stats, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, BnGeom g, float eps, float momentum,
                                                             float* __restrict__ upd_mean, float* __restrict__ upd_var,
-                                                            float2* __restrict__ table) {
+                                                            float2* __restrict__ table, unsigned* __restrict__ amax) {
+    __shared__ float sm_amax[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
+    float bound = 0.f;
     if (i < g.groups * g.C) {
         const int grp = i / g.C, c = i - grp * g.C;
         float mean, invstd, sc, sh;
         bn_coeffs(stats, gamma, beta, nullptr, nullptr, 0, g.groups, grp, g.C, c, eps, (double)g.rows, mean, invstd, sc, sh, g.det);
         table[i] = make_float2(sc, sh);
+        // |y| = |gamma xhat + beta| <= |gamma| sqrt(rows - 1) + |beta| for ANY data (a sample is at most sqrt(rows - 1) standard deviations
+        // from the mean of its rows); one binade of margin for the rounding of the sums and of the fused multiply-add
+        bound = 2.0f * (fabsf(gamma ? gamma[c] : 1.f) * sqrtf((float)g.rows) + fabsf(beta ? beta[c] : 0.f));
     }
+    if (amax) bh_amax_commit(amax, bound, blockIdx.x, sm_amax);
     if (upd_mean && blockIdx.x == 0) bn_update_running(stats, g, momentum, upd_mean, upd_var);
 }
 
@@ -444,10 +460,16 @@ int bh_bn_stats_doubles(int groups, int C) { return (int)BH_BN_SUM_DOUBLES(group
 int bh_bn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
               const float* res, float* y, double* stats, int groups, int rows, int C, float eps, float momentum,
               int flags, int use_running, void* stream) {
+    return bh_bn_fwd_amax(x, gamma, beta, running_mean, running_var, res, y, stats, groups, rows, C, eps, momentum, flags, use_running, nullptr, stream);
+}
+
+int bh_bn_fwd_amax(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                   const float* res, float* y, double* stats, int groups, int rows, int C, float eps, float momentum,
+                   int flags, int use_running, float* amax_y, void* stream) {
     BnGeom g;
     if (!x || !y || !stats) return BH_E_BADARG;
     if (use_running && (!running_mean || !running_var)) return BH_E_BADARG;
-    if (C == 1) return bn1_fwd(x, gamma, beta, running_mean, running_var, res, y, stats, groups, rows, eps, momentum, flags, use_running, bh_stream(stream));
+    if (C == 1) return amax_y ? BH_E_UNSUPPORTED : bn1_fwd(x, gamma, beta, running_mean, running_var, res, y, stats, groups, rows, eps, momentum, flags, use_running, bh_stream(stream));
     if (!bn_geom(groups, rows, C, g)) return BH_E_UNSUPPORTED;
     hipStream_t s = bh_stream(stream);
     if (!use_running && !(flags & 8)) {                       // bit 3: the producer already accumulated the sums
@@ -457,19 +479,25 @@ int bh_bn_fwd(const float* x, const float* gamma, const float* beta, float* runn
     const bool upd = !use_running && running_mean && running_var;
     hipLaunchKernelGGL(bn_apply_kernel, dim3(apply_blocks(g), groups), dim3(256), 0, s, x, gamma, beta, running_mean,
                        running_var, res, y, stats, g, eps, flags, use_running, momentum, upd ? running_mean : nullptr,
-                       upd ? running_var : nullptr);
+                       upd ? running_var : nullptr, reinterpret_cast<unsigned*>(amax_y));
     BH_LAUNCH_CHECK();
     return BH_OK;
 }
 
 int bh_bn_fwd_coeffs(const double* stats, const float* gamma, const float* beta, float* running_mean, float* running_var, int groups,
                      int rows, int C, float eps, float momentum, float* table, void* stream) {
+    return bh_bn_fwd_coeffs_amax(stats, gamma, beta, running_mean, running_var, groups, rows, C, eps, momentum, table, nullptr, stream);
+}
+
+int bh_bn_fwd_coeffs_amax(const double* stats, const float* gamma, const float* beta, float* running_mean, float* running_var, int groups,
+                          int rows, int C, float eps, float momentum, float* table, float* amax_y, void* stream) {
     BnGeom g;
     if (!stats || !table) return BH_E_BADARG;
     if (!bn_geom(groups, rows, C, g)) return BH_E_UNSUPPORTED;
     const bool upd = running_mean && running_var;
     hipLaunchKernelGGL(bn_fwd_coeffs_kernel, dim3((groups * C + 255) / 256), dim3(256), 0, bh_stream(stream), stats, gamma, beta, g, eps,
-                       momentum, upd ? running_mean : nullptr, upd ? running_var : nullptr, reinterpret_cast<float2*>(table));
+                       momentum, upd ? running_mean : nullptr, upd ? running_var : nullptr, reinterpret_cast<float2*>(table),
+                       reinterpret_cast<unsigned*>(amax_y));
     BH_LAUNCH_CHECK();
     return BH_OK;
 }
@@ -477,17 +505,25 @@ int bh_bn_fwd_coeffs(const double* stats, const float* gamma, const float* beta,
 int bh_bn_bwd(const float* gy, const float* y, const float* x, const float* gamma, const float* beta, const double* stats, float* gx,
               float* gres, float* ggamma, float* gbeta, double* scratch, int groups, int rows, int C, float eps, int flags,
               int use_running, const float* running_mean, const float* running_var, void* stream) {
+    return bh_bn_bwd_amax(gy, y, x, gamma, beta, stats, gx, gres, ggamma, gbeta, scratch, groups, rows, C, eps, flags, use_running, running_mean,
+                          running_var, nullptr, stream);
+}
+
+int bh_bn_bwd_amax(const float* gy, const float* y, const float* x, const float* gamma, const float* beta, const double* stats, float* gx,
+                   float* gres, float* ggamma, float* gbeta, double* scratch, int groups, int rows, int C, float eps, int flags,
+                   int use_running, const float* running_mean, const float* running_var, float* amax_gx, void* stream) {
     BnGeom g;
     if (!gy || !x || !gx || !stats || !scratch || ((flags & 1) && !(flags & 4) && !y)) return BH_E_BADARG;
     if ((flags & 4) && (flags & 2)) return BH_E_BADARG;        // the mask can only be recomputed without a residual input
-    if (C == 1) return bn1_bwd(gy, y, x, gamma, beta, stats, gx, gres, ggamma, gbeta, scratch, groups, rows, eps, flags, use_running,
+    if (C == 1) return amax_gx ? BH_E_UNSUPPORTED : bn1_bwd(gy, y, x, gamma, beta, stats, gx, gres, ggamma, gbeta, scratch, groups, rows, eps, flags, use_running,
                                running_mean, running_var, bh_stream(stream));
     if (!bn_geom(groups, rows, C, g)) return BH_E_UNSUPPORTED;
     hipStream_t s = bh_stream(stream);
     if (flags & 16) {            // scratch = padded sums accumulated by bh_conv_dgrad_bnreduce (training mode only)
         if (use_running) return BH_E_BADARG;
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(apply_blocks(g), groups), dim3(256), 0, s, gy, y, x, gamma, beta,
-                           (const float4*)nullptr, gx, gres, g, flags, stats, (const double*)scratch, eps, ggamma, gbeta);
+                           (const float4*)nullptr, gx, gres, g, flags, stats, (const double*)scratch, eps, ggamma, gbeta,
+                           reinterpret_cast<unsigned*>(amax_gx));
         BH_LAUNCH_CHECK();
         return BH_OK;
     }
@@ -508,7 +544,7 @@ int bh_bn_bwd(const float* gy, const float* y, const float* x, const float* gamm
     BH_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(apply_blocks(g), groups), dim3(256), 0, s, gy, y, x, gamma, beta, coef,
                        gx, gres, g, flags, (const double*)nullptr, (const double*)nullptr, eps, (float*)nullptr,
-                       (float*)nullptr);
+                       (float*)nullptr, reinterpret_cast<unsigned*>(amax_gx));
     BH_LAUNCH_CHECK();
     return BH_OK;
 }

@@ -189,3 +189,63 @@ __device__ __forceinline__ void bh_split8_np(const float4& u, const float4& v, u
     if constexpr (NP == 3) bh_split8(u, v, p[0], p[1], p[2]);
     else bh_split8_2(u, v, p[0], p[1]);
 }
+
+// F16X2 ("f16x2": bh_conv_desc.precision = 4, round 4): two FP16 pieces per operand with a power-of-two scale per tensor.
+//   x * 2^k = hi + lo + e,  hi = rn16(x 2^k), lo = rn16(x 2^k - hi)  (the difference is exact in fp32): 11 + 11 significand bits and a
+// sign, |e| <= 2^-23 |x 2^k| as long as lo is a normal fp16 number, <= 2^-25 (absolute, scaled units) below that.  A product is
+// hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 (each piece product exact in the fp32 accumulate; tools/f16_probe.hip: subnormal
+// fp16 inputs are NOT flushed); the dropped lo*lo is <= 2^-22 |a b|.  Per product ~2^-22: 16x below f32x2, one or two fp32 roundings.
+// The scale makes max |x 2^k| land in [2^14, 2^15) (fp16 overflows at 65504): k comes from a MAGNITUDE RECORD of the tensor - an
+// upper bound of max |x| that its producer left (BatchNorm apply kernels: measured; BatchNorm-on-load: |gamma| sqrt(rows) + |beta|;
+// bh_absmax: a streaming pass) - BH_AMAX_SLOTS words, one per 128-byte line, combined with max (workgroups of a producer spread their
+// integer atomic max over the slots).  Elements within 2^-18 of the bound keep all 22 bits; smaller ones degrade to an absolute error of
+// 2^-40 of the bound.  Results are rescaled by 2^-(ka + kb) in the epilogue (v_ldexp_f32: exact).
+#define BH_AMAX_SLOTS 16
+#define BH_AMAX_STRIDE 32                   // words between slots (128 bytes)
+#define BH_AMAX_WORDS (BH_AMAX_SLOTS * BH_AMAX_STRIDE)
+typedef _Float16 bh_f16x2 __attribute__((ext_vector_type(2)));
+// scale exponent for a tensor whose magnitudes are bounded by the float with these bits (>= 0): bound * 2^k in [2^14, 2^15)
+__host__ __device__ __forceinline__ int bh_f16_scale_exp(unsigned bound_bits) {
+    const int e = (int)((bound_bits >> 23) & 0xFFu);          // biased exponent (0: zero / subnormal bound)
+    int k = 14 - (e - 127);
+    if (e == 0xFF) k = 0;                                      // inf / NaN bound: no scaling, the non-finite values propagate
+    return k > 100 ? 100 : (k < -100 ? -100 : k);
+}
+// all 64 lanes: the record's maximum (lanes 0..15 load one slot each)
+__device__ __forceinline__ unsigned bh_amax_read(const unsigned* __restrict__ rec, int lane) {
+    unsigned v = lane < BH_AMAX_SLOTS ? rec[lane * BH_AMAX_STRIDE] : 0u;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)v, off, 64); v = o > v ? o : v; }
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+// a workgroup's contribution: every thread passes its own maximum of |values| (as float); one atomic per workgroup
+__device__ __forceinline__ void bh_amax_commit(unsigned* __restrict__ rec, float m, unsigned slot_seed, float* sm4 /* LDS, >= blockDim/64 floats */) {
+    m = wave_max(m);
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) sm4[wave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < nw; ++w) m = fmaxf(m, sm4[w]);
+        // NaN: fmaxf drops it; a NaN in the data shows up through the products themselves.  (bits of a non-negative float order like integers)
+        atomicMax(rec + (slot_seed % BH_AMAX_SLOTS) * BH_AMAX_STRIDE, __builtin_bit_cast(unsigned, m));
+    }
+}
+__device__ __forceinline__ void bh_split2_pair_f16(float a, float b, float s, unsigned& hi, unsigned& lo) {
+    const bh_f32x2 v = {a * s, b * s};
+    const bh_f16x2 h = __builtin_convertvector(v, bh_f16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    const bh_f32x2 r = {__builtin_fmaf(a, s, -(float)h[0]), __builtin_fmaf(b, s, -(float)h[1])};      // exact
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bh_f16x2));
+}
+__device__ __forceinline__ void bh_split8_f16(const float4& u, const float4& v, float s, uint4& hi, uint4& lo) {
+    bh_split2_pair_f16(u.x, u.y, s, hi.x, lo.x);
+    bh_split2_pair_f16(u.z, u.w, s, hi.y, lo.y);
+    bh_split2_pair_f16(v.x, v.y, s, hi.z, lo.z);
+    bh_split2_pair_f16(v.z, v.w, s, hi.w, lo.w);
+}
+// NP pieces of 8 floats in the arithmetic of the kernel: F16 = false -> bf16 pieces (s unused), true -> two fp16 pieces of x * s
+template <int NP, bool F16>
+__device__ __forceinline__ void bh_split8_any(const float4& u, const float4& v, float s, uint4 (&p)[3]) {
+    if constexpr (F16) { static_assert(NP == 2, "fp16 pieces: two"); bh_split8_f16(u, v, s, p[0], p[1]); }
+    else bh_split8_np<NP>(u, v, p);
+}

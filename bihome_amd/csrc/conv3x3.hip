@@ -49,7 +49,15 @@ __device__ unsigned long long g_c3_ts[8 * 16384];
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x8v __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+// one split-operand MFMA step (16 channels): bf16 pieces or fp16 pieces (F16X2, common.h)
+template <bool F16>
+__device__ __forceinline__ f32x16 c3_mfma16(const uint4& av, const uint4& bv, const f32x16& c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
+}
 
 // two k-planes (2 x float4) of a fragment -> the 8 bf16 operands of one v_mfma_f32_32x32x16_bf16 lane (round to nearest even)
 __device__ __forceinline__ bf16x8 c3_pack_bf16(const float4& lo, const float4& hi) {
@@ -98,6 +106,9 @@ struct C3Args {
     int dbg_noload;        // ablation bits: 1 no weight-slab DMA in the loop, 2 no halo DMA in the loop (wrong results, timing only)
     int dbg_ts;            // BH_TUNING: record phase time stamps into g_c3_ts
     int det;               // deterministic mode: the statistics / backward sums go through integer limbs (common.h bh_det_add)
+    // F16 (two fp16 pieces, common.h F16X2): magnitude record of Src (BH_AMAX_WORDS words); the weights' sixteen partial maxima sit
+    // behind their pieces (word w_bytes / 4 of Wt, written by pack_weights_amax_kernel)
+    const unsigned* amax_src;
 };
 
 constexpr int C3_HALO_BYTES = 8 * 200 * 16;          // 25600
@@ -306,9 +317,13 @@ __device__ __forceinline__ void c3_stats_merge(const C3Args& a, char* redb, doub
 // MAP4 (X3, SUBT = 1, BN = 64 only; round 3): 4 x 4 feature maps (the 512-channel layer4 of the ResNet-34 regressor) - a "sub-tile" of 64
 // GEMM rows is FOUR IMAGES, each with its own 6 x 6 zero-padded halo (144 halo slots instead of 100); a wave's 8 x 4 pixel strip is the
 // two images 2 wh, 2 wh + 1, a tap is the shift dy * 6 + dx.  Same loop, same fragment reads.
-template <bool FLIP, int BN, bool BF16 = false, int SUBT = 2, bool PACKED = false, bool X3 = false, bool BNI = false, int NP = 3, bool MAP4 = false>
+// F16 (X3, NP = 2; round 4): the two pieces are FP16 numbers of the operand times a power-of-two scale per tensor ("f16x2", precision 4,
+// w_layout 4; common.h F16X2) - same loop, same LDS image as NP = 2, ~2^-22 per product instead of 2^-18; the accumulators are
+// rescaled by 2^-(k_src + k_w) in front of the epilogue.
+template <bool FLIP, int BN, bool BF16 = false, int SUBT = 2, bool PACKED = false, bool X3 = false, bool BNI = false, int NP = 3, bool MAP4 = false, bool F16 = false>
 __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a) {
     static_assert(NP == 3 || (NP == 2 && X3), "two pieces: split form only");
+    static_assert(!F16 || (X3 && NP == 2), "fp16 pieces: the two-piece split form");
     static_assert(!MAP4 || (X3 && SUBT == 1 && BN == 64 && !BNI), "the 4 x 4 map form: split operands, one sub-tile, 64-channel tile");
     constexpr int SLOTS = MAP4 ? 144 : 100;                // halo slots of a sub-tile per k-plane
     constexpr int ROWP = MAP4 ? 6 : 10;                    // halo row pitch
@@ -332,6 +347,18 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
     constexpr unsigned OOB = 0xFFFFFFF0u;
     __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Src), 0, a.src_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wt), 0, a.w_bytes, 0x00020000);
+    float f16_s = 1.0f;                                  // F16: 2^k_src, and the exponent that undoes both scales
+    int f16_kout = 0;
+    if constexpr (F16) {
+        const unsigned* const wrec = reinterpret_cast<const unsigned*>(a.Wt) + (a.w_bytes >> 2);
+        unsigned wv = lane < 16 ? wrec[lane] : 0u;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)wv, off, 64); wv = o > wv ? o : wv; }
+        const int kw = bh_f16_scale_exp((unsigned)__builtin_amdgcn_readfirstlane((int)wv));
+        const int ka = bh_f16_scale_exp(bh_amax_read(a.amax_src, lane));
+        f16_s = __builtin_bit_cast(float, (unsigned)(127 + ka) << 23);
+        f16_kout = -(ka + kw);
+    }
 
     // ---- weight slab slots ----
     unsigned boff[2] = {0u, 0u};    // (fixed size: a template-dependent array type as a builtin operand silently drops
@@ -508,7 +535,7 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
         if ((j) * 256 + wave * 64 < 4 * HPL && (j) * 256 + tid < 4 * HPL) {                                             \
             uint4 p_[3];                                                                                                \
             X3_BNI(j, c, h);                                                                                            \
-            bh_split8_np<NP>(h[0], h[1], p_);                                                                           \
+            bh_split8_any<NP, F16>(h[0], h[1], f16_s, p_);                                                              \
             char* d_ = smem + (hs) * HALO_B + ((j) * 256 + tid) * 16;                                                   \
             _Pragma("unroll") for (int pc_ = 0; pc_ < NP; ++pc_)                                                        \
                 *reinterpret_cast<uint4*>(d_ + pc_ * 4 * HPL * 16) = p_[pc_];                                           \
@@ -529,8 +556,7 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
         float4 hb[2][2];
 #define X3_MFMA(afc, bc, s2, PA, PB)                                                                                    \
     _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                      \
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afc[i][s2][PA]),                     \
-                                                         __builtin_bit_cast(bf16x8, bc[(PB) * 2 + (s2)]), acc[i], 0, 0, 0)
+        acc[i] = c3_mfma16<F16>(afc[i][s2][PA], bc[(PB) * 2 + (s2)], acc[i])
         // A fragments of one tap: [fragment][16-channel step][piece], 4 * NP ds_read_b128 per wave (TM = 2)
 #define X3_LOAD_A(dst, ap)                                                                                              \
     _Pragma("unroll") for (int s2_ = 0; s2_ < 2; ++s2_)                                                                 \
@@ -796,6 +822,12 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a)
 #undef C3_LOAD_BX
 
     C3_STAMP(bx * gridDim.y + blockIdx.y, 2);
+    if constexpr (F16) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = __builtin_ldexpf(acc[i][r], f16_kout);
+    }
     double s1, s2;
     int img, g;
     c3_epilogue<BN, SUBT, TM, MAP4>(a, acc, bx, n0, wm, wn, wh, l31, kh2, s1, s2, img, g);
@@ -833,20 +865,24 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
     *taken = 0;
     // (packed weights only make sense to this kernel: a caller that passes them must have asked bh_conv_variant first)
     if ((d->route & BH_ROUTE_GENERIC_CONV) || d->transposed || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->in_nchw ||
-        d->out_nchw || d->precision < 0 || d->precision > 3)
+        d->out_nchw || d->precision < 0 || d->precision > 4)
         return d->w_layout ? BH_E_UNSUPPORTED : 0;
-    // split weights <-> their precision: w_layout 2 = three pieces (precision 2), w_layout 3 = two pieces (precision 3)
-    if (d->w_layout != 0 && ((d->w_layout == 2) != (d->precision == 2) || (d->w_layout == 3) != (d->precision == 3))) return BH_E_BADARG;
+    // split weights <-> their precision: w_layout 2 = three bf16 pieces (precision 2), 3 = two bf16 pieces (precision 3), 4 = two fp16
+    // pieces with power-of-two scales (precision 4: needs the magnitude record of the source tensor, bh_conv_desc.a_bound)
+    if (d->w_layout != 0 && ((d->w_layout == 2) != (d->precision == 2) || (d->w_layout == 3) != (d->precision == 3) ||
+                             (d->w_layout == 4) != (d->precision == 4))) return BH_E_BADARG;
+    if (d->w_layout == 4 && !d->a_bound) return BH_E_BADARG;
     // 4 x 4 maps (round 3: layer4 of the ResNet-34 regressor): split-operand form only, four images per sub-tile
-    const bool map4 = d->Hi == 4 && d->Wi == 4 && d->Ho == 4 && d->Wo == 4 && d->N % 4 == 0 && (d->w_layout == 2 || d->w_layout == 3) &&
+    const bool map4 = d->Hi == 4 && d->Wi == 4 && d->Ho == 4 && d->Wo == 4 && d->N % 4 == 0 && (d->w_layout >= 2 && d->w_layout <= 4) &&
                       d->Co % 64 == 0 && d->Ci % 64 == 0 && !bni && (!bn_sums || (groups >= 1 && d->N % groups == 0 && (d->N / groups) % 4 == 0));
     if (!map4 && (d->Hi % 8 || d->Wi % 8 || d->Ho != d->Hi || d->Wo != d->Wi)) return d->w_layout ? BH_E_UNSUPPORTED : 0;
     const int Kc = dgrad ? d->Co : d->Ci, Nn = dgrad ? d->Ci : d->Co;
     if (Kc % 32 || Nn % 32) return d->w_layout ? BH_E_UNSUPPORTED : 0;
     const int bn_tile = (Nn % 64) ? 32 : 64;
     const bool packed = d->w_layout != 0;              // weights in bh_conv3x3_pack fragment order (this direction's buffer)
-    const bool x3 = d->w_layout == 2 || d->w_layout == 3;   // ... cut into three / two bf16 pieces (6 / 4 bytes per weight)
-    const int np = d->w_layout == 3 ? 2 : 3;
+    const bool x3 = d->w_layout >= 2 && d->w_layout <= 4;   // ... cut into three / two bf16 pieces or two fp16 pieces (6 / 4 / 4 bytes per weight)
+    const int np = d->w_layout >= 3 ? 2 : 3;
+    const bool f16 = d->w_layout == 4;
     const bool bf16 = d->precision == 1;               // (precision 2 / 3 without split weights runs the exact fp32 form)
     const long long src_bytes = (long long)d->N * d->Hi * d->Wi * Kc * 4, w_bytes = (long long)d->Co * 9 * d->Ci * (x3 ? 2 * np : 4);
     const long long out_bytes = (long long)d->N * d->Hi * d->Wi * Nn * 4;
@@ -854,6 +890,7 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
     C3Args a = {};
     a.Src = src; a.Wt = w; a.bias = bias; a.Out = out;
     a.N = d->N; a.H = d->Hi; a.W = d->Wi; a.Kc = Kc; a.Nn = Nn; a.Cw = d->Ci; a.accumulate = accumulate;
+    a.amax_src = reinterpret_cast<const unsigned*>(d->a_bound);
     a.src_bytes = (unsigned)src_bytes; a.w_bytes = (unsigned)w_bytes; a.out_bytes = (unsigned)out_bytes;
     // sums: forward -> BatchNorm statistics of the output; dgrad + bnr -> that BatchNorm's backward sums; dgrad without
     // bnr -> plain per-channel (sum, sum of squares) of the gradient written (its column sums = the bias gradient of the
@@ -893,10 +930,9 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
         if (!x3 || dgrad || !bni->table || bni->groups < 1 || d->N % bni->groups || (long long)bni->groups * Kc * 8 > 4096) return BH_E_UNSUPPORTED;
         a.bni = bni->table; a.bni_relu = bni->relu; a.bni_groups = bni->groups; a.bni_ipg = d->N / bni->groups;
     }
-    // (all eight template arguments, as rocprofv3 prints the symbol: FLIP, BN, BF16, SUBT, PACKED, X3, BNI, NP)
-    // (all nine template arguments, as rocprofv3 prints the symbol: FLIP, BN, BF16, SUBT, PACKED, X3, BNI, NP, MAP4)
-    if (bh_query("conv3x3_halo_kernel<%s,%d,%s,%d,%s,%s,%s,%d,%s>", dgrad ? "true" : "false", bn_tile, bf16 ? "true" : "false", subt,
-                 packed ? "true" : "false", x3 ? "true" : "false", bni ? "true" : "false", np, map4 ? "true" : "false")) {
+    // (all ten template arguments, as rocprofv3 prints the symbol: FLIP, BN, BF16, SUBT, PACKED, X3, BNI, NP, MAP4, F16)
+    if (bh_query("conv3x3_halo_kernel<%s,%d,%s,%d,%s,%s,%s,%d,%s,%s>", dgrad ? "true" : "false", bn_tile, bf16 ? "true" : "false", subt,
+                 packed ? "true" : "false", x3 ? "true" : "false", bni ? "true" : "false", np, map4 ? "true" : "false", f16 ? "true" : "false")) {
         *taken = 1;
         return BH_OK;
     }
@@ -908,35 +944,42 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
                   conv3x3_halo_kernel<false, 32, true, 2, P>,  conv3x3_halo_kernel<true, 32, true, 2, P>,    \
                   conv3x3_halo_kernel<false, 64, false, 1, P>, conv3x3_halo_kernel<true, 64, false, 1, P>,   \
                   conv3x3_halo_kernel<false, 64, true, 1, P>,  conv3x3_halo_kernel<true, 64, true, 1, P>
-#define C3_XROW(NP_) conv3x3_halo_kernel<false, 64, false, 2, true, true, false, NP_>, conv3x3_halo_kernel<true, 64, false, 2, true, true, false, NP_>,  \
-                     conv3x3_halo_kernel<false, 32, false, 2, true, true, false, NP_>, conv3x3_halo_kernel<true, 32, false, 2, true, true, false, NP_>,  \
-                     conv3x3_halo_kernel<false, 64, false, 1, true, true, false, NP_>, conv3x3_halo_kernel<true, 64, false, 1, true, true, false, NP_>,  \
-                     conv3x3_halo_kernel<false, 64, false, 2, true, true, true, NP_>, conv3x3_halo_kernel<false, 32, false, 2, true, true, true, NP_>,   \
-                     conv3x3_halo_kernel<false, 64, false, 1, true, true, true, NP_>
-    static const kern_t fns[46] = {C3_ROW(false), C3_ROW(true), C3_XROW(3), C3_XROW(2),
+#define C3_XROW(NP_, F_) conv3x3_halo_kernel<false, 64, false, 2, true, true, false, NP_, false, F_>, conv3x3_halo_kernel<true, 64, false, 2, true, true, false, NP_, false, F_>,  \
+                     conv3x3_halo_kernel<false, 32, false, 2, true, true, false, NP_, false, F_>, conv3x3_halo_kernel<true, 32, false, 2, true, true, false, NP_, false, F_>,  \
+                     conv3x3_halo_kernel<false, 64, false, 1, true, true, false, NP_, false, F_>, conv3x3_halo_kernel<true, 64, false, 1, true, true, false, NP_, false, F_>,  \
+                     conv3x3_halo_kernel<false, 64, false, 2, true, true, true, NP_, false, F_>, conv3x3_halo_kernel<false, 32, false, 2, true, true, true, NP_, false, F_>,   \
+                     conv3x3_halo_kernel<false, 64, false, 1, true, true, true, NP_, false, F_>
+    // 0-23 fp32 fragments (LDS slab / packed), 24-32 three bf16 pieces, 33-41 two bf16 pieces, 42-45 the 4 x 4 map form (bf16 pieces),
+    // 46-54 two fp16 pieces, 55-56 the 4 x 4 map form with fp16 pieces
+    static const kern_t fns[57] = {C3_ROW(false), C3_ROW(true), C3_XROW(3, false), C3_XROW(2, false),
                                    conv3x3_halo_kernel<false, 64, false, 1, true, true, false, 3, true>, conv3x3_halo_kernel<true, 64, false, 1, true, true, false, 3, true>,
-                                   conv3x3_halo_kernel<false, 64, false, 1, true, true, false, 2, true>, conv3x3_halo_kernel<true, 64, false, 1, true, true, false, 2, true>};
+                                   conv3x3_halo_kernel<false, 64, false, 1, true, true, false, 2, true>, conv3x3_halo_kernel<true, 64, false, 1, true, true, false, 2, true>,
+                                   C3_XROW(2, true),
+                                   conv3x3_halo_kernel<false, 64, false, 1, true, true, false, 2, true, true>, conv3x3_halo_kernel<true, 64, false, 1, true, true, false, 2, true, true>};
 #undef C3_XROW
 #undef C3_ROW
     constexpr int HALO2 = 8 * 200 * 16, HALO1 = 8 * 100 * 16;          // one halo stage: two / one sub-tile per workgroup
     constexpr int LDS1 = 2 * HALO1 + 2 * C3_B_BYTES;                   // one sub-tile per workgroup: 41,984 B
     const int XHALO2 = 4 * np * 200 * 16, XHALO1 = 4 * np * 100 * 16;  // split form: 12 / 8 plane images per stage
     if (bh_device_once(attr_devs)) {
-        for (int i = 42; i < 46; ++i) {          // 4 x 4 map form: 144 halo slots, 12 / 8 plane images, two stages
+        for (int i = 42; i < 57; ++i) {          // 4 x 4 map form: 144 halo slots, 12 / 8 plane images, two stages
+            if (i >= 46 && i < 55) continue;
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[i]), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (i < 44 ? 12 : 8) * 144 * 16);
             if (e != hipSuccess) return (int)e;
         }
-        for (int i = 0; i < 42; ++i) {
+        for (int i0 = 0; i0 < 51; ++i0) {
+            const int i = i0 < 42 ? i0 : 33 + (i0 - 42);       // the fp16 rows (46-54) have the geometry of the two-piece bf16 rows (33-41)
+            const int fi = i0 < 42 ? i0 : 46 + (i0 - 42);
             const int j = i % 12;
             const int xi = i >= 24 ? (i - 24) % 9 : 0, xh2 = (i >= 33 ? 8 : 12) * 200 * 16, xh1 = xh2 / 2;       // split rows: 0-5 plain, 6-8 BNI
             const int full = i >= 24 ? 2 * ((xi == 4 || xi == 5 || xi == 8) ? xh1 : xh2) + (xi >= 6 ? 4096 : 0)
                                      : i < 12 ? (j < 8 ? C3_LDS_BYTES : LDS1) : 2 * (j < 8 ? HALO2 : HALO1);
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[i]), hipFuncAttributeMaxDynamicSharedMemorySize, full);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[fi]), hipFuncAttributeMaxDynamicSharedMemorySize, full);
             if (e != hipSuccess) return (int)e;
         }
     }
-    const int xrow = 24 + (np == 2 ? 9 : 0);
-    const kern_t fn = map4 ? fns[42 + (np == 2 ? 2 : 0) + (dgrad ? 1 : 0)] : bni ? fns[xrow + 6 + (subt == 1 ? 2 : bn_tile == 64 ? 0 : 1)] : x3 ? fns[xrow + (subt == 1 ? 4 : bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0)]
+    const int xrow = f16 ? 46 : 24 + (np == 2 ? 9 : 0);
+    const kern_t fn = map4 ? fns[(f16 ? 55 : 42 + (np == 2 ? 2 : 0)) + (dgrad ? 1 : 0)] : bni ? fns[xrow + 6 + (subt == 1 ? 2 : bn_tile == 64 ? 0 : 1)] : x3 ? fns[xrow + (subt == 1 ? 4 : bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0)]
                          : fns[(packed ? 12 : 0) + (subt == 1 ? 8 + (bf16 ? 2 : 0) + (dgrad ? 1 : 0)
                                                               : (bf16 ? 4 : 0) + (bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0))];
     a.dbg_noload = g_c3_noload; a.dbg_ts = g_c3_stamp; a.det = bh_deterministic() ? 1 : 0;
@@ -962,7 +1005,14 @@ __global__ void __launch_bounds__(256) pack_conv3x3_weights_kernel(const bh_pack
     const long long n4 = (long long)Co * 9 * Ci / 4;
     const float4* __restrict__ w4 = reinterpret_cast<const float4*>(j.w);
     if (j.split) {
-        const int np = j.split == 2 ? 2 : 3;              // pieces per weight (split 1: the exact three-way cut; 2: two rounded pieces)
+        const int np = j.split == 1 ? 3 : 2;              // pieces per weight (split 1: the exact three-way cut; 2: two rounded bf16 pieces; 3: two fp16 pieces)
+        float wscale = 1.0f;
+        if (j.split == 3) {                               // 2^k with max |w| 2^k in [2^14, 2^15): the sixteen partial maxima behind the pieces
+            const unsigned* rec = reinterpret_cast<const unsigned*>(j.pf ? j.pf : j.pd) + (long long)Co * 9 * Ci;
+            unsigned m = 0;
+            for (int i = 0; i < 16; ++i) m = rec[i] > m ? rec[i] : m;
+            wscale = __builtin_bit_cast(float, (unsigned)(127 + bh_f16_scale_exp(m)) << 23);
+        }
         // [chunk][tap][n tile][piece][16-channel step s2][lane] x (8 bf16): lane (l31, kh2) holds k = chunk*32 + (2*s2 + kh2)*8 + e
         const long long n8 = (long long)Co * 9 * Ci / 8;
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
@@ -989,6 +1039,7 @@ __global__ void __launch_bounds__(256) pack_conv3x3_weights_kernel(const bh_pack
                 uint4 p0, p1, p2;
                 uint4* const o = reinterpret_cast<uint4*>(dst) + (r * 2 * np + s2) * 64 + lane;
                 if (np == 3) { bh_split8(u, v, p0, p1, p2); o[4 * 64] = p2; }
+                else if (j.split == 3) bh_split8_f16(u, v, wscale, p0, p1);
                 else bh_split8_2(u, v, p0, p1);
                 o[0] = p0; o[2 * 64] = p1;
             }
@@ -1016,6 +1067,38 @@ __global__ void __launch_bounds__(256) pack_conv3x3_weights_kernel(const bh_pack
             reinterpret_cast<float4*>(j.pd)[i] = make_float4(src[0], src[ks], src[2 * ks], src[3 * ks]);
         }
     }
+}
+
+// split = 3 (fp16 pieces): the layer's max |w| as sixteen partial maxima (workgroup x -> word x behind the pieces of BOTH buffers; plain
+// stores, nothing to zero), read by the pack kernel and by every consumer of the buffer
+__global__ void __launch_bounds__(256) pack_weights_amax_kernel(const bh_pack3x3_job* __restrict__ jobs) {
+    const bh_pack3x3_job j = jobs[blockIdx.y];
+    if (j.split != 3) return;
+    __shared__ float sm[4];
+    const long long n4 = (long long)j.Co * 9 * j.Ci / 4;
+    const float4* __restrict__ w4 = reinterpret_cast<const float4*>(j.w);
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += 16ll * 256) {
+        const float4 v = w4[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+        if (j.pf) j.pf[n4 * 4 + blockIdx.x] = m;
+        if (j.pd) j.pd[n4 * 4 + blockIdx.x] = m;
+    }
+}
+
+// tables with split = 3 jobs: the maxima pass, then the pack (two launches for the whole network)
+extern "C" int bh_conv3x3_pack_f16(const bh_pack3x3_job* jobs_dev, int njobs, void* stream) {
+    if (!jobs_dev || njobs < 0) return BH_E_BADARG;
+    if (njobs == 0) return BH_OK;
+    hipLaunchKernelGGL(pack_weights_amax_kernel, dim3(16, njobs), dim3(256), 0, bh_stream(stream), jobs_dev);
+    BH_LAUNCH_CHECK();
+    return bh_conv3x3_pack(jobs_dev, njobs, stream);
 }
 
 extern "C" int bh_conv3x3_pack(const bh_pack3x3_job* jobs_dev, int njobs, void* stream) {

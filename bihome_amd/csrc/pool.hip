@@ -97,6 +97,25 @@ __global__ void __launch_bounds__(256) add_kernel(const float* __restrict__ a, c
     }
 }
 
+// max |x| into a magnitude record (common.h F16X2): 512 looping workgroups, eight float4 per lane in flight, one integer atomic max each
+__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, size_t n4, size_t n, unsigned* __restrict__ rec) {
+    __shared__ float sm[4];
+    const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
+    float m = 0.f;
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 7 * stride < n4; i += 8 * stride) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = x4[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+    }
+    for (; i < n4; i += stride) { const float4 v = x4[i]; m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w))); }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[n4 * 4 + threadIdx.x]));
+    bh_amax_commit(rec, m, blockIdx.x, sm);
+}
+
 static int nblocks(size_t work) {
     size_t b = (work + 255) / 256;
     return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
@@ -133,6 +152,17 @@ int bh_gap_fwd(const float* x, float* y, int N, int HW, int C, void* stream) {
 int bh_gap_bwd(const float* gy, float* gx, int N, int HW, int C, void* stream) {
     if (!gy || !gx) return BH_E_BADARG;
     hipLaunchKernelGGL(gap_bwd_kernel, dim3(nblocks((size_t)N * HW * C)), dim3(256), 0, bh_stream(stream), gy, gx, N, HW, C);
+    BH_LAUNCH_CHECK();
+    return BH_OK;
+}
+
+int bh_absmax(const float* x, long long n, float* record, void* stream) {
+    if (!x || !record || n < 0 || (reinterpret_cast<uintptr_t>(x) & 15)) return BH_E_BADARG;
+    if (n == 0) return BH_OK;
+    const size_t n4 = (size_t)n / 4;
+    int nb = (int)((n4 + 256 * 8 - 1) / (256 * 8));
+    nb = nb > 512 ? 512 : (nb < 1 ? 1 : nb);
+    hipLaunchKernelGGL(absmax_kernel, dim3(nb), dim3(256), 0, bh_stream(stream), x, n4, (size_t)n, reinterpret_cast<unsigned*>(record));
     BH_LAUNCH_CHECK();
     return BH_OK;
 }

@@ -757,7 +757,7 @@ long long bh_conv_wgrad_det_bytes(const bh_conv_desc* d) {
 int bh_conv_wgrad_bnin(const float* x, const float* gy, float* gw, float* gbias, const bh_conv_desc* d, float* ws, long long ws_bytes,
                        const bh_bn_in* bni, void* stream) {
     if (!d || !x || !gy || !gw || !bni || !ws) return BH_E_BADARG;
-    if (d->precision != 2 && d->precision != 3) return BH_E_UNSUPPORTED;
+    if (d->precision < 2 || d->precision > 4) return BH_E_UNSUPPORTED;
     int taken = 0;
     const int rc = bh_wgrad_x3_try(x, gy, gw, d, bh_stream(stream), &taken, ws, ws_bytes, nullptr, bni);
     if (rc != BH_OK) return rc;
@@ -784,7 +784,7 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
     const bool det = ws && bh_deterministic();
     if (det) ws_bytes &= ~7ll;                                          // (the bias entries at the end of the workspace are doubles)
     const long long bias_bytes = det ? (long long)(d->transposed ? d->Co : d->Co) * BH_ACC_WORDS * 8 : 0;
-    if ((d->precision == 2 || d->precision == 3) && !(d->route & BH_ROUTE_WGRAD_GENERIC)) {
+    if (d->precision >= 2 && d->precision <= 4 && !(d->route & BH_ROUTE_WGRAD_GENERIC)) {
         // f32x3 / f32x2 arithmetic: the halo-tiled split-operand kernel (wgrad_x3.hip) takes the 3x3 layers with channels % 64 == 0
         int taken = 0;
         const int rc = bh_wgrad_x3_try(x, gy, gw, d, s, &taken, ws, ws_bytes > bias_bytes ? ws_bytes - bias_bytes : 0, ws_need);
@@ -878,7 +878,7 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
         if (bh_query("wgrad_small_kernel<%s>", vec ? "true" : "false")) return BH_OK;
         if (vec) hipLaunchKernelGGL((wgrad_small_kernel<true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((wgrad_small_kernel<false>), grid, dim3(256), 0, s, a);
-    } else if (!(d->route & BH_ROUTE_WGRAD_GENERIC) && vec && a.use_buf && d->precision >= 0 && d->precision <= 3 && !d->transposed && d->stride == 1 && d->Ho == d->Hi &&
+    } else if (!(d->route & BH_ROUTE_WGRAD_GENERIC) && vec && a.use_buf && d->precision >= 0 && d->precision <= 4 && !d->transposed && d->stride == 1 && d->Ho == d->Hi &&
                d->Wo == d->Wi && a.hwshift >= 0 && a.M % WBK == 0 && a.Np % 64 == 0 && a.Nq % 64 == 0 && !a.xcd_map) {
         // taps per workgroup: in bf16 mode the loop is so short that the launch is bound by its operand traffic (each tap
         // re-reads x and gy: 320 MB per launch) - three taps per workgroup share gy and a third of it goes away

@@ -33,6 +33,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef short i16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) i16x4* lds_i16x4_ptr;
 
@@ -52,6 +53,9 @@ struct WX3Args {
     // max(x * scale + shift, lo) per channel (zero padding stays zero).  bni: table[groups][Ci] x (scale, shift) (bh_bn_fwd_coeffs)
     const float* bni;
     int bni_relu, bni_ipg, bni_groups;
+    // F16 (two fp16 pieces per operand, common.h F16X2): magnitude records of X (of the BatchNorm OUTPUT with BNI) and of GY
+    const unsigned* amax_x;
+    const unsigned* amax_gy;
 };
 
 template <int CB, int NP = 3>
@@ -71,8 +75,11 @@ struct WXGeom {
 
 // NP: bf16 pieces per operand - 3: the exact cut, six products (precision 2); 2: two rounded pieces, three products ("f32x2",
 // precision 3, common.h bh_split8_2)
-template <int CB, bool BNI = false, int NP = 3>
+// F16 (NP = 2; round 4): the two pieces are fp16 numbers of the operand times a power-of-two scale per tensor ("f16x2", precision 4); the
+// partial blocks are rescaled by 2^-(k_x + k_gy) when they are flushed
+template <int CB, bool BNI = false, int NP = 3, bool F16 = false>
 __global__ void __launch_bounds__(256, 1) wgrad_x3_kernel(WX3Args a) {
+    static_assert(!F16 || NP == 2, "fp16 pieces: two");
     using G = WXGeom<CB, NP>;
     constexpr int GS = G::GS, HS = G::HS, NG = G::NG;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -81,6 +88,14 @@ __global__ void __launch_bounds__(256, 1) wgrad_x3_kernel(WX3Args a) {
     const int split = blockIdx.x % a.nsplit, pair = blockIdx.x / a.nsplit;
     const int co0 = (pair / a.cbi) * CB, ci0 = (pair % a.cbi) * CB;
     constexpr unsigned OOB = 0x80000000u;
+    float f16_sx = 1.0f, f16_sg = 1.0f;
+    int f16_kout = 0;
+    if constexpr (F16) {
+        const int kx = bh_f16_scale_exp(bh_amax_read(a.amax_x, lane)), kg = bh_f16_scale_exp(bh_amax_read(a.amax_gy, lane));
+        f16_sx = __builtin_bit_cast(float, (unsigned)(127 + kx) << 23);
+        f16_sg = __builtin_bit_cast(float, (unsigned)(127 + kg) << 23);
+        f16_kout = -(kx + kg);
+    }
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.GY), 0, a.gy_bytes, 0x00020000);
 
@@ -153,7 +168,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_x3_kernel(WX3Args a) {
         constexpr int sl = decltype(SLOT)::value;
         uint4 p[3];
         if constexpr (sl < GS) {
-            bh_split8_np<NP>(rg[sl][0], rg[sl][1], p);
+            bh_split8_any<NP, F16>(rg[sl][0], rg[sl][1], f16_sg, p);
 #pragma unroll
             for (int pc = 0; pc < NP; ++pc) *reinterpret_cast<uint4*>(img + g_lds[sl] + pc * G::GP) = p[pc];
         } else if constexpr (sl < GS + HS) {
@@ -169,7 +184,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_x3_kernel(WX3Args a) {
                 v.x = ok ? __builtin_elementwise_maximum(__builtin_fmaf(v.x, t2.x, t2.y), bni_lo) : 0.f; v.y = ok ? __builtin_elementwise_maximum(__builtin_fmaf(v.y, t2.z, t2.w), bni_lo) : 0.f;
                 v.z = ok ? __builtin_elementwise_maximum(__builtin_fmaf(v.z, t3.x, t3.y), bni_lo) : 0.f; v.w = ok ? __builtin_elementwise_maximum(__builtin_fmaf(v.w, t3.z, t3.w), bni_lo) : 0.f;
             }
-            bh_split8_np<NP>(rx[j][0], rx[j][1], p);
+            bh_split8_any<NP, F16>(rx[j][0], rx[j][1], f16_sx, p);
 #pragma unroll
             for (int pc = 0; pc < NP; ++pc) *reinterpret_cast<uint4*>(img + h_lds[j] + pc * G::XP) = p[pc];
         }
@@ -247,10 +262,12 @@ __global__ void __launch_bounds__(256, 1) wgrad_x3_kernel(WX3Args a) {
                 if (pi == 3) { WX_SLOT(2, nimg); WX_PART(2, tnext); }
             }
             const int k0 = (s0 / 9) & 1, t0 = s0 % 9;
-#define WX_MM0(PA, PB) acc[t0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[k0][PA], bf[pb][0][PB], acc[t0], 0, 0, 0)
+#define WX_MFMA(A_, B_, C_) (F16 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A_), __builtin_bit_cast(f16x8, B_), C_, 0, 0, 0) \
+                                 : __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, C_, 0, 0, 0))
+#define WX_MM0(PA, PB) acc[t0] = WX_MFMA(af[k0][PA], bf[pb][0][PB], acc[t0])
             if (s1 < NSTEP) {
                 const int k1 = (s1 / 9) & 1, t1 = s1 % 9;
-#define WX_MM1(PA, PB) acc[t1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[k1][PA], bf[pb][1][PB], acc[t1], 0, 0, 0)
+#define WX_MM1(PA, PB) acc[t1] = WX_MFMA(af[k1][PA], bf[pb][1][PB], acc[t1])
                 // small partial products first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
                 if constexpr (NP == 3) { WX_MM0(2, 0); WX_MM1(2, 0); WX_MM0(0, 2); WX_MM1(0, 2); WX_MM0(1, 1); WX_MM1(1, 1); }
                 WX_MM0(1, 0); WX_MM1(1, 0); WX_MM0(0, 1); WX_MM1(0, 1); WX_MM0(0, 0); WX_MM1(0, 0);
@@ -260,6 +277,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_x3_kernel(WX3Args a) {
                 WX_MM0(1, 0); WX_MM0(0, 1); WX_MM0(0, 0);
             }
 #undef WX_MM0
+#undef WX_MFMA
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // (LDS only: the requested tile stays in flight)
     }
@@ -270,6 +288,12 @@ __global__ void __launch_bounds__(256, 1) wgrad_x3_kernel(WX3Args a) {
 #undef WX_TR
 #undef WX_OPER
     if (a.noflush == 1) return;
+    if constexpr (F16) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = __builtin_ldexpf(acc[t][r], f16_kout);
+    }
     // C/D layout: column = lane & 31 (cin), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (cout).  All workgroups finish together and
     // every one adds to the same block: each starts at another tap so that they do not queue on the same addresses.
     const int l31 = lane & 31;
@@ -376,23 +400,29 @@ int bh_wgrad_x3_try(const float* x, const float* gy, float* gw, const bh_conv_de
         else if (ws_bytes < need) return BH_E_BADARG;
         a.partials = ws;
     }
-    const int np = d->precision == 3 ? 2 : 3;
-    // (all three template arguments, as rocprofv3 prints the symbol: CB, BNI, NP)
-    if (bh_query(ws ? "wgrad_x3_kernel<%d,%s,%d>+wgrad_x3_reduce_kernel<%d>" : "wgrad_x3_kernel<%d,%s,%d>", cb, bni ? "true" : "false", np, cb)) { *taken = 1; return BH_OK; }
+    const int np = d->precision >= 3 ? 2 : 3;
+    // precision 4 (two fp16 pieces): with the magnitude records of both operands; without them the exact three-piece form runs
+    const bool f16 = d->precision == 4 && d->a_bound && d->b_bound;
+    a.amax_x = reinterpret_cast<const unsigned*>(d->a_bound); a.amax_gy = reinterpret_cast<const unsigned*>(d->b_bound);
+    // (all four template arguments, as rocprofv3 prints the symbol: CB, BNI, NP, F16)
+    if (bh_query(ws ? "wgrad_x3_kernel<%d,%s,%d,%s>+wgrad_x3_reduce_kernel<%d>" : "wgrad_x3_kernel<%d,%s,%d,%s>", cb, bni ? "true" : "false",
+                 (d->precision == 4 && !f16) ? 3 : np, f16 ? "true" : "false", cb)) { *taken = 1; return BH_OK; }
     typedef void (*kern_t)(WX3Args);
-    static const kern_t fns[8] = {wgrad_x3_kernel<64, false, 3>, wgrad_x3_kernel<32, false, 3>, wgrad_x3_kernel<64, true, 3>, wgrad_x3_kernel<32, true, 3>,
-                                  wgrad_x3_kernel<64, false, 2>, wgrad_x3_kernel<32, false, 2>, wgrad_x3_kernel<64, true, 2>, wgrad_x3_kernel<32, true, 2>};
-    static const int lds_of[8] = {2 * WXGeom<64, 3>::LDS, 2 * WXGeom<32, 3>::LDS, 2 * WXGeom<64, 3>::LDS, 2 * WXGeom<32, 3>::LDS,
-                                  2 * WXGeom<64, 2>::LDS, 2 * WXGeom<32, 2>::LDS, 2 * WXGeom<64, 2>::LDS, 2 * WXGeom<32, 2>::LDS};
+    static const kern_t fns[12] = {wgrad_x3_kernel<64, false, 3>, wgrad_x3_kernel<32, false, 3>, wgrad_x3_kernel<64, true, 3>, wgrad_x3_kernel<32, true, 3>,
+                                   wgrad_x3_kernel<64, false, 2>, wgrad_x3_kernel<32, false, 2>, wgrad_x3_kernel<64, true, 2>, wgrad_x3_kernel<32, true, 2>,
+                                   wgrad_x3_kernel<64, false, 2, true>, wgrad_x3_kernel<32, false, 2, true>, wgrad_x3_kernel<64, true, 2, true>, wgrad_x3_kernel<32, true, 2, true>};
+    static const int lds_of[12] = {2 * WXGeom<64, 3>::LDS, 2 * WXGeom<32, 3>::LDS, 2 * WXGeom<64, 3>::LDS, 2 * WXGeom<32, 3>::LDS,
+                                   2 * WXGeom<64, 2>::LDS, 2 * WXGeom<32, 2>::LDS, 2 * WXGeom<64, 2>::LDS, 2 * WXGeom<32, 2>::LDS,
+                                   2 * WXGeom<64, 2>::LDS, 2 * WXGeom<32, 2>::LDS, 2 * WXGeom<64, 2>::LDS, 2 * WXGeom<32, 2>::LDS};
     static unsigned long long attr_devs = 0;
     if (bh_device_once(attr_devs)) {
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 12; ++i) {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[i]), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                      lds_of[i] + ((i & 2) ? 4 * ((i & 1) ? 32 : 64) * 8 : 0));
             if (e != hipSuccess) return (int)e;
         }
     }
-    const int ki = (np == 2 ? 4 : 0) + (bni ? 2 : 0) + (cb == 64 ? 0 : 1);
+    const int ki = (f16 ? 8 : (np == 2 && d->precision != 4) ? 4 : 0) + (bni ? 2 : 0) + (cb == 64 ? 0 : 1);
     hipLaunchKernelGGL(fns[ki], dim3(pairs * ns), dim3(256), lds_of[ki] + tb_bytes, stream, a);
     BH_LAUNCH_CHECK();
     if (ws) {

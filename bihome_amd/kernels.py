@@ -5,7 +5,7 @@ import os
 
 import torch
 
-from ._lib import BhBnIn, BhBnReduce, BhConvDesc, BhPack3x3Job, check, lib
+from ._lib import AMAX_FLOATS, GEOMETRY_FIELDS, BhBnIn, BhBnReduce, BhConvDesc, BhPack3x3Job, check, lib
 
 
 def _p(t):
@@ -63,10 +63,14 @@ def conv_variant(d, which, accumulate=False, bn_groups=0):
     """Kernel symbol(s) a launch described by `d` runs, as the LIBRARY reports it (bh_conv_variant executes the real
     dispatch code with the launches replaced by a name record): 'fwd' / 'dgrad' / 'wgrad'.  Used for the roofline
     attribution in bench.py and the per-launch timing tables; several launches are joined by '+'."""
-    key = (tuple(getattr(d, f) for f, _ in BhConvDesc._fields_), which, bool(accumulate), int(bn_groups))
+    key = (tuple(getattr(d, f) for f in GEOMETRY_FIELDS), which, bool(accumulate), int(bn_groups))
     v = _VARIANT_CACHE.get(key)
     if v is None:
         buf = ctypes.create_string_buffer(256)
+        if d.precision == 4 and not d.a_bound:
+            # (routing does not depend on the magnitude records, but a precision-4 launch without one is refused: describe it with a dummy)
+            d = _with_layout(d, d.w_layout)
+            d.a_bound = d.b_bound = 256
         check(lib.bh_conv_variant(ctypes.byref(d), {"fwd": 0, "dgrad": 1, "wgrad": 2, "wgrad_det": 3}[which], int(bool(accumulate)), int(bn_groups),
                                   buf, 256), "bh_conv_variant")
         v = _VARIANT_CACHE[key] = buf.value.decode()
@@ -86,7 +90,7 @@ def _bni_name(v):
     """The library's name of a plain launch with the BatchNorm-on-load template argument (second to last) switched on."""
     import re
     # conv3x3_halo_kernel<..,BNI,NP,MAP4> / wgrad_x3_kernel<CB,BNI,NP>
-    return re.sub(r",false,(\d)(,false)?>", r",true,\1\2>", v, count=1)
+    return re.sub(r",false,(\d)((?:,(?:false|true))*)>", r",true,\1\2>", v, count=1)
 
 
 def conv_flops(d):
@@ -328,16 +332,45 @@ def bihome_loss_bwd(g_loss, f1, f2, f1w, f2w, m1w, m2w, m1, m2, M1, M2, numden, 
 # ------------------------------------------------------------------------------------------------
 # conv stacks
 # ------------------------------------------------------------------------------------------------
-# conv arithmetic (bh_conv_desc.precision).  'f32' (default) asks for fp32 ACCURACY and lets the library pick the evaluation:
-# the packed 3x3 kernels cut every fp32 operand exactly into three bf16 pieces and accumulate the six partial products of
-# order <= 2 in fp32 on the bf16 matrix pipe (precision 2, "f32x3": error against float64 at or below that of the fp32-input
-# MFMA form, tests/test_conv_kernels_gpu.py::test_conv3x3_f32x3_*), everything else runs v_mfma_f32_32x32x2_f32.
+# conv arithmetic (bh_conv_desc.precision).  'f32' (default) asks for fp32 ACCURACY and lets the library pick the evaluation.
+# Round 4: the packed 3x3 kernels (forward, dgrad, weight gradient: 80 % of the step's flops) evaluate every product from TWO FP16
+# pieces per operand of the operand times a power-of-two scale per tensor - 22 significand bits and a sign, three partial products
+# on v_mfma_f32_32x32x16_f16 with fp32 accumulate, results rescaled exactly (precision 4, "f16x2": ~2^-22 per product; against
+# float64 the kernels measure at or BELOW the error of the fp32-input MFMA kernels on every shape tested, tests/test_f16x2_gpu.py,
+# because sixteen products enter one fp32 accumulate rounding instead of two).  Everything else runs v_mfma_f32_32x32x2_f32.
+# 'f32x3' (precision 2, the default of rounds 2-3): the exact cut into three bf16 pieces, six partial products per product.
 # 'f32-mfma' forces the fp32-input MFMA everywhere (precision 0); 'bf16' rounds the operands to bf16 (precision 1).
 # 'f32x2' (precision 3): two bf16 pieces per operand, both rounded to nearest, three products - ~4e-6 per product (13x the fp32
-# rounding, 500x below 'bf16'); a separately reported reduced-precision arithmetic for the matrix-pipe-rate configurations.
-PRECISION = {"f32": 2, "fp32": 2, "f32x3": 2, "f32-mfma": 0, "bf16": 1, "f32x2": 3}
-SPLIT_PIECES = {2: 3, 3: 2}         # precision -> bf16 pieces per operand of the split-operand kernels
-SPLIT_LAYOUT = {2: 2, 3: 3}         # precision -> bh_conv_desc.w_layout of the packed split weights
+# rounding, 500x below 'bf16'); a separately reported reduced-precision arithmetic.
+PRECISION = {"f32": 4, "fp32": 4, "f16x2": 4, "f32x3": 2, "f32-mfma": 0, "bf16": 1, "f32x2": 3}
+SPLIT_PIECES = {2: 3, 3: 2, 4: 2}   # precision -> pieces per operand of the split-operand kernels
+SPLIT_LAYOUT = {2: 2, 3: 3, 4: 4}   # precision -> bh_conv_desc.w_layout of the packed split weights
+F16X2 = 4
+
+
+def amax_record(device):
+    """A zeroed magnitude record (include/bihome.h BH_AMAX_FLOATS); net.run_forward / run_backward cut theirs from one arena."""
+    return torch.zeros(AMAX_FLOATS, dtype=torch.float32, device=device)
+
+
+def absmax(x, rec=None):
+    """Magnitude record of a tensor by a streaming pass (the fallback where no producer kernel left one)."""
+    _chk(x)
+    if rec is None:
+        rec = amax_record(x.device)
+    with _Timed("absmax_kernel", 0.0, 4.0 * x.numel()):
+        check(lib.bh_absmax(_p(x), x.numel(), _p(rec), _stream()), "bh_absmax")
+    return rec
+
+
+def amax_of(x, make=True):
+    """The magnitude record attached to a tensor (or BnOnLoad) by its producer; make: measure it when there is none."""
+    rec = x.amax if isinstance(x, BnOnLoad) else getattr(x, "_bh_amax", None)
+    if rec is None and make:
+        if isinstance(x, BnOnLoad):
+            raise RuntimeError("BatchNorm-on-load operand without a magnitude record (bn_fwd_coeffs(..., amax=...))")
+        rec = x._bh_amax = absmax(x)
+    return rec
 
 
 def packed_layout(precision):
@@ -388,12 +421,16 @@ class WeightPacker:
     ONE bh_conv3x3_pack launch whenever a parameter version changed (every optimizer step in training, once for frozen
     weights).  Buffers and the device job table are allocated once (addresses stay fixed: HIP-graph safe)."""
 
-    def __init__(self, split=False):
+    def __init__(self, split=False, f16=False):
         # split: False / 0 = fp32 fragments (w_layout 1); True / 3 = three exact bf16 pieces (w_layout 2, precision 2);
-        # 2 = two rounded bf16 pieces (w_layout 3, precision 3 "f32x2")
+        # 2 = two rounded bf16 pieces (w_layout 3, precision 3 "f32x2"); 2 with f16: two fp16 pieces of w 2^k (w_layout 4, precision 4)
         self.pieces = 0 if not split else (2 if (split == 2 and split is not True) else 3)
         self.split = self.pieces > 0
-        self.layout = {0: 1, 3: 2, 2: 3}[self.pieces]
+        self.f16 = bool(f16)
+        if self.f16 and self.pieces != 2:
+            raise ValueError("fp16 pieces: two per weight")
+        self.layout = 4 if self.f16 else {0: 1, 3: 2, 2: 3}[self.pieces]
+        self.job_split = 3 if self.f16 else {0: 0, 3: 1, 2: 2}[self.pieces]
         self.entries = {}          # id(weight) -> (weight, pf, pd)
         self.table = None
         self.versions = None
@@ -404,6 +441,8 @@ class WeightPacker:
         if e is None:
             Co, Ci = weight.shape[0], weight.shape[1]
             n = weight.numel() * self.pieces // 2 if self.split else weight.numel()
+            if self.f16:
+                n += 16                       # the layer's sixteen partial maxima of |w| (bh_conv3x3_pack_f16)
             pf = torch.empty(n, dtype=torch.float32, device=weight.device)
             pd = torch.empty(n, dtype=torch.float32, device=weight.device) if need_dgrad else None
             e = self.entries[id(weight)] = (weight, pf, pd)
@@ -433,23 +472,33 @@ class WeightPacker:
                 if not w.permute(0, 2, 3, 1).is_contiguous():
                     raise RuntimeError("conv weight is not in kernel (channels_last) layout")
                 j.w, j.pf, j.pd = w.data_ptr(), pf.data_ptr(), (pd.data_ptr() if pd is not None else None)
-                j.Co, j.Ci, j.split = w.shape[0], w.shape[1], {0: 0, 3: 1, 2: 2}[self.pieces]
+                j.Co, j.Ci, j.split = w.shape[0], w.shape[1], self.job_split
             raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8)
             dev = next(iter(self.entries.values()))[0].device
             self.table = raw.to(dev)
             self._ptrs = [v[1] for v in vers]
-        check(lib.bh_conv3x3_pack(_p(self.table), len(self.entries), _stream()), "bh_conv3x3_pack")
+        if self.f16:
+            check(lib.bh_conv3x3_pack_f16(_p(self.table), len(self.entries), _stream()), "bh_conv3x3_pack_f16")
+        else:
+            check(lib.bh_conv3x3_pack(_p(self.table), len(self.entries), _stream()), "bh_conv3x3_pack")
         self.versions = vers
+
+
+def packer_for_precision(precision):
+    """A WeightPacker whose copies are what the packed kernels of this precision read."""
+    p = int(precision)
+    return WeightPacker(split=SPLIT_PIECES.get(p, 0), f16=p == F16X2)
 
 
 class BnOnLoad:
     """A training-mode BatchNorm(+ReLU) whose APPLY rides in its consumer: `z` is the BatchNorm's input, `table` the
     [groups][C] x (scale, shift) coefficients made by bn_fwd_coeffs.  The f32x3 3x3 forward and weight-gradient kernels take
     it as their input operand and transform it while staging (zero padding stays zero): the BatchNorm's output is never stored."""
-    __slots__ = ("z", "table", "groups", "relu")
+    __slots__ = ("z", "table", "groups", "relu", "amax")
 
-    def __init__(self, z, table, groups, relu):
+    def __init__(self, z, table, groups, relu, amax=None):
         self.z, self.table, self.groups, self.relu = z, table, groups, relu
+        self.amax = amax            # magnitude record of the (never stored) BatchNorm output: precision 4 consumers
 
     @property
     def shape(self):
@@ -461,11 +510,12 @@ class BnOnLoad:
         return b
 
 
-def bn_fwd_coeffs(stats, gamma, beta, rmean, rvar, groups, rows, C, eps, momentum):
-    """(scale, shift) table of a training-mode BatchNorm from its forward sums (+ the running-statistics update)."""
+def bn_fwd_coeffs(stats, gamma, beta, rmean, rvar, groups, rows, C, eps, momentum, amax=None):
+    """(scale, shift) table of a training-mode BatchNorm from its forward sums (+ the running-statistics update).
+    amax: zeroed magnitude record - receives the a-priori bound of the BatchNorm's output."""
     table = torch.empty((groups, C, 2), dtype=torch.float32, device=stats.device)
-    check(lib.bh_bn_fwd_coeffs(_p(stats), _p(gamma), _p(beta), _p(rmean), _p(rvar), groups, rows, C, float(eps), float(momentum),
-                               _p(table), _stream()), "bh_bn_fwd_coeffs")
+    check(lib.bh_bn_fwd_coeffs_amax(_p(stats), _p(gamma), _p(beta), _p(rmean), _p(rvar), groups, rows, C, float(eps), float(momentum),
+                                    _p(table), _p(amax), _stream()), "bh_bn_fwd_coeffs")
     return table
 
 
@@ -482,6 +532,8 @@ def conv_fwd(x, w, bias, d, bn_sums=None, groups=1, res=None, relu=False, wpacke
             raise RuntimeError("BatchNorm-on-load needs the packed f32x3 3x3 forward")
         y = torch.empty(conv_out_shape(d), dtype=torch.float32, device=x.device)
         dp = getattr(d, "bh_packed", None) or _with_layout(d, packed_layout(d.precision))
+        if dp.precision == F16X2:
+            dp.a_bound = amax_of(bol).data_ptr()
         bs = bol.struct()
         # (the library's name of the plain launch with the last template argument - BatchNorm-on-load - switched on)
         with _Timed(_bni_name(_conv_variant(dp, "fwd", bn_groups=groups if bn_sums is not None else 0)) if TIMING is not None else "",
@@ -493,6 +545,8 @@ def conv_fwd(x, w, bias, d, bn_sums=None, groups=1, res=None, relu=False, wpacke
     y = torch.empty(conv_out_shape(d), dtype=torch.float32, device=x.device)
     if wpacked is not None:
         d, w = (getattr(d, "bh_packed", None) or _with_layout(d, packed_layout(d.precision))), wpacked
+        if d.precision == F16X2:
+            d.a_bound = amax_of(x).data_ptr()
     with _Timed(_conv_variant(d, "fwd", bn_groups=groups if bn_sums is not None else 0), conv_flops(d),
                 4.0 * (x.numel() + y.numel() + w.numel())):
         if res is not None or relu:
@@ -557,6 +611,8 @@ def conv_dgrad(gy, w, d, out=None, bn_reduce=None, wkey=None, wpacked=None, cols
     _chk(gy); _chk(w)
     if wpacked is not None:
         d, w = (getattr(d, "bh_packed", None) or _with_layout(d, packed_layout(d.precision))), wpacked
+        if d.precision == F16X2:
+            d.a_bound = amax_of(gy).data_ptr()
     if colsum is not None:
         assert out is None and bn_reduce is None
         _chk(colsum, torch.float64)
@@ -609,6 +665,9 @@ def conv_wgrad(x, gy, gw, gbias, d, det_ws=None):
     that the wgrad entry is the kernel rocprofv3 lists under the same name).
     det_ws: float32 workspace of >= wgrad_det_bytes(d) bytes - the split-K partial tiles are stored there and added in a
     fixed order by a second launch (bitwise repeatable, no atomics); ignored where the shape has no deterministic form."""
+    if d.precision == F16X2 and getattr(d, "bh_wx3", True):
+        # both records -> the fp16-piece kernel; (a description without them runs the exact three-piece form)
+        d.a_bound, d.b_bound = amax_of(x).data_ptr(), amax_of(gy).data_ptr()
     if isinstance(x, BnOnLoad):
         bol, x = x, x.z
         _chk(x); _chk(gy); _chk(gw); _chk(gbias)
@@ -658,7 +717,7 @@ def bn_stats_buffer(groups, C, device):
     return torch.zeros(lib.bh_bn_stats_doubles(groups, C), dtype=torch.float64, device=device)
 
 
-def bn_fwd(x, gamma, beta, rmean, rvar, res, groups, eps, momentum, relu, training, stats=None, stats_ready=False):
+def bn_fwd(x, gamma, beta, rmean, rvar, res, groups, eps, momentum, relu, training, stats=None, stats_ready=False, amax=None):
     """x [groups*rows..., C] NHWC (any leading shape); returns (y, stats).  stats: optional zeroed sums buffer (a slice of
     the caller's arena); stats_ready: the producing conv already accumulated the sums (conv_fwd(..., bn_sums=stats))."""
     _chk(x); _chk(res)
@@ -672,13 +731,15 @@ def bn_fwd(x, gamma, beta, rmean, rvar, res, groups, eps, momentum, relu, traini
     flags = (1 if relu else 0) | (2 if res is not None else 0) | (8 if stats_ready else 0)
     nb = 4.0 * x.numel() * ((2 if (training and not stats_ready) else 1) + 1 + (1 if res is not None else 0))
     with _Timed("bn_fwd(%d kernels)" % (2 if (training and not stats_ready) else 1) + (" g%d rows%d C%d" % (groups, rows, C) if TIMING_DETAIL else ""), 0.0, nb):
-        check(lib.bh_bn_fwd(_p(x), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(res), _p(y), _p(stats), groups, rows, C,
-                            float(eps), float(momentum), flags, 0 if training else 1, _stream()), "bh_bn_fwd")
+        check(lib.bh_bn_fwd_amax(_p(x), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(res), _p(y), _p(stats), groups, rows, C,
+                                 float(eps), float(momentum), flags, 0 if training else 1, _p(amax), _stream()), "bh_bn_fwd")
+    if amax is not None:
+        y._bh_amax = amax           # zeroed magnitude record, now max |y| (measured by the apply kernel)
     return y, stats
 
 
 def bn_bwd(gy, y, x, gamma, stats, rmean, rvar, groups, eps, relu, training, want_gres, ggamma=None, gbeta=None, beta=None,
-           had_res=None, scratch=None, sums_ready=None):
+           had_res=None, scratch=None, sums_ready=None, amax=None):
     """sums_ready: the gradient sums buffer filled by conv_dgrad(..., bn_reduce=...) - reduce / finalize are skipped."""
     _chk(gy); _chk(x)
     C = gamma.numel() if gamma is not None else x.shape[-1]
@@ -695,9 +756,11 @@ def bn_bwd(gy, y, x, gamma, stats, rmean, rvar, groups, eps, relu, training, wan
     passes = 1 if sums_ready is not None else 2
     nb = 4.0 * x.numel() * (passes * (2 + (1 if (relu and not mask_from_x) else 0)) + 1 + (1 if want_gres else 0))
     with _Timed("bn_bwd(%d kernels)" % (1 if sums_ready is not None else 3) + (" g%d rows%d C%d" % (groups, rows, C) if TIMING_DETAIL else ""), 0.0, nb):
-        check(lib.bh_bn_bwd(_p(gy), _p(y), _p(x), _p(gamma), _p(beta), _p(stats), _p(gx), _p(gres), _p(ggamma), _p(gbeta),
-                            _p(scratch), groups, rows, C, float(eps), flags, 0 if training else 1, _p(rmean), _p(rvar),
-                            _stream()), "bh_bn_bwd")
+        check(lib.bh_bn_bwd_amax(_p(gy), _p(y), _p(x), _p(gamma), _p(beta), _p(stats), _p(gx), _p(gres), _p(ggamma), _p(gbeta),
+                                 _p(scratch), groups, rows, C, float(eps), flags, 0 if training else 1, _p(rmean), _p(rvar),
+                                 _p(amax), _stream()), "bh_bn_bwd")
+    if amax is not None:
+        gx._bh_amax = amax          # zeroed magnitude record, now max |gx|
     return gx, gres
 
 
@@ -739,6 +802,9 @@ def maxpool_fwd(x, want_index=True):
     y = torch.empty((N, (Hi - 1) // 2 + 1, (Wi - 1) // 2 + 1, C), dtype=torch.float32, device=x.device)
     idx = torch.empty(y.shape, dtype=torch.uint8, device=x.device) if want_index else None
     check(lib.bh_maxpool3s2_fwd(_p(x), _p(y), _p(idx), N, Hi, Wi, C, _stream()), "bh_maxpool3s2_fwd")
+    rec = getattr(x, "_bh_amax", None)
+    if rec is not None:
+        y._bh_amax = rec            # a window maximum is bounded by the bound of its input
     return y, idx
 
 
@@ -770,4 +836,6 @@ def add_(a, b):
     """a += b (same shape, contiguous)."""
     _chk(a); _chk(b)
     check(lib.bh_add(_p(a), _p(b), _p(a), a.numel(), _stream()), "bh_add")
+    if getattr(a, "_bh_amax", None) is not None:
+        a._bh_amax = None           # the magnitude record described the old contents
     return a

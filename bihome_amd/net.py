@@ -180,7 +180,7 @@ class Program:
 
 class Ctx:
     """Saved tensors of one forward pass."""
-    __slots__ = ("slots", "stats", "descs", "groups", "training", "weights", "wkeys", "wpacked")
+    __slots__ = ("slots", "stats", "descs", "groups", "training", "weights", "wkeys", "wpacked", "precision")
 
     def __init__(self):
         self.slots, self.stats, self.descs, self.weights, self.wkeys, self.wpacked = {}, {}, {}, {}, {}, {}
@@ -269,13 +269,24 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, p
     fold_cache (inference only: not training, nothing saved): a dict - every conv whose only consumer is a BatchNorm
     runs with that BatchNorm folded into its weights and the ReLU / residual add fused into its epilogue."""
     ctx = Ctx() if save else None
+    if int(precision) == K.F16X2 and (packer is None or not packer.f16):
+        # the fp16-piece kernels exist for packed weights with magnitude records of their operands (the BatchNorm kernels of a
+        # training-style pass leave them); the BatchNorm-folded inference pass runs the exact three-piece arithmetic
+        precision = 2
     if packer is not None:
         # a forward that saves for backward is (probably) followed by an optimizer step, whatever module.training says
         # (frozen-BatchNorm fine-tuning runs the backbone in eval() mode): fused optimizers do not bump version counters
         packer.refresh(training or save)
     slots = {0: x}
     if save:
-        ctx.groups, ctx.training = groups, training
+        ctx.groups, ctx.training, ctx.precision = groups, training, int(precision)
+    # precision 4: one zeroed arena of magnitude records, one per BatchNorm output (the operands of the fp16-piece 3x3 kernels)
+    amax_next = None
+    if int(precision) == K.F16X2:
+        nrec = sum(1 for op in prog.ops if op.kind == "bn")
+        amax_arena = torch.zeros(max(nrec, 1) * K.AMAX_FLOATS, dtype=torch.float32, device=x.device)
+        amax_iter = iter(amax_arena.split(K.AMAX_FLOATS))
+        amax_next = lambda: next(amax_iter)
     # BatchNorm sums: one zeroed float64 arena for the whole pass (the kernels accumulate with atomics); a conv whose
     # only consumer is a training-mode BatchNorm accumulates that layer's statistics in its own epilogue
     bn_off, total = {}, 0
@@ -344,7 +355,7 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, p
                 # f32x3 inference: the folded weights in cut fragment order (packed once per fold)
                 ent = fold_cache[(id(cop.mod), id(op.mod))]
                 if len(ent) < 4 or ent[3] is None:
-                    pk = K.WeightPacker(split=K.SPLIT_PIECES[int(precision)])
+                    pk = K.packer_for_precision(precision)
                     pf, _ = pk.get(wf, need_dgrad=False)
                     pk.refresh()
                     fold_cache[(id(cop.mod), id(op.mod))] = (ent[0], ent[1], ent[2], pf)
@@ -383,14 +394,15 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, p
                 lazy = bool(cd.bh_packs and cd.bh_wx3 and 0 < cd.bh_wx3_bytes <= (DET_WS_BYTES if K.deterministic() else X3_WS_BYTES))
             if lazy:
                 st = arena[bn_off[i]:bn_off[i] + K.bn_stats_doubles(groups, m.num_features)]
+                rec = amax_next() if amax_next else None
                 table = K.bn_fwd_coeffs(st, m.weight, m.bias, m.running_mean, m.running_var, groups,
-                                        src.numel() // (m.num_features * groups), m.num_features, m.eps, _momentum(m))
-                out = K.BnOnLoad(src, table, groups, op.relu)
+                                        src.numel() // (m.num_features * groups), m.num_features, m.eps, _momentum(m), amax=rec)
+                out = K.BnOnLoad(src, table, groups, op.relu, amax=rec)
             else:
                 out, st = K.bn_fwd(src, m.weight, m.bias, m.running_mean, m.running_var, res, groups, m.eps,
                                    _momentum(m), op.relu, training,
                                    stats=arena[bn_off[i]:bn_off[i] + K.bn_stats_doubles(groups, m.num_features)],
-                                   stats_ready=i in ready)
+                                   stats_ready=i in ready, amax=amax_next() if (amax_next and m.num_features > 1) else None)
             if training:        # flushed to the `num_batches_tracked` buffer lazily (flush_counters): no per-layer launch
                 m._bh_pending_batches = getattr(m, "_bh_pending_batches", 0) + groups
             if save:
@@ -494,6 +506,13 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
         total += K.bn_stats_doubles(ctx.groups, prog.ops[b].mod.num_features)
     red_arena = torch.zeros(total, dtype=torch.float64, device=gout.device) if total else None
     bn_reduced = {}
+    # precision 4: magnitude records of the BatchNorm input gradients (the gy operand of the fp16-piece dgrad / weight-gradient kernels)
+    amax_next = None
+    if getattr(ctx, "precision", 0) == K.F16X2:
+        nrec = sum(1 for op in prog.ops if op.kind == "bn")
+        amax_arena = torch.zeros(max(nrec, 1) * K.AMAX_FLOATS, dtype=torch.float32, device=gout.device)
+        amax_iter = iter(amax_arena.split(K.AMAX_FLOATS))
+        amax_next = lambda: next(amax_iter)
 
     for i in range(len(prog.ops) - 1, -1, -1):
         op = prog.ops[i]
@@ -553,7 +572,8 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
             gx, gres = K.bn_bwd(g, yb, x, m.weight, ctx.stats[i], m.running_mean, m.running_var, ctx.groups,
                                 m.eps, op.relu, ctx.training, op.res is not None and ((op.res != 0) or want_input_grad),
                                 m.weight.grad if train_w else None, m.bias.grad if train_w else None, beta=m.bias,
-                                had_res=op.res is not None, sums_ready=bn_reduced.get(i))
+                                had_res=op.res is not None, sums_ready=bn_reduced.get(i),
+                                amax=amax_next() if (amax_next and m.num_features > 1) else None)
             if train_w and on_param_grad is not None:
                 on_param_grad(m.weight)
                 on_param_grad(m.bias)
@@ -723,7 +743,7 @@ class Runner:
         if not self.use_packer:
             return None
         if self._packer is None or self._packer_dev != device:
-            pk = K.WeightPacker(split=K.SPLIT_PIECES.get(self.precision, 0))
+            pk = K.packer_for_precision(self.precision)
             for op in self.prog.ops:
                 m = op.mod
                 if (op.kind == "conv" and isinstance(m, nn.Conv2d) and op.extra["weight_fn"] is None and m.kernel_size == (3, 3)

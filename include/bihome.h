@@ -186,16 +186,36 @@ typedef struct {
                              * w_layout 2, every other kernel computes precision 2 as precision 0;
                              * 3 ("f32x2", REDUCED precision, reported separately): two bf16 pieces per operand, both rounded to
                              * nearest (x = hi + mid + e, |e| <= 2^-18 |x|), products hi*hi + hi*mid + mid*hi (~4e-6 per
-                             * product: 13x the fp32 rounding, 500x below precision 1); same kernels as 2 with w_layout 3 */
+                             * product: 13x the fp32 rounding, 500x below precision 1); same kernels as 2 with w_layout 3;
+                             * 4 ("f16x2", round 4: fp32 accuracy at three products): two FP16 pieces per operand of the operand times
+                             * a power-of-two scale per tensor (x 2^k = hi + lo + e, 11 + 11 significand bits and a sign: |e| <= 2^-23
+                             * of the element down to 2^-18 of the tensor's largest magnitude, an absolute 2^-40 of it below), products
+                             * hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 (~2^-22 per product: 16x below precision 3, one or two
+                             * fp32 roundings), results rescaled exactly.  The scales come from MAGNITUDE RECORDS (a_bound / b_bound
+                             * below); same kernels as 3 with w_layout 4; the weight gradient without both records runs as precision 2 */
     int w_layout;           /* 0: w is [Co][kh][kw][Ci].  2: as 1, made with bh_pack3x3_job.split = 1 (three bf16 pieces, 6 bytes
                              * per weight; requires precision 2).  3: as 1, made with split = 2 (two rounded bf16 pieces, 4 bytes
-                             * per weight; requires precision 3).  1 (3x3 / stride 1 / pad 1 only): w is the fragment-ordered copy made
+                             * per weight; requires precision 3).  4: as 1, made with split = 3 by bh_conv3x3_pack_f16 (two fp16 pieces
+                             * and the weights' maxima; requires precision 4 and a_bound).  1 (3x3 / stride 1 / pad 1 only): w is the fragment-ordered copy made
                              * by bh_conv3x3_pack - its `pf` buffer for bh_conv_fwd*, its `pd` buffer for bh_conv_dgrad* -
                              * which the halo-tiled 3x3 kernel streams straight into registers; BH_E_UNSUPPORTED when
                              * that kernel does not take the launch (ask bh_conv_variant first) */
     int route;              /* 0: automatic kernel choice (production).  BH_ROUTE_* bits: explicit per-call routing for
                              * tests and benchmarks (e.g. drive the halo-tiled 3x3 kernel on a grid it would decline) */
+    /* precision 4 only (NULL otherwise; the only per-call members of the descriptor): magnitude records (BH_AMAX_FLOATS floats each,
+     * device memory) of the operand tensors - a_bound: the tensor the launch convolves (x for forward / weight gradient - of the
+     * BatchNorm OUTPUT for the *_bnin forms -, gy for dgrad); b_bound: gy of the weight gradient.  A record holds an upper bound
+     * of max |element| as the maximum over its 16 slots (one per 128-byte line; non-negative floats): written by bh_absmax, by the
+     * *_amax forms of the BatchNorm entry points (measured) or by bh_bn_fwd_coeffs_amax (|gamma| sqrt(rows) + |beta|).  A bound
+     * that is too small overflows fp16 (inf / NaN in the result, never a silently wrong value); one that is too large by 2^j
+     * costs j of the 18 binades of full precision. */
+    const float* a_bound;
+    const float* b_bound;
 } bh_conv_desc;
+#define BH_AMAX_FLOATS 512        /* 16 slots x 32 floats (csrc/common.h BH_AMAX_*) */
+/* record[slot] = max(record[slot], max |x[i]|) over n floats: the record must be zeroed (or hold an earlier bound to be combined with).
+ * One streaming pass: the fallback where no producer kernel left a record. */
+int bh_absmax(const float* x, long long n, float* record, void* stream);
 #define BH_ROUTE_GENERIC_CONV 1   /* fwd / dgrad: never the halo-tiled 3x3 kernel (generic implicit GEMM) */
 #define BH_ROUTE_HALO_SMALL 2     /* fwd / dgrad: let the halo-tiled 3x3 kernel take grids below its workgroup minimum */
 #define BH_ROUTE_NO_STEM7 4       /* fwd: never the dedicated 7x7/2 stem kernel */
@@ -212,12 +232,16 @@ typedef struct {
     float* pd;
     int Co, Ci;
     int split;              /* 0: fp32 fragments (w_layout 1).  1: three bf16 pieces per weight (w_layout 2): pf / pd then hold
-                             * Co*9*Ci*6 bytes each.  2: two rounded bf16 pieces (w_layout 3): Co*9*Ci*4 bytes each */
+                             * Co*9*Ci*6 bytes each.  2: two rounded bf16 pieces (w_layout 3): Co*9*Ci*4 bytes each.  3: two fp16
+                             * pieces of w 2^k (w_layout 4; bh_conv3x3_pack_f16): Co*9*Ci*4 + 64 bytes each - the last 64 bytes hold
+                             * sixteen partial maxima of |w|, from which the pack and every consumer derive k */
     int reserved;
 } bh_pack3x3_job;
 /* Packs the weights of njobs layers in one launch (jobs_dev: device array).  Call after every optimizer step (the
  * parameters changed) before the next forward; frozen layers need it once. */
 int bh_conv3x3_pack(const bh_pack3x3_job* jobs_dev, int njobs, void* stream);
+/* the same for tables with split = 3 jobs: one more launch in front that takes the layers' max |w| */
+int bh_conv3x3_pack_f16(const bh_pack3x3_job* jobs_dev, int njobs, void* stream);
 
 /* Which kernel a launch described by d would run: which = 0 forward, 1 dgrad, 2 wgrad, 3 wgrad through a workspace (bh_conv_wgrad_det).  Writes the kernel template
  * instantiation (the symbol rocprofv3 lists, e.g. "conv3x3_halo_kernel<false,64,false,2>"; several launches joined by
@@ -250,6 +274,10 @@ typedef struct {
 } bh_bn_in;
 int bh_bn_fwd_coeffs(const double* stats, const float* gamma, const float* beta, float* running_mean, float* running_var, int groups,
                      int rows, int C, float eps, float momentum, float* table, void* stream);
+/* bh_bn_fwd_coeffs + the magnitude record of the BatchNorm's OUTPUT (what the *_bnin consumers convolve): the a-priori bound
+ * max_c 2 (|gamma_c| sqrt(rows) + |beta_c|) - a normalised sample is at most sqrt(rows - 1) standard deviations from its mean. */
+int bh_bn_fwd_coeffs_amax(const double* stats, const float* gamma, const float* beta, float* running_mean, float* running_var, int groups,
+                          int rows, int C, float eps, float momentum, float* table, float* amax_y, void* stream);
 int bh_conv_fwd_bnin(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, double* sums, int groups,
                      const bh_bn_in* bni, void* stream);
 int bh_conv_wgrad_bnin(const float* x, const float* gy, float* gw, float* gbias, const bh_conv_desc* d, float* ws, long long ws_bytes,
@@ -332,6 +360,10 @@ int bh_bn_scratch_doubles(int groups, int C);
 int bh_bn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
               const float* res, float* y, double* stats, int groups, int rows, int C, float eps, float momentum,
               int flags, int use_running, void* stream);
+/* the same, and amax_y (BH_AMAX_FLOATS floats, zeroed by the caller) receives the measured max |y| (precision 4 consumers) */
+int bh_bn_fwd_amax(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                   const float* res, float* y, double* stats, int groups, int rows, int C, float eps, float momentum,
+                   int flags, int use_running, float* amax_y, void* stream);
 /* adjoint. gy: grad w.r.t. y; y: the forward output (for the relu mask); x: forward input.
  * -> gx (overwritten), gres (written when non-NULL: = masked gy), ggamma/gbeta += (NULL ok => frozen).
  * flags bit2 (only without residual): recompute the ReLU mask from x (y is not read, may be NULL).
@@ -341,6 +373,12 @@ int bh_bn_bwd(const float* gy, const float* y, const float* x, const float* gamm
               float* gx, float* gres, float* ggamma, float* gbeta, double* scratch,
               int groups, int rows, int C, float eps, int flags, int use_running,
               const float* running_mean, const float* running_var, void* stream);
+
+/* the same, and amax_gx (BH_AMAX_FLOATS floats, zeroed by the caller) receives the measured max |gx| */
+int bh_bn_bwd_amax(const float* gy, const float* y, const float* x, const float* gamma, const float* beta, const double* stats,
+                   float* gx, float* gres, float* ggamma, float* gbeta, double* scratch,
+                   int groups, int rows, int C, float eps, int flags, int use_running,
+                   const float* running_mean, const float* running_var, float* amax_gx, void* stream);
 
 /* Fused tail of the Zeng backbone, `layer8` (src/backbones/Rethinking.py:145-147):
  *   Conv2d(Ci,Cm,1,bias) -> BatchNorm2d(Cm) -> ReLU -> Conv2d(Cm,Co,1,bias), NHWC x[groups*rows,Ci] -> NCHW out[N,Co,h,w]

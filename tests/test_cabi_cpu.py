@@ -94,34 +94,34 @@ def test_conv_variant_query_reports_the_dispatch():
     from bihome_amd import kernels as K
     from bihome_amd._lib import ROUTE_GENERIC_CONV, ROUTE_HALO_SMALL, ROUTE_NO_STEM7, ROUTE_WGRAD_3TAP, ROUTE_WGRAD_GENERIC
     d = K.conv_desc(128, 32, 32, 64, 64, 3, 1, 1)
-    assert K.conv_variant(d, "fwd") == "conv3x3_halo_kernel<false,64,false,2,false,false,false,3,false>"
-    assert K.conv_variant(d, "fwd", bn_groups=2) == "conv3x3_halo_kernel<false,64,false,2,false,false,false,3,false>"
-    assert K.conv_variant(d, "dgrad") == "conv3x3_halo_kernel<true,64,false,2,false,false,false,3,false>"
+    assert K.conv_variant(d, "fwd") == "conv3x3_halo_kernel<false,64,false,2,false,false,false,3,false,false>"
+    assert K.conv_variant(d, "fwd", bn_groups=2) == "conv3x3_halo_kernel<false,64,false,2,false,false,false,3,false,false>"
+    assert K.conv_variant(d, "dgrad") == "conv3x3_halo_kernel<true,64,false,2,false,false,false,3,false,false>"
     assert K.conv_variant(d, "wgrad") == "wgrad_s1_kernel<1,false>"
     assert K.dgrad_bn_reduce_ok(d)
     d8 = K.conv_desc(128, 8, 8, 256, 256, 3, 1, 1)
-    assert K.conv_variant(d8, "fwd") == "conv3x3_halo_kernel<false,64,false,1,false,false,false,3,false>"          # one sub-tile per workgroup
-    assert K.conv_variant(K.conv_desc(128, 128, 128, 32, 32, 3, 1, 1), "fwd") == "conv3x3_halo_kernel<false,32,false,2,false,false,false,3,false>"
+    assert K.conv_variant(d8, "fwd") == "conv3x3_halo_kernel<false,64,false,1,false,false,false,3,false,false>"          # one sub-tile per workgroup
+    assert K.conv_variant(K.conv_desc(128, 128, 128, 32, 32, 3, 1, 1), "fwd") == "conv3x3_halo_kernel<false,32,false,2,false,false,false,3,false,false>"
     assert K.conv_variant(K.conv_desc(128, 32, 32, 64, 64, 3, 1, 1, precision=1), "wgrad") == "wgrad_s1_kernel<3,true>"
     # packed weights (w_layout 1: fp32 fragments, 2: three bf16 pieces with precision 2 = the default 'f32' arithmetic of the models)
-    assert K.conv_variant(K._with_layout(d, 1), "fwd") == "conv3x3_halo_kernel<false,64,false,2,true,false,false,3,false>"
+    assert K.conv_variant(K._with_layout(d, 1), "fwd") == "conv3x3_halo_kernel<false,64,false,2,true,false,false,3,false,false>"
     dx = K.conv_desc(128, 32, 32, 64, 64, 3, 1, 1, precision=K.PRECISION["f32"])
     assert dx.precision == 2 and K.PRECISION["f32-mfma"] == 0
-    assert K.conv_variant(K._with_layout(dx, 2), "fwd") == "conv3x3_halo_kernel<false,64,false,2,true,true,false,3,false>"
-    assert K.conv_variant(K._with_layout(dx, 2), "dgrad") == "conv3x3_halo_kernel<true,64,false,2,true,true,false,3,false>"
-    assert K.conv_variant(dx, "fwd") == "conv3x3_halo_kernel<false,64,false,2,false,false,false,3,false>" and K.conv_variant(dx, "wgrad") == "wgrad_x3_kernel<64,false,3>"
+    assert K.conv_variant(K._with_layout(dx, 2), "fwd") == "conv3x3_halo_kernel<false,64,false,2,true,true,false,3,false,false>"
+    assert K.conv_variant(K._with_layout(dx, 2), "dgrad") == "conv3x3_halo_kernel<true,64,false,2,true,true,false,3,false,false>"
+    assert K.conv_variant(dx, "fwd") == "conv3x3_halo_kernel<false,64,false,2,false,false,false,3,false,false>" and K.conv_variant(dx, "wgrad") == "wgrad_x3_kernel<64,false,3,false>"
     assert K.wgrad_det_bytes(dx) == 256 * 36864 * 4                       # 256 partial blocks of 64 x 9 x 64
     # 'f32x2' (precision 3, w_layout 3: two rounded bf16 pieces, three products) - the same kernels with NP = 2
     d2 = K.conv_desc(128, 32, 32, 64, 64, 3, 1, 1, precision=K.PRECISION["f32x2"])
     assert d2.precision == 3 and K.packed_layout(3) == 3 and K.SPLIT_PIECES[3] == 2
-    assert K.conv_variant(K._with_layout(d2, 3), "fwd") == "conv3x3_halo_kernel<false,64,false,2,true,true,false,2,false>"
-    assert K.conv_variant(K._with_layout(d2, 3), "dgrad") == "conv3x3_halo_kernel<true,64,false,2,true,true,false,2,false>"
-    assert K.conv_variant(d2, "wgrad_det") == "wgrad_x3_kernel<64,false,2>+wgrad_x3_reduce_kernel<64>"
+    assert K.conv_variant(K._with_layout(d2, 3), "fwd") == "conv3x3_halo_kernel<false,64,false,2,true,true,false,2,false,false>"
+    assert K.conv_variant(K._with_layout(d2, 3), "dgrad") == "conv3x3_halo_kernel<true,64,false,2,true,true,false,2,false,false>"
+    assert K.conv_variant(d2, "wgrad_det") == "wgrad_x3_kernel<64,false,2,false>+wgrad_x3_reduce_kernel<64>"
     for lay, prec in ((2, 3), (3, 2), (3, 0)):
         with pytest.raises(RuntimeError):
             K.conv_variant(K._with_layout(K.conv_desc(128, 32, 32, 64, 64, 3, 1, 1, precision=prec), lay), "fwd")   # layout <-> precision
     d32 = K.conv_desc(128, 64, 64, 32, 32, 3, 1, 1, precision=2)
-    assert K.conv_variant(d32, "wgrad") == "wgrad_x3_kernel<32,false,3>" and K.conv_variant(d32, "wgrad_det") == "wgrad_x3_kernel<32,false,3>+wgrad_x3_reduce_kernel<32>"
+    assert K.conv_variant(d32, "wgrad") == "wgrad_x3_kernel<32,false,3,false>" and K.conv_variant(d32, "wgrad_det") == "wgrad_x3_kernel<32,false,3,false>+wgrad_x3_reduce_kernel<32>"
     assert K.conv_variant(K.conv_desc(128, 128, 128, 16, 16, 3, 1, 1, precision=2), "wgrad").startswith("wgrad_small")           # channels % 32
     with pytest.raises(RuntimeError):
         K.conv_variant(K._with_layout(d, 2), "fwd")                  # split weights need precision 2

@@ -561,8 +561,8 @@ def test_conv3x3_f32x3_is_fp32_accurate(K, N, H, Ci, Co, wide):
         pf, pd = pk.get(w)
         pk.refresh()
         dp = K._with_layout(d, 2 if prec == 2 else 1)
-        assert K.conv_variant(dp, "fwd").endswith(",true,true,false,3,false>" if prec == 2 else ",true,false,false,3,false>")
-        assert K.conv_variant(dp, "dgrad").endswith(",true,true,false,3,false>" if prec == 2 else ",true,false,false,3,false>")
+        assert K.conv_variant(dp, "fwd").endswith(",true,true,false,3,false,false>" if prec == 2 else ",true,false,false,3,false,false>")
+        assert K.conv_variant(dp, "dgrad").endswith(",true,true,false,3,false,false>" if prec == 2 else ",true,false,false,3,false,false>")
         y = K.conv_fwd(x, wk, b, d, wpacked=pf)
         s = K.bn_stats_buffer(1, Co, "cuda")
         assert torch.equal(y, K.conv_fwd(x, wk, b, d, bn_sums=s, groups=1, wpacked=pf))
@@ -836,7 +836,7 @@ def test_conv3x3_f32x2_two_piece_mode(K, N, H, Ci, Co):
             pf, pd = pk.get(w)
             pk.refresh()
             dp = K._with_layout(d, K.packed_layout(prec))
-            assert K.conv_variant(dp, "fwd").endswith(",true,true,false,%d,false>" % K.SPLIT_PIECES[prec])
+            assert K.conv_variant(dp, "fwd").endswith(",true,true,false,%d,false,false>" % K.SPLIT_PIECES[prec])
             y = K.conv_fwd(x, wk, b, d, wpacked=pf)
             s = K.bn_stats_buffer(1, Co, "cuda")
             assert torch.equal(y, K.conv_fwd(x, wk, b, d, bn_sums=s, groups=1, wpacked=pf))
@@ -847,7 +847,7 @@ def test_conv3x3_f32x2_two_piece_mode(K, N, H, Ci, Co):
         gw = torch.zeros(Co, 3, 3, Ci, device="cuda")
         need = K.wgrad_det_bytes(d)
         if prec != 1 and need > 0:
-            assert K.conv_variant(d, "wgrad_det").startswith("wgrad_x3_kernel<%d,false,%d>" % (64 if (Ci % 64 == 0 and Co % 64 == 0) else 32, K.SPLIT_PIECES[prec]))
+            assert K.conv_variant(d, "wgrad_det").startswith("wgrad_x3_kernel<%d,false,%d,false>" % (64 if (Ci % 64 == 0 and Co % 64 == 0) else 32, K.SPLIT_PIECES[prec]))
             K.conv_wgrad(x, gy, gw, None, d, det_ws=torch.empty(need // 4, dtype=torch.float32, device="cuda"))
         else:
             K.conv_wgrad(x, gy, gw, None, d)
@@ -882,7 +882,7 @@ def test_conv3x3_halo_kernel_on_4x4_maps(K, N, Ci, Co, prec, groups):
     b = torch.randn(Co, generator=g).cuda()
     d = K.conv_desc(N, 4, 4, Ci, Co, 3, 1, 1, precision=prec, route=ROUTE_HALO_SMALL)
     dp = K._with_layout(d, K.packed_layout(prec))
-    assert K.conv_variant(dp, "fwd").endswith(",%d,true>" % K.SPLIT_PIECES[prec]) and K.conv_variant(dp, "dgrad").endswith(",%d,true>" % K.SPLIT_PIECES[prec])
+    assert K.conv_variant(dp, "fwd").endswith(",%d,true,false>" % K.SPLIT_PIECES[prec]) and K.conv_variant(dp, "dgrad").endswith(",%d,true,false>" % K.SPLIT_PIECES[prec])
     assert K.packs_3x3(d)
     pk = K.WeightPacker(split=K.SPLIT_PIECES[prec])
     pf, pd = pk.get(w)

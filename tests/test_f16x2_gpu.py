@@ -1,0 +1,242 @@
+"""'f16x2' arithmetic (bh_conv_desc.precision = 4, round 4): two FP16 pieces per operand with a power-of-two scale per tensor, three
+products per product on v_mfma_f32_32x32x16_f16 - the 3x3 / stride-1 layers (forward, dgrad, weight gradient) at fp32 accuracy for
+half the matrix-pipe work of f32x3.  Every kernel is compared with torch float64 NEXT TO the fp32-input MFMA kernel (precision 0)
+and the exact three-piece form (precision 2) on the same data: the claim under test is "within 4x of the fp32-input MFMA kernel's
+error" (VERDICT r03 item 1), on every shape of the f32x3 tests including the 24-binade and the cancellation case."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    from bihome_amd import kernels
+    return kernels
+
+
+def _packed(K, w, prec):
+    pk = K.packer_for_precision(prec) if prec in K.SPLIT_PIECES else K.WeightPacker()
+    pf, pd = pk.get(w)
+    pk.refresh()
+    return pk, pf, pd
+
+
+def _rel(a, ref):
+    return ((a.cpu().double() - ref).norm() / ref.norm()).item()
+
+
+@pytest.mark.parametrize("N,H,Ci,Co,wide", [
+    (128, 32, 64, 64, False),    # the bench shape: two tile positions per workgroup, two chunks
+    (8, 16, 128, 128, False),    # four chunks, two n tiles
+    (8, 8, 256, 256, False),     # one sub-tile per workgroup, eight chunks
+    (4, 64, 32, 32, False),      # 32-channel tile, single chunk (one halo stage)
+    (3, 24, 96, 160, False),     # odd sub-tile count, three chunks, 64- and 32-wide n tiles
+    (5, 16, 32, 64, False),      # single chunk, odd image count
+    (8, 16, 64, 64, True),       # operands spread over 24 binades
+])
+def test_conv3x3_f16x2_forward_and_dgrad(K, N, H, Ci, Co, wide):
+    from bihome_amd._lib import ROUTE_HALO_SMALL
+    g = torch.Generator().manual_seed(N * 7 + H)
+    x = torch.randn(N, H, H, Ci, generator=g)
+    gy = torch.randn(N, H, H, Co, generator=g) * 1e-4                    # gradients are small numbers: the scale has work to do
+    if wide:
+        x = x * torch.exp2(torch.randint(-12, 12, x.shape, generator=g).float())
+        gy = gy * torch.exp2(torch.randint(-12, 12, gy.shape, generator=g).float())
+    x, gy = x.cuda(), gy.cuda()
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * 0.05).cuda().contiguous(memory_format=torch.channels_last)
+    wk = w.permute(0, 2, 3, 1)
+    b = torch.randn(Co, generator=g).cuda()
+    xd, wd = x.double().cpu().permute(0, 3, 1, 2), w.double().cpu()
+    ref = F.conv2d(xd, wd, b.double().cpu(), 1, 1).permute(0, 2, 3, 1)
+    refd = F.conv_transpose2d(gy.double().cpu().permute(0, 3, 1, 2), wd, None, 1, 1).permute(0, 2, 3, 1)
+    err = {}
+    for prec in (0, 2, 3, 4):
+        d = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=prec, route=ROUTE_HALO_SMALL)
+        pk, pf, pd = _packed(K, w, prec)
+        dp = K._with_layout(d, K.packed_layout(prec))
+        if prec == 4:
+            assert K.conv_variant(dp, "fwd").endswith(",true,true,false,2,false,true>") and K.conv_variant(dp, "dgrad").endswith(",2,false,true>")
+        y = K.conv_fwd(x, wk, b, d, wpacked=pf)
+        s = K.bn_stats_buffer(1, Co, "cuda")
+        assert torch.equal(y, K.conv_fwd(x, wk, b, d, bn_sums=s, groups=1, wpacked=pf))
+        gx = K.conv_dgrad(gy, wk, d, wpacked=pd)
+        acc = x.clone()
+        acc._bh_amax = None
+        K.conv_dgrad(gy, wk, d, out=acc, wpacked=pd)
+        assert _rel(acc, (x + gx).cpu().double()) < 1e-6
+        err[prec] = (_rel(y, ref), _rel(gx, refd))
+    print("\nf16x2 fwd/dgrad N%d H%d %d->%d%s: rel-L2 vs f64  fp32-mfma %.2e / %.2e  f32x3 %.2e / %.2e  f32x2 %.2e / %.2e  f16x2 %.2e / %.2e"
+          % (N, H, Ci, Co, " wide" if wide else "", *err[0], *err[2], *err[3], *err[4]))
+    assert err[4][0] <= 4.0 * err[0][0] and err[4][1] <= 4.0 * err[0][1], err
+    assert err[4][0] < 0.2 * err[3][0] and err[4][1] < 0.2 * err[3][1], err       # and well below the two-piece bf16 form
+
+
+def test_f16x2_packed_pieces_reconstruct_the_weights(K):
+    Co, Ci = 64, 96
+    g = torch.Generator().manual_seed(3)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * torch.exp2(torch.randint(-10, 3, (Co, Ci, 3, 3), generator=g).float())).cuda()
+    w = w.contiguous(memory_format=torch.channels_last)
+    wk = w.permute(0, 2, 3, 1)
+    pk, pf, pd = _packed(K, w, 4)
+    n = Co * 9 * Ci
+    assert pf.numel() == n + 16 and pd.numel() == n + 16
+    amax = pf[n:].max().item()
+    assert amax == w.abs().max().item() and pd[n:].max().item() == amax
+    import math
+    k = 14 - math.floor(math.log2(amax))
+    pieces = pf[:n].view(torch.float16).view(-1, 2, 2, 64, 8)                     # [chunk*tap*ntile][piece][step][lane][e]
+    assert torch.isfinite(pieces.float()).all() and pieces[:, 0].abs().max().item() < 2.0 ** 15 * 1.0001
+    total = pieces.double().sum(1) * 2.0 ** -k
+    NW = Co // 32
+    back = torch.empty(Co, 9, Ci, dtype=torch.float64, device="cuda")
+    t = total.view(Ci // 32, 9, NW, 2, 2, 32, 8)                                  # [c][tap][nt][s2][kh2][l31][e]
+    back.view(NW, 32, 9, Ci // 32, 2, 2, 8).copy_(t.permute(2, 5, 1, 0, 3, 4, 6))
+    wref = wk.reshape(Co, 9, Ci).double()
+    # 22 bits and a sign down to 2^-18 of the maximum, an absolute 2^-40 of it (2^-25 in scaled units) below
+    tol = torch.maximum(wref.abs() * 2.0 ** -22, torch.full_like(wref, 2.0 ** -25 * 2.0 ** -k))
+    assert ((back - wref).abs() <= tol).all()
+
+
+@pytest.mark.parametrize("N,H,Ci,Co", [
+    (128, 32, 64, 64), (2, 8, 64, 64), (3, 24, 64, 128), (8, 8, 256, 128), (16, 16, 128, 128), (5, 40, 64, 64), (4, 64, 32, 32),
+    (3, 24, 32, 96), (2, 16, 64, 32),
+])
+def test_wgrad_f16x2_kernel(K, N, H, Ci, Co):
+    g = torch.Generator().manual_seed(N + H + Ci)
+    x = torch.randn(N, H, H, Ci, generator=g).cuda()
+    gy = (torch.randn(N, H, H, Co, generator=g) * 3e-5).cuda()
+    w = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x.double().cpu().permute(0, 3, 1, 2), w, None, 1, 1)
+    ref = torch.autograd.grad(y, w, gy.double().cpu().permute(0, 3, 1, 2))[0].permute(0, 2, 3, 1)       # [Co][3][3][Ci]
+    err = {}
+    for prec in (0, 2, 3, 4):
+        d = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=prec)
+        need = K.wgrad_det_bytes(d)
+        ws = torch.empty(max(need, 4) // 4, dtype=torch.float32, device="cuda") if need else None
+        gw = torch.zeros(Co, 3, 3, Ci, device="cuda")
+        K.conv_wgrad(x, gy, gw, None, d, det_ws=ws)
+        err[prec] = _rel(gw, ref)
+        if prec == 4:
+            assert K.conv_variant(d, "wgrad_det").startswith("wgrad_x3_kernel<%d,false,2,true>" % (64 if (Ci % 64 == 0 and Co % 64 == 0) else 32))
+            g1 = torch.ones(Co, 3, 3, Ci, device="cuda")
+            K.conv_wgrad(x, gy, g1, None, d, det_ws=ws)
+            assert _rel(g1 - 1.0, gw.cpu().double()) < 1e-2 * 1.0 and torch.equal(gw, gw)       # lands on what gw holds (1 + 1e-5-sized entries)
+            gw2 = torch.zeros(Co, 3, 3, Ci, device="cuda")
+            K.conv_wgrad(x, gy, gw2, None, d, det_ws=ws)
+            assert torch.equal(gw, gw2)                                                          # workspace form: bitwise repeatable
+            gw3 = torch.zeros(Co, 3, 3, Ci, device="cuda")
+            K.conv_wgrad(x, gy, gw3, None, d)                                                    # atomics form
+            assert _rel(gw3, gw.cpu().double()) < 2e-6
+    print("\nf16x2 wgrad N%d H%d %d->%d: rel-L2 vs f64  fp32-mfma %.2e  f32x3 %.2e  f32x2 %.2e  f16x2 %.2e" % (N, H, Ci, Co, err[0], err[2], err[3], err[4]))
+    assert err[4] <= 4.0 * err[0] + 1e-8 and err[4] < 0.25 * err[3], err
+
+
+def test_conv3x3_f16x2_error_bound_under_cancellation(K):
+    """Dot products whose terms cancel to ~1e-4 of sum |a||b|, operands with all 24 significand bits set: the ABSOLUTE error in units
+    of sum_k |a_k||b_k| 2^-24 stays a small constant (f32x3: <= 4; f16x2 drops 2 bits per operand: <= 16)."""
+    from bihome_amd._lib import ROUTE_HALO_SMALL
+    N, H, Ci, Co = 8, 16, 64, 64
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(N, H, H, Ci, generator=g)
+    x = (x.view(torch.int32) | 0x7FF).view(torch.float32)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) * 0.05
+    w[:, 1::2] = -w[:, 0::2] * (1.0 + 1e-4 * torch.randn(Co, Ci // 2, 3, 3, generator=g))
+    x[..., 1::2] = x[..., 0::2] * (1.0 + 1e-4 * torch.randn(N, H, H, Ci // 2, generator=g))
+    x, w = x.cuda(), w.cuda().contiguous(memory_format=torch.channels_last)
+    wk = w.permute(0, 2, 3, 1)
+    xd, wd = x.double().cpu().permute(0, 3, 1, 2), w.double().cpu()
+    ref = F.conv2d(xd, wd, None, 1, 1).permute(0, 2, 3, 1)
+    mag = F.conv2d(xd.abs(), wd.abs(), None, 1, 1).permute(0, 2, 3, 1)
+    assert (ref.abs() / mag).median() < 1e-3
+    ulps = {}
+    for prec in (0, 2, 3, 4):
+        d = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=prec, route=ROUTE_HALO_SMALL)
+        pk, pf, _ = _packed(K, w, prec)
+        y = K.conv_fwd(x, wk, None, d, wpacked=pf)
+        ulps[prec] = ((y.cpu().double() - ref).abs() / (mag * 2.0 ** -24)).max().item()
+    print("\ncancellation: max |err| / (sum|a||b| 2^-24): fp32-mfma %.2f  f32x3 %.2f  f32x2 %.2f  f16x2 %.2f" % (ulps[0], ulps[2], ulps[3], ulps[4]))
+    assert ulps[4] < 16.0 and ulps[4] < 0.1 * ulps[3], ulps
+
+
+@pytest.mark.parametrize("N,H,Ci,Co,relu", [(8, 16, 64, 64, True), (4, 32, 32, 32, False), (16, 8, 256, 256, True), (6, 24, 128, 64, True)])
+def test_f16x2_batchnorm_on_load_and_records(K, N, H, Ci, Co, relu):
+    """The BatchNorm kernels leave the magnitude records the fp16-piece consumers need: bn_fwd / bn_bwd measure max |y| / max |gx|
+    exactly, bn_fwd_coeffs writes the a-priori bound (>= the actual maximum); BatchNorm-on-load forward + weight gradient in f16x2
+    against the materialised float64 form."""
+    from bihome_amd._lib import ROUTE_HALO_SMALL
+    groups = 2
+    g = torch.Generator().manual_seed(N + Ci)
+    z = (torch.randn(N, H, H, Ci, generator=g) * 3.0 + 1.0).cuda()
+    gamma = (torch.rand(Ci, generator=g) + 0.5).cuda()
+    beta = (torch.randn(Ci, generator=g) * 0.2).cuda()
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * 0.05).cuda().contiguous(memory_format=torch.channels_last)
+    wk = w.permute(0, 2, 3, 1)
+    gy = (torch.randn(N, H, H, Co, generator=g) * 1e-3).cuda()
+    rows = N * H * H // groups
+    # float64 reference of BatchNorm(+ReLU) per group, conv forward and weight gradient
+    zd = z.double().cpu().view(groups, -1, Ci)
+    mu, var = zd.mean(1, keepdim=True), zd.var(1, unbiased=False, keepdim=True)
+    yd = ((zd - mu) / torch.sqrt(var + 1e-5) * gamma.double().cpu() + beta.double().cpu())
+    if relu:
+        yd = yd.clamp_min(0)
+    yd = yd.view(N, H, H, Ci)
+    wt = w.double().cpu().requires_grad_(True)
+    out = F.conv2d(yd.permute(0, 3, 1, 2), wt, None, 1, 1)
+    gw_ref = torch.autograd.grad(out, wt, gy.double().cpu().permute(0, 3, 1, 2))[0].permute(0, 2, 3, 1)
+    ref = out.detach().permute(0, 2, 3, 1)
+    # measured record of the materialised form
+    rm, rv = torch.zeros(Ci, device="cuda"), torch.ones(Ci, device="cuda")
+    rec = K.amax_record("cuda")
+    y, st = K.bn_fwd(z, gamma, beta, rm, rv, None, groups, 1e-5, 0.1, relu, True, amax=rec)
+    assert y._bh_amax is rec and rec.max().item() == y.abs().max().item()
+    # a-priori record of the on-load form
+    st2 = K.bn_stats_buffer(groups, Ci, "cuda")
+    st2.copy_(st)
+    rec2 = K.amax_record("cuda")
+    table = K.bn_fwd_coeffs(st2, gamma, beta, rm.clone(), rv.clone(), groups, rows, Ci, 1e-5, 0.1, amax=rec2)
+    bound = rec2.max().item()
+    assert bound >= yd.abs().max().item() and bound <= 4.0 * ((gamma.abs().max().item()) * rows ** 0.5 + beta.abs().max().item())
+    err = {}
+    for prec in (2, 4):
+        d = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=prec, route=ROUTE_HALO_SMALL)
+        d.bh_wx3 = True
+        pk, pf, pd = _packed(K, w, prec)
+        bol = K.BnOnLoad(z, table, groups, relu, amax=rec2)
+        yo = K.conv_fwd(bol, wk, None, d, wpacked=pf)
+        need = K.wgrad_det_bytes(d)
+        ws = torch.empty(need // 4, dtype=torch.float32, device="cuda")
+        gw = torch.zeros(Co, 3, 3, Ci, device="cuda")
+        K.conv_wgrad(bol, gy, gw, None, d, det_ws=ws)
+        err[prec] = (_rel(yo, ref), _rel(gw, gw_ref))
+    print("\nBatchNorm-on-load N%d H%d %d->%d: fwd / wgrad rel-L2 vs f64  f32x3 %.2e / %.2e  f16x2 %.2e / %.2e" % (N, H, Ci, Co, *err[2], *err[4]))
+    assert err[4][0] <= 4.0 * err[2][0] + 1e-7 and err[4][1] <= 4.0 * err[2][1] + 1e-7, err
+    # backward record: max |gx| measured by the apply kernel
+    g_in = (torch.randn(N, H, H, Ci, generator=g) * 1e-2).cuda()
+    recb = K.amax_record("cuda")
+    gx, _ = K.bn_bwd(g_in, y, z, gamma, st, rm, rv, groups, 1e-5, relu, True, False, beta=beta, had_res=False, amax=recb)
+    assert gx._bh_amax is recb and recb.max().item() == gx.abs().max().item()
+
+
+def test_f16x2_a_wrong_record_is_loud_not_silently_wrong(K):
+    """A magnitude record that UNDERSTATES the tensor overflows fp16: the result carries inf / NaN, never a plausible wrong number;
+    an overstated one (2^10 too large) only costs precision gracefully."""
+    from bihome_amd._lib import ROUTE_HALO_SMALL
+    N, H, Ci, Co = 8, 16, 64, 64
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, H, H, Ci, generator=g).cuda()
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * 0.05).cuda().contiguous(memory_format=torch.channels_last)
+    wk = w.permute(0, 2, 3, 1)
+    ref = F.conv2d(x.double().cpu().permute(0, 3, 1, 2), w.double().cpu(), None, 1, 1).permute(0, 2, 3, 1)
+    d = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=4, route=ROUTE_HALO_SMALL)
+    pk, pf, _ = _packed(K, w, 4)
+    x._bh_amax = torch.full((K.AMAX_FLOATS,), 1e-3, device="cuda")
+    y = K.conv_fwd(x, wk, None, d, wpacked=pf)
+    assert not torch.isfinite(y).all()
+    x._bh_amax = torch.full((K.AMAX_FLOATS,), float(x.abs().max().item()) * 1024.0, device="cuda")
+    y = K.conv_fwd(x, wk, None, d, wpacked=pf)
+    assert _rel(y, ref) < 2e-6
+    x._bh_amax = None
+    y = K.conv_fwd(x, wk, None, d, wpacked=pf)           # no record: measured by a streaming pass
+    assert x._bh_amax is not None and x._bh_amax.max().item() == x.abs().max().item() and _rel(y, ref) < 1e-6

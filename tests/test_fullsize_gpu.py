@@ -76,7 +76,7 @@ def _check_grads(model_params, g64, g32, max_bad=4, mult=1.0):
     return e, e32
 
 
-@pytest.mark.parametrize("precision", ["f32", "f32x2"])
+@pytest.mark.parametrize("precision", ["f32", "f16x2", "f32x3", "f32x2"])
 def test_zeng_train_step_b64_vs_oracle(precision):
     """configs[1] at its bench size (64 pairs = 128 stacked images): first forward + backward against the oracle in float32
     and float64 with identical weights and DSAC indices.  'f32x2' (two rounded bf16 pieces per operand in the 3x3 layers, reported
@@ -112,7 +112,9 @@ def test_zeng_train_step_b64_vs_oracle(precision):
     # f32: measured 1.5e-5 (round 2) - 3.0e-5 (round 3, BatchNorm statistics of the stem from its own epilogue), asserted at 6e-5.
     # f32x2 on THIS config sits at north_star's loss bound (measured 1.02e-4: the loss is a difference of nearly equal feature distances;
     # on configs[3], which the mode was built for, it is 4.8e-6): asserted at 2e-4 and stated in DESIGN.md 8; MACE holds 1e-3 with 100x to spare
-    assert rel <= (6e-5 if precision == "f32" else 2e-4), (loss.item(), r64["loss"], r32["loss"])
+    # f16x2 (two fp16 pieces with per-tensor scales, three products; round 4) and f32x3 (the exact three-piece cut, six products) are
+    # held to the SAME assertions as 'f32' - whichever of the two 'f32' maps to
+    assert rel <= (6e-5 if precision != "f32x2" else 2e-4), (loss.item(), r64["loss"], r32["loss"])
     assert abs(mace(dgt, dh) - r64["mace"]) < 1e-3, (mace(dgt, dh), r64["mace"])
     for k in ("pf_hat_12", "pf_hat_21"):
         e, e32 = relerr(data[k].detach().cpu(), r64["fields"][k]), relerr(r32["fields"][k], r64["fields"][k])
@@ -122,7 +124,7 @@ def test_zeng_train_step_b64_vs_oracle(precision):
     _check_grads(model[0].named_parameters(), r64["grads"], r32["grads"], mult=4.0 if precision == "f32x2" else 1.0)
 
 
-@pytest.mark.parametrize("precision", ["f32", "f32x2"])
+@pytest.mark.parametrize("precision", ["f32", "f16x2", "f32x2"])
 def test_detone_step_b64_vs_oracle(precision):
     """configs[3]'s model (ResNet-34 regressor + biHomE) at 64 pairs in float32 against the oracle.  'f32x2' (two rounded bf16
     pieces per operand, three MFMA products: the matrix-pipe-rate mode of configs[3]) is held to the SAME tolerances."""
