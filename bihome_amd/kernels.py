@@ -561,25 +561,41 @@ def conv_fwd(x, w, bias, d, bn_sums=None, groups=1, res=None, relu=False, wpacke
     return y
 
 
-_STEM_WT = {}
+_STEM_WT = {}          # (id(param), device, Ci) -> [version, table]: one table per stem parameter, NEVER freed or replaced - a
+                       # captured HIP graph holds its address; a changed weight is written into the same storage
+_STEM_WT_DIRTY = set()
+
+
+def invalidate_stem_tables():
+    """The weights may have changed behind the version counters (graph replay, broadcast): rebuild every table IN PLACE at its next use."""
+    _STEM_WT_DIRTY.update(_STEM_WT.keys())
 
 
 def _stem_dgrad_two_step(gy, w, d, wkey=None):
     """dgrad of the 1- or 3-input-channel 7x7/2 stem as (1x1 MFMA GEMM gy x w^T -> per-source-pixel tap table) + col2im.
     w is the kernel-layout weight [Co][7][7][Ci]; the result is NCHW [N,Ci,Hi,Wi] (== NHWC for Ci = 1).
-    wkey: identity of the SOURCE parameter, (id(param), param._version) - `w` itself may be a per-forward temporary (the
+    wkey: the SOURCE parameter and its version, (param, param._version) - `w` itself may be a per-forward temporary (the
     extractor's channel-summed stem weight) whose address and version repeat although the parameter changed; without a
     key the transposed table is rebuilt on every call (64 x 52 floats)."""
-    key = None if wkey is None else (wkey, str(w.device), d.Ci)
     cols = 49 * d.Ci
     ld = (cols + 3) // 4 * 4                                                          # 52 / 148
-    wt = _STEM_WT.get(key) if key is not None else None
-    if wt is None:
+    import weakref
+    key = None if wkey is None else (id(wkey[0]), str(w.device), d.Ci)
+    ent = _STEM_WT.get(key) if key is not None else None
+    if ent is not None and (ent[2]() is not wkey[0] or ent[1].shape != (ld, 1, 1, d.Co)):
+        ent = None                                                                    # (the id of a dead parameter was reused)
+    if ent is None:
         wt = torch.zeros(ld, 1, 1, d.Co, dtype=torch.float32, device=w.device)        # [tap*Ci + c, padded][Co]
         wt[:cols, 0, 0, :] = w.reshape(d.Co, cols).t()
         if key is not None:
-            _STEM_WT.clear()
-            _STEM_WT[key] = wt
+            _STEM_WT[key] = [wkey[1], wt, weakref.ref(wkey[0])]
+            _STEM_WT_DIRTY.discard(key)
+    else:
+        wt = ent[1]
+        if ent[0] != wkey[1] or key in _STEM_WT_DIRTY:
+            wt[:cols, 0, 0, :] = w.reshape(d.Co, cols).t()                            # same storage: graph-safe
+            ent[0] = wkey[1]
+            _STEM_WT_DIRTY.discard(key)
     d1 = conv_desc(d.N, d.Ho, d.Wo, d.Co, ld, 1, 1, 0, precision=d.precision)
     tm = conv_fwd(gy, wt, None, d1)                                                   # [N,Ho,Wo,ld]
     shape = (d.N, d.Hi, d.Wi, 1) if d.Ci == 1 else (d.N, d.Ci, d.Hi, d.Wi)
@@ -604,7 +620,7 @@ def conv_dgrad(gy, w, d, out=None, bn_reduce=None, wkey=None, wpacked=None, cols
     """colsum (only when dgrad_bn_reduce_ok(d), no `out`, no bn_reduce): zeroed bn_stats_buffer(1, Ci) - the per-channel sums
     of the gradient written are accumulated in the epilogue (bias gradient of the producer of this conv's input).
     wpacked: the dgrad buffer of WeightPacker for this conv.
-    wkey: (id(param), param._version) of the parameter `w` was derived from (cache key of derived weight tables).
+    wkey: (param, param._version) of the parameter `w` was derived from (cache key of derived weight tables).
     bn_reduce (only when dgrad_bn_reduce_ok(d)): dict(z, y, stats, gamma, beta, eps, relu, sums, groups) of the
     BatchNorm whose output gradient this call completes - its backward sums are accumulated into `sums` (zeroed
     bn_stats_buffer) in the conv epilogue; pass them to bn_bwd(..., sums_ready=sums)."""

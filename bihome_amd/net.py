@@ -197,7 +197,7 @@ def _conv_geometry(mod, x_shape, in_nchw, out_nchw, precision=0):
     3x3 kernel eligible for packed weights / for the fused BatchNorm reduce) and its packed-layout twin: building the
     ctypes struct and asking bh_conv_variant costs ~20 us of host time per launch otherwise, which is what bounds the
     shorter models (ResNet-34 regressor: 13.1 -> 15-17 ms/step when it was done per call)."""
-    key = (id(mod), tuple(x_shape), bool(in_nchw), bool(out_nchw), int(precision))
+    key = (id(mod), tuple(x_shape), bool(in_nchw), bool(out_nchw), int(precision), K.deterministic())   # (the workspace bytes depend on the mode)
     hit = _GEOM_CACHE.get(key)
     if hit is not None and hit[0] is mod:
         return hit[1]
@@ -381,7 +381,7 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, p
             if save:
                 ctx.descs[i], ctx.weights[i] = d, wk
                 ctx.wpacked[i] = pk[2] if pk else None
-                ctx.wkeys[i] = (id(op.mod.weight), op.mod.weight._version)
+                ctx.wkeys[i] = (op.mod.weight, op.mod.weight._version)
         elif op.kind == "bn":
             m = op.mod
             res = slots[op.res] if op.res is not None else None
@@ -689,7 +689,7 @@ def invalidate_caches(model=None):
         r._fold.clear()
         if r._packer is not None:
             r._packer.invalidate()
-    K._STEM_WT.clear()
+    K.invalidate_stem_tables()
 
 
 class Runner:

@@ -61,7 +61,7 @@ def main():
         np.savez(out, flat=flat, loss=loss.item(), w0=w0.numpy(), rm0=rm0.numpy(), n_buckets=len(red.buckets), n_hook=n_hook,
                  w_after=model[0].layer4[0].upper_branch[0].weight.detach().cpu().numpy())
     else:
-        np.savez(out + ".rank1.npz", w0=w0.numpy(), rm0=rm0.numpy(),
+        np.savez(out + ".rank%d.npz" % rank, w0=w0.numpy(), rm0=rm0.numpy(), loss=loss.item(),
                  w_after=model[0].layer4[0].upper_branch[0].weight.detach().cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()

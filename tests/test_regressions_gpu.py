@@ -262,3 +262,39 @@ def test_graph_replays_invalidate_folded_and_packed_caches():
     assert relerr(e1, e2_ref) > 1e-3                        # three optimizer steps really moved the prediction
     loss, _, _ = gs(data)                                   # and training continues on the graph after an eval
     assert np.isfinite(loss.item())
+
+
+def test_graph_replays_keep_the_stem_table_a_captured_graph_reads():
+    """Round-3 ADVICE (medium): invalidate_caches() after a replay used to DROP the transposed stem table of the frozen extractor -
+    the tensor whose address the captured 1x1 GEMM of the stem dgrad reads.  The table must keep its storage (refreshed in place at
+    its next eager use): same address after replays + torch.cuda.empty_cache(), replays still give the captured step's numbers."""
+    from bihome_amd import kernels as K
+    from bihome_amd.graph import GraphedStep
+    from bihome_amd.step import build_model, build_optimizer, train_step
+    cfg = configs.get("zeng-bihome")
+    d = synth.make_pairs(8, seed=16)
+    data = {k: cuda(d[k]) for k in ("patch_1", "patch_2", "delta")}
+    g = torch.Generator().manual_seed(9)
+    data["choice_12"] = torch.randint(1, 128 * 128, (8, 128), generator=g).cuda()
+    data["choice_21"] = torch.randint(1, 128 * 128, (8, 128), generator=g).cuda()
+    model = build_model(cfg)
+    load_synthetic(model[0], 0)
+    load_synthetic(model[1].auxiliary_resnet, 0)
+    opt, sched = build_optimizer(model, cfg["SOLVER"], capturable=True)
+    gs = GraphedStep(model, opt, sched, data)
+    stem = model[1].auxiliary_resnet.resnet.conv1.weight
+    mine = {k: v for k, v in K._STEM_WT.items() if v[2]() is stem}
+    assert len(mine) == 1
+    key, ent = next(iter(mine.items()))
+    ptr, table = ent[1].data_ptr(), ent[1].clone()
+    l1 = gs(data)[0].item()
+    assert K._STEM_WT[key][1].data_ptr() == ptr              # invalidate_caches ran: the entry and its storage are still there
+    junk = [torch.full((1 << 20,), float("nan"), device="cuda") for _ in range(8)]       # anything freed would be reused by these
+    torch.cuda.empty_cache()
+    l2 = gs(data)[0].item()
+    del junk
+    assert np.isfinite(l1) and np.isfinite(l2)
+    assert torch.equal(K._STEM_WT[key][1], table)            # frozen weights: the contents a replay reads never changed
+    # an eager step after the replays rebuilds the (dirty) table into the SAME storage
+    train_step(model, dict(data), opt, None)
+    assert K._STEM_WT[key][1].data_ptr() == ptr and key not in K._STEM_WT_DIRTY and torch.equal(K._STEM_WT[key][1], table)
