@@ -153,7 +153,10 @@ def roofline_leg(model, data, opt, sched, reducer, nsteps=2):
                      "flops_per_launch": r["flops"] / max(r["n"], 1), "bytes_per_launch": r["bytes"] / max(r["n"], 1)})
     K.TIMING = None
     rows.sort(key=lambda r: -r["ms_per_step"])
-    top = rows[0]
+    # the roofline object describes ONE kernel instantiation: rows that time a C-ABI call of several launches ("bn_bwd(3 kernels)",
+    # "tail_bwd(5 kernels)": reduce + finalize + apply of different shapes under one key) stay in the breakdown but are not `top`
+    single = [r for r in rows if "kernels)" not in r["kernel"] or "(1 kernels)" in r["kernel"]]
+    top = single[0] if single else rows[0]
     traffic, traffic_src = pmc_traffic(top["kernel"])
     # BASELINE.json's HBM-bound part: homography warp + perceptual-feature L1 / triplet reduction (SURVEY.md 8(d) bytes)
     hp = [r for r in rows if r["kernel"] in ("warp_fwd_kernel", "warp_bwd_kernel", "triplet_fwd_kernel", "triplet_bwd_kernel")]

@@ -99,6 +99,7 @@ SIGNATURES = {
     "bh_tail_ws_doubles": [c_int, c_int, c_int],
     "bh_tail_scratch_floats": [c_int, c_int, c_int],
     "bh_tail_fwd": [P] * 11 + [c_int] * 6 + [c_float, c_float, c_int, P],
+    "bh_tail_fwd_route": [P] * 11 + [c_int] * 6 + [c_float, c_float, c_int, c_int, P],
     "bh_tail_bwd": [P] * 17 + [c_int] * 6 + [c_float, c_int, P],
     "bh_synth_pairs": [P] * 5 + [c_int] * 5 + [c_float, c_float, P, P, P],
     "bh_maxpool3s2_fwd": [P, P, P, c_int, c_int, c_int, c_int, P],

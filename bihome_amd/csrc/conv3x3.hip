@@ -37,6 +37,11 @@
 #define C3_X3_PIPE 0
 #endif
 
+#ifndef C3_BN32_WAVES
+// waves per SIMD the two-piece 32-channel-tile kernels (the single-chunk full-resolution decoder layers) are compiled for
+#define C3_BN32_WAVES 2
+#endif
+
 #ifdef BH_TUNING
 // phase time stamps (100 MHz wall clock) of the halo kernels: [workgroup tile][8] = start, first barrier, loop end, epilogue end, XCC / CU id
 __device__ unsigned long long g_c3_ts[8 * 16384];
@@ -321,7 +326,7 @@ __device__ __forceinline__ void c3_stats_merge(const C3Args& a, char* redb, doub
 // w_layout 4; common.h F16X2) - same loop, same LDS image as NP = 2, ~2^-22 per product instead of 2^-18; the accumulators are
 // rescaled by 2^-(k_src + k_w) in front of the epilogue.
 template <bool FLIP, int BN, bool BF16 = false, int SUBT = 2, bool PACKED = false, bool X3 = false, bool BNI = false, int NP = 3, bool MAP4 = false, bool F16 = false>
-__global__ void __launch_bounds__(256, X3 ? 2 : 1) conv3x3_halo_kernel(C3Args a) {
+__global__ void __launch_bounds__(256, X3 ? ((BN == 32 && NP == 2 && !BNI) ? C3_BN32_WAVES : 2) : 1) conv3x3_halo_kernel(C3Args a) {
     static_assert(NP == 3 || (NP == 2 && X3), "two pieces: split form only");
     static_assert(!F16 || (X3 && NP == 2), "fp16 pieces: the two-piece split form");
     static_assert(!MAP4 || (X3 && SUBT == 1 && BN == 64 && !BNI), "the 4 x 4 map form: split operands, one sub-tile, 64-channel tile");

@@ -780,8 +780,12 @@ def bn_bwd(gy, y, x, gamma, stats, rmean, rvar, groups, eps, relu, training, wan
     return gx, gres
 
 
-def tail_fwd(x, w1, b1, gamma, beta, rmean, rvar, w2, b2, groups, hw, eps, momentum, training):
-    """x NHWC [N,h,w,Ci] -> out NCHW [N,Co,h,w] through conv1x1+BN+ReLU+conv1x1 (fused); returns (out, ws)."""
+TAIL_ROUTE_VALU_FWD = 1     # include/bihome.h BH_TAIL_ROUTE_VALU_FWD
+
+
+def tail_fwd(x, w1, b1, gamma, beta, rmean, rvar, w2, b2, groups, hw, eps, momentum, training, route=0):
+    """x NHWC [N,h,w,Ci] -> out NCHW [N,Co,h,w] through conv1x1+BN+ReLU+conv1x1 (fused); returns (out, ws).
+    route: per-call bits of bh_tail_fwd_route (TAIL_ROUTE_VALU_FWD keeps the per-pixel VALU kernel)."""
     _chk(x)
     N, h, w, Ci = x.shape
     Cm, Co = w1.shape[0], w2.shape[0]
@@ -789,10 +793,10 @@ def tail_fwd(x, w1, b1, gamma, beta, rmean, rvar, w2, b2, groups, hw, eps, momen
     out = torch.empty((N, Co, h, w), dtype=torch.float32, device=x.device)
     ws = torch.empty(lib.bh_tail_ws_doubles(groups, Ci, Cm), dtype=torch.float64, device=x.device)
     fl = 2.0 * N * h * w * Cm * (Ci + Co)
-    with _Timed("tail_fwd(3 kernels)", fl, 4.0 * (x.numel() * (2 if training else 1) + out.numel())):
-        check(lib.bh_tail_fwd(_p(x), _p(w1), _p(b1), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(w2), _p(b2), _p(out),
-                              _p(ws), groups, rows, hw, Ci, Cm, Co, float(eps), float(momentum), 0 if training else 1,
-                              _stream()), "bh_tail_fwd")
+    with _Timed("tail_fwd(4 kernels)", fl, 4.0 * (x.numel() * (2 if training else 1) + out.numel())):
+        check(lib.bh_tail_fwd_route(_p(x), _p(w1), _p(b1), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(w2), _p(b2), _p(out),
+                                    _p(ws), groups, rows, hw, Ci, Cm, Co, float(eps), float(momentum), 0 if training else 1,
+                                    int(route), _stream()), "bh_tail_fwd")
     return out, ws
 
 
@@ -805,7 +809,7 @@ def tail_bwd(gout, x, w1, b1, gamma, beta, w2, ws, rmean, rvar, groups, hw, eps,
     gx = torch.empty_like(x) if want_gx else None
     scratch = torch.empty(lib.bh_tail_scratch_floats(groups, Ci, Cm), dtype=torch.float32, device=x.device)
     fl = 2.0 * N * h * w * Cm * (3 * Ci + 2 * Co + Ci)
-    with _Timed("tail_bwd(4 kernels)", fl, 4.0 * (x.numel() * 3 + gout.numel() * 3)):
+    with _Timed("tail_bwd(5 kernels)", fl, 4.0 * (x.numel() * 3 + gout.numel() * 3)):
         check(lib.bh_tail_bwd(_p(gout), _p(x), _p(w1), _p(b1), _p(gamma), _p(beta), _p(w2), _p(ws), _p(rmean), _p(rvar),
                               _p(gx), _p(gw1), _p(ggamma), _p(gbeta), _p(gw2), _p(gb2), _p(scratch), groups, rows, hw, Ci,
                               Cm, Co, float(eps), 0 if training else 1, _stream()), "bh_tail_bwd")

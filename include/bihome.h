@@ -391,7 +391,18 @@ int bh_tail_fwd(const float* x, const float* w1, const float* b1, const float* g
                 float* running_mean, float* running_var, const float* w2, const float* b2, float* out, double* ws,
                 int groups, int rows, int hw, int Ci, int Cm, int Co, float eps, float momentum, int use_running,
                 void* stream);
-/* adjoint: gout[N,Co,h,w] -> gx[groups*rows,Ci] (overwritten, NULL ok); gw1[Cm][Ci], ggamma, gbeta, gw2[Co][Cm], gb2 += */
+/* Same call with a per-call route (no process state): 0 = the library's choice - round 4: for Ci = 16, Co <= 2, rows % 32 == 0 and
+ * hw % 32 == 0 the Ci -> Cm product runs on the matrix pipe in the exact three-bf16-piece arithmetic (tail_fwd_mfma_kernel);
+ * bit 0 (BH_TAIL_ROUTE_VALU_FWD) keeps the per-pixel VALU kernel (tests compare the two, tools time them). */
+#define BH_TAIL_ROUTE_VALU_FWD 1
+int bh_tail_fwd_route(const float* x, const float* w1, const float* b1, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, const float* w2, const float* b2, float* out, double* ws,
+                      int groups, int rows, int hw, int Ci, int Cm, int Co, float eps, float momentum, int use_running,
+                      int route, void* stream);
+/* adjoint: gout[N,Co,h,w] -> gx[groups*rows,Ci] (overwritten, NULL ok); gw1[Cm][Ci], ggamma, gbeta, gw2[Co][Cm], gb2 +=
+ * Round 4: pixels whose output gradient is exactly zero are skipped by the reduction (they add exactly zero: on the biHomE path only
+ * the DSAC-sampled points of the field carry a gradient), and gx = c0 - M x (the BatchNorm mean terms, an affine map of x made once
+ * per group) + the Cm-channel term where the gradient is non-zero.  Dense gradients take the per-lane channel loop as before. */
 int bh_tail_bwd(const float* gout, const float* x, const float* w1, const float* b1, const float* gamma,
                 const float* beta, const float* w2, const double* ws, const float* running_mean,
                 const float* running_var, float* gx, float* gw1, float* ggamma, float* gbeta, float* gw2, float* gb2,

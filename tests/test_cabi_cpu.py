@@ -105,8 +105,13 @@ def test_conv_variant_query_reports_the_dispatch():
     assert K.conv_variant(K.conv_desc(128, 32, 32, 64, 64, 3, 1, 1, precision=1), "wgrad") == "wgrad_s1_kernel<3,true>"
     # packed weights (w_layout 1: fp32 fragments, 2: three bf16 pieces with precision 2 = the default 'f32' arithmetic of the models)
     assert K.conv_variant(K._with_layout(d, 1), "fwd") == "conv3x3_halo_kernel<false,64,false,2,true,false,false,3,false,false>"
-    dx = K.conv_desc(128, 32, 32, 64, 64, 3, 1, 1, precision=K.PRECISION["f32"])
-    assert dx.precision == 2 and K.PRECISION["f32-mfma"] == 0
+    assert K.PRECISION["f32"] == 4 and K.PRECISION["f32-mfma"] == 0          # round 4: the default 'f32' is the fp16-piece arithmetic
+    d4 = K.conv_desc(128, 32, 32, 64, 64, 3, 1, 1, precision=K.PRECISION["f32"])
+    assert K.packed_layout(4) == 4 and K.SPLIT_PIECES[4] == 2
+    assert K.conv_variant(K._with_layout(d4, 4), "fwd") == "conv3x3_halo_kernel<false,64,false,2,true,true,false,2,false,true>"
+    assert K.conv_variant(K._with_layout(d4, 4), "dgrad") == "conv3x3_halo_kernel<true,64,false,2,true,true,false,2,false,true>"
+    dx = K.conv_desc(128, 32, 32, 64, 64, 3, 1, 1, precision=K.PRECISION["f32x3"])
+    assert dx.precision == 2
     assert K.conv_variant(K._with_layout(dx, 2), "fwd") == "conv3x3_halo_kernel<false,64,false,2,true,true,false,3,false,false>"
     assert K.conv_variant(K._with_layout(dx, 2), "dgrad") == "conv3x3_halo_kernel<true,64,false,2,true,true,false,3,false,false>"
     assert K.conv_variant(dx, "fwd") == "conv3x3_halo_kernel<false,64,false,2,false,false,false,3,false,false>" and K.conv_variant(dx, "wgrad") == "wgrad_x3_kernel<64,false,3,false>"

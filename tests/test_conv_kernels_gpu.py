@@ -221,10 +221,14 @@ def test_maxpool_gap_add(K, N, H, C):
     assert torch.equal(a, s)
 
 
+@pytest.mark.parametrize("sparse", [0, 1, 2])
 @pytest.mark.parametrize("groups,N,H,Ci,Cm,Co,training", [(2, 2, 16, 16, 128, 2, True), (1, 3, 8, 16, 128, 2, True),
-                                                          (2, 1, 32, 8, 64, 3, True), (2, 2, 16, 16, 128, 2, False)])
-def test_fused_tail_fwd_bwd(K, groups, N, H, Ci, Cm, Co, training):
-    """conv1x1+BN+ReLU+conv1x1 fused (csrc/tail.hip) against the unfused float64 PyTorch chain, one BN call per group."""
+                                                          (2, 1, 32, 8, 64, 3, True), (2, 2, 16, 16, 128, 2, False),
+                                                          (2, 3, 32, 16, 128, 2, True), (1, 2, 16, 16, 64, 1, True)])
+def test_fused_tail_fwd_bwd(K, groups, N, H, Ci, Cm, Co, training, sparse):
+    """conv1x1+BN+ReLU+conv1x1 fused (csrc/tail.hip) against the unfused float64 PyTorch chain, one BN call per group.
+    sparse 1 / 2: the output gradient is non-zero on ~1 % / ~15 % of the pixels only (the biHomE field gradient lives on the DSAC
+    samples): the zero-skipping reduction and the affine + sparse / + dense-wave forms of the input gradient (round 4)."""
     NN = groups * N
     x = (rnd((NN, Ci, H, H), 40) * 1.5 + 0.3).astype(np.float32)
     w1 = (rnd((Cm, Ci, 1, 1), 41) / np.sqrt(Ci)).astype(np.float32)
@@ -252,7 +256,17 @@ def test_fused_tail_fwd_bwd(K, groups, N, H, Ci, Cm, Co, training):
     close(out.cpu(), ref.detach(), 3e-5)
     close(rm.cpu(), bn.running_mean, 1e-5)
     close(rv.cpu(), bn.running_var, 2e-5)
+    if sparse == 0:
+        # the matrix-pipe forward (the library's choice where the shape allows) against the per-pixel VALU forward: same fp32-grade result
+        rm2, rv2 = C(rm0), C(rv0)
+        a2 = args[:4] + (rm2, rv2) + args[6:]
+        out_v, _ = K.tail_fwd(xg, *a2, groups, H * H, bn.eps, 0.1, training, route=K.TAIL_ROUTE_VALU_FWD)
+        close(out_v.cpu(), ref.detach(), 3e-5)
+        close(out.cpu(), out_v.cpu(), 1e-5)
     gy = rnd(tuple(ref.shape), 49)
+    if sparse:
+        keep = np.random.RandomState(77).rand(NN, 1, H, H) < (0.01 if sparse == 1 else 0.15)
+        gy = np.where(np.broadcast_to(keep, gy.shape), gy, 0).astype(np.float32)
     # ReLU inputs within rounding of zero may take the other branch in float32: keep them out of the gradient check
     near = (torch.cat(pre, 0).detach().abs() < 1e-4).any(1, keepdim=True).numpy()
     gy = np.where(np.broadcast_to(near, gy.shape), 0, gy).astype(np.float32)
@@ -498,7 +512,7 @@ def test_conv3x3_packed_weights_match_lds_slab_path(K, N, H, Ci, Co, prec):
     pf, pd = pk.get(w)
     pk.refresh()
     dp = K._with_layout(d, 1)
-    assert K.conv_variant(dp, "fwd").endswith(",true,false,false,3,false>") and K.conv_variant(dp, "dgrad").endswith(",true,false,false,3,false>")
+    assert K.conv_variant(dp, "fwd").endswith(",true,false,false,3,false,false>") and K.conv_variant(dp, "dgrad").endswith(",true,false,false,3,false,false>")
     y0 = K.conv_fwd(x, wk, b, d)
     y1 = K.conv_fwd(x, wk, b, d, wpacked=pf)
     assert torch.equal(y0, y1)
