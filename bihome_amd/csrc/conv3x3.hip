@@ -102,6 +102,9 @@ struct C3Args {
     int imgs_per_group, groups;
     int dbg_nch;           // ablation: number of channel chunks to run (-1 = all)
     int tpb, gx_total;     // tile positions per workgroup (see the loop in the kernel), total positions along x
+    int stat_acc;          // the tpb positions of a workgroup lie in ONE statistics group: their column sums are added in registers and leave
+                           // with one atomic per (channel, moment) and workgroup (round 4: the full-resolution 32-channel layers launched
+                           // 16384 workgroups = 8192 same-address f64 atomics of ~30 ns each per entry - 245 us of a 275 us kernel)
     int NW;                // PACKED: number of 32-wide output-channel tiles (Nn / 32)
     // X3 forward with BNI: Src is the INPUT of a training-mode BatchNorm (+ReLU) whose output this convolution consumes; the halo
     // staging applies y = max(x * scale + shift, lo) per channel on the way to LDS (padding stays zero), so that BatchNorm's
@@ -438,6 +441,8 @@ __global__ void __launch_bounds__(256, X3 ? ((BN == 32 && NP == 2 && !BNI) ? C3_
             reinterpret_cast<float4*>(smem + a.bni_lds)[i] = reinterpret_cast<const float4*>(a.bni)[i];
         __syncthreads();
     }
+    double S1 = 0.0, S2 = 0.0;                          // stat_acc: column sums over this workgroup's tile positions
+    int Simg = 0, Sg = 0x7fffffff, Sbx = 0;
     for (int it = 0; it < a.tpb; ++it) {
     const int bx = blockIdx.x * a.tpb + it;
     if (bx >= a.gx_total) break;
@@ -836,13 +841,17 @@ __global__ void __launch_bounds__(256, X3 ? ((BN == 32 && NP == 2 && !BNI) ? C3_
     double s1, s2;
     int img, g;
     c3_epilogue<BN, SUBT, TM, MAP4>(a, acc, bx, n0, wm, wn, wh, l31, kh2, s1, s2, img, g);
-    if (a.bn_sums) c3_stats_merge<BN, 0>(a, smem, s1, s2, img, g, bx, n0, wave, lane, tid);
+    if (a.bn_sums) {
+        if (a.stat_acc) { S1 += s1; S2 += s2; Sbx = bx; if (g < Sg) { Sg = g; Simg = img; } }    // (out-of-range sub-tiles add zero)
+        else c3_stats_merge<BN, 0>(a, smem, s1, s2, img, g, bx, n0, wave, lane, tid);
+    }
 #ifdef BH_TUNING
     if (a.dbg_ts) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (stores of the tile have left the wave)
 #endif
     __syncthreads();            // the next tile's DMA overwrites the LDS this tile's statistics merge just read
     C3_STAMP(bx * gridDim.y + blockIdx.y, 3);
     }
+    if (a.bn_sums && a.stat_acc) c3_stats_merge<BN, 0>(a, smem, S1, S2, Simg, Sg, Sbx, n0, wave, lane, tid);
 }
 
 constexpr int C3_MIN_BLOCKS = 256;      // below this many workgroups the generic kernel's finer tiles fill the chip better
@@ -926,6 +935,18 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
         const long long wgs = (long long)grid.x * grid.y;
         if (g_c3_tpb >= 2 && !(d->route & BH_ROUTE_C3_ONE_POSITION) && subt == 2 && Kc / 32 > 1 && wgs > 512 && wgs <= 1024) {
             a.tpb = 2; grid.x = (grid.x + 1) / 2;
+        }
+    }
+    if (bn_sums && !map4 && !(d->route & BH_ROUTE_C3_ONE_POSITION) && groups >= 1 && a.subtiles % (subt * groups) == 0) {
+        // statistics epilogues: every workgroup ends with one f64 atomic per (channel, moment) and the memory-side atomic unit takes
+        // ~30 ns per same-address atomic - keep the workgroups per statistics group at <= 1024 by walking several tile positions per
+        // workgroup (all inside one group) and adding their column sums in registers
+        const int ppg = a.subtiles / (subt * groups);            // tile positions per statistics group
+        int t = a.tpb;
+        while (ppg % (t * 2) == 0 && ppg / t > 1024 && t < 64) t *= 2;
+        if (ppg % t == 0 && (t > 1 || a.tpb == 1)) {
+            if (t != a.tpb) { a.tpb = t; grid.x = (a.gx_total + t - 1) / t; }
+            a.stat_acc = 1;
         }
     }
     if (!(d->route & BH_ROUTE_HALO_SMALL) && (int)((map4 ? a.subtiles : (a.subtiles + 1) / 2) * grid.y) < (map4 ? C3_MIN_BLOCKS / 2 : C3_MIN_BLOCKS))
