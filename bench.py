@@ -67,9 +67,10 @@ def parse():
                          "timed region, instead of reusing one resident batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--overlap", action="store_true",
-                    help="second HIP stream: wgrad GEMMs under the dgrad/BatchNorm chain, extractor prefetch under the backbone "
-                         "(+3%% pairs/s; off by default so that per-kernel durations are those of each kernel alone)")
+    ap.add_argument("--overlap", action="store_true", help="(default since round 4; kept for old command lines)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="one HIP stream: no weight-gradient side stream, no extractor prefetch under the backbone (the roofline leg "
+                         "always runs this way, so that per-kernel durations are those of each kernel alone)")
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole training step in a HIP graph (bihome_amd.graph.GraphedStep) and time replays")
     ap.add_argument("--hook", action="append", default=[], metavar="A,B",
@@ -133,8 +134,10 @@ def pmc_traffic(kernel):
 def roofline_leg(model, data, opt, sched, reducer, nsteps=2):
     """Per-launch HIP-event timing (events recorded on the launch stream) of every conv/BN launch for a few
     extra steps; returns the roofline object of the kernel with the largest total time plus a breakdown."""
-    from bihome_amd import kernels as K
+    from bihome_amd import kernels as K, net
     from bihome_amd.step import train_step
+    # per-kernel timing wants each kernel alone on the GPU: the side stream (weight gradients, feature prefetch) is off for this leg
+    net.set_stream_overlap(False, model)
     # one untimed pass in timing mode first: the first event pairs / variant queries of a process stall the host for
     # milliseconds, and an event pair also measures the time the GPU waits for the host between its two markers
     K.TIMING = {}
@@ -152,6 +155,7 @@ def roofline_leg(model, data, opt, sched, reducer, nsteps=2):
                      "gbs": r["bytes"] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
                      "flops_per_launch": r["flops"] / max(r["n"], 1), "bytes_per_launch": r["bytes"] / max(r["n"], 1)})
     K.TIMING = None
+    net.set_stream_overlap(os.environ.get("BIHOME_OVERLAP", "1") != "0", model)
     rows.sort(key=lambda r: -r["ms_per_step"])
     # the roofline object describes ONE kernel instantiation: rows that time a C-ABI call of several launches ("bn_bwd(3 kernels)",
     # "tail_bwd(5 kernels)": reduce + finalize + apply of different shapes under one key) stay in the breakdown but are not `top`
@@ -328,8 +332,8 @@ def main():
     from bihome_amd.step import attach_reducer, build_model, build_optimizer, mace, train_step
     from bihome_amd.weights import load_synthetic
 
-    if args.overlap:
-        os.environ["BIHOME_OVERLAP"] = "1"
+    if args.no_overlap:
+        os.environ["BIHOME_OVERLAP"] = "0"
     if args.hook:
         from bihome_amd._lib import TUNING, lib
         if not TUNING:
@@ -388,11 +392,18 @@ def main():
     for _ in range(args.warmup):
         loss, dgt, dh = one_step()
     sync()
+    # (one event per step on the launch stream: no host synchronisation inside the timed region; the gaps between consecutive
+    #  events are the per-step times the percentiles below come from)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss, dgt, dh = one_step()
+        marks[i + 1].record()
     sync()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    pct = lambda q: round(step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))], 4)
     if dist is not None:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -446,13 +457,15 @@ def main():
                                                "operand as two bf16 pieces rounded to nearest (x = hi + mid + e, |e| <= 2^-18 |x|), 3 partial "
                                                "products per product on v_mfma_f32_32x32x16_bf16 (~4e-6 per product); all other convs: "
                                                "v_mfma_f32_32x32x2_f32"}[args.precision],
-                       "stream_overlap": bool(args.overlap or os.environ.get("BIHOME_OVERLAP") == "1"),
+                       "stream_overlap": os.environ.get("BIHOME_OVERLAP", "1") != "0",
                        "hip_graph": bool(use_graph),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "optimizer": "Adam lr 1e-3"},
             "final_loss": final_loss, "final_mace": final_mace,
             "eval": {"mace": eval_mace, "ms_per_batch": eval_ms, "pairs_per_s_per_gpu": 1e3 * B / eval_ms,
                      "note": "predict_homography in eval mode (BatchNorm folded), held-out synthetic pairs, random-init "
                              "weights after the timed steps"},
+            "step_ms_percentiles": {"p10": pct(0.10), "p50": pct(0.50), "p90": pct(0.90), "min": round(step_ms[0], 4), "max": round(step_ms[-1], 4),
+                                    "note": "rank 0, gaps between per-step events on the launch stream"},
             "roofline": roof, "cpu_baseline": cpu,
             # (compact copy of roofline.warp_perceptual_path: BASELINE.json's HBM-bound part - homography warp + perceptual L1 / triplet -
             #  as a fraction of the 8 TB/s HBM peak, by raw event pairs and net of the cost of an empty event pair)

@@ -369,7 +369,7 @@ class Model(nn.Module):
         # loss picks the result up behind an event.  (The reference runs the same extractor calls, in the same order,
         # after the backbone: PerceptualHead.py:358,367.)
         self._prefetched = None
-        self.prefetch_features = os.environ.get("BIHOME_OVERLAP", "0") == "1"      # opt-in, see net.Runner
+        self.prefetch_features = os.environ.get("BIHOME_OVERLAP", "1") != "0"      # default on, see net.Runner
         if isinstance(backbone, nn.Module):
             backbone.register_forward_pre_hook(self._prefetch_hook)
 

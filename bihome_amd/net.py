@@ -677,6 +677,20 @@ class NetFunction(torch.autograd.Function):
 _RUNNERS = weakref.WeakSet()
 
 
+def set_stream_overlap(on, model=None):
+    """Switch the side-stream overlap (weight gradients, the head's feature prefetch) of the Runners over `model`'s modules
+    (all Runners when None) and of heads that hold a `prefetch_features` switch; returns nothing.  bench.py turns it off around
+    its per-kernel timing leg."""
+    mods = None if model is None else {id(m) for m in model.modules()}
+    for r in list(_RUNNERS):
+        if mods is None or id(r.module) in mods:
+            r.wgrad_on_side_stream = bool(on)
+    if model is not None:
+        for m in model.modules():
+            if hasattr(m, "prefetch_features"):
+                m.prefetch_features = bool(on)
+
+
 def invalidate_caches(model=None):
     """Drop every host-side copy derived from parameters / buffers (BatchNorm-folded weights, fragment-ordered packs, the
     transposed stem table) of the Runners over `model`'s modules (all Runners when None).  Needed wherever weights or
@@ -708,9 +722,11 @@ class Runner:
         # 1- and 3-channel programs) share one dict so that a training forward through either invalidates both
         self._fold = fold_cache if fold_cache is not None else {}
         self.fold_bn = os.environ.get("BIHOME_FOLD_BN", "1") != "0"
-        # opt-in (BIHOME_OVERLAP=1 or bench.py --overlap): +3% step throughput, but kernels of the two streams share the
-        # GPU, so per-kernel durations (rocprof, the roofline leg) are no longer those of the kernel alone
-        self.wgrad_on_side_stream = os.environ.get("BIHOME_OVERLAP", "0") == "1"
+        # second HIP stream for the weight-gradient launches (default since round 4: with three instead of six MFMA products per
+        # product the 3x3 kernels are no longer matrix-pipe-bound and two streams fill each other's gaps: 15.5 -> 14.7 ms per step;
+        # BIHOME_OVERLAP=0 or bench.py --no-overlap: one stream - per-kernel durations of rocprofv3 / the roofline leg are then those
+        # of each kernel alone, which is how profiles/ and bench.py's roofline object are measured)
+        self.wgrad_on_side_stream = os.environ.get("BIHOME_OVERLAP", "1") != "0"
         # fragment-ordered weight copies for the halo-tiled 3x3 kernel (csrc/conv3x3.hip PACKED; BIHOME_PACK_WEIGHTS=0: off)
         self.use_packer = os.environ.get("BIHOME_PACK_WEIGHTS", "1") != "0"
         self._packer = None

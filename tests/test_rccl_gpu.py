@@ -69,6 +69,30 @@ def test_bench_refuses_more_ranks_than_gpus():
     assert r.returncode != 0 and "n_gpus" not in r.stdout and "WORLD_SIZE=1" in r.stderr
 
 
+def test_bench_eight_ranks_over_gloo_prints_the_eight_gpu_line():
+    """Round-3 VERDICT item 6b: `bench.py --gpus 8` end to end - self-spawn of eight ranks, rank count by all-reduce, shards, the bucketed
+    all-reduce from the backward hooks, max-over-ranks timing, ONE rank-0 JSON line with n_gpus 8 and global_batch 512 (BASELINE.json
+    configs[2]'s split, 64 pairs per rank).  The eight ranks share the one MI355X of the box over gloo (BIHOME_DIST_BACKEND: dev only), so
+    the number is a functional check, NOT a scaling measurement; the RCCL run on eight GPUs is the driver's."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(BIHOME_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-roofline", "--config", "zeng-bihome-pds"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["global_batch"] == 512 and d["config"]["parallelism"] == "dp8"
+    assert d["value"] > 0 and abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert "world_size=8" in r.stderr and "counted 8 ranks" in r.stderr
+    log = os.path.join(ROOT, "gpurun_out", "bench_8_rank_gloo.log")
+    os.makedirs(os.path.dirname(log), exist_ok=True)
+    with open(log, "w") as f:
+        f.write("bench.py --gpus 8 (eight ranks share ONE MI355X over gloo: functional check, not a scaling number)\n")
+        f.write("\n".join(l for l in r.stderr.splitlines() if "bench.py:" in l) + "\n" + lines[0] + "\n")
+
+
 def test_bench_json_line_contract():
     """`python bench.py` (N = 1, few steps): ONE JSON line with the fields the driver and the judge read - metric / value / unit / n_gpus /
     steps / warmup / ms_per_step / scaling / dtype / config.workload, `roofline` (bound, achieved, peak, unit, frac, traffic, the measured
@@ -82,7 +106,7 @@ def test_bench_json_line_contract():
     assert len(lines) == 1
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-              "data", "config", "roofline", "cpu_baseline", "hbm_path_frac"):
+              "data", "config", "roofline", "cpu_baseline", "hbm_path_frac", "step_ms_percentiles"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["dtype"] == "f32"
     assert d["unit"] == "image-pairs/s" and d["value"] > 1000 and "workload" in d["config"] and "model" not in d["config"]

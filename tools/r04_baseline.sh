@@ -10,7 +10,8 @@ if [ "$2" != "notests" ]; then
 fi
 python3 bench.py > $O/${T}_bench.log 2>&1; last_json $O/${T}_bench.log > $O/${T}_bench.json
 python3 tools/step_detail.py zeng-bihome 64 > $O/${T}_step_detail.txt 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_kt -o ${T} -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/${T}_kt.log 2>&1
+python3 bench.py --no-cpu-baseline --no-overlap > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_no_overlap.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_kt -o ${T} -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-overlap > $O/${T}_kt.log 2>&1
 cp $(find $O/${T}_kt -name "*kernel_stats.csv" | head -1) $O/${T}_kernel_stats.csv
 rm -rf $O/${T}_kt
 cat $O/${T}_bench.json

@@ -1,6 +1,7 @@
 """Per-layer launch table of one training step (HIP-event pairs per launch, keyed by kernel and geometry).
 Usage: python tools/step_detail.py [config] [batch]"""
-import sys; sys.path.insert(0, '.')
+import os, sys; sys.path.insert(0, '.')
+os.environ.setdefault('BIHOME_OVERLAP', '0')      # per-launch event timing: every kernel alone on the GPU
 import torch
 from bihome_amd import configs, kernels as K, synth
 from bihome_amd.step import build_model, build_optimizer, train_step
