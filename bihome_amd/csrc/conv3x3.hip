@@ -102,6 +102,8 @@ struct C3Args {
     int imgs_per_group, groups;
     int dbg_nch;           // ablation: number of channel chunks to run (-1 = all)
     int tpb, gx_total;     // tile positions per workgroup (see the loop in the kernel), total positions along x
+    int desync;            // > 0: the workgroups of every second dispatch round of 256 sleep desync x 8128 cycles before their first load, so that
+                           // the two workgroups that share a CU run out of phase (one in its MFMA loop while the other loads / stores)
     int stat_acc;          // the tpb positions of a workgroup lie in ONE statistics group: their column sums are added in registers and leave
                            // with one atomic per (channel, moment) and workgroup (round 4: the full-resolution 32-channel layers launched
                            // 16384 workgroups = 8192 same-address f64 atomics of ~30 ns each per entry - 245 us of a 275 us kernel)
@@ -443,6 +445,9 @@ __global__ void __launch_bounds__(256, X3 ? ((BN == 32 && NP == 2 && !BNI) ? C3_
     }
     double S1 = 0.0, S2 = 0.0;                          // stat_acc: column sums over this workgroup's tile positions
     int Simg = 0, Sg = 0x7fffffff, Sbx = 0;
+    if (a.desync > 0 && (((blockIdx.x + gridDim.x * blockIdx.y) >> 8) & 1)) {
+        for (int i = 0; i < a.desync; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     for (int it = 0; it < a.tpb; ++it) {
     const int bx = blockIdx.x * a.tpb + it;
     if (bx >= a.gx_total) break;
@@ -855,7 +860,7 @@ __global__ void __launch_bounds__(256, X3 ? ((BN == 32 && NP == 2 && !BNI) ? C3_
 }
 
 constexpr int C3_MIN_BLOCKS = 256;      // below this many workgroups the generic kernel's finer tiles fill the chip better
-BH_KNOB(g_c3_noload, 0); BH_KNOB(g_c3_dbg_nch, -1); BH_KNOB(g_c3_subt, 2); BH_KNOB(g_c3_tpb, 2); BH_KNOB(g_c3_stamp, 0);
+BH_KNOB(g_c3_noload, 0); BH_KNOB(g_c3_dbg_nch, -1); BH_KNOB(g_c3_subt, 2); BH_KNOB(g_c3_tpb, 2); BH_KNOB(g_c3_stamp, 0); BH_KNOB(g_c3_desync, 0);
 #ifdef BH_TUNING
 // copies the phase time stamps of the last instrumented launch to the host (n entries of 8 x u64)
 extern "C" int bh_debug_read_c3_stamps(unsigned long long* out, int n) {
@@ -865,6 +870,7 @@ extern "C" int bh_debug_read_c3_stamps(unsigned long long* out, int n) {
 void bh_conv3x3_tune(int disable, int min_blocks) {
     (void)min_blocks;
     if (disable == 70 || disable == 71) { g_c3_stamp = disable - 70; return; }        // phase time stamps off / on
+    if (disable >= 200 && disable < 264) { g_c3_desync = disable - 200; return; }
     if (disable <= -100) { g_c3_dbg_nch = -100 - disable - 1; return; }            // -100 -> -1 (all), -101 -> 0 chunks, -102 -> 1 ...
     if (disable >= 60 && disable < 68) { g_c3_noload = disable - 60; return; }
     if (disable >= 20 && disable < 24) { g_c3_tpb = disable - 20; return; }        // tile positions per workgroup on two-round launches (1 / 2)
@@ -1008,7 +1014,7 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
     const kern_t fn = map4 ? fns[(f16 ? 55 : 42 + (np == 2 ? 2 : 0)) + (dgrad ? 1 : 0)] : bni ? fns[xrow + 6 + (subt == 1 ? 2 : bn_tile == 64 ? 0 : 1)] : x3 ? fns[xrow + (subt == 1 ? 4 : bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0)]
                          : fns[(packed ? 12 : 0) + (subt == 1 ? 8 + (bf16 ? 2 : 0) + (dgrad ? 1 : 0)
                                                               : (bf16 ? 4 : 0) + (bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0))];
-    a.dbg_noload = g_c3_noload; a.dbg_ts = g_c3_stamp; a.det = bh_deterministic() ? 1 : 0;
+    a.dbg_noload = g_c3_noload; a.dbg_ts = g_c3_stamp; a.desync = g_c3_desync; a.det = bh_deterministic() ? 1 : 0;
     const int stage = map4 ? 4 * np * 144 * 16 : x3 ? (subt == 1 ? XHALO1 : XHALO2) : subt == 1 ? HALO1 : HALO2;
     const int lds = packed ? (Kc / 32 > 1 ? 2 : 1) * stage                                    // halo stages only
                            : (subt == 1 ? LDS1 : C3_LDS_BYTES) - (Kc / 32 > 1 ? 0 : stage);   // single chunk: one halo stage

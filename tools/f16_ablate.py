@@ -1,0 +1,33 @@
+"""Round 4: where the time of the fp16-piece (three-product) 3x3 kernels goes.  (a) fixed cost: 0 / 1 / 2 / all channel chunks; (b) the loop without
+its in-loop weight loads (1), halo staging (2), fragment reads (4) - wrong results, timing only.  BIHOME_TUNING=1 python tools/f16_ablate.py"""
+import sys; sys.path.insert(0, '.')
+import torch
+from bihome_amd import kernels as K
+from bihome_amd._lib import lib
+def bench(fn, n=30):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+for (N, H, Ci, Co) in [(128, 32, 64, 64), (128, 16, 128, 128), (128, 8, 256, 256), (128, 128, 32, 32)]:
+    d = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=4)
+    x = torch.randn(N, H, H, Ci, device='cuda')
+    gy = torch.randn(N, H, H, Co, device='cuda')
+    w = (torch.randn(Co, Ci, 3, 3, device='cuda') * 0.05).contiguous(memory_format=torch.channels_last)
+    wk = w.permute(0, 2, 3, 1)
+    pk = K.packer_for_precision(4); pf, pd = pk.get(w); pk.refresh()
+    for name, fn in (("fwd", lambda: K.conv_fwd(x, wk, None, d, wpacked=pf)), ("dgrad", lambda: K.conv_dgrad(gy, wk, d, wpacked=pd))):
+        out = []
+        for n in (0, 1, 2, -1):
+            lib.bh_debug_force_tile(-8, n)
+            out.append('%d chunks: %.1f' % (n, bench(fn)))
+        lib.bh_debug_force_tile(-8, -1)
+        out2 = []
+        for bits in (0, 1, 2, 4, 7):
+            lib.bh_debug_force_tile(-18, bits)
+            out2.append('%d: %.1f' % (bits, bench(fn)))
+        lib.bh_debug_force_tile(-18, 0)
+        print((N, H, Ci, Co), name, ' | '.join(out), ' || noload ', ' | '.join(out2), flush=True)

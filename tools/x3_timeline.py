@@ -7,11 +7,12 @@ from bihome_amd import kernels as K
 from bihome_amd._lib import lib
 mode = sys.argv[1] if len(sys.argv) > 1 else "fwd"
 N, H, Ci, Co = 128, 32, 64, 64
-d = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=2)
+PREC = int(__import__("os").environ.get("X3_PREC", "4"))
+d = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=PREC)
 x = torch.randn(N, H, H, Ci, device='cuda'); gy = torch.randn(N, H, H, Co, device='cuda')
 w = (torch.randn(Co, Ci, 3, 3, device='cuda') * 0.05).contiguous(memory_format=torch.channels_last)
 wk = w.permute(0, 2, 3, 1)
-pk = K.WeightPacker(split=True); pf, pd = pk.get(w); pk.refresh()
+pk = K.packer_for_precision(PREC); pf, pd = pk.get(w); pk.refresh()
 s = K.bn_stats_buffer(2, Co, "cuda")
 def run():
     if mode == "fwd": K.conv_fwd(x, wk, None, d, wpacked=pf)
