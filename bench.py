@@ -422,13 +422,19 @@ def main():
     roof, rows = (None, None)
     if not args.no_roofline:
         roof, rows = roofline_leg(model, data, opt, sched, reducer)
+        if dist is not None:
+            dist.barrier()                 # the probe below (2 GiB, synchronising) runs on rank 0 only: keep the ranks together around it
         if rank == 0:
             mp = measured_peaks()
             roof["measured_peaks"] = mp
             # `frac` is against the vendor peak (the contract); this is the same `achieved` against what the chip sustains
             sustained = mp["bf16_mfma_random_operands_TFLOPs"] if (roof.get("unit") == "TFLOP/s" and roof.get("peak") == PEAK_BF16_MFMA_TFLOPS) \
                 else (mp["hbm_copy_GBs"] if roof.get("unit") == "GB/s" else None)
+            # (None for rooflines bound by the fp32-input MFMA pipe - `--precision f32-mfma`, the zhang / detone tops: only the bf16 / fp16 pipe
+            #  and an HBM copy are probed)
             roof["frac_of_measured_peak"] = (roof["achieved"] / sustained) if sustained else None
+        if dist is not None:
+            dist.barrier()
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and CH == 1:    # the reference (and so the oracle) has no RGB path
         cpu = cpu_baseline(cfg)

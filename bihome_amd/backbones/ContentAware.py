@@ -83,8 +83,15 @@ class Model(nn.Module):
         self.feature_extractor = FeatureExtractor(self.precision)
         self.variant = str.lower(kwargs['VARIANT'])
         assert 'oneline' in self.variant or 'doubleline' in self.variant, 'Only OneLine or DoubleLine variant is supported'
-        self.resnet34 = _ResNet34(2, 8)                                        # :106-110
-        self.init()                                                            # :113-114 (kaiming / ones / zeros)
+        # Upstream (ContentAware.py:101-114) calls init() BEFORE it builds the pretrained resnet, so on the pretrained path the replaced
+        # 2-channel conv1 and the fc keep torch's default initialisation (kaiming_uniform, a = sqrt(5)) and only the mask predictor / feature
+        # extractor get kaiming_normal; without a checkpoint init() runs over everything.
+        if isinstance(pre, str) and pre:
+            self.init()
+            self.resnet34 = _ResNet34(2, 8)                                    # :106-110 (default init: conv1 / fc as upstream)
+        else:
+            self.resnet34 = _ResNet34(2, 8)
+            self.init()                                                        # :113-114 (kaiming / ones / zeros)
         net.to_kernel_layout_(self)
         if isinstance(pre, str) and pre:
             from ..weights import load_imagenet_resnet34
