@@ -49,24 +49,29 @@ P = c_void_p
 SIGNATURES = {
     "bh_version": [],
     "bh_probe_mfma_bf16": [c_int, P, P, P],
-    "bh_set_deterministic": [c_int],
-    "bh_get_deterministic": [],
     "bh_device_arch": [c_char_p, c_int],
     "bh_h4pt_fwd": [P, c_int, c_float, c_float, P, P, P],
     "bh_h4pt_bwd": [P, P, P, c_int, c_float, c_float, P, P],
     "bh_dlt_fwd": [P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P],
     "bh_dlt_bwd": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P],
+    "bh_dlt_bwd_f": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_int, P],
     "bh_dsac_scores_fwd": [P, c_int, c_int, P, P],
     "bh_dsac_scores_bwd": [P, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P],
+    "bh_dsac_scores_bwd_f": [P, P, P, P, c_int, c_int, c_int, c_int, P, P, P, c_int, P],
     "bh_scale_samples_fwd": [P, P, c_int, c_int64, c_int, P, P],
     "bh_scale_samples_bwd": [P, P, P, c_int, c_int64, c_int, P, P, P],
+    "bh_scale_samples_bwd_f": [P, P, P, c_int, c_int64, c_int, P, P, c_int, P],
     "bh_dsac_score": [P, P, c_int, c_int, c_int, c_int, P, P, P],
     "bh_warp_fwd": [P, P, c_int, c_int, c_int, c_int, c_int, P, P, P],
+    "bh_warp_fwd_f": [P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P],
     "bh_warp_bwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P],
+    "bh_warp_bwd_f": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_int, P],
     "bh_triplet_l1_fwd": [P] * 8 + [c_int, c_int, c_int, P, P, P, P],
+    "bh_triplet_l1_fwd_f": [P] * 8 + [c_int, c_int, c_int, P, P, P, c_int, P],
     "bh_bihome_loss_fwd": [P, P, P, c_int, c_float, P, P],
     "bh_bihome_loss_bwd": [P] * 14 + [c_int, c_int, c_int, c_float] + [P] * 6 + [P],
     "bh_oneline_loss_fwd": [P, P, P, P, P, c_int, c_int, c_int, c_float, c_int, P, P, P, P, P, P],
+    "bh_oneline_loss_fwd_f": [P, P, P, P, P, c_int, c_int, c_int, c_float, c_int, P, P, P, P, P, c_int, P],
     "bh_oneline_loss_bwd": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P],
     "bh_zhang_triplet_fwd": [P] * 8 + [c_int, c_int, c_float, c_int, P, P, P, P],
     "bh_zhang_triplet_bwd": [P] * 12 + [c_int, c_int, c_int] + [P] * 6 + [P],
@@ -101,6 +106,7 @@ SIGNATURES = {
     "bh_tail_fwd": [P] * 11 + [c_int] * 6 + [c_float, c_float, c_int, P],
     "bh_tail_fwd_route": [P] * 11 + [c_int] * 6 + [c_float, c_float, c_int, c_int, P],
     "bh_tail_bwd": [P] * 17 + [c_int] * 6 + [c_float, c_int, P],
+    "bh_tail_bwd_f": [P] * 17 + [c_int] * 6 + [c_float, c_int, c_int, P],
     "bh_synth_pairs": [P] * 5 + [c_int] * 5 + [c_float, c_float, P, P, P],
     "bh_maxpool3s2_fwd": [P, P, P, c_int, c_int, c_int, c_int, P],
     "bh_maxpool3s2_bwd": [P, P, P, c_int, c_int, c_int, c_int, P],
@@ -138,10 +144,9 @@ def _load():
 
 
 lib = _load()
-# BIHOME_DETERMINISTIC=1: order-independent reductions in every kernel (include/bihome.h bh_set_deterministic); kernels.set_deterministic
-# switches it at run time
-if os.environ.get("BIHOME_DETERMINISTIC", "0") == "1":
-    lib.bh_set_deterministic(1)
+# (BIHOME_DETERMINISTIC=1 is read by kernels.py: the library holds no mode, every call carries its own bit - include/bihome.h
+#  "Deterministic calls")
+ROUTE_DETERMINISTIC, BN_DETERMINISTIC, F_DETERMINISTIC = 128, 32, 1
 
 
 def check(rc, what):

@@ -17,9 +17,10 @@ struct BnGeom {
     int det;               // deterministic mode: cross-workgroup sums through integer limbs (common.h bh_det_add)
 };
 
-static bool bn_geom(int groups, int rows, int C, BnGeom& g) {
+// det: 1 = this call accumulates / reads through the integer limbs (BH_BN_DETERMINISTIC), 0 = word 0 only, -1 = readers look
+static bool bn_geom(int groups, int rows, int C, BnGeom& g, int det) {
     if (C % 4 || groups < 1 || rows < 1) return false;
-    g.groups = groups; g.rows = rows; g.C = C; g.C4 = C / 4; g.det = bh_deterministic() ? 1 : 0;
+    g.groups = groups; g.rows = rows; g.C = C; g.C4 = C / 4; g.det = det;
     if (g.C4 > 256 || (256 % g.C4)) return false;
     g.LPR = g.C4; g.RPP = 256 / g.LPR;
     int n = rows / (g.RPP * 4);          // >= 4 rows per lane per chunk; up to 256 chunks x groups workgroups
@@ -438,9 +439,9 @@ __global__ void __launch_bounds__(256) bn_fwd_coeffs_kernel(const double* __rest
 
 // per-channel sums of an NHWC tensor into caller-zeroed sums[groups][C][2] (used by bh_bn_fwd and by the conv entry
 // point that hands the statistics to the BatchNorm that follows it)
-int bn_launch_stats(const float* x, int groups, int rows, int C, double* sums, hipStream_t s) {
+int bn_launch_stats(const float* x, int groups, int rows, int C, double* sums, hipStream_t s, int det) {
     BnGeom g;
-    if (!bn_geom(groups, rows, C, g)) return BH_E_UNSUPPORTED;
+    if (!bn_geom(groups, rows, C, g, det ? 1 : 0)) return BH_E_UNSUPPORTED;
     hipLaunchKernelGGL(bn_stats_kernel, dim3(g.nchunks, groups), dim3(256), 0, s, x, g, sums);
     BH_LAUNCH_CHECK();
     return BH_OK;
@@ -470,7 +471,7 @@ int bh_bn_fwd_amax(const float* x, const float* gamma, const float* beta, float*
     if (!x || !y || !stats) return BH_E_BADARG;
     if (use_running && (!running_mean || !running_var)) return BH_E_BADARG;
     if (C == 1) return amax_y ? BH_E_UNSUPPORTED : bn1_fwd(x, gamma, beta, running_mean, running_var, res, y, stats, groups, rows, eps, momentum, flags, use_running, bh_stream(stream));
-    if (!bn_geom(groups, rows, C, g)) return BH_E_UNSUPPORTED;
+    if (!bn_geom(groups, rows, C, g, (flags & BH_BN_DETERMINISTIC) ? 1 : 0)) return BH_E_UNSUPPORTED;
     hipStream_t s = bh_stream(stream);
     if (!use_running && !(flags & 8)) {                       // bit 3: the producer already accumulated the sums
         hipLaunchKernelGGL(bn_stats_kernel, dim3(g.nchunks, groups), dim3(256), 0, s, x, g, stats);
@@ -493,7 +494,7 @@ int bh_bn_fwd_coeffs_amax(const double* stats, const float* gamma, const float* 
                           int rows, int C, float eps, float momentum, float* table, float* amax_y, void* stream) {
     BnGeom g;
     if (!stats || !table) return BH_E_BADARG;
-    if (!bn_geom(groups, rows, C, g)) return BH_E_UNSUPPORTED;
+    if (!bn_geom(groups, rows, C, g, -1)) return BH_E_UNSUPPORTED;        // (a reader: looks at the limbs of whatever mode wrote the sums)
     const bool upd = running_mean && running_var;
     hipLaunchKernelGGL(bn_fwd_coeffs_kernel, dim3((groups * C + 255) / 256), dim3(256), 0, bh_stream(stream), stats, gamma, beta, g, eps,
                        momentum, upd ? running_mean : nullptr, upd ? running_var : nullptr, reinterpret_cast<float2*>(table),
@@ -517,7 +518,7 @@ int bh_bn_bwd_amax(const float* gy, const float* y, const float* x, const float*
     if ((flags & 4) && (flags & 2)) return BH_E_BADARG;        // the mask can only be recomputed without a residual input
     if (C == 1) return amax_gx ? BH_E_UNSUPPORTED : bn1_bwd(gy, y, x, gamma, beta, stats, gx, gres, ggamma, gbeta, scratch, groups, rows, eps, flags, use_running,
                                running_mean, running_var, bh_stream(stream));
-    if (!bn_geom(groups, rows, C, g)) return BH_E_UNSUPPORTED;
+    if (!bn_geom(groups, rows, C, g, (flags & BH_BN_DETERMINISTIC) ? 1 : 0)) return BH_E_UNSUPPORTED;
     hipStream_t s = bh_stream(stream);
     if (flags & 16) {            // scratch = padded sums accumulated by bh_conv_dgrad_bnreduce (training mode only)
         if (use_running) return BH_E_BADARG;

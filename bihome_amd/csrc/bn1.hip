@@ -12,9 +12,9 @@ struct Bn1Geom {
     long long rows, rows_per_chunk;
 };
 
-static bool bn1_geom(int groups, int rows, Bn1Geom& g) {
+static bool bn1_geom(int groups, int rows, Bn1Geom& g, int det) {
     if (groups < 1 || rows < 1) return false;
-    g.groups = groups; g.rows = rows; g.det = bh_deterministic() ? 1 : 0;
+    g.groups = groups; g.rows = rows; g.det = det;
     long long n = rows / 4096;
     if (n < 1) n = 1;
     if (n > BN1_MAX_CHUNKS) n = BN1_MAX_CHUNKS;
@@ -175,7 +175,7 @@ static int bn1_blocks(const Bn1Geom& g) {
 int bn1_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, const float* res, float* y,
             double* stats, int groups, int rows, float eps, float momentum, int flags, int use_running, hipStream_t s) {
     Bn1Geom g;
-    if (!bn1_geom(groups, rows, g)) return BH_E_UNSUPPORTED;
+    if (!bn1_geom(groups, rows, g, (flags & BH_BN_DETERMINISTIC) ? 1 : 0)) return BH_E_UNSUPPORTED;
     if (!use_running && !(flags & 8)) {
         hipLaunchKernelGGL(bn1_stats_kernel, dim3(g.nchunks, groups), dim3(256), 0, s, x, g, stats);
         BH_LAUNCH_CHECK();
@@ -191,7 +191,7 @@ int bn1_bwd(const float* gy, const float* y, const float* x, const float* gamma,
             float* gres, float* ggamma, float* gbeta, double* scratch, int groups, int rows, float eps, int flags, int use_running,
             const float* running_mean, const float* running_var, hipStream_t s) {
     Bn1Geom g;
-    if (!bn1_geom(groups, rows, g)) return BH_E_UNSUPPORTED;
+    if (!bn1_geom(groups, rows, g, (flags & BH_BN_DETERMINISTIC) ? 1 : 0)) return BH_E_UNSUPPORTED;
     if (flags & 16) return BH_E_UNSUPPORTED;                 // (no conv epilogue produces the sums of a one-channel BatchNorm)
     hipLaunchKernelGGL(bn1_bwd_reduce_kernel, dim3(g.nchunks, groups), dim3(256), 0, s, gy, y, x, gamma, beta, stats, running_mean,
                        running_var, g, eps, flags, use_running, scratch);

@@ -4,12 +4,9 @@
 #include <stdio.h>
 #include <string.h>
 
-#include <atomic>
 
 thread_local BhQuery* bh_query_ctx = nullptr;
 
-static std::atomic<int> g_deterministic{0};
-bool bh_deterministic() { return g_deterministic.load(std::memory_order_relaxed) != 0; }
 
 bool bh_query(const char* fmt, ...) {
     BhQuery* q = bh_query_ctx;
@@ -28,8 +25,6 @@ extern "C" {
 
 int bh_version(void) { return 1; }
 
-int bh_set_deterministic(int on) { return g_deterministic.exchange(on ? 1 : 0); }
-int bh_get_deterministic(void) { return g_deterministic.load() ? 1 : 0; }
 
 int bh_device_arch(char* buf, int buflen) {
     hipDeviceProp_t prop;

@@ -53,7 +53,8 @@ static inline bool bh_device_once(unsigned long long& mask) {
 // addend's own rounding onto that grid is a function of the addend alone).  Readers add word 0 and the limbs; a caller-zeroed
 // entry that was only written in the default mode has zero limbs, so one reader serves both modes.
 #define BH_ACC_WORDS 4
-bool bh_deterministic();                                       // host: the library-wide mode (capi.hip)
+// (round 4: the mode is a PER-CALL bit - BH_ROUTE_DETERMINISTIC in bh_conv_desc.route, BH_BN_DETERMINISTIC in the BatchNorm flags,
+//  BH_F_DETERMINISTIC in the flags argument of the bh_*_f entry points; the library holds no mode of its own)
 __device__ __forceinline__ void bh_det_add(double* entry, double v) {
     if (!(fabs(v) < 0x1p62)) { atomicAdd(entry, v); return; }  // inf / NaN / out of range: stays visible in word 0
     const double hi = trunc(v);

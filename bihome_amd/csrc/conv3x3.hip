@@ -1014,7 +1014,7 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
     const kern_t fn = map4 ? fns[(f16 ? 55 : 42 + (np == 2 ? 2 : 0)) + (dgrad ? 1 : 0)] : bni ? fns[xrow + 6 + (subt == 1 ? 2 : bn_tile == 64 ? 0 : 1)] : x3 ? fns[xrow + (subt == 1 ? 4 : bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0)]
                          : fns[(packed ? 12 : 0) + (subt == 1 ? 8 + (bf16 ? 2 : 0) + (dgrad ? 1 : 0)
                                                               : (bf16 ? 4 : 0) + (bn_tile == 64 ? 0 : 2) + (dgrad ? 1 : 0))];
-    a.dbg_noload = g_c3_noload; a.dbg_ts = g_c3_stamp; a.desync = g_c3_desync; a.det = bh_deterministic() ? 1 : 0;
+    a.dbg_noload = g_c3_noload; a.dbg_ts = g_c3_stamp; a.desync = g_c3_desync; a.det = (d->route & BH_ROUTE_DETERMINISTIC) ? 1 : 0;
     const int stage = map4 ? 4 * np * 144 * 16 : x3 ? (subt == 1 ? XHALO1 : XHALO2) : subt == 1 ? HALO1 : HALO2;
     const int lds = packed ? (Kc / 32 > 1 ? 2 : 1) * stage                                    // halo stages only
                            : (subt == 1 ? LDS1 : C3_LDS_BYTES) - (Kc / 32 > 1 ? 0 : stage);   // single chunk: one halo stage

@@ -919,7 +919,7 @@ void bh_wgrad_x3_tune(int what, int v);
 int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* out, const bh_conv_desc* d, int dgrad,
                    int accumulate, hipStream_t stream, int* taken, double* bn_sums, int groups, const float* res = nullptr,
                    int relu = 0, const bh_bn_reduce* bnr = nullptr, const bh_bn_in* bni = nullptr);
-int bn_launch_stats(const float* x, int groups, int rows, int C, double* sums, hipStream_t s);
+int bn_launch_stats(const float* x, int groups, int rows, int C, double* sums, hipStream_t s, int det);
 int bh_stem7_try(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, int relu,
                  hipStream_t stream, int* taken, double* bn_sums = nullptr, int groups = 1);
 
@@ -1002,7 +1002,7 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, cons
         // every workgroup ends with one atomic per (channel, moment): beyond ~2k workgroups per address the atomic unit
         // (one same-address f64 atomic per ~30 ns) is slower than a separate statistics pass
         if (d->out_nchw || rpg % 128 || rpg * groups > 2048ll * 64) return BH_E_UNSUPPORTED;
-        a.bn_sums = bn_sums; a.bn_rpg = (int)rpg; a.bn_groups = groups; a.bn_C = d->Co; a.bn_det = bh_deterministic() ? 1 : 0;
+        a.bn_sums = bn_sums; a.bn_rpg = (int)rpg; a.bn_groups = groups; a.bn_C = d->Co; a.bn_det = (d->route & BH_ROUTE_DETERMINISTIC) ? 1 : 0;
     }
     a.Src = x; a.Bw = w; a.bias = bias; a.Out = y; a.bf16 = d->precision == 1;
     a.Hs = d->Hi; a.Ws = d->Wi; a.Cs = d->Ci; a.Kc = d->Ci;
@@ -1063,7 +1063,7 @@ int bh_conv_fwd_bnstats(const float* x, const float* w, const float* bias, float
         if (rc) return rc;
     }
     if (bh_query("bn_stats_kernel")) return BH_OK;
-    return bn_launch_stats(y, groups, (d->N / groups) * d->Ho * d->Wo, d->Co, sums, bh_stream(stream));
+    return bn_launch_stats(y, groups, (d->N / groups) * d->Ho * d->Wo, d->Co, sums, bh_stream(stream), (d->route & BH_ROUTE_DETERMINISTIC) ? 1 : 0);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -541,10 +541,15 @@ int bh_dlt_fwd(const float* pf, const int64_t* choice, int B, int n, int P, int 
 
 int bh_dlt_bwd(const float* pf, const int64_t* choice, const double* eig, const float* g_delta, const double* g_Hdlt, int B,
                int n, int P, int h, int w, float* g_pf, void* stream) {
+    return bh_dlt_bwd_f(pf, choice, eig, g_delta, g_Hdlt, B, n, P, h, w, g_pf, 0, stream);
+}
+
+int bh_dlt_bwd_f(const float* pf, const int64_t* choice, const double* eig, const float* g_delta, const double* g_Hdlt, int B,
+                 int n, int P, int h, int w, float* g_pf, int flags, void* stream) {
     if (!pf || !choice || !eig || !g_delta || !g_pf || B < 0 || n < 1 || P < 4) return BH_E_BADARG;
     if (P > 64 * DLT_MAXPTS) return BH_E_UNSUPPORTED;
     if (B == 0) return BH_OK;
-    if (bh_deterministic()) {
+    if (flags & BH_F_DETERMINISTIC) {
         for (int j = 0; j < n; ++j) {
             hipLaunchKernelGGL(dlt_bwd_kernel, dim3(B, 1), dim3(64), 0, bh_stream(stream), pf, choice, eig, g_delta, g_Hdlt, P, h, w,
                                g_pf, n, j, 1);
@@ -581,11 +586,16 @@ int bh_dsac_scores_fwd(const float* err, int B, int n, float* scores, void* stre
 
 int bh_dsac_scores_bwd(const float* pf, const float* Hdlt, const float* scores, const float* g_scores, int B, int n, int h,
                        int w, float* g_err, double* g_Hdlt, float* g_pf, void* stream) {
+    return bh_dsac_scores_bwd_f(pf, Hdlt, scores, g_scores, B, n, h, w, g_err, g_Hdlt, g_pf, 0, stream);
+}
+
+int bh_dsac_scores_bwd_f(const float* pf, const float* Hdlt, const float* scores, const float* g_scores, int B, int n, int h,
+                         int w, float* g_err, double* g_Hdlt, float* g_pf, int flags, void* stream) {
     if (!pf || !Hdlt || !scores || !g_scores || !g_err || !g_Hdlt || !g_pf || B < 0 || n < 1) return BH_E_BADARG;
     if (B == 0) return BH_OK;
     hipLaunchKernelGGL(dsac_softmax_bwd_kernel, dim3((B + 63) / 64), dim3(64), 0, bh_stream(stream), scores, g_scores, B, n, g_err);
     BH_LAUNCH_CHECK();
-    hipLaunchKernelGGL(dsac_score_bwd_kernel, dim3(B, bh_deterministic() ? 1 : n), dim3(256), 0, bh_stream(stream), pf, Hdlt, g_err, h, w,
+    hipLaunchKernelGGL(dsac_score_bwd_kernel, dim3(B, (flags & BH_F_DETERMINISTIC) ? 1 : n), dim3(256), 0, bh_stream(stream), pf, Hdlt, g_err, h, w,
                        g_Hdlt, g_pf, n);
     BH_LAUNCH_CHECK();
     return BH_OK;

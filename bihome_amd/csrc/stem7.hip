@@ -151,7 +151,7 @@ int bh_stem7_try(const float* x, const float* w, const float* bias, float* y, co
     if (d->Ho % 8 || d->Wo % 8 || d->Ho * 2 != d->Hi || d->Wo * 2 != d->Wi) return BH_OK;
     Stem7Args a = {};
     a.x = x; a.w = w; a.bias = bias; a.y = y; a.relu = relu;
-    a.bn_sums = bn_sums; a.groups = groups > 0 ? groups : 1; a.imgs_per_group = d->N / a.groups; a.det = bh_deterministic() ? 1 : 0;
+    a.bn_sums = bn_sums; a.groups = groups > 0 ? groups : 1; a.imgs_per_group = d->N / a.groups; a.det = (d->route & BH_ROUTE_DETERMINISTIC) ? 1 : 0;
     a.N = d->N; a.Hi = d->Hi; a.Wi = d->Wi; a.Ho = d->Ho; a.Wo = d->Wo;
     a.tiles_x = d->Wo / 8; a.tiles_per_img = (d->Ho / 8) * a.tiles_x; a.ntiles = d->N * a.tiles_per_img;
     if (a.ntiles < 256) return BH_OK;

@@ -930,6 +930,14 @@ int bh_tail_bwd(const float* gout, const float* x, const float* w1, const float*
                 const float* w2, const double* ws, const float* running_mean, const float* running_var, float* gx, float* gw1,
                 float* ggamma, float* gbeta, float* gw2, float* gb2, float* scratch, int groups, int rows, int hw, int Ci, int Cm,
                 int Co, float eps, int use_running, void* stream) {
+    return bh_tail_bwd_f(gout, x, w1, b1, gamma, beta, w2, ws, running_mean, running_var, gx, gw1, ggamma, gbeta, gw2, gb2, scratch, groups, rows,
+                         hw, Ci, Cm, Co, eps, use_running, 0, stream);
+}
+
+int bh_tail_bwd_f(const float* gout, const float* x, const float* w1, const float* b1, const float* gamma, const float* beta,
+                  const float* w2, const double* ws, const float* running_mean, const float* running_var, float* gx, float* gw1,
+                  float* ggamma, float* gbeta, float* gw2, float* gb2, float* scratch, int groups, int rows, int hw, int Ci, int Cm,
+                  int Co, float eps, int use_running, int flags, void* stream) {
     TailGeom g;
     if (!gout || !x || !w1 || !w2 || !ws || !scratch) return BH_E_BADARG;
     if (!tail_geom(groups, rows, hw, Ci, Cm, Co, g) || (Ci != 16 && Ci != 32 && Ci != 8)) return BH_E_UNSUPPORTED;
@@ -968,7 +976,7 @@ int bh_tail_bwd(const float* gout, const float* x, const float* w1, const float*
 #undef TAIL_BWD
     if (gb2) {
         const int nimg = groups * rows / hw;
-        hipLaunchKernelGGL(tail_gb2_kernel, dim3(bh_deterministic() ? 1 : (nimg < 256 ? nimg : 256), Co), dim3(256), 0, s, gout, nimg, Co, hw, gb2);
+        hipLaunchKernelGGL(tail_gb2_kernel, dim3((flags & BH_F_DETERMINISTIC) ? 1 : (nimg < 256 ? nimg : 256), Co), dim3(256), 0, s, gout, nimg, Co, hw, gb2);
         BH_LAUNCH_CHECK();
     }
     return BH_OK;

@@ -390,13 +390,19 @@ int bh_zhang_triplet_bwd(const float* g_loss, const float* f1, const float* f2, 
 int bh_oneline_loss_fwd(const float* f1, const float* f2, const float* f1w, const float* m1w, const float* m2, int B, int hw,
                         int C, float margin, int rep, const float* sample_w, float* T, double* numden, float* per_sample,
                         float* loss, void* stream) {
+    return bh_oneline_loss_fwd_f(f1, f2, f1w, m1w, m2, B, hw, C, margin, rep, sample_w, T, numden, per_sample, loss, 0, stream);
+}
+
+int bh_oneline_loss_fwd_f(const float* f1, const float* f2, const float* f1w, const float* m1w, const float* m2, int B, int hw,
+                          int C, float margin, int rep, const float* sample_w, float* T, double* numden, float* per_sample,
+                          float* loss, int flags, void* stream) {
     if (!f1 || !f2 || !f1w || !m1w || !T || !numden || !loss || B < 0 || rep < 1 || B % rep) return BH_E_BADARG;
     if (C % 4 || C < 4 || (C / 4 < 64 && (64 % (C / 4)))) return BH_E_UNSUPPORTED;
     hipStream_t s = bh_stream(stream);
     if (B > 0) {
         hipError_t e = hipMemsetAsync(numden, 0, sizeof(double) * 2 * (size_t)B, s);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(oneline_fwd_kernel, dim3(bh_deterministic() ? 1 : TRIP_BLOCKS_PER_SAMPLE, B), dim3(256), 0, s, f1, f2, f1w, m1w, m2, hw, C,
+        hipLaunchKernelGGL(oneline_fwd_kernel, dim3((flags & BH_F_DETERMINISTIC) ? 1 : TRIP_BLOCKS_PER_SAMPLE, B), dim3(256), 0, s, f1, f2, f1w, m1w, m2, hw, C,
                            margin, rep, T, numden);
         BH_LAUNCH_CHECK();
     }
@@ -420,12 +426,18 @@ int bh_oneline_loss_bwd(const float* g_loss, const float* f2, const float* f1w, 
 int bh_triplet_l1_fwd(const float* f1, const float* f2, const float* f1w, const float* f2w, const float* m1w,
                       const float* m2w, const float* m1, const float* m2, int B, int hw, int C, float* M1, float* M2,
                       double* numden, void* stream) {
+    return bh_triplet_l1_fwd_f(f1, f2, f1w, f2w, m1w, m2w, m1, m2, B, hw, C, M1, M2, numden, 0, stream);
+}
+
+int bh_triplet_l1_fwd_f(const float* f1, const float* f2, const float* f1w, const float* f2w, const float* m1w,
+                        const float* m2w, const float* m1, const float* m2, int B, int hw, int C, float* M1, float* M2,
+                        double* numden, int flags, void* stream) {
     if (!f1 || !f2 || !f1w || !f2w || !m1w || !m2w || !M1 || !M2 || !numden || B < 0) return BH_E_BADARG;
     if (C % 4 || C < 4 || (C / 4 < 64 && (64 % (C / 4)))) return BH_E_UNSUPPORTED;
     if (B == 0) return BH_OK;
     hipError_t e = hipMemsetAsync(numden, 0, sizeof(double) * 4 * (size_t)B, bh_stream(stream));
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(triplet_fwd_kernel, dim3(bh_deterministic() ? 1 : TRIP_FWD_BLOCKS_PER_SAMPLE, B), dim3(256), 0, bh_stream(stream), f1, f2, f1w,
+    hipLaunchKernelGGL(triplet_fwd_kernel, dim3((flags & BH_F_DETERMINISTIC) ? 1 : TRIP_FWD_BLOCKS_PER_SAMPLE, B), dim3(256), 0, bh_stream(stream), f1, f2, f1w,
                        f2w, m1w, m2w, m1, m2, hw, C, M1, M2, numden);
     BH_LAUNCH_CHECK();
     return BH_OK;
@@ -469,11 +481,16 @@ int bh_scale_samples_fwd(const float* x, const float* s, int Bn, long long L, in
 
 int bh_scale_samples_bwd(const float* g_y, const float* x, const float* s, int Bn, long long L, int rep, float* g_x, float* g_s,
                          void* stream) {
+    return bh_scale_samples_bwd_f(g_y, x, s, Bn, L, rep, g_x, g_s, 0, stream);
+}
+
+int bh_scale_samples_bwd_f(const float* g_y, const float* x, const float* s, int Bn, long long L, int rep, float* g_x, float* g_s,
+                           int flags, void* stream) {
     if (!g_y || !x || !s || !g_s || Bn < 0 || rep < 1 || L % 4 || (g_x && rep != 1)) return BH_E_BADARG;
     if (Bn == 0) return BH_OK;
     hipError_t e = hipMemsetAsync(g_s, 0, sizeof(float) * (size_t)Bn, bh_stream(stream));
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(scale_samples_bwd_kernel, dim3(bh_deterministic() ? 1 : 32, Bn), dim3(256), 0, bh_stream(stream), g_y, x, s, L, rep, g_x, g_s);
+    hipLaunchKernelGGL(scale_samples_bwd_kernel, dim3((flags & BH_F_DETERMINISTIC) ? 1 : 32, Bn), dim3(256), 0, bh_stream(stream), g_y, x, s, L, rep, g_x, g_s);
     BH_LAUNCH_CHECK();
     return BH_OK;
 }

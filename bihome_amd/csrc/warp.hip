@@ -103,6 +103,31 @@ __global__ void __launch_bounds__(256) warp_fwd_kernel(const float* __restrict__
     }
 }
 
+// pooled coverage for pool = 32, deterministic form (round 4): one workgroup per 32 x 32 window walks its four 16 x 16 quarters in a
+// fixed order and is the only writer of the window (the default form adds the quarter sums with float atomics).  grid (w/32, h/32, B)
+__global__ void __launch_bounds__(256) warp_cov32_kernel(const double* __restrict__ H64, int h, int w, float* __restrict__ cov) {
+    __shared__ float part[4];
+    const int b = blockIdx.z;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    float tot = 0.0f;
+    for (int q = 0; q < 4; ++q) {
+        const int x = blockIdx.x * 32 + (q & 1) * 16 + tx, y = blockIdx.y * 32 + (q >> 1) * 16 + ty;
+        float u, v, iz;
+        bool guard;
+        project(H64 + (size_t)b * 9, x, y, u, v, iz, guard);
+        const Tap t = make_tap(u, v, w, h);
+        const float w00 = (1 - t.fx) * (1 - t.fy), w01 = t.fx * (1 - t.fy), w10 = (1 - t.fx) * t.fy, w11 = t.fx * t.fy;
+        const bool v00 = t.vx0 && t.vy0, v01 = t.vx1 && t.vy0, v10 = t.vx0 && t.vy1, v11 = t.vx1 && t.vy1;
+        const float cv = (v00 ? w00 : 0.0f) + (v01 ? w01 : 0.0f) + (v10 ? w10 : 0.0f) + (v11 ? w11 : 0.0f);
+        const float s = window_sum_16x4(cv, 16);           // the 16 x 4 strip of this wave
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+        __syncthreads();
+        tot += (part[0] + part[1] + part[2] + part[3]) / 1024.0f;      // (the same quarter value the atomic form adds)
+    }
+    if (threadIdx.x == 0) cov[((size_t)b * (h / 32) + blockIdx.y) * (w / 32) + blockIdx.x] = tot;
+}
+
 // adjoint: per pixel dL/du, dL/dv -> 9 sums per sample
 __global__ void __launch_bounds__(256) warp_bwd_kernel(const float* __restrict__ img, const double* __restrict__ H64,
                                                        const float* __restrict__ g_out, const float* __restrict__ g_cov,
@@ -360,6 +385,11 @@ extern "C" {
 
 int bh_warp_fwd(const float* img, const double* H64, int B, int C, int h, int w, int pool, float* out, float* cov,
                 void* stream) {
+    return bh_warp_fwd_f(img, H64, B, C, h, w, pool, out, cov, 0, stream);
+}
+
+int bh_warp_fwd_f(const float* img, const double* H64, int B, int C, int h, int w, int pool, float* out, float* cov,
+                  int flags, void* stream) {
     if (!H64 || B < 0 || (img && !out) || (!img && !cov)) return BH_E_BADARG;
     if ((h % 16) || (w % 16) || (pool != 1 && pool != 2 && pool != 4 && pool != 8 && pool != 16 && pool != 32) || (h % pool) || (w % pool)) return BH_E_UNSUPPORTED;
     if (B == 0) return BH_OK;
@@ -369,6 +399,13 @@ int bh_warp_fwd(const float* img, const double* H64, int B, int C, int h, int w,
         else hipLaunchKernelGGL(warp_fwd4_kernel<1>, dim3(w / 64, h / 16, B), dim3(256), 0, bh_stream(stream), img, H64, C, h, w, out, cov);
         BH_LAUNCH_CHECK();
         return BH_OK;
+    }
+    if (pool > 16 && cov && (flags & BH_F_DETERMINISTIC)) {
+        // deterministic call: the coverage by the one-writer kernel, the image (if any) by the generic kernel without a coverage output
+        hipLaunchKernelGGL(warp_cov32_kernel, dim3(w / 32, h / 32, B), dim3(256), 0, bh_stream(stream), H64, h, w, cov);
+        BH_LAUNCH_CHECK();
+        if (!img) return BH_OK;
+        cov = nullptr;
     }
     if (pool > 16 && cov) {       // quarter-window partial sums are added with atomics
         hipError_t e = hipMemsetAsync(cov, 0, (size_t)B * (h / pool) * (w / pool) * sizeof(float), bh_stream(stream));
@@ -382,13 +419,18 @@ int bh_warp_fwd(const float* img, const double* H64, int B, int C, int h, int w,
 
 int bh_warp_bwd(const float* img, const double* H64, const float* g_out, const float* g_cov, int B, int C, int h, int w,
                 int pool, double* gH, void* stream) {
+    return bh_warp_bwd_f(img, H64, g_out, g_cov, B, C, h, w, pool, gH, 0, stream);
+}
+
+int bh_warp_bwd_f(const float* img, const double* H64, const float* g_out, const float* g_cov, int B, int C, int h, int w,
+                  int pool, double* gH, int flags, void* stream) {
     if (!H64 || !gH || B < 0 || (g_out && !img)) return BH_E_BADARG;
     if ((h % 16) || (w % 16) || (pool != 1 && pool != 2 && pool != 4 && pool != 8 && pool != 16 && pool != 32) || (h % pool) || (w % pool)) return BH_E_UNSUPPORTED;
     if (B == 0) return BH_OK;
     if (pool == 4 && (w % 64) == 0) {
         int rpt = g_warp_rpt_bwd;
         while (rpt > 1 && h % (16 * rpt)) rpt >>= 1;
-        const dim3 grid = bh_deterministic() ? dim3(1, 1, B) : dim3(w / 64, h / (16 * rpt), B);
+        const dim3 grid = (flags & BH_F_DETERMINISTIC) ? dim3(1, 1, B) : dim3(w / 64, h / (16 * rpt), B);
         hipStream_t s = bh_stream(stream);
         if (rpt >= 4) hipLaunchKernelGGL(warp_bwd4_kernel<4>, grid, dim3(256), 0, s, img, H64, g_out, g_cov, C, h, w, gH);
         else if (rpt == 2) hipLaunchKernelGGL(warp_bwd4_kernel<2>, grid, dim3(256), 0, s, img, H64, g_out, g_cov, C, h, w, gH);
@@ -396,7 +438,7 @@ int bh_warp_bwd(const float* img, const double* H64, const float* g_out, const f
         BH_LAUNCH_CHECK();
         return BH_OK;
     }
-    hipLaunchKernelGGL(warp_bwd_kernel, bh_deterministic() ? dim3(1, 1, B) : dim3(w / 16, h / 16, B), dim3(256), 0, bh_stream(stream), img,
+    hipLaunchKernelGGL(warp_bwd_kernel, (flags & BH_F_DETERMINISTIC) ? dim3(1, 1, B) : dim3(w / 16, h / 16, B), dim3(256), 0, bh_stream(stream), img,
                        H64, g_out, g_cov, C, h, w, pool, gH);
     BH_LAUNCH_CHECK();
     return BH_OK;

@@ -778,10 +778,10 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
     if (!d || !x || !gy || !gw) return BH_E_BADARG;
     if (d->out_nchw && (d->Co > 4 || d->transposed)) return BH_E_UNSUPPORTED;
     hipStream_t s = bh_stream(stream);
-    // deterministic mode (bh_set_deterministic): with a workspace EVERY shape has an order-independent form - the f32x3 and
+    // deterministic call (BH_ROUTE_DETERMINISTIC): with a workspace EVERY shape has an order-independent form - the f32x3 and
     // stride-1 kernels store partial tiles, all others accumulate through integer-limb shadow entries; the last Co entries of
     // the workspace serve the bias gradient
-    const bool det = ws && bh_deterministic();
+    const bool det = ws && (d->route & BH_ROUTE_DETERMINISTIC);
     if (det) ws_bytes &= ~7ll;                                          // (the bias entries at the end of the workspace are doubles)
     const long long bias_bytes = det ? (long long)(d->transposed ? d->Co : d->Co) * BH_ACC_WORDS * 8 : 0;
     if (d->precision >= 2 && d->precision <= 4 && !(d->route & BH_ROUTE_WGRAD_GENERIC)) {

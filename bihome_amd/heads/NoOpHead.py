@@ -18,6 +18,7 @@ import torch.nn as nn
 from .. import kernels as K
 
 
+@K.scoped_module
 class Model(nn.Module):
 
     def __init__(self, backbone, **kwargs):

@@ -122,6 +122,7 @@ class AuxiliaryResnet(nn.Module):
 # -----------------------------------------------------------------------------------------------
 # autograd nodes
 # -----------------------------------------------------------------------------------------------
+@K.scoped_function
 class _DltFunction(torch.autograd.Function):
     """pf[N,2,h,w], choice[N,n*P] -> delta_hat[N,n,4,2], Hdlt[N,n,3,3]  (ransac_utils.py:47-74 +
     PerceptualHead.py:125-146,175-178)."""
@@ -146,6 +147,7 @@ class _DltFunction(torch.autograd.Function):
         return K.dlt_bwd(pf, choice, eig, g, ctx.n, ctx.P, g_H=gH), None, None, None
 
 
+@K.scoped_function
 class _DsacScores(torch.autograd.Function):
     """DSACSoftmax.__score_hypotheses (ransac_utils.py:76-128): scores[N,n] = softmax(-sum_points |H.coord - map|_1), with
     its adjoint w.r.t. the perspective field (every point) and the hypotheses' homographies."""
@@ -167,6 +169,7 @@ class _DsacScores(torch.autograd.Function):
         return g_pf, g_Hd.to(torch.float32).view(-1, ctx.n, 3, 3)
 
 
+@K.scoped_function
 class _ScaleSamples(torch.autograd.Function):
     """y[b] = x[b // rep] * s[b] (multihead_resnet_loss' score weighting, PerceptualHead.py:276-280)."""
 
@@ -187,6 +190,7 @@ class _ScaleSamples(torch.autograd.Function):
         return g_x, g_s, None
 
 
+@K.scoped_function
 class _BiHomELoss(torch.autograd.Function):
     """triplet_resnet_loss, double-line branch (PerceptualHead.py:320-714) for stacked directions.
     patches[2B,1,h,w] = cat(patch_1, patch_2); delta[2B,4,2] = cat(delta_hat_12, delta_hat_21)."""
@@ -239,6 +243,7 @@ class _BiHomELoss(torch.autograd.Function):
         return gdelta, None, None
 
 
+@K.scoped_function
 class _IHomELoss(torch.autograd.Function):
     """triplet_resnet_loss, one-line branch (iHomE; PerceptualHead.py:320-538): only patch_1 is warped, hinge with a
     numeric margin.  patches[2B,1,h,w] = cat(patch_1, patch_2); delta[B,4,2] = delta_hat_12."""
@@ -289,6 +294,7 @@ class _IHomELoss(torch.autograd.Function):
         return gdelta, None, None, g_scores, None
 
 
+@K.scoped_function
 class _WarpFeatures(torch.autograd.Function):
     """multihead_resnet_loss (PerceptualHead.py:245-315): features of the warped patch_1 as a differentiable function
     of delta_hat.  p1[B,1,h,w], delta[B,4,2] -> NHWC features [B,h/s,w/s,C]."""
@@ -327,6 +333,7 @@ def _tb_scalars(data, groups):
 
 
 # -----------------------------------------------------------------------------------------------
+@K.scoped_module
 class Model(nn.Module):
 
     def __init__(self, backbone, **kwargs):

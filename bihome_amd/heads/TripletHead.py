@@ -18,6 +18,7 @@ from .. import kernels as K
 from .. import net
 
 
+@K.scoped_function
 class _ZhangTripletLoss(torch.autograd.Function):
     """delta[2B | B,4,2] = cat(delta_hat_12, delta_hat_21) (one line: delta_hat_12), patches[2B,1,h,w] = cat(patch_1, patch_2),
     feat[2B,1,h,w] = the backbone's features of the unwarped patches (they carry gradients: the extractor is trainable)."""
@@ -80,6 +81,7 @@ class _ZhangTripletLoss(torch.autograd.Function):
         return gdelta, None, torch.cat([g_f1, g_f2], 0), None
 
 
+@K.scoped_module
 class Model(nn.Module):
 
     def __init__(self, backbone, **kwargs):

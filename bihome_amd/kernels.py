@@ -5,22 +5,107 @@ import os
 
 import torch
 
-from ._lib import AMAX_FLOATS, GEOMETRY_FIELDS, BhBnIn, BhBnReduce, BhConvDesc, BhPack3x3Job, check, lib
+from ._lib import (AMAX_FLOATS, BN_DETERMINISTIC, F_DETERMINISTIC, GEOMETRY_FIELDS, ROUTE_DETERMINISTIC, BhBnIn, BhBnReduce, BhConvDesc,
+                   BhPack3x3Job, check, lib)
 
 
 def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+# Deterministic calls (include/bihome.h "Deterministic calls"): the C library has NO mode - every launch carries its own bit.  What is
+# kept here is host-side convenience: a default for newly built models (BIHOME_DETERMINISTIC=1 / set_deterministic) and a scope that the
+# models' forward / backward passes open around their launches with THEIR mode (net.Runner.det, the heads' .det), so two models of one
+# process can run in different modes.
+_DET_DEFAULT = os.environ.get("BIHOME_DETERMINISTIC", "0") == "1"
+_DET_SCOPE = []
+
+
 def set_deterministic(on=True):
-    """Library-wide deterministic mode (include/bihome.h bh_set_deterministic): every cross-workgroup sum becomes order-independent
-    - bit-identical training steps from run to run, and HIP-graph replays identical to eager steps.  Returns the previous setting.
-    (BIHOME_DETERMINISTIC=1 sets it at import.)  Must not change between the capture and the replays of a graph."""
-    return bool(lib.bh_set_deterministic(1 if on else 0))
+    """The mode of calls made OUTSIDE a model's scope and the default of models built from now on: every cross-workgroup sum
+    order-independent - bit-identical training steps from run to run, HIP-graph replays identical to eager steps.  Returns the
+    previous default.  A model keeps the mode it was built with (net.Runner.det, head.det)."""
+    global _DET_DEFAULT
+    prev, _DET_DEFAULT = _DET_DEFAULT, bool(on)
+    return prev
 
 
 def deterministic():
-    return bool(lib.bh_get_deterministic())
+    """The mode of the calls being made right now (innermost det_scope, else the default)."""
+    return _DET_SCOPE[-1] if _DET_SCOPE else _DET_DEFAULT
+
+
+class det_scope:
+    """with det_scope(on): ... - the wrappers below set the per-call bit of every launch inside from `on`."""
+
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        _DET_SCOPE.append(self.on)
+        return self
+
+    def __exit__(self, *exc):
+        _DET_SCOPE.pop()
+
+
+def scoped_function(cls):
+    """Class decorator for torch.autograd.Function subclasses that launch kernels: forward records the mode in force (ctx.det),
+    backward re-opens it - a backward pass runs wherever autograd calls it, long after the model's own scope was closed."""
+    fwd, bwd = cls.forward, cls.backward
+
+    def forward(ctx, *a, **k):
+        ctx.det = deterministic()
+        return fwd(ctx, *a, **k)
+
+    def backward(ctx, *g):
+        with det_scope(ctx.det):
+            return bwd(ctx, *g)
+    cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
+    return cls
+
+
+def scoped_module(cls):
+    """Class decorator for the head modules: the mode is fixed when the module is built (self.det) and forward /
+    predict_homography open a scope with it."""
+    init = cls.__init__
+
+    def __init__(self, *a, **k):
+        init(self, *a, **k)
+        if not hasattr(self, "det"):
+            self.det = deterministic()
+    cls.__init__ = __init__
+    for name in ("forward", "predict_homography"):
+        fn = cls.__dict__.get(name)
+        if fn is None:
+            continue
+
+        def wrap(fn):
+            def method(self, *a, **k):
+                with det_scope(self.det):
+                    return fn(self, *a, **k)
+            method.__name__, method.__doc__ = fn.__name__, fn.__doc__
+            return method
+        setattr(cls, name, wrap(fn))
+    return cls
+
+
+def _mark(d):
+    _route_det(d)
+    dp = getattr(d, "bh_packed", None)
+    if dp is not None:
+        _route_det(dp)
+    return d
+
+
+def _fdet():
+    return F_DETERMINISTIC if deterministic() else 0
+
+
+def _route_det(d):
+    """The descriptor with its BH_ROUTE_DETERMINISTIC bit set from the current scope (in place: descriptors are per-call host objects)."""
+    d.route = (d.route | ROUTE_DETERMINISTIC) if deterministic() else (d.route & ~ROUTE_DETERMINISTIC)
+    return d
 
 
 def _stream():
@@ -149,7 +234,7 @@ def dlt_bwd(pf, choice, eig, g_delta, n, P, g_H=None):
     _chk(pf); _chk(choice, torch.int64); _chk(eig, torch.float64); _chk(g_delta); _chk(g_H, torch.float64)
     B, _, h, w = pf.shape
     g_pf = torch.zeros_like(pf)
-    check(lib.bh_dlt_bwd(_p(pf), _p(choice), _p(eig), _p(g_delta), _p(g_H), B, n, P, h, w, _p(g_pf), _stream()), "bh_dlt_bwd")
+    check(lib.bh_dlt_bwd_f(_p(pf), _p(choice), _p(eig), _p(g_delta), _p(g_H), B, n, P, h, w, _p(g_pf), _fdet(), _stream()), "bh_dlt_bwd")
     return g_pf
 
 
@@ -171,7 +256,7 @@ def dsac_scores_bwd(pf, Hd, scores, g_scores, n):
     g_err = torch.empty_like(scores)
     g_Hd = torch.empty(B * n, 9, dtype=torch.float64, device=pf.device)
     g_pf = torch.zeros_like(pf)
-    check(lib.bh_dsac_scores_bwd(_p(pf), _p(Hd), _p(scores), _p(g_scores), B, n, h, w, _p(g_err), _p(g_Hd), _p(g_pf), _stream()),
+    check(lib.bh_dsac_scores_bwd_f(_p(pf), _p(Hd), _p(scores), _p(g_scores), B, n, h, w, _p(g_err), _p(g_Hd), _p(g_pf), _fdet(), _stream()),
           "bh_dsac_scores_bwd")
     return g_pf, g_Hd
 
@@ -192,7 +277,7 @@ def scale_samples_bwd(g_y, x, s, rep, want_gx):
     L = x.numel() // x.shape[0]
     g_x = torch.empty_like(g_y) if want_gx else None
     g_s = torch.empty(Bn, dtype=torch.float32, device=x.device)
-    check(lib.bh_scale_samples_bwd(_p(g_y), _p(x), _p(s), Bn, L, rep, _p(g_x), _p(g_s), _stream()), "bh_scale_samples_bwd")
+    check(lib.bh_scale_samples_bwd_f(_p(g_y), _p(x), _p(s), Bn, L, rep, _p(g_x), _p(g_s), _fdet(), _stream()), "bh_scale_samples_bwd")
     return g_x, g_s
 
 
@@ -215,7 +300,7 @@ def warp_fwd(img, H64, pool=4, want_cov=True):
     out = torch.empty_like(img)
     cov = torch.empty(B, h // pool, w // pool, dtype=torch.float32, device=img.device) if want_cov else None
     with _Timed("warp_fwd_kernel", 0.0, 4.0 * (img.numel() + out.numel() + (cov.numel() if want_cov else 0))):     # 8 B/px/channel
-        check(lib.bh_warp_fwd(_p(img), _p(H64), B, C, h, w, pool, _p(out), _p(cov), _stream()), "bh_warp_fwd")
+        check(lib.bh_warp_fwd_f(_p(img), _p(H64), B, C, h, w, pool, _p(out), _p(cov), _fdet(), _stream()), "bh_warp_fwd")
     return out, cov
 
 
@@ -223,7 +308,7 @@ def mask_coverage_fwd(H64, h, w, pool=4):
     _chk(H64, torch.float64)
     B = H64.shape[0]
     cov = torch.empty(B, h // pool, w // pool, dtype=torch.float32, device=H64.device)
-    check(lib.bh_warp_fwd(None, _p(H64), B, 1, h, w, pool, None, _p(cov), _stream()), "bh_warp_fwd(cov)")
+    check(lib.bh_warp_fwd_f(None, _p(H64), B, 1, h, w, pool, None, _p(cov), _fdet(), _stream()), "bh_warp_fwd(cov)")
     return cov
 
 
@@ -233,7 +318,7 @@ def warp_bwd(img, H64, g_out, g_cov, pool=4, gH=None):
     if gH is None:
         gH = torch.zeros(B, 9, dtype=torch.float64, device=img.device)
     with _Timed("warp_bwd_kernel", 0.0, 4.0 * (img.numel() + g_out.numel() + (g_cov.numel() if g_cov is not None else 0))):
-        check(lib.bh_warp_bwd(_p(img), _p(H64), _p(g_out), _p(g_cov), B, C, h, w, pool, _p(gH), _stream()), "bh_warp_bwd")
+        check(lib.bh_warp_bwd_f(_p(img), _p(H64), _p(g_out), _p(g_cov), B, C, h, w, pool, _p(gH), _fdet(), _stream()), "bh_warp_bwd")
     return gH
 
 
@@ -249,8 +334,8 @@ def triplet_l1_fwd(f1, f2, f1w, f2w, m1w, m2w, m1=None, m2=None):
     M2 = torch.empty_like(M1)
     numden = torch.empty(B, 4, dtype=torch.float64, device=f1.device)
     with _Timed("triplet_fwd_kernel", 0.0, 4.0 * (4 * f1.numel() + 4 * M1.numel())):      # 4 feature maps in, masks in, M1 / M2 out
-        check(lib.bh_triplet_l1_fwd(_p(f1), _p(f2), _p(f1w), _p(f2w), _p(m1w), _p(m2w), _p(m1), _p(m2), B, hf * wf, C,
-                                    _p(M1), _p(M2), _p(numden), _stream()), "bh_triplet_l1_fwd")
+        check(lib.bh_triplet_l1_fwd_f(_p(f1), _p(f2), _p(f1w), _p(f2w), _p(m1w), _p(m2w), _p(m1), _p(m2), B, hf * wf, C,
+                                      _p(M1), _p(M2), _p(numden), _fdet(), _stream()), "bh_triplet_l1_fwd")
     return M1, M2, numden
 
 
@@ -264,8 +349,8 @@ def oneline_loss_fwd(f1, f2, f1w, m1w, margin, m2=None, rep=1, sample_w=None):
     numden = torch.empty(B, 2, dtype=torch.float64, device=f1.device)
     per = torch.empty(B, dtype=torch.float32, device=f1.device)
     loss = torch.empty(1, dtype=torch.float32, device=f1.device)
-    check(lib.bh_oneline_loss_fwd(_p(f1), _p(f2), _p(f1w), _p(m1w), _p(m2), B, hf * wf, C, float(margin), rep, _p(sample_w), _p(T),
-                                  _p(numden), _p(per), _p(loss), _stream()), "bh_oneline_loss_fwd")
+    check(lib.bh_oneline_loss_fwd_f(_p(f1), _p(f2), _p(f1w), _p(m1w), _p(m2), B, hf * wf, C, float(margin), rep, _p(sample_w), _p(T),
+                                    _p(numden), _p(per), _p(loss), _fdet(), _stream()), "bh_oneline_loss_fwd")
     return loss, T, numden, per
 
 
@@ -382,7 +467,7 @@ _ENV_ROUTE = int(os.environ.get("BIHOME_ROUTE", "0"))     # benchmarks: OR these
 def conv_desc(N, Hi, Wi, Ci, Co, k, stride, pad, transposed=False, in_nchw=False, out_nchw=False, precision=0, route=0):
     d = BhConvDesc()
     d.precision = int(precision)
-    d.route = int(route) | _ENV_ROUTE
+    d.route = int(route) | _ENV_ROUTE | (ROUTE_DETERMINISTIC if deterministic() else 0)
     d.N, d.Hi, d.Wi, d.Ci, d.Co = N, Hi, Wi, Ci, Co
     d.kh = d.kw = k
     d.stride, d.pad = stride, pad
@@ -524,6 +609,7 @@ def conv_fwd(x, w, bias, d, bn_sums=None, groups=1, res=None, relu=False, wpacke
     bn_sums: zeroed float64 sums buffer - the conv also accumulates the batch statistics of its output for the
     BatchNorm that follows (bn_fwd(..., stats=bn_sums, stats_ready=True)).  res / relu: inference epilogue
     y = act(conv + bias + res) (BatchNorm folded into w, bias by the caller)."""
+    _mark(d)
     if isinstance(x, BnOnLoad):
         # the BatchNorm in front of this conv is applied on load (packed f32x3 forward only)
         bol, x = x, x.z
@@ -532,6 +618,7 @@ def conv_fwd(x, w, bias, d, bn_sums=None, groups=1, res=None, relu=False, wpacke
             raise RuntimeError("BatchNorm-on-load needs the packed f32x3 3x3 forward")
         y = torch.empty(conv_out_shape(d), dtype=torch.float32, device=x.device)
         dp = getattr(d, "bh_packed", None) or _with_layout(d, packed_layout(d.precision))
+        _route_det(dp)
         if dp.precision == F16X2:
             dp.a_bound = amax_of(bol).data_ptr()
         bs = bol.struct()
@@ -544,7 +631,7 @@ def conv_fwd(x, w, bias, d, bn_sums=None, groups=1, res=None, relu=False, wpacke
     _chk(x); _chk(w); _chk(bias); _chk(res)
     y = torch.empty(conv_out_shape(d), dtype=torch.float32, device=x.device)
     if wpacked is not None:
-        d, w = (getattr(d, "bh_packed", None) or _with_layout(d, packed_layout(d.precision))), wpacked
+        d, w = _route_det(getattr(d, "bh_packed", None) or _with_layout(d, packed_layout(d.precision))), wpacked
         if d.precision == F16X2:
             d.a_bound = amax_of(x).data_ptr()
     with _Timed(_conv_variant(d, "fwd", bn_groups=groups if bn_sums is not None else 0), conv_flops(d),
@@ -625,8 +712,9 @@ def conv_dgrad(gy, w, d, out=None, bn_reduce=None, wkey=None, wpacked=None, cols
     BatchNorm whose output gradient this call completes - its backward sums are accumulated into `sums` (zeroed
     bn_stats_buffer) in the conv epilogue; pass them to bn_bwd(..., sums_ready=sums)."""
     _chk(gy); _chk(w)
+    _mark(d)
     if wpacked is not None:
-        d, w = (getattr(d, "bh_packed", None) or _with_layout(d, packed_layout(d.precision))), wpacked
+        d, w = _route_det(getattr(d, "bh_packed", None) or _with_layout(d, packed_layout(d.precision))), wpacked
         if d.precision == F16X2:
             d.a_bound = amax_of(gy).data_ptr()
     if colsum is not None:
@@ -673,7 +761,7 @@ def conv_dgrad(gy, w, d, out=None, bn_reduce=None, wkey=None, wpacked=None, cols
 
 def wgrad_det_bytes(d):
     """Workspace bytes of the deterministic weight-gradient form for this conv (0: not available for the shape)."""
-    return int(lib.bh_conv_wgrad_det_bytes(ctypes.byref(d)))
+    return int(lib.bh_conv_wgrad_det_bytes(ctypes.byref(_route_det(d))))
 
 
 def conv_wgrad(x, gy, gw, gbias, d, det_ws=None):
@@ -681,6 +769,7 @@ def conv_wgrad(x, gy, gw, gbias, d, det_ws=None):
     that the wgrad entry is the kernel rocprofv3 lists under the same name).
     det_ws: float32 workspace of >= wgrad_det_bytes(d) bytes - the split-K partial tiles are stored there and added in a
     fixed order by a second launch (bitwise repeatable, no atomics); ignored where the shape has no deterministic form."""
+    _route_det(d)
     if d.precision == F16X2 and getattr(d, "bh_wx3", True):
         # both records -> the fp16-piece kernel; (a description without them runs the exact three-piece form)
         d.a_bound, d.b_bound = amax_of(x).data_ptr(), amax_of(gy).data_ptr()
@@ -744,7 +833,7 @@ def bn_fwd(x, gamma, beta, rmean, rvar, res, groups, eps, momentum, relu, traini
     if stats is None:
         stats = bn_stats_buffer(groups, C, x.device)
         stats_ready = False
-    flags = (1 if relu else 0) | (2 if res is not None else 0) | (8 if stats_ready else 0)
+    flags = (1 if relu else 0) | (2 if res is not None else 0) | (8 if stats_ready else 0) | (BN_DETERMINISTIC if deterministic() else 0)
     nb = 4.0 * x.numel() * ((2 if (training and not stats_ready) else 1) + 1 + (1 if res is not None else 0))
     with _Timed("bn_fwd(%d kernels)" % (2 if (training and not stats_ready) else 1) + (" g%d rows%d C%d" % (groups, rows, C) if TIMING_DETAIL else ""), 0.0, nb):
         check(lib.bh_bn_fwd_amax(_p(x), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(res), _p(y), _p(stats), groups, rows, C,
@@ -768,7 +857,8 @@ def bn_bwd(gy, y, x, gamma, stats, rmean, rvar, groups, eps, relu, training, wan
         scratch = torch.empty(lib.bh_bn_scratch_doubles(groups, C), dtype=torch.float64, device=x.device)
     had_res = want_gres if had_res is None else had_res
     mask_from_x = relu and not had_res          # y = relu(x*scale+shift): the mask is recomputed, y is not read
-    flags = (1 if relu else 0) | (2 if want_gres else 0) | (4 if mask_from_x else 0) | (16 if sums_ready is not None else 0)
+    flags = ((1 if relu else 0) | (2 if want_gres else 0) | (4 if mask_from_x else 0) | (16 if sums_ready is not None else 0)
+             | (BN_DETERMINISTIC if deterministic() else 0))
     passes = 1 if sums_ready is not None else 2
     nb = 4.0 * x.numel() * (passes * (2 + (1 if (relu and not mask_from_x) else 0)) + 1 + (1 if want_gres else 0))
     with _Timed("bn_bwd(%d kernels)" % (1 if sums_ready is not None else 3) + (" g%d rows%d C%d" % (groups, rows, C) if TIMING_DETAIL else ""), 0.0, nb):
@@ -810,9 +900,9 @@ def tail_bwd(gout, x, w1, b1, gamma, beta, w2, ws, rmean, rvar, groups, hw, eps,
     scratch = torch.empty(lib.bh_tail_scratch_floats(groups, Ci, Cm), dtype=torch.float32, device=x.device)
     fl = 2.0 * N * h * w * Cm * (3 * Ci + 2 * Co + Ci)
     with _Timed("tail_bwd(5 kernels)", fl, 4.0 * (x.numel() * 3 + gout.numel() * 3)):
-        check(lib.bh_tail_bwd(_p(gout), _p(x), _p(w1), _p(b1), _p(gamma), _p(beta), _p(w2), _p(ws), _p(rmean), _p(rvar),
-                              _p(gx), _p(gw1), _p(ggamma), _p(gbeta), _p(gw2), _p(gb2), _p(scratch), groups, rows, hw, Ci,
-                              Cm, Co, float(eps), 0 if training else 1, _stream()), "bh_tail_bwd")
+        check(lib.bh_tail_bwd_f(_p(gout), _p(x), _p(w1), _p(b1), _p(gamma), _p(beta), _p(w2), _p(ws), _p(rmean), _p(rvar),
+                                _p(gx), _p(gw1), _p(ggamma), _p(gbeta), _p(gw2), _p(gb2), _p(scratch), groups, rows, hw, Ci,
+                                Cm, Co, float(eps), 0 if training else 1, _fdet(), _stream()), "bh_tail_bwd")
     return gx
 
 

@@ -644,6 +644,16 @@ class NetFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, anchor, runner, groups, grad_mode=True):
+        with K.det_scope(runner.det):               # every launch of this pass carries the Runner's own determinism bit
+            return NetFunction._forward(ctx, x, anchor, runner, groups, grad_mode)
+
+    @staticmethod
+    def backward(ctx, g):
+        with K.det_scope(ctx.runner.det):
+            return NetFunction._backward(ctx, g)
+
+    @staticmethod
+    def _forward(ctx, x, anchor, runner, groups, grad_mode=True):
         # (needs_input_grad reflects requires_grad of the inputs even under torch.no_grad(): the caller passes the mode)
         need = grad_mode and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         training = runner.module.training
@@ -658,7 +668,7 @@ class NetFunction(torch.autograd.Function):
         return out
 
     @staticmethod
-    def backward(ctx, g):
+    def _backward(ctx, g):
         r = ctx.runner
         if r.flat is not None:
             r.flat.attach(g.device)
@@ -713,6 +723,10 @@ class Runner:
         _RUNNERS.add(self)
         self.module, self.prog = module, prog
         self.precision = K.PRECISION[str(precision).lower()]     # conv operand precision (0 fp32, 1 bf16 operands, 2 f32x3)
+        # deterministic calls (include/bihome.h): a property of THIS Runner, fixed when it is built (kernels.set_deterministic /
+        # BIHOME_DETERMINISTIC=1 give the default, `with kernels.det_scope(True): build_model(...)` a per-model choice) - the library has
+        # no process-wide mode, two models of one process may differ
+        self.det = K.deterministic()
         params = [p for p in module.parameters() if p.requires_grad]
         self.flat = FlatGrads(params) if (trainable and params) else None
         self.anchor = params[0] if (trainable and params) else None

@@ -32,27 +32,31 @@ extern "C" {
 int bh_version(void);
 int bh_device_arch(char* buf, int buflen);
 
-/* Deterministic mode (round 3; what torch.use_deterministic_algorithms is to the reference's ATen path, train.py:379-387).
+/* Deterministic calls (round 3: a process-wide switch; round 4: a PER-CALL bit - the library holds no mode and no other mutable
+ * state).  What torch.use_deterministic_algorithms is to the reference's ATen path (train.py:379-387).
  * By default cross-workgroup sums use hardware floating-point atomics, whose rounding depends on arrival order: two runs of the
- * same step differ in the last bits.  bh_set_deterministic(1) (process-wide, returns the previous setting; read at launch time,
- * so it must not change between a forward pass and its backward - the sums a forward leaves for the backward are encoded per mode - nor between
- * the capture and the replays of a HIP graph) makes every launch of this library order-independent:
- *   - BatchNorm statistics / backward sums / bias column sums accumulated in conv epilogues: exact integer-limb accumulation inside
- *     the padded sums entries (csrc/common.h bh_det_add; the readers understand both encodings);
- *   - weight and bias gradients: bh_conv_wgrad_det with a workspace of bh_conv_wgrad_det_bytes(d) - partial tiles added in split
- *     order (f32x3 / stride-1 kernels) or integer-limb shadow entries (every other shape).  bh_conv_wgrad / bh_conv_bias_grad have
- *     no workspace and stay atomic;
- *   - warp adjoint, triplet / one-line reductions, score weighting, the tail's bias gradient: one workgroup per sample / channel;
- *   - DLT adjoint: duplicates of a sample's indices are added in point order inside the wave, hypotheses in launch order;
- *   - not covered: the pooled coverage of bh_warp_fwd with pool = 32 (four quarter-window atomics per window).
- * Same arithmetic otherwise: results differ from the default mode only by the order of additions. */
+ * same step differ in the last bits.  With the bit set a launch is order-independent:
+ *   - conv family (bh_conv_desc.route & BH_ROUTE_DETERMINISTIC): BatchNorm statistics / backward sums / bias column sums accumulated
+ *     in conv epilogues go through exact integer limbs inside the padded sums entries (csrc/common.h bh_det_add); weight and bias
+ *     gradients: bh_conv_wgrad_det with a workspace of bh_conv_wgrad_det_bytes(d) - partial tiles added in split order (split-operand /
+ *     stride-1 kernels) or integer-limb shadow entries (every other shape).  bh_conv_wgrad / bh_conv_bias_grad have no workspace
+ *     and stay atomic;
+ *   - BatchNorm (flags & BH_BN_DETERMINISTIC in bh_bn_fwd* / bh_bn_bwd*): the statistics pass writes, and every pass reads, the limb
+ *     encoding.  A sums table must be written and read in ONE mode (the forward that leaves sums for its backward, a conv epilogue and
+ *     the BatchNorm that consumes its statistics); bh_bn_fwd_coeffs looks at both encodings;
+ *   - bh_warp_bwd_f, bh_triplet_l1_fwd_f, bh_oneline_loss_fwd_f, bh_scale_samples_bwd_f, bh_dsac_scores_bwd_f, bh_tail_bwd_f
+ *     (flags & BH_F_DETERMINISTIC): one workgroup per sample / channel is the only writer of its sums;
+ *   - bh_dlt_bwd_f: duplicates of a sample's indices are added in point order inside the wave, hypotheses in launch order;
+ *   - bh_warp_fwd_f with pool = 32: the pooled coverage by a one-writer kernel (the default adds four quarter-window sums with atomics).
+ * The entry points without the _f suffix are the same calls with flags = 0.  Same arithmetic otherwise: results differ from the
+ * default only by the order of additions.  A HIP graph replays whatever bits its captured launches carried. */
+#define BH_F_DETERMINISTIC 1          /* flags argument of the bh_*_f entry points */
+#define BH_BN_DETERMINISTIC 32        /* flags argument of bh_bn_fwd / bh_bn_fwd_amax / bh_bn_bwd / bh_bn_bwd_amax */
 /* Measured matrix-pipe peak for the roofline: sustained TFLOP/s of a bare v_mfma_f32_32x32x16_bf16 stream on the whole
  * chip (two workgroups of four waves per CU, ~5 ms), with constant operands (random_operands = 0) or random-bit operands (1: the data
  * toggling of real tensors - on MI355X the power-limited rate, 25-35 % below the first).  Synchronises the stream.  sink_dev: 4 bytes of
  * device memory (never written). */
 int bh_probe_mfma_bf16(int random_operands, float* sink_dev, double* tflops, void* stream);
-int bh_set_deterministic(int on);
-int bh_get_deterministic(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Geometry (per-sample small dense algebra, double precision inside)
@@ -81,6 +85,8 @@ int bh_dlt_fwd(const float* pf, const int64_t* choice, int B, int n, int P, int 
  * bh_dsac_scores_bwd), added to the one that arrives through delta_hat */
 int bh_dlt_bwd(const float* pf, const int64_t* choice, const double* eig, const float* g_delta, const double* g_Hdlt,
                int B, int n, int P, int h, int w, float* g_pf, void* stream);
+int bh_dlt_bwd_f(const float* pf, const int64_t* choice, const double* eig, const float* g_delta, const double* g_Hdlt,
+                 int B, int n, int P, int h, int w, float* g_pf, int flags, void* stream);      /* flags: BH_F_DETERMINISTIC */
 
 /* DSACSoftmax.__score_hypotheses ('repr_error'), src/heads/ransac_utils.py:76-128, and the
  * arg-max of softmax(-err) == arg-min of err at src/heads/PerceptualHead.py:755-757:
@@ -95,6 +101,8 @@ int bh_dsac_score(const float* pf, const float* Hdlt, int B, int n, int h, int w
 int bh_dsac_scores_fwd(const float* err, int B, int n, float* scores, void* stream);
 int bh_dsac_scores_bwd(const float* pf, const float* Hdlt, const float* scores, const float* g_scores, int B, int n, int h,
                        int w, float* g_err, double* g_Hdlt, float* g_pf, void* stream);
+int bh_dsac_scores_bwd_f(const float* pf, const float* Hdlt, const float* scores, const float* g_scores, int B, int n, int h,
+                         int w, float* g_err, double* g_Hdlt, float* g_pf, int flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Homography warp (warp_image, src/data/utils.py:54-59 -> kornia.warp_perspective(bilinear, zeros,
@@ -102,13 +110,17 @@ int bh_dsac_scores_bwd(const float* pf, const float* Hdlt, const float* scores, 
  * + AvgPool2d(k) (src/heads/PerceptualHead.py:380-382,401,447-459) fused into the same pass.
  * ------------------------------------------------------------------------------------------- */
 /* img[B,C,h,w] (NULL => only the coverage is produced), H64[B,9]; out[B,C,h,w] (may be NULL when
- * img is NULL); cov[B,h/pool,w/pool] (NULL => skipped). h,w multiples of pool; pool in {1,2,4,8,16}. */
+ * img is NULL); cov[B,h/pool,w/pool] (NULL => skipped). h,w multiples of pool; pool in {1,2,4,8,16,32}. */
 int bh_warp_fwd(const float* img, const double* H64, int B, int C, int h, int w, int pool,
                 float* out, float* cov, void* stream);
+int bh_warp_fwd_f(const float* img, const double* H64, int B, int C, int h, int w, int pool,
+                  float* out, float* cov, int flags, void* stream);         /* flags: BH_F_DETERMINISTIC (matters for pool = 32) */
 /* adjoint w.r.t. H only (the image is data): g_out[B,C,h,w] (NULL ok), g_cov[B,h/pool,w/pool]
  * (NULL ok) -> gH[B,9] += (double, atomics; caller zeroes) */
 int bh_warp_bwd(const float* img, const double* H64, const float* g_out, const float* g_cov,
                 int B, int C, int h, int w, int pool, double* gH, void* stream);
+int bh_warp_bwd_f(const float* img, const double* H64, const float* g_out, const float* g_cov,
+                  int B, int C, int h, int w, int pool, double* gH, int flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * biHomE triplet L1 reduction (triplet_resnet_loss, double-line / l1 / channel-agnostic / str margin:
@@ -119,6 +131,9 @@ int bh_warp_bwd(const float* img, const double* H64, const float* g_out, const f
 int bh_triplet_l1_fwd(const float* f1, const float* f2, const float* f1w, const float* f2w,
                       const float* m1w, const float* m2w, const float* m1, const float* m2,
                       int B, int hw, int C, float* M1, float* M2, double* numden, void* stream);
+int bh_triplet_l1_fwd_f(const float* f1, const float* f2, const float* f1w, const float* f2w,
+                        const float* m1w, const float* m2w, const float* m1, const float* m2,
+                        int B, int hw, int C, float* M1, float* M2, double* numden, int flags, void* stream);
 /* loss4[4] = { loss, ln1, ln2, ln3 }: ln_k = sum_b num/max(den,1); ln3 = sum_b ||H1 H2 - I||_F^2;
  * loss = ln1 + ln2 + mu*ln3 (PerceptualHead.py:656-665) */
 int bh_bihome_loss_fwd(const double* numden, const double* H1, const double* H2, int B, float mu,
@@ -141,6 +156,9 @@ int bh_bihome_loss_bwd(const float* g_loss, const float* f1, const float* f2, co
 int bh_oneline_loss_fwd(const float* f1, const float* f2, const float* f1w, const float* m1w, const float* m2, int B, int hw,
                         int C, float margin, int rep, const float* sample_w, float* T, double* numden, float* per_sample,
                         float* loss, void* stream);
+int bh_oneline_loss_fwd_f(const float* f1, const float* f2, const float* f1w, const float* m1w, const float* m2, int B, int hw,
+                          int C, float margin, int rep, const float* sample_w, float* T, double* numden, float* per_sample,
+                          float* loss, int flags, void* stream);
 /* adjoint: g_loss[1] -> g_f1w[B,hw,C], g_m1w[B,hw] (overwritten); d loss / d sample_w[b] = g_loss * per_sample[b] */
 int bh_oneline_loss_bwd(const float* g_loss, const float* f2, const float* f1w, const float* m1w, const float* m2,
                         const float* T, const double* numden, int B, int hw, int C, int rep, const float* sample_w,
@@ -163,6 +181,8 @@ int bh_zhang_triplet_bwd(const float* g_loss, const float* f1, const float* f2, 
 int bh_scale_samples_fwd(const float* x, const float* s, int Bn, long long L, int rep, float* y, void* stream);
 int bh_scale_samples_bwd(const float* g_y, const float* x, const float* s, int Bn, long long L, int rep, float* g_x, float* g_s,
                          void* stream);
+int bh_scale_samples_bwd_f(const float* g_y, const float* x, const float* s, int Bn, long long L, int rep, float* g_x, float* g_s,
+                           int flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Conv stacks (Rethinking._forward src/backbones/Rethinking.py:284-294 with blocks
@@ -223,6 +243,7 @@ int bh_absmax(const float* x, long long n, float* record, void* stream);
 #define BH_ROUTE_WGRAD_3TAP 16    /* wgrad: three taps per workgroup in the stride-1 fast path */
 #define BH_ROUTE_C3_ONE_SUBTILE 32  /* fwd / dgrad: halo-tiled 3x3 kernel with one 8x8 sub-tile per workgroup (64-channel tile) */
 #define BH_ROUTE_C3_ONE_POSITION 64 /* fwd / dgrad: halo-tiled 3x3 kernel never walks two tile positions per workgroup */
+#define BH_ROUTE_DETERMINISTIC 128  /* every launch of this call is order-independent (see "Deterministic calls" above) */
 
 /* One 3x3 layer's weights for bh_conv3x3_pack: w[Co][3][3][Ci] (Co, Ci multiples of 32) -> pf (forward operand order) and
  * pd (dgrad operand order: transposed, taps flipped), Co*9*Ci floats each (split: 1.5x that); either may be NULL. */
@@ -333,7 +354,7 @@ int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, cons
  * With precision 2 (f32x3: 3x3 layers, H and W multiples of 8, channels multiples of 64) this is the FAST form - the kernel
  * keeps one 64 x 9 x 64 block per workgroup and storing + reducing <= 256 of them costs less than the atomics tail.
  * BH_E_UNSUPPORTED for other shapes (use bh_conv_wgrad). */
-/* In deterministic mode (bh_set_deterministic) every shape has a workspace form (bh_conv_wgrad_det_bytes > 0) and gbias, when given,
+/* In a deterministic call (BH_ROUTE_DETERMINISTIC) every shape has a workspace form (bh_conv_wgrad_det_bytes > 0) and gbias, when given,
  * is accumulated deterministically as well (its entries are the last Co * 32 bytes of the workspace). */
 long long bh_conv_wgrad_det_bytes(const bh_conv_desc* d);
 int bh_conv_wgrad_det(const float* x, const float* gy, float* gw, float* gbias, const bh_conv_desc* d, float* ws, long long ws_bytes,
@@ -347,7 +368,7 @@ int bh_conv_bias_grad(const float* gy, float* gbias, const bh_conv_desc* d, void
  * calls into one launch and keeps the statistics separate per group).  x,y: [groups*rows, C].
  *   stats[groups, C, 2] double = {mean, biased var}; running stats are updated group after group
  *   with `momentum`, unbiased variance, exactly like consecutive nn.BatchNorm2d calls.
- *   flags: bit0 relu, bit1 residual add (y = act(bn(x) + res)). eval mode: use_running = 1. */
+ *   flags: bit0 relu, bit1 residual add (y = act(bn(x) + res)), BH_BN_DETERMINISTIC. eval mode: use_running = 1. */
 /* stats (forward): bh_bn_stats_doubles() doubles = [groups,C,2] per-channel sums (sum x, sum x^2), each entry on its
  * own 128-byte line (same-line f64 atomics serialise; layout in csrc/common.h).  Accumulated with f64 atomics: MUST BE
  * ZERO on entry unless eval mode; flags bit3 = the sums were already accumulated by bh_conv_fwd_bnstats.  Kept for the
@@ -408,6 +429,11 @@ int bh_tail_bwd(const float* gout, const float* x, const float* w1, const float*
                 const float* running_var, float* gx, float* gw1, float* ggamma, float* gbeta, float* gw2, float* gb2,
                 float* scratch, int groups, int rows, int hw, int Ci, int Cm, int Co, float eps, int use_running,
                 void* stream);
+int bh_tail_bwd_f(const float* gout, const float* x, const float* w1, const float* b1, const float* gamma,
+                  const float* beta, const float* w2, const double* ws, const float* running_mean,
+                  const float* running_var, float* gx, float* gw1, float* ggamma, float* gbeta, float* gw2, float* gb2,
+                  float* scratch, int groups, int rows, int hw, int Ci, int Cm, int Co, float eps, int use_running,
+                  int flags, void* stream);                                   /* flags: BH_F_DETERMINISTIC (the bias gradient gb2) */
 
 /* Synthetic pair generator (next-row f1): HomographyNetPrep + PhotometricDistortSimple + DictToGrayscale +
  * DictStandardize of src/data/transforms.py:296-330,344-378,441-725 for B samples in one launch.

@@ -142,3 +142,75 @@ def test_limb_accumulation_of_batchnorm_sums_is_exact_and_repeatable(det):
     ref_out = F.batch_norm(y.view(2, -1, C).permute(0, 2, 1).reshape(2, C, -1)[0:1].double(), None, None, training=True).float()
     got = out.view(2, -1, C)[0].t()
     assert (got.cpu() - ref_out[0].cpu()).abs().max().item() < 2e-5
+
+
+def test_two_models_of_one_process_run_in_different_modes():
+    """Round-3 VERDICT item 8: the library has no process-wide mode - the bit travels with every call (bh_conv_desc.route, the BatchNorm
+    flags, the flags argument of the bh_*_f entry points) and a model keeps the mode it was built with.  A deterministic and a default
+    model are built in ONE process and stepped alternately; the deterministic one must reproduce, bit for bit, the run of a deterministic
+    model that had the process to itself, whatever the other one does in between."""
+    from bihome_amd import kernels as K
+    from bihome_amd.step import build_model, build_optimizer, train_step
+    assert not hasattr(K.lib, "bh_set_deterministic")          # (no such switch in the C ABI any more)
+    cfg = configs.get("zeng-bihome")
+    B = 8
+    d = synth.make_pairs(B, seed=33)
+    g = torch.Generator().manual_seed(9)
+    ch = [torch.randint(1, 128 * 128, (B, 128), generator=g).cuda() for _ in range(2)]
+
+    def batch(i):
+        b = {k: torch.tensor(np.roll(d[k], i, axis=0)).cuda() for k in ("patch_1", "patch_2", "delta")}
+        b["choice_12"], b["choice_21"] = torch.roll(ch[0], i, 0), torch.roll(ch[1], i, 0)
+        return b
+
+    def build(det_on):
+        with K.det_scope(det_on):
+            model = build_model(cfg)
+            load_synthetic(model[0], 0)
+            load_synthetic(model[1].auxiliary_resnet, 0)
+            opt, sched = build_optimizer(model, cfg["SOLVER"])
+            train_step(model, batch(0), opt, sched)           # (Runners are built lazily at the first forward: inside the scope)
+        return model, opt, sched
+
+    prev = K.set_deterministic(False)
+    try:
+        solo = build(True)
+        assert solo[0][0]._runner.det and solo[0][1].det
+        solo_losses = [train_step(*solo[:1], batch(i), *solo[1:])[0].item() for i in (1, 2)]
+        torch.cuda.synchronize()
+        solo_params = {k: v.detach().float().cpu().clone() for k, v in solo[0][0].state_dict().items()}
+        a, b_ = build(True), build(False)
+        assert a[0][0]._runner.det and not b_[0][0]._runner.det and not b_[0][1].det
+        la, lb = [], []
+        for i in (1, 2):                                      # interleaved, no scope around the calls: each model carries its mode
+            lb.append(train_step(b_[0], batch(i), b_[1], b_[2])[0].item())
+            la.append(train_step(a[0], batch(i), a[1], a[2])[0].item())
+        torch.cuda.synchronize()
+        assert la == solo_losses, (la, solo_losses)
+        pa = {k: v.detach().float().cpu() for k, v in a[0][0].state_dict().items()}
+        bad = [k for k in pa if not torch.equal(pa[k], solo_params[k])]
+        assert not bad, bad[:10]
+        assert abs(lb[0] - la[0]) <= 1e-5 * abs(la[0]) + 1e-6      # the default model: same arithmetic, atomics order differs
+    finally:
+        K.set_deterministic(prev)
+
+
+def test_pool32_coverage_has_a_one_writer_form(det):
+    """Round-3 'not covered' item: bh_warp_fwd with pool = 32 (AUXILIARY_RESNET_OUTPUT_LAYER 4) adds four quarter-window sums with float
+    atomics; a deterministic call computes every window in one workgroup, quarters in a fixed order - repeatable bits, same values to
+    rounding, with and without an image."""
+    K = det
+    g = torch.Generator().manual_seed(3)
+    B, h = 6, 128
+    delta = ((torch.rand(B, 4, 2, generator=g) - 0.5) * 48).cuda()
+    H64, _ = K.h4pt_fwd(delta, h)
+    img = torch.randn(B, 1, h, h, generator=g).cuda()
+    outs = [K.warp_fwd(img, H64, 32) for _ in range(3)]
+    assert all(torch.equal(outs[0][1], o[1]) and torch.equal(outs[0][0], o[0]) for o in outs[1:])
+    cov_only = K.mask_coverage_fwd(H64, h, h, 32)
+    assert torch.equal(cov_only, outs[0][1])
+    K.set_deterministic(False)
+    ref = K.warp_fwd(img, H64, 32)
+    K.set_deterministic(True)
+    assert torch.equal(ref[0], outs[0][0])
+    assert (ref[1] - outs[0][1]).abs().max().item() < 1e-6 and ref[1].abs().max().item() > 0.1

@@ -14,6 +14,8 @@ python3 bench.py --no-cpu-baseline --config detone-bihome > $O/tmp.log 2>&1; las
 python3 bench.py --no-cpu-baseline --config detone-bihome --precision bf16 > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_detone_bf16.json
 python3 bench.py --no-cpu-baseline --config detone-bihome --precision f32x2 > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_detone_f32x2.json
 python3 bench.py --no-cpu-baseline --precision f32x2 > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_f32x2.json
+python3 bench.py --no-cpu-baseline --precision f32x3 > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_f32x3.json
+python3 bench.py --no-cpu-baseline --steps 200 --warmup 20 --no-roofline > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_steps200.json
 BIHOME_DETERMINISTIC=1 python3 bench.py --no-cpu-baseline > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_deterministic.json
 [ -x tools/mfma_clock_probe.bin ] && tools/mfma_clock_probe.bin > $O/${T}_mfma_clock_probe.txt 2>&1
 [ -f bihome_amd/libbihome_hip_tuning.so ] && for m in fwd fwdstats dgrad; do BIHOME_TUNING=1 python3 tools/x3_timeline.py $m; done > $O/${T}_x3_timeline.txt 2>&1
