@@ -458,6 +458,8 @@ def main():
                                                "exactly into 3 bf16 pieces, 6 partial products per product on v_mfma_f32_32x32x16_bf16; all "
                                                "other convs: v_mfma_f32_32x32x2_f32 (the default arithmetic of rounds 2-3)",
                                       "f32-mfma": "fp32 tensors, v_mfma_f32_32x32x2_f32 everywhere",
+                                      "bf16": "REDUCED precision (not the headline): fp32 tensors in HBM, conv operands rounded to bf16 on their "
+                                              "way to v_mfma_f32_32x32x16_bf16, fp32 accumulate",
                                       "f16x2": F16X2_TEXT,
                                       "f32x2": "REDUCED precision (not the headline): fp32 tensors, fp32 accumulate; 3x3 / stride-1 convs: each "
                                                "operand as two bf16 pieces rounded to nearest (x = hi + mid + e, |e| <= 2^-18 |x|), 3 partial "
