@@ -1,5 +1,5 @@
 """The same short training run (fresh device-generated pairs every step, same seeds) in the two fp32-accurate arithmetics -
-'f32' (f32x3 in the 3x3 layers) and 'f32-mfma' (fp32-input MFMA everywhere) - and, for scale, twice in 'f32-mfma' with
+'f32' (round 4: fp16 pieces in the 3x3 layers), 'f32x3' (the exact three-piece cut) and 'f32-mfma' (fp32-input MFMA everywhere) - and, for scale, twice in 'f32-mfma' with
 different atomics orders: loss / MACE averaged over windows of steps.  Training from random weights is chaotic, so the
 trajectories differ step by step; what must agree is their statistics.   python tools/train_compare.py [steps] [batch]"""
 import sys; sys.path.insert(0, '.')
@@ -33,6 +33,7 @@ def run(precision, tag):
     print("%-22s loss per pair / MACE per window of %d steps: %s" % (tag, win, "  ".join(out)), flush=True)
 
 
-run("f32", "f32 (f32x3)")
+run("f32", "f32 (f16x2, round 4)")
+run("f32x3", "f32x3 (exact cut)")
 run("f32-mfma", "f32-mfma run 1")
 run("f32-mfma", "f32-mfma run 2")
