@@ -401,6 +401,237 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
     if (amax) bh_amax_commit(amax, vmax, blockIdx.x + blockIdx.y * 7u, sm_amax);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Two-branch join (round 4): y = relu(bn_a(xa) + bn_b(xb)) - the end of every residual unit whose lower branch ends in its own
+// BatchNorm (ResNet50DeconvBlock / the strided ResNet34ConvBlock, src/backbones/utils.py:60-82,85-112).  Unfused that is
+// bn(xb) -> l (read + write), bn(xa, res = l) -> y (two reads + write): the normalised lower branch is written and read back
+// for nothing.  Here both BatchNorms are applied in ONE pass (two reads, one write), and the adjoint - d = gy [y > 0],
+// gxa = sc_a (d - k1 - xhat_a k2a), gxb = sc_b (d - k1 - xhat_b k2b) with the SHARED k1 = mean d - is one reduce pass over
+// (gy, y, xa, xb) for the three sums and one apply pass, instead of reduce + apply per branch with the masked gradient
+// written and read in between.  grid (nblk, groups)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bn_join_apply_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
+                                                            const float* __restrict__ gamma_a, const float* __restrict__ beta_a,
+                                                            const float* __restrict__ gamma_b, const float* __restrict__ beta_b,
+                                                            const double* __restrict__ stats_a, const double* __restrict__ stats_b,
+                                                            float* __restrict__ y, BnGeom g, float eps_a, float eps_b, int relu,
+                                                            float mom_a, float mom_b, float* __restrict__ rm_a, float* __restrict__ rv_a,
+                                                            float* __restrict__ rm_b, float* __restrict__ rv_b, unsigned* __restrict__ amax) {
+    __shared__ float sm_amax[4];
+    float vmax = 0.f;
+    const int cq = threadIdx.x % g.LPR, r0 = threadIdx.x / g.LPR;
+    const int grp = blockIdx.y;
+    BnRaw ra[4], rb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ra[i] = bn_raw(stats_a, gamma_a, beta_a, nullptr, nullptr, 0, g.groups, grp, g.C, cq * 4 + i, g.det);
+        rb[i] = bn_raw(stats_b, gamma_b, beta_b, nullptr, nullptr, 0, g.groups, grp, g.C, cq * 4 + i, g.det);
+    }
+    const size_t gbase = ((size_t)grp * g.rows) * g.C + cq * 4;
+    const int stride = gridDim.x * g.RPP;
+    int r = blockIdx.x * g.RPP + r0;
+    float4 a[4], q[4];
+    auto issue = [&](int rbase) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = rbase + u * stride;
+            const bool ok = rr < g.rows;
+            a[u] = ok ? *reinterpret_cast<const float4*>(xa + gbase + (size_t)rr * g.C) : make_float4(0.f, 0.f, 0.f, 0.f);
+            q[u] = ok ? *reinterpret_cast<const float4*>(xb + gbase + (size_t)rr * g.C) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    issue(r);
+    float sca[4], scb[4], sh[4];
+    const double inv_rows = 1.0 / (double)g.rows;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float m, is, sha, shb;
+        bn_coeffs_from_raw(ra[i], 0, eps_a, inv_rows, m, is, sca[i], sha);
+        bn_coeffs_from_raw(rb[i], 0, eps_b, inv_rows, m, is, scb[i], shb);
+        sh[i] = sha + shb;
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        if (rm_a) bn_update_running(stats_a, g, mom_a, rm_a, rv_a);
+        if (rm_b) bn_update_running(stats_b, g, mom_b, rm_b, rv_b);
+    }
+    while (true) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r + u * stride;
+            if (rr >= g.rows) break;
+            float4 o = make_float4(__builtin_fmaf(a[u].x, sca[0], __builtin_fmaf(q[u].x, scb[0], sh[0])),
+                                   __builtin_fmaf(a[u].y, sca[1], __builtin_fmaf(q[u].y, scb[1], sh[1])),
+                                   __builtin_fmaf(a[u].z, sca[2], __builtin_fmaf(q[u].z, scb[2], sh[2])),
+                                   __builtin_fmaf(a[u].w, sca[3], __builtin_fmaf(q[u].w, scb[3], sh[3])));
+            if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            *reinterpret_cast<float4*>(y + gbase + (size_t)rr * g.C) = o;
+            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+        }
+        r += 4 * stride;
+        if (r >= g.rows) break;
+        issue(r);
+    }
+    if (amax) bh_amax_commit(amax, vmax, blockIdx.x + blockIdx.y * 7u, sm_amax);
+}
+
+// reduce: per chunk (sum d, sum d xhat_a, sum d xhat_b) per channel, d = gy [y > 0] (relu) - grid (nchunks, groups); part[grp][chunk][C][3]
+__global__ void __launch_bounds__(256) bn_join_bwd_reduce_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                                                 const float* __restrict__ xa, const float* __restrict__ xb,
+                                                                 const double* __restrict__ stats_a, const double* __restrict__ stats_b,
+                                                                 BnGeom g, float eps_a, float eps_b, int relu, double* __restrict__ part) {
+    __shared__ double sm[256 * 12];
+    const int cq = threadIdx.x % g.LPR, r0 = threadIdx.x / g.LPR;
+    const int grp = blockIdx.y, chunk = blockIdx.x;
+    const int rbeg = chunk * g.rows_per_chunk, rend = min(g.rows, rbeg + g.rows_per_chunk);
+    float ma[4], ia[4], mb[4], ib[4], t0, t1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bn_coeffs(stats_a, nullptr, nullptr, nullptr, nullptr, 0, g.groups, grp, g.C, cq * 4 + i, eps_a, (double)g.rows, ma[i], ia[i], t0, t1, g.det);
+        bn_coeffs(stats_b, nullptr, nullptr, nullptr, nullptr, 0, g.groups, grp, g.C, cq * 4 + i, eps_b, (double)g.rows, mb[i], ib[i], t0, t1, g.det);
+    }
+    const size_t gbase = ((size_t)grp * g.rows) * g.C + cq * 4;
+    double v[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto accumulate = [&](float4 d, const float4& yv, const float4& a, const float4& b) {
+        if (relu) {
+            if (!(yv.x > 0.f)) d.x = 0.f;
+            if (!(yv.y > 0.f)) d.y = 0.f;
+            if (!(yv.z > 0.f)) d.z = 0.f;
+            if (!(yv.w > 0.f)) d.w = 0.f;
+        }
+        v[0] += d.x; v[1] += d.y; v[2] += d.z; v[3] += d.w;
+        v[4] += (double)(d.x * ((a.x - ma[0]) * ia[0])); v[5] += (double)(d.y * ((a.y - ma[1]) * ia[1]));
+        v[6] += (double)(d.z * ((a.z - ma[2]) * ia[2])); v[7] += (double)(d.w * ((a.w - ma[3]) * ia[3]));
+        v[8] += (double)(d.x * ((b.x - mb[0]) * ib[0])); v[9] += (double)(d.y * ((b.y - mb[1]) * ib[1]));
+        v[10] += (double)(d.z * ((b.z - mb[2]) * ib[2])); v[11] += (double)(d.w * ((b.w - mb[3]) * ib[3]));
+    };
+    int r = rbeg + r0;
+    for (; r + 3 * g.RPP < rend; r += 4 * g.RPP) {
+        float4 d[4], yv[4], a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t off = gbase + (size_t)(r + u * g.RPP) * g.C;
+            d[u] = *reinterpret_cast<const float4*>(gy + off);
+            yv[u] = relu ? *reinterpret_cast<const float4*>(y + off) : make_float4(1.f, 1.f, 1.f, 1.f);
+            a[u] = *reinterpret_cast<const float4*>(xa + off);
+            b[u] = *reinterpret_cast<const float4*>(xb + off);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) accumulate(d[u], yv[u], a[u], b[u]);
+    }
+    for (; r < rend; r += g.RPP) {
+        const size_t off = gbase + (size_t)r * g.C;
+        accumulate(*reinterpret_cast<const float4*>(gy + off), relu ? *reinterpret_cast<const float4*>(y + off) : make_float4(1.f, 1.f, 1.f, 1.f),
+                   *reinterpret_cast<const float4*>(xa + off), *reinterpret_cast<const float4*>(xb + off));
+    }
+    reduce_rows<12>(v, g.LPR, g.RPP, sm);
+    if ((int)threadIdx.x < g.LPR) {
+        double* p = part + (((size_t)grp * g.nchunks + chunk) * g.C + cq * 4) * 3;
+        for (int i = 0; i < 4; ++i) { p[i * 3] = v[i]; p[i * 3 + 1] = v[4 + i]; p[i * 3 + 2] = v[8 + i]; }
+    }
+}
+
+// one wavefront per channel: totals (deterministic), dgamma / dbeta of both BatchNorms, coef[grp][c] = (mean d, mean d xhat_a, mean d xhat_b, 0)
+__global__ void __launch_bounds__(64) bn_join_bwd_finalize_kernel(const double* __restrict__ part, BnGeom g, float* __restrict__ gg_a,
+                                                                  float* __restrict__ gb_a, float* __restrict__ gg_b, float* __restrict__ gb_b,
+                                                                  float4* __restrict__ coef) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    double t1 = 0, t2a = 0, t2b = 0;
+    for (int grp = 0; grp < g.groups; ++grp) {
+        double s1 = 0, s2a = 0, s2b = 0;
+        for (int k = lane; k < g.nchunks; k += 64) {
+            const double* p = part + (((size_t)grp * g.nchunks + k) * g.C + c) * 3;
+            s1 += p[0]; s2a += p[1]; s2b += p[2];
+        }
+        s1 = wave_sum(s1); s2a = wave_sum(s2a); s2b = wave_sum(s2b);
+        if (lane == 0) {
+            const float invn = 1.0f / (float)g.rows;
+            coef[(size_t)grp * g.C + c] = make_float4((float)s1 * invn, (float)s2a * invn, (float)s2b * invn, 0.f);
+        }
+        t1 += s1; t2a += s2a; t2b += s2b;
+    }
+    if (lane == 0) {
+        if (gg_a) gg_a[c] += (float)t2a;
+        if (gb_a) gb_a[c] += (float)t1;
+        if (gg_b) gg_b[c] += (float)t2b;
+        if (gb_b) gb_b[c] += (float)t1;
+    }
+}
+
+// apply: grid (nblk, groups)
+__global__ void __launch_bounds__(256) bn_join_bwd_apply_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                                                const float* __restrict__ xa, const float* __restrict__ xb,
+                                                                const float* __restrict__ gamma_a, const float* __restrict__ gamma_b,
+                                                                const double* __restrict__ stats_a, const double* __restrict__ stats_b,
+                                                                const float4* __restrict__ coef, float* __restrict__ gxa,
+                                                                float* __restrict__ gxb, BnGeom g, float eps_a, float eps_b, int relu,
+                                                                unsigned* __restrict__ amax_a, unsigned* __restrict__ amax_b) {
+    __shared__ float sm_amax[4];
+    float vmax_a = 0.f, vmax_b = 0.f;
+    const int cq = threadIdx.x % g.LPR, r0 = threadIdx.x / g.LPR;
+    const int grp = blockIdx.y;
+    BnRaw ra[4], rb[4];
+    float4 cf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = cq * 4 + i;
+        ra[i] = bn_raw(stats_a, gamma_a, nullptr, nullptr, nullptr, 0, g.groups, grp, g.C, c, g.det);
+        rb[i] = bn_raw(stats_b, gamma_b, nullptr, nullptr, nullptr, 0, g.groups, grp, g.C, c, g.det);
+        cf[i] = coef[(size_t)grp * g.C + c];
+    }
+    const size_t gbase = ((size_t)grp * g.rows) * g.C + cq * 4;
+    const int stride = gridDim.x * g.RPP;
+    int r = blockIdx.x * g.RPP + r0;
+    float4 dv[4], yv[4], av[4], bv[4];
+    auto issue = [&](int rbase) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = rbase + u * stride;
+            const size_t off = gbase + (size_t)rr * g.C;
+            const bool ok = rr < g.rows;
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            dv[u] = ok ? *reinterpret_cast<const float4*>(gy + off) : z;
+            yv[u] = (ok && relu) ? *reinterpret_cast<const float4*>(y + off) : make_float4(1.f, 1.f, 1.f, 1.f);
+            av[u] = ok ? *reinterpret_cast<const float4*>(xa + off) : z;
+            bv[u] = ok ? *reinterpret_cast<const float4*>(xb + off) : z;
+        }
+    };
+    issue(r);
+    float ma[4], ia[4], sca[4], mb[4], ib[4], scb[4], t;
+    const double inv_rows = 1.0 / (double)g.rows;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bn_coeffs_from_raw(ra[i], 0, eps_a, inv_rows, ma[i], ia[i], sca[i], t);
+        bn_coeffs_from_raw(rb[i], 0, eps_b, inv_rows, mb[i], ib[i], scb[i], t);
+    }
+    while (true) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r + u * stride;
+            if (rr >= g.rows) break;
+            const size_t off = gbase + (size_t)rr * g.C;
+            float d[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
+            const float yy[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
+            const float a[4] = {av[u].x, av[u].y, av[u].z, av[u].w}, b[4] = {bv[u].x, bv[u].y, bv[u].z, bv[u].w};
+            float oa[4], ob[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (relu && !(yy[i] > 0.f)) d[i] = 0.f;
+                const float e = d[i] - cf[i].x;
+                oa[i] = sca[i] * (e - (a[i] - ma[i]) * ia[i] * cf[i].y);
+                ob[i] = scb[i] * (e - (b[i] - mb[i]) * ib[i] * cf[i].z);
+                vmax_a = fmaxf(vmax_a, fabsf(oa[i])); vmax_b = fmaxf(vmax_b, fabsf(ob[i]));
+            }
+            *reinterpret_cast<float4*>(gxa + off) = make_float4(oa[0], oa[1], oa[2], oa[3]);
+            *reinterpret_cast<float4*>(gxb + off) = make_float4(ob[0], ob[1], ob[2], ob[3]);
+        }
+        r += 4 * stride;
+        if (r >= g.rows) break;
+        issue(r);
+    }
+    if (amax_a) bh_amax_commit(amax_a, vmax_a, blockIdx.x + blockIdx.y * 7u, sm_amax);
+    if (amax_b) { __syncthreads(); bh_amax_commit(amax_b, vmax_b, blockIdx.x + blockIdx.y * 5u, sm_amax); }
+}
+
 BH_KNOB(g_bn_apply_cap, 512);        // workgroups per apply launch: two per CU that loop beat a one-shot grid of 2048 by 15-30 % (tools/bn_apply_sweep.py; tuning: bh_debug_force_tile(-20, n))
 #ifdef BH_TUNING
 void bh_bn_tune(int cap) { g_bn_apply_cap = cap; }
@@ -551,5 +782,48 @@ int bh_bn_bwd_amax(const float* gy, const float* y, const float* x, const float*
 }
 
 int bh_bn_scratch_doubles(int groups, int C) { return groups * C * 2 * (1 + (BN_MAX_CHUNKS > 256 ? BN_MAX_CHUNKS : 256)); }
+
+int bh_bn_stats(const float* x, double* stats, int groups, int rows, int C, int flags, void* stream) {
+    if (!x || !stats) return BH_E_BADARG;
+    return bn_launch_stats(x, groups, rows, C, stats, bh_stream(stream), (flags & BH_BN_DETERMINISTIC) ? 1 : 0);
+}
+
+int bh_bn_join_scratch_doubles(int groups, int C) { return groups * C * 2 + groups * C * 3 * (BN_MAX_CHUNKS > 256 ? BN_MAX_CHUNKS : 256); }
+
+int bh_bn_join_fwd(const float* xa, const float* xb, const float* gamma_a, const float* beta_a, float* rmean_a, float* rvar_a,
+                   const float* gamma_b, const float* beta_b, float* rmean_b, float* rvar_b, const double* stats_a, const double* stats_b,
+                   float* y, int groups, int rows, int C, float eps_a, float eps_b, float momentum_a, float momentum_b, int flags,
+                   float* amax_y, void* stream) {
+    BnGeom g;
+    if (!xa || !xb || !y || !stats_a || !stats_b) return BH_E_BADARG;
+    if (!bn_geom(groups, rows, C, g, (flags & BH_BN_DETERMINISTIC) ? 1 : 0)) return BH_E_UNSUPPORTED;
+    hipLaunchKernelGGL(bn_join_apply_kernel, dim3(apply_blocks(g), groups), dim3(256), 0, bh_stream(stream), xa, xb, gamma_a, beta_a, gamma_b,
+                       beta_b, stats_a, stats_b, y, g, eps_a, eps_b, flags & 1, momentum_a, momentum_b, (rmean_a && rvar_a) ? rmean_a : nullptr,
+                       rvar_a, (rmean_b && rvar_b) ? rmean_b : nullptr, rvar_b, reinterpret_cast<unsigned*>(amax_y));
+    BH_LAUNCH_CHECK();
+    return BH_OK;
+}
+
+int bh_bn_join_bwd(const float* gy, const float* y, const float* xa, const float* xb, const float* gamma_a, const float* gamma_b,
+                   const double* stats_a, const double* stats_b, float* gxa, float* gxb, float* ggamma_a, float* gbeta_a, float* ggamma_b,
+                   float* gbeta_b, double* scratch, int groups, int rows, int C, float eps_a, float eps_b, int flags, float* amax_gxa,
+                   float* amax_gxb, void* stream) {
+    BnGeom g;
+    if (!gy || !xa || !xb || !gxa || !gxb || !stats_a || !stats_b || !scratch || ((flags & 1) && !y)) return BH_E_BADARG;
+    if (!bn_geom(groups, rows, C, g, (flags & BH_BN_DETERMINISTIC) ? 1 : 0)) return BH_E_UNSUPPORTED;
+    hipStream_t s = bh_stream(stream);
+    float4* coef = reinterpret_cast<float4*>(scratch);
+    double* part = scratch + (size_t)groups * C * 2;
+    hipLaunchKernelGGL(bn_join_bwd_reduce_kernel, dim3(g.nchunks, groups), dim3(256), 0, s, gy, y, xa, xb, stats_a, stats_b, g, eps_a, eps_b,
+                       flags & 1, part);
+    BH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_join_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, part, g, ggamma_a, gbeta_a, ggamma_b, gbeta_b, coef);
+    BH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_join_bwd_apply_kernel, dim3(apply_blocks(g), groups), dim3(256), 0, s, gy, y, xa, xb, gamma_a, gamma_b, stats_a,
+                       stats_b, coef, gxa, gxb, g, eps_a, eps_b, flags & 1, reinterpret_cast<unsigned*>(amax_gxa),
+                       reinterpret_cast<unsigned*>(amax_gxb));
+    BH_LAUNCH_CHECK();
+    return BH_OK;
+}
 
 }  // extern "C"

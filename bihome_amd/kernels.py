@@ -870,6 +870,63 @@ def bn_bwd(gy, y, x, gamma, stats, rmean, rvar, groups, eps, relu, training, wan
     return gx, gres
 
 
+def bn_stats(x, stats, groups, C):
+    """stats (zeroed slice of the caller's arena) += per-channel (sum, sum of squares) of x: the statistics pass alone."""
+    _chk(x); _chk(stats, torch.float64)
+    rows = x.numel() // C // groups
+    with _Timed("bn_stats_kernel", 0.0, 4.0 * x.numel()):
+        check(lib.bh_bn_stats(_p(x), _p(stats), groups, rows, C, BN_DETERMINISTIC if deterministic() else 0, _stream()), "bh_bn_stats")
+    return stats
+
+
+class BnJoinPending:
+    """The lower-branch BatchNorm of a residual unit whose apply rides in the join (bn_join_fwd): `x` is its INPUT, `stats` its sums."""
+    __slots__ = ("x", "stats", "mod")
+
+    def __init__(self, x, stats, mod):
+        self.x, self.stats, self.mod = x, stats, mod
+
+    @property
+    def shape(self):
+        return self.x.shape
+
+
+def bn_join_fwd(xa, xb, ma, mb, stats_a, stats_b, groups, relu, mom_a, mom_b, amax=None):
+    """y = act(bn_a(xa) + bn_b(xb)) (training mode, both statistics tables already accumulated); ma / mb: the BatchNorm2d modules."""
+    _chk(xa); _chk(xb); _chk(stats_a, torch.float64); _chk(stats_b, torch.float64)
+    C = ma.num_features
+    rows = xa.numel() // C // groups
+    y = torch.empty_like(xa)
+    flags = (1 if relu else 0) | (BN_DETERMINISTIC if deterministic() else 0)
+    with _Timed("bn_join_fwd" + (" g%d rows%d C%d" % (groups, rows, C) if TIMING_DETAIL else ""), 0.0, 12.0 * xa.numel()):
+        check(lib.bh_bn_join_fwd(_p(xa), _p(xb), _p(ma.weight), _p(ma.bias), _p(ma.running_mean), _p(ma.running_var), _p(mb.weight), _p(mb.bias),
+                                 _p(mb.running_mean), _p(mb.running_var), _p(stats_a), _p(stats_b), _p(y), groups, rows, C, float(ma.eps),
+                                 float(mb.eps), float(mom_a), float(mom_b), flags, _p(amax), _stream()), "bh_bn_join_fwd")
+    if amax is not None:
+        y._bh_amax = amax
+    return y
+
+
+def bn_join_bwd(gy, y, xa, xb, ma, mb, stats_a, stats_b, groups, relu, train_a, train_b, amax_a=None, amax_b=None):
+    """-> (gxa, gxb); the affine parameters' gradients are added to .grad when train_a / train_b."""
+    _chk(gy); _chk(xa); _chk(xb)
+    C = ma.num_features
+    rows = xa.numel() // C // groups
+    gxa, gxb = torch.empty_like(xa), torch.empty_like(xb)
+    scratch = torch.empty(lib.bh_bn_join_scratch_doubles(groups, C), dtype=torch.float64, device=xa.device)
+    flags = (1 if relu else 0) | (BN_DETERMINISTIC if deterministic() else 0)
+    with _Timed("bn_join_bwd(3 kernels)" + (" g%d rows%d C%d" % (groups, rows, C) if TIMING_DETAIL else ""), 0.0, 40.0 * xa.numel()):
+        check(lib.bh_bn_join_bwd(_p(gy), _p(y), _p(xa), _p(xb), _p(ma.weight), _p(mb.weight), _p(stats_a), _p(stats_b), _p(gxa), _p(gxb),
+                                 _p(ma.weight.grad) if train_a else None, _p(ma.bias.grad) if train_a else None,
+                                 _p(mb.weight.grad) if train_b else None, _p(mb.bias.grad) if train_b else None, _p(scratch), groups, rows, C,
+                                 float(ma.eps), float(mb.eps), flags, _p(amax_a), _p(amax_b), _stream()), "bh_bn_join_bwd")
+    if amax_a is not None:
+        gxa._bh_amax = amax_a
+    if amax_b is not None:
+        gxb._bh_amax = amax_b
+    return gxa, gxb
+
+
 TAIL_ROUTE_VALU_FWD = 1     # include/bihome.h BH_TAIL_ROUTE_VALU_FWD
 
 

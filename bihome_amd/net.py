@@ -180,10 +180,11 @@ class Program:
 
 class Ctx:
     """Saved tensors of one forward pass."""
-    __slots__ = ("slots", "stats", "descs", "groups", "training", "weights", "wkeys", "wpacked", "precision")
+    __slots__ = ("slots", "stats", "descs", "groups", "training", "weights", "wkeys", "wpacked", "precision", "joined")
 
     def __init__(self):
         self.slots, self.stats, self.descs, self.weights, self.wkeys, self.wpacked = {}, {}, {}, {}, {}, {}
+        self.joined = {}          # join BatchNorm op index -> lower-branch BatchNorm op index (kernels.bn_join_fwd)
 
 
 _GEOM_CACHE = {}
@@ -325,6 +326,20 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, p
                     and not prog.ops[j].extra["in_nchw"] and id(prog.ops[j].mod.weight) in packer.entries
                     and groups * op.mod.num_features * 8 <= 4096):
                 bn_on_load.add(i)
+    # Two-branch join (round 4): a training-mode BatchNorm whose residual input is itself the output of a training-mode BatchNorm that
+    # nobody else reads (the lower branch of ResNet50DeconvBlock / the strided ResNet34ConvBlock): the lower BatchNorm is not applied
+    # on its own - both are applied, added and rectified in ONE pass (kernels.bn_join_fwd), the adjoint is one reduce + one apply
+    joins = {}                                            # join bn op index -> lower bn op index
+    if training and os.environ.get("BIHOME_BN_JOIN", "1") != "0":
+        producer_ = {op.dst: j for j, op in enumerate(prog.ops)}
+        for i, op in enumerate(prog.ops):
+            j = producer_.get(op.res) if (op.kind == "bn" and op.res is not None) else None
+            if (j is not None and prog.ops[j].kind == "bn" and prog.ops[j].res is None and not prog.ops[j].relu
+                    and users.get(op.res, 0) == 1 and j not in bn_on_load and i not in bn_on_load
+                    and op.mod.num_features == prog.ops[j].mod.num_features and op.mod.num_features % 4 == 0
+                    and op.mod.weight is not None and prog.ops[j].mod.weight is not None):
+                joins[i] = j
+    join_lower = set(joins.values())
     folded = {}                                           # bn op index -> conv op index (conv deferred to the bn's position)
     if fold_cache is not None and not training and not save:
         users = {}
@@ -386,6 +401,32 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, p
             m = op.mod
             res = slots[op.res] if op.res is not None else None
             lazy = False
+            if i in join_lower and src.shape[0] % groups == 0:
+                # the lower branch of a join: statistics only (from the producer's epilogue, else one pass); applied inside the join
+                st = arena[bn_off[i]:bn_off[i] + K.bn_stats_doubles(groups, m.num_features)]
+                if i not in ready:
+                    K.bn_stats(src, st, groups, m.num_features)
+                m._bh_pending_batches = getattr(m, "_bh_pending_batches", 0) + groups
+                if save:
+                    ctx.stats[i] = st
+                slots[op.dst] = K.BnJoinPending(src, st, m)
+                continue
+            if i in joins and isinstance(res, K.BnJoinPending) and src.shape[0] % groups == 0:
+                st = arena[bn_off[i]:bn_off[i] + K.bn_stats_doubles(groups, m.num_features)]
+                if i not in ready:
+                    K.bn_stats(src, st, groups, m.num_features)
+                out = K.bn_join_fwd(src, res.x, m, res.mod, st, res.stats, groups, op.relu, _momentum(m), _momentum(res.mod),
+                                    amax=amax_next() if amax_next else None)
+                m._bh_pending_batches = getattr(m, "_bh_pending_batches", 0) + groups
+                if save:
+                    ctx.stats[i] = st
+                    ctx.joined[i] = joins[i]
+                slots[op.dst] = out
+                continue
+            if isinstance(res, K.BnJoinPending):          # (a join that could not be formed after all: apply the lower BatchNorm now)
+                lo, _ = K.bn_fwd(res.x, res.mod.weight, res.mod.bias, res.mod.running_mean, res.mod.running_var, None, groups, res.mod.eps,
+                                 _momentum(res.mod), False, training, stats=res.stats, stats_ready=True)
+                res = slots[op.res] = lo
             if i in bn_on_load and i in ready and src.shape[0] % groups == 0:
                 cop = prog.ops[consumer[op.dst]]
                 cd = _conv_geometry(cop.mod, src.shape, False, cop.extra["out_nchw"], precision)
@@ -482,7 +523,7 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
         for j, op in enumerate(prog.ops):
             b = producer.get(op.src)
             if (op.kind == "conv" and b is not None and prog.ops[b].kind == "bn" and last_consumer.get(op.src) == j
-                    and j in ctx.descs and ctx.descs[j].bh_reduce_ok and ctx.descs[j].N % ctx.groups == 0):
+                    and j in ctx.descs and ctx.descs[j].bh_reduce_ok and ctx.descs[j].N % ctx.groups == 0 and b not in ctx.joined):
                 fuse_bn[j] = b
     # A 3x3 conv that is the ONLY consumer of a biased (transposed) conv's output: the column sums of its input gradient
     # are that layer's bias gradient - accumulated in the dgrad epilogue instead of a streaming pass over the gradient
@@ -563,6 +604,22 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
                     K.conv_dgrad(g, wk, d, out=grads[op.src], bn_reduce=red, wkey=ctx.wkeys[i], wpacked=ctx.wpacked.get(i))
                 else:
                     grads[op.src] = K.conv_dgrad(g, wk, d, bn_reduce=red, wkey=ctx.wkeys[i], wpacked=ctx.wpacked.get(i))
+        elif op.kind == "bn" and i in ctx.joined:
+            j = ctx.joined[i]
+            lop, m, lm = prog.ops[j], op.mod, prog.ops[j].mod
+            train_a = want_wgrad and m.weight.requires_grad
+            train_b = want_wgrad and lm.weight.requires_grad
+            xb = slots[lop.src]
+            gxa, gxb = K.bn_join_bwd(g, slots[op.dst], x, xb, m, lm, ctx.stats[i], ctx.stats[j], ctx.groups, op.relu, train_a, train_b,
+                                     amax_a=amax_next() if amax_next else None, amax_b=amax_next() if amax_next else None)
+            if on_param_grad is not None:
+                for p_, tr_ in ((m.weight, train_a), (m.bias, train_a), (lm.weight, train_b), (lm.bias, train_b)):
+                    if tr_:
+                        on_param_grad(p_)
+            if need_src_grad:
+                contribute(op.src, gxa)
+            if (lop.src != 0) or want_input_grad:
+                contribute(lop.src, gxb)
         elif op.kind == "bn":
             m = op.mod
             train_w = want_wgrad and m.weight is not None and m.weight.requires_grad

@@ -401,6 +401,25 @@ int bh_bn_bwd_amax(const float* gy, const float* y, const float* x, const float*
                    int groups, int rows, int C, float eps, int flags, int use_running,
                    const float* running_mean, const float* running_var, float* amax_gx, void* stream);
 
+/* Two-branch join (round 4): y = act(bn_a(xa) + bn_b(xb)), both BatchNorms in training mode with their own statistics tables (already
+ * accumulated: by the producers' epilogues or bh_bn_stats-style passes) - the end of ResNet50DeconvBlock / the strided ResNet34ConvBlock
+ * (src/backbones/utils.py:60-82, 85-112) without writing the normalised lower branch.  flags: bit0 relu, BH_BN_DETERMINISTIC.  Running
+ * statistics of both are updated (NULL: skipped).  amax_y as in bh_bn_fwd_amax.
+ * Adjoint: gy, y (ReLU mask), xa, xb -> gxa, gxb (overwritten), ggamma / gbeta of both += (NULL ok); scratch: bh_bn_join_scratch_doubles()
+ * doubles; amax_gxa / amax_gxb (NULL ok) receive max |gxa| / max |gxb|.  One reduce pass for the three sums (sum d, sum d xhat_a,
+ * sum d xhat_b with d = gy [y > 0]) and one apply pass. */
+/* the statistics pass alone: stats (zeroed, bh_bn_stats_doubles() doubles) += per-channel (sum x, sum x^2); flags: BH_BN_DETERMINISTIC */
+int bh_bn_stats(const float* x, double* stats, int groups, int rows, int C, int flags, void* stream);
+int bh_bn_join_scratch_doubles(int groups, int C);
+int bh_bn_join_fwd(const float* xa, const float* xb, const float* gamma_a, const float* beta_a, float* rmean_a, float* rvar_a,
+                   const float* gamma_b, const float* beta_b, float* rmean_b, float* rvar_b, const double* stats_a, const double* stats_b,
+                   float* y, int groups, int rows, int C, float eps_a, float eps_b, float momentum_a, float momentum_b, int flags,
+                   float* amax_y, void* stream);
+int bh_bn_join_bwd(const float* gy, const float* y, const float* xa, const float* xb, const float* gamma_a, const float* gamma_b,
+                   const double* stats_a, const double* stats_b, float* gxa, float* gxb, float* ggamma_a, float* gbeta_a, float* ggamma_b,
+                   float* gbeta_b, double* scratch, int groups, int rows, int C, float eps_a, float eps_b, int flags, float* amax_gxa,
+                   float* amax_gxb, void* stream);
+
 /* Fused tail of the Zeng backbone, `layer8` (src/backbones/Rethinking.py:145-147):
  *   Conv2d(Ci,Cm,1,bias) -> BatchNorm2d(Cm) -> ReLU -> Conv2d(Cm,Co,1,bias), NHWC x[groups*rows,Ci] -> NCHW out[N,Co,h,w]
  * (hw = h*w pixels per image, rows = pixels per group).  The Cm-channel intermediate is never materialised: its batch

@@ -921,3 +921,42 @@ def test_conv3x3_halo_kernel_on_4x4_maps(K, N, Ci, Co, prec, groups):
     dg = K.conv_desc(N, 4, 4, Ci, Co, 3, 1, 1, precision=0, route=ROUTE_GENERIC_CONV)
     close(y.cpu(), K.conv_fwd(x, wk, b, dg).cpu(), 2e-5)
     close(gx.cpu(), K.conv_dgrad(gy, wk, dg).cpu(), 2e-5)
+
+
+@pytest.mark.parametrize("groups,N,H,C,relu", [(2, 2, 16, 16, True), (1, 3, 8, 64, True), (2, 2, 8, 128, False), (2, 1, 32, 32, True)])
+def test_two_branch_batchnorm_join(K, groups, N, H, C, relu):
+    """y = act(bn_a(xa) + bn_b(xb)) (round 4: the end of a decoder / strided residual unit in one pass, src/backbones/utils.py:60-82) and
+    its adjoint against the unfused float64 PyTorch chain, one BatchNorm call per group; running statistics of both BatchNorms."""
+    NN = groups * N
+    xa = (rnd((NN, C, H, H), 60) * 1.3 + 0.2).astype(np.float32)
+    xb = (rnd((NN, C, H, H), 61) * 0.7 - 0.1).astype(np.float32)
+    D = lambda a: torch.tensor(a, dtype=torch.float64)
+    bna, bnb = torch.nn.BatchNorm2d(C).double(), torch.nn.BatchNorm2d(C).double()
+    for i, bn in enumerate((bna, bnb)):
+        bn.weight.data, bn.bias.data = D(1 + 0.3 * rnd((C,), 62 + i)), D(0.3 * rnd((C,), 64 + i))
+    xat, xbt = D(xa).requires_grad_(True), D(xb).requires_grad_(True)
+    outs = []
+    for g in range(groups):
+        o = bna(xat[g * N:(g + 1) * N]) + bnb(xbt[g * N:(g + 1) * N])
+        outs.append(F.relu(o) if relu else o)
+    ref = torch.cat(outs, 0)
+    C_ = lambda a: torch.tensor(a).cuda()
+    ma, mb = torch.nn.BatchNorm2d(C).cuda(), torch.nn.BatchNorm2d(C).cuda()
+    for m, bn in ((ma, bna), (mb, bnb)):
+        m.weight.data, m.bias.data = bn.weight.data.float().cuda(), bn.bias.data.float().cuda()
+        m.weight.grad, m.bias.grad = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    xag, xbg = C_(xa).permute(0, 2, 3, 1).contiguous(), C_(xb).permute(0, 2, 3, 1).contiguous()
+    sa, sb = K.bn_stats_buffer(groups, C, "cuda"), K.bn_stats_buffer(groups, C, "cuda")
+    K.bn_stats(xag, sa, groups, C); K.bn_stats(xbg, sb, groups, C)
+    y = K.bn_join_fwd(xag, xbg, ma, mb, sa, sb, groups, relu, 0.1, 0.1)
+    close(y.cpu().permute(0, 3, 1, 2), ref.detach(), 2e-6)
+    close(ma.running_mean.cpu(), bna.running_mean, 1e-5); close(mb.running_var.cpu(), bnb.running_var, 1e-5)
+    gy = rnd(tuple(ref.shape), 66)
+    near = (torch.cat(outs, 0).detach().abs() < 1e-5).numpy() if relu else np.zeros(gy.shape, bool)
+    gy = np.where(near, 0, gy).astype(np.float32)
+    ref.backward(D(gy))
+    gxa, gxb = K.bn_join_bwd(C_(gy).permute(0, 2, 3, 1).contiguous(), y, xag, xbg, ma, mb, sa, sb, groups, relu, True, True)
+    close(gxa.cpu().permute(0, 3, 1, 2), xat.grad, 3e-5)
+    close(gxb.cpu().permute(0, 3, 1, 2), xbt.grad, 3e-5)
+    close(ma.weight.grad.cpu(), bna.weight.grad, 3e-5); close(ma.bias.grad.cpu(), bna.bias.grad, 3e-5)
+    close(mb.weight.grad.cpu(), bnb.weight.grad, 3e-5); close(mb.bias.grad.cpu(), bnb.bias.grad, 3e-5)
