@@ -84,6 +84,7 @@ SIGNATURES = {
     "bh_conv_variant": [POINTER(BhConvDesc), c_int, c_int, c_int, c_char_p, c_int],
     "bh_conv_fwd": [P, P, P, P, POINTER(BhConvDesc), P],
     "bh_conv_fwd_act": [P, P, P, P, P, POINTER(BhConvDesc), c_int, P],
+    "bh_conv_fwd_amax": [P, P, P, P, POINTER(BhConvDesc), P, P],
     "bh_conv_fwd_bnstats": [P, P, P, P, POINTER(BhConvDesc), P, c_int, P],
     "bh_conv_fwd_bnin": [P, P, P, P, POINTER(BhConvDesc), P, c_int, POINTER(BhBnIn), P],
     "bh_conv_wgrad_bnin": [P, P, P, P, POINTER(BhConvDesc), P, c_int64, POINTER(BhBnIn), P],

@@ -53,6 +53,7 @@ struct GemmArgs {
     double* bn_sums;
     int bn_det;              // deterministic mode: integer-limb accumulation (common.h bh_det_add)
     int bn_rpg, bn_groups, bn_C;
+    unsigned* amax_out;      // optional magnitude record of the output (common.h F16X2): max |value stored|, one atomic max per workgroup
 };
 
 
@@ -556,6 +557,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
         bvj[j] = (a.bias && nok[j]) ? a.bias[co] : 0.0f;
     }
     const bool want_stats = a.bn_sums != nullptr;
+    float vmax = 0.f;                                   // a.amax_out: max |v| of this thread's stores
     if (a.out_bytes) {
         // 32-bit addressing through buffer descriptors (out-of-range rows / columns get an out-of-range offset: the
         // store is dropped, a load returns 0); statistics as float partial sums per fragment quad, totals in double,
@@ -614,6 +616,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
                         }
                         if (a.relu) v = fmaxf(v, 0.0f);
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsO, off, 0, 0);
+                        if (mok && nok[j]) vmax = fmaxf(vmax, fabsf(v));
                         if (want_stats) {
                             const float vs = (mok && nok[j]) ? v : 0.f;
                             q1[j] += vs; q2[j] = __builtin_fmaf(vs, vs, q2[j]);
@@ -670,11 +673,16 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
                 if (a.res) v += a.res[off];
                 if (a.relu) v = fmaxf(v, 0.0f);
                 a.Out[off] = v;
+                vmax = fmaxf(vmax, fabsf(v));
                 st1[j] += (double)v;
                 st2[j] += (double)v * (double)v;
             }
         }
     }
+    }
+    if (a.amax_out) {
+        __shared__ float sm_amax[4];
+        bh_amax_commit(a.amax_out, vmax, blockIdx.x + blockIdx.y * 7u, sm_amax);
     }
     if (a.bn_sums) {
         // column sums of the tile: half-waves merged by a shuffle, the WM waves of a column range through LDS (the
@@ -979,22 +987,23 @@ int bh_debug_force_tile(int bm, int bn) {
 #endif
 
 static int conv_fwd_impl(const float* x, const float* w, const float* bias, const float* res, float* y, const bh_conv_desc* d,
-                         int relu, void* stream, double* bn_sums = nullptr, int groups = 1) {
+                         int relu, void* stream, double* bn_sums = nullptr, int groups = 1, float* amax_y = nullptr) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!x || !w || !y) return BH_E_BADARG;
     if (res && d->out_nchw) return BH_E_UNSUPPORTED;
-    if (!res && !bn_sums) {
+    if (!res && !bn_sums && !amax_y) {
         int taken = 0;
         rc = bh_stem7_try(x, w, bias, y, d, relu, bh_stream(stream), &taken);
         if (rc || taken) return rc;
     }
-    if (!bn_sums) {
+    if (!bn_sums && !amax_y) {
         int taken = 0;
         rc = bh_conv3x3_try(x, w, bias, y, d, 0, 0, bh_stream(stream), &taken, nullptr, 1, res, relu);
         if (rc || taken) return rc;
     }
     GemmArgs a = {};
+    a.amax_out = reinterpret_cast<unsigned*>(amax_y);
     a.res = res; a.relu = relu;
     if (bn_sums) {
         // rows of the GEMM per statistics group (input pixels for the transposed conv, whose taps scatter inside the image)
@@ -1027,6 +1036,11 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, cons
 
 int bh_conv_fwd(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, void* stream) {
     return conv_fwd_impl(x, w, bias, nullptr, y, d, 0, stream);
+}
+
+int bh_conv_fwd_amax(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, float* amax_y, void* stream) {
+    if (!amax_y) return BH_E_BADARG;
+    return conv_fwd_impl(x, w, bias, nullptr, y, d, 0, stream, nullptr, 1, amax_y);
 }
 
 int bh_conv_fwd_act(const float* x, const float* w, const float* bias, const float* res, float* y, const bh_conv_desc* d,

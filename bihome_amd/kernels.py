@@ -604,7 +604,7 @@ def bn_fwd_coeffs(stats, gamma, beta, rmean, rvar, groups, rows, C, eps, momentu
     return table
 
 
-def conv_fwd(x, w, bias, d, bn_sums=None, groups=1, res=None, relu=False, wpacked=None):
+def conv_fwd(x, w, bias, d, bn_sums=None, groups=1, res=None, relu=False, wpacked=None, amax=None):
     """wpacked: the forward buffer of WeightPacker for this conv (then `w` is only used for the byte count).
     bn_sums: zeroed float64 sums buffer - the conv also accumulates the batch statistics of its output for the
     BatchNorm that follows (bn_fwd(..., stats=bn_sums, stats_ready=True)).  res / relu: inference epilogue
@@ -639,6 +639,10 @@ def conv_fwd(x, w, bias, d, bn_sums=None, groups=1, res=None, relu=False, wpacke
         if res is not None or relu:
             check(lib.bh_conv_fwd_act(_p(x), _p(w), _p(bias), _p(res), _p(y), ctypes.byref(d), int(bool(relu)), _stream()),
                   "bh_conv_fwd_act")
+        elif amax is not None and bn_sums is None and wpacked is None:
+            # (amax: zeroed magnitude record - the generic kernel measures max |y| in its epilogue; precision-4 consumers of y)
+            check(lib.bh_conv_fwd_amax(_p(x), _p(w), _p(bias), _p(y), ctypes.byref(d), _p(amax), _stream()), "bh_conv_fwd_amax")
+            y._bh_amax = amax
         elif bn_sums is None:
             check(lib.bh_conv_fwd(_p(x), _p(w), _p(bias), _p(y), ctypes.byref(d), _stream()), "bh_conv_fwd")
         else:

@@ -284,7 +284,7 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, p
     # precision 4: one zeroed arena of magnitude records, one per BatchNorm output (the operands of the fp16-piece 3x3 kernels)
     amax_next = None
     if int(precision) == K.F16X2:
-        nrec = sum(1 for op in prog.ops if op.kind == "bn")
+        nrec = sum(1 for op in prog.ops if op.kind == "bn" or (op.kind == "conv" and isinstance(op.mod, nn.ConvTranspose2d)))
         amax_arena = torch.zeros(max(nrec, 1) * K.AMAX_FLOATS, dtype=torch.float32, device=x.device)
         amax_iter = iter(amax_arena.split(K.AMAX_FLOATS))
         amax_next = lambda: next(amax_iter)
@@ -391,6 +391,10 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, p
                                  bn_sums=arena[bn_off[b]:bn_off[b] + K.bn_stats_doubles(groups, d.Co)], groups=groups,
                                  wpacked=pk[1] if pk else None)
                 ready.add(b)
+            elif amax_next and pk is None and isinstance(op.mod, nn.ConvTranspose2d) and not e["out_nchw"]:
+                # a transposed conv in front of a packed fp16-piece 3x3 conv (the decoder units): the magnitude record of its output from
+                # its own epilogue instead of a bh_absmax pass over the (up to 268 MB) tensor
+                out = K.conv_fwd(src, wk, op.mod.bias, d, amax=amax_next())
             else:
                 out = K.conv_fwd(src, wk, op.mod.bias, d, wpacked=pk[1] if pk else None)
             if save:

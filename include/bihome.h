@@ -277,6 +277,12 @@ int bh_debug_force_tile(int bm, int bn);
 #endif
 /* y = conv(x, w) (+ bias[Co] if bias != NULL) */
 int bh_conv_fwd(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, void* stream);
+/* bh_conv_fwd on the generic implicit-GEMM kernel (Conv2d of any geometry, ConvTranspose2d with k == s) that also leaves the magnitude
+ * record of its output: amax_y (BH_AMAX_FLOATS floats, zeroed by the caller) receives max |y| - what the fp16-piece 3x3 kernels (precision 4)
+ * need of their source tensor; round 4: the transposed convs in front of the decoder units' 3x3 convs (their outputs were measured by a
+ * separate bh_absmax pass, 4 launches of 25-55 us per step). */
+int bh_conv_fwd_amax(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, float* amax_y, void* stream);
+
 /* y = act(conv(x, w) + bias + res): res (NULL ok) has the layout of y, relu != 0 applies max(.,0).  The inference path:
  * an eval-mode BatchNorm is folded into (w, bias) by the host and its ReLU / residual add ride in the conv epilogue. */
 int bh_conv_fwd_act(const float* x, const float* w, const float* bias, const float* res, float* y, const bh_conv_desc* d,
