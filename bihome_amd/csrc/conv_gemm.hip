@@ -53,6 +53,11 @@ struct GemmArgs {
     double* bn_sums;
     int bn_det;              // deterministic mode: integer-limb accumulation (common.h bh_det_add)
     int bn_rpg, bn_groups, bn_C;
+    // round 4: BatchNorm-on-load for 1x1 / stride-1 convs (the 1x1 conv of a decoder unit behind BatchNorm + ReLU): Src is the INPUT of that
+    // BatchNorm, the A operand is transformed y = max(x * scale + shift, lo) per channel between the global load and the LDS store
+    // (buffer-loader, fp32 C4 layout only).  bni: table[groups][Kc] x (scale, shift); rows of an M tile lie in one group (bni_rpg % BM == 0)
+    const float* bni;
+    int bni_relu, bni_rpg;
     unsigned* amax_out;      // optional magnitude record of the output (common.h F16X2): max |value stored|, one atomic max per workgroup
 };
 
@@ -157,6 +162,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
     const int ktiles = VEC ? a.T * kchunks : (a.T * a.Kc + BK - 1) / BK;   // scalar path: K linear over (t, c)
 
     float4 ra[AIT], rb[BIT];
+    float4 bt0 = make_float4(1.f, 0.f, 1.f, 0.f), bt1 = bt0;      // a.bni: (scale, shift) of the four channels of this thread's A chunk
 
     // division-free tile walk for the vectorised path: (tap, ky, kx, channel chunk) of the NEXT tile to load
     int nx_t = 0, nx_ky = 0, nx_kx = 0, nx_c0 = 0;
@@ -227,6 +233,10 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
             const int tap_pix = nx_ky * a.Ws + nx_kx;
             const unsigned toffA = (unsigned)((a.adjoint ? -tap_pix : tap_pix) * a.Cs + c0) * 4u;
             const bool cokA = c0 + a_chunk * 4 < a.Kc;
+            if (a.bni) {
+                const float4* tb = reinterpret_cast<const float4*>(a.bni + ((size_t)(m0 / a.bni_rpg) * a.Kc + (cokA ? c0 + a_chunk * 4 : 0)) * 2);
+                bt0 = tb[0]; bt1 = tb[1];
+            }
 #pragma unroll
             for (int i = 0; i < AIT; ++i) {
                 const bool ok = ((a_mask[i] >> t) & 1ull) && cokA;
@@ -413,6 +423,18 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
             return;
         }
         if constexpr (C4) {
+            if (a.bni) {
+                const float lo = a.bni_relu ? 0.0f : -__builtin_inff();
+#pragma unroll
+                for (int i = 0; i < AIT; ++i) {
+                    if (m0 + a_row0 + i * AROWS < a.M) {          // (rows past the end stay zero)
+                        ra[i].x = __builtin_elementwise_maximum(__builtin_fmaf(ra[i].x, bt0.x, bt0.y), lo);
+                        ra[i].y = __builtin_elementwise_maximum(__builtin_fmaf(ra[i].y, bt0.z, bt0.w), lo);
+                        ra[i].z = __builtin_elementwise_maximum(__builtin_fmaf(ra[i].z, bt1.x, bt1.y), lo);
+                        ra[i].w = __builtin_elementwise_maximum(__builtin_fmaf(ra[i].w, bt1.z, bt1.w), lo);
+                    }
+                }
+            }
 #pragma unroll
             for (int i = 0; i < AIT; ++i) {
                 const int row = a_row0 + i * AROWS;
@@ -750,8 +772,10 @@ static int dispatch(const GemmArgs& a_in, hipStream_t s) {
     if (a.ewshift < 0) a.ehwshift = -1;
     if (a.M <= 0 || a.Nn <= 0) return BH_OK;
     const bool vec = !a.src_nchw && (a.Kc % 4 == 0) && (a.Cs % 4 == 0);
+    if (a.bni && (!vec || a.bf16)) return BH_E_UNSUPPORTED;
     a.use_buf = vec && !(a.adjoint && a.stride > 1) && (a.Nn % 4 == 0) && a.T <= 64 && a.src_elems > 0 &&
                 a.src_elems < (1ll << 29) && a.bw_elems > 0 && a.bw_elems < (1ll << 29) && (a.Kc % 32 == 0) && !g_no_buf;
+    if (a.bni && !a.use_buf) return BH_E_UNSUPPORTED;
     a.src_bytes = (unsigned)(a.src_elems * 4);
     a.bw_bytes = (unsigned)(a.bw_elems * 4);
     {
@@ -987,23 +1011,33 @@ int bh_debug_force_tile(int bm, int bn) {
 #endif
 
 static int conv_fwd_impl(const float* x, const float* w, const float* bias, const float* res, float* y, const bh_conv_desc* d,
-                         int relu, void* stream, double* bn_sums = nullptr, int groups = 1, float* amax_y = nullptr) {
+                         int relu, void* stream, double* bn_sums = nullptr, int groups = 1, float* amax_y = nullptr,
+                         const bh_bn_in* bni = nullptr) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!x || !w || !y) return BH_E_BADARG;
     if (res && d->out_nchw) return BH_E_UNSUPPORTED;
-    if (!res && !bn_sums && !amax_y) {
+    if (bni) {
+        // 1x1 / stride 1 / pad 0 NHWC conv through the buffer-loader fp32 kernel only; the table's groups are equal stacks of images
+        if (d->transposed || d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0 || d->in_nchw || d->out_nchw || d->precision == 1 ||
+            !bni->table || bni->groups < 1 || d->N % bni->groups || d->Ci % 32 || d->Co % 4 || res || relu)
+            return BH_E_UNSUPPORTED;
+        const long long rpg_ = (long long)(d->N / bni->groups) * d->Ho * d->Wo;
+        if (rpg_ % 128 || (long long)d->N * d->Hi * d->Wi * d->Ci >= (1ll << 29)) return BH_E_UNSUPPORTED;
+    }
+    if (!res && !bn_sums && !amax_y && !bni) {
         int taken = 0;
         rc = bh_stem7_try(x, w, bias, y, d, relu, bh_stream(stream), &taken);
         if (rc || taken) return rc;
     }
-    if (!bn_sums && !amax_y) {
+    if (!bn_sums && !amax_y && !bni) {
         int taken = 0;
         rc = bh_conv3x3_try(x, w, bias, y, d, 0, 0, bh_stream(stream), &taken, nullptr, 1, res, relu);
         if (rc || taken) return rc;
     }
     GemmArgs a = {};
     a.amax_out = reinterpret_cast<unsigned*>(amax_y);
+    if (bni) { a.bni = bni->table; a.bni_relu = bni->relu; a.bni_rpg = (int)((long long)(d->N / bni->groups) * d->Ho * d->Wo); }
     a.res = res; a.relu = relu;
     if (bn_sums) {
         // rows of the GEMM per statistics group (input pixels for the transposed conv, whose taps scatter inside the image)
@@ -1053,6 +1087,18 @@ int bh_conv_fwd_bnin(const float* x, const float* w, const float* bias, float* y
     int rc = check_desc(d);
     if (rc) return rc;
     if (!x || !w || !y || !bni || d->out_nchw || (sums && (groups < 1 || d->N % groups))) return BH_E_BADARG;
+    if (d->kh == 1 && d->kw == 1) {
+        // round 4: the 1x1 conv behind BatchNorm + ReLU (decoder units): the generic kernel transforms its A operand while staging;
+        // statistics of the output in its epilogue where the grid allows, else one statistics pass over y
+        rc = conv_fwd_impl(x, w, bias, nullptr, y, d, 0, stream, sums, groups, nullptr, bni);
+        if (rc == BH_E_UNSUPPORTED && sums) {
+            rc = conv_fwd_impl(x, w, bias, nullptr, y, d, 0, stream, nullptr, 1, nullptr, bni);
+            if (rc) return rc;
+            if (bh_query("bn_stats_kernel")) return BH_OK;
+            return bn_launch_stats(y, groups, (d->N / groups) * d->Ho * d->Wo, d->Co, sums, bh_stream(stream), (d->route & BH_ROUTE_DETERMINISTIC) ? 1 : 0);
+        }
+        return rc;
+    }
     int taken = 0;
     rc = bh_conv3x3_try(x, w, bias, y, d, 0, 0, bh_stream(stream), &taken, sums, sums ? groups : 1, nullptr, 0, nullptr, bni);
     if (rc) return rc;

@@ -33,6 +33,10 @@ struct WgradArgs {
     int xcd_map;             // XCD-aware (tile, tap, split) order, see wgrad_kernel
     int noflush;             // ablation (bh_debug_force_tile(-7, 1)): skip the atomic flush
     float* partials;         // deterministic mode (wgrad_s1): per-workgroup partial tiles go here instead of into atomics
+    // round 4 (wgrad_small_kernel<true>, 1x1 convs): Q is the INPUT of a training-mode BatchNorm (+ReLU) whose output the conv consumed -
+    // transformed per channel while staging; bni[groups <= 2][Cq] x (scale, shift), images per group bni_ipg
+    const float* bni;
+    int bni_relu, bni_ipg, bni_groups;
     double* shadow;          // deterministic mode (every other kernel): integer-limb entries (common.h bh_det_add), BH_ACC_WORDS words per
                              // element of Out at the element's offset; wgrad_shadow_finalize_kernel adds them to Out
 };
@@ -390,6 +394,16 @@ __global__ void __launch_bounds__(256) wgrad_small_kernel(WgradArgs a) {
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     float4 rp[4], rq[4];
     const int hw = a.Ho * a.Wo;
+    float4 tq[2][2];                                    // a.bni: (scale, shift) of this thread's four Q channels, per group
+    if (VEC && a.bni) {
+        const int qc_ = min(q0 + chunk * 4, a.Cq - 4);
+#pragma unroll
+        for (int g_ = 0; g_ < 2; ++g_) {
+            const float4* tb = reinterpret_cast<const float4*>(a.bni + ((size_t)(g_ < a.bni_groups ? g_ : 0) * a.Cq + qc_) * 2);
+            tq[g_][0] = tb[0]; tq[g_][1] = tb[1];
+        }
+    }
+    const float bni_lo = a.bni_relu ? 0.0f : -__builtin_inff();
 
     auto load_tile = [&](int mk) {
 #pragma unroll
@@ -420,8 +434,17 @@ __global__ void __launch_bounds__(256) wgrad_small_kernel(WgradArgs a) {
                 const int qc = q0 + chunk * 4;
                 if (VEC) {
                     int iy, ix;
-                    if (qc < a.Nq && q_coord(a, oy, ox, t, iy, ix))
+                    if (qc < a.Nq && q_coord(a, oy, ox, t, iy, ix)) {
                         vq = *reinterpret_cast<const float4*>(a.Q + (((size_t)nb * a.Hs + iy) * a.Ws + ix) * a.Cq + qc);
+                        if (a.bni) {
+                            const int g_ = (nb >= a.bni_ipg) ? 1 : 0;
+                            const float4 t0 = g_ ? tq[1][0] : tq[0][0], t1 = g_ ? tq[1][1] : tq[0][1];
+                            vq.x = __builtin_elementwise_maximum(__builtin_fmaf(vq.x, t0.x, t0.y), bni_lo);
+                            vq.y = __builtin_elementwise_maximum(__builtin_fmaf(vq.y, t0.z, t0.w), bni_lo);
+                            vq.z = __builtin_elementwise_maximum(__builtin_fmaf(vq.z, t1.x, t1.y), bni_lo);
+                            vq.w = __builtin_elementwise_maximum(__builtin_fmaf(vq.w, t1.z, t1.w), bni_lo);
+                        }
+                    }
                 } else {
                     float e[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -737,7 +760,7 @@ int bh_conv_bias_grad(const float* gy, float* gbias, const bh_conv_desc* d, void
 }
 
 static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gbias, const bh_conv_desc* d, void* stream,
-                           float* ws, long long ws_bytes, long long* ws_need);
+                           float* ws, long long ws_bytes, long long* ws_need, const bh_bn_in* bni = nullptr);
 
 int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, const bh_conv_desc* d, void* stream) {
     return conv_wgrad_impl(x, gy, gw, gbias, d, stream, nullptr, 0, nullptr);
@@ -756,7 +779,10 @@ long long bh_conv_wgrad_det_bytes(const bh_conv_desc* d) {
 
 int bh_conv_wgrad_bnin(const float* x, const float* gy, float* gw, float* gbias, const bh_conv_desc* d, float* ws, long long ws_bytes,
                        const bh_bn_in* bni, void* stream) {
-    if (!d || !x || !gy || !gw || !bni || !ws) return BH_E_BADARG;
+    if (!d || !x || !gy || !gw || !bni) return BH_E_BADARG;
+    if (d->kh == 1 && d->kw == 1)        // round 4: 1x1 convs behind BatchNorm + ReLU - the small-channel kernel transforms x while staging
+        return conv_wgrad_impl(x, gy, gw, gbias, d, stream, ws, ws_bytes, nullptr, bni);
+    if (!ws) return BH_E_BADARG;
     if (d->precision < 2 || d->precision > 4) return BH_E_UNSUPPORTED;
     int taken = 0;
     const int rc = bh_wgrad_x3_try(x, gy, gw, d, bh_stream(stream), &taken, ws, ws_bytes, nullptr, bni);
@@ -774,7 +800,7 @@ int bh_conv_wgrad_det(const float* x, const float* gy, float* gw, float* gbias, 
 }  // extern "C"
 
 static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gbias, const bh_conv_desc* d, void* stream,
-                           float* ws, long long ws_bytes, long long* ws_need) {
+                           float* ws, long long ws_bytes, long long* ws_need, const bh_bn_in* bni) {
     if (!d || !x || !gy || !gw) return BH_E_BADARG;
     if (d->out_nchw && (d->Co > 4 || d->transposed)) return BH_E_UNSUPPORTED;
     hipStream_t s = bh_stream(stream);
@@ -784,7 +810,10 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
     const bool det = ws && (d->route & BH_ROUTE_DETERMINISTIC);
     if (det) ws_bytes &= ~7ll;                                          // (the bias entries at the end of the workspace are doubles)
     const long long bias_bytes = det ? (long long)(d->transposed ? d->Co : d->Co) * BH_ACC_WORDS * 8 : 0;
-    if (d->precision >= 2 && d->precision <= 4 && !(d->route & BH_ROUTE_WGRAD_GENERIC)) {
+    if (bni && (d->transposed || d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0 || d->in_nchw || d->out_nchw || !bni->table ||
+                bni->groups < 1 || bni->groups > 2 || d->N % bni->groups || d->Ci % 4))
+        return BH_E_UNSUPPORTED;
+    if (!bni && d->precision >= 2 && d->precision <= 4 && !(d->route & BH_ROUTE_WGRAD_GENERIC)) {
         // f32x3 / f32x2 arithmetic: the halo-tiled split-operand kernel (wgrad_x3.hip) takes the 3x3 layers with channels % 64 == 0
         int taken = 0;
         const int rc = bh_wgrad_x3_try(x, gy, gw, d, s, &taken, ws, ws_bytes > bias_bytes ? ws_bytes - bias_bytes : 0, ws_need);
@@ -846,7 +875,11 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
         a.xcd_map = 1;
     }
     dim3 grid(tiles, ty, split);
-    if (ws && small && !det) return BH_E_UNSUPPORTED;
+    if (bni) {
+        if (!small || !vec) return BH_E_UNSUPPORTED;     // (the small-channel kernel only: the decoder units' 1x1 convs up to 64 -> 32)
+        a.bni = bni->table; a.bni_relu = bni->relu; a.bni_groups = bni->groups; a.bni_ipg = d->N / bni->groups;
+    }
+    if (ws && small && !det) { if (bni) ws = nullptr; else return BH_E_UNSUPPORTED; }
     const long long numel = (long long)a.Np * a.sOp;                    // elements of gw
     auto shadow_begin = [&]() -> int {                                  // the shapes without a partial-tile form
         const long long need = numel * BH_ACC_WORDS * 8 + bias_bytes;

@@ -614,6 +614,16 @@ def conv_fwd(x, w, bias, d, bn_sums=None, groups=1, res=None, relu=False, wpacke
         # the BatchNorm in front of this conv is applied on load (packed f32x3 forward only)
         bol, x = x, x.z
         _chk(x); _chk(bias); _chk(bn_sums, torch.float64)
+        if d.kh == 1 and wpacked is None and res is None and not relu:
+            # round 4: a 1x1 conv behind BatchNorm + ReLU (decoder units) - the generic kernel transforms its A operand while staging
+            _chk(w)
+            y = torch.empty(conv_out_shape(d), dtype=torch.float32, device=x.device)
+            bs = bol.struct()
+            with _Timed((conv_variant(d, "fwd") + " bnin" + (" fwd N%d %dx%d C%d->%d k1" % (d.N, d.Hi, d.Wi, d.Ci, d.Co) if TIMING_DETAIL else "")) if TIMING is not None else "",
+                        conv_flops(d), 4.0 * (x.numel() + y.numel() + w.numel())):
+                check(lib.bh_conv_fwd_bnin(_p(x), _p(w), _p(bias), _p(y), ctypes.byref(d), _p(bn_sums), groups, ctypes.byref(bs), _stream()),
+                      "bh_conv_fwd_bnin(1x1)")
+            return y
         if wpacked is None or res is not None or relu:
             raise RuntimeError("BatchNorm-on-load needs the packed f32x3 3x3 forward")
         y = torch.empty(conv_out_shape(d), dtype=torch.float32, device=x.device)
@@ -780,6 +790,15 @@ def conv_wgrad(x, gy, gw, gbias, d, det_ws=None):
     if isinstance(x, BnOnLoad):
         bol, x = x, x.z
         _chk(x); _chk(gy); _chk(gw); _chk(gbias)
+        if d.kh == 1:
+            # round 4: 1x1 conv behind BatchNorm + ReLU - the small-channel kernel transforms x while staging (no workspace outside
+            # deterministic calls)
+            bs = bol.struct()
+            ws_ = det_ws if deterministic() else None
+            with _Timed((conv_variant(d, "wgrad") + " bnin") if TIMING is not None else "", conv_flops(d), 4.0 * (x.numel() + gy.numel() + gw.numel())):
+                check(lib.bh_conv_wgrad_bnin(_p(x), _p(gy), _p(gw), _p(gbias), ctypes.byref(d), _p(ws_), ws_.numel() * 4 if ws_ is not None else 0,
+                                             ctypes.byref(bs), _stream()), "bh_conv_wgrad_bnin(1x1)")
+            return
         need = wgrad_det_bytes(d)
         if det_ws is None or not (0 < need <= det_ws.numel() * 4):
             raise RuntimeError("BatchNorm-on-load needs the f32x3 weight gradient and its workspace")

@@ -314,6 +314,23 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, p
     # staging it (kernels.BnOnLoad): one launch and two tensor passes per such layer gone (the inner BatchNorm of every
     # residual unit).  Needs the sums from the producer's epilogue (fused_stats) and a table of <= 4 KB.
     bn_on_load = set()
+    bn_on_load_1x1 = set()
+    if training and os.environ.get("BIHOME_BN_ON_LOAD_1X1", "1") != "0" and groups <= 2 and int(precision) != 1:      # (not the bf16-operand mode)
+        # round 4: the same for a 1x1 / stride-1 conv consumer with <= 32 channels on one side (the 1x1 conv of the decoder units behind
+        # BatchNorm + ReLU at 64 x 64 and 128 x 128): generic forward kernel and small-channel weight-gradient kernel transform on load
+        consumer_ = {}
+        for j, op in enumerate(prog.ops):
+            consumer_.setdefault(op.src, j)
+        fused_bn_ = set(fused_stats.values())
+        for i, op in enumerate(prog.ops):
+            j = consumer_.get(op.dst)
+            if (op.kind == "bn" and op.res is None and i in fused_bn_ and users.get(op.dst, 0) == 1 and j is not None
+                    and prog.ops[j].kind == "conv" and prog.ops[j].src == op.dst and prog.ops[j].extra["weight_fn"] is None
+                    and not prog.ops[j].extra["in_nchw"] and not prog.ops[j].extra["out_nchw"] and isinstance(prog.ops[j].mod, nn.Conv2d)
+                    and prog.ops[j].mod.kernel_size == (1, 1) and prog.ops[j].mod.stride == (1, 1) and prog.ops[j].mod.padding == (0, 0)
+                    and prog.ops[j].mod.in_channels % 32 == 0 and prog.ops[j].mod.out_channels % 4 == 0
+                    and min(prog.ops[j].mod.in_channels, prog.ops[j].mod.out_channels) <= 32 and prog.ops[j].mod.weight.requires_grad):
+                bn_on_load_1x1.add(i)
     if training and packer is not None and int(precision) in K.SPLIT_PIECES and os.environ.get("BIHOME_BN_ON_LOAD", "1") != "0":
         consumer = {}
         for j, op in enumerate(prog.ops):
@@ -431,7 +448,9 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, p
                 lo, _ = K.bn_fwd(res.x, res.mod.weight, res.mod.bias, res.mod.running_mean, res.mod.running_var, None, groups, res.mod.eps,
                                  _momentum(res.mod), False, training, stats=res.stats, stats_ready=True)
                 res = slots[op.res] = lo
-            if i in bn_on_load and i in ready and src.shape[0] % groups == 0:
+            if i in bn_on_load_1x1 and i in ready and src.shape[0] % groups == 0 and (src.numel() // (m.num_features * groups)) % 128 == 0:
+                lazy = True
+            elif i in bn_on_load and i in ready and src.shape[0] % groups == 0:
                 cop = prog.ops[consumer[op.dst]]
                 cd = _conv_geometry(cop.mod, src.shape, False, cop.extra["out_nchw"], precision)
                 # (the consumer's weight gradient must fit the fixed f32x3 workspace, else its backward could not take the

@@ -960,3 +960,41 @@ def test_two_branch_batchnorm_join(K, groups, N, H, C, relu):
     close(gxb.cpu().permute(0, 3, 1, 2), xbt.grad, 3e-5)
     close(ma.weight.grad.cpu(), bna.weight.grad, 3e-5); close(ma.bias.grad.cpu(), bna.bias.grad, 3e-5)
     close(mb.weight.grad.cpu(), bnb.weight.grad, 3e-5); close(mb.bias.grad.cpu(), bnb.bias.grad, 3e-5)
+
+
+@pytest.mark.parametrize("N,H,Ci,Co,relu", [(4, 32, 32, 16, True), (2, 64, 64, 32, True), (6, 16, 32, 64, False), (128, 32, 32, 16, True)])
+def test_batchnorm_on_load_1x1_matches_materialised_batchnorm(K, N, H, Ci, Co, relu):
+    """Round 4: the 1x1 conv of a decoder unit behind BatchNorm + ReLU (src/backbones/utils.py:60-82) - generic forward kernel and
+    small-channel weight-gradient kernel apply the BatchNorm while staging their operand.  Against the unfused sequence: forward,
+    forward + BatchNorm sums of the conv's own output, weight gradient, in the default and in a deterministic call."""
+    groups = 2
+    g = torch.Generator().manual_seed(N + H + Ci)
+    z = (torch.randn(N, H, H, Ci, generator=g) * 1.5 + 0.3).cuda()
+    gamma = (torch.rand(Ci, generator=g) + 0.5).cuda()
+    beta = (torch.randn(Ci, generator=g) * 0.2).cuda()
+    w = (torch.randn(Co, Ci, 1, 1, generator=g) * 0.2).cuda().contiguous(memory_format=torch.channels_last)
+    wk = w.permute(0, 2, 3, 1)
+    gy = torch.randn(N, H, H, Co, generator=g).cuda()
+    rm, rv = torch.zeros(Ci).cuda(), torch.ones(Ci).cuda()
+    a, st = K.bn_fwd(z, gamma, beta, rm, rv, None, groups, 1e-5, 0.1, relu, True)
+    table = K.bn_fwd_coeffs(st, gamma, beta, rm.clone(), rv.clone(), groups, N * H * H // groups, Ci, 1e-5, 0.1)
+    lazy = K.BnOnLoad(z, table, groups, relu)
+    for det_on in (False, True):
+        with K.det_scope(det_on):
+            d = K.conv_desc(N, H, H, Ci, Co, 1, 1, 0)
+            y_ref = K.conv_fwd(a, wk, None, d)
+            y = K.conv_fwd(lazy, wk, None, d)
+            close(y.cpu(), y_ref.cpu(), 2e-6)
+            s0, s1 = K.bn_stats_buffer(groups, Co, "cuda"), K.bn_stats_buffer(groups, Co, "cuda")
+            K.conv_fwd(a, wk, None, d, bn_sums=s0, groups=groups)
+            y2 = K.conv_fwd(lazy, wk, None, d, bn_sums=s1, groups=groups)
+            assert torch.equal(y2, y)
+            o0, _ = K.bn_fwd(y_ref, None, None, torch.zeros(Co).cuda(), torch.ones(Co).cuda(), None, groups, 1e-5, 0.1, False, True, stats=s0, stats_ready=True)
+            o1, _ = K.bn_fwd(y2, None, None, torch.zeros(Co).cuda(), torch.ones(Co).cuda(), None, groups, 1e-5, 0.1, False, True, stats=s1, stats_ready=True)
+            close(o1.cpu(), o0.cpu(), 1e-5)
+            assert K.conv_variant(d, "wgrad").startswith("wgrad_small_kernel<true>")
+            ws = torch.empty(max(K.wgrad_det_bytes(d), 4) // 4 + 64, dtype=torch.float32, device="cuda") if det_on else None
+            g0, g1 = torch.zeros(Co, 1, 1, Ci, device="cuda"), torch.zeros(Co, 1, 1, Ci, device="cuda")
+            K.conv_wgrad(a, gy, g0, None, d, det_ws=ws)
+            K.conv_wgrad(lazy, gy, g1, None, d, det_ws=ws)
+            close(g1.cpu(), g0.cpu(), 3e-6)

@@ -190,7 +190,9 @@ def test_two_models_of_one_process_run_in_different_modes():
         pa = {k: v.detach().float().cpu() for k, v in a[0][0].state_dict().items()}
         bad = [k for k in pa if not torch.equal(pa[k], solo_params[k])]
         assert not bad, bad[:10]
-        assert abs(lb[0] - la[0]) <= 1e-5 * abs(la[0]) + 1e-6      # the default model: same arithmetic, atomics order differs
+        # the default model: same arithmetic, atomics order differs (after one Adam step from random weights the near-cancelling loss
+        # moves by a few 1e-5 between two default runs as well: a sanity band, the bitwise assertions above are the claim)
+        assert abs(lb[0] - la[0]) <= 1e-4 * abs(la[0]) + 1e-5
     finally:
         K.set_deterministic(prev)
 
