@@ -28,8 +28,12 @@ def shard_range(global_batch, rank, world_size):
 
 class FlatGradReducer:
 
-    def __init__(self, flat_grads, bucket_bytes=8 << 20, group=None, op=None):
+    def __init__(self, flat_grads, bucket_bytes=8 << 20, group=None, op=None, defer=False):
         self.fg = flat_grads
+        # defer: the conv stack runs SEVERAL times per step (the ContentAware feature extractor: patches in the backbone, warped patches
+        # in the head) - a parameter's gradient is only final after the last of those backward walks, so nothing leaves from the hooks;
+        # allreduce() launches every bucket at the end of the step
+        self.defer = bool(defer)
         self.group = group
         self.op = op if op is not None else dist.ReduceOp.SUM
         self.bucket_elems = max(1, bucket_bytes // 4)
@@ -66,7 +70,7 @@ class FlatGradReducer:
     # ---- called from run_backward as parameter gradients become final ------------------------------
     def param_ready(self, p):
         b = self.param_bucket.get(id(p))
-        if b is None:
+        if b is None or self.defer:
             return
         self.pending[b] -= 1
         if self.pending[b] == 0:
