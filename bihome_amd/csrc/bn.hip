@@ -402,6 +402,68 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
+// BatchNorm + ReLU + MaxPool2d(3, 2, 1) in one pass (round 4: the stem of the backbone and of the perceptual extractor,
+// Rethinking.py:31-36 / torchvision resnet conv1-bn1-relu-maxpool): the 64 x 64 x 64 activation between BatchNorm and pooling
+// (134 MB at 128 images) is never written or read - the adjoint needs the BatchNorm INPUT only (ReLU mask recomputed) and the
+// arg-max positions.  y[N,Ho,Wo,C], idx: window position (0..8) of the first maximum per element (the ATen tie rule, as
+// maxpool_fwd_kernel).  grid-stride over output float4s; coefficient table [groups][C] x (scale, shift) in LDS.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bn_maxpool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ rmean,
+                                                             const float* __restrict__ rvar, const double* __restrict__ stats,
+                                                             float* __restrict__ y, unsigned char* __restrict__ idx, BnGeom g, int N,
+                                                             int Hi, int Wi, int Ho, int Wo, float eps, int relu, int use_running,
+                                                             float momentum, float* __restrict__ upd_mean, float* __restrict__ upd_var,
+                                                             unsigned* __restrict__ amax) {
+    extern __shared__ __attribute__((aligned(16))) float tb[];          // [groups][C][2]
+    __shared__ float sm_amax[4];
+    for (int e = threadIdx.x; e < g.groups * g.C; e += 256) {
+        float m, is, sc, sh;
+        bn_coeffs(stats, gamma, beta, rmean, rvar, use_running, g.groups, e / g.C, g.C, e % g.C, eps, (double)g.rows, m, is, sc, sh, g.det);
+        tb[2 * e] = sc; tb[2 * e + 1] = sh;
+    }
+    __syncthreads();
+    if (upd_mean && blockIdx.x == 0) bn_update_running(stats, g, momentum, upd_mean, upd_var);
+    const int C4 = g.C4, ipg = N / g.groups;
+    const float lo = relu ? 0.0f : -INFINITY;
+    float vmax = 0.f;
+    const size_t total = (size_t)N * Ho * Wo * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        size_t p = i / C4;
+        const int ox = (int)(p % Wo); p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        const float4* t4 = reinterpret_cast<const float4*>(tb + ((size_t)(n / ipg) * g.C + c * 4) * 2);
+        const float4 t0 = t4[0], t1 = t4[1];                           // (sc0, sh0, sc1, sh1), (sc2, sh2, sc3, sh3)
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        uchar4 w = make_uchar4(0, 0, 0, 0);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 - 1 + ky;
+            if (iy < 0 || iy >= Hi) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 - 1 + kx;
+                if (ix < 0 || ix >= Wi) continue;
+                const unsigned char t = (unsigned char)(ky * 3 + kx);
+                float4 v = *reinterpret_cast<const float4*>(x + ((((size_t)n * Hi + iy) * Wi + ix) * C4 + c) * 4);
+                v.x = fmaxf(__builtin_fmaf(v.x, t0.x, t0.y), lo); v.y = fmaxf(__builtin_fmaf(v.y, t0.z, t0.w), lo);
+                v.z = fmaxf(__builtin_fmaf(v.z, t1.x, t1.y), lo); v.w = fmaxf(__builtin_fmaf(v.w, t1.z, t1.w), lo);
+                if (v.x > m.x) { m.x = v.x; w.x = t; }
+                if (v.y > m.y) { m.y = v.y; w.y = t; }
+                if (v.z > m.z) { m.z = v.z; w.z = t; }
+                if (v.w > m.w) { m.w = v.w; w.w = t; }
+            }
+        }
+        *reinterpret_cast<float4*>(y + i * 4) = m;
+        if (idx) *reinterpret_cast<uchar4*>(idx + i * 4) = w;
+        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(m.x), fabsf(m.y))), fmaxf(fabsf(m.z), fabsf(m.w)));
+    }
+    if (amax) bh_amax_commit(amax, vmax, blockIdx.x, sm_amax);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Two-branch join (round 4): y = relu(bn_a(xa) + bn_b(xb)) - the end of every residual unit whose lower branch ends in its own
 // BatchNorm (ResNet50DeconvBlock / the strided ResNet34ConvBlock, src/backbones/utils.py:60-82,85-112).  Unfused that is
 // bn(xb) -> l (read + write), bn(xa, res = l) -> y (two reads + write): the normalised lower branch is written and read back
@@ -786,6 +848,33 @@ int bh_bn_scratch_doubles(int groups, int C) { return groups * C * 2 * (1 + (BN_
 int bh_bn_stats(const float* x, double* stats, int groups, int rows, int C, int flags, void* stream) {
     if (!x || !stats) return BH_E_BADARG;
     return bn_launch_stats(x, groups, rows, C, stats, bh_stream(stream), (flags & BH_BN_DETERMINISTIC) ? 1 : 0);
+}
+
+int bh_bn_maxpool_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* y,
+                      unsigned char* idx, double* stats, int groups, int N, int Hi, int Wi, int C, float eps, float momentum, int flags,
+                      int use_running, float* amax_y, void* stream) {
+    BnGeom g;
+    if (!x || !y || !stats || N < 1 || groups < 1 || N % groups) return BH_E_BADARG;
+    if (use_running && (!running_mean || !running_var)) return BH_E_BADARG;
+    const int rows = (N / groups) * Hi * Wi;
+    if (!bn_geom(groups, rows, C, g, (flags & BH_BN_DETERMINISTIC) ? 1 : 0) || groups * C * 8 > 32768) return BH_E_UNSUPPORTED;
+    hipStream_t s = bh_stream(stream);
+    if (!use_running && !(flags & 8)) {                       // bit 3: the producer already accumulated the sums
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(g.nchunks, groups), dim3(256), 0, s, x, g, stats);
+        BH_LAUNCH_CHECK();
+    }
+    const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
+    const size_t total = (size_t)N * Ho * Wo * (C / 4);
+    size_t nb = (total + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    nb = (nb * 256 / (C / 4)) * (C / 4) / 256;               // (keeps gridDim * 256 a multiple of C / 4: any value is correct, this is tidy)
+    if (nb < 1) nb = 1;
+    const bool upd = !use_running && running_mean && running_var;
+    hipLaunchKernelGGL(bn_maxpool_fwd_kernel, dim3((unsigned)nb), dim3(256), (size_t)groups * C * 8, s, x, gamma, beta, running_mean, running_var,
+                       stats, y, idx, g, N, Hi, Wi, Ho, Wo, eps, flags & 1, use_running, momentum, upd ? running_mean : nullptr,
+                       upd ? running_var : nullptr, reinterpret_cast<unsigned*>(amax_y));
+    BH_LAUNCH_CHECK();
+    return BH_OK;
 }
 
 int bh_bn_join_scratch_doubles(int groups, int C) { return groups * C * 2 + groups * C * 3 * (BN_MAX_CHUNKS > 256 ? BN_MAX_CHUNKS : 256); }

@@ -902,6 +902,30 @@ def bn_stats(x, stats, groups, C):
     return stats
 
 
+class BnPooled:
+    """A BatchNorm(+ReLU) whose only consumer is MaxPool2d(3, 2, 1), both done by bn_maxpool_fwd: the BatchNorm's output does not exist;
+    `pooled` / `idx` are what the pooling op returns, `shape` the shape the BatchNorm output would have had (for the adjoint)."""
+    __slots__ = ("pooled", "idx", "shape")
+
+    def __init__(self, pooled, idx, shape):
+        self.pooled, self.idx, self.shape = pooled, idx, tuple(shape)
+
+
+def bn_maxpool_fwd(x, gamma, beta, rmean, rvar, groups, eps, momentum, relu, training, stats, stats_ready, want_index=True, amax=None):
+    """x NHWC -> BnPooled(maxpool3s2(act(bn(x))), idx, x.shape) in one pass; stats as in bn_fwd."""
+    _chk(x)
+    N, Hi, Wi, C = x.shape
+    y = torch.empty((N, (Hi - 1) // 2 + 1, (Wi - 1) // 2 + 1, C), dtype=torch.float32, device=x.device)
+    idx = torch.empty(y.shape, dtype=torch.uint8, device=x.device) if want_index else None
+    flags = (1 if relu else 0) | (8 if stats_ready else 0) | (BN_DETERMINISTIC if deterministic() else 0)
+    with _Timed("bn_maxpool_fwd" + (" N%d %dx%d C%d" % (N, Hi, Wi, C) if TIMING_DETAIL else ""), 0.0, 4.0 * (x.numel() + y.numel()) + y.numel()):
+        check(lib.bh_bn_maxpool_fwd(_p(x), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(y), _p(idx), _p(stats), groups, N, Hi, Wi, C,
+                                    float(eps), float(momentum), flags, 0 if training else 1, _p(amax), _stream()), "bh_bn_maxpool_fwd")
+    if amax is not None:
+        y._bh_amax = amax
+    return BnPooled(y, idx, x.shape)
+
+
 class BnJoinPending:
     """The lower-branch BatchNorm of a residual unit whose apply rides in the join (bn_join_fwd): `x` is its INPUT, `stats` its sums."""
     __slots__ = ("x", "stats", "mod")

@@ -448,6 +448,19 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, p
                 lo, _ = K.bn_fwd(res.x, res.mod.weight, res.mod.bias, res.mod.running_mean, res.mod.running_var, None, groups, res.mod.eps,
                                  _momentum(res.mod), False, training, stats=res.stats, stats_ready=True)
                 res = slots[op.res] = lo
+            nxt = prog.ops[i + 1] if i + 1 < len(prog.ops) else None
+            if (res is None and nxt is not None and nxt.kind == "maxpool" and nxt.src == op.dst and src.dim() == 4 and src.shape[0] % groups == 0
+                    and m.num_features % 4 == 0 and m.num_features > 1 and sum(1 for o_ in prog.ops if o_.src == op.dst or o_.res == op.dst) == 1
+                    and os.environ.get("BIHOME_BN_POOL", "1") != "0"):
+                # BatchNorm (+ReLU) -> MaxPool2d(3, 2, 1), its only consumer: one pass, the activation in between is never stored
+                st = arena[bn_off[i]:bn_off[i] + K.bn_stats_doubles(groups, m.num_features)]
+                slots[op.dst] = K.bn_maxpool_fwd(src, m.weight, m.bias, m.running_mean, m.running_var, groups, m.eps, _momentum(m), op.relu,
+                                                 training, st, i in ready, want_index=save, amax=amax_next() if amax_next else None)
+                if training:
+                    m._bh_pending_batches = getattr(m, "_bh_pending_batches", 0) + groups
+                if save:
+                    ctx.stats[i] = st
+                continue
             if i in bn_on_load_1x1 and i in ready and src.shape[0] % groups == 0 and (src.numel() // (m.num_features * groups)) % 128 == 0:
                 lazy = True
             elif i in bn_on_load and i in ready and src.shape[0] % groups == 0:
@@ -482,7 +495,10 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, p
             if save:
                 ctx.stats[i] = ws
         elif op.kind == "maxpool":
-            out, idx = K.maxpool_fwd(src, want_index=save)
+            if isinstance(src, K.BnPooled):               # pooled by the fused BatchNorm kernel already
+                out, idx = src.pooled, src.idx
+            else:
+                out, idx = K.maxpool_fwd(src, want_index=save)
             if save:
                 ctx.stats[i] = idx
         elif op.kind == "gap":
@@ -647,7 +663,7 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
             m = op.mod
             train_w = want_wgrad and m.weight is not None and m.weight.requires_grad
             yb = slots[op.dst]
-            if isinstance(yb, K.BnOnLoad):                # applied on load by its consumer: no output tensor (the mask comes from x)
+            if isinstance(yb, (K.BnOnLoad, K.BnPooled)):  # applied on load by its consumer / fused with the pooling: no output tensor (the mask comes from x)
                 yb = None
             gx, gres = K.bn_bwd(g, yb, x, m.weight, ctx.stats[i], m.running_mean, m.running_var, ctx.groups,
                                 m.eps, op.relu, ctx.training, op.res is not None and ((op.res != 0) or want_input_grad),

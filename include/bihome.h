@@ -407,6 +407,14 @@ int bh_bn_bwd_amax(const float* gy, const float* y, const float* x, const float*
                    int groups, int rows, int C, float eps, int flags, int use_running,
                    const float* running_mean, const float* running_var, float* amax_gx, void* stream);
 
+/* BatchNorm (+ReLU) + MaxPool2d(3, 2, 1) in one pass (round 4: conv1-bn1-relu-maxpool of the backbone stem, Rethinking.py:31-36, and of the
+ * perceptual extractor): x[N,Hi,Wi,C] -> y[N,Ho,Wo,C], idx (one byte per element: window position 0..8 of the first maximum, as
+ * bh_maxpool3s2_fwd; NULL ok).  stats / flags / use_running / momentum / amax_y as in bh_bn_fwd_amax (flags: bit0 relu, bit3 sums ready,
+ * BH_BN_DETERMINISTIC).  The activation between BatchNorm and pooling is never stored: the adjoint is bh_maxpool3s2_bwd followed by bh_bn_bwd
+ * with the mask recomputed from x (flags bit2). */
+int bh_bn_maxpool_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* y,
+                      unsigned char* idx, double* stats, int groups, int N, int Hi, int Wi, int C, float eps, float momentum, int flags,
+                      int use_running, float* amax_y, void* stream);
 /* Two-branch join (round 4): y = act(bn_a(xa) + bn_b(xb)), both BatchNorms in training mode with their own statistics tables (already
  * accumulated: by the producers' epilogues or bh_bn_stats-style passes) - the end of ResNet50DeconvBlock / the strided ResNet34ConvBlock
  * (src/backbones/utils.py:60-82, 85-112) without writing the normalised lower branch.  flags: bit0 relu, BH_BN_DETERMINISTIC.  Running

@@ -998,3 +998,28 @@ def test_batchnorm_on_load_1x1_matches_materialised_batchnorm(K, N, H, Ci, Co, r
             K.conv_wgrad(a, gy, g0, None, d, det_ws=ws)
             K.conv_wgrad(lazy, gy, g1, None, d, det_ws=ws)
             close(g1.cpu(), g0.cpu(), 3e-6)
+
+
+@pytest.mark.parametrize("groups,N,H,C,training", [(2, 4, 16, 64, True), (1, 3, 10, 32, True), (2, 2, 64, 64, False)])
+def test_batchnorm_relu_maxpool_in_one_pass(K, groups, N, H, C, training):
+    """bh_bn_maxpool_fwd (round 4: conv1-bn1-relu-maxpool of the stems) against bh_bn_fwd followed by bh_maxpool3s2_fwd: pooled values, arg-max
+    positions, running statistics; and the adjoint through the saved positions + the BatchNorm backward with the mask recomputed from x
+    equals the unfused adjoint."""
+    g = torch.Generator().manual_seed(H + C)
+    x = (torch.randn(N, H, H, C, generator=g) * 1.2 + 0.1).cuda()
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+    rm0, rv0 = (torch.randn(C, generator=g) * 0.1).cuda(), (torch.rand(C, generator=g) + 0.5).cuda()
+    rm1, rv1 = rm0.clone(), rv0.clone()
+    y, st = K.bn_fwd(x, gamma, beta, rm0, rv0, None, groups, 1e-5, 0.1, True, training)
+    p_ref, i_ref = K.maxpool_fwd(y)
+    st1 = K.bn_stats_buffer(groups, C, "cuda")
+    fused = K.bn_maxpool_fwd(x, gamma, beta, rm1, rv1, groups, 1e-5, 0.1, True, training, st1, False)
+    close(fused.pooled.cpu(), p_ref.cpu(), 2e-6)
+    assert (fused.idx != i_ref).float().mean().item() < 1e-3          # (ties / values within a rounding of each other may pick the other tap)
+    close(rm1.cpu(), rm0.cpu(), 1e-6); close(rv1.cpu(), rv0.cpu(), 1e-6)
+    gp = torch.randn(p_ref.shape, generator=g).cuda()
+    gy_ref = K.maxpool_bwd(i_ref, gp, tuple(y.shape))
+    gy = K.maxpool_bwd(fused.idx, gp, fused.shape)
+    gx_ref, _ = K.bn_bwd(gy_ref, y, x, gamma, st, rm0, rv0, groups, 1e-5, True, training, False, beta=beta, had_res=False)
+    gx, _ = K.bn_bwd(gy, None, x, gamma, st1, rm1, rv1, groups, 1e-5, True, training, False, beta=beta, had_res=False)
+    assert ((gx - gx_ref).norm() / gx_ref.norm()).item() < 2e-3       # (a different tap of a tie moves single elements)
