@@ -441,6 +441,10 @@ def run_zhang_scenario(ref_bb_cls, ref_head_cls, cfg, dtype, batch=4, seed=41, s
     grads_of = ("feature_extractor.layer1.0.weight", "feature_extractor.layer2.1.weight", "feature_extractor.layer3.0.weight",
                 "feature_extractor.layer3.1.weight", "feature_extractor.layer3.1.bias", "resnet34.conv1.weight",
                 "resnet34.layer4.2.conv2.weight", "resnet34.fc.bias")
+    trained_mask = not cfg["MODEL"]["BACKBONE"]["FIX_MASK"]             # round 4: the mask predictor runs and is trained (ContentAware.py:36-50)
+    if trained_mask:
+        grads_of += ("mask_predictor.layer1.0.weight", "mask_predictor.layer3.1.weight", "mask_predictor.layer5.0.weight",
+                     "mask_predictor.layer5.1.weight", "mask_predictor.layer5.1.bias")
     model.train()
     for it in range(steps):
         opt.zero_grad()
@@ -462,6 +466,10 @@ def run_zhang_scenario(ref_bb_cls, ref_head_cls, cfg, dtype, batch=4, seed=41, s
                 out["gradnorm/" + name] = np.float64(g.norm().item())
             out["grad/feature_extractor.layer3.0.weight"] = params["feature_extractor.layer3.0.weight"].grad.double().numpy().copy()
             out["grad/feature_extractor.layer1.0.weight"] = params["feature_extractor.layer1.0.weight"].grad.double().numpy().copy()
+            if trained_mask:
+                out["mask_1_sub"], out["mask_2_csum"] = sub(data["mask_1"], 8), csum(data["mask_2"])
+                out["grad/mask_predictor.layer5.0.weight"] = params["mask_predictor.layer5.0.weight"].grad.double().numpy().copy()
+                out["grad/mask_predictor.layer1.0.weight"] = params["mask_predictor.layer1.0.weight"].grad.double().numpy().copy()
         opt.step()
         sched.step()
         out["loss"].append(loss.item())
@@ -469,7 +477,9 @@ def run_zhang_scenario(ref_bb_cls, ref_head_cls, cfg, dtype, batch=4, seed=41, s
                                                         delta_hat.detach().numpy().reshape(-1, 2), axis=-1))))
     sd = bb.state_dict()
     for k in ("feature_extractor.layer1.1.running_mean", "feature_extractor.layer1.1.running_var", "feature_extractor.layer3.1.running_mean",
-              "feature_extractor.layer3.1.running_var", "feature_extractor.layer3.1.num_batches_tracked", "resnet34.bn1.running_mean"):
+              "feature_extractor.layer3.1.running_var", "feature_extractor.layer3.1.num_batches_tracked", "resnet34.bn1.running_mean") + \
+            (("mask_predictor.layer1.1.running_mean", "mask_predictor.layer5.1.running_mean", "mask_predictor.layer5.1.running_var",
+              "mask_predictor.layer5.1.num_batches_tracked") if trained_mask else ()):
         out["state/" + k] = sd[k].double().numpy().copy()
     model.eval()
     with torch.no_grad():
@@ -601,6 +611,22 @@ def main():
     warnings.filterwarnings("ignore")
     orig_only = "--orig-only" in sys.argv          # regenerate just the supervised "-orig" fixtures
     round2 = [a for a in sys.argv[1:] if a.startswith("--round2")]      # --round2 or --round2=name1,name2
+    if "--round4" in sys.argv:                     # trained masks (FIX_MASK False; plain and with the per-sample max normalisation): zhang_mask*_b4_*.npz
+        import copy
+        ContentAware = importlib.import_module("src.backbones.ContentAware")
+        TripletHead = importlib.import_module("src.heads.TripletHead")
+        for m in (ContentAware, TripletHead):
+            assert os.path.realpath(m.__file__).startswith(os.path.realpath(REF)), m.__file__
+        for name, strength in (("zhang_mask", None), ("zhang_masknorm", 0.5)):
+            cfg = copy.deepcopy(configs.get("zhang-orig"))
+            cfg["MODEL"]["BACKBONE"]["FIX_MASK"] = False
+            if strength is not None:
+                cfg["MODEL"]["BACKBONE"]["MASK_NORMALIZATION_STRENGTH"] = strength
+            for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+                r = run_zhang_scenario(ContentAware.Model, TripletHead.Model, cfg, dtype)
+                np.savez_compressed(os.path.join(outdir, "%s_b4_%s.npz" % (name, tag)), **r)
+                print(name, tag, "loss", r["loss"], "mace", r["mace"])
+        return
     if "--round3" in sys.argv:                     # the Zhang baseline (ContentAware + TripletHead): tests/golden/zhang_orig_b4_{f32,f64}.npz
         ContentAware = importlib.import_module("src.backbones.ContentAware")
         TripletHead = importlib.import_module("src.heads.TripletHead")

@@ -267,14 +267,26 @@ def test_score_weighted_multi_hypothesis_training(golden, base, loss_name):
             np.testing.assert_allclose(dh.numpy(), g["delta_hat_12"], atol=1e-6)
 
 
-def test_zhang_content_aware_triplet_head(golden):
+def _zhang_cfg(fixture):
+    """zhang-orig, and its two trained-mask variants (round 4: FIX_MASK False, plain and with MASK_NORMALIZATION_STRENGTH 0.5)."""
+    import copy
+    cfg = copy.deepcopy(configs.get("zhang-orig"))
+    if fixture != "zhang_orig":
+        cfg["MODEL"]["BACKBONE"]["FIX_MASK"] = False
+    if fixture == "zhang_masknorm":
+        cfg["MODEL"]["BACKBONE"]["MASK_NORMALIZATION_STRENGTH"] = 0.5
+    return cfg
+
+
+@pytest.mark.parametrize("fixture", ["zhang_orig", "zhang_mask", "zhang_masknorm"])
+def test_zhang_content_aware_triplet_head(golden, fixture):
     """Round 3: the Zhang baseline - oracle ContentAwareBackbone + ZhangTripletHead against the fixture made by the reference's own
     src/backbones/ContentAware.py + src/heads/TripletHead.py (oracle/make_golden.py --round3): two Adam steps at B = 4 in float64 -
     losses, MACE, both regressed offsets, the feature maps, gradients of the feature extractor (which runs four times per step: two
     patches in the backbone, two warped patches in the head), the running statistics after the steps (they pin the order of those
     four calls) and the eval-mode prediction."""
-    g = golden("zhang_orig_b4_f64")
-    cfg = configs.get("zhang-orig")
+    g = golden(fixture + "_b4_f64")
+    cfg = _zhang_cfg(fixture)
     bb, head = O.build(cfg)
     load_synthetic(bb, 0)
     bb.double(); head.double()
@@ -287,6 +299,10 @@ def test_zhang_content_aware_triplet_head(golden):
         loss, dgt, dh = head(bb(data))
         loss.backward()
         if it == 0:
+            if "mask_1_sub" in g:          # trained masks: the predictor's output (Sigmoid, per-sample max normalisation) and its gradients
+                np.testing.assert_allclose(data["mask_1"].detach().numpy()[..., ::8, ::8], g["mask_1_sub"], atol=1e-9)
+                m2 = data["mask_2"].detach().numpy().astype(np.float64)
+                np.testing.assert_allclose([m2.sum(), np.abs(m2).sum(), (m2 * m2).sum()], g["mask_2_csum"], rtol=1e-9)
             np.testing.assert_allclose(data["delta_hat_12"].detach().numpy(), g["delta_hat_12"], atol=1e-8)
             np.testing.assert_allclose(data["delta_hat_21"].detach().numpy(), g["delta_hat_21"], atol=1e-8)
             np.testing.assert_allclose(data["feature_1"].detach().numpy()[..., ::8, ::8], g["feature_1_sub"], atol=1e-9)
