@@ -75,6 +75,10 @@ SIGNATURES = {
     "bh_oneline_loss_bwd": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P],
     "bh_zhang_triplet_fwd": [P] * 8 + [c_int, c_int, c_float, c_int, P, P, P, P],
     "bh_zhang_triplet_bwd": [P] * 12 + [c_int, c_int, c_int] + [P] * 6 + [P],
+    "bh_zhang_triplet_bwd_m": [P] * 12 + [c_int, c_int, c_int] + [P] * 8 + [P],
+    "bh_warp_bwd_img_f": [P, P, c_int, c_int, c_int, c_int, P, P, c_int, P],
+    "bh_mask_fwd": [P, P, c_int, c_int, c_float, P, P, P, P, P],
+    "bh_mask_bwd": [P] * 7 + [c_int, c_int, c_float, P, P, P],
     "bh_conv3x3_pack": [P, c_int, P],
     "bh_conv3x3_pack_f16": [P, c_int, P],
     "bh_absmax": [P, c_int64, P, P],
@@ -143,6 +147,8 @@ def _load():
         fn.restype = c_int
     lib.bh_conv_wgrad_det_bytes.argtypes = [POINTER(BhConvDesc)]      # (the one entry point that does not return a status)
     lib.bh_conv_wgrad_det_bytes.restype = c_int64
+    lib.bh_warp_bwd_img_scratch_doubles.argtypes = [c_int, c_int, c_int, c_int, c_int]
+    lib.bh_warp_bwd_img_scratch_doubles.restype = ctypes.c_size_t
     if TUNING:
         lib.bh_debug_force_tile.argtypes = [c_int, c_int]
         lib.bh_debug_force_tile.restype = c_int

@@ -315,7 +315,8 @@ __global__ void __launch_bounds__(256) zhang_triplet_fwd_kernel(const float* __r
 }
 
 // adjoint: g_loss[1] -> g_f1, g_f2, g_f1w, g_f2w (the feature extractor is TRAINABLE here: all four feature maps carry gradients),
-// g_m1w, g_m2w (the warped masks; the unwarped masks m1 / m2 are treated as constants: FIX_MASK).  All overwritten.
+// g_m1w, g_m2w (the warped masks) and - trained masks, round 4 - g_m2 / g_m1 (the unwarped masks: m2 weights line 1, m1 line 2; NULL:
+// constants, FIX_MASK).  All overwritten.
 __global__ void __launch_bounds__(256) zhang_triplet_bwd_kernel(const float* __restrict__ g_loss, const float* __restrict__ f1,
                                                                 const float* __restrict__ f2, const float* __restrict__ f1w,
                                                                 const float* __restrict__ f2w, const float* __restrict__ m1w,
@@ -324,7 +325,8 @@ __global__ void __launch_bounds__(256) zhang_triplet_bwd_kernel(const float* __r
                                                                 const float* __restrict__ T2, const double* __restrict__ numden, int hw,
                                                                 int hinge, float* __restrict__ g_f1, float* __restrict__ g_f2,
                                                                 float* __restrict__ g_f1w, float* __restrict__ g_f2w,
-                                                                float* __restrict__ g_m1w, float* __restrict__ g_m2w) {
+                                                                float* __restrict__ g_m1w, float* __restrict__ g_m2w,
+                                                                float* __restrict__ g_m1, float* __restrict__ g_m2) {
     const int b = blockIdx.y;
     const size_t o = (size_t)b * hw;
     const float g = g_loss[0];
@@ -342,7 +344,9 @@ __global__ void __launch_bounds__(256) zhang_triplet_bwd_kernel(const float* __r
         const float k1 = g * i1 * wa * on1;
         float ga = -k1 * sc, gc = k1 * (sc - sa);
         g_f1w[o + p] = k1 * sa;
-        g_m1w[o + p] = g * v2 * ((hinge ? fmaxf(t1, 0.f) : t1) * i1 - q1);
+        const float e1 = g * ((hinge ? fmaxf(t1, 0.f) : t1) * i1 - q1);      // d loss / d (m1w m2)
+        g_m1w[o + p] = e1 * v2;
+        if (g_m2) g_m2[o + p] = e1 * m1w[o + p];
         if (f2w) {
             const float cw = f2w[o + p];
             const float sb = (float)((cw > a) - (cw < a));           // sign(f2w - f1)
@@ -353,8 +357,10 @@ __global__ void __launch_bounds__(256) zhang_triplet_bwd_kernel(const float* __r
             const float k2 = g * i2 * wb * on2;
             ga += k2 * (-sb - sc); gc += k2 * sc;
             g_f2w[o + p] = k2 * sb;
-            g_m2w[o + p] = g * v1 * ((hinge ? fmaxf(t2, 0.f) : t2) * i2 - q2);
-        }
+            const float e2 = g * ((hinge ? fmaxf(t2, 0.f) : t2) * i2 - q2);
+            g_m2w[o + p] = e2 * v1;
+            if (g_m1) g_m1[o + p] = e2 * m2w[o + p];
+        } else if (g_m1) g_m1[o + p] = 0.f;                                  // (one line: m1 enters only through its warp)
         g_f1[o + p] = ga; g_f2[o + p] = gc;
     }
 }
@@ -375,6 +381,14 @@ int bh_zhang_triplet_fwd(const float* f1, const float* f2, const float* f1w, con
 int bh_zhang_triplet_bwd(const float* g_loss, const float* f1, const float* f2, const float* f1w, const float* f2w, const float* m1w,
                          const float* m2w, const float* m1, const float* m2, const float* T1, const float* T2, const double* numden, int B,
                          int hw, int hinge, float* g_f1, float* g_f2, float* g_f1w, float* g_f2w, float* g_m1w, float* g_m2w, void* stream) {
+    return bh_zhang_triplet_bwd_m(g_loss, f1, f2, f1w, f2w, m1w, m2w, m1, m2, T1, T2, numden, B, hw, hinge, g_f1, g_f2, g_f1w, g_f2w, g_m1w,
+                                  g_m2w, nullptr, nullptr, stream);
+}
+
+int bh_zhang_triplet_bwd_m(const float* g_loss, const float* f1, const float* f2, const float* f1w, const float* f2w, const float* m1w,
+                           const float* m2w, const float* m1, const float* m2, const float* T1, const float* T2, const double* numden, int B,
+                           int hw, int hinge, float* g_f1, float* g_f2, float* g_f1w, float* g_f2w, float* g_m1w, float* g_m2w,
+                           float* g_m1, float* g_m2, void* stream) {
     if (!g_loss || !f1 || !f2 || !f1w || !m1w || !T1 || !numden || !g_f1 || !g_f2 || !g_f1w || !g_m1w ||
         (f2w && (!m2w || !T2 || !g_f2w || !g_m2w)) || B < 0 || hw < 1)
         return BH_E_BADARG;
@@ -382,7 +396,7 @@ int bh_zhang_triplet_bwd(const float* g_loss, const float* f1, const float* f2, 
     int nb = (hw + 1023) / 1024;
     if (nb > 16) nb = 16;
     hipLaunchKernelGGL(zhang_triplet_bwd_kernel, dim3(nb, B), dim3(256), 0, bh_stream(stream), g_loss, f1, f2, f1w, f2w, m1w, m2w, m1, m2, T1,
-                       T2, numden, hw, hinge, g_f1, g_f2, g_f1w, g_f2w, g_m1w, g_m2w);
+                       T2, numden, hw, hinge, g_f1, g_f2, g_f1w, g_f2w, g_m1w, g_m2w, g_m1, g_m2);
     BH_LAUNCH_CHECK();
     return BH_OK;
 }

@@ -372,6 +372,45 @@ __global__ void __launch_bounds__(256) warp_bwd4_kernel(const float* __restrict_
         atomicAdd(gH + (size_t)b * 9 + threadIdx.x, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// adjoint w.r.t. the IMAGE (round 4: the trained masks of the Zhang baseline are warped - src/heads/TripletHead.py:60,69 - and their
+// gradient has to reach the mask predictor): g_img[b,c,tap] += g_out[b,c,y,x] * bilinear weight, the transpose of warp_fwd_kernel's
+// gather with the same taps, weights and validity.  A scatter with float atomics into the caller-zeroed g_img; a deterministic call adds
+// into integer-limb entries (common.h) and a second kernel rounds them to float.  grid (w/16, h/16, B)
+// ---------------------------------------------------------------------------------------------
+template <bool DET>
+__global__ void __launch_bounds__(256) warp_bwd_img_kernel(const double* __restrict__ H64, const float* __restrict__ g_out, int C, int h, int w,
+                                                           float* __restrict__ g_img, double* __restrict__ entries) {
+    const int b = blockIdx.z;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int x = blockIdx.x * 16 + tx, y = blockIdx.y * 16 + ty;
+    float u, v, iz;
+    bool guard;
+    project(H64 + (size_t)b * 9, x, y, u, v, iz, guard);
+    Tap t = make_tap(u, v, w, h);
+    const int x0 = (int)fminf(fmaxf(t.x0f, -2.0f), (float)w), y0 = (int)fminf(fmaxf(t.y0f, -2.0f), (float)h);
+    const float w00 = (1 - t.fx) * (1 - t.fy), w01 = t.fx * (1 - t.fy), w10 = (1 - t.fx) * t.fy, w11 = t.fx * t.fy;
+    const bool v00 = t.vx0 && t.vy0, v01 = t.vx1 && t.vy0, v10 = t.vx0 && t.vy1, v11 = t.vx1 && t.vy1;
+    for (int c = 0; c < C; ++c) {
+        const size_t base = ((size_t)b * C + c) * h * w;
+        const float g = g_out[base + (size_t)y * w + x];
+        if (g == 0.0f) continue;
+        auto add = [&](size_t idx, float val) {
+            if constexpr (DET) bh_det_add(entries + idx * BH_ACC_WORDS, (double)val);
+            else atomicAdd(g_img + idx, val);
+        };
+        if (v00) add(base + (size_t)y0 * w + x0, g * w00);
+        if (v01) add(base + (size_t)y0 * w + x0 + 1, g * w01);
+        if (v10) add(base + (size_t)(y0 + 1) * w + x0, g * w10);
+        if (v11) add(base + (size_t)(y0 + 1) * w + x0 + 1, g * w11);
+    }
+}
+
+__global__ void __launch_bounds__(256) warp_entries_to_float_kernel(const double* __restrict__ entries, size_t n, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (float)bh_acc_read(entries + i * BH_ACC_WORDS, 1);
+}
+
 // rows per thread of the pool = 4 kernels (tuning hook: bh_debug_force_tile(-14 / -15, n))
 BH_KNOB(g_warp_rpt_fwd, 1); BH_KNOB(g_warp_rpt_bwd, 2);       // measured (tools/hbm_path_bench.py): fwd 11.6 / 12.0 us, adjoint 14.7 / 13.4 / 15.4 us
 #ifdef BH_TUNING
@@ -440,6 +479,32 @@ int bh_warp_bwd_f(const float* img, const double* H64, const float* g_out, const
     }
     hipLaunchKernelGGL(warp_bwd_kernel, (flags & BH_F_DETERMINISTIC) ? dim3(1, 1, B) : dim3(w / 16, h / 16, B), dim3(256), 0, bh_stream(stream), img,
                        H64, g_out, g_cov, C, h, w, pool, gH);
+    BH_LAUNCH_CHECK();
+    return BH_OK;
+}
+
+size_t bh_warp_bwd_img_scratch_doubles(int B, int C, int h, int w, int flags) {
+    return (flags & BH_F_DETERMINISTIC) ? (size_t)B * C * h * w * BH_ACC_WORDS : 0;
+}
+
+int bh_warp_bwd_img_f(const double* H64, const float* g_out, int B, int C, int h, int w, float* g_img, double* scratch, int flags,
+                      void* stream) {
+    if (!H64 || !g_out || !g_img || B < 0 || C < 1 || ((flags & BH_F_DETERMINISTIC) && !scratch)) return BH_E_BADARG;
+    if ((h % 16) || (w % 16)) return BH_E_UNSUPPORTED;
+    if (B == 0) return BH_OK;
+    hipStream_t s = bh_stream(stream);
+    const size_t n = (size_t)B * C * h * w;
+    if (flags & BH_F_DETERMINISTIC) {
+        hipError_t e = hipMemsetAsync(scratch, 0, n * BH_ACC_WORDS * sizeof(double), s);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(warp_bwd_img_kernel<true>, dim3(w / 16, h / 16, B), dim3(256), 0, s, H64, g_out, C, h, w, g_img, scratch);
+        BH_LAUNCH_CHECK();
+        hipLaunchKernelGGL(warp_entries_to_float_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scratch, n, g_img);
+    } else {
+        hipError_t e = hipMemsetAsync(g_img, 0, n * sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(warp_bwd_img_kernel<false>, dim3(w / 16, h / 16, B), dim3(256), 0, s, H64, g_out, C, h, w, g_img, scratch);
+    }
     BH_LAUNCH_CHECK();
     return BH_OK;
 }

@@ -322,6 +322,46 @@ def warp_bwd(img, H64, g_out, g_cov, pool=4, gH=None):
     return gH
 
 
+def warp_bwd_img(H64, g_out):
+    """Adjoint of warp_fwd w.r.t. the image (the trained masks of the Zhang baseline, TripletHead.py:60,69): g_out[B,C,h,w] -> g_img."""
+    _chk(H64, torch.float64); _chk(g_out)
+    B, C, h, w = g_out.shape
+    g_img = torch.empty_like(g_out)
+    flags = _fdet()
+    n = lib.bh_warp_bwd_img_scratch_doubles(B, C, h, w, flags)
+    scratch = torch.empty(n, dtype=torch.float64, device=g_out.device) if n else None
+    check(lib.bh_warp_bwd_img_f(_p(H64), _p(g_out), B, C, h, w, _p(g_img), _p(scratch), flags, _stream()), "bh_warp_bwd_img_f")
+    return g_img
+
+
+# ------------------------------------------------------------------------------------------------
+# trained content masks (Zhang baseline, FIX_MASK False)
+# ------------------------------------------------------------------------------------------------
+def mask_fwd(y, f, strength):
+    """y[N,1,h,w] = the mask predictor's last BatchNorm output, f = the features (None: mask only) -> (m, g | None, smax[N], imax[N])
+    (ContentAware.py:24-26,28-35,128-134: Sigmoid, per-sample max normalisation when strength > 0, G = m * f)."""
+    _chk(y); _chk(f)
+    N, P = y.shape[0], y.numel() // y.shape[0]
+    m = torch.empty_like(y)
+    g = torch.empty_like(y) if f is not None else None
+    smax = torch.empty(N, dtype=torch.float32, device=y.device)
+    imax = torch.empty(N, dtype=torch.int32, device=y.device)
+    check(lib.bh_mask_fwd(_p(y), _p(f), N, P, float(strength), _p(m), _p(g), _p(smax), _p(imax), _stream()), "bh_mask_fwd")
+    return m, g, smax, imax
+
+
+def mask_bwd(y, f, m, smax, imax, g_m, g_g, strength, want_gf=True):
+    """-> (g_y, g_f | None); g_m / g_g None = no gradient from that consumer."""
+    for t in (y, f, m, g_m, g_g):
+        _chk(t)
+    N, P = y.shape[0], y.numel() // y.shape[0]
+    g_y = torch.empty_like(y)
+    g_f = torch.empty_like(y) if (want_gf and g_g is not None) else None
+    check(lib.bh_mask_bwd(_p(y), _p(f), _p(m), _p(smax), _p(imax), _p(g_m), _p(g_g), N, P, float(strength), _p(g_y), _p(g_f), _stream()),
+          "bh_mask_bwd")
+    return g_y, g_f
+
+
 # ------------------------------------------------------------------------------------------------
 # triplet
 # ------------------------------------------------------------------------------------------------
@@ -378,17 +418,22 @@ def zhang_triplet_fwd(f1, f2, f1w, f2w, m1w, m2w, margin, hinge, m1=None, m2=Non
     return T1, T2, numden
 
 
-def zhang_triplet_bwd(g_loss, f1, f2, f1w, f2w, m1w, m2w, T1, T2, numden, hinge, m1=None, m2=None):
-    """-> (g_f1, g_f2, g_f1w, g_f2w | None, g_m1w, g_m2w | None), shaped like their tensors."""
+def zhang_triplet_bwd(g_loss, f1, f2, f1w, f2w, m1w, m2w, T1, T2, numden, hinge, m1=None, m2=None, mask_grads=False):
+    """-> (g_f1, g_f2, g_f1w, g_f2w | None, g_m1w, g_m2w | None), shaped like their tensors; mask_grads (trained masks): two more,
+    (g_m1, g_m2) - the gradients of the unwarped masks."""
     _chk(g_loss)
     B, hw = f1.shape[0], f1.numel() // f1.shape[0]
     g_f1, g_f2, g_f1w = torch.empty_like(f1), torch.empty_like(f2), torch.empty_like(f1w)
     g_m1w = torch.empty_like(m1w)
     g_f2w = torch.empty_like(f2w) if f2w is not None else None
     g_m2w = torch.empty_like(m2w) if f2w is not None else None
-    check(lib.bh_zhang_triplet_bwd(_p(g_loss), _p(f1), _p(f2), _p(f1w), _p(f2w), _p(m1w), _p(m2w), _p(m1), _p(m2), _p(T1), _p(T2), _p(numden),
-                                   B, hw, int(bool(hinge)), _p(g_f1), _p(g_f2), _p(g_f1w), _p(g_f2w), _p(g_m1w), _p(g_m2w), _stream()),
-          "bh_zhang_triplet_bwd")
+    g_m1 = torch.empty_like(m1w) if mask_grads else None
+    g_m2 = torch.empty_like(m1w) if mask_grads else None
+    check(lib.bh_zhang_triplet_bwd_m(_p(g_loss), _p(f1), _p(f2), _p(f1w), _p(f2w), _p(m1w), _p(m2w), _p(m1), _p(m2), _p(T1), _p(T2), _p(numden),
+                                     B, hw, int(bool(hinge)), _p(g_f1), _p(g_f2), _p(g_f1w), _p(g_f2w), _p(g_m1w), _p(g_m2w), _p(g_m1), _p(g_m2),
+                                     _stream()), "bh_zhang_triplet_bwd_m")
+    if mask_grads:
+        return g_f1, g_f2, g_f1w, g_f2w, g_m1w, g_m2w, g_m1, g_m2
     return g_f1, g_f2, g_f1w, g_f2w, g_m1w, g_m2w
 
 

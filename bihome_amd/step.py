@@ -128,20 +128,22 @@ def attach_reducer(model, bucket_bytes=8 << 20):
     if backbone._runner is None:
         backbone._runner = backbone._build()
     runners.append(backbone._runner)
-    fe = getattr(backbone, "feature_extractor", None)
-    if fe is not None:
-        if fe._runner is None:
-            from . import net
-            net.to_kernel_layout_(fe)
-            fe._runner = fe._build()
-        runners.append(fe._runner)
+    mp = getattr(backbone, "mask_predictor", None)
+    for sub in (getattr(backbone, "feature_extractor", None), mp if (mp is not None and not mp.fix_mask) else None):
+        if sub is not None:          # (a trained mask predictor, FIX_MASK False, owns a third buffer)
+            if sub._runner is None:
+                from . import net
+                net.to_kernel_layout_(sub)
+                sub._runner = sub._build()
+            runners.append(sub._runner)
     dev = next(backbone.parameters()).device
     reds = []
     for k, r in enumerate(runners):
         if r.flat is None:
             continue
         r.flat.ensure(dev)
-        # (the feature extractor runs twice per step - its gradients are final only after both backward walks: no launches from hooks)
+        # (the feature extractor runs twice per step - its gradients are final only after both backward walks: no launches from hooks;
+        #  the mask predictor's walk is short and late - deferred as well)
         r.reducer = FlatGradReducer(r.flat, bucket_bytes=bucket_bytes, defer=k > 0)
         reds.append(r.reducer)
     broadcast_model(model)

@@ -121,6 +121,12 @@ int bh_warp_bwd(const float* img, const double* H64, const float* g_out, const f
                 int B, int C, int h, int w, int pool, double* gH, void* stream);
 int bh_warp_bwd_f(const float* img, const double* H64, const float* g_out, const float* g_cov,
                   int B, int C, int h, int w, int pool, double* gH, int flags, void* stream);
+/* adjoint w.r.t. the IMAGE (the trained masks of the Zhang baseline are warped, src/heads/TripletHead.py:60,69, and their gradient must
+ * reach the mask predictor): g_out[B,C,h,w] -> g_img[B,C,h,w] (overwritten) = transpose of the bilinear gather with the same taps and
+ * zero padding.  flags & BH_F_DETERMINISTIC: scratch = bh_warp_bwd_img_scratch_doubles(...) doubles (integer-limb entries); else NULL. */
+size_t bh_warp_bwd_img_scratch_doubles(int B, int C, int h, int w, int flags);
+int bh_warp_bwd_img_f(const double* H64, const float* g_out, int B, int C, int h, int w, float* g_img, double* scratch, int flags,
+                      void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * biHomE triplet L1 reduction (triplet_resnet_loss, double-line / l1 / channel-agnostic / str margin:
@@ -176,6 +182,20 @@ int bh_zhang_triplet_fwd(const float* f1, const float* f2, const float* f1w, con
 int bh_zhang_triplet_bwd(const float* g_loss, const float* f1, const float* f2, const float* f1w, const float* f2w, const float* m1w,
                          const float* m2w, const float* m1, const float* m2, const float* T1, const float* T2, const double* numden, int B,
                          int hw, int hinge, float* g_f1, float* g_f2, float* g_f1w, float* g_f2w, float* g_m1w, float* g_m2w, void* stream);
+/* the same adjoint with the gradients of the UNWARPED masks (trained masks, FIX_MASK False: m2 weights line 1, m1 line 2):
+ * g_m1 / g_m2[B,hw] overwritten, NULL = not wanted (bh_zhang_triplet_bwd is this call with both NULL). */
+int bh_zhang_triplet_bwd_m(const float* g_loss, const float* f1, const float* f2, const float* f1w, const float* f2w, const float* m1w,
+                           const float* m2w, const float* m1, const float* m2, const float* T1, const float* T2, const double* numden, int B,
+                           int hw, int hinge, float* g_f1, float* g_f2, float* g_f1w, float* g_f2w, float* g_m1w, float* g_m2w,
+                           float* g_m1, float* g_m2, void* stream);
+/* Trained content masks (src/backbones/ContentAware.py:24-26,28-35,47-50,128-134) after the mask predictor's last BatchNorm y[N,P]
+ * (P = h w pixels of a one-channel map): s = sigmoid(y); strength > 0: m = clamp(s / (max_p s * strength), 0, 1) (per-sample maximum),
+ * else m = s; g = m * f (f, g NULL: the mask only).  smax[N] / imax[N]: the maximum of s and its first pixel (kept for the adjoint).
+ * Adjoint: g_m (gradient of the mask from the head, NULL = none) and g_g (gradient of g from the resnet, NULL = none) -> g_y and g_f
+ * (NULL = not wanted); the maximum's gradient goes to pixel imax (torch: max(1)[0] backward).  One workgroup per sample, no atomics. */
+int bh_mask_fwd(const float* y, const float* f, int N, int P, float strength, float* m, float* g, float* smax, int* imax, void* stream);
+int bh_mask_bwd(const float* y, const float* f, const float* m, const float* smax, const int* imax, const float* g_m, const float* g_g,
+                int N, int P, float strength, float* g_y, float* g_f, void* stream);
 /* y[b,:] = x[b / rep,:] * s[b] over Bn hypotheses of L floats (the score weighting of multihead_resnet_loss,
  * PerceptualHead.py:276-280) and its adjoint (g_x only for rep = 1, may be NULL; g_s[Bn] overwritten). */
 int bh_scale_samples_fwd(const float* x, const float* s, int Bn, long long L, int rep, float* y, void* stream);

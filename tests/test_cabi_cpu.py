@@ -216,7 +216,8 @@ def test_ctypes_structs_mirror_the_header():
 
 def test_zhang_plugins_are_discoverable_and_share_the_reference_state_dict_schema():
     """src.backbones.ContentAware / src.heads.TripletHead (round 3) resolve through the reference's importlib discovery (train.py:675-690)
-    and carry the state-dict keys of the oracle's module tree (which the reference fixture pins); FIX_MASK False is refused loudly."""
+    and carry the state-dict keys of the oracle's module tree (which the reference fixture pins); FIX_MASK False (round 4: built) keeps
+    the same schema and, like every other path, has no CPU form."""
     import importlib
     import torch
     from bihome_amd import configs
@@ -230,9 +231,11 @@ def test_zhang_plugins_are_discoverable_and_share_the_reference_state_dict_schem
     assert set(torch.nn.Sequential(bb, head).state_dict().keys()) == set(model.state_dict().keys())
     for k, v in bb.state_dict().items():
         assert tuple(model[0].state_dict()[k].shape) == tuple(v.shape), k
-    bad = configs.get("zhang-orig")
-    bad["MODEL"]["BACKBONE"]["FIX_MASK"] = False
-    with pytest.raises(NotImplementedError):
-        build_model(bad, "cpu")
-    with pytest.raises(RuntimeError, match="no CPU"):
-        model[0]({"patch_1": torch.zeros(1, 1, 128, 128), "patch_2": torch.zeros(1, 1, 128, 128)})
+    import copy
+    trained = copy.deepcopy(configs.get("zhang-orig"))
+    trained["MODEL"]["BACKBONE"]["FIX_MASK"] = False
+    tm = build_model(trained, "cpu")
+    assert set(tm.state_dict().keys()) == set(model.state_dict().keys())
+    for mdl in (model, tm):
+        with pytest.raises(RuntimeError, match="no CPU"):
+            mdl[0]({"patch_1": torch.zeros(1, 1, 128, 128), "patch_2": torch.zeros(1, 1, 128, 128)})

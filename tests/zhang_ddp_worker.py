@@ -21,7 +21,11 @@ def main():
     from bihome_amd.ddp import shard_range
     from bihome_amd.step import attach_reducer, build_model, build_optimizer
     from bihome_amd.weights import load_synthetic
-    cfg = configs.get("zhang-orig")
+    import copy
+    cfg = copy.deepcopy(configs.get("zhang-orig"))
+    trained_masks = len(sys.argv) > 3 and sys.argv[3] == "trained-masks"       # FIX_MASK False: the mask predictor is a third conv stack
+    if trained_masks:
+        cfg["MODEL"]["BACKBONE"]["FIX_MASK"] = False
     model = build_model(cfg, "cuda")
     load_synthetic(model[0], rank)                          # replicas start DIFFERENT: attach_reducer broadcasts rank 0's
     opt, sched = build_optimizer(model, cfg["SOLVER"])
@@ -35,9 +39,10 @@ def main():
     loss.backward()
     red.allreduce()
     torch.cuda.synchronize()
+    extra = {"predictor": model[0].mask_predictor._runner.flat.flat.detach().cpu().numpy()} if trained_masks else {}
     np.savez(out + ".rank%d.npz" % rank, resnet=model[0]._runner.flat.flat.detach().cpu().numpy(),
              extractor=model[0].feature_extractor._runner.flat.flat.detach().cpu().numpy(), loss=loss.item(),
-             n_reducers=len(getattr(red, "reducers", [red])))
+             n_reducers=len(getattr(red, "reducers", [red])), **extra)
     dist.barrier()
     dist.destroy_process_group()
 
