@@ -25,7 +25,12 @@ def det():
 
 def _three_steps(cfg_name, B=8, capturable=False, graph=False, steps=3):
     from bihome_amd.step import build_model, build_optimizer, train_step
-    cfg = configs.get(cfg_name)
+    if cfg_name == "zhang-orig-trained-masks":              # round 4: FIX_MASK False with the per-sample max normalisation
+        import copy
+        cfg = copy.deepcopy(configs.get("zhang-orig"))
+        cfg["MODEL"]["BACKBONE"].update(FIX_MASK=False, MASK_NORMALIZATION_STRENGTH=0.5)
+    else:
+        cfg = configs.get(cfg_name)
     model = build_model(cfg)
     load_synthetic(model[0], 0)
     if hasattr(model[1], "auxiliary_resnet"):
@@ -54,7 +59,7 @@ def _three_steps(cfg_name, B=8, capturable=False, graph=False, steps=3):
     return losses, params
 
 
-@pytest.mark.parametrize("cfg_name", ["zeng-bihome", "detone-bihome"])
+@pytest.mark.parametrize("cfg_name", ["zeng-bihome", "detone-bihome", "zhang-orig", "zhang-orig-trained-masks"])
 def test_three_steps_are_bitwise_repeatable(det, cfg_name):
     l0, p0 = _three_steps(cfg_name)
     l1, p1 = _three_steps(cfg_name)
