@@ -860,7 +860,7 @@ __global__ void __launch_bounds__(256, X3 ? ((BN == 32 && NP == 2 && !BNI) ? C3_
 }
 
 constexpr int C3_MIN_BLOCKS = 256;      // below this many workgroups the generic kernel's finer tiles fill the chip better
-BH_KNOB(g_c3_noload, 0); BH_KNOB(g_c3_dbg_nch, -1); BH_KNOB(g_c3_subt, 2); BH_KNOB(g_c3_tpb, 2); BH_KNOB(g_c3_stamp, 0); BH_KNOB(g_c3_desync, 0);
+BH_KNOB(g_c3_noload, 0); BH_KNOB(g_c3_dbg_nch, -1); BH_KNOB(g_c3_subt, 2); BH_KNOB(g_c3_tpb, 2); BH_KNOB(g_c3_stamp, 0); BH_KNOB(g_c3_desync, 0); BH_KNOB(g_c3_walk32, 1);
 #ifdef BH_TUNING
 // copies the phase time stamps of the last instrumented launch to the host (n entries of 8 x u64)
 extern "C" int bh_debug_read_c3_stamps(unsigned long long* out, int n) {
@@ -871,6 +871,7 @@ void bh_conv3x3_tune(int disable, int min_blocks) {
     (void)min_blocks;
     if (disable == 70 || disable == 71) { g_c3_stamp = disable - 70; return; }        // phase time stamps off / on
     if (disable >= 200 && disable < 264) { g_c3_desync = disable - 200; return; }
+    if (disable == 300 || disable == 301) { g_c3_walk32 = disable - 300; return; }         // (-43, 0|1): several positions per workgroup in the 32-channel launches without statistics off / on
     if (disable <= -100) { g_c3_dbg_nch = -100 - disable - 1; return; }            // -100 -> -1 (all), -101 -> 0 chunks, -102 -> 1 ...
     if (disable >= 60 && disable < 68) { g_c3_noload = disable - 60; return; }
     if (disable >= 20 && disable < 24) { g_c3_tpb = disable - 20; return; }        // tile positions per workgroup on two-round launches (1 / 2)
@@ -954,6 +955,15 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
             if (t != a.tpb) { a.tpb = t; grid.x = (a.gx_total + t - 1) / t; }
             a.stat_acc = 1;
         }
+    }
+    if (x3 && !map4 && bn_tile == 32 && a.tpb == 1 && !bn_sums && g_c3_walk32 && !(d->route & BH_ROUTE_C3_ONE_POSITION)) {
+        // 32-channel split-operand launches without statistics (the full-resolution dgrad, the 64 x 64 decoder layers): several tile
+        // positions per workgroup as well - ~1024 workgroups instead of 4-16 thousand: 252 -> 223 us at 128 x 128, 63 -> 60.5 us at
+        // 64 x 64 (tools/c3_walk32.py; requesting the next position's halo under the current position's taps on top of it LOSES 5 %:
+        // profiles/r04_c3_f16_ablation.txt (h))
+        int t = 1;
+        while (a.gx_total % (t * 2) == 0 && (long long)(a.gx_total / (t * 2)) * grid.y >= 1024 && t < 64) t *= 2;
+        if (t > 1) { a.tpb = t; grid.x = a.gx_total / t; }
     }
     if (!(d->route & BH_ROUTE_HALO_SMALL) && (int)((map4 ? a.subtiles : (a.subtiles + 1) / 2) * grid.y) < (map4 ? C3_MIN_BLOCKS / 2 : C3_MIN_BLOCKS))
         return d->w_layout ? BH_E_UNSUPPORTED : 0;
