@@ -956,13 +956,15 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
             a.stat_acc = 1;
         }
     }
-    if (x3 && !map4 && bn_tile == 32 && a.tpb == 1 && !bn_sums && g_c3_walk32 && !(d->route & BH_ROUTE_C3_ONE_POSITION)) {
-        // 32-channel split-operand launches without statistics (the full-resolution dgrad, the 64 x 64 decoder layers): several tile
-        // positions per workgroup as well - ~1024 workgroups instead of 4-16 thousand: 252 -> 223 us at 128 x 128, 63 -> 60.5 us at
-        // 64 x 64 (tools/c3_walk32.py; requesting the next position's halo under the current position's taps on top of it LOSES 5 %:
-        // profiles/r04_c3_f16_ablation.txt (h))
+    if (x3 && !map4 && a.tpb == 1 && !bn_sums && g_c3_walk32 && !(d->route & BH_ROUTE_C3_ONE_POSITION)) {
+        // split-operand launches without statistics (the dgrads of the big layers): several tile positions per workgroup as well - down to
+        // ~1024 workgroups with the 32-channel tile (from 4-16 thousand: 252 -> 223 us at 128 x 128 x 32, 63 -> 60.5 us at 64 x 64 x 32),
+        // ~512 with the 64-channel tile (142 -> 128 us at 64 x 64 x 64, 117 -> 111 us at 32 x 32 x 128, nothing at 16 x 16 x 256);
+        // tools/c3_walk32.py, profiles/r04_c3_f16_ablation.txt (h).  (Requesting the next position's halo under the current
+        // position's taps on top of the walk LOSES 5 %: same record.)
+        const long long target = bn_tile == 32 ? 1024 : 512;
         int t = 1;
-        while (a.gx_total % (t * 2) == 0 && (long long)(a.gx_total / (t * 2)) * grid.y >= 1024 && t < 64) t *= 2;
+        while (a.gx_total % (t * 2) == 0 && (long long)(a.gx_total / (t * 2)) * grid.y >= target && t < 64) t *= 2;
         if (t > 1) { a.tpb = t; grid.x = a.gx_total / t; }
     }
     if (!(d->route & BH_ROUTE_HALO_SMALL) && (int)((map4 ? a.subtiles : (a.subtiles + 1) / 2) * grid.y) < (map4 ? C3_MIN_BLOCKS / 2 : C3_MIN_BLOCKS))
