@@ -950,7 +950,7 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
         // workgroup (all inside one group) and adding their column sums in registers
         const int ppg = a.subtiles / (subt * groups);            // tile positions per statistics group
         int t = a.tpb;
-        const long long wtarget = (x3 && bn_tile == 64) ? 512 : 2048;    // workgroups of the launch (all groups, all N tiles)
+        const long long wtarget = (x3 && bn_tile == 64) ? 512 : (x3 ? 1024 : 2048);    // workgroups of the launch (all groups, all N tiles)
         while (ppg % (t * 2) == 0 && (ppg / t > 1024 || (long long)(ppg / t) * groups * grid.y > wtarget) && t < 64) t *= 2;
         if (ppg % t == 0 && (t > 1 || a.tpb == 1)) {
             if (t != a.tpb) { a.tpb = t; grid.x = (a.gx_total + t - 1) / t; }
