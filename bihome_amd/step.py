@@ -20,6 +20,42 @@ def build_model(cfg, device="cuda"):
     return model
 
 
+class _FlatAdam(torch.optim.Adam):
+    """torch's Adam (train.py:703-707) over the FLAT parameter buffers of the conv stacks (net.FlatGrads.ensure_params) plus whatever
+    parameters live outside them: the same element-wise update, one tensor per conv stack instead of ~170 (265 -> 86 us per step on the
+    Zeng backbone, tools/adam_flat_ab.py).  `zero_grad` zeroes the flat gradient buffers in place - the parameters keep the `.grad` views
+    the weight-gradient kernels write through."""
+
+    def __init__(self, flats, rest, **kw):
+        self._flats = flats                                # [(net.FlatGrads, flat nn.Parameter)]
+        self._rest = rest
+        super().__init__([fp for _, fp in flats] + rest, **kw)
+
+    def _sync(self):
+        for fg, fp in self._flats:
+            pf = fg.ensure_params(fp.device)
+            if pf.data_ptr() != fp.data_ptr():             # re-flattened (model.to(), a replaced p.data): Adam's moments stay, the handle moves
+                fp.data = pf
+            g = fg.attach(fp.device)
+            if fp.grad is None or fp.grad.data_ptr() != g.data_ptr():
+                fp.grad = g
+
+    def step(self, closure=None):
+        self._sync()
+        return super().step(closure)
+
+    def zero_grad(self, set_to_none=True):
+        for fg, fp in self._flats:
+            if fg.flat is not None:
+                fg.attach(fp.device).zero_()
+        for p in self._rest:
+            if p.grad is not None:
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.zero_()
+
+
 def build_optimizer(model, solver, capturable=False):
     """capturable: Adam state (step counter, lr) lives on the device so that the update can be captured in a HIP graph
     (bihome_amd.graph.GraphedStep)."""
@@ -32,8 +68,22 @@ def build_optimizer(model, solver, capturable=False):
     if capturable:
         kw["capturable"] = True
         lr = torch.tensor(float(lr), device=params[0].device)
-    opt = torch.optim.Adam(params, lr=lr, betas=(solver["MOMENTUM_1"], solver["MOMENTUM_2"]),
-                           weight_decay=float(solver.get("L2_WEIGHT_DECAY", 0)), **kw)
+    adam_kw = dict(lr=lr, betas=(solver["MOMENTUM_1"], solver["MOMENTUM_2"]), weight_decay=float(solver.get("L2_WEIGHT_DECAY", 0)), **kw)
+    if fused and os.environ.get("BIHOME_FLAT_ADAM", "1") != "0":
+        from . import net
+        flats, taken = [], set()
+        for r in net.trainable_runners(model):
+            dev = r.flat.params[0].device
+            r.flat.ensure(dev)
+            fp = torch.nn.Parameter(r.flat.ensure_params(dev), requires_grad=True)
+            fp.grad = r.flat.attach(dev)
+            flats.append((r.flat, fp))
+            taken.update(id(p) for p in r.flat.params)
+        if flats:
+            opt = _FlatAdam(flats, [p for p in params if id(p) not in taken and p.requires_grad], **adam_kw)
+            sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=solver["MILESTONES"], gamma=solver["LR_DECAY"])
+            return opt, sched
+    opt = torch.optim.Adam(params, **adam_kw)
     sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=solver["MILESTONES"], gamma=solver["LR_DECAY"])
     return opt, sched
 

@@ -298,3 +298,65 @@ def test_graph_replays_keep_the_stem_table_a_captured_graph_reads():
     # an eager step after the replays rebuilds the (dirty) table into the SAME storage
     train_step(model, dict(data), opt, None)
     assert K._STEM_WT[key][1].data_ptr() == ptr and key not in K._STEM_WT_DIRTY and torch.equal(K._STEM_WT[key][1], table)
+
+
+def test_flat_parameter_adam_equals_per_tensor_adam_and_survives_replaced_parameters(monkeypatch):
+    """Round 4: step.build_optimizer hands torch's fused Adam ONE flat tensor per conv stack (net.FlatGrads.ensure_params: the parameters
+    become views into it) instead of ~170 tensors.  Claims: (1) three training steps give bit-identical parameters and losses with and
+    without it (the update is element-wise either way); (2) state_dict / load_state_dict see the same parameters; (3) a parameter whose
+    `.data` is REPLACED after the optimizer was built (a loader, `model.to()`) is folded back into the flat buffer at the next step and the
+    new values are the ones that train."""
+    from bihome_amd.step import build_model, build_optimizer, train_step
+    cfg = configs.get("zeng-bihome")
+    d = synth.make_pairs(4, seed=21)
+    g = torch.Generator().manual_seed(3)
+    ch = [torch.randint(1, 128 * 128, (4, 128), generator=g).cuda() for _ in range(2)]
+
+    def batch():
+        b = {k: torch.tensor(d[k]).cuda() for k in ("patch_1", "patch_2", "delta")}
+        b["choice_12"], b["choice_21"] = ch
+        return b
+
+    def run(flat, replace_at=None):
+        monkeypatch.setenv("BIHOME_FLAT_ADAM", "1" if flat else "0")
+        model = build_model(cfg)
+        load_synthetic(model[0], 0); load_synthetic(model[1].auxiliary_resnet, 0)
+        opt, sched = build_optimizer(model, cfg["SOLVER"])
+        assert (type(opt).__name__ == "_FlatAdam") == flat
+        losses = []
+        for it in range(3):
+            if replace_at == it:
+                w = model[0].layer1[0].weight if hasattr(model[0], "layer1") else next(model[0].parameters())
+                first = next(p for p in model[0].parameters() if p.dim() == 4)
+                first.data = (first.data * 0.5).contiguous(memory_format=torch.channels_last)      # a NEW tensor behind the parameter
+            losses.append(train_step(model, batch(), opt, sched)[0].item())
+        torch.cuda.synchronize()
+        return losses, {k: v.detach().clone() for k, v in model[0].state_dict().items()}, model, opt
+
+    from bihome_amd import kernels as K
+    prev = K.set_deterministic(True)                         # (bit-identical runs need order-independent gradient sums)
+    try:
+        _flat_adam_claims(run)
+    finally:
+        K.set_deterministic(prev)
+
+
+def _flat_adam_claims(run):
+    l_ref, p_ref, _, _ = run(False)
+    l_again, p_again, _, _ = run(False)
+    assert l_ref == l_again and not [k for k in p_ref if not torch.equal(p_ref[k], p_again[k])]      # the baseline itself repeats
+    l_flat, p_flat, model, opt = run(True)
+    assert l_ref == l_flat, (l_ref, l_flat)
+    assert not [k for k in p_ref if not torch.equal(p_ref[k], p_flat[k])]
+    # every trainable parameter of the backbone is a view into the flat buffer the optimizer owns
+    fg, fp = opt._flats[0]
+    lo, hi = fp.data_ptr(), fp.data_ptr() + fp.numel() * 4
+    assert all(lo <= p.data_ptr() < hi for p in model[0].parameters() if p.requires_grad)
+    sd = {k: v.clone() for k, v in model[0].state_dict().items()}
+    model[0].load_state_dict(sd)                             # in place: still views
+    assert all(lo <= p.data_ptr() < hi for p in model[0].parameters() if p.requires_grad)
+    # a replaced parameter: the per-tensor optimizer and the flat one agree again
+    l_ref2, p_ref2, _, _ = run(False, replace_at=1)
+    l_flat2, p_flat2, _, _ = run(True, replace_at=1)
+    assert l_ref2 == l_flat2 and l_ref2[1:] != l_ref[1:], (l_ref2, l_flat2, l_ref)
+    assert not [k for k in p_ref2 if not torch.equal(p_ref2[k], p_flat2[k])]
