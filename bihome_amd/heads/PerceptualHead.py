@@ -232,12 +232,9 @@ class _BiHomELoss(torch.autograd.Function):
         h = patches.shape[-1]
         g = g_loss.reshape(1).to(torch.float32).contiguous()
         fw = featw.detach()
-        gf1w, gf2w, gm1w, gm2w, gH1, gH2 = K.bihome_loss_bwd(g, feat[:B], feat[B:], fw[:B], fw[B:], cov[:B], cov[B:], None,
-                                                             None, M1, M2, numden, H64[:B], H64[B:], head.triplet_mu)
-        gfeatw = torch.cat([gf1w, gf2w], 0)
+        gfeatw, gcov, gH = K.bihome_loss_bwd(g, feat[:B], feat[B:], fw[:B], fw[B:], cov[:B], cov[B:], None, None, M1, M2, numden,
+                                             H64[:B], H64[B:], head.triplet_mu, joined=True)      # (both directions in one tensor each)
         (gwarp,) = torch.autograd.grad(featw, wl, gfeatw)        # extractor dgrad (one NetFunction node)
-        gcov = torch.cat([gm1w, gm2w], 0)
-        gH = torch.cat([gH1, gH2], 0)
         K.warp_bwd(patches, H64, gwarp.contiguous(), gcov, ctx.pool, gH=gH)
         gdelta = K.h4pt_bwd(delta, H64, gH, h)
         return gdelta, None, None

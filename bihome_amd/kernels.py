@@ -445,17 +445,21 @@ def bihome_loss_fwd(numden, H1, H2, mu):
     return loss4
 
 
-def bihome_loss_bwd(g_loss, f1, f2, f1w, f2w, m1w, m2w, m1, m2, M1, M2, numden, H1, H2, mu):
+def bihome_loss_bwd(g_loss, f1, f2, f1w, f2w, m1w, m2w, m1, m2, M1, M2, numden, H1, H2, mu, joined=False):
+    """joined: the two directions' outputs are the halves of ONE [2B, ...] tensor each and (g_fw, g_mw, gH) are returned whole (the
+    caller's extractor / warp adjoints take both directions in one call: no torch.cat of 33 MB)."""
     _chk(g_loss)
     B, hf, wf, C = f1.shape
-    g_f1w, g_f2w = torch.empty_like(f1w), torch.empty_like(f2w)
-    g_m1w, g_m2w = torch.empty_like(m1w), torch.empty_like(m2w)
-    gH1 = torch.empty(B, 9, dtype=torch.float64, device=f1.device)
-    gH2 = torch.empty_like(gH1)
+    g_fw = torch.empty((2 * B,) + tuple(f1w.shape[1:]), dtype=torch.float32, device=f1.device)
+    g_mw = torch.empty((2 * B,) + tuple(m1w.shape[1:]), dtype=torch.float32, device=f1.device)
+    gH = torch.empty(2 * B, 9, dtype=torch.float64, device=f1.device)
+    g_f1w, g_f2w, g_m1w, g_m2w, gH1, gH2 = g_fw[:B], g_fw[B:], g_mw[:B], g_mw[B:], gH[:B], gH[B:]
     with _Timed("triplet_bwd_kernel", 0.0, 4.0 * (6 * f1.numel() + 6 * M1.numel())):      # 4 feature maps in, 2 gradients out
         check(lib.bh_bihome_loss_bwd(_p(g_loss), _p(f1), _p(f2), _p(f1w), _p(f2w), _p(m1w), _p(m2w), _p(m1), _p(m2), _p(M1),
                                      _p(M2), _p(numden), _p(H1), _p(H2), B, hf * wf, C, float(mu), _p(g_f1w), _p(g_f2w),
                                      _p(g_m1w), _p(g_m2w), _p(gH1), _p(gH2), _stream()), "bh_bihome_loss_bwd")
+    if joined:
+        return g_fw, g_mw, gH
     return g_f1w, g_f2w, g_m1w, g_m2w, gH1, gH2
 
 
