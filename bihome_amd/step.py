@@ -26,10 +26,80 @@ class _FlatAdam(torch.optim.Adam):
     Zeng backbone, tools/adam_flat_ab.py).  `zero_grad` zeroes the flat gradient buffers in place - the parameters keep the `.grad` views
     the weight-gradient kernels write through."""
 
-    def __init__(self, flats, rest, **kw):
+    def __init__(self, flats, rest, all_params=None, **kw):
         self._flats = flats                                # [(net.FlatGrads, flat nn.Parameter)]
         self._rest = rest
+        self._all = list(all_params) if all_params is not None else None     # model.parameters() in order: the checkpoint layout
         super().__init__([fp for _, fp in flats] + rest, **kw)
+
+    # ---- checkpoints in the REFERENCE's layout ------------------------------------------------------------------------------
+    # src/utils/checkpoint.py:31-53 saves optimizer.state_dict() of torch.optim.Adam(model.parameters()) (train.py:703-707): one
+    # state entry per parameter of the model, indexed in model.parameters() order.  state_dict() presents exactly that (the moments
+    # of a flat buffer cut into per-parameter tensors), load_state_dict() takes it (or this class's own flat form) - so a checkpoint
+    # written by the reference's trainer resumes here and one written here resumes there.
+    def _where(self):
+        loc = {}
+        for g, (fg, _) in enumerate(self._flats):
+            for j, p in enumerate(fg.params):
+                loc[id(p)] = (g, j)
+        return loc
+
+    def state_dict(self):
+        if self._all is None:
+            return super().state_dict()
+        loc, state = self._where(), {}
+        moments = []
+        for fg, fp in self._flats:
+            st = self.state.get(fp, {})
+            moments.append({k: (fg._views_of(v) if (torch.is_tensor(v) and v.numel() == fp.numel() and k != "step") else v) for k, v in st.items()})
+        for i, p in enumerate(self._all):
+            if id(p) in loc:
+                g, j = loc[id(p)]
+                if moments[g]:
+                    state[i] = {k: (v[j].clone() if isinstance(v, list) else (v.clone() if torch.is_tensor(v) else v)) for k, v in moments[g].items()}
+            elif p in self.state and self.state[p]:
+                state[i] = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.state[p].items()}
+        group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        group["params"] = list(range(len(self._all)))
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        n_own = sum(len(g["params"]) for g in self.param_groups)
+        n_in = sum(len(g["params"]) for g in sd["param_groups"])
+        if self._all is None or (n_in == n_own and n_in != len(self._all)):
+            return super().load_state_dict(sd)            # this class's own flat form
+        if n_in != len(self._all):
+            raise ValueError("optimizer checkpoint holds %d parameters, the model has %d" % (n_in, len(self._all)))
+        loc = self._where()
+        for k, v in sd["param_groups"][0].items():
+            if k != "params" and k in self.param_groups[0]:
+                self.param_groups[0][k] = v if not torch.is_tensor(self.param_groups[0][k]) else self.param_groups[0][k].copy_(torch.as_tensor(v))
+        self._sync()
+        index = {pid: i for i, pid in enumerate(sd["param_groups"][0]["params"])}
+        byid = {i: sd["state"].get(pid, sd["state"].get(str(pid))) for pid, i in index.items()}
+        with torch.no_grad():
+            for g, (fg, fp) in enumerate(self._flats):
+                st = self.state[fp]
+                entries = [(j, byid.get(i)) for i, p in enumerate(self._all) if id(p) in loc and loc[id(p)][0] == g for j in [loc[id(p)][1]]]
+                have = [e for _, e in entries if e]
+                if not have:
+                    st.clear()
+                    continue
+                step = torch.as_tensor(have[0]["step"], dtype=torch.float32).detach().clone()     # (never alias the checkpoint's tensor)
+                cap = self.param_groups[0].get("capturable") or self.param_groups[0].get("fused")
+                st["step"] = step.to(fp.device) if cap else step.cpu()
+                for key in [k for k in have[0] if k != "step"]:
+                    flat = torch.zeros_like(fp.data)
+                    views = fg._views_of(flat)
+                    for j, e in entries:
+                        if e and key in e:
+                            views[j].copy_(e[key])
+                    st[key] = flat
+            rest_ids = {id(q) for q in self._rest}
+            for i, p in enumerate(self._all):
+                if id(p) not in loc and id(p) in rest_ids and byid.get(i):
+                    self.state[p] = {k: (v.detach().clone().to(p.device if k != "step" else v.device) if torch.is_tensor(v) else v)
+                                     for k, v in byid[i].items()}
 
     def _sync(self):
         for fg, fp in self._flats:
@@ -80,7 +150,7 @@ def build_optimizer(model, solver, capturable=False):
             flats.append((r.flat, fp))
             taken.update(id(p) for p in r.flat.params)
         if flats:
-            opt = _FlatAdam(flats, [p for p in params if id(p) not in taken and p.requires_grad], **adam_kw)
+            opt = _FlatAdam(flats, [p for p in params if id(p) not in taken and p.requires_grad], all_params=params, **adam_kw)
             sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=solver["MILESTONES"], gamma=solver["LR_DECAY"])
             return opt, sched
     opt = torch.optim.Adam(params, **adam_kw)

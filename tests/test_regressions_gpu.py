@@ -360,3 +360,61 @@ def _flat_adam_claims(run):
     l_flat2, p_flat2, _, _ = run(True, replace_at=1)
     assert l_ref2 == l_flat2 and l_ref2[1:] != l_ref[1:], (l_ref2, l_flat2, l_ref)
     assert not [k for k in p_ref2 if not torch.equal(p_ref2[k], p_flat2[k])]
+
+
+def test_flat_adam_checkpoints_in_the_reference_layout(monkeypatch):
+    """The flat-buffer optimizer reads and writes optimizer checkpoints in the layout of torch.optim.Adam(model.parameters()) - what the
+    reference's CheckPointer saves (src/utils/checkpoint.py:31-53, train.py:703-707): two steps with the per-tensor optimizer, its
+    state_dict() loaded into a flat-buffer optimizer over a copy of the model, the third step equal bit for bit; and back: the flat
+    optimizer's state_dict() has one entry per model parameter and resumes a plain torch Adam to the same fourth step."""
+    from bihome_amd import kernels as K
+    from bihome_amd.step import build_model, build_optimizer, train_step
+    cfg = configs.get("zeng-bihome")
+    d = synth.make_pairs(4, seed=23)
+    g = torch.Generator().manual_seed(4)
+    ch = [torch.randint(1, 128 * 128, (4, 128), generator=g).cuda() for _ in range(2)]
+
+    def batch():
+        b = {k: torch.tensor(d[k]).cuda() for k in ("patch_1", "patch_2", "delta")}
+        b["choice_12"], b["choice_21"] = ch
+        return b
+
+    def make(flat, model_state=None):
+        monkeypatch.setenv("BIHOME_FLAT_ADAM", "1" if flat else "0")
+        model = build_model(cfg)
+        load_synthetic(model[0], 0); load_synthetic(model[1].auxiliary_resnet, 0)
+        if model_state is not None:
+            model.load_state_dict(model_state)
+        opt, sched = build_optimizer(model, cfg["SOLVER"])
+        return model, opt, sched
+
+    prev = K.set_deterministic(True)
+    try:
+        ma, oa, sa = make(False)
+        for _ in range(2):
+            train_step(ma, batch(), oa, sa)
+        msd = {k: v.clone() for k, v in ma.state_dict().items()}
+        osd = oa.state_dict()
+        n_params = len(list(ma.parameters()))
+        assert len(osd["param_groups"][0]["params"]) == n_params
+        mb, ob, sb = make(True, msd)
+        ob.load_state_dict(osd)
+        la = train_step(ma, batch(), oa, sa)[0].item()
+        lb = train_step(mb, batch(), ob, sb)[0].item()
+        assert la == lb, (la, lb)
+        pa, pb = ma[0].state_dict(), mb[0].state_dict()
+        assert not [k for k in pa if not torch.equal(pa[k], pb[k])]
+        # and back: one entry per model parameter, tensors shaped like the parameters
+        fsd = ob.state_dict()
+        assert len(fsd["param_groups"][0]["params"]) == n_params and set(fsd["state"]) == set(oa.state_dict()["state"])
+        some = next(i for i, p in enumerate(mb.parameters()) if p.dim() == 4 and i in fsd["state"])
+        assert tuple(fsd["state"][some]["exp_avg"].shape) == tuple(list(mb.parameters())[some].shape)
+        mc, oc, sc = make(False, {k: v.clone() for k, v in mb.state_dict().items()})
+        oc.load_state_dict(fsd)
+        lb2 = train_step(mb, batch(), ob, sb)[0].item()
+        lc = train_step(mc, batch(), oc, sc)[0].item()
+        assert lb2 == lc, (lb2, lc)
+        pb, pc = mb[0].state_dict(), mc[0].state_dict()
+        assert not [k for k in pb if not torch.equal(pb[k], pc[k])]
+    finally:
+        K.set_deterministic(prev)
