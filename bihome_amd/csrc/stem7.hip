@@ -166,3 +166,100 @@ int bh_stem7_try(const float* x, const float* w, const float* bias, float* y, co
     *taken = 1;
     return BH_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// dgrad of the ONE-input-channel 7x7 / 2 stem (the frozen extractor's conv1 on a warped patch, PerceptualHead.py:52-55,377,398: the
+// gradient has to reach the homography through the image) in one kernel (round 4).  It used to be a 1x1 GEMM gy x w^T into a per-pixel tap
+// table (109 MB written and read back) + a col2im pass: 73 + 129 us.  Here a workgroup OWNS a 16 x 16 tile of the image: it stages the
+// 11 x 11 gy pixels that reach it (x 64 channels) in LDS, multiplies them with the 64 x 49 filter bank (v_mfma_f32_32x32x2_f32: wave m =
+// 32 of the 121 -> 128 pixels x 2 x 32 taps, K = 64 channels), leaves the 121 x 49 tap table in LDS (over the staged gy) and every thread
+// sums the <= 16 taps of its image pixel.  No atomics (a first form that scattered 8 x 8 gy tiles into the image with float atomics spent
+// its time in 3.6 M device-scope atomics: 182 us), 1.9x the GEMM work of the two-pass form and none of its 218 MB.  The same sums in another order
+// than the two-pass form; deterministic by construction.  gy [N][Ho][Wo][64] NHWC, w [64][7][7][1], gx [N][1][2 Ho][2 Wo].
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) stem7_dgrad_c1_kernel(const float* __restrict__ gy, const float* __restrict__ w, float* __restrict__ gx,
+                                                             int Ho, int Wo, int tiles_x, int tiles_per_img, int ntiles) {
+    constexpr int GP = 68;                               // row pitch of the gy tile in LDS (floats): 16-byte rows for the staging stores
+    constexpr int TP = 53;                               // row pitch of the tap table (49 used)
+    __shared__ float Wt[64 * 64];                        // [k = channel][n = tap, 49 used]
+    __shared__ __attribute__((aligned(16))) float gt[128 * GP];   // [gy pixel of the 11 x 11 window, 121 used][channel]; then the tap table [121][TP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh2 = lane >> 5;
+    for (int i = tid; i < 64 * 64; i += 256) {
+        const int k = i >> 6, n = i & 63;
+        Wt[i] = n < 49 ? w[k * 49 + n] : 0.f;
+    }
+    const int Hi = 2 * Ho, Wi = 2 * Wo;
+    const int py = tid >> 4, px = tid & 15;              // this thread's image pixel inside the tile
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int img = tile / tiles_per_img, t = tile - img * tiles_per_img;
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        const int oy0 = ty * 8 - 1, ox0 = tx * 8 - 1;    // first gy pixel of the window: image rows 16 ty .. 16 ty + 15 see oy0 .. oy0 + 10
+        __syncthreads();                                 // the previous tile's tap table has been read (and Wt is complete)
+        // 128 window slots x 16 float4: thread -> (slot, 4 channels); slots past 121 and pixels outside gy are zero
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int q = j * 256 + tid, slot = q >> 4, c4 = (q & 15) * 4;
+            const int wy = slot / 11, wx = slot - wy * 11;
+            const int oy = oy0 + wy, ox = ox0 + wx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (slot < 121 && (unsigned)oy < (unsigned)Ho && (unsigned)ox < (unsigned)Wo)
+                v = *reinterpret_cast<const float4*>(gy + (((size_t)img * Ho + oy) * Wo + ox) * 64 + c4);
+            *reinterpret_cast<float4*>(gt + slot * GP + c4) = v;
+        }
+        __syncthreads();
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        const float* ap = gt + (wave * 32 + l31) * GP + kh2;
+        const float* bp = Wt + kh2 * 64 + l31;
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) {
+            const float av = ap[2 * kk];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[2 * kk * 64], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[2 * kk * 64 + 32], acc1, 0, 0, 0);
+        }
+        __syncthreads();                                 // every wave has read its gy rows: the table may overwrite them
+        // C/D layout: col = lane&31 (tap), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (slot of the wave's 32)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int slot = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh2;
+            gt[slot * TP + l31] = acc0[r];
+            if (l31 < 17) gt[slot * TP + 32 + l31] = acc1[r];
+        }
+        __syncthreads();
+        // image pixel (iy, ix): taps (ky, kx) with iy + 3 - ky even, gy pixel ((iy + 3 - ky) / 2, (ix + 3 - kx) / 2)
+        const int iy = ty * 16 + py, ix = tx * 16 + px;
+        const int ky0 = (iy + 3) & 1, kx0 = (ix + 3) & 1;
+        float sum = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int ky = ky0 + 2 * a;
+            const int wy = ((iy + 3 - ky) >> 1) - oy0;   // (inside the window by construction; rows outside gy hold zeros)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int kx = kx0 + 2 * b;
+                const int wx = ((ix + 3 - kx) >> 1) - ox0;
+                if (ky < 7 && kx < 7) sum += gt[(wy * 11 + wx) * TP + ky * 7 + kx];
+            }
+        }
+        gx[((size_t)img * Hi + iy) * Wi + ix] = sum;
+    }
+}
+
+extern "C" int bh_stem7_dgrad_c1(const float* gy, const float* w, float* gx, const bh_conv_desc* d, void* stream) {
+    if (!gy || !w || !gx || !d) return BH_E_BADARG;
+    if (d->transposed || d->Ci != 1 || d->Co != 64 || d->kh != 7 || d->kw != 7 || d->stride != 2 || d->pad != 3 || d->out_nchw ||
+        d->Ho % 8 || d->Wo % 8 || d->Ho * 2 != d->Hi || d->Wo * 2 != d->Wi)
+        return BH_E_UNSUPPORTED;
+    if (d->N == 0) return BH_OK;
+    if (bh_query("stem7_dgrad_c1_kernel")) return BH_OK;
+    hipStream_t s = bh_stream(stream);
+    const int tiles_x = d->Wo / 8, tpi = (d->Ho / 8) * tiles_x, ntiles = d->N * tpi;
+    int blocks = 256 * 3;
+    if (blocks > ntiles) blocks = ntiles;
+    hipLaunchKernelGGL(stem7_dgrad_c1_kernel, dim3(blocks), dim3(256), 0, s, gy, w, gx, d->Ho, d->Wo, tiles_x, tpi, ntiles);
+    BH_LAUNCH_CHECK();
+    return BH_OK;
+}
+

@@ -800,6 +800,13 @@ def conv_dgrad(gy, w, d, out=None, bn_reduce=None, wkey=None, wpacked=None, cols
         return out
     if (out is None and not d.transposed and d.kh == 7 and d.stride == 2 and not d.out_nchw
             and (d.Ci == 1 or (d.Ci == 3 and d.in_nchw)) and d.Co % 4 == 0 and d.N * d.Ho * d.Wo >= 4096):
+        if (d.Ci == 1 and d.Co == 64 and d.pad == 3 and d.Ho % 8 == 0 and d.Wo % 8 == 0 and d.Ho * 2 == d.Hi and d.Wo * 2 == d.Wi
+                and w.is_contiguous() and os.environ.get("BIHOME_STEM_DGRAD_FUSED", "1") != "0"):
+            # one kernel (round 4): a workgroup owns a 16 x 16 image tile - window GEMM into a tap table in LDS + gather; no tap table in HBM
+            gx = torch.empty((d.N, d.Hi, d.Wi, 1), dtype=torch.float32, device=gy.device)
+            with _Timed("stem7_dgrad_c1_kernel", conv_flops(d), 4.0 * (gy.numel() + gx.numel())):
+                check(lib.bh_stem7_dgrad_c1(_p(gy), _p(w), _p(gx), ctypes.byref(d), _stream()), "bh_stem7_dgrad_c1")
+            return gx
         return _stem_dgrad_two_step(gy, w, d, wkey)
     acc = out is not None
     if (not d.transposed and d.stride == 2 and not d.in_nchw and not d.out_nchw and d.Co % 4 == 0 and d.Ci % 4 == 0

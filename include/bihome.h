@@ -372,6 +372,10 @@ int bh_bias_grad_from_sums(const double* sums, float* gbias, int groups, int C, 
  * Tm[N*Ho*Wo][ldT] = gy x w^T (one 1x1 bh_conv_fwd launch; column = tap*Ci + c, ldT >= 49*Ci padded)
  * -> gx[N,Ci,Hi,Wi] = col2im(Tm). */
 int bh_col2im_c1(const float* Tm, float* gx, const bh_conv_desc* d, int ldT, void* stream);
+/* The same dgrad for ONE input channel in one kernel (round 4: no tap table in HBM): gy[N,Ho,Wo,64] NHWC, w[64][7][7][1] -> gx[N,1,2Ho,2Wo]
+ * (overwritten).  The frozen extractor's conv1 on a warped patch (src/heads/PerceptualHead.py:52-55,377,398).  BH_E_UNSUPPORTED for other
+ * geometries: the caller keeps the two-pass form for those.  No atomics: every image tile has one writer. */
+int bh_stem7_dgrad_c1(const float* gy, const float* w, float* gx, const bh_conv_desc* d, void* stream);
 /* gw += x^T * gy ; gbias += sum gy  (accumulated: caller zeroes; gbias NULL ok) */
 int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, const bh_conv_desc* d, void* stream);
 /* Deterministic form of bh_conv_wgrad for the stride-1 "same" 3x3 / 5x5 / 7x7 layers its fast path takes (Co, Ci multiples

@@ -110,9 +110,14 @@ def test_first_conv_nchw_input(K, N, Hi, Ci, Co):
     close(gw.cpu().permute(0, 3, 1, 2), wt.grad)
 
 
-@pytest.mark.parametrize("N,Hi", [(2, 32), (8, 64)])       # small: direct gather kernel; large: 1x1 GEMM + col2im
-def test_gray_stem_conv_and_its_dgrad(K, N, Hi):
-    """Extractor conv1 on a 1-channel image (PerceptualHead.py:52-55) and the dgrad the warp needs."""
+@pytest.mark.parametrize("N,Hi,det", [(2, 32, False), (8, 64, False), (3, 128, False), (8, 64, True)])
+def test_gray_stem_conv_and_its_dgrad(K, N, Hi, det):
+    """Extractor conv1 on a 1-channel image (PerceptualHead.py:52-55) and the dgrad the warp needs.  Small: the direct gather kernel;
+    large: one kernel (tile GEMM + overlap-add in LDS + atomics into the image, round 4: bh_stem7_dgrad_c1); large in a deterministic
+    call: the two-pass form (1x1 GEMM into a tap table + col2im)."""
+    if det:
+        with K.det_scope(True):
+            return test_gray_stem_conv_and_its_dgrad(K, N, Hi, False)
     x = rnd((N, 1, Hi, Hi), 12)
     w = rnd((64, 1, 7, 7), 13) / 7
     d = K.conv_desc(N, Hi, Hi, 1, 64, 7, 2, 3)
