@@ -100,6 +100,7 @@ SIGNATURES = {
     "bh_conv_dgrad_bnreduce": [P, P, P, POINTER(BhConvDesc), c_int, POINTER(BhBnReduce), P, c_int, P],
     "bh_col2im_c1": [P, P, POINTER(BhConvDesc), c_int, P],
     "bh_stem7_dgrad_c1": [P, P, P, POINTER(BhConvDesc), P],
+    "bh_stem7_wgrad": [P, P, P, POINTER(BhConvDesc), P, ctypes.c_size_t, P],
     "bh_conv_wgrad": [P, P, P, P, POINTER(BhConvDesc), P],
     "bh_conv_wgrad_det": [P, P, P, P, POINTER(BhConvDesc), P, c_int64, P],
     "bh_conv_bias_grad": [P, P, POINTER(BhConvDesc), P],
@@ -148,6 +149,8 @@ def _load():
         fn.restype = c_int
     lib.bh_conv_wgrad_det_bytes.argtypes = [POINTER(BhConvDesc)]      # (the one entry point that does not return a status)
     lib.bh_conv_wgrad_det_bytes.restype = c_int64
+    lib.bh_stem7_wgrad_ws_bytes.argtypes = [POINTER(BhConvDesc)]
+    lib.bh_stem7_wgrad_ws_bytes.restype = ctypes.c_size_t
     lib.bh_warp_bwd_img_scratch_doubles.argtypes = [c_int, c_int, c_int, c_int, c_int]
     lib.bh_warp_bwd_img_scratch_doubles.restype = ctypes.c_size_t
     if TUNING:

@@ -263,3 +263,117 @@ extern "C" int bh_stem7_dgrad_c1(const float* gy, const float* w, float* gx, con
     return BH_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// weight gradient of the 7x7 / 2 stem with CIN stacked image planes (the backbone's first conv: Rethinking.py:31, ResNet34.py:17) in a
+// dedicated kernel (round 4; the generic split-K kernel ran this K = 49 CIN gather at 37 TFLOP/s: 176 us).  gW[co][tap] = sum over pixels
+// of gy[pixel][co] * x[patch of the pixel][tap]: a persistent workgroup walks 8 x 8 tiles of gy, stages the tile ([64 pixels][64 channels])
+// and its 21 x 21 input patch per plane in LDS and accumulates D[co][n = plane * 49 + tap] over the 64 pixels of the tile
+// (v_mfma_f32_32x32x2_f32, k = pixel: the A fragment is gy[pixel][co] - one ds_read_b32 with a literal offset, the B fragment
+// patch[tap offset of the lane + literal pixel offset], as in stem7_fwd_kernel); wave w owns taps [32 w, 32 w + 32) x all 64 co, the
+// accumulators live across the workgroup's tiles.  Partial results go to a workspace [workgroups][64][128] and a second kernel adds them in
+// workgroup order: no atomics, bitwise repeatable.  x [N][CIN][Hi][Wi], gy [N][Ho][Wo][64], gw [64][7][7][CIN] +=.
+// ---------------------------------------------------------------------------------------------
+template <int CIN>
+__global__ void __launch_bounds__(256) stem7_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ ws,
+                                                          int Hi, int Wi, int Ho, int Wo, int tiles_x, int tiles_per_img, int ntiles) {
+    static_assert(49 * CIN <= 128, "taps of all planes in 128 columns");
+    constexpr int GP = 68, PW = 21, PCH = PW * PW;
+    __shared__ __attribute__((aligned(16))) float gt[64 * GP];       // [pixel][co]
+    __shared__ float patch[CIN * PCH + 64];                           // (+64: lanes past the last tap read in bounds)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh2 = lane >> 5;
+    const int n = wave * 32 + l31;
+    const int tap_off = n < 49 * CIN ? (n / 49) * PCH + ((n % 49) / 7) * PW + (n % 49) % 7 : 0;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    for (int i = tid; i < 64; i += 256) patch[CIN * PCH + i] = 0.f;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int img = tile / tiles_per_img, t = tile - img * tiles_per_img;
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        const int iy0 = ty * 16 - 3, ix0 = tx * 16 - 3;
+        __syncthreads();                                 // the previous tile's fragment reads are done
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = j * 256 + tid, pix = q >> 4, c4 = (q & 15) * 4;
+            const int oy = ty * 8 + (pix >> 3), ox = tx * 8 + (pix & 7);
+            *reinterpret_cast<float4*>(gt + pix * GP + c4) = *reinterpret_cast<const float4*>(gy + (((size_t)img * Ho + oy) * Wo + ox) * 64 + c4);
+        }
+        for (int i = tid; i < CIN * PCH; i += 256) {
+            const int c = i / PCH, r = i - c * PCH, yy = r / PW, xx = r - yy * PW;
+            const int iy = iy0 + yy, ix = ix0 + xx;
+            float v = 0.f;
+            if ((unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi) v = x[(((size_t)img * CIN + c) * Hi + iy) * Wi + ix];
+            patch[i] = v;
+        }
+        __syncthreads();
+        const float* ap = gt + kh2 * GP + l31;
+        const float* bp = patch + tap_off + 2 * kh2;
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) {
+            // pixel p = 2 kk + kh2 of the tile: (py, px) = (kk >> 2, ((2 kk) & 7) + kh2) -> patch offset 2 py * 21 + 2 px
+            const float bv = bp[42 * (kk >> 2) + 2 * ((2 * kk) & 7)];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * kk * GP], bv, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * kk * GP + 32], bv, acc1, 0, 0, 0);
+        }
+    }
+    // C/D layout: col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (co of the 32-block)
+    float* out = ws + (size_t)blockIdx.x * 64 * 128;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = (r & 3) + 8 * (r >> 2) + 4 * kh2;
+        out[co * 128 + n] = acc0[r];
+        out[(co + 32) * 128 + n] = acc1[r];
+    }
+}
+
+template <int CIN>
+__global__ void __launch_bounds__(256) stem7_wgrad_reduce_kernel(const float* __restrict__ ws, int nwg, float* __restrict__ gw) {
+    // block = 16 outputs x 16 slices of the workgroup list: a thread adds every 16th partial (independent loads in flight), the slices
+    // meet in LDS in slice order
+    __shared__ float red[16][17];
+    const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + o;                   // (co, n)
+    const bool ok = i < 64 * 49 * CIN;
+    const int co = ok ? i / (49 * CIN) : 0, n = ok ? i - co * (49 * CIN) : 0;
+    float s = 0.f;
+    if (ok)
+        for (int g = sl; g < nwg; g += 16) s += ws[((size_t)g * 64 + co) * 128 + n];
+    red[sl][o] = s;
+    __syncthreads();
+    if (sl == 0 && ok) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][o];
+        const int c = n / 49, tp = n - c * 49;
+        gw[((size_t)co * 49 + tp) * CIN + c] += t;
+    }
+}
+
+static bool stem7_wgrad_ok(const bh_conv_desc* d) {
+    return d && !d->transposed && d->kh == 7 && d->kw == 7 && d->stride == 2 && d->pad == 3 && d->Co == 64 && d->Ci == 2 && d->in_nchw &&
+           !d->out_nchw && d->Ho % 8 == 0 && d->Wo % 8 == 0 && d->Ho * 2 == d->Hi && d->Wo * 2 == d->Wi && d->N * (d->Ho / 8) * (d->Wo / 8) >= 512;
+}
+static int stem7_wgrad_blocks(const bh_conv_desc* d) {
+    const int ntiles = d->N * (d->Ho / 8) * (d->Wo / 8);
+    return ntiles < 1024 ? ntiles : 1024;
+}
+
+extern "C" size_t bh_stem7_wgrad_ws_bytes(const bh_conv_desc* d) {
+    return stem7_wgrad_ok(d) ? (size_t)stem7_wgrad_blocks(d) * 64 * 128 * sizeof(float) : 0;
+}
+
+extern "C" int bh_stem7_wgrad(const float* x, const float* gy, float* gw, const bh_conv_desc* d, float* ws, size_t ws_bytes, void* stream) {
+    if (!x || !gy || !gw || !d || !ws) return BH_E_BADARG;
+    if (!stem7_wgrad_ok(d)) return BH_E_UNSUPPORTED;
+    if (ws_bytes < bh_stem7_wgrad_ws_bytes(d)) return BH_E_BADARG;
+    if (bh_query("stem7_wgrad_kernel<2>+stem7_wgrad_reduce_kernel<2>")) return BH_OK;
+    hipStream_t s = bh_stream(stream);
+    const int tiles_x = d->Wo / 8, tpi = (d->Ho / 8) * tiles_x, ntiles = d->N * tpi, blocks = stem7_wgrad_blocks(d);
+    hipLaunchKernelGGL(stem7_wgrad_kernel<2>, dim3(blocks), dim3(256), 0, s, x, gy, ws, d->Hi, d->Wi, d->Ho, d->Wo, tiles_x, tpi, ntiles);
+    BH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(stem7_wgrad_reduce_kernel<2>, dim3((64 * 98 + 15) / 16), dim3(256), 0, s, ws, blocks, gw);
+    BH_LAUNCH_CHECK();
+    return BH_OK;
+}
+

@@ -834,6 +834,9 @@ def wgrad_det_bytes(d):
     return int(lib.bh_conv_wgrad_det_bytes(ctypes.byref(_route_det(d))))
 
 
+_STEM_WGRAD_WS = {}      # (device, bytes) -> the stem weight gradient's partial-sum workspace (one launch per step and model on one stream)
+
+
 def conv_wgrad(x, gy, gw, gbias, d, det_ws=None):
     """gw += x^T gy (split-K MFMA kernel, fp32 atomics); gbias += column sums of gy (separate launch, own timing entry so
     that the wgrad entry is the kernel rocprofv3 lists under the same name).
@@ -865,6 +868,18 @@ def conv_wgrad(x, gy, gw, gbias, d, det_ws=None):
                                          ctypes.byref(bs), _stream()), "bh_conv_wgrad_bnin")
         return
     _chk(x); _chk(gy); _chk(gw); _chk(gbias)
+    if (d.kh == 7 and d.stride == 2 and d.Ci == 2 and d.in_nchw and gbias is None and gw.is_contiguous()
+            and os.environ.get("BIHOME_STEM_WGRAD_FUSED", "1") != "0"):
+        # the backbone's stem (round 4): dedicated kernel + ordered reduction through a private workspace (no atomics: every mode)
+        need = lib.bh_stem7_wgrad_ws_bytes(ctypes.byref(d))
+        if need:
+            key = (str(x.device), int(need))
+            ws = _STEM_WGRAD_WS.get(key)
+            if ws is None:
+                ws = _STEM_WGRAD_WS[key] = torch.empty(need // 4, dtype=torch.float32, device=x.device)
+            with _Timed("stem7_wgrad_kernel<2>+stem7_wgrad_reduce_kernel<2>", conv_flops(d), 4.0 * (x.numel() + gy.numel() + gw.numel())):
+                check(lib.bh_stem7_wgrad(_p(x), _p(gy), _p(gw), ctypes.byref(d), _p(ws), need, _stream()), "bh_stem7_wgrad")
+            return
     det = deterministic()
     if det and det_ws is None:
         raise RuntimeError("deterministic mode: conv_wgrad needs a workspace (det_ws) - bh_conv_wgrad has only the atomic form")

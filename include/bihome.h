@@ -376,6 +376,12 @@ int bh_col2im_c1(const float* Tm, float* gx, const bh_conv_desc* d, int ldT, voi
  * (overwritten).  The frozen extractor's conv1 on a warped patch (src/heads/PerceptualHead.py:52-55,377,398).  BH_E_UNSUPPORTED for other
  * geometries: the caller keeps the two-pass form for those.  No atomics: every image tile has one writer. */
 int bh_stem7_dgrad_c1(const float* gy, const float* w, float* gx, const bh_conv_desc* d, void* stream);
+/* Weight gradient of the backbone's 7x7 / 2 stem on TWO stacked image planes (Rethinking.py:31, ResNet34.py:17) in a dedicated kernel
+ * (round 4): x[N,2,Hi,Wi] NCHW, gy[N,Ho,Wo,64] NHWC, gw[64][7][7][2] +=.  Partial sums of the persistent workgroups go through the
+ * caller's workspace (bh_stem7_wgrad_ws_bytes(d) bytes, 0 = geometry not taken) and are added in workgroup order: no atomics, bitwise
+ * repeatable.  bh_conv_wgrad computes the same gradient for every geometry. */
+size_t bh_stem7_wgrad_ws_bytes(const bh_conv_desc* d);
+int bh_stem7_wgrad(const float* x, const float* gy, float* gw, const bh_conv_desc* d, float* ws, size_t ws_bytes, void* stream);
 /* gw += x^T * gy ; gbias += sum gy  (accumulated: caller zeroes; gbias NULL ok) */
 int bh_conv_wgrad(const float* x, const float* gy, float* gw, float* gbias, const bh_conv_desc* d, void* stream);
 /* Deterministic form of bh_conv_wgrad for the stride-1 "same" 3x3 / 5x5 / 7x7 layers its fast path takes (Co, Ci multiples

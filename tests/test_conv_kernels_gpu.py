@@ -91,9 +91,11 @@ def test_conv_transpose_2x2(K, N, Hi, Ci, Co):
     close(gb.cpu(), bt.grad)
 
 
-@pytest.mark.parametrize("N,Hi,Ci,Co", [(3, 32, 2, 64), (2, 48, 3, 64)])
+@pytest.mark.parametrize("N,Hi,Ci,Co", [(3, 32, 2, 64), (2, 48, 3, 64), (8, 128, 2, 64), (5, 160, 2, 64)])
 def test_first_conv_nchw_input(K, N, Hi, Ci, Co):
-    """7x7/2 on the NCHW network input (Rethinking.py:31, ResNet34.py:17): scalar gather path."""
+    """7x7/2 on the NCHW network input (Rethinking.py:31, ResNet34.py:17): scalar gather path; two planes and >= 512 8x8 tiles
+    (the last two cases): stem7_fwd_kernel<2> and the dedicated weight-gradient kernel (round 4: bh_stem7_wgrad - accumulates into gw,
+    bitwise repeatable)."""
     x = rnd((N, Ci, Hi, Hi), 9)
     w = rnd((Co, Ci, 7, 7), 10) / 10
     d = K.conv_desc(N, Hi, Hi, Ci, Co, 7, 2, 3, in_nchw=True)
@@ -108,6 +110,16 @@ def test_first_conv_nchw_input(K, N, Hi, Ci, Co):
     gw = torch.zeros_like(wg)
     K.conv_wgrad(torch.tensor(x).cuda(), torch.tensor(gy).permute(0, 2, 3, 1).contiguous().cuda(), gw, None, d)
     close(gw.cpu().permute(0, 3, 1, 2), wt.grad)
+    if N * (Hi // 16) ** 2 >= 512 and Ci == 2:
+        from bihome_amd._lib import lib
+        import ctypes
+        assert lib.bh_stem7_wgrad_ws_bytes(ctypes.byref(d)) > 0
+        gw2 = gw.clone()
+        K.conv_wgrad(torch.tensor(x).cuda(), torch.tensor(gy).permute(0, 2, 3, 1).contiguous().cuda(), gw2, None, d)      # += : twice the gradient
+        close(gw2.cpu().permute(0, 3, 1, 2), 2 * wt.grad)
+        gw3 = torch.zeros_like(wg)
+        K.conv_wgrad(torch.tensor(x).cuda(), torch.tensor(gy).permute(0, 2, 3, 1).contiguous().cuda(), gw3, None, d)
+        assert torch.equal(gw3, gw)                                                                                         # no atomics
 
 
 @pytest.mark.parametrize("N,Hi,det", [(2, 32, False), (8, 64, False), (3, 128, False), (8, 64, True)])
