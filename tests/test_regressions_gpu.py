@@ -264,10 +264,13 @@ def test_graph_replays_invalidate_folded_and_packed_caches():
     assert np.isfinite(loss.item())
 
 
-def test_graph_replays_keep_the_stem_table_a_captured_graph_reads():
+def test_graph_replays_keep_the_stem_table_a_captured_graph_reads(monkeypatch):
     """Round-3 ADVICE (medium): invalidate_caches() after a replay used to DROP the transposed stem table of the frozen extractor -
     the tensor whose address the captured 1x1 GEMM of the stem dgrad reads.  The table must keep its storage (refreshed in place at
-    its next eager use): same address after replays + torch.cuda.empty_cache(), replays still give the captured step's numbers."""
+    its next eager use): same address after replays + torch.cuda.empty_cache(), replays still give the captured step's numbers.
+    (Round 4: the one-channel stem's dgrad is one kernel without a table - bh_stem7_dgrad_c1; the two-pass form with its table is still
+    what three-channel stems run, and what this test switches back to.)"""
+    monkeypatch.setenv("BIHOME_STEM_DGRAD_FUSED", "0")
     from bihome_amd import kernels as K
     from bihome_amd.graph import GraphedStep
     from bihome_amd.step import build_model, build_optimizer, train_step
