@@ -1,7 +1,7 @@
 """The warp + perceptual path (BASELINE.json's HBM-bound part) from a rocprofv3 kernel_stats.csv: sum of the average durations of the four
-launches of a step and the fraction of 8 TB/s for the 205 MB they move.  python tools/hbm_path_from_csv.py profiles/r04h_kernel_stats.csv"""
+launches of a step and the fraction of 8 TB/s for the 205 MB they move.  python tools/hbm_path_from_csv.py profiles/r04j_kernel_stats.csv"""
 import csv, sys
-rows = list(csv.DictReader(open(sys.argv[1] if len(sys.argv) > 1 else "profiles/r04h_kernel_stats.csv")))
+rows = list(csv.DictReader(open(sys.argv[1] if len(sys.argv) > 1 else "profiles/r04j_kernel_stats.csv")))
 want = ("triplet_fwd_kernel", "triplet_bwd_kernel", "warp_fwd4_kernel", "warp_bwd4_kernel")
 tot = 0.0
 for w in want:
