@@ -144,9 +144,16 @@ def roofline_leg(model, data, opt, sched, reducer, nsteps=2):
     train_step(model, dict(data), opt, sched, reducer=reducer, loss_fn=LOSS_FN[0])
     torch.cuda.synchronize()
     K.TIMING = {}
+    # an event pair also measures the time the GPU waits for the HOST between its two markers, and the instrumented pass (two event records
+    # per launch) is host-bound on boxes with a slow host: ~20 ms of device work is queued in front of every instrumented step, so that the
+    # host runs ahead of the GPU and the pairs measure the device (round 4: hbm_path_frac.raw moved 0.31 -> 0.21 between two boxes without it)
+    lead = torch.empty(1 << 28, dtype=torch.float32, device=next(model.parameters()).device)
     for _ in range(nsteps):
+        for _ in range(50):
+            lead.add_(1.0)
         train_step(model, dict(data), opt, sched, reducer=reducer, loss_fn=LOSS_FN[0])
     torch.cuda.synchronize()
+    del lead
     rows = []
     for name, r in K.TIMING.items():
         ms = sum(a.elapsed_time(b) for a, b in r["events"])
