@@ -245,6 +245,11 @@ def measured_peaks():
         check(lib.bh_probe_mfma_bf16(rnd, ctypes.c_void_p(sink.data_ptr()), ctypes.byref(v),
                                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "bh_probe_mfma_bf16")
         out[name] = round(v.value, 1)
+    for name, rnd in (("f32_mfma_constant_operands_TFLOPs", 0), ("f32_mfma_random_operands_TFLOPs", 1)):      # (the generic / stem kernels' instruction)
+        v = ctypes.c_double(0.0)
+        check(lib.bh_probe_mfma_f32(rnd, ctypes.c_void_p(sink.data_ptr()), ctypes.byref(v),
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "bh_probe_mfma_f32")
+        out[name] = round(v.value, 1)
     a = torch.empty(1 << 28, dtype=torch.float32, device="cuda")          # 1 GiB read + 1 GiB written: beyond the Infinity Cache
     b = torch.empty_like(a)
     b.copy_(a)

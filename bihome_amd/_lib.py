@@ -49,6 +49,7 @@ P = c_void_p
 SIGNATURES = {
     "bh_version": [],
     "bh_probe_mfma_bf16": [c_int, P, P, P],
+    "bh_probe_mfma_f32": [c_int, P, P, P],
     "bh_device_arch": [c_char_p, c_int],
     "bh_h4pt_fwd": [P, c_int, c_float, c_float, P, P, P],
     "bh_h4pt_bwd": [P, P, P, c_int, c_float, c_float, P, P],

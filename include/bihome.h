@@ -57,6 +57,8 @@ int bh_device_arch(char* buf, int buflen);
  * toggling of real tensors - on MI355X the power-limited rate, 25-35 % below the first).  Synchronises the stream.  sink_dev: 4 bytes of
  * device memory (never written). */
 int bh_probe_mfma_bf16(int random_operands, float* sink_dev, double* tflops, void* stream);
+/* the same stream of v_mfma_f32_32x32x2_f32 (the fp32-input instruction of the generic, stem and small-channel kernels) */
+int bh_probe_mfma_f32(int random_operands, float* sink_dev, double* tflops, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Geometry (per-sample small dense algebra, double precision inside)
