@@ -47,6 +47,57 @@ static bool tail_geom(int groups, int rows, int hw, int Ci, int Cm, int Co, Tail
 static inline size_t off_xmom(const TailGeom& g) { return (size_t)g.groups * g.Cm * 2; }
 static inline size_t off_part(const TailGeom& g) { return off_xmom(g) + (size_t)g.groups * (g.Ci + g.Ci * g.Ci); }
 
+// ---- first/second moments of x for Ci = 16 on the matrix pipe (round 4): X^T X is a GEMM.  v_mfma_f32_16x16x4_f32 takes A[i][k] and
+// B[k][j] from lane 16 k + i / 16 k + j: with i, j = channel and k = pixel BOTH operands are the same register, and that register is one
+// coalesced dword load - lane L reads element L of four consecutive pixels (64 floats).  No LDS, no barrier inside the loop (the form below
+// staged 64-pixel slabs in LDS between two barriers: 72 us on 2 x 1M pixels, 1.9 TB/s).  The fp32 accumulators (D[i][j] in lane 16 (i / 4) + j,
+// register i % 4 - the matrix is symmetric, so the orientation does not matter) and the per-lane first-moment sums are flushed into doubles
+// every 256 pixels.  grid (nchunks, groups), block 256: the four waves interleave 4-pixel steps of the chunk. ----
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) tail_xmoments16_mfma_kernel(const float* __restrict__ x, TailGeom g, double* __restrict__ part) {
+    __shared__ double red[4][272];
+    const int grp = blockIdx.y, chunk = blockIdx.x;
+    const int rbeg = chunk * g.rows_per_chunk, rend = min(g.rows, rbeg + g.rows_per_chunk);
+    const float* base = x + (size_t)grp * g.rows * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double dxx[4] = {0, 0, 0, 0}, dx = 0;
+    f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+    float sx = 0.f;
+    // eight 4-pixel steps per trip: the eight loads are in flight together (a trip of one wave = 128 pixels, of the block = 512)
+    for (int p0 = rbeg + 4 * wave; p0 < rend; p0 += 128) {
+        float a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = p0 + 16 * u + (lane >> 4);
+            a[u] = p < rend ? base[(size_t)p * 16 + (lane & 15)] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], a[u], acc, 0, 0, 0);
+            sx += a[u];
+        }
+        if ((((p0 - rbeg) >> 7) & 7) == 7) {             // every 8 trips = 256 pixels of this wave: fp32 blocks -> doubles
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { dxx[r] += (double)acc[r]; acc[r] = 0.f; }
+            dx += (double)sx; sx = 0.f;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dxx[r] += (double)acc[r];
+    dx += (double)sx;
+    dx += __shfl_xor(dx, 16, 64);                       // the four pixel rows of a step hold the same channel
+    dx += __shfl_xor(dx, 32, 64);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][(4 * (lane >> 4) + r) * 16 + (lane & 15)] = dxx[r];
+    if (lane < 16) red[wave][256 + lane] = dx;
+    __syncthreads();
+    double* o = part + ((size_t)grp * g.nchunks + chunk) * (16 + 256);
+    for (int e = threadIdx.x; e < 272; e += 256) {
+        const double tot = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+        if (e < 256) o[16 + e] = tot; else o[e - 256] = tot;
+    }
+}
+
 // ---- first/second moments of x: grid (nchunks, groups), block 256 ----
 // Ci = 16 (the Zeng tail): a thread owns a 4 x 4 block of the 16 x 16 second-moment matrix for every 16th pixel of a 64-pixel
 // slab (16 threads = one matrix, 16 pixel groups per block): two ds_read_b128 per 16 FMAs instead of two ds_read_b32 per FMA
@@ -893,7 +944,10 @@ int bh_tail_fwd_route(const float* x, const float* w1, const float* b1, const fl
     if (use_running && (!running_mean || !running_var)) return BH_E_BADARG;
     hipStream_t s = bh_stream(stream);
     if (!use_running) {
-        hipLaunchKernelGGL(tail_xmoments_kernel, dim3(g.nchunks, groups), dim3(256), 0, s, x, g, ws + off_part(g));
+        if (Ci == 16 && !(tail_route & 2))
+            hipLaunchKernelGGL(tail_xmoments16_mfma_kernel, dim3(g.nchunks, groups), dim3(256), 0, s, x, g, ws + off_part(g));
+        else
+            hipLaunchKernelGGL(tail_xmoments_kernel, dim3(g.nchunks, groups), dim3(256), 0, s, x, g, ws + off_part(g));
         BH_LAUNCH_CHECK();
         hipLaunchKernelGGL(tail_xmom_reduce_kernel, dim3(Ci + Ci * Ci, groups), dim3(64), 0, s, ws + off_part(g), g,
                            ws + off_xmom(g));

@@ -1046,6 +1046,7 @@ def bn_join_bwd(gy, y, xa, xb, ma, mb, stats_a, stats_b, groups, relu, train_a, 
 
 
 TAIL_ROUTE_VALU_FWD = 1     # include/bihome.h BH_TAIL_ROUTE_VALU_FWD
+TAIL_ROUTE_LDS_MOMENTS = 2  # include/bihome.h BH_TAIL_ROUTE_LDS_MOMENTS
 
 
 def tail_fwd(x, w1, b1, gamma, beta, rmean, rvar, w2, b2, groups, hw, eps, momentum, training, route=0):

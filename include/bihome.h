@@ -481,6 +481,7 @@ int bh_tail_fwd(const float* x, const float* w1, const float* b1, const float* g
  * hw % 32 == 0 the Ci -> Cm product runs on the matrix pipe in the exact three-bf16-piece arithmetic (tail_fwd_mfma_kernel);
  * bit 0 (BH_TAIL_ROUTE_VALU_FWD) keeps the per-pixel VALU kernel (tests compare the two, tools time them). */
 #define BH_TAIL_ROUTE_VALU_FWD 1
+#define BH_TAIL_ROUTE_LDS_MOMENTS 2      /* bit 1: the input moments by the LDS-slab kernel instead of the matrix-pipe one (Ci = 16) */
 int bh_tail_fwd_route(const float* x, const float* w1, const float* b1, const float* gamma, const float* beta,
                       float* running_mean, float* running_var, const float* w2, const float* b2, float* out, double* ws,
                       int groups, int rows, int hw, int Ci, int Cm, int Co, float eps, float momentum, int use_running,

@@ -238,6 +238,11 @@ def test_maxpool_gap_add(K, N, H, C):
     assert torch.equal(a, s)
 
 
+def relerr64(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-300)
+
+
 @pytest.mark.parametrize("sparse", [0, 1, 2])
 @pytest.mark.parametrize("groups,N,H,Ci,Cm,Co,training", [(2, 2, 16, 16, 128, 2, True), (1, 3, 8, 16, 128, 2, True),
                                                           (2, 1, 32, 8, 64, 3, True), (2, 2, 16, 16, 128, 2, False),
@@ -280,6 +285,16 @@ def test_fused_tail_fwd_bwd(K, groups, N, H, Ci, Cm, Co, training, sparse):
         out_v, _ = K.tail_fwd(xg, *a2, groups, H * H, bn.eps, 0.1, training, route=K.TAIL_ROUTE_VALU_FWD)
         close(out_v.cpu(), ref.detach(), 3e-5)
         close(out.cpu(), out_v.cpu(), 1e-5)
+        # the input moments on the matrix pipe (round 4, Ci = 16: X^T X as a GEMM) against the LDS-slab kernel: the BatchNorm statistics
+        # derived from them (workspace head: [groups][Cm][2] sums) agree to double-precision rounding of fp32-accumulated blocks
+        rm3, rv3 = C(rm0), C(rv0)
+        a3 = args[:4] + (rm3, rv3) + args[6:]
+        out_l, ws_l = K.tail_fwd(xg, *a3, groups, H * H, bn.eps, 0.1, training, route=K.TAIL_ROUTE_LDS_MOMENTS)
+        close(out_l.cpu(), ref.detach(), 3e-5)
+        if training:
+            n = groups * Cm * 2
+            assert relerr64(ws[:n].cpu().numpy(), ws_l[:n].cpu().numpy()) < 1e-6
+            close(rv3.cpu(), rv.cpu(), 1e-6)
     gy = rnd(tuple(ref.shape), 49)
     if sparse:
         keep = np.random.RandomState(77).rand(NN, 1, H, H) < (0.01 if sparse == 1 else 0.15)
