@@ -35,6 +35,8 @@ def x3_pieces(kernel):
     if kernel.startswith("wgrad_x3_kernel<"):                     # template arguments: CB, BNI, NP
         args = kernel[len("wgrad_x3_kernel<"):].split(">")[0].split(",")
         return int(args[2]) if len(args) >= 3 else 3
+    if kernel.startswith("conv3x3_pc_kernel<"):                   # template arguments: DGRAD, BNI - fp16 pieces only (csrc/conv3x3_pc.hip)
+        return 2
     if kernel.startswith("conv3x3_halo_kernel<"):                 # template arguments: FLIP, BN, BF16, SUBT, PACKED, X3, BNI, NP
         args = kernel[len("conv3x3_halo_kernel<"):].split(">")[0].split(",")
         if len(args) >= 6 and args[5] == "true":
@@ -46,6 +48,8 @@ F16X2_TEXT = ("fp32 tensors, fp32 accumulate; 3x3 / stride-1 convs (fwd, dgrad, 
               "other convs: v_mfma_f32_32x32x2_f32")
 def x3_is_f16(kernel):
     """fp16 pieces with per-tensor scales (the last template argument of both split-operand kernels; v_mfma_f32_32x32x16_f16)."""
+    if kernel.startswith("conv3x3_pc_kernel<"):
+        return True
     args = kernel.split(">")[0].split(",")
     return bool(x3_pieces(kernel)) and len(args) in (4, 10) and args[-1] == "true"
 
@@ -447,6 +451,51 @@ def main():
             roof["frac_of_measured_peak"] = (roof["achieved"] / sustained) if sustained else None
         if dist is not None:
             dist.barrier()
+    dist_info = None
+    if dist is not None:
+        # The N-GPU line proves itself (round-4 VERDICT item 8): backend and RCCL version, ranks counted by an all-reduce, the buckets, the
+        # exchange alone (event-timed around the bucket sequence: launch -> Work.wait() puts the RCCL stream's completion on the timed
+        # stream) and the SAME ranks stepping WITHOUT the exchange in the same run - what each replica costs alone, warm, on this node.
+        reds = reducer.reducers if hasattr(reducer, "reducers") else [reducer]
+        nref = max(5, min(args.steps, 20))
+        for r in reds:
+            r.enabled = False
+        for _ in range(3):
+            one_step()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(nref):
+            one_step()
+        sync()
+        tref = torch.tensor([time.perf_counter() - t1], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tref, op=dist.ReduceOp.MAX)
+        ms_alone = 1e3 * tref.item() / nref
+        for r in reds:
+            r.enabled = True
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        payload = sum((hi - lo) * 4 for r in reds for (lo, hi) in r.buckets)
+        nrep = 5
+        sync()
+        e0.record()
+        for _ in range(nrep):
+            works = [dist.all_reduce(r.fg.flat[lo:hi], async_op=True) for r in reds for (lo, hi) in r.buckets]
+            for w in works:
+                w.wait()
+        e1.record()
+        torch.cuda.synchronize()
+        tar = torch.tensor([e0.elapsed_time(e1) / nrep], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tar, op=dist.ReduceOp.MAX)
+        dist_info = {"backend": backend, "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None),
+                     "world_size": world, "ranks_counted": int(ones.item()), "devices_per_node": ndev,
+                     "buckets": sum(len(r.buckets) for r in reds), "payload_bytes_per_step": payload, "reduce_op": "SUM",
+                     "allreduce_ms_per_step": tar.item(),
+                     "allreduce_note": "the step's bucket sequence alone (nothing to overlap with), max over ranks; inside a step the buckets "
+                                       "leave from the backward hooks and run under the remaining backward kernels",
+                     "same_run_ms_per_step_without_exchange": ms_alone, "same_run_reference_steps": nref,
+                     "exchange_overhead_ms_per_step": ms - ms_alone,
+                     "scaling_efficiency": ms_alone / ms,
+                     "scaling_efficiency_note": "ms/step of these ranks stepping WITHOUT the exchange (each replica alone, warm, same run) / "
+                                                "ms/step with it; weak scaling, so value = n_gpus x pairs per GPU / ms"}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and CH == 1:    # the reference (and so the oracle) has no RGB path
         cpu = cpu_baseline(cfg)
@@ -486,7 +535,7 @@ def main():
                              "weights after the timed steps"},
             "step_ms_percentiles": {"p10": pct(0.10), "p50": pct(0.50), "p90": pct(0.90), "min": round(step_ms[0], 4), "max": round(step_ms[-1], 4),
                                     "note": "rank 0, gaps between per-step events on the launch stream"},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "distributed": dist_info,
             # (compact copy of roofline.warp_perceptual_path: BASELINE.json's HBM-bound part - homography warp + perceptual L1 / triplet -
             #  as a fraction of the 8 TB/s HBM peak, by raw event pairs and net of the cost of an empty event pair)
             "hbm_path_frac": ({"raw": roof["warp_perceptual_path"]["frac_of_hbm_peak"],

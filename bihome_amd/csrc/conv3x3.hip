@@ -25,6 +25,7 @@
 // workgroup barrier per 32-channel chunk instead of nine: the four waves of a workgroup (and the two workgroups of a
 // CU) drift freely through the taps.  Forward and dgrad are the same loop (the flip / transpose lives in the pack).
 #include "common.h"
+#include "conv3x3_args.h"
 #include <type_traits>
 
 #ifndef C3_X3_PIPE
@@ -50,76 +51,6 @@ __device__ unsigned long long g_c3_ts[8 * 16384];
 #else
 #define C3_STAMP(tile, k) do { } while (0)
 #endif
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x8v __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef __attribute__((address_space(3))) void* lds_void_ptr;
-
-// one split-operand MFMA step (16 channels): bf16 pieces or fp16 pieces (F16X2, common.h)
-template <bool F16>
-__device__ __forceinline__ f32x16 c3_mfma16(const uint4& av, const uint4& bv, const f32x16& c) {
-    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv), c, 0, 0, 0);
-    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
-}
-
-// two k-planes (2 x float4) of a fragment -> the 8 bf16 operands of one v_mfma_f32_32x32x16_bf16 lane (round to nearest even)
-__device__ __forceinline__ bf16x8 c3_pack_bf16(const float4& lo, const float4& hi) {
-    f32x8v v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    return __builtin_convertvector(v, bf16x8);
-}
-
-// pixel row (0..7) of the 8x4 strip held by lane quad q = l31 >> 2: 0 1 3 2 5 4 6 7 (see a_lane in the kernel)
-__device__ __forceinline__ int c3_strip_row(int q) { return q ^ (((q >> 1) ^ (q >> 2)) & 1); }
-
-struct C3Args {
-    const float* Src;
-    const float* Wt;
-    const float* bias;
-    float* Out;
-    int N, H, W;
-    int Kc, Nn;            // contraction channels (= source channels), output channels
-    int Cw;                // innermost dim of the weight tensor [Co][9][Cw]
-    int accumulate;
-    unsigned src_bytes, w_bytes, out_bytes;
-    int tx_shift, tpi_shift;   // log2(tiles_x), log2(tiles_per_img) when both are powers of two, else -1
-    int tiles_x, tiles_per_img, subtiles;
-    const float* res;      // optional residual (same layout as Out) and ReLU applied in the epilogue (inference path)
-    int relu;
-    // optional (dgrad): the tensor written here is the gradient w.r.t. the OUTPUT of a training-mode BatchNorm (+ReLU);
-    // the epilogue also accumulates that BatchNorm's backward sums (sum g*mask, sum g*mask*xhat) into bn_sums, so its
-    // adjoint needs no separate reduce pass.  bnr_z: the BatchNorm input, bnr_y: its output (ReLU mask when a residual
-    // was added; NULL -> the mask is recomputed from z), bnr_stats: forward sums (mean / variance), rows per group
-    const float* bnr_z;
-    const float* bnr_y;
-    const double* bnr_stats;
-    const float* bnr_gamma;
-    const float* bnr_beta;
-    float bnr_eps;
-    int bnr_relu, bnr_rows;
-    double* bn_sums;       // optional [groups][Nn][2]: += per-channel (sum, sum of squares) of the output (forward only)
-    int imgs_per_group, groups;
-    int dbg_nch;           // ablation: number of channel chunks to run (-1 = all)
-    int tpb, gx_total;     // tile positions per workgroup (see the loop in the kernel), total positions along x
-    int desync;            // > 0: the workgroups of every second dispatch round of 256 sleep desync x 8128 cycles before their first load, so that
-                           // the two workgroups that share a CU run out of phase (one in its MFMA loop while the other loads / stores)
-    int stat_acc;          // the tpb positions of a workgroup lie in ONE statistics group: their column sums are added in registers and leave
-                           // with one atomic per (channel, moment) and workgroup (round 4: the full-resolution 32-channel layers launched
-                           // 16384 workgroups = 8192 same-address f64 atomics of ~30 ns each per entry - 245 us of a 275 us kernel)
-    int NW;                // PACKED: number of 32-wide output-channel tiles (Nn / 32)
-    // X3 forward with BNI: Src is the INPUT of a training-mode BatchNorm (+ReLU) whose output this convolution consumes; the halo
-    // staging applies y = max(x * scale + shift, lo) per channel on the way to LDS (padding stays zero), so that BatchNorm's
-    // output tensor never exists.  bni: table[groups][Kc] x (scale, shift) of bh_bn_fwd_coeffs, copied to LDS at bni_lds
-    const float* bni;
-    int bni_relu, bni_ipg, bni_groups, bni_lds;
-    int dbg_noload;        // ablation bits: 1 no weight-slab DMA in the loop, 2 no halo DMA in the loop (wrong results, timing only)
-    int dbg_ts;            // BH_TUNING: record phase time stamps into g_c3_ts
-    int det;               // deterministic mode: the statistics / backward sums go through integer limbs (common.h bh_det_add)
-    // F16 (two fp16 pieces, common.h F16X2): magnitude record of Src (BH_AMAX_WORDS words); the weights' sixteen partial maxima sit
-    // behind their pieces (word w_bytes / 4 of Wt, written by pack_weights_amax_kernel)
-    const unsigned* amax_src;
-};
 
 constexpr int C3_HALO_BYTES = 8 * 200 * 16;          // 25600
 constexpr int C3_B_BYTES = 8192;
@@ -860,7 +791,7 @@ __global__ void __launch_bounds__(256, X3 ? ((BN == 32 && NP == 2 && !BNI) ? C3_
 }
 
 constexpr int C3_MIN_BLOCKS = 256;      // below this many workgroups the generic kernel's finer tiles fill the chip better
-BH_KNOB(g_c3_noload, 0); BH_KNOB(g_c3_dbg_nch, -1); BH_KNOB(g_c3_subt, 2); BH_KNOB(g_c3_tpb, 2); BH_KNOB(g_c3_stamp, 0); BH_KNOB(g_c3_desync, 0); BH_KNOB(g_c3_walk32, 1);
+BH_KNOB(g_c3_noload, 0); BH_KNOB(g_c3_dbg_nch, -1); BH_KNOB(g_c3_subt, 2); BH_KNOB(g_c3_tpb, 2); BH_KNOB(g_c3_stamp, 0); BH_KNOB(g_c3_desync, 0); BH_KNOB(g_c3_walk32, 1); BH_KNOB(g_c3_pc, 1);
 #ifdef BH_TUNING
 // copies the phase time stamps of the last instrumented launch to the host (n entries of 8 x u64)
 extern "C" int bh_debug_read_c3_stamps(unsigned long long* out, int n) {
@@ -872,8 +803,9 @@ void bh_conv3x3_tune(int disable, int min_blocks) {
     if (disable == 70 || disable == 71) { g_c3_stamp = disable - 70; return; }        // phase time stamps off / on
     if (disable >= 200 && disable < 264) { g_c3_desync = disable - 200; return; }
     if (disable == 300 || disable == 301) { g_c3_walk32 = disable - 300; return; }         // (-43, 0|1): several positions per workgroup in the 32-channel launches without statistics off / on
+    if (disable == 310 || disable == 311) { g_c3_pc = disable - 310; return; }            // (-44, 0|1): persistent producer / consumer kernel off / on
     if (disable <= -100) { g_c3_dbg_nch = -100 - disable - 1; return; }            // -100 -> -1 (all), -101 -> 0 chunks, -102 -> 1 ...
-    if (disable >= 60 && disable < 68) { g_c3_noload = disable - 60; return; }
+    if (disable >= 400 && disable < 464) { g_c3_noload = disable - 400; return; }      // (-18, bits): ablation bits (halo kernel 1 2 4; producer / consumer kernel 1 .. 16)
     if (disable >= 20 && disable < 24) { g_c3_tpb = disable - 20; return; }        // tile positions per workgroup on two-round launches (1 / 2)
     if (disable >= 11 && disable <= 13) { g_c3_subt = disable - 10; return; }      // 1 / 2 (automatic) / 3 (always two) sub-tiles per workgroup
 }
@@ -974,6 +906,14 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
     if (bni) {      // BatchNorm-on-load: the f32x3 forward only, table of <= 4 KB (two groups x 256 channels) in LDS
         if (!x3 || dgrad || !bni->table || bni->groups < 1 || d->N % bni->groups || (long long)bni->groups * Kc * 8 > 4096) return BH_E_UNSUPPORTED;
         a.bni = bni->table; a.bni_relu = bni->relu; a.bni_groups = bni->groups; a.bni_ipg = d->N / bni->groups;
+    }
+    // fp16-piece launches of the 64-channel tile: persistent producer / consumer workgroups (conv3x3_pc.hip, round 5) unless the call routes
+    // to the one-workgroup-per-tile kernel below (BH_ROUTE_C3_TILE_WG: A/B measurements, the bit-identity tests)
+    if (f16 && !map4 && bn_tile == 64 && !(d->route & (BH_ROUTE_C3_TILE_WG | BH_ROUTE_C3_ONE_SUBTILE | BH_ROUTE_C3_ONE_POSITION)) && g_c3_pc) {
+        C3Args b = a;
+        b.det = (d->route & BH_ROUTE_DETERMINISTIC) ? 1 : 0; b.dbg_noload = g_c3_noload;
+        const int st = bh_conv3x3_pc_launch(b, dgrad, bni ? bni->table : nullptr, bni ? bni->groups : 0, bni ? bni->relu : 0, false, stream);
+        if (st != BH_E_UNSUPPORTED) { if (st == BH_OK) *taken = 1; return st; }
     }
     // (all ten template arguments, as rocprofv3 prints the symbol: FLIP, BN, BF16, SUBT, PACKED, X3, BNI, NP, MAP4, F16)
     if (bh_query("conv3x3_halo_kernel<%s,%d,%s,%d,%s,%s,%s,%d,%s,%s>", dgrad ? "true" : "false", bn_tile, bf16 ? "true" : "false", subt,

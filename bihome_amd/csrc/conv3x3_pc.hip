@@ -1,0 +1,642 @@
+// 3x3 / stride 1 / pad 1 convolution (forward and dgrad) in the fp16-piece arithmetic ("f16x2", bh_conv_desc.precision = 4) on PERSISTENT
+// workgroups with SPECIALISED waves (round 5).
+//
+// conv3x3_halo_kernel (conv3x3.hip) runs a tile's three phases - stage-in, tap loop, store - one after the other in the same four waves, and
+// the two workgroups of a CU run them in lockstep: on 128 x 32 x 32 x 64 the launch costs 15 us of stores + first stage, 15 us of MFMA and 11 us
+// of in-loop loads, added up (profiles/r04_c3_f16_ablation.txt).  Here ONE workgroup of twelve waves owns a CU for the whole launch and walks
+// its share of the (128-pixel x 64-channel) tiles; every wave has one job:
+//   waves 0-3    C  consumers: ds_read_b128 fragments + v_mfma_f32_32x32x16_f16, nothing else.  Wave (wm, wn) owns sub-tile wm x channels
+//                   [32 wn, 32 wn + 32) as before; a tap is two halves of six MFMAs (16-channel step 0 / 1), the fragments of the next half
+//                   are requested while the current half multiplies (two register sets, no copies).  At a tile's end the accumulators go
+//                   to an LDS hand-over tile (32 ds_write_b32 per wave) and the next tile starts at once.
+//   waves 4-5    H  halo staging: a 32-channel chunk's two 10 x 10 halos global -> registers -> BatchNorm-on-load (optional) -> two fp16
+//                   pieces -> LDS.  TWO chunks are in flight (a register set per halo stage): a slot round is cut, written, and the same
+//                   registers request the round of the chunk after next - nothing else in these waves waits on the vector-memory counter,
+//                   so every load has two chunk times (~3.5 us) to arrive.  Lane = (halo pixel, 8-channel plane): whole 128-byte lines.
+//   waves 6-7    D  the packed weight fragments of kernel row r + 2 by LDS-DMA into a ring of three row slots (twelve 1 KB pieces per wave and
+//                   row; the only vector-memory traffic of these waves, so "the previous row has landed" is an exact counter wait).
+//   waves 8-11   E  the previous tile's epilogue out of the hand-over tile: 2^-(ka + kb) rescale, bias, accumulate / residual / ReLU,
+//                   BatchNorm statistics or BatchNorm-backward sums, with 16-byte loads and stores (lane = pixel x four channels: 1 KB
+//                   contiguous per instruction; the halo kernel stored 4 bytes per lane).  What a unit reads from HBM is requested four
+//                   units ahead; stores are never waited for.  The epilogue's options are a template argument (EM): no dead branches.
+// Synchronisation is one s_barrier per kernel row (3 taps = 36 MFMAs per consumer wave), placed right after a consumer has REQUESTED the
+// row's last fragments: the row's weight slot and - on the last row of a chunk - the chunk's halo stage are then free for the producers.
+// Two halo stages, three weight-row slots, one hand-over tile: 158.5 KB of the CU's 160.
+// The MFMA order per accumulator (chunk, tap, 16-channel step, products lo*hi, hi*lo, hi*hi) is that of conv3x3_halo_kernel: the
+// convolution results are bit-identical to it (tests/test_conv_pc_gpu.py); the statistics sums are accumulated in double per element (the halo
+// kernel: float per fragment quad, then double) and agree to rounding.
+#include "conv3x3_args.h"
+#include <type_traits>
+
+namespace {
+constexpr int PC_HPL = 200;                          // halo slots per k-plane: two sub-tiles x 10 x 10
+constexpr int PC_PS = PC_HPL * 16 + 32;              // plane stride: +32 B so that the H waves' ds_write_b128 (lane = pixel x plane) spread over all banks
+constexpr int PC_PIECE = 4 * PC_PS;                  // four 8-channel planes per fp16 piece
+constexpr int PC_STAGE = 2 * PC_PIECE;               // one halo stage (hi / lo pieces): 25,856 B
+constexpr int PC_BTAP = 8192;                        // one tap's weight fragments: [n tile 2][piece 2][16-channel step 2][lane] x 16 B
+constexpr int PC_BROW = 3 * PC_BTAP;                 // one kernel row
+constexpr int PC_OFF_B = 2 * PC_STAGE;
+constexpr int PC_OFF_EPI = PC_OFF_B + 3 * PC_BROW;
+constexpr int PC_EPI_BYTES = 128 * 64 * 4;           // hand-over tile [128 pixels][64 channels] fp32
+constexpr int PC_OFF_RED = PC_OFF_EPI + PC_EPI_BYTES;
+constexpr int PC_RED_BYTES = 4 * 128 * 8;            // statistics partials of the four E waves: [wave][channel 64][moment 2] doubles
+constexpr int PC_LDS = PC_OFF_RED + PC_RED_BYTES;    // 162,304 B of 163,840
+constexpr unsigned PC_XOOB = 0x80000000u;            // out-of-range buffer offset (tensor sizes are below 2^31): the load returns zeros
+
+#define PC_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define PC_BARRIER_VM() asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+__device__ __forceinline__ void pc_decode(const C3Args& a, int g, int& img, int& ty, int& tx) {
+    if (a.tpi_shift >= 0) { img = g >> a.tpi_shift; const int t = g & (a.tiles_per_img - 1); ty = t >> a.tx_shift; tx = t & (a.tiles_x - 1); }
+    else { img = g / a.tiles_per_img; const int t = g - img * a.tiles_per_img; ty = t / a.tiles_x; tx = t - ty * a.tiles_x; }
+}
+
+// a.tpb: tiles per workgroup; a.gx_total: tile positions (two 8 x 8 sub-tiles each); tile index wt -> channel tile wt / gx_total, position
+// wt % gx_total (a workgroup's consecutive tiles share their weights and their statistics entries)
+// EM (epilogue mode, E waves): bit 0 statistics (forward sums / column sums / BatchNorm-backward sums), bit 1 one tensor added (the old gradient
+// of a join, or the residual of the inference path), bit 2 BatchNorm-backward form (reads that BatchNorm's input z), bit 3 ... with the ReLU
+// mask taken from its saved output y
+template <bool DGRAD, bool BNI, int EM>
+__global__ void __launch_bounds__(768) conv3x3_pc_kernel(C3Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NY = a.Nn >> 6;
+    const int total = a.gx_total * NY;
+    const int wt0 = blockIdx.x * a.tpb;
+    const int Tw = min(a.tpb, total - wt0);              // tiles of this workgroup (>= 1)
+    const int nch = a.Kc >> 5;
+    const int K = Tw * nch;                              // chunks
+    const int R = K * 3;                                 // kernel rows = barrier phases
+
+    if (wave < 4) {
+        // =============================== C: consumers ===============================
+        const int l31 = lane & 31, kh2 = lane >> 5;
+        const int wm = wave & 1, wn = wave >> 1;
+        const int sr_ = c3_strip_row(l31 >> 2);
+        const char* const aL = smem + kh2 * PC_PS + (wm * 100 + sr_ * 10 + (l31 & 3)) * 16;
+        const char* const bL = smem + PC_OFF_B + wn * 4096 + lane * 16;
+        int eoff[4];                                     // hand-over tile: byte offset of (strip row of register quad rq, x = 0, this lane's channel)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) eoff[rq] = PC_OFF_EPI + ((wm * 64 + c3_strip_row(2 * rq + kh2) * 8) * 64 + wn * 32 + l31) * 4;
+        // two fragment sets ([fragment][piece] + [piece] of one 16-channel step): a half tap multiplies one set while the fragments of the next
+        // half tap are requested into the other (six MFMAs ~ 200 cycles ahead; three sets / twelve MFMAs measured the same)
+        uint4 FA0[2][2], FB0[2], FA1[2][2], FB1[2];
+        f32x16 acc[2];
+#ifdef BH_TUNING
+        const int dbg = a.dbg_noload;
+#else
+        constexpr int dbg = 0;
+#endif
+        // fragments of one half tap: ap = this lane's halo position of the tap, bp = this lane's slot of the tap's weight image
+#define PC_LOADH(A_, B_, ap, bp, s2)                                                                                    \
+    do {                                                                                                                \
+        if (!(dbg & 2)) {                                                                                               \
+        _Pragma("unroll") for (int pc_ = 0; pc_ < 2; ++pc_) {                                                           \
+            _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                            \
+                A_[i_][pc_] = *reinterpret_cast<const uint4*>((ap) + pc_ * PC_PIECE + 2 * (s2) * PC_PS + i_ * 64);      \
+            B_[pc_] = *reinterpret_cast<const uint4*>((bp) + (pc_ * 2 + (s2)) * 1024);                                   \
+        }                                                                                                               \
+        }                                                                                                               \
+    } while (0)
+        // products lo*hi, hi*lo, hi*hi (small first), fragment 0 then 1: the order of conv3x3_halo_kernel's X3_MFMA
+#define PC_MFMA6(A_, B_)                                                                                                \
+    do {                                                                                                                \
+        if (!(dbg & 1)) {                                                                                               \
+        acc[0] = c3_mfma16<true>(A_[0][1], B_[0], acc[0]); acc[1] = c3_mfma16<true>(A_[1][1], B_[0], acc[1]);           \
+        acc[0] = c3_mfma16<true>(A_[0][0], B_[1], acc[0]); acc[1] = c3_mfma16<true>(A_[1][0], B_[1], acc[1]);           \
+        acc[0] = c3_mfma16<true>(A_[0][0], B_[0], acc[0]); acc[1] = c3_mfma16<true>(A_[1][0], B_[0], acc[1]);           \
+        }                                                                                                               \
+    } while (0)
+        // one MFMA : one LDS read, six times (the requests of the other register set ride in the gaps of this half's products)
+#define PC_INTERLEAVE()                                                                                                 \
+    do {                                                                                                                \
+        _Pragma("unroll") for (int g_ = 0; g_ < 6; ++g_) {                                                              \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                          \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                          \
+        }                                                                                                               \
+    } while (0)
+        PC_BARRIER();                                    // B(-1): halo stage 0 and weight row 0 are in LDS
+        PC_LOADH(FA0, FB0, aL, bL, 0);
+        int kap = 0;                                     // chunk counter: halo stage = kap & 1; the weight slot of kernel row r is slot r
+        for (int ti = 0; ti < Tw; ++ti) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+            for (int c = 0; c < nch; ++c, ++kap) {
+                const int par = kap & 1;
+                const bool more = kap + 1 < K;
+#pragma unroll
+                for (int row = 0; row < 3; ++row) {
+                    const char* const rp = aL + par * PC_STAGE + row * 160;          // tap (row, 0) of this chunk's halo stage
+                    const char* const sp = bL + row * PC_BROW;
+                    // tap 0 of the next kernel row (next chunk: the other stage; after the last chunk the request is repeated on this row -
+                    // harmless, and the loop body stays branch-free)
+                    const char* const nrp = row < 2 ? rp + 160 : (more ? aL + (par ^ 1) * PC_STAGE : rp);
+                    const char* const nsp = row < 2 ? sp + PC_BROW : bL;
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        // half 0: step 1 of this tap is requested, step 0 multiplies
+                        PC_LOADH(FA1, FB1, rp + t * 16, sp + t * PC_BTAP, 1);
+                        PC_MFMA6(FA0, FB0);
+                        PC_INTERLEAVE();
+                        if (t == 2) PC_BARRIER();        // B(rho): the row's last fragments are on their way - its weight slot (row 2: and the halo stage) are free
+                        // half 1: step 0 of the next tap is requested, step 1 multiplies
+                        if (t < 2) PC_LOADH(FA0, FB0, rp + (t + 1) * 16, sp + (t + 1) * PC_BTAP, 0);
+                        else PC_LOADH(FA0, FB0, nrp, nsp, 0);
+                        PC_MFMA6(FA1, FB1);
+                        PC_INTERLEAVE();
+                    }
+                }
+            }
+            // hand the accumulators over: element (i, r) = pixel (strip row of (r >> 2, kh2), x = 4 i + (r & 3)), channel wn * 32 + l31
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    *reinterpret_cast<float*>(smem + eoff[r >> 2] + (4 * i + (r & 3)) * 256) = acc[i][r];
+        }
+        PC_BARRIER();                                    // F1: the last tile is in the hand-over tile
+        PC_BARRIER();                                    // F2
+        PC_BARRIER();                                    // F3
+        PC_BARRIER();                                    // F4
+#undef PC_LOADH
+#undef PC_MFMA6
+#undef PC_INTERLEAVE
+        return;
+    }
+
+    if (wave < 8) {
+        // =============================== H: halo staging (4 waves) ===============================
+        // Slot round j (0 .. 3) of a chunk: halo pixel hp = j * 64 + (ht >> 2) of the [2 sub-tiles][10][10] image, this thread's 8-channel
+        // plane (ht & 3).  Chunk k lives in register set k & 1 (= its halo stage): round j of chunk k + 1 is cut and written in the row
+        // phases listed below and the same registers immediately request round j of chunk k + 3.
+        const int ht = tid - 256;
+        const int plane = ht & 3;
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Src), 0, a.src_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BNI ? a.bni : a.Src), 0,
+                                                                              BNI ? (unsigned)(a.bni_groups * a.Kc * 8) : 0u, 0x00020000);
+        constexpr int NR = 4;
+        int lo[NR];                                       // LDS byte offset of the slot inside a piece image
+        int hsub[NR], hyx[NR];                            // sub-tile, (hy << 8) | hx
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int hp = j * 64 + (ht >> 2);
+            const int s_ = hp >= 100 ? 1 : 0, p_ = hp - 100 * s_;
+            const int hy = (p_ * 205) >> 11, hx = p_ - hy * 10;
+            hsub[j] = s_; hyx[j] = (hy << 8) | hx;
+            lo[j] = plane * PC_PS + hp * 16;
+        }
+        unsigned xoff[NR];                                // global byte offset of the slot's 32 bytes in chunk 0 of the tile being loaded (PC_XOOB: padding)
+        unsigned tboff = 0;                               // BNI: byte offset of this plane's coefficients in chunk 0 of that tile's group
+        auto h_tile = [&](int wt) {
+            const int bx = wt % a.gx_total;
+            int org[2], oy0[2], ox0[2];
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) {
+                const int g = bx * 2 + s_;
+                int img, ty, tx;
+                pc_decode(a, g < a.subtiles ? g : 0, img, ty, tx);
+                oy0[s_] = ty * 8 - 1; ox0[s_] = tx * 8 - 1;
+                org[s_] = g < a.subtiles ? (img * a.H + oy0[s_]) * a.W + ox0[s_] : (int)0x80000000;
+                if (BNI && s_ == 0) tboff = (unsigned)((img / a.bni_ipg) * a.Kc + plane * 8) * 8u;
+            }
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const int s_ = hsub[j], hy = hyx[j] >> 8, hx = hyx[j] & 255;
+                const int y = (s_ ? oy0[1] : oy0[0]) + hy, x = (s_ ? ox0[1] : ox0[0]) + hx;
+                const int o = s_ ? org[1] : org[0];
+                unsigned off = PC_XOOB;
+                if (j * 64 + (ht >> 2) < PC_HPL && o != (int)0x80000000 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
+                    off = ((unsigned)(o + hy * a.W + hx) * (unsigned)a.Kc + (unsigned)(plane * 8)) * 4u;
+                xoff[j] = off;
+            }
+        };
+        float4 hA[NR][2], hB[NR][2];                      // the rounds in flight: even chunks / odd chunks
+        float4 tbA[4], tbB[4];                            // BNI: (scale, shift) of this plane's 8 channels of those chunks
+        unsigned okA = 0, okB = 0;                        // bit j: slot round j of that chunk lies inside the image
+        int li_t = 0, li_c = 0;                           // (tile, chunk of the tile) whose rounds are being requested
+        // (the last round holds 32 slots: the first half-wave of wave 4)
+#define PC_H_LIVE(j) ((j) * 256 + (wave - 4) * 64 < 4 * PC_HPL)
+        auto h_issue = [&](auto J, float4 (&h)[NR][2], float4 (&tb)[4], unsigned& okm) {
+            constexpr int j = decltype(J)::value;
+            if (j == 0) {
+                if (li_c == 0) h_tile(wt0 + li_t);
+                if constexpr (BNI) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        tb[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsT, tboff + (unsigned)q * 16u, (unsigned)(li_c * 256), 0));
+                }
+            }
+            if (PC_H_LIVE(j)) {
+                h[j][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, xoff[j], (unsigned)(li_c * 128), 0));
+                h[j][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, xoff[j] + 16u, (unsigned)(li_c * 128), 0));
+            }
+            okm = (okm & ~(1u << j)) | ((xoff[j] != PC_XOOB ? 1u : 0u) << j);
+            if (j == NR - 1) { if (++li_c == nch) { li_c = 0; ++li_t; } }
+        };
+        float f16_s = 1.0f;
+        const float bni_lo = a.bni_relu ? 0.0f : -__builtin_inff();
+        auto h_cut = [&](auto J, int stage, float4 (&h)[NR][2], float4 (&tb)[4], unsigned okm) {
+            constexpr int j = decltype(J)::value;
+            if (PC_H_LIVE(j) && j * 64 + (ht >> 2) < PC_HPL) {
+                char* const st = smem + stage * PC_STAGE;
+                float4 u = h[j][0], v = h[j][1];
+                if constexpr (BNI) {
+                    // y = max(x * scale + shift, lo) on the slot's 8 channels; padding stays zero
+                    const bool ok = (okm >> j) & 1u;
+                    u.x = ok ? __builtin_elementwise_maximum(__builtin_fmaf(u.x, tb[0].x, tb[0].y), bni_lo) : 0.f;
+                    u.y = ok ? __builtin_elementwise_maximum(__builtin_fmaf(u.y, tb[0].z, tb[0].w), bni_lo) : 0.f;
+                    u.z = ok ? __builtin_elementwise_maximum(__builtin_fmaf(u.z, tb[1].x, tb[1].y), bni_lo) : 0.f;
+                    u.w = ok ? __builtin_elementwise_maximum(__builtin_fmaf(u.w, tb[1].z, tb[1].w), bni_lo) : 0.f;
+                    v.x = ok ? __builtin_elementwise_maximum(__builtin_fmaf(v.x, tb[2].x, tb[2].y), bni_lo) : 0.f;
+                    v.y = ok ? __builtin_elementwise_maximum(__builtin_fmaf(v.y, tb[2].z, tb[2].w), bni_lo) : 0.f;
+                    v.z = ok ? __builtin_elementwise_maximum(__builtin_fmaf(v.z, tb[3].x, tb[3].y), bni_lo) : 0.f;
+                    v.w = ok ? __builtin_elementwise_maximum(__builtin_fmaf(v.w, tb[3].z, tb[3].w), bni_lo) : 0.f;
+                }
+                uint4 p0, p1;
+                bh_split8_f16(u, v, f16_s, p0, p1);
+                *reinterpret_cast<uint4*>(st + lo[j]) = p0;
+                *reinterpret_cast<uint4*>(st + PC_PIECE + lo[j]) = p1;
+            }
+        };
+#ifdef BH_TUNING
+        const bool hoff = a.dbg_noload & 4;               // ablation: no halo staging at all (timing only)
+#else
+        constexpr bool hoff = false;
+#endif
+        using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>; using J2 = std::integral_constant<int, 2>;
+        using J3 = std::integral_constant<int, 3>;
+        // round j of chunk `stage`-parity -> LDS, then round j of the chunk two further -> in flight in the same registers.  (The BatchNorm
+        // coefficients of the chunk two further are requested with its round 0: they must not replace this chunk's before its round 3 is
+        // cut - the set's coefficient registers are reloaded by round 3's issue instead.)
+#define PC_H_ROUND(J, cut, issue, stage)                                                                                \
+    do {                                                                                                                \
+        if (stage) { if (cut) h_cut(J{}, 1, hB, tbB, okB); if (issue) h_issue(J{}, hB, tbB, okB); }                     \
+        else       { if (cut) h_cut(J{}, 0, hA, tbA, okA); if (issue) h_issue(J{}, hA, tbA, okA); }                     \
+    } while (0)
+#define PC_H_ALL(cut, issue, stage)                                                                                     \
+    do {                                                                                                                \
+        PC_H_ROUND(J0, cut, issue, stage); PC_H_ROUND(J1, cut, issue, stage); PC_H_ROUND(J2, cut, issue, stage);        \
+        PC_H_ROUND(J3, cut, issue, stage);                                                                              \
+    } while (0)
+        if (!hoff) {
+            // chunks 0 and 1 requested at once (then the source tensor's scale, whose loads ride behind them); chunk 0 cut; chunk 2 requested
+            PC_H_ALL(false, true, 0);
+            if (1 < K) PC_H_ALL(false, true, 1);
+            f16_s = __builtin_bit_cast(float, (unsigned)(127 + bh_f16_scale_exp(bh_amax_read(a.amax_src, lane))) << 23);
+            PC_H_ALL(true, false, 0);
+            if (2 < K) PC_H_ALL(false, true, 0);
+        }
+        PC_BARRIER();                                     // B(-1)
+        for (int kap = 0; kap < K; ++kap) {
+            // chunk kap + 1 -> the stage the consumers left at B(3 kap - 1), in three shares; chunk kap + 3 into flight behind each share
+            const bool cut = kap + 1 < K && !hoff, iss = kap + 3 < K && !hoff;
+            const int stg = (kap + 1) & 1;
+            // (BatchNorm-on-load: a chunk's coefficients are requested with its round 0, i.e. while the later rounds of the chunk two before
+            //  are still to be cut with THEIR coefficients - so the whole chunk is cut before any of its registers is re-requested)
+            if constexpr (BNI) {
+                PC_H_ROUND(J0, cut, false, stg); PC_H_ROUND(J1, cut, false, stg);
+                PC_BARRIER();                             // row 0
+                PC_H_ROUND(J2, cut, false, stg);
+                PC_BARRIER();                             // row 1
+                PC_H_ROUND(J3, cut, false, stg);
+                PC_H_ALL(false, iss, stg);
+                PC_BARRIER();                             // row 2
+            } else {
+                PC_H_ROUND(J0, cut, iss, stg); PC_H_ROUND(J1, cut, iss, stg);
+                PC_BARRIER();                             // row 0
+                PC_H_ROUND(J2, cut, iss, stg);
+                PC_BARRIER();                             // row 1
+                PC_H_ROUND(J3, cut, iss, stg);
+                PC_BARRIER();                             // row 2
+            }
+        }
+        PC_BARRIER();                                     // F1
+        PC_BARRIER();                                     // F2
+        PC_BARRIER();                                     // F3
+        PC_BARRIER();                                     // F4
+#undef PC_H_ALL
+#undef PC_H_ROUND
+#undef PC_H_LIVE
+        return;
+    }
+
+    // wait until at most n vector-memory operations (the youngest n) are outstanding; everything the caller must not leave behind is older
+    auto wait_vm = [&](int n) {
+#define PC_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+        switch (n < 0 ? 0 : (n > 36 ? 36 : n)) {
+            PC_W(0) PC_W(1) PC_W(2) PC_W(3) PC_W(4) PC_W(5) PC_W(6) PC_W(7) PC_W(8) PC_W(9) PC_W(10) PC_W(11) PC_W(12) PC_W(13) PC_W(14) PC_W(15)
+            PC_W(16) PC_W(17) PC_W(18) PC_W(19) PC_W(20) PC_W(21) PC_W(22) PC_W(23) PC_W(24) PC_W(25) PC_W(26) PC_W(27) PC_W(28) PC_W(29) PC_W(30)
+            PC_W(31) PC_W(32) PC_W(33) PC_W(34) PC_W(35) PC_W(36)
+        }
+#undef PC_W
+    };
+
+    // =============================== E: weight rows + epilogue (4 waves) ===============================
+    {
+        const int ew = wave - 8;
+        const int cq = lane & 15, pl = lane >> 4;         // channel quad (channels 4 cq .. 4 cq + 3 of the tile), pixel of the unit
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(a.Out, 0, a.out_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.Out), 0, a.out_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bnr_z ? a.bnr_z : a.Out), 0, a.out_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bnr_y ? a.bnr_y : a.Out), 0, a.out_bytes, 0x00020000);
+        constexpr bool stats = EM & 1, use_ext = EM & 2, rd_z = EM & 4, rd_y = EM & 8;
+        const bool rd_res = a.res != nullptr;             // (use_ext: the residual when there is one, else the old gradient)
+        const unsigned nn4 = (unsigned)a.Nn * 4u;
+#ifdef BH_TUNING
+        const bool eoff_ = a.dbg_noload & 16;             // ablation: no epilogue (timing only)
+#else
+        constexpr bool eoff_ = false;
+#endif
+
+        // ---- state of the tile whose epilogue RUNS, and of the tile whose operands are being FETCHED (the same or the next) ----
+        unsigned tbase[2] = {0u, 0u}, fbase[2] = {0u, 0u};   // byte offset of (sub-tile origin, channel n0) in the output tensor
+        bool tvalid[2] = {false, false}, fvalid[2] = {false, false};
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 r_invstd = bv, r_cx0 = bv, r_sc = bv, r_sh = bv;      // BatchNorm-reduce coefficients of the lane's four channels
+        int cur_grp = -1, cur_n0 = 0;
+        double S1[4] = {0.0, 0.0, 0.0, 0.0}, S2[4] = {0.0, 0.0, 0.0, 0.0};
+        bool have = false;                                // S1 / S2 hold something
+        // Statistics leave the workgroup with ONE f64 atomic per (channel, moment): stash() puts this wave's sums (reduced over its four pixel
+        // lanes) into LDS, commit() - behind the next barrier - lets E wave 0 add the four waves' sums and issue the atomics.  Happens when the
+        // workgroup's tile range crosses a statistics group or channel tile, and at the end.
+        int pend_grp = 0, pend_n0 = 0;
+        bool pending = false;
+        auto stash = [&]() {
+            double* const red = reinterpret_cast<double*>(smem + PC_OFF_RED);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                double s1 = S1[e], s2 = S2[e];
+                s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+                if (pl == 0) { red[(ew * 64 + cq * 4 + e) * 2] = s1; red[(ew * 64 + cq * 4 + e) * 2 + 1] = s2; }
+                S1[e] = 0.0; S2[e] = 0.0;
+            }
+            pend_grp = cur_grp; pend_n0 = cur_n0; pending = true; have = false;
+        };
+        auto commit = [&]() {
+            if (!pending) return;
+            if (ew == 0) {
+                const double* const red = reinterpret_cast<const double*>(smem + PC_OFF_RED);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int idx = q * 64 + lane;            // (channel, moment)
+                    const double tot = ((red[idx] + red[128 + idx]) + red[256 + idx]) + red[384 + idx];
+                    bh_acc_add(&a.bn_sums[bn_sum_index(0, a.groups, pend_grp, a.Nn, pend_n0 + (idx >> 1), idx & 1)], tot, a.det);
+                }
+            }
+            pending = false;
+        };
+        auto tile_geom = [&](int wt, unsigned (&base)[2], bool (&valid)[2], int& grp, int& n0) {
+            const int ny_ = wt / a.gx_total, bx = wt - ny_ * a.gx_total;
+            n0 = ny_ * 64; grp = 0;
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) {
+                const int g = bx * 2 + s_;
+                int img, ty, tx;
+                pc_decode(a, g < a.subtiles ? g : 0, img, ty, tx);
+                valid[s_] = g < a.subtiles;
+                base[s_] = ((unsigned)((img * a.H + ty * 8) * a.W + tx * 8) * (unsigned)a.Nn + (unsigned)n0) * 4u;
+                if (s_ == 0) grp = img / a.imgs_per_group;
+            }
+        };
+        auto f_tile = [&](int wt) { int g_, n_; tile_geom(wt, fbase, fvalid, g_, n_); };
+        auto e_tile = [&](int wt) {
+            int grp, n0;
+            tile_geom(wt, tbase, tvalid, grp, n0);
+            if (stats && have && (grp != cur_grp || n0 != cur_n0)) stash();
+            if (grp != cur_grp || n0 != cur_n0) {
+                cur_grp = grp; cur_n0 = n0;
+                const int n = n0 + cq * 4;
+                bv = a.bias ? *reinterpret_cast<const float4*>(a.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rd_z) {
+                    float isd[4], cx[4], sc[4], sh[4];
+                    const double rows = (double)a.bnr_rows;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const double mu = bn_sum_total(a.bnr_stats, a.groups, grp, a.Nn, n + e, 0, a.det) / rows;
+                        double var = bn_sum_total(a.bnr_stats, a.groups, grp, a.Nn, n + e, 1, a.det) / rows - mu * mu;
+                        if (var < 0) var = 0;
+                        const float mean = (float)mu;
+                        isd[e] = 1.0f / sqrtf((float)var + a.bnr_eps);
+                        sc[e] = (a.bnr_gamma ? a.bnr_gamma[n + e] : 1.f) * isd[e];
+                        sh[e] = (a.bnr_beta ? a.bnr_beta[n + e] : 0.f) - mean * sc[e];
+                        cx[e] = -mean * isd[e];
+                    }
+                    r_invstd = make_float4(isd[0], isd[1], isd[2], isd[3]); r_cx0 = make_float4(cx[0], cx[1], cx[2], cx[3]);
+                    r_sc = make_float4(sc[0], sc[1], sc[2], sc[3]); r_sh = make_float4(sh[0], sh[1], sh[2], sh[3]);
+                }
+            }
+        };
+        // Epilogue unit idx (0 .. 7) of this wave = unit u = ew + 4 idx of the tile: four pixels x 64 channels = 1 KB of the hand-over tile and
+        // of the output row.  What a unit reads from HBM (old gradient, residual, BatchNorm input / output) is requested FOUR units ahead
+        // into register set idx & 3 (epi_fetch), two or more barrier phases before epi_run needs it; the stores are never waited for.
+        // Addressing: unit u = ew + 4 idx covers pixels (sub-tile idx >> 2, row (ew >> 1) + 2 (idx & 3), x = 4 (ew & 1) + pl): the lane part of the
+        // byte offset is ONE tile-independent VGPR, the rest (sub-tile origin + row step) rides in the scalar offset of the buffer instruction.
+        int nops = 0;                                     // vector-memory operations (epilogue loads + stores) this wave issued in the current phase
+        float4 pf_a[4], pf_z[4], pf_y[4];                  // pf_a: the old gradient (dgrad joins) OR the residual (inference forward) - never both
+        constexpr int nld = (use_ext ? 1 : 0) + (rd_z ? 1 : 0) + (rd_y ? 1 : 0);      // loads per unit
+        const unsigned voff = (unsigned)((ew >> 1) * a.W + ((ew & 1) << 2) + pl) * nn4 + (unsigned)cq * 16u;
+        const unsigned rowstep2 = 2u * (unsigned)a.W * nn4;
+        const char* const epi_l = smem + PC_OFF_EPI + ew * 1024 + lane * 16;
+        const __amdgpu_buffer_rsrc_t rsA_ = rd_res ? rsR : rsO;
+        auto epi_fetch = [&](auto IDX) {                   // unit idx of the FETCH tile -> set idx & 3
+            constexpr int idx = decltype(IDX)::value, q = idx & 3;
+            if (nld == 0 || !((idx >> 2) ? fvalid[1] : fvalid[0])) return;
+            const unsigned so = ((idx >> 2) ? fbase[1] : fbase[0]) + (unsigned)q * rowstep2;
+            nops += nld;
+            if constexpr (use_ext) pf_a[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA_, voff, so, 0));
+            if constexpr (rd_z) pf_z[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsZ, voff, so, 0));
+            if constexpr (rd_y) pf_y[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsY, voff, so, 0));
+        };
+        int kout = 0;
+        auto epi_run = [&](auto IDX) {                     // unit idx of the RUN tile, operands in set idx & 3
+            constexpr int idx = decltype(IDX)::value, q = idx & 3;
+            if (!((idx >> 2) ? tvalid[1] : tvalid[0])) return;
+            const unsigned so = ((idx >> 2) ? tbase[1] : tbase[0]) + (unsigned)q * rowstep2;
+            const float4 av = *reinterpret_cast<const float4*>(epi_l + idx * 4096);
+            const float4 z0 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 o = use_ext ? pf_a[q] : z0, zz = rd_z ? pf_z[q] : z0, yy = rd_y ? pf_y[q] : z0;
+            const float accv[4] = {av.x, av.y, av.z, av.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w};
+            const float oo[4] = {o.x, o.y, o.z, o.w};
+            const float z4[4] = {zz.x, zz.y, zz.z, zz.w}, y4[4] = {yy.x, yy.y, yy.z, yy.w};
+            const float isd[4] = {r_invstd.x, r_invstd.y, r_invstd.z, r_invstd.w}, cx[4] = {r_cx0.x, r_cx0.y, r_cx0.z, r_cx0.w};
+            const float sc[4] = {r_sc.x, r_sc.y, r_sc.z, r_sc.w}, sh[4] = {r_sh.x, r_sh.y, r_sh.z, r_sh.w};
+            float out[4];
+            const bool do_relu = a.relu != 0, mask_on = rd_z && a.bnr_relu;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = __builtin_ldexpf(accv[e], kout) + bb[e];
+                if constexpr (use_ext) v += oo[e];         // (0 + old, or 0 + residual: the halo kernel's `ext`)
+                v = do_relu ? fmaxf(v, 0.0f) : v;
+                out[e] = v;
+                if constexpr (stats) {
+                    // forward / column sums: (v, v^2); BatchNorm backward: (g, g xhat) with g = v under the ReLU mask of that BatchNorm
+                    float vm = v, t = v;
+                    if constexpr (rd_z) {
+                        const float yv = rd_y ? y4[e] : __builtin_fmaf(z4[e], sc[e], sh[e]);
+                        vm = (mask_on && !(yv > 0.f)) ? 0.f : v;
+                        t = __builtin_fmaf(z4[e], isd[e], cx[e]);
+                    }
+                    S1[e] += (double)vm;
+                    S2[e] = __builtin_fma((double)vm, (double)t, S2[e]);
+                }
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, make_float4(out[0], out[1], out[2], out[3])),
+                                                   rsO, voff, so, 0);
+            have = true; ++nops;
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+        using I6 = std::integral_constant<int, 6>; using I7 = std::integral_constant<int, 7>;
+        // unit idx of the run tile, then the request four units ahead: units 4 .. 7 of the same tile, or 0 .. 3 of the next one (`nxt`: its
+        // tile index, -1 = none; its geometry is made when the first of them is requested)
+#define PC_E_STEP(IDX, FIDX, nxt)                                                                                       \
+    do {                                                                                                                \
+        epi_run(IDX{});                                                                                                 \
+        if (IDX::value < 4) epi_fetch(FIDX{});                                                                          \
+        else if ((nxt) >= 0) { if (IDX::value == 4) f_tile(nxt); epi_fetch(FIDX{}); }                                   \
+    } while (0)
+#define PC_E_UNITS(k0, k1, nxt)                                                                                         \
+    do {                                                                                                                \
+        if ((k0) <= 0 && 0 < (k1)) PC_E_STEP(I0, I4, nxt);                                                              \
+        if ((k0) <= 1 && 1 < (k1)) PC_E_STEP(I1, I5, nxt);                                                              \
+        if ((k0) <= 2 && 2 < (k1)) PC_E_STEP(I2, I6, nxt);                                                              \
+        if ((k0) <= 3 && 3 < (k1)) PC_E_STEP(I3, I7, nxt);                                                              \
+        if ((k0) <= 4 && 4 < (k1)) PC_E_STEP(I4, I0, nxt);                                                              \
+        if ((k0) <= 5 && 5 < (k1)) PC_E_STEP(I5, I1, nxt);                                                              \
+        if ((k0) <= 6 && 6 < (k1)) PC_E_STEP(I6, I2, nxt);                                                              \
+        if ((k0) <= 7 && 7 < (k1)) PC_E_STEP(I7, I3, nxt);                                                              \
+    } while (0)
+
+        // ---- weight rows: kernel row r of a chunk lives in ring slot r (3 taps x [2 n tiles][2 pieces][2 steps] x 1 KB, six pieces per E wave).
+        // Row rho + 2 is requested at the END of phase rho (its slot was left at B(rho - 1)) and must have landed at B(rho + 1).  The LDS-DMA is
+        // inline assembly: the compiler orders every LDS read behind an LDS-DMA it knows of with vmcnt(0), which would put the DMA's latency
+        // in front of every epilogue unit.  Its completion is counted by hand (wait_vm: everything this wave issued after the previous
+        // phase's DMA may still fly; the compiler's own counted waits for the epilogue loads do not see the DMAs and can only wait longer).
+#ifdef BH_TUNING
+        const bool doff = a.dbg_noload & 8;               // ablation: no weights (timing only)
+#else
+        constexpr bool doff = false;
+#endif
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wt), 0, a.w_bytes, 0x00020000);
+        const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+        const unsigned lane16 = (unsigned)lane * 16u;
+        auto dma_num = [&](int r) {                       // weight row number r = (tile, chunk, kernel row)
+            const int kp = r / 3, row = r - kp * 3, ti_ = kp / nch, c_ = kp - ti_ * nch;
+            const int ny = (wt0 + ti_) / a.gx_total;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int piece = ew * 2 + jj;
+                    const unsigned so = (unsigned)(((c_ * 9 + row * 3 + t) * a.NW + ny * 2) * 4096 + piece * 1024);
+                    const unsigned dst = lds0 + (unsigned)(PC_OFF_B + row * PC_BROW + t * PC_BTAP + piece * 1024);
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(lane16), "s"(dst), "s"(rsB), "s"(so) : "memory");
+                }
+        };
+        int pro = 0;
+        if (!doff) { dma_num(0); if (R > 1) { dma_num(1); ++pro; } if (R > 2) { dma_num(2); ++pro; } }
+        if (!eoff_) {
+            // the scales of the fp16 pieces (2^ka source, 2^kw weights: waiting for them also lands the three rows), then units 0 .. 3 of the
+            // first tile go into flight
+            const unsigned* const wrec = reinterpret_cast<const unsigned*>(a.Wt) + (a.w_bytes >> 2);
+            unsigned wv = lane < 16 ? wrec[lane] : 0u;
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)wv, off, 64); wv = o > wv ? o : wv; }
+            kout = -(bh_f16_scale_exp((unsigned)__builtin_amdgcn_readfirstlane((int)wv)) + bh_f16_scale_exp(bh_amax_read(a.amax_src, lane)));
+            asm volatile("" :: "s"(kout) : "memory");       // (the requests below stay behind the scale loads)
+            f_tile(wt0);
+            epi_fetch(I0{}); epi_fetch(I1{}); epi_fetch(I2{}); epi_fetch(I3{});
+        }
+        wait_vm(eoff_ ? 6 * pro : nops);                  // row 0 (in fact all three rows) has landed; the epilogue requests may fly
+        PC_BARRIER();                                     // B(-1)
+        const int nph = 3 * nch;                          // phases per tile
+        const int U = (8 + (nph - 1) - 1) / (nph - 1);    // epilogue units per wave and phase (phases 1 .. nph - 1 of the next tile)
+        int rho = 0;
+        for (int ti = 0; ti < Tw; ++ti) {
+            for (int k = 0; k < nph; ++k, ++rho) {        // phase k of this tile = kernel row rho: ends at B(rho)
+                nops = 0;
+                // this phase's share of the PREVIOUS tile's epilogue (the hand-over tile is readable from phase 1 on)
+                if (ti > 0 && !eoff_) {
+                    if (k == 0) e_tile(wt0 + ti - 1);
+                    else {
+                        if (k == 1) commit();
+                        const int k0 = (k - 1) * U, k1 = min(k0 + U, 8);
+                        if (k0 < 8) PC_E_UNITS(k0, k1, wt0 + ti);      // (the next tile to finish is this one: ti < Tw)
+                    }
+                }
+                // weight row rho + 2 -> the slot the consumers left at B(rho - 1)
+                int nd = 0;
+                if (rho >= 1 && rho + 2 < R && !doff) { dma_num(rho + 2); nd = 6; }
+                // row rho + 1 (requested at the end of the previous phase, or in the prologue) has landed: everything issued since may fly
+                wait_vm(nops + nd);
+                PC_BARRIER();                             // B(rho)
+            }
+        }
+        PC_BARRIER();                                     // F1: the last tile's accumulators are in the hand-over tile
+        if (!eoff_) e_tile(wt0 + Tw - 1);
+        PC_BARRIER();                                     // F2
+        commit();
+        PC_BARRIER();                                     // F3 (the sums buffer in LDS is free again)
+        if (!eoff_) {
+            PC_E_UNITS(0, 8, -1);
+            if (stats) stash();
+        }
+        PC_BARRIER();                                     // F4
+        commit();
+#undef PC_E_UNITS
+#undef PC_E_STEP
+    }
+}
+}  // namespace
+
+int bh_conv3x3_pc_launch(C3Args& a, int dgrad, const float* bni_table, int bni_groups, int bni_relu, bool query_only, hipStream_t stream) {
+    if (a.Kc % 32 || a.Nn % 64 || a.subtiles < 1) return BH_E_UNSUPPORTED;
+    // both sub-tiles of a tile position lie in one statistics group / BatchNorm-on-load group
+    const long long sub_per_group = (long long)a.imgs_per_group * a.tiles_per_img;
+    if ((a.bn_sums || a.bnr_z) && (sub_per_group % 2)) return BH_E_UNSUPPORTED;
+    if (a.accumulate && a.res) return BH_E_UNSUPPORTED;          // (one added tensor: the old gradient of a join OR the inference path's residual)
+    if (a.bnr_z && !a.bn_sums) return BH_E_UNSUPPORTED;
+    if (bni_table) {
+        if (dgrad || bni_groups < 1 || a.N % bni_groups || ((long long)(a.N / bni_groups) * a.tiles_per_img) % 2) return BH_E_UNSUPPORTED;
+        a.bni = bni_table; a.bni_groups = bni_groups; a.bni_relu = bni_relu; a.bni_ipg = a.N / bni_groups;
+    }
+    const int em = (a.bn_sums ? 1 : 0) | ((a.accumulate || a.res) ? 2 : 0) | (a.bnr_z ? 4 : 0) | ((a.bnr_z && a.bnr_relu && a.bnr_y) ? 8 : 0);
+    // instantiated: forward {plain, statistics, residual} x BatchNorm-on-load {no, yes (no residual)}; dgrad {plain, column sums, accumulate,
+    // BatchNorm sums [+ accumulate] [+ saved output]}
+    typedef void (*kern_t)(C3Args);
+    struct Row { int dgrad, bni, em; kern_t fn; };
+#define PC_ROW(D, B, E) {D, B, E, conv3x3_pc_kernel<(D) != 0, (B) != 0, E>}
+    static const Row rows[] = {PC_ROW(0, 0, 0), PC_ROW(0, 0, 1), PC_ROW(0, 0, 2), PC_ROW(0, 1, 0), PC_ROW(0, 1, 1),
+                               PC_ROW(1, 0, 0), PC_ROW(1, 0, 1), PC_ROW(1, 0, 2), PC_ROW(1, 0, 5), PC_ROW(1, 0, 7), PC_ROW(1, 0, 13), PC_ROW(1, 0, 15)};
+#undef PC_ROW
+    constexpr int NROWS = sizeof(rows) / sizeof(rows[0]);
+    kern_t fn = nullptr;
+    for (int i = 0; i < NROWS; ++i)
+        if (rows[i].dgrad == (dgrad ? 1 : 0) && rows[i].bni == (bni_table ? 1 : 0) && rows[i].em == em) fn = rows[i].fn;
+    if (!fn) return BH_E_UNSUPPORTED;
+    a.gx_total = (a.subtiles + 1) / 2;
+    const long long total = (long long)a.gx_total * (a.Nn / 64);
+    const int cus = 256;
+    const int T = (int)((total + cus - 1) / cus);
+    const int grid = (int)((total + T - 1) / T);
+    a.tpb = T;
+    a.NW = a.Nn / 32;
+    if (bh_query("conv3x3_pc_kernel<%s,%s,%d>", dgrad ? "true" : "false", bni_table ? "true" : "false", em)) return BH_OK;
+    if (query_only) return BH_OK;
+    static unsigned long long attr_devs = 0;
+    if (bh_device_once(attr_devs)) {
+        for (int i = 0; i < NROWS; ++i) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rows[i].fn), hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(768), PC_LDS, stream, a);
+    BH_LAUNCH_CHECK();
+    return BH_OK;
+}

@@ -34,6 +34,7 @@ class FlatGradReducer:
         # in the head) - a parameter's gradient is only final after the last of those backward walks, so nothing leaves from the hooks;
         # allreduce() launches every bucket at the end of the step
         self.defer = bool(defer)
+        self.enabled = True          # False: the hooks and allreduce() exchange nothing (bench.py's same-run single-replica reference steps)
         self.group = group
         self.op = op if op is not None else dist.ReduceOp.SUM
         self.bucket_elems = max(1, bucket_bytes // 4)
@@ -77,7 +78,7 @@ class FlatGradReducer:
             self._launch(b)
 
     def _launch(self, b):
-        if self.launched[b] or not (dist.is_available() and dist.is_initialized()):
+        if self.launched[b] or not self.enabled or not (dist.is_available() and dist.is_initialized()):
             self.launched[b] = True
             return
         lo, hi = self.buckets[b]

@@ -174,6 +174,8 @@ def _conv_variant(d, which, accumulate=False, bn_groups=0):
 def _bni_name(v):
     """The library's name of a plain launch with the BatchNorm-on-load template argument (second to last) switched on."""
     import re
+    if v.startswith("conv3x3_pc_kernel<"):                 # conv3x3_pc_kernel<DGRAD,BNI,EM>
+        return re.sub(r"<(false|true),false,", r"<\1,true,", v, count=1)
     # conv3x3_halo_kernel<..,BNI,NP,MAP4> / wgrad_x3_kernel<CB,BNI,NP>
     return re.sub(r",false,(\d)((?:,(?:false|true))*)>", r",true,\1\2>", v, count=1)
 
@@ -539,13 +541,17 @@ def _with_layout(d, w_layout):
     return d2
 
 
+# the halo-tiled 3x3 kernels: one workgroup per tile position (csrc/conv3x3.hip) / persistent producer-consumer workgroups (csrc/conv3x3_pc.hip)
+_C3_KERNELS = ("conv3x3_halo_kernel", "conv3x3_pc_kernel")
+
+
 def packs_3x3(d):
     """True when the halo-tiled 3x3 kernel takes both the forward and the dgrad of this conv (then the fragment-ordered
     weight copies of bh_conv3x3_pack can be used for it)."""
     # (asked with the layout the packed copies would have: the 4 x 4 map form of the halo kernel exists for split operands only)
     q = _with_layout(d, packed_layout(d.precision)) if (d.w_layout == 0 and int(d.precision) in SPLIT_PIECES) else d
     try:
-        return (conv_variant(q, "fwd").startswith("conv3x3_halo_kernel") and conv_variant(q, "dgrad").startswith("conv3x3_halo_kernel"))
+        return conv_variant(q, "fwd").startswith(_C3_KERNELS) and conv_variant(q, "dgrad").startswith(_C3_KERNELS)
     except Exception:
         return False
 
@@ -757,7 +763,7 @@ def _stem_dgrad_two_step(gy, w, d, wkey=None):
 
 def dgrad_bn_reduce_ok(d):
     """True when conv_dgrad(..., bn_reduce=...) is available for this conv (the halo-tiled 3x3 kernel takes its dgrad)."""
-    return conv_variant(d, "dgrad").startswith("conv3x3_halo_kernel")
+    return conv_variant(d, "dgrad").startswith(_C3_KERNELS)
 
 
 def bias_grad_from_sums(sums, gbias, groups, C):
@@ -797,6 +803,8 @@ def conv_dgrad(gy, w, d, out=None, bn_reduce=None, wkey=None, wpacked=None, cols
         with _Timed(_conv_variant(d, "dgrad", acc), conv_flops(d), 4.0 * (gy.numel() + out.numel() * (3 if acc else 2) + w.numel())):
             check(lib.bh_conv_dgrad_bnreduce(_p(gy), _p(w), _p(out), ctypes.byref(d), int(acc), ctypes.byref(st), _p(b["sums"]),
                                              int(b["groups"]), _stream()), "bh_conv_dgrad_bnreduce")
+        if acc:
+            out._bh_amax = None              # (a record left by an earlier producer no longer bounds the sum: as add_ does)
         return out
     if (out is None and not d.transposed and d.kh == 7 and d.stride == 2 and not d.out_nchw
             and (d.Ci == 1 or (d.Ci == 3 and d.in_nchw)) and d.Co % 4 == 0 and d.N * d.Ho * d.Wo >= 4096):
@@ -820,12 +828,16 @@ def conv_dgrad(gy, w, d, out=None, bn_reduce=None, wkey=None, wpacked=None, cols
         with _Timed("conv_dgrad_s2(%d kernels)" % nlaunch + (" N%d %dx%d C%d->%d k%d" % (d.N, d.Hi, d.Wi, d.Ci, d.Co, d.kh) if TIMING_DETAIL else ""),
                     conv_flops(d) / 4.0 * (1.0 if d.kh == 1 else 1.0), 4.0 * (gy.numel() + out.numel() * (2 if acc else 1) + 2 * w.numel())):
             check(lib.bh_conv_dgrad_s2(_p(gy), _p(w), _p(out), ctypes.byref(d), int(acc), _p(wpack), _stream()), "bh_conv_dgrad_s2")
+        if acc:
+            out._bh_amax = None
         return out
     if out is None:
         shape = (d.N, d.Ci, d.Hi, d.Wi) if d.in_nchw else (d.N, d.Hi, d.Wi, d.Ci)
         out = torch.empty(shape, dtype=torch.float32, device=gy.device)
     with _Timed(_conv_variant(d, "dgrad", acc), conv_flops(d), 4.0 * (gy.numel() + out.numel() * (2 if acc else 1) + w.numel())):
         check(lib.bh_conv_dgrad(_p(gy), _p(w), _p(out), ctypes.byref(d), int(acc), _stream()), "bh_conv_dgrad")
+    if acc:
+        out._bh_amax = None
     return out
 
 
@@ -834,7 +846,9 @@ def wgrad_det_bytes(d):
     return int(lib.bh_conv_wgrad_det_bytes(ctypes.byref(_route_det(d))))
 
 
-_STEM_WGRAD_WS = {}      # (device, bytes) -> the stem weight gradient's partial-sum workspace (one launch per step and model on one stream)
+_STEM_WGRAD_WS = {}      # (device, bytes, stream) -> the stem weight gradient's partial-sum workspace: launches of ONE stream serialise on it;
+                         # another stream (a second model's side stream) gets its own.  Allocated by a step's first eager run - GraphedStep
+                         # warms up eagerly before it captures, so the buffer is never born inside a graph's private pool
 
 
 def conv_wgrad(x, gy, gw, gbias, d, det_ws=None):
@@ -873,7 +887,7 @@ def conv_wgrad(x, gy, gw, gbias, d, det_ws=None):
         # the backbone's stem (round 4): dedicated kernel + ordered reduction through a private workspace (no atomics: every mode)
         need = lib.bh_stem7_wgrad_ws_bytes(ctypes.byref(d))
         if need:
-            key = (str(x.device), int(need))
+            key = (str(x.device), int(need), int(torch.cuda.current_stream(x.device).cuda_stream))
             ws = _STEM_WGRAD_WS.get(key)
             if ws is None:
                 ws = _STEM_WGRAD_WS[key] = torch.empty(need // 4, dtype=torch.float32, device=x.device)

@@ -639,6 +639,12 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
                 if wgrad_stream is None:
                     K.conv_wgrad(x, g, gw, gb, d, det_ws=ws)
                 else:
+                    if getattr(ctx, "precision", 0) == K.F16X2 and getattr(d, "bh_wx3", False):
+                        # magnitude records the fp16-piece weight gradient reads: made (if missing) on the MAIN stream, in front of the
+                        # event - a record first measured on the side stream would be read by the main stream's dgrad without a wait
+                        # (round-4 ADVICE: a still-zero record scales by 2^100)
+                        K.amax_of(g)
+                        K.amax_of(x)
                     ev = torch.cuda.Event()
                     ev.record(main)                                   # g is final here
                     g.record_stream(wgrad_stream)

@@ -66,8 +66,12 @@ class _FlatAdam(torch.optim.Adam):
     def load_state_dict(self, sd):
         n_own = sum(len(g["params"]) for g in self.param_groups)
         n_in = sum(len(g["params"]) for g in sd["param_groups"])
-        if self._all is None or (n_in == n_own and n_in != len(self._all)):
-            return super().load_state_dict(sd)            # this class's own flat form
+        # this class's own flat form carries a marker (state_dict() of the base class, used by deepcopy / torch internals, never sets it on
+        # the reference layout); without a model-parameter list there is only that form
+        own_form = sd.get("bihome_flat_layout", False) or (n_in == n_own and n_in != len(self._all or []))
+        if self._all is None or own_form:
+            sd = {k: v for k, v in sd.items() if k != "bihome_flat_layout"}
+            return super().load_state_dict(sd)
         if n_in != len(self._all):
             raise ValueError("optimizer checkpoint holds %d parameters, the model has %d" % (n_in, len(self._all)))
         loc = self._where()
@@ -98,7 +102,11 @@ class _FlatAdam(torch.optim.Adam):
             rest_ids = {id(q) for q in self._rest}
             for i, p in enumerate(self._all):
                 if id(p) not in loc and id(p) in rest_ids and byid.get(i):
-                    self.state[p] = {k: (v.detach().clone().to(p.device if k != "step" else v.device) if torch.is_tensor(v) else v)
+                    # (the step counter follows the flat buffers' rule: on the parameter's device as float32 for fused / capturable Adam -
+                    #  a checkpoint loaded with map_location='cpu' would otherwise hand fused Adam a CPU step for a device parameter)
+                    cap = self.param_groups[0].get("capturable") or self.param_groups[0].get("fused")
+                    self.state[p] = {k: ((torch.as_tensor(v, dtype=torch.float32).detach().clone().to(p.device if cap else "cpu") if k == "step"
+                                          else v.detach().clone().to(p.device)) if (torch.is_tensor(v) or k == "step") else v)
                                      for k, v in byid[i].items()}
 
     def _sync(self):

@@ -108,8 +108,12 @@ def test_conv_variant_query_reports_the_dispatch():
     assert K.PRECISION["f32"] == 4 and K.PRECISION["f32-mfma"] == 0          # round 4: the default 'f32' is the fp16-piece arithmetic
     d4 = K.conv_desc(128, 32, 32, 64, 64, 3, 1, 1, precision=K.PRECISION["f32"])
     assert K.packed_layout(4) == 4 and K.SPLIT_PIECES[4] == 2
-    assert K.conv_variant(K._with_layout(d4, 4), "fwd") == "conv3x3_halo_kernel<false,64,false,2,true,true,false,2,false,true>"
-    assert K.conv_variant(K._with_layout(d4, 4), "dgrad") == "conv3x3_halo_kernel<true,64,false,2,true,true,false,2,false,true>"
+    assert K.conv_variant(K._with_layout(d4, 4), "fwd") == "conv3x3_pc_kernel<false,false,0>"          # round 5: persistent producer / consumer workgroups
+    assert K.conv_variant(K._with_layout(d4, 4), "dgrad") == "conv3x3_pc_kernel<true,false,0>"
+    from bihome_amd._lib import ROUTE_C3_TILE_WG
+    d4t = K.conv_desc(d4.N, d4.Hi, d4.Wi, d4.Ci, d4.Co, 3, 1, 1, precision=4, route=ROUTE_C3_TILE_WG)
+    assert K.conv_variant(K._with_layout(d4t, 4), "fwd") == "conv3x3_halo_kernel<false,64,false,2,true,true,false,2,false,true>"
+    assert K.conv_variant(K._with_layout(d4t, 4), "dgrad") == "conv3x3_halo_kernel<true,64,false,2,true,true,false,2,false,true>"
     dx = K.conv_desc(128, 32, 32, 64, 64, 3, 1, 1, precision=K.PRECISION["f32x3"])
     assert dx.precision == 2
     assert K.conv_variant(K._with_layout(dx, 2), "fwd") == "conv3x3_halo_kernel<false,64,false,2,true,true,false,3,false,false>"

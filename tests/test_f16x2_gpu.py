@@ -57,7 +57,9 @@ def test_conv3x3_f16x2_forward_and_dgrad(K, N, H, Ci, Co, wide):
         pk, pf, pd = _packed(K, w, prec)
         dp = K._with_layout(d, K.packed_layout(prec))
         if prec == 4:
-            assert K.conv_variant(dp, "fwd").endswith(",true,true,false,2,false,true>") and K.conv_variant(dp, "dgrad").endswith(",2,false,true>")
+            # (round 5: the 64-channel tile runs on the persistent producer / consumer kernel, the 32-channel tile on the halo kernel)
+            assert K.conv_variant(dp, "fwd").endswith((",true,true,false,2,false,true>", "conv3x3_pc_kernel<false,false,0>"))
+            assert K.conv_variant(dp, "dgrad").endswith((",2,false,true>", "conv3x3_pc_kernel<true,false,0>"))
         y = K.conv_fwd(x, wk, b, d, wpacked=pf)
         s = K.bn_stats_buffer(1, Co, "cuda")
         assert torch.equal(y, K.conv_fwd(x, wk, b, d, bn_sums=s, groups=1, wpacked=pf))
@@ -69,7 +71,7 @@ def test_conv3x3_f16x2_forward_and_dgrad(K, N, H, Ci, Co, wide):
         err[prec] = (_rel(y, ref), _rel(gx, refd))
     print("\nf16x2 fwd/dgrad N%d H%d %d->%d%s: rel-L2 vs f64  fp32-mfma %.2e / %.2e  f32x3 %.2e / %.2e  f32x2 %.2e / %.2e  f16x2 %.2e / %.2e"
           % (N, H, Ci, Co, " wide" if wide else "", *err[0], *err[2], *err[3], *err[4]))
-    assert err[4][0] <= 4.0 * err[0][0] and err[4][1] <= 4.0 * err[0][1], err
+    assert err[4][0] <= 1.5 * err[0][0] and err[4][1] <= 1.5 * err[0][1], err       # (measured 0.6-0.7 x the fp32-input MFMA kernel's error; round-4 VERDICT: was 4 x)
     assert err[4][0] < 0.2 * err[3][0] and err[4][1] < 0.2 * err[3][1], err       # and well below the two-piece bf16 form
 
 
@@ -130,12 +132,12 @@ def test_wgrad_f16x2_kernel(K, N, H, Ci, Co):
             K.conv_wgrad(x, gy, gw3, None, d)                                                    # atomics form
             assert _rel(gw3, gw.cpu().double()) < 2e-6
     print("\nf16x2 wgrad N%d H%d %d->%d: rel-L2 vs f64  fp32-mfma %.2e  f32x3 %.2e  f32x2 %.2e  f16x2 %.2e" % (N, H, Ci, Co, err[0], err[2], err[3], err[4]))
-    assert err[4] <= 4.0 * err[0] + 1e-8 and err[4] < 0.25 * err[3], err
+    assert err[4] <= 1.5 * err[0] + 1e-8 and err[4] < 0.25 * err[3], err       # (measured 0.75 x)
 
 
 def test_conv3x3_f16x2_error_bound_under_cancellation(K):
     """Dot products whose terms cancel to ~1e-4 of sum |a||b|, operands with all 24 significand bits set: the ABSOLUTE error in units
-    of sum_k |a_k||b_k| 2^-24 stays a small constant (f32x3: <= 4; f16x2 drops 2 bits per operand: <= 16)."""
+    of sum_k |a_k||b_k| 2^-24 stays a small constant (f32x3: <= 4; f16x2 drops 2 bits per operand: measured 0.65, asserted < 2)."""
     from bihome_amd._lib import ROUTE_HALO_SMALL
     N, H, Ci, Co = 8, 16, 64, 64
     g = torch.Generator().manual_seed(77)
@@ -157,7 +159,7 @@ def test_conv3x3_f16x2_error_bound_under_cancellation(K):
         y = K.conv_fwd(x, wk, None, d, wpacked=pf)
         ulps[prec] = ((y.cpu().double() - ref).abs() / (mag * 2.0 ** -24)).max().item()
     print("\ncancellation: max |err| / (sum|a||b| 2^-24): fp32-mfma %.2f  f32x3 %.2f  f32x2 %.2f  f16x2 %.2f" % (ulps[0], ulps[2], ulps[3], ulps[4]))
-    assert ulps[4] < 16.0 and ulps[4] < 0.1 * ulps[3], ulps
+    assert ulps[4] < 2.0 and ulps[4] < 0.1 * ulps[3], ulps       # (measured 0.65; the fp32-input MFMA kernel 0.17: the one case where the mode is weaker)
 
 
 @pytest.mark.parametrize("N,H,Ci,Co,relu", [(8, 16, 64, 64, True), (4, 32, 32, 32, False), (16, 8, 256, 256, True), (6, 24, 128, 64, True)])
