@@ -800,7 +800,7 @@ extern "C" int bh_debug_read_c3_stamps(unsigned long long* out, int n) {
 }
 void bh_conv3x3_tune(int disable, int min_blocks) {
     (void)min_blocks;
-    if (disable == 70 || disable == 71) { g_c3_stamp = disable - 70; return; }        // phase time stamps off / on
+    if (disable >= 500 && disable < 1000) { g_c3_stamp = disable - 500; return; }     // (-40, n): phase time stamps off (0) / on (halo kernel: any n > 0; persistent kernel: workgroup n - 1)
     if (disable >= 200 && disable < 264) { g_c3_desync = disable - 200; return; }
     if (disable == 300 || disable == 301) { g_c3_walk32 = disable - 300; return; }         // (-43, 0|1): several positions per workgroup in the 32-channel launches without statistics off / on
     if (disable == 310 || disable == 311) { g_c3_pc = disable - 310; return; }            // (-44, 0|1): persistent producer / consumer kernel off / on
@@ -911,7 +911,7 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
     // to the one-workgroup-per-tile kernel below (BH_ROUTE_C3_TILE_WG: A/B measurements, the bit-identity tests)
     if (f16 && !map4 && bn_tile == 64 && !(d->route & (BH_ROUTE_C3_TILE_WG | BH_ROUTE_C3_ONE_SUBTILE | BH_ROUTE_C3_ONE_POSITION)) && g_c3_pc) {
         C3Args b = a;
-        b.det = (d->route & BH_ROUTE_DETERMINISTIC) ? 1 : 0; b.dbg_noload = g_c3_noload;
+        b.det = (d->route & BH_ROUTE_DETERMINISTIC) ? 1 : 0; b.dbg_noload = g_c3_noload; b.dbg_ts = g_c3_stamp;
         const int st = bh_conv3x3_pc_launch(b, dgrad, bni ? bni->table : nullptr, bni ? bni->groups : 0, bni ? bni->relu : 0, false, stream);
         if (st != BH_E_UNSUPPORTED) { if (st == BH_OK) *taken = 1; return st; }
     }

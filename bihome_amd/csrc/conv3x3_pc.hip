@@ -9,12 +9,12 @@
 //                   [32 wn, 32 wn + 32) as before; a tap is two halves of six MFMAs (16-channel step 0 / 1), the fragments of the next half
 //                   are requested while the current half multiplies (two register sets, no copies).  At a tile's end the accumulators go
 //                   to an LDS hand-over tile (32 ds_write_b32 per wave) and the next tile starts at once.
-//   waves 4-5    H  halo staging: a 32-channel chunk's two 10 x 10 halos global -> registers -> BatchNorm-on-load (optional) -> two fp16
+//   waves 4-6    H  halo staging: a 32-channel chunk's two 10 x 10 halos global -> registers -> BatchNorm-on-load (optional) -> two fp16
 //                   pieces -> LDS.  TWO chunks are in flight (a register set per halo stage): a slot round is cut, written, and the same
 //                   registers request the round of the chunk after next - nothing else in these waves waits on the vector-memory counter,
 //                   so every load has two chunk times (~3.5 us) to arrive.  Lane = (halo pixel, 8-channel plane): whole 128-byte lines.
-//   waves 6-7    D  the packed weight fragments of kernel row r + 2 by LDS-DMA into a ring of three row slots (twelve 1 KB pieces per wave and
-//                   row; the only vector-memory traffic of these waves, so "the previous row has landed" is an exact counter wait).
+//   wave  7      D  the packed weight fragments of kernel row r + 2 by LDS-DMA into a ring of three row slots (24 pieces of 1 KB per row;
+//                   the only vector-memory traffic of this wave, so "the previous row has landed" is an exact counter wait).
 //   waves 8-11   E  the previous tile's epilogue out of the hand-over tile: 2^-(ka + kb) rescale, bias, accumulate / residual / ReLU,
 //                   BatchNorm statistics or BatchNorm-backward sums, with 16-byte loads and stores (lane = pixel x four channels: 1 KB
 //                   contiguous per instruction; the halo kernel stored 4 bytes per lane).  What a unit reads from HBM is requested four
@@ -43,7 +43,22 @@ constexpr int PC_RED_BYTES = 4 * 128 * 8;            // statistics partials of t
 constexpr int PC_LDS = PC_OFF_RED + PC_RED_BYTES;    // 162,304 B of 163,840
 constexpr unsigned PC_XOOB = 0x80000000u;            // out-of-range buffer offset (tensor sizes are below 2^31): the load returns zeros
 
+#ifdef BH_TUNING
+// barrier time stamps of workgroup 0 (shader clock): [role C / H / D / E][barrier number][arrival, release]
+__device__ unsigned long long g_pc_ts[4 * 160 * 2];
+#define PC_BARRIER()                                                                                                    \
+    do {                                                                                                                \
+        const bool st_ = a.dbg_ts && blockIdx.x == (unsigned)(a.dbg_ts - 1) && (tid & 63) == 0 && (wave == 0 || wave == 4 || wave == 7 || wave == 8);        \
+        const int role_ = wave == 0 ? 0 : (wave == 4 ? 1 : (wave == 7 ? 2 : 3));                                        \
+        if (st_ && pc_nb < 160) g_pc_ts[(role_ * 160 + pc_nb) * 2] = __builtin_readcyclecounter();                      \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                                \
+        if (st_ && pc_nb < 160) g_pc_ts[(role_ * 160 + pc_nb) * 2 + 1] = __builtin_readcyclecounter();                  \
+        ++pc_nb;                                                                                                        \
+    } while (0)
+#else
 #define PC_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+#define PC_H_ASM 0        // (1: the H waves' loads as inline assembly with hand-counted waits - see the note in the H role; not yet sound)
 #define PC_BARRIER_VM() asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 __device__ __forceinline__ void pc_decode(const C3Args& a, int g, int& img, int& ty, int& tx) {
@@ -68,6 +83,21 @@ __global__ void __launch_bounds__(768) conv3x3_pc_kernel(C3Args a) {
     const int nch = a.Kc >> 5;
     const int K = Tw * nch;                              // chunks
     const int R = K * 3;                                 // kernel rows = barrier phases
+#ifdef BH_TUNING
+    int pc_nb = 0;
+#endif
+
+    // wait until at most n vector-memory operations (the youngest n) are outstanding; everything the caller must not leave behind is older
+    auto wait_vm = [&](int n) {
+#define PC_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+        switch (n < 0 ? 0 : (n > 48 ? 48 : n)) {
+            PC_W(0) PC_W(1) PC_W(2) PC_W(3) PC_W(4) PC_W(5) PC_W(6) PC_W(7) PC_W(8) PC_W(9) PC_W(10) PC_W(11) PC_W(12) PC_W(13) PC_W(14) PC_W(15)
+            PC_W(16) PC_W(17) PC_W(18) PC_W(19) PC_W(20) PC_W(21) PC_W(22) PC_W(23) PC_W(24) PC_W(25) PC_W(26) PC_W(27) PC_W(28) PC_W(29) PC_W(30)
+            PC_W(31) PC_W(32) PC_W(33) PC_W(34) PC_W(35) PC_W(36) PC_W(37) PC_W(38) PC_W(39) PC_W(40) PC_W(41) PC_W(42) PC_W(43) PC_W(44) PC_W(45)
+            PC_W(46) PC_W(47) PC_W(48)
+        }
+#undef PC_W
+    };
 
     if (wave < 4) {
         // =============================== C: consumers ===============================
@@ -89,32 +119,45 @@ __global__ void __launch_bounds__(768) conv3x3_pc_kernel(C3Args a) {
         constexpr int dbg = 0;
 #endif
         // fragments of one half tap: ap = this lane's halo position of the tap, bp = this lane's slot of the tap's weight image
+#define PC_LD_A(A_, ap, s2, i_, pc_) A_[i_][pc_] = *reinterpret_cast<const uint4*>((ap) + (pc_) * PC_PIECE + 2 * (s2) * PC_PS + (i_) * 64)
+#define PC_LD_B(B_, bp, s2, pc_) B_[pc_] = *reinterpret_cast<const uint4*>((bp) + ((pc_) * 2 + (s2)) * 1024)
 #define PC_LOADH(A_, B_, ap, bp, s2)                                                                                    \
     do {                                                                                                                \
-        if (!(dbg & 2)) {                                                                                               \
-        _Pragma("unroll") for (int pc_ = 0; pc_ < 2; ++pc_) {                                                           \
-            _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                            \
-                A_[i_][pc_] = *reinterpret_cast<const uint4*>((ap) + pc_ * PC_PIECE + 2 * (s2) * PC_PS + i_ * 64);      \
-            B_[pc_] = *reinterpret_cast<const uint4*>((bp) + (pc_ * 2 + (s2)) * 1024);                                   \
-        }                                                                                                               \
-        }                                                                                                               \
+        PC_LD_A(A_, ap, s2, 0, 1); PC_LD_B(B_, bp, s2, 0); PC_LD_A(A_, ap, s2, 1, 1);                                   \
+        PC_LD_A(A_, ap, s2, 0, 0); PC_LD_B(B_, bp, s2, 1); PC_LD_A(A_, ap, s2, 1, 0);                                   \
     } while (0)
-        // products lo*hi, hi*lo, hi*hi (small first), fragment 0 then 1: the order of conv3x3_halo_kernel's X3_MFMA
-#define PC_MFMA6(A_, B_)                                                                                                \
+        // One half tap: six products - lo*hi, hi*lo, hi*hi (small first) for fragment 0 and 1, the order of conv3x3_halo_kernel's X3_MFMA per
+        // accumulator - ALTERNATING between the two accumulators, each followed by one fragment request of the next half tap (in the order
+        // that half will use them).  sched_barrier(0) pins this order: left alone the compiler issues the three products of an accumulator
+        // back to back, and a v_mfma_f32_32x32x16_f16 that depends on the one in front of it waits ~20 cycles beyond the 32 of the
+        // pipe (tools/pc_timeline.py: 2.0 kilo-cycles per kernel row of 36 MFMAs where 1.15 are the pipe's).
+#define PC_STEP(ACC, AV, BV, LD)                                                                                        \
     do {                                                                                                                \
-        if (!(dbg & 1)) {                                                                                               \
-        acc[0] = c3_mfma16<true>(A_[0][1], B_[0], acc[0]); acc[1] = c3_mfma16<true>(A_[1][1], B_[0], acc[1]);           \
-        acc[0] = c3_mfma16<true>(A_[0][0], B_[1], acc[0]); acc[1] = c3_mfma16<true>(A_[1][0], B_[1], acc[1]);           \
-        acc[0] = c3_mfma16<true>(A_[0][0], B_[0], acc[0]); acc[1] = c3_mfma16<true>(A_[1][0], B_[0], acc[1]);           \
-        }                                                                                                               \
+        ACC = c3_mfma16<true>(AV, BV, ACC);                                                                             \
+        LD;                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
     } while (0)
-        // one MFMA : one LDS read, six times (the requests of the other register set ride in the gaps of this half's products)
-#define PC_INTERLEAVE()                                                                                                 \
+#define PC_HALF(UA, UB, LA, LB, ap, bp, s2)                                                                             \
     do {                                                                                                                \
-        _Pragma("unroll") for (int g_ = 0; g_ < 6; ++g_) {                                                              \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                          \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                          \
-        }                                                                                                               \
+        PC_STEP(acc[0], UA[0][1], UB[0], PC_LD_A(LA, ap, s2, 0, 1));                                                    \
+        PC_STEP(acc[1], UA[1][1], UB[0], PC_LD_B(LB, bp, s2, 0));                                                       \
+        PC_STEP(acc[0], UA[0][0], UB[1], PC_LD_A(LA, ap, s2, 1, 1));                                                    \
+        PC_STEP(acc[1], UA[1][0], UB[1], PC_LD_A(LA, ap, s2, 0, 0));                                                    \
+        PC_STEP(acc[0], UA[0][0], UB[0], PC_LD_B(LB, bp, s2, 1));                                                       \
+        PC_STEP(acc[1], UA[1][0], UB[0], PC_LD_A(LA, ap, s2, 1, 0));                                                    \
+    } while (0)
+        // the half tap in front of a barrier: its six requests (the row's LAST fragments) go out first, so that they have returned when the
+        // six products are through and the lgkmcnt(0) in front of the barrier does not drain the pipe
+#define PC_HALF_PRE(UA, UB, LA, LB, ap, bp, s2)                                                                         \
+    do {                                                                                                                \
+        PC_LOADH(LA, LB, ap, bp, s2);                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        PC_STEP(acc[0], UA[0][1], UB[0], (void)0);                                                                      \
+        PC_STEP(acc[1], UA[1][1], UB[0], (void)0);                                                                      \
+        PC_STEP(acc[0], UA[0][0], UB[1], (void)0);                                                                      \
+        PC_STEP(acc[1], UA[1][0], UB[1], (void)0);                                                                      \
+        PC_STEP(acc[0], UA[0][0], UB[0], (void)0);                                                                      \
+        PC_STEP(acc[1], UA[1][0], UB[0], (void)0);                                                                      \
     } while (0)
         PC_BARRIER();                                    // B(-1): halo stage 0 and weight row 0 are in LDS
         PC_LOADH(FA0, FB0, aL, bL, 0);
@@ -135,22 +178,26 @@ __global__ void __launch_bounds__(768) conv3x3_pc_kernel(C3Args a) {
                     // harmless, and the loop body stays branch-free)
                     const char* const nrp = row < 2 ? rp + 160 : (more ? aL + (par ^ 1) * PC_STAGE : rp);
                     const char* const nsp = row < 2 ? sp + PC_BROW : bL;
+                    if (dbg & 1) { PC_BARRIER(); continue; }       // (ablation: barriers only)
 #pragma unroll
                     for (int t = 0; t < 3; ++t) {
-                        // half 0: step 1 of this tap is requested, step 0 multiplies
-                        PC_LOADH(FA1, FB1, rp + t * 16, sp + t * PC_BTAP, 1);
-                        PC_MFMA6(FA0, FB0);
-                        PC_INTERLEAVE();
-                        if (t == 2) PC_BARRIER();        // B(rho): the row's last fragments are on their way - its weight slot (row 2: and the halo stage) are free
-                        // half 1: step 0 of the next tap is requested, step 1 multiplies
-                        if (t < 2) PC_LOADH(FA0, FB0, rp + (t + 1) * 16, sp + (t + 1) * PC_BTAP, 0);
-                        else PC_LOADH(FA0, FB0, nrp, nsp, 0);
-                        PC_MFMA6(FA1, FB1);
-                        PC_INTERLEAVE();
+                        // half 0: step 0 multiplies, step 1 of this tap is requested
+                        if (t < 2) PC_HALF(FA0, FB0, FA1, FB1, rp + t * 16, sp + t * PC_BTAP, 1);
+                        else {
+                            PC_HALF_PRE(FA0, FB0, FA1, FB1, rp + t * 16, sp + t * PC_BTAP, 1);
+                            PC_BARRIER();                // B(rho): the row's last fragments are in registers - its weight slot (row 2: and the halo stage) are free
+                        }
+                        // half 1: step 1 multiplies, step 0 of the next tap is requested
+                        if (t < 2) PC_HALF(FA1, FB1, FA0, FB0, rp + (t + 1) * 16, sp + (t + 1) * PC_BTAP, 0);
+                        else PC_HALF(FA1, FB1, FA0, FB0, nrp, nsp, 0);
                     }
                 }
             }
-            // hand the accumulators over: element (i, r) = pixel (strip row of (r >> 2, kh2), x = 4 i + (r & 3)), channel wn * 32 + l31
+            // hand the accumulators over: element (i, r) = pixel (strip row of (r >> 2, kh2), x = 4 i + (r & 3)), channel wn * 32 + l31.
+            // The last products must have left the matrix pipe before their registers are read: the compiler's hazard padding did not
+            // survive the loop structure in every instantiation (dgrad + BatchNorm sums: sporadic stale quads in the first row of a tile),
+            // so the wait states are spelled out - 32 of them per tile, tied to both accumulators.
+            asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -161,35 +208,40 @@ __global__ void __launch_bounds__(768) conv3x3_pc_kernel(C3Args a) {
         PC_BARRIER();                                    // F2
         PC_BARRIER();                                    // F3
         PC_BARRIER();                                    // F4
+#undef PC_HALF_PRE
+#undef PC_HALF
+#undef PC_STEP
 #undef PC_LOADH
-#undef PC_MFMA6
-#undef PC_INTERLEAVE
+#undef PC_LD_A
+#undef PC_LD_B
         return;
     }
 
-    if (wave < 8) {
-        // =============================== H: halo staging (4 waves) ===============================
-        // Slot round j (0 .. 3) of a chunk: halo pixel hp = j * 64 + (ht >> 2) of the [2 sub-tiles][10][10] image, this thread's 8-channel
+    if (wave < 7) {
+        // =============================== H: halo staging (3 waves) ===============================
+        // Slot round j (0 .. 4) of a chunk: halo pixel hp = j * 48 + (ht >> 2) of the [2 sub-tiles][10][10] image, this thread's 8-channel
         // plane (ht & 3).  Chunk k lives in register set k & 1 (= its halo stage): round j of chunk k + 1 is cut and written in the row
         // phases listed below and the same registers immediately request round j of chunk k + 3.
+        //
+        // The loads are inline assembly with hand-counted waits: left to the compiler, a load whose use lies two chunk loops ahead is waited
+        // for with vmcnt(0) - i.e. together with everything requested since, one HBM round trip per row phase (tools/pc_timeline.py: the H
+        // waves were the last at 22 of 29 barriers).  nis counts this wave's loads; seq[j] = nis right after round j's requests, so
+        // "nis - seq[j]" younger loads may stay in flight when round j is needed.  Between a request and its wait statement - which names
+        // the registers - the values are only carried, never read.  So that the compiler has no reason to COPY a register whose load is
+        // still in flight, every request and every wait is unconditional straight-line code (a round that has nothing to load asks for an
+        // out-of-range offset: zeros, at once); only the cut arithmetic and the LDS stores sit under conditions, and the chunk loop is
+        // unrolled by two so that the register set is a compile-time choice.
+        // (the producers' instruction streams are short and must not wait for issue slots behind the consumer wave of their SIMD, which is
+        //  older and would win every arbitration: tools/pc_timeline.py showed ~20 cycles per H / E instruction at equal priority)
+        __builtin_amdgcn_s_setprio(2);
         const int ht = tid - 256;
         const int plane = ht & 3;
         const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Src), 0, a.src_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BNI ? a.bni : a.Src), 0,
                                                                               BNI ? (unsigned)(a.bni_groups * a.Kc * 8) : 0u, 0x00020000);
-        constexpr int NR = 4;
-        int lo[NR];                                       // LDS byte offset of the slot inside a piece image
-        int hsub[NR], hyx[NR];                            // sub-tile, (hy << 8) | hx
-#pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            const int hp = j * 64 + (ht >> 2);
-            const int s_ = hp >= 100 ? 1 : 0, p_ = hp - 100 * s_;
-            const int hy = (p_ * 205) >> 11, hx = p_ - hy * 10;
-            hsub[j] = s_; hyx[j] = (hy << 8) | hx;
-            lo[j] = plane * PC_PS + hp * 16;
-        }
+        constexpr int NR = 5;
+        const int lo0 = plane * PC_PS + (ht >> 2) * 16;   // LDS byte offset of round 0's slot inside a piece image (round j: + j * 48 * 16)
         unsigned xoff[NR];                                // global byte offset of the slot's 32 bytes in chunk 0 of the tile being loaded (PC_XOOB: padding)
-        unsigned tboff = 0;                               // BNI: byte offset of this plane's coefficients in chunk 0 of that tile's group
         auto h_tile = [&](int wt) {
             const int bx = wt % a.gx_total;
             int org[2], oy0[2], ox0[2];
@@ -200,142 +252,191 @@ __global__ void __launch_bounds__(768) conv3x3_pc_kernel(C3Args a) {
                 pc_decode(a, g < a.subtiles ? g : 0, img, ty, tx);
                 oy0[s_] = ty * 8 - 1; ox0[s_] = tx * 8 - 1;
                 org[s_] = g < a.subtiles ? (img * a.H + oy0[s_]) * a.W + ox0[s_] : (int)0x80000000;
-                if (BNI && s_ == 0) tboff = (unsigned)((img / a.bni_ipg) * a.Kc + plane * 8) * 8u;
             }
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
-                const int s_ = hsub[j], hy = hyx[j] >> 8, hx = hyx[j] & 255;
+                const int hp = j * 48 + (ht >> 2);
+                const int s_ = hp >= 100 ? 1 : 0, p_ = hp - 100 * s_;
+                const int hy = (p_ * 205) >> 11, hx = p_ - hy * 10;
                 const int y = (s_ ? oy0[1] : oy0[0]) + hy, x = (s_ ? ox0[1] : ox0[0]) + hx;
                 const int o = s_ ? org[1] : org[0];
                 unsigned off = PC_XOOB;
-                if (j * 64 + (ht >> 2) < PC_HPL && o != (int)0x80000000 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
+                if (hp < PC_HPL && o != (int)0x80000000 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
                     off = ((unsigned)(o + hy * a.W + hx) * (unsigned)a.Kc + (unsigned)(plane * 8)) * 4u;
                 xoff[j] = off;
             }
         };
-        float4 hA[NR][2], hB[NR][2];                      // the rounds in flight: even chunks / odd chunks
-        float4 tbA[4], tbB[4];                            // BNI: (scale, shift) of this plane's 8 channels of those chunks
+        typedef float pc_f4 __attribute__((ext_vector_type(4)));
+        pc_f4 hA[NR][2], hB[NR][2];                       // the rounds in flight: even chunks / odd chunks
+        pc_f4 tb[4];                                      // BNI: (scale, shift) of this plane's 8 channels of the chunk being cut (ONE set: it is
+                                                          // requested when the previous chunk's last round has been cut, a row phase ahead)
         unsigned okA = 0, okB = 0;                        // bit j: slot round j of that chunk lies inside the image
+        int nis = 0, seq_tb = 0, seqA[NR] = {0, 0, 0, 0, 0}, seqB[NR] = {0, 0, 0, 0, 0};
         int li_t = 0, li_c = 0;                           // (tile, chunk of the tile) whose rounds are being requested
-        // (the last round holds 32 slots: the first half-wave of wave 4)
-#define PC_H_LIVE(j) ((j) * 256 + (wave - 4) * 64 < 4 * PC_HPL)
-        auto h_issue = [&](auto J, float4 (&h)[NR][2], float4 (&tb)[4], unsigned& okm) {
-            constexpr int j = decltype(J)::value;
-            if (j == 0) {
-                if (li_c == 0) h_tile(wt0 + li_t);
-                if constexpr (BNI) {
+        // the coefficients of chunk number k (its tile's statistics group, its 32 channels, this thread's plane); k >= K: nothing (zeros)
+        auto tb_issue = [&](int k) {
+            const int ti_ = k / nch, c_ = k - ti_ * nch;
+            const int bx = (wt0 + (k < K ? ti_ : 0)) % a.gx_total;
+            int img, ty, tx;
+            pc_decode(a, bx * 2 < a.subtiles ? bx * 2 : 0, img, ty, tx);
+            const unsigned vo = k < K ? (unsigned)((img / a.bni_ipg) * a.Kc + plane * 8) * 8u : PC_XOOB, so = (unsigned)(c_ * 256);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        tb[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsT, tboff + (unsigned)q * 16u, (unsigned)(li_c * 256), 0));
-                }
-            }
-            if (PC_H_LIVE(j)) {
-                h[j][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, xoff[j], (unsigned)(li_c * 128), 0));
-                h[j][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, xoff[j] + 16u, (unsigned)(li_c * 128), 0));
-            }
-            okm = (okm & ~(1u << j)) | ((xoff[j] != PC_XOOB ? 1u : 0u) << j);
-            if (j == NR - 1) { if (++li_c == nch) { li_c = 0; ++li_t; } }
+            for (int q = 0; q < 4; ++q)
+                tb[q] = __builtin_bit_cast(pc_f4, __builtin_amdgcn_raw_buffer_load_b128(rsT, vo + (unsigned)q * 16u, so, 0));
+            nis += 4; seq_tb = nis;
+        };
+        // round j of the next chunk in sequence (en: there is one - else an out-of-range request) -> register set h
+        auto h_issue = [&](auto J, pc_f4 (&h)[NR][2], unsigned& okm, int (&seq)[NR], bool en) {
+            constexpr int j = decltype(J)::value;
+            if (j == 0 && en && li_c == 0) h_tile(wt0 + li_t);
+            const unsigned vo = en ? xoff[j] : PC_XOOB, so = en ? (unsigned)(li_c * 128) : 0u;
+            h[j][0] = __builtin_bit_cast(pc_f4, __builtin_amdgcn_raw_buffer_load_b128(rsA, vo, so, 0));
+            h[j][1] = __builtin_bit_cast(pc_f4, __builtin_amdgcn_raw_buffer_load_b128(rsA, vo + 16u, so, 0));
+            nis += 2; seq[j] = nis;
+            okm = (okm & ~(1u << j)) | ((vo != PC_XOOB ? 1u : 0u) << j);
+            if (j == NR - 1 && en) { if (++li_c == nch) { li_c = 0; ++li_t; } }
         };
         float f16_s = 1.0f;
         const float bni_lo = a.bni_relu ? 0.0f : -__builtin_inff();
-        auto h_cut = [&](auto J, int stage, float4 (&h)[NR][2], float4 (&tb)[4], unsigned okm) {
+        // round j of register set h -> fp16 pieces in halo stage `stage` (en: the chunk exists)
+        auto h_cut = [&](auto J, int stage, pc_f4 (&h)[NR][2], unsigned okm, const int (&seq)[NR], bool en) {
             constexpr int j = decltype(J)::value;
-            if (PC_H_LIVE(j) && j * 64 + (ht >> 2) < PC_HPL) {
+            if constexpr (BNI) {
+                if (j == 0 && PC_H_ASM) {                  // this chunk's coefficients (younger than its rounds: everything older has then arrived too)
+                    wait_vm(nis - seq_tb);
+                    asm volatile("" : "+v"(tb[0]), "+v"(tb[1]), "+v"(tb[2]), "+v"(tb[3]));
+                }
+            }
+            if (PC_H_ASM) {
+                wait_vm(nis - seq[j]);                     // round j has arrived
+                asm volatile("" : "+v"(h[j][0]), "+v"(h[j][1]));
+            }
+            if (en && j * 48 + (ht >> 2) < PC_HPL) {
                 char* const st = smem + stage * PC_STAGE;
-                float4 u = h[j][0], v = h[j][1];
+                float4 u = make_float4(h[j][0][0], h[j][0][1], h[j][0][2], h[j][0][3]), v = make_float4(h[j][1][0], h[j][1][1], h[j][1][2], h[j][1][3]);
                 if constexpr (BNI) {
                     // y = max(x * scale + shift, lo) on the slot's 8 channels; padding stays zero
                     const bool ok = (okm >> j) & 1u;
-                    u.x = ok ? __builtin_elementwise_maximum(__builtin_fmaf(u.x, tb[0].x, tb[0].y), bni_lo) : 0.f;
-                    u.y = ok ? __builtin_elementwise_maximum(__builtin_fmaf(u.y, tb[0].z, tb[0].w), bni_lo) : 0.f;
-                    u.z = ok ? __builtin_elementwise_maximum(__builtin_fmaf(u.z, tb[1].x, tb[1].y), bni_lo) : 0.f;
-                    u.w = ok ? __builtin_elementwise_maximum(__builtin_fmaf(u.w, tb[1].z, tb[1].w), bni_lo) : 0.f;
-                    v.x = ok ? __builtin_elementwise_maximum(__builtin_fmaf(v.x, tb[2].x, tb[2].y), bni_lo) : 0.f;
-                    v.y = ok ? __builtin_elementwise_maximum(__builtin_fmaf(v.y, tb[2].z, tb[2].w), bni_lo) : 0.f;
-                    v.z = ok ? __builtin_elementwise_maximum(__builtin_fmaf(v.z, tb[3].x, tb[3].y), bni_lo) : 0.f;
-                    v.w = ok ? __builtin_elementwise_maximum(__builtin_fmaf(v.w, tb[3].z, tb[3].w), bni_lo) : 0.f;
+                    u.x = ok ? __builtin_elementwise_maximum(__builtin_fmaf(u.x, tb[0][0], tb[0][1]), bni_lo) : 0.f;
+                    u.y = ok ? __builtin_elementwise_maximum(__builtin_fmaf(u.y, tb[0][2], tb[0][3]), bni_lo) : 0.f;
+                    u.z = ok ? __builtin_elementwise_maximum(__builtin_fmaf(u.z, tb[1][0], tb[1][1]), bni_lo) : 0.f;
+                    u.w = ok ? __builtin_elementwise_maximum(__builtin_fmaf(u.w, tb[1][2], tb[1][3]), bni_lo) : 0.f;
+                    v.x = ok ? __builtin_elementwise_maximum(__builtin_fmaf(v.x, tb[2][0], tb[2][1]), bni_lo) : 0.f;
+                    v.y = ok ? __builtin_elementwise_maximum(__builtin_fmaf(v.y, tb[2][2], tb[2][3]), bni_lo) : 0.f;
+                    v.z = ok ? __builtin_elementwise_maximum(__builtin_fmaf(v.z, tb[3][0], tb[3][1]), bni_lo) : 0.f;
+                    v.w = ok ? __builtin_elementwise_maximum(__builtin_fmaf(v.w, tb[3][2], tb[3][3]), bni_lo) : 0.f;
                 }
                 uint4 p0, p1;
                 bh_split8_f16(u, v, f16_s, p0, p1);
-                *reinterpret_cast<uint4*>(st + lo[j]) = p0;
-                *reinterpret_cast<uint4*>(st + PC_PIECE + lo[j]) = p1;
+                *reinterpret_cast<uint4*>(st + lo0 + j * 768) = p0;
+                *reinterpret_cast<uint4*>(st + PC_PIECE + lo0 + j * 768) = p1;
             }
         };
 #ifdef BH_TUNING
-        const bool hoff = a.dbg_noload & 4;               // ablation: no halo staging at all (timing only)
+        const bool hon = !(a.dbg_noload & 4);             // ablation: no halo staging at all (timing only)
 #else
-        constexpr bool hoff = false;
+        constexpr bool hon = true;
 #endif
         using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>; using J2 = std::integral_constant<int, 2>;
-        using J3 = std::integral_constant<int, 3>;
-        // round j of chunk `stage`-parity -> LDS, then round j of the chunk two further -> in flight in the same registers.  (The BatchNorm
-        // coefficients of the chunk two further are requested with its round 0: they must not replace this chunk's before its round 3 is
-        // cut - the set's coefficient registers are reloaded by round 3's issue instead.)
-#define PC_H_ROUND(J, cut, issue, stage)                                                                                \
+        using J3 = std::integral_constant<int, 3>; using J4 = std::integral_constant<int, 4>;
+        // the three row phases of chunk number kap_: chunk kap_ + 1 (register set / halo stage SET) -> LDS in three shares, chunk kap_ + 3
+        // into flight behind each share; BatchNorm-on-load: chunk kap_ + 2's coefficients once chunk kap_ + 1 is through
+#define PC_H_CHUNK(kap_, h, okm, seq, SET, AHEAD)                                                                       \
     do {                                                                                                                \
-        if (stage) { if (cut) h_cut(J{}, 1, hB, tbB, okB); if (issue) h_issue(J{}, hB, tbB, okB); }                     \
-        else       { if (cut) h_cut(J{}, 0, hA, tbA, okA); if (issue) h_issue(J{}, hA, tbA, okA); }                     \
+        const bool cut_ = (kap_) + 1 < K && hon, iss_ = (kap_) + (AHEAD) < K && hon;                                    \
+        h_cut(J0{}, SET, h, okm, seq, cut_); h_issue(J0{}, h, okm, seq, iss_);                                          \
+        h_cut(J1{}, SET, h, okm, seq, cut_); h_issue(J1{}, h, okm, seq, iss_);                                          \
+        PC_BARRIER();                                 /* row 0 */                                                       \
+        h_cut(J2{}, SET, h, okm, seq, cut_); h_issue(J2{}, h, okm, seq, iss_);                                          \
+        h_cut(J3{}, SET, h, okm, seq, cut_); h_issue(J3{}, h, okm, seq, iss_);                                          \
+        PC_BARRIER();                                 /* row 1 */                                                       \
+        h_cut(J4{}, SET, h, okm, seq, cut_); h_issue(J4{}, h, okm, seq, iss_);                                          \
+        if constexpr (BNI) tb_issue(hon ? (kap_) + 2 : K);                                                              \
+        PC_BARRIER();                                 /* row 2 */                                                       \
     } while (0)
-#define PC_H_ALL(cut, issue, stage)                                                                                     \
-    do {                                                                                                                \
-        PC_H_ROUND(J0, cut, issue, stage); PC_H_ROUND(J1, cut, issue, stage); PC_H_ROUND(J2, cut, issue, stage);        \
-        PC_H_ROUND(J3, cut, issue, stage);                                                                              \
-    } while (0)
-        if (!hoff) {
-            // chunks 0 and 1 requested at once (then the source tensor's scale, whose loads ride behind them); chunk 0 cut; chunk 2 requested
-            PC_H_ALL(false, true, 0);
-            if (1 < K) PC_H_ALL(false, true, 1);
+#define PC_H_ISSUE_ALL(h, okm, seq, en)                                                                                 \
+    do { h_issue(J0{}, h, okm, seq, en); h_issue(J1{}, h, okm, seq, en); h_issue(J2{}, h, okm, seq, en);                \
+         h_issue(J3{}, h, okm, seq, en); h_issue(J4{}, h, okm, seq, en); } while (0)
+        if constexpr (!BNI) {
+            // chunks 0 and 1 requested at once (then the source tensor's scale, whose loads the compiler waits for - and with them, being
+            // younger, for both chunks); chunk 0 cut; chunk 2 requested
+            PC_H_ISSUE_ALL(hA, okA, seqA, hon);
+            PC_H_ISSUE_ALL(hB, okB, seqB, 1 < K && hon);
             f16_s = __builtin_bit_cast(float, (unsigned)(127 + bh_f16_scale_exp(bh_amax_read(a.amax_src, lane))) << 23);
-            PC_H_ALL(true, false, 0);
-            if (2 < K) PC_H_ALL(false, true, 0);
-        }
-        PC_BARRIER();                                     // B(-1)
-        for (int kap = 0; kap < K; ++kap) {
-            // chunk kap + 1 -> the stage the consumers left at B(3 kap - 1), in three shares; chunk kap + 3 into flight behind each share
-            const bool cut = kap + 1 < K && !hoff, iss = kap + 3 < K && !hoff;
-            const int stg = (kap + 1) & 1;
-            // (BatchNorm-on-load: a chunk's coefficients are requested with its round 0, i.e. while the later rounds of the chunk two before
-            //  are still to be cut with THEIR coefficients - so the whole chunk is cut before any of its registers is re-requested)
-            if constexpr (BNI) {
-                PC_H_ROUND(J0, cut, false, stg); PC_H_ROUND(J1, cut, false, stg);
-                PC_BARRIER();                             // row 0
-                PC_H_ROUND(J2, cut, false, stg);
-                PC_BARRIER();                             // row 1
-                PC_H_ROUND(J3, cut, false, stg);
-                PC_H_ALL(false, iss, stg);
-                PC_BARRIER();                             // row 2
-            } else {
-                PC_H_ROUND(J0, cut, iss, stg); PC_H_ROUND(J1, cut, iss, stg);
-                PC_BARRIER();                             // row 0
-                PC_H_ROUND(J2, cut, iss, stg);
-                PC_BARRIER();                             // row 1
-                PC_H_ROUND(J3, cut, iss, stg);
-                PC_BARRIER();                             // row 2
+            h_cut(J0{}, 0, hA, okA, seqA, hon); h_cut(J1{}, 0, hA, okA, seqA, hon); h_cut(J2{}, 0, hA, okA, seqA, hon);
+            h_cut(J3{}, 0, hA, okA, seqA, hon); h_cut(J4{}, 0, hA, okA, seqA, hon);
+            PC_H_ISSUE_ALL(hA, okA, seqA, 2 < K && hon);
+            PC_BARRIER();                                 // B(-1)
+            for (int kap = 0; kap < K; kap += 2) {
+                PC_H_CHUNK(kap, hB, okB, seqB, 1, 3);     // chunk kap + 1 (odd) lives in set B / stage 1
+                if (kap + 1 < K) PC_H_CHUNK(kap + 1, hA, okA, seqA, 0, 3);
             }
+        } else {
+            // BatchNorm-on-load: ONE register set (the coefficient registers and the transform's temporaries take the room of the second):
+            // a round of chunk kap + 1 is cut and the same registers request that round of chunk kap + 2 - one chunk time in flight
+            (void)hB; (void)okB; (void)seqB;
+            tb_issue(hon ? 0 : K);
+            PC_H_ISSUE_ALL(hA, okA, seqA, hon);
+            f16_s = __builtin_bit_cast(float, (unsigned)(127 + bh_f16_scale_exp(bh_amax_read(a.amax_src, lane))) << 23);
+            h_cut(J0{}, 0, hA, okA, seqA, hon); h_cut(J1{}, 0, hA, okA, seqA, hon); h_cut(J2{}, 0, hA, okA, seqA, hon);
+            h_cut(J3{}, 0, hA, okA, seqA, hon); h_cut(J4{}, 0, hA, okA, seqA, hon);
+            tb_issue(hon ? 1 : K);
+            PC_H_ISSUE_ALL(hA, okA, seqA, 1 < K && hon);
+            PC_BARRIER();                                 // B(-1)
+            for (int kap = 0; kap < K; ++kap) PC_H_CHUNK(kap, hA, okA, seqA, (kap + 1) & 1, 2);
         }
         PC_BARRIER();                                     // F1
         PC_BARRIER();                                     // F2
         PC_BARRIER();                                     // F3
         PC_BARRIER();                                     // F4
-#undef PC_H_ALL
-#undef PC_H_ROUND
-#undef PC_H_LIVE
+#undef PC_H_ISSUE_ALL
+#undef PC_H_CHUNK
         return;
     }
 
-    // wait until at most n vector-memory operations (the youngest n) are outstanding; everything the caller must not leave behind is older
-    auto wait_vm = [&](int n) {
-#define PC_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-        switch (n < 0 ? 0 : (n > 36 ? 36 : n)) {
-            PC_W(0) PC_W(1) PC_W(2) PC_W(3) PC_W(4) PC_W(5) PC_W(6) PC_W(7) PC_W(8) PC_W(9) PC_W(10) PC_W(11) PC_W(12) PC_W(13) PC_W(14) PC_W(15)
-            PC_W(16) PC_W(17) PC_W(18) PC_W(19) PC_W(20) PC_W(21) PC_W(22) PC_W(23) PC_W(24) PC_W(25) PC_W(26) PC_W(27) PC_W(28) PC_W(29) PC_W(30)
-            PC_W(31) PC_W(32) PC_W(33) PC_W(34) PC_W(35) PC_W(36)
+    if (wave < 8) {
+        // =============================== D: weight rows by LDS-DMA (1 wave) ===============================
+        // Kernel row r of a chunk lives in ring slot r: 3 taps x [2 n tiles][2 pieces][2 steps] x 1 KB = 24 pieces.  Row rho + 2 is requested
+        // in phase rho (its slot was left at B(rho - 1)) and must have landed at B(rho + 1): nothing else in this wave touches the
+        // vector-memory counter, so "all but this phase's 24" is exact.
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wt), 0, a.w_bytes, 0x00020000);
+#ifdef BH_TUNING
+        const bool doff = a.dbg_noload & 8;               // ablation: no weights (timing only)
+#else
+        constexpr bool doff = false;
+#endif
+        auto dma_num = [&](int r) {                       // weight row number r = (tile, chunk, kernel row)
+            const int kp = r / 3, row = r - kp * 3, ti_ = kp / nch, c_ = kp - ti_ * nch;
+            const int ny = (wt0 + ti_) / a.gx_total;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int piece = 0; piece < 8; ++piece) {
+                    const unsigned so = (unsigned)(((c_ * 9 + row * 3 + t) * a.NW + ny * 2) * 4096 + piece * 1024);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_ptr)(smem + PC_OFF_B + row * PC_BROW + t * PC_BTAP + piece * 1024), 16,
+                                                             (unsigned)lane * 16u, so, 0, 0);
+                }
+        };
+        int pro = 0;
+        if (!doff) { dma_num(0); if (R > 1) { dma_num(1); ++pro; } if (R > 2) { dma_num(2); ++pro; } }
+        wait_vm(24 * pro);                                // row 0 has landed
+        PC_BARRIER();                                     // B(-1)
+        for (int rho = 0; rho < R; ++rho) {
+            int nd = 0;
+            if (rho >= 1 && rho + 2 < R && !doff) { dma_num(rho + 2); nd = 24; }
+            wait_vm(rho == 0 ? ((R > 2 && !doff) ? 24 : 0) : nd);       // row rho + 1 has landed
+            PC_BARRIER();                                 // B(rho)
         }
-#undef PC_W
-    };
+        PC_BARRIER();                                     // F1
+        PC_BARRIER();                                     // F2
+        PC_BARRIER();                                     // F3
+        PC_BARRIER();                                     // F4
+        return;
+    }
 
-    // =============================== E: weight rows + epilogue (4 waves) ===============================
+    // =============================== E: epilogue (4 waves) ===============================
     {
+        __builtin_amdgcn_s_setprio(1);
         const int ew = wave - 8;
         const int cq = lane & 15, pl = lane >> 4;         // channel quad (channels 4 cq .. 4 cq + 3 of the tile), pixel of the unit
         const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(a.Out, 0, a.out_bytes, 0x00020000);
@@ -435,7 +536,6 @@ __global__ void __launch_bounds__(768) conv3x3_pc_kernel(C3Args a) {
         // into register set idx & 3 (epi_fetch), two or more barrier phases before epi_run needs it; the stores are never waited for.
         // Addressing: unit u = ew + 4 idx covers pixels (sub-tile idx >> 2, row (ew >> 1) + 2 (idx & 3), x = 4 (ew & 1) + pl): the lane part of the
         // byte offset is ONE tile-independent VGPR, the rest (sub-tile origin + row step) rides in the scalar offset of the buffer instruction.
-        int nops = 0;                                     // vector-memory operations (epilogue loads + stores) this wave issued in the current phase
         float4 pf_a[4], pf_z[4], pf_y[4];                  // pf_a: the old gradient (dgrad joins) OR the residual (inference forward) - never both
         constexpr int nld = (use_ext ? 1 : 0) + (rd_z ? 1 : 0) + (rd_y ? 1 : 0);      // loads per unit
         const unsigned voff = (unsigned)((ew >> 1) * a.W + ((ew & 1) << 2) + pl) * nn4 + (unsigned)cq * 16u;
@@ -446,7 +546,6 @@ __global__ void __launch_bounds__(768) conv3x3_pc_kernel(C3Args a) {
             constexpr int idx = decltype(IDX)::value, q = idx & 3;
             if (nld == 0 || !((idx >> 2) ? fvalid[1] : fvalid[0])) return;
             const unsigned so = ((idx >> 2) ? fbase[1] : fbase[0]) + (unsigned)q * rowstep2;
-            nops += nld;
             if constexpr (use_ext) pf_a[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA_, voff, so, 0));
             if constexpr (rd_z) pf_z[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsZ, voff, so, 0));
             if constexpr (rd_y) pf_y[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsY, voff, so, 0));
@@ -486,7 +585,7 @@ __global__ void __launch_bounds__(768) conv3x3_pc_kernel(C3Args a) {
             }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, make_float4(out[0], out[1], out[2], out[3])),
                                                    rsO, voff, so, 0);
-            have = true; ++nops;
+            have = true;
         };
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
         using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
@@ -511,39 +610,8 @@ __global__ void __launch_bounds__(768) conv3x3_pc_kernel(C3Args a) {
         if ((k0) <= 7 && 7 < (k1)) PC_E_STEP(I7, I3, nxt);                                                              \
     } while (0)
 
-        // ---- weight rows: kernel row r of a chunk lives in ring slot r (3 taps x [2 n tiles][2 pieces][2 steps] x 1 KB, six pieces per E wave).
-        // Row rho + 2 is requested at the END of phase rho (its slot was left at B(rho - 1)) and must have landed at B(rho + 1).  The LDS-DMA is
-        // inline assembly: the compiler orders every LDS read behind an LDS-DMA it knows of with vmcnt(0), which would put the DMA's latency
-        // in front of every epilogue unit.  Its completion is counted by hand (wait_vm: everything this wave issued after the previous
-        // phase's DMA may still fly; the compiler's own counted waits for the epilogue loads do not see the DMAs and can only wait longer).
-#ifdef BH_TUNING
-        const bool doff = a.dbg_noload & 8;               // ablation: no weights (timing only)
-#else
-        constexpr bool doff = false;
-#endif
-        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wt), 0, a.w_bytes, 0x00020000);
-        const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
-        const unsigned lane16 = (unsigned)lane * 16u;
-        auto dma_num = [&](int r) {                       // weight row number r = (tile, chunk, kernel row)
-            const int kp = r / 3, row = r - kp * 3, ti_ = kp / nch, c_ = kp - ti_ * nch;
-            const int ny = (wt0 + ti_) / a.gx_total;
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    const int piece = ew * 2 + jj;
-                    const unsigned so = (unsigned)(((c_ * 9 + row * 3 + t) * a.NW + ny * 2) * 4096 + piece * 1024);
-                    const unsigned dst = lds0 + (unsigned)(PC_OFF_B + row * PC_BROW + t * PC_BTAP + piece * 1024);
-                    unsigned keep;
-                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                                 : "=&s"(keep) : "v"(lane16), "s"(dst), "s"(rsB), "s"(so) : "memory");
-                }
-        };
-        int pro = 0;
-        if (!doff) { dma_num(0); if (R > 1) { dma_num(1); ++pro; } if (R > 2) { dma_num(2); ++pro; } }
         if (!eoff_) {
-            // the scales of the fp16 pieces (2^ka source, 2^kw weights: waiting for them also lands the three rows), then units 0 .. 3 of the
-            // first tile go into flight
+            // the scales of the fp16 pieces (2^ka source, 2^kw weights), then units 0 .. 3 of the first tile go into flight
             const unsigned* const wrec = reinterpret_cast<const unsigned*>(a.Wt) + (a.w_bytes >> 2);
             unsigned wv = lane < 16 ? wrec[lane] : 0u;
 #pragma unroll
@@ -553,14 +621,11 @@ __global__ void __launch_bounds__(768) conv3x3_pc_kernel(C3Args a) {
             f_tile(wt0);
             epi_fetch(I0{}); epi_fetch(I1{}); epi_fetch(I2{}); epi_fetch(I3{});
         }
-        wait_vm(eoff_ ? 6 * pro : nops);                  // row 0 (in fact all three rows) has landed; the epilogue requests may fly
         PC_BARRIER();                                     // B(-1)
         const int nph = 3 * nch;                          // phases per tile
         const int U = (8 + (nph - 1) - 1) / (nph - 1);    // epilogue units per wave and phase (phases 1 .. nph - 1 of the next tile)
-        int rho = 0;
         for (int ti = 0; ti < Tw; ++ti) {
-            for (int k = 0; k < nph; ++k, ++rho) {        // phase k of this tile = kernel row rho: ends at B(rho)
-                nops = 0;
+            for (int k = 0; k < nph; ++k) {               // phase k of this tile: ends at B(rho)
                 // this phase's share of the PREVIOUS tile's epilogue (the hand-over tile is readable from phase 1 on)
                 if (ti > 0 && !eoff_) {
                     if (k == 0) e_tile(wt0 + ti - 1);
@@ -570,11 +635,6 @@ __global__ void __launch_bounds__(768) conv3x3_pc_kernel(C3Args a) {
                         if (k0 < 8) PC_E_UNITS(k0, k1, wt0 + ti);      // (the next tile to finish is this one: ti < Tw)
                     }
                 }
-                // weight row rho + 2 -> the slot the consumers left at B(rho - 1)
-                int nd = 0;
-                if (rho >= 1 && rho + 2 < R && !doff) { dma_num(rho + 2); nd = 6; }
-                // row rho + 1 (requested at the end of the previous phase, or in the prologue) has landed: everything issued since may fly
-                wait_vm(nops + nd);
                 PC_BARRIER();                             // B(rho)
             }
         }
@@ -594,6 +654,12 @@ __global__ void __launch_bounds__(768) conv3x3_pc_kernel(C3Args a) {
     }
 }
 }  // namespace
+
+#ifdef BH_TUNING
+extern "C" int bh_debug_read_pc_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pc_ts), sizeof(unsigned long long) * 4 * 160 * 2, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 int bh_conv3x3_pc_launch(C3Args& a, int dgrad, const float* bni_table, int bni_groups, int bni_relu, bool query_only, hipStream_t stream) {
     if (a.Kc % 32 || a.Nn % 64 || a.subtiles < 1) return BH_E_UNSUPPORTED;

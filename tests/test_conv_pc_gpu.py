@@ -158,16 +158,31 @@ def test_dgrad_batchnorm_reduce_bit_identical(K, N, H, Ci, Co, relu, with_y, acc
 
 
 def test_deterministic_call_is_repeatable(K):
-    from bihome_amd._lib import ROUTE_DETERMINISTIC, ROUTE_HALO_SMALL
+    """In a deterministic scope (BH_ROUTE_DETERMINISTIC) the statistics leave through integer limbs: bitwise repeatable, whatever the order
+    in which the workgroups arrive."""
+    from bihome_amd._lib import ROUTE_HALO_SMALL
     N, H, Ci, Co = 16, 16, 128, 128
     x, gy, wk, b, pf, pd, g = _operands(K, N, H, Ci, Co, seed=4)
-    d = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=4, route=ROUTE_HALO_SMALL | ROUTE_DETERMINISTIC)
     runs = []
-    for _ in range(3):
-        s = K.bn_stats_buffer(2, Co, "cuda")
-        y = K.conv_fwd(x, wk, b, d, bn_sums=s, groups=2, wpacked=pf)
-        runs.append((y, s))
-    assert all(torch.equal(runs[0][0], r[0]) and torch.equal(runs[0][1], r[1]) for r in runs[1:])
+    with K.det_scope(True):
+        d = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=4, route=ROUTE_HALO_SMALL)
+        assert K.conv_variant(K._with_layout(d, 4), "fwd", bn_groups=2).startswith("conv3x3_pc_kernel")
+        for _ in range(4):
+            s = K.bn_stats_buffer(2, Co, "cuda")
+            y = K.conv_fwd(x, wk, b, d, bn_sums=s, groups=2, wpacked=pf)
+            runs.append((y, s))
+    assert all(torch.equal(runs[0][0], r[0]) for r in runs[1:])
+    for r in runs[1:]:
+        ds = (runs[0][1].view(torch.int64) != r[1].view(torch.int64)).reshape(-1, 16)       # (bit patterns: a negative limb read as a double is a NaN)
+        assert not ds.any(), (int(ds.sum()), ds.any(0).tolist())
+    # and the limbs hold the same totals as the default mode's doubles
+    d0 = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=4, route=ROUTE_HALO_SMALL)
+    s0 = K.bn_stats_buffer(2, Co, "cuda")
+    K.conv_fwd(x, wk, b, d0, bn_sums=s0, groups=2, wpacked=pf)
+    e = runs[0][1].reshape(-1, 16)
+    limbs = e[:, 1:4].contiguous().view(torch.int64).double()
+    tot = e[:, 0] + limbs[:, 0] + limbs[:, 1] * 2.0 ** -40 + limbs[:, 2] * 2.0 ** -80
+    _sums_close(tot, s0.reshape(-1, 16)[:, 0], 1e-12)
 
 
 def _bench(fn, n=30):
