@@ -912,7 +912,7 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
     if (f16 && !map4 && bn_tile == 64 && !(d->route & (BH_ROUTE_C3_TILE_WG | BH_ROUTE_C3_ONE_SUBTILE | BH_ROUTE_C3_ONE_POSITION)) && g_c3_pc) {
         C3Args b = a;
         b.det = (d->route & BH_ROUTE_DETERMINISTIC) ? 1 : 0; b.dbg_noload = g_c3_noload; b.dbg_ts = g_c3_stamp;
-        const int st = bh_conv3x3_pc_launch(b, dgrad, bni ? bni->table : nullptr, bni ? bni->groups : 0, bni ? bni->relu : 0, false, stream);
+        const int st = bh_conv3x3_pc_launch(b, dgrad, bni ? bni->table : nullptr, bni ? bni->groups : 0, bni ? bni->relu : 0, (d->route & BH_ROUTE_C3_PC) != 0, stream);
         if (st != BH_E_UNSUPPORTED) { if (st == BH_OK) *taken = 1; return st; }
     }
     // (all ten template arguments, as rocprofv3 prints the symbol: FLIP, BN, BF16, SUBT, PACKED, X3, BNI, NP, MAP4, F16)

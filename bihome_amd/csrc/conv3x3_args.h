@@ -77,4 +77,5 @@ struct C3Args {
 // conv3x3_pc.hip: the fp16-piece launches of the 64-channel tile on persistent producer / consumer workgroups (round 5).
 // `a` arrives filled by bh_conv3x3_try (tensor pointers, geometry, epilogue options); returns BH_OK after the launch, or
 // BH_E_UNSUPPORTED (nothing launched) when the launch does not fit the kernel.
-int bh_conv3x3_pc_launch(C3Args& a, int dgrad, const float* bni_table, int bni_groups, int bni_relu, bool query_only, hipStream_t stream);
+// force: take every launch the kernel supports (else only those where it is the faster kernel today)
+int bh_conv3x3_pc_launch(C3Args& a, int dgrad, const float* bni_table, int bni_groups, int bni_relu, bool force, hipStream_t stream);

@@ -661,7 +661,7 @@ extern "C" int bh_debug_read_pc_stamps(unsigned long long* out) {
 }
 #endif
 
-int bh_conv3x3_pc_launch(C3Args& a, int dgrad, const float* bni_table, int bni_groups, int bni_relu, bool query_only, hipStream_t stream) {
+int bh_conv3x3_pc_launch(C3Args& a, int dgrad, const float* bni_table, int bni_groups, int bni_relu, bool force, hipStream_t stream) {
     if (a.Kc % 32 || a.Nn % 64 || a.subtiles < 1) return BH_E_UNSUPPORTED;
     // both sub-tiles of a tile position lie in one statistics group / BatchNorm-on-load group
     const long long sub_per_group = (long long)a.imgs_per_group * a.tiles_per_img;
@@ -690,11 +690,15 @@ int bh_conv3x3_pc_launch(C3Args& a, int dgrad, const float* bni_table, int bni_g
     const long long total = (long long)a.gx_total * (a.Nn / 64);
     const int cus = 256;
     const int T = (int)((total + cus - 1) / cus);
+    // Where the persistent kernel is the faster one today (tests/test_conv_pc_gpu.py __main__, one MI355X): every forward form and the plain
+    // dgrad; the dgrad forms whose epilogue READS tensors (old gradient, BatchNorm input / output) only with one tile per workgroup - with
+    // several, the epilogue waves' loads (compiler-counted, one HBM round trip per barrier phase) hold the consumers up and the halo kernel
+    // wins by 0 - 5 %.  BH_ROUTE_C3_PC takes the launch regardless (tests, A/B).
+    if (!force && (em & 14) && dgrad && T > 1) return BH_E_UNSUPPORTED;
     const int grid = (int)((total + T - 1) / T);
     a.tpb = T;
     a.NW = a.Nn / 32;
     if (bh_query("conv3x3_pc_kernel<%s,%s,%d>", dgrad ? "true" : "false", bni_table ? "true" : "false", em)) return BH_OK;
-    if (query_only) return BH_OK;
     static unsigned long long attr_devs = 0;
     if (bh_device_once(attr_devs)) {
         for (int i = 0; i < NROWS; ++i) {

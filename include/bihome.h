@@ -266,6 +266,8 @@ int bh_absmax(const float* x, long long n, float* record, void* stream);
 #define BH_ROUTE_C3_ONE_SUBTILE 32  /* fwd / dgrad: halo-tiled 3x3 kernel with one 8x8 sub-tile per workgroup (64-channel tile) */
 #define BH_ROUTE_C3_ONE_POSITION 64 /* fwd / dgrad: halo-tiled 3x3 kernel never walks two tile positions per workgroup */
 #define BH_ROUTE_DETERMINISTIC 128  /* every launch of this call is order-independent (see "Deterministic calls" above) */
+#define BH_ROUTE_C3_PC 512          /* fwd / dgrad, precision 4, 64-channel tile: the persistent producer / consumer kernel for every launch it supports
+                                     * (default: only where it is the faster one) */
 #define BH_ROUTE_C3_TILE_WG 256     /* fwd / dgrad, precision 4: the one-workgroup-per-tile halo kernel instead of the persistent producer /
                                      * consumer kernel (round 5) - same convolution results bit for bit */
 

@@ -25,8 +25,8 @@ def K():
 
 
 def _descs(K, N, H, Ci, Co):
-    from bihome_amd._lib import ROUTE_C3_TILE_WG, ROUTE_HALO_SMALL
-    new = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=4, route=ROUTE_HALO_SMALL)
+    from bihome_amd._lib import ROUTE_C3_PC, ROUTE_C3_TILE_WG, ROUTE_HALO_SMALL
+    new = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=4, route=ROUTE_HALO_SMALL | ROUTE_C3_PC)
     old = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=4, route=ROUTE_HALO_SMALL | ROUTE_C3_TILE_WG)
     # (the persistent kernel takes the 64-channel output tile: forward Co % 64 == 0, dgrad Ci % 64 == 0; the other direction of such a
     #  layer runs the halo kernel's 32-channel tile either way)
@@ -200,7 +200,7 @@ def _bench(fn, n=30):
 if __name__ == "__main__":
     sys.path.insert(0, ".")
     from bihome_amd import kernels as K
-    from bihome_amd._lib import ROUTE_C3_TILE_WG
+    from bihome_amd._lib import ROUTE_C3_PC, ROUTE_C3_TILE_WG
     shapes = [(128, 32, 64, 64), (128, 16, 128, 128), (128, 8, 256, 256), (128, 64, 64, 64), (128, 32, 128, 128), (128, 16, 256, 256)]
     if len(sys.argv) > 1:
         shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
@@ -212,7 +212,7 @@ if __name__ == "__main__":
         base = torch.randn(N, H, H, Ci, generator=g).cuda()
         res = {}
         for rnd in range(3):                   # alternate the two kernels (the first variant measured in a process runs slower whatever it is)
-            for tag, route in (("pc", 0), ("halo", ROUTE_C3_TILE_WG)):
+            for tag, route in (("pc", ROUTE_C3_PC), ("halo", ROUTE_C3_TILE_WG)):
                 d = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=4, route=route)
                 s = K.bn_stats_buffer(2, Co, "cuda"); s2 = K.bn_stats_buffer(2, Ci, "cuda")
                 bnr = dict(z=z, y=None, stats=st, gamma=gamma, beta=beta, eps=1e-5, relu=True, sums=s2, groups=2)

@@ -7,25 +7,25 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out
 last_json() { python3 -c "import sys; print([l for l in open(sys.argv[1]) if l.startswith('{')][-1].strip())" "$1"; }
 python3 bench.py > $O/${T}_bench.log 2>&1; last_json $O/${T}_bench.log > $O/${T}_bench.json
-python3 bench.py --no-cpu-baseline --precision f32-mfma > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_f32_mfma.json
-python3 bench.py --no-cpu-baseline --no-overlap > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_no_overlap.json
-python3 bench.py --no-cpu-baseline --graph > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_graph.json
-python3 bench.py --no-cpu-baseline --config detone-bihome > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_detone.json
-python3 bench.py --no-cpu-baseline --config detone-bihome --precision bf16 > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_detone_bf16.json
-python3 bench.py --no-cpu-baseline --config detone-bihome --precision f32x2 > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_detone_f32x2.json
-python3 bench.py --no-cpu-baseline --precision f32x2 > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_f32x2.json
-python3 bench.py --no-cpu-baseline --precision f32x3 > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_f32x3.json
-python3 bench.py --no-cpu-baseline --steps 200 --warmup 20 --no-roofline > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_steps200.json
-BIHOME_DETERMINISTIC=1 python3 bench.py --no-cpu-baseline > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_deterministic.json
+python3 bench.py --no-alt --no-cpu-baseline --precision f32-mfma > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_f32_mfma.json
+python3 bench.py --no-alt --no-cpu-baseline --no-overlap > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_no_overlap.json
+python3 bench.py --no-alt --no-cpu-baseline --graph > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_graph.json
+python3 bench.py --no-alt --no-cpu-baseline --config detone-bihome > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_detone.json
+python3 bench.py --no-alt --no-cpu-baseline --config detone-bihome --precision bf16 > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_detone_bf16.json
+python3 bench.py --no-alt --no-cpu-baseline --config detone-bihome --precision f32x2 > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_detone_f32x2.json
+python3 bench.py --no-alt --no-cpu-baseline --precision f32x2 > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_f32x2.json
+python3 bench.py --no-alt --no-cpu-baseline --precision f32x3 > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_f32x3.json
+python3 bench.py --no-alt --no-cpu-baseline --steps 200 --warmup 20 --no-roofline > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_steps200.json
+BIHOME_DETERMINISTIC=1 python3 bench.py --no-alt --no-cpu-baseline > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_deterministic.json
 [ -x tools/mfma_clock_probe.bin ] && tools/mfma_clock_probe.bin > $O/${T}_mfma_clock_probe.txt 2>&1
-[ -f bihome_amd/libbihome_hip_tuning.so ] && for m in fwd fwdstats dgrad; do BIHOME_TUNING=1 python3 tools/x3_timeline.py $m; done > $O/${T}_x3_timeline.txt 2>&1
+[ -f bihome_amd/libbihome_hip_tuning.so ] && { for m in fwd bnr; do BIHOME_TUNING=1 python3 tools/pc_timeline.py 128,32,64,64 $m; done; BIHOME_TUNING=1 python3 tools/pc_timeline.py 128,8,256,256 fwd; BIHOME_TUNING=1 python3 tools/pc_ablate.py; } > $O/${T}_pc_timeline.txt 2>&1
 python3 tools/step_detail.py zeng-bihome 64 > $O/${T}_step_detail.txt 2>&1
-python3 bench.py --no-cpu-baseline --config zeng-bihome-rgb256 > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_rgb256.json
-python3 bench.py --no-cpu-baseline --config zeng-bihome-pds > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_pds.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_kt -o ${T} -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-overlap > $O/${T}_kt.log 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/${T}_mfma -o ${T} -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-overlap > $O/tmp.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${T}_fetch -o ${T} -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-overlap > $O/tmp.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${T}_write -o ${T} -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-overlap > $O/tmp.log 2>&1
+python3 bench.py --no-alt --no-cpu-baseline --config zeng-bihome-rgb256 > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_rgb256.json
+python3 bench.py --no-alt --no-cpu-baseline --config zeng-bihome-pds > $O/tmp.log 2>&1; last_json $O/tmp.log > $O/${T}_bench_pds.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_kt -o ${T} -- python3 bench.py --no-alt --steps 20 --warmup 5 --no-cpu-baseline --no-overlap > $O/${T}_kt.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/${T}_mfma -o ${T} -- python3 bench.py --no-alt --steps 6 --warmup 2 --no-cpu-baseline --no-overlap > $O/tmp.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${T}_fetch -o ${T} -- python3 bench.py --no-alt --steps 6 --warmup 2 --no-cpu-baseline --no-overlap > $O/tmp.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${T}_write -o ${T} -- python3 bench.py --no-alt --steps 6 --warmup 2 --no-cpu-baseline --no-overlap > $O/tmp.log 2>&1
 cp $(find $O/${T}_kt -name "*kernel_stats.csv" | head -1) $O/${T}_kernel_stats.csv
 python3 tools/mfma_busy_summary.py $(find $O/${T}_mfma -name "*counter_collection.csv" | head -1) $O/${T}_mfma_busy.json
 python3 tools/pmc_summary.py $(find $O/${T}_fetch -name "*counter_collection.csv" | head -1) $(find $O/${T}_write -name "*counter_collection.csv" | head -1) $O/${T}_pmc_traffic.json

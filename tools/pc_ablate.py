@@ -4,7 +4,7 @@ epilogue.  31 = barriers only.  BIHOME_TUNING=1 python tools/pc_ablate.py"""
 import sys; sys.path.insert(0, '.')
 import torch
 from bihome_amd import kernels as K
-from bihome_amd._lib import lib, ROUTE_C3_TILE_WG
+from bihome_amd._lib import lib, ROUTE_C3_PC, ROUTE_C3_TILE_WG
 def bench(fn, n=30):
     for _ in range(3): fn()
     torch.cuda.synchronize()
@@ -26,7 +26,7 @@ for (N, H, Ci, Co) in shapes:
     gamma, beta = torch.rand(Ci, device='cuda') + 0.5, torch.randn(Ci, device='cuda') * 0.2
     st = K.bn_stats_buffer(2, Ci, "cuda"); K.bn_stats(z, st, 2, Ci)
     base = torch.randn(N, H, H, Ci, device='cuda')
-    d = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=4)
+    d = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=4, route=ROUTE_C3_PC)
     dh = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=4, route=ROUTE_C3_TILE_WG)
     s = K.bn_stats_buffer(2, Co, "cuda"); s2 = K.bn_stats_buffer(2, Ci, "cuda")
     bnr = dict(z=z, y=None, stats=st, gamma=gamma, beta=beta, eps=1e-5, relu=True, sums=s2, groups=2)

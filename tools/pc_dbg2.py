@@ -1,7 +1,7 @@
 import sys; sys.path.insert(0, '.')
 import torch
 from bihome_amd import kernels as K
-from bihome_amd._lib import ROUTE_C3_TILE_WG, ROUTE_HALO_SMALL
+from bihome_amd._lib import ROUTE_C3_PC, ROUTE_C3_TILE_WG, ROUTE_HALO_SMALL
 N, H, Ci, Co = 40, 32, 64, 64
 g = torch.Generator().manual_seed(3)
 gy = torch.randn(N, H, H, Co, generator=g).cuda()
@@ -11,7 +11,7 @@ pk = K.packer_for_precision(4); pf, pd = pk.get(w); pk.refresh()
 z = (torch.randn(N, H, H, Ci, generator=g) * 1.5 + 0.3).cuda()
 gamma = (torch.rand(Ci, generator=g) + 0.5).cuda(); beta = (torch.randn(Ci, generator=g) * 0.2).cuda()
 st = K.bn_stats_buffer(2, Ci, "cuda"); K.bn_stats(z, st, 2, Ci)
-new = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=4, route=ROUTE_HALO_SMALL)
+new = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=4, route=ROUTE_HALO_SMALL | ROUTE_C3_PC)
 old = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=4, route=ROUTE_HALO_SMALL | ROUTE_C3_TILE_WG)
 for rep in range(3):
     outs = []

@@ -3,7 +3,7 @@ Run under `timeout -s KILL`: a barrier-count mistake in a persistent kernel hang
 import sys; sys.path.insert(0, '.')
 import torch
 from bihome_amd import kernels as K
-from bihome_amd._lib import ROUTE_C3_TILE_WG, ROUTE_HALO_SMALL
+from bihome_amd._lib import ROUTE_C3_PC, ROUTE_C3_TILE_WG, ROUTE_HALO_SMALL
 for (N, H, Ci, Co) in [(2, 8, 64, 64), (8, 16, 64, 64), (4, 8, 256, 256), (40, 32, 64, 64)]:
     g = torch.Generator().manual_seed(1)
     x = torch.randn(N, H, H, Ci, generator=g).cuda()
@@ -11,7 +11,7 @@ for (N, H, Ci, Co) in [(2, 8, 64, 64), (8, 16, 64, 64), (4, 8, 256, 256), (40, 3
     w = (torch.randn(Co, Ci, 3, 3, generator=g) * 0.05).cuda().contiguous(memory_format=torch.channels_last)
     wk = w.permute(0, 2, 3, 1)
     pk = K.packer_for_precision(4); pf, pd = pk.get(w); pk.refresh()
-    new = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=4, route=ROUTE_HALO_SMALL)
+    new = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=4, route=ROUTE_HALO_SMALL | ROUTE_C3_PC)
     old = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=4, route=ROUTE_HALO_SMALL | ROUTE_C3_TILE_WG)
     print((N, H, Ci, Co), K.conv_variant(K._with_layout(new, 4), "fwd"), flush=True)
     y0 = K.conv_fwd(x, wk, None, old, wpacked=pf); torch.cuda.synchronize()

@@ -4,7 +4,7 @@ BIHOME_TUNING=1 python tools/pc_timeline.py [N,H,Ci,Co] [mode: fwd|stats|bnr]"""
 import sys, ctypes; sys.path.insert(0, '.')
 import numpy as np, torch
 from bihome_amd import kernels as K
-from bihome_amd._lib import lib
+from bihome_amd._lib import lib, ROUTE_C3_PC
 shape = tuple(int(v) for v in sys.argv[1].split(",")) if len(sys.argv) > 1 else (128, 32, 64, 64)
 mode = sys.argv[2] if len(sys.argv) > 2 else "fwd"
 N, H, Ci, Co = shape
@@ -16,7 +16,7 @@ z = torch.randn(N, H, H, Ci, device='cuda') * 1.5 + 0.3
 gamma, beta = torch.rand(Ci, device='cuda') + 0.5, torch.randn(Ci, device='cuda') * 0.2
 st = K.bn_stats_buffer(2, Ci, "cuda"); K.bn_stats(z, st, 2, Ci)
 base = torch.randn(N, H, H, Ci, device='cuda')
-d = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=4)
+d = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=4, route=ROUTE_C3_PC)
 s = K.bn_stats_buffer(2, Co, "cuda"); s2 = K.bn_stats_buffer(2, Ci, "cuda")
 bnr = dict(z=z, y=None, stats=st, gamma=gamma, beta=beta, eps=1e-5, relu=True, sums=s2, groups=2)
 fn = {"fwd": lambda: K.conv_fwd(x, wk, None, d, wpacked=pf), "stats": lambda: K.conv_fwd(x, wk, None, d, bn_sums=s, groups=2, wpacked=pf),
