@@ -61,6 +61,13 @@ __device__ unsigned long long g_pc_ts[4 * 160 * 2];
 #define PC_H_ASM 0        // (1: the H waves' loads as inline assembly with hand-counted waits - see the note in the H role; not yet sound)
 #define PC_BARRIER_VM() asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+// maximum over lanes 0 .. 15 of a wave (the sixteen slots of a magnitude record / the sixteen partial maxima behind packed weights)
+__device__ __forceinline__ unsigned pc_amax_reduce(unsigned v) {
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)v, off, 64); v = o > v ? o : v; }
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+
 __device__ __forceinline__ void pc_decode(const C3Args& a, int g, int& img, int& ty, int& tx) {
     if (a.tpi_shift >= 0) { img = g >> a.tpi_shift; const int t = g & (a.tiles_per_img - 1); ty = t >> a.tx_shift; tx = t & (a.tiles_x - 1); }
     else { img = g / a.tiles_per_img; const int t = g - img * a.tiles_per_img; ty = t / a.tiles_x; tx = t - ty * a.tiles_x; }
@@ -360,9 +367,10 @@ __global__ void __launch_bounds__(768) conv3x3_pc_kernel(C3Args a) {
         if constexpr (!BNI) {
             // chunks 0 and 1 requested at once (then the source tensor's scale, whose loads the compiler waits for - and with them, being
             // younger, for both chunks); chunk 0 cut; chunk 2 requested
+            const unsigned rec_ = lane < BH_AMAX_SLOTS ? a.amax_src[lane * BH_AMAX_STRIDE] : 0u;      // (the source tensor's magnitude record: in flight with the halos)
             PC_H_ISSUE_ALL(hA, okA, seqA, hon);
             PC_H_ISSUE_ALL(hB, okB, seqB, 1 < K && hon);
-            f16_s = __builtin_bit_cast(float, (unsigned)(127 + bh_f16_scale_exp(bh_amax_read(a.amax_src, lane))) << 23);
+            f16_s = __builtin_bit_cast(float, (unsigned)(127 + bh_f16_scale_exp(pc_amax_reduce(rec_))) << 23);
             h_cut(J0{}, 0, hA, okA, seqA, hon); h_cut(J1{}, 0, hA, okA, seqA, hon); h_cut(J2{}, 0, hA, okA, seqA, hon);
             h_cut(J3{}, 0, hA, okA, seqA, hon); h_cut(J4{}, 0, hA, okA, seqA, hon);
             PC_H_ISSUE_ALL(hA, okA, seqA, 2 < K && hon);
@@ -375,9 +383,10 @@ __global__ void __launch_bounds__(768) conv3x3_pc_kernel(C3Args a) {
             // BatchNorm-on-load: ONE register set (the coefficient registers and the transform's temporaries take the room of the second):
             // a round of chunk kap + 1 is cut and the same registers request that round of chunk kap + 2 - one chunk time in flight
             (void)hB; (void)okB; (void)seqB;
+            const unsigned rec_ = lane < BH_AMAX_SLOTS ? a.amax_src[lane * BH_AMAX_STRIDE] : 0u;
             tb_issue(hon ? 0 : K);
             PC_H_ISSUE_ALL(hA, okA, seqA, hon);
-            f16_s = __builtin_bit_cast(float, (unsigned)(127 + bh_f16_scale_exp(bh_amax_read(a.amax_src, lane))) << 23);
+            f16_s = __builtin_bit_cast(float, (unsigned)(127 + bh_f16_scale_exp(pc_amax_reduce(rec_))) << 23);
             h_cut(J0{}, 0, hA, okA, seqA, hon); h_cut(J1{}, 0, hA, okA, seqA, hon); h_cut(J2{}, 0, hA, okA, seqA, hon);
             h_cut(J3{}, 0, hA, okA, seqA, hon); h_cut(J4{}, 0, hA, okA, seqA, hon);
             tb_issue(hon ? 1 : K);
@@ -542,19 +551,19 @@ __global__ void __launch_bounds__(768) conv3x3_pc_kernel(C3Args a) {
         const unsigned rowstep2 = 2u * (unsigned)a.W * nn4;
         const char* const epi_l = smem + PC_OFF_EPI + ew * 1024 + lane * 16;
         const __amdgpu_buffer_rsrc_t rsA_ = rd_res ? rsR : rsO;
-        auto epi_fetch = [&](auto IDX) {                   // unit idx of the FETCH tile -> set idx & 3
-            constexpr int idx = decltype(IDX)::value, q = idx & 3;
+        auto epi_fetch = [&](auto Q, int idx) {            // unit idx of the FETCH tile -> register set q
+            constexpr int q = decltype(Q)::value;
             if (nld == 0 || !((idx >> 2) ? fvalid[1] : fvalid[0])) return;
-            const unsigned so = ((idx >> 2) ? fbase[1] : fbase[0]) + (unsigned)q * rowstep2;
+            const unsigned so = ((idx >> 2) ? fbase[1] : fbase[0]) + (unsigned)(idx & 3) * rowstep2;
             if constexpr (use_ext) pf_a[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA_, voff, so, 0));
             if constexpr (rd_z) pf_z[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsZ, voff, so, 0));
             if constexpr (rd_y) pf_y[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsY, voff, so, 0));
         };
         int kout = 0;
-        auto epi_run = [&](auto IDX) {                     // unit idx of the RUN tile, operands in set idx & 3
-            constexpr int idx = decltype(IDX)::value, q = idx & 3;
+        auto epi_run = [&](auto Q, int idx) {              // unit idx of the RUN tile, operands in register set q
+            constexpr int q = decltype(Q)::value;
             if (!((idx >> 2) ? tvalid[1] : tvalid[0])) return;
-            const unsigned so = ((idx >> 2) ? tbase[1] : tbase[0]) + (unsigned)q * rowstep2;
+            const unsigned so = ((idx >> 2) ? tbase[1] : tbase[0]) + (unsigned)(idx & 3) * rowstep2;
             const float4 av = *reinterpret_cast<const float4*>(epi_l + idx * 4096);
             const float4 z0 = make_float4(0.f, 0.f, 0.f, 0.f);
             const float4 o = use_ext ? pf_a[q] : z0, zz = rd_z ? pf_z[q] : z0, yy = rd_y ? pf_y[q] : z0;
@@ -583,47 +592,57 @@ __global__ void __launch_bounds__(768) conv3x3_pc_kernel(C3Args a) {
                     S2[e] = __builtin_fma((double)vm, (double)t, S2[e]);
                 }
             }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, make_float4(out[0], out[1], out[2], out[3])),
-                                                   rsO, voff, so, 0);
+            // gfx950 hazard, found the hard way (round 5): a 128-bit buffer store whose soffset is an SGPR reads its data registers over several
+            // cycles AFTER it issues - a VALU instruction that overwrites the first data register right behind the store (the compiler reused it
+            // as the next unit's ReLU temporary) reached some lanes first: sporadic wrong first channels in lanes 12..15 of each 16.  LLVM's hazard
+            // table holds this case for safe ("no hazard when soffset is a register") and pads nothing, so the wait states are spelled out, tied
+            // to the data registers (which therefore stay live until they have passed).
+            const __attribute__((ext_vector_type(4))) unsigned ov =
+                __builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, make_float4(out[0], out[1], out[2], out[3]));
+            __builtin_amdgcn_raw_buffer_store_b128(ov, rsO, voff, so, 0);
+            asm volatile("s_nop 3" :: "v"(ov));
             have = true;
         };
-        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-        using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
-        using I6 = std::integral_constant<int, 6>; using I7 = std::integral_constant<int, 7>;
-        // unit idx of the run tile, then the request four units ahead: units 4 .. 7 of the same tile, or 0 .. 3 of the next one (`nxt`: its
-        // tile index, -1 = none; its geometry is made when the first of them is requested)
-#define PC_E_STEP(IDX, FIDX, nxt)                                                                                       \
-    do {                                                                                                                \
-        epi_run(IDX{});                                                                                                 \
-        if (IDX::value < 4) epi_fetch(FIDX{});                                                                          \
-        else if ((nxt) >= 0) { if (IDX::value == 4) f_tile(nxt); epi_fetch(FIDX{}); }                                   \
-    } while (0)
-#define PC_E_UNITS(k0, k1, nxt)                                                                                         \
-    do {                                                                                                                \
-        if ((k0) <= 0 && 0 < (k1)) PC_E_STEP(I0, I4, nxt);                                                              \
-        if ((k0) <= 1 && 1 < (k1)) PC_E_STEP(I1, I5, nxt);                                                              \
-        if ((k0) <= 2 && 2 < (k1)) PC_E_STEP(I2, I6, nxt);                                                              \
-        if ((k0) <= 3 && 3 < (k1)) PC_E_STEP(I3, I7, nxt);                                                              \
-        if ((k0) <= 4 && 4 < (k1)) PC_E_STEP(I4, I0, nxt);                                                              \
-        if ((k0) <= 5 && 5 < (k1)) PC_E_STEP(I5, I1, nxt);                                                              \
-        if ((k0) <= 6 && 6 < (k1)) PC_E_STEP(I6, I2, nxt);                                                              \
-        if ((k0) <= 7 && 7 < (k1)) PC_E_STEP(I7, I3, nxt);                                                              \
-    } while (0)
+        // ---- schedule: two wave GROUPS take turns.  Group g = ew >> 1 is active in the phases k = 1 .. nph - 1 of a tile with k odd (g = 0) /
+        // even (g = 1); in an active phase a wave runs one BATCH of <= 4 of its eight units (register set = position in the batch) and then
+        // requests the operands of its next batch - which it will need two barrier phases (~3.5 kilo-cycles) later.  The compiler waits
+        // for a load whose use lies in a later loop iteration with vmcnt(0): with this turn-taking the only loads a wave has in flight at
+        // that wait ARE the batch it needs (requested two phases ago), so the conservative wait costs nothing - with all four waves working
+        // every phase it cost one HBM round trip per phase (tools/pc_timeline.py: the E waves last at 16 of 29 barriers).
+        using Q0 = std::integral_constant<int, 0>; using Q1 = std::integral_constant<int, 1>; using Q2 = std::integral_constant<int, 2>;
+        using Q3 = std::integral_constant<int, 3>;
+        const int nph = 3 * nch;                          // phases per tile
+        const int grp = ew >> 1;
+        const int nA = grp ? (nph - 1) / 2 : nph / 2;     // active phases per tile (>= 1)
+        constexpr int UB = 4, NB = 2;                     // units per batch, batches per tile
+        const int BPP = (NB + nA - 1) / nA;               // batches per active phase (2 only for one-chunk tiles)
+        auto run_batch = [&](int b) {
+            const int i0 = b * UB;
+            epi_run(Q0{}, i0 + 0); epi_run(Q1{}, i0 + 1); epi_run(Q2{}, i0 + 2); epi_run(Q3{}, i0 + 3);
+        };
+        auto fetch_batch = [&](int b) {
+            const int i0 = b * UB;
+            epi_fetch(Q0{}, i0 + 0); epi_fetch(Q1{}, i0 + 1); epi_fetch(Q2{}, i0 + 2); epi_fetch(Q3{}, i0 + 3);
+        };
+        // batch b of the run tile, then the request of the batch after it: b + 1 of the same tile, or batch 0 of tile `nxt` (-1: none)
+        auto step_batch = [&](int b, int nxt) {
+            run_batch(b);
+            if (nld == 0) return;
+            if (b + 1 < NB) fetch_batch(b + 1);
+            else if (nxt >= 0) { f_tile(nxt); fetch_batch(0); }
+        };
 
         if (!eoff_) {
-            // the scales of the fp16 pieces (2^ka source, 2^kw weights), then units 0 .. 3 of the first tile go into flight
+            // the scales of the fp16 pieces (2^ka source, 2^kw weights), then batch 0 of the first tile goes into flight
             const unsigned* const wrec = reinterpret_cast<const unsigned*>(a.Wt) + (a.w_bytes >> 2);
-            unsigned wv = lane < 16 ? wrec[lane] : 0u;
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)wv, off, 64); wv = o > wv ? o : wv; }
-            kout = -(bh_f16_scale_exp((unsigned)__builtin_amdgcn_readfirstlane((int)wv)) + bh_f16_scale_exp(bh_amax_read(a.amax_src, lane)));
+            const unsigned wv = lane < 16 ? wrec[lane] : 0u;
+            const unsigned rec_ = lane < BH_AMAX_SLOTS ? a.amax_src[lane * BH_AMAX_STRIDE] : 0u;
+            kout = -(bh_f16_scale_exp(pc_amax_reduce(wv)) + bh_f16_scale_exp(pc_amax_reduce(rec_)));
             asm volatile("" :: "s"(kout) : "memory");       // (the requests below stay behind the scale loads)
             f_tile(wt0);
-            epi_fetch(I0{}); epi_fetch(I1{}); epi_fetch(I2{}); epi_fetch(I3{});
+            fetch_batch(0);
         }
         PC_BARRIER();                                     // B(-1)
-        const int nph = 3 * nch;                          // phases per tile
-        const int U = (8 + (nph - 1) - 1) / (nph - 1);    // epilogue units per wave and phase (phases 1 .. nph - 1 of the next tile)
         for (int ti = 0; ti < Tw; ++ti) {
             for (int k = 0; k < nph; ++k) {               // phase k of this tile: ends at B(rho)
                 // this phase's share of the PREVIOUS tile's epilogue (the hand-over tile is readable from phase 1 on)
@@ -631,8 +650,10 @@ __global__ void __launch_bounds__(768) conv3x3_pc_kernel(C3Args a) {
                     if (k == 0) e_tile(wt0 + ti - 1);
                     else {
                         if (k == 1) commit();
-                        const int k0 = (k - 1) * U, k1 = min(k0 + U, 8);
-                        if (k0 < 8) PC_E_UNITS(k0, k1, wt0 + ti);      // (the next tile to finish is this one: ti < Tw)
+                        if ((k & 1) != grp) {             // this group's turn: active phase number a_ of the tile
+                            const int a_ = grp ? (k >> 1) - 1 : (k >> 1);
+                            for (int bb = 0; bb < BPP; ++bb) { const int b = a_ * BPP + bb; if (b < NB) step_batch(b, wt0 + ti); }
+                        }
                     }
                 }
                 PC_BARRIER();                             // B(rho)
@@ -644,13 +665,11 @@ __global__ void __launch_bounds__(768) conv3x3_pc_kernel(C3Args a) {
         commit();
         PC_BARRIER();                                     // F3 (the sums buffer in LDS is free again)
         if (!eoff_) {
-            PC_E_UNITS(0, 8, -1);
+            for (int b = 0; b < NB; ++b) step_batch(b, -1);
             if (stats) stash();
         }
         PC_BARRIER();                                     // F4
         commit();
-#undef PC_E_UNITS
-#undef PC_E_STEP
     }
 }
 }  // namespace

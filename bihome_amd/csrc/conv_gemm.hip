@@ -1002,6 +1002,7 @@ int bh_debug_force_tile(int bm, int bn) {
     if (bm == -18) { bh_conv3x3_tune(400 + bn, 0); return BH_OK; }       // (-18, bits): 3x3 kernel ablation - 1 no weight DMA, 2 no halo DMA in the loop
     if (bm == -30) { bh_wgrad_x3_tune(0, bn); return BH_OK; }            // (-30, n): workgroups per launch of the f32x3 wgrad kernel
     if (bm == -31) { bh_wgrad_x3_tune(1, bn); return BH_OK; }            // (-31, 1): ablation - that kernel without its atomic flush
+    if (bm == -32) { bh_wgrad_x3_tune(2, bn); return BH_OK; }            // (-32, 0 / 1): the fp16-piece kernel's four-wave / eight-wave (producer + consumer) form
     if (bm == -20) { bh_bn_tune(bn); return BH_OK; }                     // (-20, n): workgroups per BatchNorm apply launch
     if (bm == -14) { bh_warp_tune(0, bn); return BH_OK; }               // (-14, 1|2): warp forward rows per thread
     if (bm == -15) { bh_warp_tune(1, bn); return BH_OK; }               // (-15, 1|2|4): warp adjoint rows per thread

@@ -77,13 +77,21 @@ struct WXGeom {
 // precision 3, common.h bh_split8_2)
 // F16 (NP = 2; round 4): the two pieces are fp16 numbers of the operand times a power-of-two scale per tensor ("f16x2", precision 4); the
 // partial blocks are rescaled by 2^-(k_x + k_gy) when they are flushed
-template <int CB, bool BNI = false, int NP = 3, bool F16 = false>
-__global__ void __launch_bounds__(256, 1) wgrad_x3_kernel(WX3Args a) {
+// PC (round 5; CB = 64, fp16 pieces): the workgroup has EIGHT waves with two roles - waves 0..3 (one per SIMD) only read fragments and issue
+// MFMAs, waves 4..7 (one per SIMD, raised priority) own the staging: they wait for the loads of tile k + 1, cut them into pieces, write the
+// other LDS image and request tile k + 2, all inside the consumers' tile k.  Same tiles per workgroup, same MFMA order, same partial
+// blocks as the four-wave form: the results are bitwise the same; what changes is that the cut's VALU work and the LDS writes no longer
+// sit in the instruction stream of the wave that feeds the matrix pipe (which is alone on its SIMD and stalls for every one of them).
+// Two waves per SIMD leave 256 registers per wave: 144 accumulators + <= 112 for fragments and addresses.
+template <int CB, bool BNI = false, int NP = 3, bool F16 = false, bool PC = false>
+__global__ void __launch_bounds__(PC ? 512 : 256, 1) wgrad_x3_kernel(WX3Args a) {
     static_assert(!F16 || NP == 2, "fp16 pieces: two");
+    static_assert(!PC || (CB == 64 && F16), "producer / consumer form: 64-channel blocks of fp16 pieces");
     using G = WXGeom<CB, NP>;
     constexpr int GS = G::GS, HS = G::HS, NG = G::NG;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool producer = PC && threadIdx.x >= 256;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;      // (PC: index within the role)
     const int wm = CB == 64 ? (wave & 1) : 0, wn = CB == 64 ? (wave >> 1) : 0;      // CB = 64: cout half, cin half of the block
     const int split = blockIdx.x % a.nsplit, pair = blockIdx.x / a.nsplit;
     const int co0 = (pair / a.cbi) * CB, ci0 = (pair % a.cbi) * CB;
@@ -128,9 +136,11 @@ __global__ void __launch_bounds__(256, 1) wgrad_x3_kernel(WX3Args a) {
     for (int j = 0; j < HS; ++j) { h_ok[j] = false; h_tb[j] = 0; }
     constexpr int TB0 = 2 * G::LDS;                               // [groups][CB] x (scale, shift) of this workgroup's input-channel block
     if constexpr (BNI) {
-        for (int i = tid; i < a.bni_groups * CB; i += 256) {
-            const int grp = i / CB, ch = i - grp * CB;
-            reinterpret_cast<float2*>(smem + TB0)[i] = reinterpret_cast<const float2*>(a.bni)[grp * a.Ci + ci0 + ch];
+        if (!PC || producer) {
+            for (int i = tid; i < a.bni_groups * CB; i += 256) {
+                const int grp = i / CB, ch = i - grp * CB;
+                reinterpret_cast<float2*>(smem + TB0)[i] = reinterpret_cast<const float2*>(a.bni)[grp * a.Ci + ci0 + ch];
+            }
         }
     }
     if constexpr (BNI) __syncthreads();
@@ -192,6 +202,30 @@ __global__ void __launch_bounds__(256, 1) wgrad_x3_kernel(WX3Args a) {
 #define WX_SLOT(n, img) stage_slot(std::integral_constant<int, (n)>{}, img)
 #define WX_PART(n, t) issue_part(t, std::integral_constant<int, (n)>{})
 
+    // tiles of this workgroup: split, split + nsplit, ...
+    const int nt = a.ntiles > split ? (a.ntiles - split + a.nsplit - 1) / a.nsplit : 0;
+    if constexpr (PC) {
+        if (producer) {
+            // ---- staging waves: image k & 1 is complete at the barrier that opens the consumers' tile k ----
+            __builtin_amdgcn_s_setprio(2);
+            if (nt > 0) {
+                WX_PART(-1, split);
+                WX_SLOT(0, smem); WX_SLOT(1, smem); WX_SLOT(2, smem); WX_SLOT(3, smem); WX_SLOT(4, smem); WX_SLOT(5, smem);
+                if (nt > 1) WX_PART(-1, split + a.nsplit);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            for (int k = 0; k < nt; ++k) {
+                if (k + 1 < nt) {
+                    char* const nimg = smem + ((k + 1) & 1) * G::LDS;
+                    WX_SLOT(0, nimg); WX_SLOT(1, nimg); WX_SLOT(2, nimg); WX_SLOT(3, nimg); WX_SLOT(4, nimg); WX_SLOT(5, nimg);
+                    if (k + 2 < nt) WX_PART(-1, split + (k + 2) * a.nsplit);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            return;
+        }
+    }
+
     // ---- fragment addresses.  16-lane group (lane >> 4) & 1 -> channels 16..31 of the wave's 32; lane >> 5 = K half.
     // Within a group lane 4j + g points at row j of the 2x2 pixel block (j >> 1 down, j & 1 right), channels 4g..4g+3; the
     // K = 16 step ks covers tile rows 2ks, 2ks + 1: K half kh2 and read r take the block at columns 4 kh2 + 2r.
@@ -219,14 +253,14 @@ __global__ void __launch_bounds__(256, 1) wgrad_x3_kernel(WX3Args a) {
         const i16x4 v1_ = WX_TR(lb, pc * G::XP + (2 * (ks) + (tap) / 3) * G::XROW + ((tap) % 3 + 2) * G::PIX);          \
         dst[pc] = WX_OPER(v0_, v1_); }
 
-    // tiles of this workgroup: split, split + nsplit, ...
-    const int nt = a.ntiles > split ? (a.ntiles - split + a.nsplit - 1) / a.nsplit : 0;
-    if (nt > 0) {
-        WX_PART(-1, split);
-        WX_SLOT(0, smem); WX_SLOT(1, smem); WX_SLOT(2, smem); WX_SLOT(3, smem); WX_SLOT(4, smem); WX_SLOT(5, smem);   // (slots past GS + HS: nothing)
+    if constexpr (!PC) {
+        if (nt > 0) {
+            WX_PART(-1, split);
+            WX_SLOT(0, smem); WX_SLOT(1, smem); WX_SLOT(2, smem); WX_SLOT(3, smem); WX_SLOT(4, smem); WX_SLOT(5, smem);   // (slots past GS + HS: nothing)
+        }
     }
-    __syncthreads();
-    if (nt > 1) WX_PART(-1, split + a.nsplit);
+    if constexpr (PC) asm volatile("s_barrier" ::: "memory"); else __syncthreads();
+    if constexpr (!PC) { if (nt > 1) WX_PART(-1, split + a.nsplit); }
     constexpr int NSTEP = CB == 64 ? 36 : 9;                       // (ks, tap) steps of a wave per tile
     constexpr int NQ = CB == 64 ? 9 : 5;                           // pairs per half of the (two-level, fully unrolled) pair loop
     for (int k = 0; k < nt; ++k) {
@@ -252,7 +286,8 @@ __global__ void __launch_bounds__(256, 1) wgrad_x3_kernel(WX3Args a) {
                     WX_LOAD_B(bf[pb ^ 1][f & 1], f / 9, f % 9);
                 }
             // the next tile: cut and write a register group, then re-request it for the tile after
-            if (CB == 64) {
+            if constexpr (PC) {
+            } else if (CB == 64) {
                 if (pi == 3) { WX_SLOT(0, nimg); WX_SLOT(1, nimg); WX_PART(0, tnext); }
                 if (pi == 8) { WX_SLOT(2, nimg); WX_SLOT(3, nimg); WX_PART(1, tnext); }
                 if (pi == 13) { WX_SLOT(4, nimg); WX_SLOT(5, nimg); WX_PART(2, tnext); }
@@ -358,9 +393,9 @@ __global__ void __launch_bounds__(256) wgrad_x3_reduce_kernel(const float* __res
     }
 }
 
-BH_KNOB(g_wx3_target, 256); BH_KNOB(g_wx3_noflush, 0);
+BH_KNOB(g_wx3_target, 256); BH_KNOB(g_wx3_noflush, 0); BH_KNOB(g_wx3_pc, 1);
 #ifdef BH_TUNING
-void bh_wgrad_x3_tune(int what, int v) { if (what == 0) g_wx3_target = v; else if (what == 1) g_wx3_noflush = v; }
+void bh_wgrad_x3_tune(int what, int v) { if (what == 0) g_wx3_target = v; else if (what == 1) g_wx3_noflush = v; else if (what == 2) g_wx3_pc = v; }
 #endif
 
 // *taken = 1 when the shape is eligible (3x3 / stride 1 / pad 1, NHWC, H and W multiples of 8, channels multiples of 32).
@@ -404,26 +439,31 @@ int bh_wgrad_x3_try(const float* x, const float* gy, float* gw, const bh_conv_de
     // precision 4 (two fp16 pieces): with the magnitude records of both operands; without them the exact three-piece form runs
     const bool f16 = d->precision == 4 && d->a_bound && d->b_bound;
     a.amax_x = reinterpret_cast<const unsigned*>(d->a_bound); a.amax_gy = reinterpret_cast<const unsigned*>(d->b_bound);
-    // (all four template arguments, as rocprofv3 prints the symbol: CB, BNI, NP, F16)
-    if (bh_query(ws ? "wgrad_x3_kernel<%d,%s,%d,%s>+wgrad_x3_reduce_kernel<%d>" : "wgrad_x3_kernel<%d,%s,%d,%s>", cb, bni ? "true" : "false",
-                 (d->precision == 4 && !f16) ? 3 : np, f16 ? "true" : "false", cb)) { *taken = 1; return BH_OK; }
+    // fp16 pieces, 64-channel blocks: the eight-wave producer / consumer form (same partial blocks, bitwise the same sums)
+    const bool pc = f16 && cb == 64 && g_wx3_pc;
+    // (the template arguments as rocprofv3 prints the symbol: CB, BNI, NP, F16 and - when set - PC)
+    if (bh_query(ws ? "wgrad_x3_kernel<%d,%s,%d,%s%s>+wgrad_x3_reduce_kernel<%d>" : "wgrad_x3_kernel<%d,%s,%d,%s%s>", cb, bni ? "true" : "false",
+                 (d->precision == 4 && !f16) ? 3 : np, f16 ? "true" : "false", pc ? ",true" : "", cb)) { *taken = 1; return BH_OK; }
     typedef void (*kern_t)(WX3Args);
-    static const kern_t fns[12] = {wgrad_x3_kernel<64, false, 3>, wgrad_x3_kernel<32, false, 3>, wgrad_x3_kernel<64, true, 3>, wgrad_x3_kernel<32, true, 3>,
+    static const kern_t fns[14] = {wgrad_x3_kernel<64, false, 3>, wgrad_x3_kernel<32, false, 3>, wgrad_x3_kernel<64, true, 3>, wgrad_x3_kernel<32, true, 3>,
                                    wgrad_x3_kernel<64, false, 2>, wgrad_x3_kernel<32, false, 2>, wgrad_x3_kernel<64, true, 2>, wgrad_x3_kernel<32, true, 2>,
-                                   wgrad_x3_kernel<64, false, 2, true>, wgrad_x3_kernel<32, false, 2, true>, wgrad_x3_kernel<64, true, 2, true>, wgrad_x3_kernel<32, true, 2, true>};
-    static const int lds_of[12] = {2 * WXGeom<64, 3>::LDS, 2 * WXGeom<32, 3>::LDS, 2 * WXGeom<64, 3>::LDS, 2 * WXGeom<32, 3>::LDS,
+                                   wgrad_x3_kernel<64, false, 2, true>, wgrad_x3_kernel<32, false, 2, true>, wgrad_x3_kernel<64, true, 2, true>, wgrad_x3_kernel<32, true, 2, true>,
+                                   wgrad_x3_kernel<64, false, 2, true, true>, wgrad_x3_kernel<64, true, 2, true, true>};
+    static const int lds_of[14] = {2 * WXGeom<64, 3>::LDS, 2 * WXGeom<32, 3>::LDS, 2 * WXGeom<64, 3>::LDS, 2 * WXGeom<32, 3>::LDS,
                                    2 * WXGeom<64, 2>::LDS, 2 * WXGeom<32, 2>::LDS, 2 * WXGeom<64, 2>::LDS, 2 * WXGeom<32, 2>::LDS,
-                                   2 * WXGeom<64, 2>::LDS, 2 * WXGeom<32, 2>::LDS, 2 * WXGeom<64, 2>::LDS, 2 * WXGeom<32, 2>::LDS};
+                                   2 * WXGeom<64, 2>::LDS, 2 * WXGeom<32, 2>::LDS, 2 * WXGeom<64, 2>::LDS, 2 * WXGeom<32, 2>::LDS,
+                                   2 * WXGeom<64, 2>::LDS, 2 * WXGeom<64, 2>::LDS};
     static unsigned long long attr_devs = 0;
     if (bh_device_once(attr_devs)) {
-        for (int i = 0; i < 12; ++i) {
+        for (int i = 0; i < 14; ++i) {
+            const bool tb = i < 12 ? (i & 2) != 0 : i == 13;
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[i]), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     lds_of[i] + ((i & 2) ? 4 * ((i & 1) ? 32 : 64) * 8 : 0));
+                                                     lds_of[i] + (tb ? 4 * ((i < 12 && (i & 1)) ? 32 : 64) * 8 : 0));
             if (e != hipSuccess) return (int)e;
         }
     }
-    const int ki = (f16 ? 8 : (np == 2 && d->precision != 4) ? 4 : 0) + (bni ? 2 : 0) + (cb == 64 ? 0 : 1);
-    hipLaunchKernelGGL(fns[ki], dim3(pairs * ns), dim3(256), lds_of[ki] + tb_bytes, stream, a);
+    const int ki = pc ? 12 + (bni ? 1 : 0) : (f16 ? 8 : (np == 2 && d->precision != 4) ? 4 : 0) + (bni ? 2 : 0) + (cb == 64 ? 0 : 1);
+    hipLaunchKernelGGL(fns[ki], dim3(pairs * ns), dim3(pc ? 512 : 256), lds_of[ki] + tb_bytes, stream, a);
     BH_LAUNCH_CHECK();
     if (ws) {
         if (cb == 64) hipLaunchKernelGGL(wgrad_x3_reduce_kernel<64>, dim3(36864 / 64, pairs), dim3(256), 0, stream, ws, gw, ns, a.cbi, d->Ci);

@@ -121,7 +121,8 @@ def test_wgrad_f16x2_kernel(K, N, H, Ci, Co):
         K.conv_wgrad(x, gy, gw, None, d, det_ws=ws)
         err[prec] = _rel(gw, ref)
         if prec == 4:
-            assert K.conv_variant(d, "wgrad_det").startswith("wgrad_x3_kernel<%d,false,2,true>" % (64 if (Ci % 64 == 0 and Co % 64 == 0) else 32))
+            # (64-channel blocks: the eight-wave producer / consumer form, fifth template argument)
+            assert K.conv_variant(d, "wgrad_det").startswith("wgrad_x3_kernel<64,false,2,true,true>" if (Ci % 64 == 0 and Co % 64 == 0) else "wgrad_x3_kernel<32,false,2,true>")
             g1 = torch.ones(Co, 3, 3, Ci, device="cuda")
             K.conv_wgrad(x, gy, g1, None, d, det_ws=ws)
             assert _rel(g1 - 1.0, gw.cpu().double()) < 1e-2 * 1.0 and torch.equal(gw, gw)       # lands on what gw holds (1 + 1e-5-sized entries)

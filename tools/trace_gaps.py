@@ -1,0 +1,43 @@
+"""GPU idle time in a rocprofv3 --kernel-trace CSV of bench.py: union of the kernel intervals over the last steps against the wall span,
+and which kernels the device waited in front of.  python tools/trace_gaps.py <kernel_trace.csv> [span_from_the_end_in_ms=150]"""
+import csv
+import sys
+from collections import defaultdict
+
+rows = []
+with open(sys.argv[1]) as f:
+    for r in csv.DictReader(f):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+rows.sort()
+span_ms = float(sys.argv[2]) if len(sys.argv) > 2 else 150.0
+t_end = max(e for _, e, _ in rows)
+rows = [r for r in rows if r[0] >= t_end - span_ms * 1e6]
+t0 = rows[0][0]
+busy, cur_end, gaps = 0, t0, defaultdict(lambda: [0, 0])
+overlap = 0
+for s, e, name in rows:
+    if s > cur_end:
+        g = s - cur_end
+        short = name.split("(")[0][-60:]
+        gaps[short][0] += g; gaps[short][1] += 1
+        busy += e - s
+        cur_end = e
+    else:
+        overlap += min(e, cur_end) - s
+        if e > cur_end:
+            busy += e - cur_end
+            cur_end = e
+wall = cur_end - t0
+print("kernels %d  wall %.2f ms  busy (union) %.2f ms  idle %.2f ms (%.1f %%)  overlapped kernel time %.2f ms" %
+      (len(rows), wall / 1e6, busy / 1e6, (wall - busy) / 1e6, 100.0 * (wall - busy) / wall, overlap / 1e6))
+hist = defaultdict(int)
+prev_end = t0
+for s, e, name in rows:
+    if s > prev_end:
+        g = (s - prev_end) / 1e3
+        hist["<2us" if g < 2 else "<5us" if g < 5 else "<10us" if g < 10 else "<50us" if g < 50 else ">=50us"] += 1
+    prev_end = max(prev_end, e)
+print("gap histogram:", dict(hist))
+print("idle in front of (top 25):")
+for name, (t, n) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:25]:
+    print("  %8.3f ms  %5d x  %6.2f us  %s" % (t / 1e6, n, t / n / 1e3, name))
