@@ -76,6 +76,7 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true",
                     help="one HIP stream: no weight-gradient side stream, no extractor prefetch under the backbone (the roofline leg "
                          "always runs this way, so that per-kernel durations are those of each kernel alone)")
+    ap.add_argument("--host-profile", action="store_true", help="print the host-side enqueue time per step and a cProfile of five steps to stderr")
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole training step in a HIP graph (bihome_amd.graph.GraphedStep) and time replays")
     ap.add_argument("--hook", action="append", default=[], metavar="A,B",
@@ -427,6 +428,22 @@ def main():
         dt = t.item()
     ms = 1e3 * dt / args.steps
     value = world * B * args.steps / dt
+    if args.host_profile and rank == 0:
+        # host side of the step (tools/: where does Python spend the launch time?): enqueue time per step against the device time, then cProfile
+        import cProfile, pstats
+        sync()
+        th = []
+        for _ in range(10):
+            t1 = time.perf_counter(); one_step(); th.append(time.perf_counter() - t1)
+        sync()
+        print("host enqueue ms per step: %s (device: %.2f)" % (" ".join("%.2f" % (1e3 * v) for v in th), ms), file=sys.stderr)
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(5):
+            one_step()
+        pr.disable()
+        sync()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(45)
     final_loss, final_mace = float(loss.item()), mace(dgt, dh)
 
     # inference leg (eval.py:80-112): eval-mode forward + DLT on fresh batches, BatchNorms folded into the convs

@@ -877,6 +877,195 @@ int bh_bn_maxpool_fwd(const float* x, const float* gamma, const float* beta, flo
     return BH_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Adjoint of bn_maxpool_fwd in two passes over the BatchNorm INPUT (round 5).  Unfused it was bh_maxpool3s2_bwd (writes the 134 MB
+// full-resolution gradient of the extractor stem) followed by bh_bn_bwd (reads it twice, next to x): 850 MB per call, three calls per step.
+// Here the full-resolution gradient never exists: both passes rebuild d(pixel) = sum of the pooled gradients of the (<= 4) windows whose
+// recorded arg-max points at the pixel (the gather form of maxpool_bwd_kernel; gy and idx are a quarter of the size and stay in L2),
+// mask it with the recomputed ReLU and either accumulate (sum d, sum d xhat) - chunk partials in fixed order, bn_bwd_finalize_kernel
+// makes the coefficient table - or write gx = scale (d - mean d - xhat mean(d xhat)).  490 MB per call.
+// ---------------------------------------------------------------------------------------------
+struct PoolGeom { int Hi, Wi, Ho, Wo, ipg; };      // ipg: images per group
+
+// The (<= 4) windows that contain input pixel (iy, ix): rows iy >> 1 and (iy + 1) >> 1 (the same for even iy), columns alike.  Branch-free:
+// all four candidates are loaded (clamped to the first where they do not exist) so that the loads of several pixels can be in flight
+// together; they are added in the order of maxpool_bwd_kernel's loops (bitwise the same d).
+struct PoolTaps {
+    uchar4 w[4];
+    float4 g[4];
+    unsigned char t[4];
+    bool ok[4];
+};
+__device__ __forceinline__ void pooled_taps_load(PoolTaps& q, const unsigned char* __restrict__ idx, const float* __restrict__ gy, const PoolGeom& pg,
+                                                 int n, int iy, int ix, int C4, int c, bool live) {
+    const int oyA = iy >> 1, oyB = (iy + 1) >> 1, oxA = ix >> 1, oxB = (ix + 1) >> 1;
+    const bool vy = oyB != oyA && oyB < pg.Ho, vx = oxB != oxA && oxB < pg.Wo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool by = k >> 1, bx = k & 1;
+        q.ok[k] = live && (!by || vy) && (!bx || vx);
+        const int oy = (by && vy) ? oyB : oyA, ox = (bx && vx) ? oxB : oxA;
+        q.t[k] = (unsigned char)((iy - (oy * 2 - 1)) * 3 + (ix - (ox * 2 - 1)));
+        const size_t o = live ? (((size_t)n * pg.Ho + oy) * pg.Wo + ox) * C4 + c : 0;
+        q.w[k] = *reinterpret_cast<const uchar4*>(idx + o * 4);
+        q.g[k] = *reinterpret_cast<const float4*>(gy + o * 4);
+    }
+}
+__device__ __forceinline__ float4 pooled_taps_sum(const PoolTaps& q) {
+    float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (q.ok[k] && q.w[k].x == q.t[k]) d.x += q.g[k].x;
+        if (q.ok[k] && q.w[k].y == q.t[k]) d.y += q.g[k].y;
+        if (q.ok[k] && q.w[k].z == q.t[k]) d.z += q.g[k].z;
+        if (q.ok[k] && q.w[k].w == q.t[k]) d.w += q.g[k].w;
+    }
+    return d;
+}
+
+// grid (nchunks, groups): rows of a group = its images' pixels, as bn_bwd_reduce_kernel; four rows per lane in flight
+__global__ void __launch_bounds__(256) bn_maxpool_bwd_reduce_kernel(const float* __restrict__ gy, const unsigned char* __restrict__ idx,
+                                                                    const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, const double* __restrict__ stats,
+                                                                    const float* __restrict__ rmean, const float* __restrict__ rvar, BnGeom g,
+                                                                    PoolGeom pg, float eps, int relu, int use_running, double* __restrict__ part) {
+    __shared__ double sm[256 * 8];
+    const int cq = threadIdx.x % g.LPR, r0 = threadIdx.x / g.LPR;
+    const int grp = blockIdx.y, chunk = blockIdx.x;
+    const int rbeg = chunk * g.rows_per_chunk, rend = min(g.rows, rbeg + g.rows_per_chunk);
+    float mean[4], invstd[4], sc[4], sh[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        bn_coeffs(stats, gamma, beta, rmean, rvar, use_running, g.groups, grp, g.C, cq * 4 + i, eps, (double)g.rows, mean[i], invstd[i], sc[i], sh[i], g.det);
+    const size_t gbase = ((size_t)grp * g.rows) * g.C + cq * 4;
+    const int hw = pg.Hi * pg.Wi;
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r = rbeg + r0; r < rend; r += 4 * g.RPP) {
+        float4 a[4];
+        PoolTaps q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r + u * g.RPP;
+            const bool live = rr < rend;
+            const int rc = live ? rr : rbeg;
+            const int nl = rc / hw, p = rc - nl * hw, iy = p / pg.Wi, ix = p - iy * pg.Wi;
+            a[u] = *reinterpret_cast<const float4*>(x + gbase + (size_t)rc * g.C);
+            pooled_taps_load(q[u], idx, gy, pg, grp * pg.ipg + nl, iy, ix, g.C4, cq, live);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (r + u * g.RPP >= rend) break;
+            float4 d = pooled_taps_sum(q[u]);
+            const float4 av = a[u];
+            if (relu) {
+                if (!(av.x * sc[0] + sh[0] > 0.f)) d.x = 0.f;
+                if (!(av.y * sc[1] + sh[1] > 0.f)) d.y = 0.f;
+                if (!(av.z * sc[2] + sh[2] > 0.f)) d.z = 0.f;
+                if (!(av.w * sc[3] + sh[3] > 0.f)) d.w = 0.f;
+            }
+            v[0] += d.x; v[1] += d.y; v[2] += d.z; v[3] += d.w;
+            v[4] += (double)(d.x * ((av.x - mean[0]) * invstd[0]));
+            v[5] += (double)(d.y * ((av.y - mean[1]) * invstd[1]));
+            v[6] += (double)(d.z * ((av.z - mean[2]) * invstd[2]));
+            v[7] += (double)(d.w * ((av.w - mean[3]) * invstd[3]));
+        }
+    }
+    reduce_rows<8>(v, g.LPR, g.RPP, sm);
+    if ((int)threadIdx.x < g.LPR) {
+        double* p = part + (((size_t)grp * g.nchunks + chunk) * g.C + cq * 4) * 2;
+        for (int i = 0; i < 4; ++i) { p[i * 2] = v[i]; p[i * 2 + 1] = v[4 + i]; }
+    }
+}
+
+// grid (nblk, groups); coef[grp][c] = (mean, invstd, mean d, mean d xhat) from bn_bwd_finalize_kernel
+__global__ void __launch_bounds__(256) bn_maxpool_bwd_apply_kernel(const float* __restrict__ gy, const unsigned char* __restrict__ idx,
+                                                                   const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, const float4* __restrict__ coef,
+                                                                   float* __restrict__ gx, BnGeom g, PoolGeom pg, int relu,
+                                                                   unsigned* __restrict__ amax) {
+    __shared__ float sm_amax[4];
+    float vmax = 0.f;
+    const int cq = threadIdx.x % g.LPR, r0 = threadIdx.x / g.LPR;
+    const int grp = blockIdx.y;
+    float mean[4], invstd[4], sc[4], sh[4], k1[4], k2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = cq * 4 + i;
+        const float4 cf = coef[(size_t)grp * g.C + c];
+        const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+        mean[i] = cf.x; invstd[i] = cf.y; k1[i] = cf.z; k2[i] = cf.w;
+        sc[i] = gm * cf.y;
+        sh[i] = bt - cf.x * sc[i];
+    }
+    const size_t gbase = ((size_t)grp * g.rows) * g.C + cq * 4;
+    const int hw = pg.Hi * pg.Wi;
+    const int stride = gridDim.x * g.RPP;
+    for (int r = blockIdx.x * g.RPP + r0; r < g.rows; r += 4 * stride) {
+        float4 a[4];
+        PoolTaps q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r + u * stride;
+            const bool live = rr < g.rows;
+            const int rc = live ? rr : 0;
+            const int nl = rc / hw, p = rc - nl * hw, iy = p / pg.Wi, ix = p - iy * pg.Wi;
+            a[u] = *reinterpret_cast<const float4*>(x + gbase + (size_t)rc * g.C);
+            pooled_taps_load(q[u], idx, gy, pg, grp * pg.ipg + nl, iy, ix, g.C4, cq, live);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r + u * stride;
+            if (rr >= g.rows) break;
+            float4 d = pooled_taps_sum(q[u]);
+            const float4 av = a[u];
+            if (relu) {
+                if (!(av.x * sc[0] + sh[0] > 0.f)) d.x = 0.f;
+                if (!(av.y * sc[1] + sh[1] > 0.f)) d.y = 0.f;
+                if (!(av.z * sc[2] + sh[2] > 0.f)) d.z = 0.f;
+                if (!(av.w * sc[3] + sh[3] > 0.f)) d.w = 0.f;
+            }
+            float4 o;
+            o.x = sc[0] * (d.x - k1[0] - (av.x - mean[0]) * invstd[0] * k2[0]);
+            o.y = sc[1] * (d.y - k1[1] - (av.y - mean[1]) * invstd[1] * k2[1]);
+            o.z = sc[2] * (d.z - k1[2] - (av.z - mean[2]) * invstd[2] * k2[2]);
+            o.w = sc[3] * (d.w - k1[3] - (av.w - mean[3]) * invstd[3] * k2[3]);
+            *reinterpret_cast<float4*>(gx + gbase + (size_t)rr * g.C) = o;
+            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+        }
+    }
+    if (amax) bh_amax_commit(amax, vmax, blockIdx.x + blockIdx.y * 7u, sm_amax);
+}
+
+int bh_bn_maxpool_bwd(const float* gy, const unsigned char* idx, const float* x, const float* gamma, const float* beta, const double* stats,
+                      float* gx, float* ggamma, float* gbeta, double* scratch, int groups, int N, int Hi, int Wi, int C, float eps, int flags,
+                      int use_running, const float* running_mean, const float* running_var, float* amax_gx, void* stream) {
+    BnGeom g;
+    if (!gy || !idx || !x || !gx || !stats || !scratch || N < 1 || groups < 1 || N % groups) return BH_E_BADARG;
+    if (use_running && (!running_mean || !running_var)) return BH_E_BADARG;
+    const long long rows = (long long)(N / groups) * Hi * Wi;
+    if (rows >= (1ll << 31) || !bn_geom(groups, (int)rows, C, g, (flags & BH_BN_DETERMINISTIC) ? 1 : 0)) return BH_E_UNSUPPORTED;
+    PoolGeom pg = {Hi, Wi, (Hi - 1) / 2 + 1, (Wi - 1) / 2 + 1, N / groups};
+    hipStream_t s = bh_stream(stream);
+    // scratch as in bh_bn_bwd: [groups][C] float4 coefficient table, then the per-chunk partial sums
+    float4* coef = reinterpret_cast<float4*>(scratch);
+    double* part = scratch + (size_t)groups * C * 2;
+    const bool need_sums = !use_running || ggamma || gbeta;
+    if (need_sums) {
+        hipLaunchKernelGGL(bn_maxpool_bwd_reduce_kernel, dim3(g.nchunks, groups), dim3(256), 0, s, gy, idx, x, gamma, beta, stats, running_mean,
+                           running_var, g, pg, eps, flags & 1, use_running, part);
+        BH_LAUNCH_CHECK();
+    }
+    BnGeom gf = g;
+    if (!need_sums) gf.nchunks = 0;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, part, gf, stats, running_mean, running_var, eps, use_running, ggamma,
+                       gbeta, coef);
+    BH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_maxpool_bwd_apply_kernel, dim3(apply_blocks(g), groups), dim3(256), 0, s, gy, idx, x, gamma, beta, coef, gx, g, pg,
+                       flags & 1, reinterpret_cast<unsigned*>(amax_gx));
+    BH_LAUNCH_CHECK();
+    return BH_OK;
+}
+
 int bh_bn_join_scratch_doubles(int groups, int C) { return groups * C * 2 + groups * C * 3 * (BN_MAX_CHUNKS > 256 ? BN_MAX_CHUNKS : 256); }
 
 int bh_bn_join_fwd(const float* xa, const float* xb, const float* gamma_a, const float* beta_a, float* rmean_a, float* rvar_a,

@@ -1108,6 +1108,33 @@ def maxpool_fwd(x, want_index=True):
     return y, idx
 
 
+class PooledGrad:
+    """Gradient of a BnPooled slot: the pooled gradient and the arg-max positions, handed from the pooling op's adjoint to the BatchNorm's
+    (bn_maxpool_bwd) - the full-resolution gradient in between is never formed."""
+    __slots__ = ("gy", "idx")
+
+    def __init__(self, gy, idx):
+        self.gy, self.idx = gy, idx
+
+
+def bn_maxpool_bwd(pg, x, gamma, beta, stats, rmean, rvar, groups, eps, relu, training, ggamma=None, gbeta=None, amax=None):
+    """Adjoint of bn_maxpool_fwd: PooledGrad + the BatchNorm input -> gx (bh_bn_maxpool_bwd; bitwise what maxpool_bwd + bn_bwd give)."""
+    gy, idx = pg.gy, pg.idx
+    _chk(gy); _chk(idx, torch.uint8); _chk(x)
+    N, Hi, Wi, C = x.shape
+    gx = torch.empty_like(x)
+    scratch = torch.empty(lib.bh_bn_scratch_doubles(groups, C), dtype=torch.float64, device=x.device)
+    flags = (1 if relu else 0) | (BN_DETERMINISTIC if deterministic() else 0)
+    with _Timed("bn_maxpool_bwd(3 kernels)" + (" g%d N%d %dx%d C%d" % (groups, N, Hi, Wi, C) if TIMING_DETAIL else ""), 0.0,
+                4.0 * (3 * x.numel() + 2 * gy.numel()) + 2.0 * idx.numel()):
+        check(lib.bh_bn_maxpool_bwd(_p(gy), _p(idx), _p(x), _p(gamma), _p(beta), _p(stats), _p(gx), _p(ggamma), _p(gbeta), _p(scratch), groups,
+                                    N, Hi, Wi, C, float(eps), flags, 0 if training else 1, _p(rmean), _p(rvar), _p(amax), _stream()),
+              "bh_bn_maxpool_bwd")
+    if amax is not None:
+        gx._bh_amax = amax
+    return gx
+
+
 def maxpool_bwd(idx, gy, in_shape):
     _chk(idx, torch.uint8); _chk(gy)
     N, Hi, Wi, C = in_shape

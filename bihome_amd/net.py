@@ -14,6 +14,7 @@ MI355X-first choices:
     in a HIP graph.
 """
 import os
+import sys
 import weakref
 
 import torch
@@ -600,6 +601,29 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
                 pm = prog.ops[p].mod
                 if pm.bias is not None and pm.bias.requires_grad and pm.weight.requires_grad and prog.ops[p].extra["weight_fn"] is None:
                     fuse_bias[j] = p
+    if os.environ.get("BIHOME_BN_PLAN") == "1" and not getattr(prog, "_bn_plan_printed", False):
+        # tools/: which BatchNorm adjoints still run their own reduce pass, and what completes their output gradient
+        prog._bn_plan_printed = True
+        lc = {}
+        for j, op in enumerate(prog.ops):
+            for sl in (op.src, op.res):
+                if sl is not None and sl not in lc:
+                    lc[sl] = j
+        for b, op in enumerate(prog.ops):
+            if op.kind != "bn":
+                continue
+            j = lc.get(op.dst)
+            cons = prog.ops[j] if j is not None else None
+            what = "output" if cons is None else cons.kind
+            if cons is not None and cons.kind == "conv":
+                m = cons.mod
+                what = "%s k%s s%s %d->%d" % (type(m).__name__, getattr(m, "kernel_size", "?"), getattr(m, "stride", "?"),
+                                               getattr(m, "in_channels", getattr(m, "in_features", 0)), getattr(m, "out_channels", getattr(m, "out_features", 0)))
+            elif cons is not None and cons.kind == "bn":
+                what = "bn(res)" if cons.res == op.dst else "bn"
+            print("BN_PLAN op %3d C%-4d %s last consumer: op %s %s | fused=%s joined=%s shape=%s" %
+                  (b, op.mod.num_features, "relu" if op.relu else "    ", j, what, b in fuse_bn.values(), b in ctx.joined,
+                   tuple(slots[op.src].shape) if hasattr(slots[op.src], "shape") else "?"), file=sys.stderr)
     red_off, total = {}, 0
     bias_off = {}
     for j, p in fuse_bias.items():
@@ -695,6 +719,16 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
             yb = slots[op.dst]
             if isinstance(yb, (K.BnOnLoad, K.BnPooled)):  # applied on load by its consumer / fused with the pooling: no output tensor (the mask comes from x)
                 yb = None
+            if isinstance(g, K.PooledGrad):              # BatchNorm (+ReLU) + MaxPool in one pass: its adjoint in one call too
+                gx = K.bn_maxpool_bwd(g, x, m.weight, m.bias, ctx.stats[i], m.running_mean, m.running_var, ctx.groups, m.eps, op.relu,
+                                      ctx.training, m.weight.grad if train_w else None, m.bias.grad if train_w else None,
+                                      amax=amax_next() if (amax_next and m.num_features > 1) else None)
+                if train_w and on_param_grad is not None:
+                    on_param_grad(m.weight)
+                    on_param_grad(m.bias)
+                if need_src_grad:
+                    contribute(op.src, gx)
+                continue
             gx, gres = K.bn_bwd(g, yb, x, m.weight, ctx.stats[i], m.running_mean, m.running_var, ctx.groups,
                                 m.eps, op.relu, ctx.training, op.res is not None and ((op.res != 0) or want_input_grad),
                                 m.weight.grad if train_w else None, m.bias.grad if train_w else None, beta=m.bias,
@@ -731,7 +765,10 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
                 contribute(op.src, gx)
         elif op.kind == "maxpool":
             if need_src_grad:
-                contribute(op.src, K.maxpool_bwd(ctx.stats[i], g, tuple(x.shape)))
+                if isinstance(x, K.BnPooled) and op.src not in grads and os.environ.get("BIHOME_BN_POOL_BWD", "1") != "0":
+                    grads[op.src] = K.PooledGrad(g, ctx.stats[i])          # (consumed by the BatchNorm's adjoint: bn_maxpool_bwd)
+                else:
+                    contribute(op.src, K.maxpool_bwd(ctx.stats[i], g, tuple(x.shape)))
         elif op.kind == "gap":
             if need_src_grad:
                 contribute(op.src, K.gap_bwd(g, tuple(x.shape)))

@@ -451,6 +451,14 @@ int bh_bn_bwd_amax(const float* gy, const float* y, const float* x, const float*
 int bh_bn_maxpool_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* y,
                       unsigned char* idx, double* stats, int groups, int N, int Hi, int Wi, int C, float eps, float momentum, int flags,
                       int use_running, float* amax_y, void* stream);
+/* Adjoint of bh_bn_maxpool_fwd in one call (round 5): gy[N,Ho,Wo,C] and idx as written by the forward, x the BatchNorm input -> gx[N,Hi,Wi,C]
+ * (and ggamma / gbeta +=, NULL ok).  The full-resolution gradient between pooling and BatchNorm is never stored (bh_maxpool3s2_bwd + bh_bn_bwd
+ * wrote and re-read it: 850 -> 490 MB on the extractor stem, /root/reference/src/heads/PerceptualHead.py:50-60).  scratch: bh_bn_scratch_doubles
+ * doubles; flags: bit0 relu (mask recomputed from x), BH_BN_DETERMINISTIC; use_running / running_* / amax_gx as in bh_bn_bwd_amax.  The sums are
+ * chunk partials added in fixed order: bitwise reproducible in either mode. */
+int bh_bn_maxpool_bwd(const float* gy, const unsigned char* idx, const float* x, const float* gamma, const float* beta, const double* stats,
+                      float* gx, float* ggamma, float* gbeta, double* scratch, int groups, int N, int Hi, int Wi, int C, float eps, int flags,
+                      int use_running, const float* running_mean, const float* running_var, float* amax_gx, void* stream);
 /* Two-branch join (round 4): y = act(bn_a(xa) + bn_b(xb)), both BatchNorms in training mode with their own statistics tables (already
  * accumulated: by the producers' epilogues or bh_bn_stats-style passes) - the end of ResNet50DeconvBlock / the strided ResNet34ConvBlock
  * (src/backbones/utils.py:60-82, 85-112) without writing the normalised lower branch.  flags: bit0 relu, BH_BN_DETERMINISTIC.  Running

@@ -1055,3 +1055,11 @@ def test_batchnorm_relu_maxpool_in_one_pass(K, groups, N, H, C, training):
     gx_ref, _ = K.bn_bwd(gy_ref, y, x, gamma, st, rm0, rv0, groups, 1e-5, True, training, False, beta=beta, had_res=False)
     gx, _ = K.bn_bwd(gy, None, x, gamma, st1, rm1, rv1, groups, 1e-5, True, training, False, beta=beta, had_res=False)
     assert ((gx - gx_ref).norm() / gx_ref.norm()).item() < 2e-3       # (a different tap of a tie moves single elements)
+    # round 5: the adjoint in one call (bh_bn_maxpool_bwd - the full-resolution gradient is never stored): bitwise the two-call result, also
+    # the parameter gradients and the magnitude record
+    gg0, gb0, gg1, gb1 = (torch.zeros(C, device="cuda") for _ in range(4))
+    rec0, rec1 = K.amax_record("cuda"), K.amax_record("cuda")
+    gx0, _ = K.bn_bwd(gy, None, x, gamma, st1, rm1, rv1, groups, 1e-5, True, training, False, gg0, gb0, beta=beta, had_res=False, amax=rec0)
+    gx1 = K.bn_maxpool_bwd(K.PooledGrad(gp, fused.idx), x, gamma, beta, st1, rm1, rv1, groups, 1e-5, True, training, gg1, gb1, amax=rec1)
+    assert torch.equal(gx1, gx0) and torch.equal(gg1, gg0) and torch.equal(gb1, gb0)
+    assert float(rec1.max()) == float(rec0.max()) == float(gx0.abs().max())

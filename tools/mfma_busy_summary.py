@@ -20,7 +20,7 @@ def main():
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.defaultdict(int)
     for r in csv.DictReader(open(sys.argv[1])):
-        k = re.sub(r"^void ", "", r["Kernel_Name"])
+        k = re.sub(r"^void ", "", r["Kernel_Name"]).replace("(anonymous namespace)::", "")
         k = re.sub(r"\(.*$", "", k).replace(" ", "")
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Counter_Name"] == "GRBM_GUI_ACTIVE":

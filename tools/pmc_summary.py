@@ -17,7 +17,7 @@ import sys
 def agg(path):
     out = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(path)):
-        k = re.sub(r"^void ", "", r["Kernel_Name"])
+        k = re.sub(r"^void ", "", r["Kernel_Name"]).replace("(anonymous namespace)::", "")
         k = re.sub(r"\(.*$", "", k).replace(" ", "")
         out[k][0] += 1
         out[k][1] += float(r["Counter_Value"])

@@ -1,5 +1,5 @@
 """GPU idle time in a rocprofv3 --kernel-trace CSV of bench.py: union of the kernel intervals over the last steps against the wall span,
-and which kernels the device waited in front of.  python tools/trace_gaps.py <kernel_trace.csv> [span_from_the_end_in_ms=150]"""
+and which kernels the device waited in front of.  python tools/trace_gaps.py <kernel_trace.csv> [first_step=10] [last_step=20]"""
 import csv
 import sys
 from collections import defaultdict
@@ -9,9 +9,13 @@ with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-span_ms = float(sys.argv[2]) if len(sys.argv) > 2 else 150.0
-t_end = max(e for _, e, _ in rows)
-rows = [r for r in rows if r[0] >= t_end - span_ms * 1e6]
+# window: the launches between two occurrences of the optimiser kernel (flat_adam) - whole training steps out of the timed region
+marks = [i for i, r in enumerate(rows) if "adam" in r[2].lower()]
+lo = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+hi = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+if len(marks) > hi:
+    rows = rows[marks[lo] + 1:marks[hi] + 1]
+    print("steps %d..%d of the trace: %.3f ms per step" % (lo, hi, (rows[-1][1] - rows[0][0]) / 1e6 / (hi - lo)))
 t0 = rows[0][0]
 busy, cur_end, gaps = 0, t0, defaultdict(lambda: [0, 0])
 overlap = 0
