@@ -954,6 +954,11 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
 int bn_launch_stats(const float* x, int groups, int rows, int C, double* sums, hipStream_t s, int det);
 int bh_stem7_try(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, int relu,
                  hipStream_t stream, int* taken, double* bn_sums = nullptr, int groups = 1);
+int bh_pointwise_try(const float* x, const float* w, const float* bias, float* y, const bh_conv_desc* d, hipStream_t stream, int* taken,
+                     double* bn_sums, int groups, float* amax_y, const bh_bn_in* bni);
+#ifdef BH_TUNING
+void bh_pointwise_tune(int what, int v);
+#endif
 
 static int check_desc(const bh_conv_desc* d) {
     if (!d) return BH_E_BADARG;
@@ -1002,6 +1007,8 @@ int bh_debug_force_tile(int bm, int bn) {
     if (bm == -18) { bh_conv3x3_tune(400 + bn, 0); return BH_OK; }       // (-18, bits): 3x3 kernel ablation - 1 no weight DMA, 2 no halo DMA in the loop
     if (bm == -30) { bh_wgrad_x3_tune(0, bn); return BH_OK; }            // (-30, n): workgroups per launch of the f32x3 wgrad kernel
     if (bm == -31) { bh_wgrad_x3_tune(1, bn); return BH_OK; }            // (-31, 1): ablation - that kernel without its atomic flush
+    if (bm == -33) { bh_pointwise_tune(0, bn); return BH_OK; }           // (-33, 0 / 1): the pointwise streaming kernel off / on
+    if (bm == -34) { bh_pointwise_tune(1, bn); return BH_OK; }           // (-34, n): its workgroups per launch
     if (bm == -32) { bh_wgrad_x3_tune(2, bn); return BH_OK; }            // (-32, 0 / 1): the fp16-piece kernel's four-wave / eight-wave (producer + consumer) form
     if (bm == -20) { bh_bn_tune(bn); return BH_OK; }                     // (-20, n): workgroups per BatchNorm apply launch
     if (bm == -14) { bh_warp_tune(0, bn); return BH_OK; }               // (-14, 1|2): warp forward rows per thread
@@ -1036,6 +1043,12 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, cons
     if (!bn_sums && !amax_y && !bni) {
         int taken = 0;
         rc = bh_conv3x3_try(x, w, bias, y, d, 0, 0, bh_stream(stream), &taken, nullptr, 1, res, relu);
+        if (rc || taken) return rc;
+    }
+    if (!res && !relu && (!bn_sums || (groups >= 1 && d->N % groups == 0))) {
+        // the decoder's pointwise layers on the large maps: the persistent streaming kernel (csrc/pointwise.hip)
+        int taken = 0;
+        rc = bh_pointwise_try(x, w, bias, y, d, bh_stream(stream), &taken, bn_sums, groups, amax_y, bni);
         if (rc || taken) return rc;
     }
     GemmArgs a = {};
