@@ -38,7 +38,7 @@ int bh_device_arch(char* buf, int buflen) {
 }
 
 int bh_conv_variant(const bh_conv_desc* d, int which, int accumulate, int with_bnstats /* = bn_groups */, char* buf, int n) {
-    if (!d || !buf || n < 2 || which < 0 || which > 3) return BH_E_BADARG;
+    if (!d || !buf || n < 2 || which < 0 || which > 6) return BH_E_BADARG;
     BhQuery q;
     q.name[0] = 0; q.len = 0;
     // non-null placeholders: in query mode no kernel is launched and no pointer is dereferenced
@@ -49,7 +49,13 @@ int bh_conv_variant(const bh_conv_desc* d, int which, int accumulate, int with_b
     if (which == 0) rc = with_bnstats ? bh_conv_fwd_bnstats(p, p, nullptr, p, d, pd, with_bnstats, nullptr) : bh_conv_fwd(p, p, nullptr, p, d, nullptr);
     else if (which == 1) rc = bh_conv_dgrad(p, p, p, d, accumulate, nullptr);
     else if (which == 2) rc = bh_conv_wgrad(p, p, p, nullptr, d, nullptr);
-    else rc = bh_conv_wgrad_det(p, p, p, nullptr, d, p, 1ll << 40, nullptr);      // 3: the workspace form
+    else if (which == 3) rc = bh_conv_wgrad_det(p, p, p, nullptr, d, p, 1ll << 40, nullptr);      // 3: the workspace form
+    else if (which == 6) rc = bh_conv_dgrad_colsum(p, p, p, d, pd, nullptr);
+    else {                                                                        // 4 / 5: bh_conv_dgrad_bnreduce, mask from z / from y
+        bh_bn_reduce bnr = {};
+        bnr.z = p; bnr.y = which == 5 ? p : nullptr; bnr.stats = pd; bnr.gamma = p; bnr.beta = p; bnr.eps = 1e-5f; bnr.relu = 1;
+        rc = bh_conv_dgrad_bnreduce(p, p, p, d, accumulate, &bnr, pd, with_bnstats > 0 ? with_bnstats : 1, nullptr);
+    }
     bh_query_ctx = nullptr;
     if (rc) return rc;
     strncpy(buf, q.name, (size_t)n - 1);

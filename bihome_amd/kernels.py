@@ -156,7 +156,7 @@ def conv_variant(d, which, accumulate=False, bn_groups=0):
             # (routing does not depend on the magnitude records, but a precision-4 launch without one is refused: describe it with a dummy)
             d = _with_layout(d, d.w_layout)
             d.a_bound = d.b_bound = 256
-        check(lib.bh_conv_variant(ctypes.byref(d), {"fwd": 0, "dgrad": 1, "wgrad": 2, "wgrad_det": 3}[which], int(bool(accumulate)), int(bn_groups),
+        check(lib.bh_conv_variant(ctypes.byref(d), {"fwd": 0, "dgrad": 1, "wgrad": 2, "wgrad_det": 3, "dgrad_bnr_z": 4, "dgrad_bnr_y": 5, "dgrad_colsum": 6}[which], int(bool(accumulate)), int(bn_groups),
                                   buf, 256), "bh_conv_variant")
         v = _VARIANT_CACHE[key] = buf.value.decode()
     return v
@@ -167,7 +167,7 @@ def _conv_variant(d, which, accumulate=False, bn_groups=0):
         return ""
     v = conv_variant(d, which, accumulate, bn_groups)
     if TIMING_DETAIL:
-        v += " %s N%d %dx%d C%d->%d k%d s%d%s" % (which, d.N, d.Hi, d.Wi, d.Ci, d.Co, d.kh, d.stride, " T" if d.transposed else "")
+        v += " %s N%d %dx%d C%d->%d k%d s%d%s" % (which.split("_")[0], d.N, d.Hi, d.Wi, d.Ci, d.Co, d.kh, d.stride, " T" if d.transposed else "")
     return v
 
 
@@ -790,7 +790,7 @@ def conv_dgrad(gy, w, d, out=None, bn_reduce=None, wkey=None, wpacked=None, cols
         assert out is None and bn_reduce is None
         _chk(colsum, torch.float64)
         out = torch.empty((d.N, d.Hi, d.Wi, d.Ci), dtype=torch.float32, device=gy.device)
-        with _Timed(_conv_variant(d, "dgrad"), conv_flops(d), 4.0 * (gy.numel() + out.numel() + w.numel())):
+        with _Timed(_conv_variant(d, "dgrad_colsum"), conv_flops(d), 4.0 * (gy.numel() + out.numel() + w.numel())):
             check(lib.bh_conv_dgrad_colsum(_p(gy), _p(w), _p(out), ctypes.byref(d), _p(colsum), _stream()), "bh_conv_dgrad_colsum")
         return out
     if bn_reduce is not None:
@@ -800,7 +800,8 @@ def conv_dgrad(gy, w, d, out=None, bn_reduce=None, wkey=None, wpacked=None, cols
         b = bn_reduce
         _chk(b["z"]); _chk(b["y"]); _chk(b["stats"], torch.float64); _chk(b["sums"], torch.float64)
         st = BhBnReduce(_p(b["z"]), _p(b["y"]), _p(b["stats"]), _p(b["gamma"]), _p(b["beta"]), float(b["eps"]), int(bool(b["relu"])))
-        with _Timed(_conv_variant(d, "dgrad", acc), conv_flops(d), 4.0 * (gy.numel() + out.numel() * (3 if acc else 2) + w.numel())):
+        with _Timed(_conv_variant(d, "dgrad_bnr_y" if b["y"] is not None else "dgrad_bnr_z", acc, int(b["groups"])), conv_flops(d),
+                    4.0 * (gy.numel() + out.numel() * ((3 if acc else 2) + (1 if b["y"] is not None else 0)) + w.numel())):
             check(lib.bh_conv_dgrad_bnreduce(_p(gy), _p(w), _p(out), ctypes.byref(d), int(acc), ctypes.byref(st), _p(b["sums"]),
                                              int(b["groups"]), _stream()), "bh_conv_dgrad_bnreduce")
         if acc:

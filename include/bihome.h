@@ -290,7 +290,8 @@ int bh_conv3x3_pack(const bh_pack3x3_job* jobs_dev, int njobs, void* stream);
 /* the same for tables with split = 3 jobs: one more launch in front that takes the layers' max |w| */
 int bh_conv3x3_pack_f16(const bh_pack3x3_job* jobs_dev, int njobs, void* stream);
 
-/* Which kernel a launch described by d would run: which = 0 forward, 1 dgrad, 2 wgrad, 3 wgrad through a workspace (bh_conv_wgrad_det).  Writes the kernel template
+/* Which kernel a launch described by d would run: which = 0 forward, 1 dgrad, 2 wgrad, 3 wgrad through a workspace (bh_conv_wgrad_det),
+ * 4 / 5 bh_conv_dgrad_bnreduce with the ReLU mask from z / from y (bn_groups = its groups), 6 bh_conv_dgrad_colsum.  Writes the kernel template
  * instantiation (the symbol rocprofv3 lists, e.g. "conv3x3_halo_kernel<false,64,false,2>"; several launches joined by
  * '+') into buf[n].  Runs the real dispatch code with the launches replaced by a name record, so it cannot drift from it.
  * accumulate / bn_groups (0: plain bh_conv_fwd, > 0: bh_conv_fwd_bnstats with that many groups) mirror the arguments of

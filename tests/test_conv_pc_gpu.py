@@ -86,6 +86,32 @@ def test_forward_bit_identical(K, N, H, Ci, Co):
     assert ((y - ref).norm() / ref.norm()).item() < 1e-6
 
 
+def test_epilogue_store_hazard_stress(K):
+    """Round 5: a 128-bit buffer store whose data registers were overwritten by the next VALU instruction corrupted single channels in a few
+    of 2048 sub-tiles, and only under some timings (csrc/conv3x3_pc.hip: the `s_nop 3` behind the store).  The forms that hit it - epilogue
+    operands on the multi-tile shape - repeated, with a second stream keeping the memory system busy."""
+    N, H, Ci, Co = 128, 32, 64, 64
+    new, old = _descs(K, N, H, Ci, Co)
+    x, gy, wk, b, pf, pd, g = _operands(K, N, H, Ci, Co, seed=5)
+    res = torch.randn(N, H, H, Co, generator=g).cuda()
+    base = torch.randn(N, H, H, Ci, generator=g).cuda()
+    y0 = K.conv_fwd(x, wk, b, old, res=res, relu=True, wpacked=pf)
+    o0 = base.clone()
+    K.conv_dgrad(gy, wk, old, out=o0, wpacked=pd)
+    side = torch.cuda.Stream()
+    junk = torch.empty(1 << 26, device="cuda")
+    for it in range(12):
+        if it % 2:
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    junk.add_(1.0)
+        assert torch.equal(K.conv_fwd(x, wk, b, new, res=res, relu=True, wpacked=pf), y0)
+        o1 = base.clone()
+        K.conv_dgrad(gy, wk, new, out=o1, wpacked=pd)
+        assert torch.equal(o1, o0)
+    torch.cuda.synchronize()
+
+
 # (shapes the BatchNorm kernels take: two groups, C / 4 dividing 256; (4, 16, 32, 64) is a ONE-chunk forward: three barrier phases per tile)
 BN_SHAPES = [s for s in SHAPES if s[0] % 2 == 0 and 256 % (s[2] // 4) == 0] + [(4, 16, 32, 64), (24, 16, 32, 64)]
 
