@@ -115,6 +115,7 @@ SIGNATURES = {
     "bh_bn_join_scratch_doubles": [c_int, c_int],
     "bh_bn_join_fwd": [P] * 13 + [c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int, P, P],
     "bh_bn_join_bwd": [P] * 15 + [c_int, c_int, c_int, c_float, c_float, c_int, P, P, P],
+    "bh_bn_join_bwd_remask": [P] * 16 + [c_int, c_int, c_int, c_float, c_float, c_int, P, P, P],
     "bh_tail_ws_doubles": [c_int, c_int, c_int],
     "bh_tail_scratch_floats": [c_int, c_int, c_int],
     "bh_tail_fwd": [P] * 11 + [c_int] * 6 + [c_float, c_float, c_int, P],

@@ -540,7 +540,9 @@ __global__ void __launch_bounds__(256) bn_join_apply_kernel(const float* __restr
 __global__ void __launch_bounds__(256) bn_join_bwd_reduce_kernel(const float* __restrict__ gy, const float* __restrict__ y,
                                                                  const float* __restrict__ xa, const float* __restrict__ xb,
                                                                  const double* __restrict__ stats_a, const double* __restrict__ stats_b,
-                                                                 BnGeom g, float eps_a, float eps_b, int relu, double* __restrict__ part) {
+                                                                 BnGeom g, float eps_a, float eps_b, int relu, double* __restrict__ part,
+                                                                 const float* __restrict__ gamma_a, const float* __restrict__ beta_a,
+                                                                 const float* __restrict__ gamma_b, const float* __restrict__ beta_b, int remask) {
     __shared__ double sm[256 * 12];
     const int cq = threadIdx.x % g.LPR, r0 = threadIdx.x / g.LPR;
     const int grp = blockIdx.y, chunk = blockIdx.x;
@@ -551,9 +553,27 @@ __global__ void __launch_bounds__(256) bn_join_bwd_reduce_kernel(const float* __
         bn_coeffs(stats_a, nullptr, nullptr, nullptr, nullptr, 0, g.groups, grp, g.C, cq * 4 + i, eps_a, (double)g.rows, ma[i], ia[i], t0, t1, g.det);
         bn_coeffs(stats_b, nullptr, nullptr, nullptr, nullptr, 0, g.groups, grp, g.C, cq * 4 + i, eps_b, (double)g.rows, mb[i], ib[i], t0, t1, g.det);
     }
+    // remask (round 5): the ReLU mask is recomputed from xa, xb with the forward kernel's own arithmetic (bn_join_apply_kernel: the same
+    // coefficient expressions, the same two FMAs) - y, a fourth 134 MB stream at the full-resolution join, is not read
+    float sca[4] = {0.f, 0.f, 0.f, 0.f}, scb[4] = {0.f, 0.f, 0.f, 0.f}, shm[4] = {0.f, 0.f, 0.f, 0.f};
+    if (remask) {
+        const double inv_rows = 1.0 / (double)g.rows;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const BnRaw ra = bn_raw(stats_a, gamma_a, beta_a, nullptr, nullptr, 0, g.groups, grp, g.C, cq * 4 + i, g.det);
+            const BnRaw rb = bn_raw(stats_b, gamma_b, beta_b, nullptr, nullptr, 0, g.groups, grp, g.C, cq * 4 + i, g.det);
+            float m, is, sha, shb;
+            bn_coeffs_from_raw(ra, 0, eps_a, inv_rows, m, is, sca[i], sha);
+            bn_coeffs_from_raw(rb, 0, eps_b, inv_rows, m, is, scb[i], shb);
+            shm[i] = sha + shb;
+        }
+    }
+    const bool rd_y = relu && !remask;
     const size_t gbase = ((size_t)grp * g.rows) * g.C + cq * 4;
     double v[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    auto accumulate = [&](float4 d, const float4& yv, const float4& a, const float4& b) {
+    auto accumulate = [&](float4 d, float4 yv, const float4& a, const float4& b) {
+        if (remask) yv = make_float4(__builtin_fmaf(a.x, sca[0], __builtin_fmaf(b.x, scb[0], shm[0])), __builtin_fmaf(a.y, sca[1], __builtin_fmaf(b.y, scb[1], shm[1])),
+                                     __builtin_fmaf(a.z, sca[2], __builtin_fmaf(b.z, scb[2], shm[2])), __builtin_fmaf(a.w, sca[3], __builtin_fmaf(b.w, scb[3], shm[3])));
         if (relu) {
             if (!(yv.x > 0.f)) d.x = 0.f;
             if (!(yv.y > 0.f)) d.y = 0.f;
@@ -573,7 +593,7 @@ __global__ void __launch_bounds__(256) bn_join_bwd_reduce_kernel(const float* __
         for (int u = 0; u < 4; ++u) {
             const size_t off = gbase + (size_t)(r + u * g.RPP) * g.C;
             d[u] = *reinterpret_cast<const float4*>(gy + off);
-            yv[u] = relu ? *reinterpret_cast<const float4*>(y + off) : make_float4(1.f, 1.f, 1.f, 1.f);
+            yv[u] = rd_y ? *reinterpret_cast<const float4*>(y + off) : make_float4(1.f, 1.f, 1.f, 1.f);
             a[u] = *reinterpret_cast<const float4*>(xa + off);
             b[u] = *reinterpret_cast<const float4*>(xb + off);
         }
@@ -582,7 +602,7 @@ __global__ void __launch_bounds__(256) bn_join_bwd_reduce_kernel(const float* __
     }
     for (; r < rend; r += g.RPP) {
         const size_t off = gbase + (size_t)r * g.C;
-        accumulate(*reinterpret_cast<const float4*>(gy + off), relu ? *reinterpret_cast<const float4*>(y + off) : make_float4(1.f, 1.f, 1.f, 1.f),
+        accumulate(*reinterpret_cast<const float4*>(gy + off), rd_y ? *reinterpret_cast<const float4*>(y + off) : make_float4(1.f, 1.f, 1.f, 1.f),
                    *reinterpret_cast<const float4*>(xa + off), *reinterpret_cast<const float4*>(xb + off));
     }
     reduce_rows<12>(v, g.LPR, g.RPP, sm);
@@ -626,7 +646,8 @@ __global__ void __launch_bounds__(256) bn_join_bwd_apply_kernel(const float* __r
                                                                 const double* __restrict__ stats_a, const double* __restrict__ stats_b,
                                                                 const float4* __restrict__ coef, float* __restrict__ gxa,
                                                                 float* __restrict__ gxb, BnGeom g, float eps_a, float eps_b, int relu,
-                                                                unsigned* __restrict__ amax_a, unsigned* __restrict__ amax_b) {
+                                                                unsigned* __restrict__ amax_a, unsigned* __restrict__ amax_b,
+                                                                const float* __restrict__ beta_a, const float* __restrict__ beta_b, int remask) {
     __shared__ float sm_amax[4];
     float vmax_a = 0.f, vmax_b = 0.f;
     const int cq = threadIdx.x % g.LPR, r0 = threadIdx.x / g.LPR;
@@ -636,8 +657,8 @@ __global__ void __launch_bounds__(256) bn_join_bwd_apply_kernel(const float* __r
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = cq * 4 + i;
-        ra[i] = bn_raw(stats_a, gamma_a, nullptr, nullptr, nullptr, 0, g.groups, grp, g.C, c, g.det);
-        rb[i] = bn_raw(stats_b, gamma_b, nullptr, nullptr, nullptr, 0, g.groups, grp, g.C, c, g.det);
+        ra[i] = bn_raw(stats_a, gamma_a, remask ? beta_a : nullptr, nullptr, nullptr, 0, g.groups, grp, g.C, c, g.det);
+        rb[i] = bn_raw(stats_b, gamma_b, remask ? beta_b : nullptr, nullptr, nullptr, 0, g.groups, grp, g.C, c, g.det);
         cf[i] = coef[(size_t)grp * g.C + c];
     }
     const size_t gbase = ((size_t)grp * g.rows) * g.C + cq * 4;
@@ -652,18 +673,20 @@ __global__ void __launch_bounds__(256) bn_join_bwd_apply_kernel(const float* __r
             const bool ok = rr < g.rows;
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             dv[u] = ok ? *reinterpret_cast<const float4*>(gy + off) : z;
-            yv[u] = (ok && relu) ? *reinterpret_cast<const float4*>(y + off) : make_float4(1.f, 1.f, 1.f, 1.f);
+            yv[u] = (ok && relu && !remask) ? *reinterpret_cast<const float4*>(y + off) : make_float4(1.f, 1.f, 1.f, 1.f);
             av[u] = ok ? *reinterpret_cast<const float4*>(xa + off) : z;
             bv[u] = ok ? *reinterpret_cast<const float4*>(xb + off) : z;
         }
     };
     issue(r);
-    float ma[4], ia[4], sca[4], mb[4], ib[4], scb[4], t;
+    float ma[4], ia[4], sca[4], mb[4], ib[4], scb[4], shm[4];
     const double inv_rows = 1.0 / (double)g.rows;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        bn_coeffs_from_raw(ra[i], 0, eps_a, inv_rows, ma[i], ia[i], sca[i], t);
-        bn_coeffs_from_raw(rb[i], 0, eps_b, inv_rows, mb[i], ib[i], scb[i], t);
+        float sha, shb;
+        bn_coeffs_from_raw(ra[i], 0, eps_a, inv_rows, ma[i], ia[i], sca[i], sha);
+        bn_coeffs_from_raw(rb[i], 0, eps_b, inv_rows, mb[i], ib[i], scb[i], shb);
+        shm[i] = sha + shb;                                    // (remask: the forward kernel's shift - with beta = NULL it is not used)
     }
     while (true) {
 #pragma unroll
@@ -672,11 +695,12 @@ __global__ void __launch_bounds__(256) bn_join_bwd_apply_kernel(const float* __r
             if (rr >= g.rows) break;
             const size_t off = gbase + (size_t)rr * g.C;
             float d[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
-            const float yy[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
+            float yy[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
             const float a[4] = {av[u].x, av[u].y, av[u].z, av[u].w}, b[4] = {bv[u].x, bv[u].y, bv[u].z, bv[u].w};
             float oa[4], ob[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                if (remask) yy[i] = __builtin_fmaf(a[i], sca[i], __builtin_fmaf(b[i], scb[i], shm[i]));
                 if (relu && !(yy[i] > 0.f)) d[i] = 0.f;
                 const float e = d[i] - cf[i].x;
                 oa[i] = sca[i] * (e - (a[i] - ma[i]) * ia[i] * cf[i].y);
@@ -1082,26 +1106,43 @@ int bh_bn_join_fwd(const float* xa, const float* xb, const float* gamma_a, const
     return BH_OK;
 }
 
-int bh_bn_join_bwd(const float* gy, const float* y, const float* xa, const float* xb, const float* gamma_a, const float* gamma_b,
-                   const double* stats_a, const double* stats_b, float* gxa, float* gxb, float* ggamma_a, float* gbeta_a, float* ggamma_b,
-                   float* gbeta_b, double* scratch, int groups, int rows, int C, float eps_a, float eps_b, int flags, float* amax_gxa,
-                   float* amax_gxb, void* stream) {
+static int bn_join_bwd_impl(const float* gy, const float* y, const float* xa, const float* xb, const float* gamma_a, const float* gamma_b,
+                            const float* beta_a, const float* beta_b, int remask,
+                            const double* stats_a, const double* stats_b, float* gxa, float* gxb, float* ggamma_a, float* gbeta_a, float* ggamma_b,
+                            float* gbeta_b, double* scratch, int groups, int rows, int C, float eps_a, float eps_b, int flags, float* amax_gxa,
+                            float* amax_gxb, void* stream) {
     BnGeom g;
-    if (!gy || !xa || !xb || !gxa || !gxb || !stats_a || !stats_b || !scratch || ((flags & 1) && !y)) return BH_E_BADARG;
+    if (!gy || !xa || !xb || !gxa || !gxb || !stats_a || !stats_b || !scratch || ((flags & 1) && !remask && !y)) return BH_E_BADARG;
     if (!bn_geom(groups, rows, C, g, (flags & BH_BN_DETERMINISTIC) ? 1 : 0)) return BH_E_UNSUPPORTED;
     hipStream_t s = bh_stream(stream);
     float4* coef = reinterpret_cast<float4*>(scratch);
     double* part = scratch + (size_t)groups * C * 2;
     hipLaunchKernelGGL(bn_join_bwd_reduce_kernel, dim3(g.nchunks, groups), dim3(256), 0, s, gy, y, xa, xb, stats_a, stats_b, g, eps_a, eps_b,
-                       flags & 1, part);
+                       flags & 1, part, gamma_a, beta_a, gamma_b, beta_b, remask);
     BH_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_join_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, part, g, ggamma_a, gbeta_a, ggamma_b, gbeta_b, coef);
     BH_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_join_bwd_apply_kernel, dim3(apply_blocks(g), groups), dim3(256), 0, s, gy, y, xa, xb, gamma_a, gamma_b, stats_a,
                        stats_b, coef, gxa, gxb, g, eps_a, eps_b, flags & 1, reinterpret_cast<unsigned*>(amax_gxa),
-                       reinterpret_cast<unsigned*>(amax_gxb));
+                       reinterpret_cast<unsigned*>(amax_gxb), beta_a, beta_b, remask);
     BH_LAUNCH_CHECK();
     return BH_OK;
+}
+
+int bh_bn_join_bwd(const float* gy, const float* y, const float* xa, const float* xb, const float* gamma_a, const float* gamma_b,
+                   const double* stats_a, const double* stats_b, float* gxa, float* gxb, float* ggamma_a, float* gbeta_a, float* ggamma_b,
+                   float* gbeta_b, double* scratch, int groups, int rows, int C, float eps_a, float eps_b, int flags, float* amax_gxa,
+                   float* amax_gxb, void* stream) {
+    return bn_join_bwd_impl(gy, y, xa, xb, gamma_a, gamma_b, nullptr, nullptr, 0, stats_a, stats_b, gxa, gxb, ggamma_a, gbeta_a, ggamma_b, gbeta_b,
+                            scratch, groups, rows, C, eps_a, eps_b, flags, amax_gxa, amax_gxb, stream);
+}
+
+int bh_bn_join_bwd_remask(const float* gy, const float* xa, const float* xb, const float* gamma_a, const float* beta_a, const float* gamma_b,
+                          const float* beta_b, const double* stats_a, const double* stats_b, float* gxa, float* gxb, float* ggamma_a,
+                          float* gbeta_a, float* ggamma_b, float* gbeta_b, double* scratch, int groups, int rows, int C, float eps_a, float eps_b,
+                          int flags, float* amax_gxa, float* amax_gxb, void* stream) {
+    return bn_join_bwd_impl(gy, nullptr, xa, xb, gamma_a, gamma_b, beta_a, beta_b, 1, stats_a, stats_b, gxa, gxb, ggamma_a, gbeta_a, ggamma_b,
+                            gbeta_b, scratch, groups, rows, C, eps_a, eps_b, flags, amax_gxa, amax_gxb, stream);
 }
 
 }  // extern "C"

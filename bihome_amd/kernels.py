@@ -1048,7 +1048,17 @@ def bn_join_bwd(gy, y, xa, xb, ma, mb, stats_a, stats_b, groups, relu, train_a, 
     gxa, gxb = torch.empty_like(xa), torch.empty_like(xb)
     scratch = torch.empty(lib.bh_bn_join_scratch_doubles(groups, C), dtype=torch.float64, device=xa.device)
     flags = (1 if relu else 0) | (BN_DETERMINISTIC if deterministic() else 0)
-    with _Timed("bn_join_bwd(3 kernels)" + (" g%d rows%d C%d" % (groups, rows, C) if TIMING_DETAIL else ""), 0.0, 40.0 * xa.numel()):
+    # (round 5: the ReLU mask is recomputed from xa, xb - `y` is not read; BIHOME_JOIN_REMASK=0: the form that reads it)
+    if os.environ.get("BIHOME_JOIN_REMASK", "1") != "0":
+        with _Timed("bn_join_bwd(3 kernels)" + (" g%d rows%d C%d" % (groups, rows, C) if TIMING_DETAIL else ""), 0.0, 32.0 * xa.numel()):
+            check(lib.bh_bn_join_bwd_remask(_p(gy), _p(xa), _p(xb), _p(ma.weight), _p(ma.bias), _p(mb.weight), _p(mb.bias), _p(stats_a),
+                                            _p(stats_b), _p(gxa), _p(gxb),
+                                            _p(ma.weight.grad) if train_a else None, _p(ma.bias.grad) if train_a else None,
+                                            _p(mb.weight.grad) if train_b else None, _p(mb.bias.grad) if train_b else None, _p(scratch), groups,
+                                            rows, C, float(ma.eps), float(mb.eps), flags, _p(amax_a), _p(amax_b), _stream()),
+                  "bh_bn_join_bwd_remask")
+    else:
+      with _Timed("bn_join_bwd(3 kernels)" + (" g%d rows%d C%d" % (groups, rows, C) if TIMING_DETAIL else ""), 0.0, 40.0 * xa.numel()):
         check(lib.bh_bn_join_bwd(_p(gy), _p(y), _p(xa), _p(xb), _p(ma.weight), _p(mb.weight), _p(stats_a), _p(stats_b), _p(gxa), _p(gxb),
                                  _p(ma.weight.grad) if train_a else None, _p(ma.bias.grad) if train_a else None,
                                  _p(mb.weight.grad) if train_b else None, _p(mb.bias.grad) if train_b else None, _p(scratch), groups, rows, C,

@@ -478,6 +478,14 @@ int bh_bn_join_bwd(const float* gy, const float* y, const float* xa, const float
                    const double* stats_a, const double* stats_b, float* gxa, float* gxb, float* ggamma_a, float* gbeta_a, float* ggamma_b,
                    float* gbeta_b, double* scratch, int groups, int rows, int C, float eps_a, float eps_b, int flags, float* amax_gxa,
                    float* amax_gxb, void* stream);
+/* The same adjoint with the ReLU mask RECOMPUTED from xa, xb (round 5): y is not read - the kernels evaluate the forward kernel's own
+ * expression y = fma(xa, sc_a, fma(xb, sc_b, sh_a + sh_b)) with the same coefficient arithmetic, so the mask is bitwise the forward's
+ * decision and the result bitwise bh_bn_join_bwd's; one of four input streams less in both passes (1.34 -> 1.07 GB at the full-resolution
+ * join of ResNet50DeconvBlock, /root/reference/src/backbones/utils.py:60-82).  beta_a / beta_b: the BatchNorms' shifts (NULL: 0). */
+int bh_bn_join_bwd_remask(const float* gy, const float* xa, const float* xb, const float* gamma_a, const float* beta_a, const float* gamma_b,
+                          const float* beta_b, const double* stats_a, const double* stats_b, float* gxa, float* gxb, float* ggamma_a,
+                          float* gbeta_a, float* ggamma_b, float* gbeta_b, double* scratch, int groups, int rows, int C, float eps_a, float eps_b,
+                          int flags, float* amax_gxa, float* amax_gxb, void* stream);
 
 /* Fused tail of the Zeng backbone, `layer8` (src/backbones/Rethinking.py:145-147):
  *   Conv2d(Ci,Cm,1,bias) -> BatchNorm2d(Cm) -> ReLU -> Conv2d(Cm,Co,1,bias), NHWC x[groups*rows,Ci] -> NCHW out[N,Co,h,w]

@@ -992,6 +992,14 @@ def test_two_branch_batchnorm_join(K, groups, N, H, C, relu):
     close(gxb.cpu().permute(0, 3, 1, 2), xbt.grad, 3e-5)
     close(ma.weight.grad.cpu(), bna.weight.grad, 3e-5); close(ma.bias.grad.cpu(), bna.bias.grad, 3e-5)
     close(mb.weight.grad.cpu(), bnb.weight.grad, 3e-5); close(mb.bias.grad.cpu(), bnb.bias.grad, 3e-5)
+    # round 5: K.bn_join_bwd recomputes the ReLU mask from xa, xb (bh_bn_join_bwd_remask); the form that reads y gives bitwise the same
+    import os
+    os.environ["BIHOME_JOIN_REMASK"] = "0"
+    try:
+        gxa0, gxb0 = K.bn_join_bwd(C_(gy).permute(0, 2, 3, 1).contiguous(), y, xag, xbg, ma, mb, sa, sb, groups, relu, False, False)
+    finally:
+        del os.environ["BIHOME_JOIN_REMASK"]
+    assert torch.equal(gxa0, gxa) and torch.equal(gxb0, gxb)
 
 
 @pytest.mark.parametrize("N,H,Ci,Co,relu", [(4, 32, 32, 16, True), (2, 64, 64, 32, True), (6, 16, 32, 64, False), (128, 32, 32, 16, True)])
