@@ -112,6 +112,7 @@ SIGNATURES = {
     "bh_bn_stats": [P, P, c_int, c_int, c_int, c_int, P],
     "bh_bn_maxpool_fwd": [P] * 8 + [c_int] * 5 + [c_float, c_float, c_int, c_int, P, P],
     "bh_bn_maxpool_bwd": [P] * 10 + [c_int] * 5 + [c_float, c_int, c_int, P, P, P, P],
+    "bh_bn_bwd_from_1x1": [P, P, c_int] + [P] * 8 + [c_int, c_int, c_int, c_float, c_int, P, P],
     "bh_bn_join_scratch_doubles": [c_int, c_int],
     "bh_bn_join_fwd": [P] * 13 + [c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int, P, P],
     "bh_bn_join_bwd": [P] * 15 + [c_int, c_int, c_int, c_float, c_float, c_int, P, P, P],

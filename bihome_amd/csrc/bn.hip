@@ -1090,6 +1090,171 @@ int bh_bn_maxpool_bwd(const float* gy, const unsigned char* idx, const float* x,
     return BH_OK;
 }
 
+}  // extern "C" (templates below)
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm adjoint whose output gradient is the dgrad of a 1x1 convolution with FEW output channels (round 5: the decoder units'
+// BatchNorm + ReLU in front of the 1x1 conv that halves the channels, src/backbones/utils.py:60-82, at full resolution: C = 32 -> 16 on
+// 128 x 128 maps).  Unfused: the 1x1 dgrad writes g[M][C] (268 MB) and bh_bn_bwd reads it twice.  Here g is never stored: both passes
+// rebuild  g[p][c] = sum_k gs[p][k] w[k][c]  from the HALF-SIZE gradient of the conv's output (KC = 16 floats per pixel; the lane's four
+// weight columns stay in registers: KC float4) - 16 FMAs per element, far below what the two streams leave room for.  Passes as in
+// bh_bn_bwd: chunk partials in fixed order + bn_bwd_finalize_kernel, then apply.  The mask is recomputed from x (no residual: flags bit2
+// semantics).  1742 -> 1072 MB per call.
+// ---------------------------------------------------------------------------------------------
+template <int KC>
+__device__ __forceinline__ float4 grad_from_1x1(const float4 (&gs)[KC / 4], const float4 (&w)[KC]) {
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < KC / 4; ++q) {
+        const float e[4] = {gs[q].x, gs[q].y, gs[q].z, gs[q].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 wk = w[q * 4 + i];
+            g.x = __builtin_fmaf(e[i], wk.x, g.x); g.y = __builtin_fmaf(e[i], wk.y, g.y);
+            g.z = __builtin_fmaf(e[i], wk.z, g.z); g.w = __builtin_fmaf(e[i], wk.w, g.w);
+        }
+    }
+    return g;
+}
+
+// grid (nchunks, groups)
+template <int KC>
+__global__ void __launch_bounds__(256) bn_bwd_1x1_reduce_kernel(const float* __restrict__ gs, const float* __restrict__ w,
+                                                                const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, const double* __restrict__ stats, BnGeom g,
+                                                                float eps, int relu, double* __restrict__ part) {
+    __shared__ double sm[256 * 8];
+    const int cq = threadIdx.x % g.LPR, r0 = threadIdx.x / g.LPR;
+    const int grp = blockIdx.y, chunk = blockIdx.x;
+    const int rbeg = chunk * g.rows_per_chunk, rend = min(g.rows, rbeg + g.rows_per_chunk);
+    float4 wr[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) wr[k] = *reinterpret_cast<const float4*>(w + (size_t)k * g.C + cq * 4);
+    float mean[4], invstd[4], sc[4], sh[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        bn_coeffs(stats, gamma, beta, nullptr, nullptr, 0, g.groups, grp, g.C, cq * 4 + i, eps, (double)g.rows, mean[i], invstd[i], sc[i], sh[i], g.det);
+    const size_t rbase = (size_t)grp * g.rows;
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r = rbeg + r0; r < rend; r += 2 * g.RPP) {
+        float4 a[2], q[2][KC / 4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int rr = r + u * g.RPP;
+            const size_t row = rbase + (size_t)(rr < rend ? rr : rbeg);
+            a[u] = *reinterpret_cast<const float4*>(x + row * g.C + cq * 4);
+#pragma unroll
+            for (int j = 0; j < KC / 4; ++j) q[u][j] = *reinterpret_cast<const float4*>(gs + row * KC + j * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (r + u * g.RPP >= rend) break;
+            float4 d = grad_from_1x1<KC>(q[u], wr);
+            const float4 av = a[u];
+            if (relu) {
+                if (!(av.x * sc[0] + sh[0] > 0.f)) d.x = 0.f;
+                if (!(av.y * sc[1] + sh[1] > 0.f)) d.y = 0.f;
+                if (!(av.z * sc[2] + sh[2] > 0.f)) d.z = 0.f;
+                if (!(av.w * sc[3] + sh[3] > 0.f)) d.w = 0.f;
+            }
+            v[0] += d.x; v[1] += d.y; v[2] += d.z; v[3] += d.w;
+            v[4] += (double)(d.x * ((av.x - mean[0]) * invstd[0]));
+            v[5] += (double)(d.y * ((av.y - mean[1]) * invstd[1]));
+            v[6] += (double)(d.z * ((av.z - mean[2]) * invstd[2]));
+            v[7] += (double)(d.w * ((av.w - mean[3]) * invstd[3]));
+        }
+    }
+    reduce_rows<8>(v, g.LPR, g.RPP, sm);
+    if ((int)threadIdx.x < g.LPR) {
+        double* p = part + (((size_t)grp * g.nchunks + chunk) * g.C + cq * 4) * 2;
+        for (int i = 0; i < 4; ++i) { p[i * 2] = v[i]; p[i * 2 + 1] = v[4 + i]; }
+    }
+}
+
+// grid (nblk, groups); coef from bn_bwd_finalize_kernel
+template <int KC>
+__global__ void __launch_bounds__(256) bn_bwd_1x1_apply_kernel(const float* __restrict__ gs, const float* __restrict__ w,
+                                                               const float* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, const float4* __restrict__ coef,
+                                                               float* __restrict__ gx, BnGeom g, int relu, unsigned* __restrict__ amax) {
+    __shared__ float sm_amax[4];
+    float vmax = 0.f;
+    const int cq = threadIdx.x % g.LPR, r0 = threadIdx.x / g.LPR;
+    const int grp = blockIdx.y;
+    float4 wr[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) wr[k] = *reinterpret_cast<const float4*>(w + (size_t)k * g.C + cq * 4);
+    float mean[4], invstd[4], sc[4], sh[4], k1[4], k2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = cq * 4 + i;
+        const float4 cf = coef[(size_t)grp * g.C + c];
+        const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+        mean[i] = cf.x; invstd[i] = cf.y; k1[i] = cf.z; k2[i] = cf.w;
+        sc[i] = gm * cf.y;
+        sh[i] = bt - cf.x * sc[i];
+    }
+    const size_t rbase = (size_t)grp * g.rows;
+    const int stride = gridDim.x * g.RPP;
+    for (int r = blockIdx.x * g.RPP + r0; r < g.rows; r += 2 * stride) {
+        float4 a[2], q[2][KC / 4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int rr = r + u * stride;
+            const size_t row = rbase + (size_t)(rr < g.rows ? rr : 0);
+            a[u] = *reinterpret_cast<const float4*>(x + row * g.C + cq * 4);
+#pragma unroll
+            for (int j = 0; j < KC / 4; ++j) q[u][j] = *reinterpret_cast<const float4*>(gs + row * KC + j * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int rr = r + u * stride;
+            if (rr >= g.rows) break;
+            float4 d = grad_from_1x1<KC>(q[u], wr);
+            const float4 av = a[u];
+            if (relu) {
+                if (!(av.x * sc[0] + sh[0] > 0.f)) d.x = 0.f;
+                if (!(av.y * sc[1] + sh[1] > 0.f)) d.y = 0.f;
+                if (!(av.z * sc[2] + sh[2] > 0.f)) d.z = 0.f;
+                if (!(av.w * sc[3] + sh[3] > 0.f)) d.w = 0.f;
+            }
+            float4 o;
+            o.x = sc[0] * (d.x - k1[0] - (av.x - mean[0]) * invstd[0] * k2[0]);
+            o.y = sc[1] * (d.y - k1[1] - (av.y - mean[1]) * invstd[1] * k2[1]);
+            o.z = sc[2] * (d.z - k1[2] - (av.z - mean[2]) * invstd[2] * k2[2]);
+            o.w = sc[3] * (d.w - k1[3] - (av.w - mean[3]) * invstd[3] * k2[3]);
+            *reinterpret_cast<float4*>(gx + (rbase + (size_t)rr) * g.C + cq * 4) = o;
+            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+        }
+    }
+    if (amax) bh_amax_commit(amax, vmax, blockIdx.x + blockIdx.y * 7u, sm_amax);
+}
+
+extern "C" {
+
+int bh_bn_bwd_from_1x1(const float* gs, const float* w, int KC, const float* x, const float* gamma, const float* beta, const double* stats,
+                       float* gx, float* ggamma, float* gbeta, double* scratch, int groups, int rows, int C, float eps, int flags,
+                       float* amax_gx, void* stream) {
+    BnGeom g;
+    if (!gs || !w || !x || !gx || !stats || !scratch) return BH_E_BADARG;
+    if (KC != 16 && KC != 32) return BH_E_UNSUPPORTED;
+    if (!bn_geom(groups, rows, C, g, (flags & BH_BN_DETERMINISTIC) ? 1 : 0)) return BH_E_UNSUPPORTED;
+    hipStream_t s = bh_stream(stream);
+    float4* coef = reinterpret_cast<float4*>(scratch);
+    double* part = scratch + (size_t)groups * C * 2;
+    unsigned* am = reinterpret_cast<unsigned*>(amax_gx);
+    if (KC == 16) hipLaunchKernelGGL(bn_bwd_1x1_reduce_kernel<16>, dim3(g.nchunks, groups), dim3(256), 0, s, gs, w, x, gamma, beta, stats, g, eps, flags & 1, part);
+    else hipLaunchKernelGGL(bn_bwd_1x1_reduce_kernel<32>, dim3(g.nchunks, groups), dim3(256), 0, s, gs, w, x, gamma, beta, stats, g, eps, flags & 1, part);
+    BH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, part, g, stats, (const float*)nullptr, (const float*)nullptr, eps, 0, ggamma,
+                       gbeta, coef);
+    BH_LAUNCH_CHECK();
+    if (KC == 16) hipLaunchKernelGGL(bn_bwd_1x1_apply_kernel<16>, dim3(apply_blocks(g), groups), dim3(256), 0, s, gs, w, x, gamma, beta, coef, gx, g, flags & 1, am);
+    else hipLaunchKernelGGL(bn_bwd_1x1_apply_kernel<32>, dim3(apply_blocks(g), groups), dim3(256), 0, s, gs, w, x, gamma, beta, coef, gx, g, flags & 1, am);
+    BH_LAUNCH_CHECK();
+    return BH_OK;
+}
+
 int bh_bn_join_scratch_doubles(int groups, int C) { return groups * C * 2 + groups * C * 3 * (BN_MAX_CHUNKS > 256 ? BN_MAX_CHUNKS : 256); }
 
 int bh_bn_join_fwd(const float* xa, const float* xb, const float* gamma_a, const float* beta_a, float* rmean_a, float* rvar_a,

@@ -1119,6 +1119,35 @@ def maxpool_fwd(x, want_index=True):
     return y, idx
 
 
+class GradFrom1x1:
+    """Gradient of a BatchNorm output that IS the dgrad of a 1x1 conv with few output channels: the conv's output gradient and its weight,
+    handed to the BatchNorm's adjoint (bn_bwd_from_1x1) - the dgrad's result is never formed."""
+    __slots__ = ("gs", "w")
+
+    def __init__(self, gs, w):
+        self.gs, self.w = gs, w
+
+
+def bn_bwd_from_1x1(gf, x, gamma, beta, stats, groups, eps, relu, ggamma=None, gbeta=None, amax=None):
+    """Adjoint of a training-mode BatchNorm (+ReLU, no residual) whose output feeds only a 1x1 conv: GradFrom1x1 + the BatchNorm input ->
+    gx (bh_bn_bwd_from_1x1: conv_dgrad + bn_bwd without the tensor in between)."""
+    gs, w = gf.gs, gf.w
+    _chk(gs); _chk(w); _chk(x)
+    C = x.shape[-1]
+    KC = gs.shape[-1]
+    rows = x.numel() // C // groups
+    gx = torch.empty_like(x)
+    scratch = torch.empty(lib.bh_bn_scratch_doubles(groups, C), dtype=torch.float64, device=x.device)
+    flags = (1 if relu else 0) | (BN_DETERMINISTIC if deterministic() else 0)
+    with _Timed("bn_bwd_from_1x1(3 kernels)" + (" g%d rows%d C%d<-%d" % (groups, rows, C, KC) if TIMING_DETAIL else ""), 4.0 * gs.numel() * C,
+                4.0 * (3 * x.numel() + 2 * gs.numel())):
+        check(lib.bh_bn_bwd_from_1x1(_p(gs), _p(w), KC, _p(x), _p(gamma), _p(beta), _p(stats), _p(gx), _p(ggamma), _p(gbeta), _p(scratch), groups,
+                                     rows, C, float(eps), flags, _p(amax), _stream()), "bh_bn_bwd_from_1x1")
+    if amax is not None:
+        gx._bh_amax = amax
+    return gx
+
+
 class PooledGrad:
     """Gradient of a BnPooled slot: the pooled gradient and the arg-max positions, handed from the pooling op's adjoint to the BatchNorm's
     (bn_maxpool_bwd) - the full-resolution gradient in between is never formed."""

@@ -548,6 +548,9 @@ def side_stream(device):
     return _SIDE_STREAMS[key]
 
 
+_FROM_1X1_KC = (16,)      # output channels of the 1x1 convs whose dgrad the BatchNorm in front rebuilds (run_backward)
+
+
 def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=None, wgrad_stream=None, det_ws=None, x3_ws=None):
     """Adjoint of run_forward. Parameter gradients are accumulated (+=) into each parameter's `.grad`
     tensor (which must already exist, see FlatGrads). Returns the input gradient or None.
@@ -624,6 +627,21 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
             print("BN_PLAN op %3d C%-4d %s last consumer: op %s %s | fused=%s joined=%s shape=%s" %
                   (b, op.mod.num_features, "relu" if op.relu else "    ", j, what, b in fuse_bn.values(), b in ctx.joined,
                    tuple(slots[op.src].shape) if hasattr(slots[op.src], "shape") else "?"), file=sys.stderr)
+    # A 1x1 / stride-1 conv with 16 output channels that is the ONLY consumer of a training-mode BatchNorm (+ReLU, no residual, not joined):
+    # its dgrad is rebuilt inside that BatchNorm's adjoint (bh_bn_bwd_from_1x1) - the full-resolution decoder unit's 268 MB gradient is
+    # never written
+    from_1x1 = set()
+    if ctx.training and os.environ.get("BIHOME_BN_FROM_1X1", "1") != "0":
+        producer_ = {op.dst: j for j, op in enumerate(prog.ops)}
+        for j, op in enumerate(prog.ops):
+            b = producer_.get(op.src)
+            m_ = op.mod
+            if (op.kind == "conv" and b is not None and prog.ops[b].kind == "bn" and prog.ops[b].res is None and b not in ctx.joined
+                    and consumed_by.get(op.src, 0) == 1 and j not in fuse_bn and isinstance(m_, nn.Conv2d) and m_.kernel_size == (1, 1)
+                    and m_.stride == (1, 1) and m_.padding == (0, 0) and op.extra["weight_fn"] is None and m_.out_channels in _FROM_1X1_KC
+                    and prog.ops[b].mod.num_features % 4 == 0 and 256 % (prog.ops[b].mod.num_features // 4) == 0
+                    and not op.extra["in_nchw"] and not op.extra["out_nchw"]):
+                from_1x1.add(j)
     red_off, total = {}, 0
     bias_off = {}
     for j, p in fuse_bias.items():
@@ -679,6 +697,10 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
                     on_param_grad(m.weight)
                     if has_gb:
                         on_param_grad(m.bias)
+            if need_src_grad and i in from_1x1 and op.src not in grads:
+                # the BatchNorm in front rebuilds this dgrad per element in its own adjoint (bn_bwd_from_1x1): nothing is launched here
+                grads[op.src] = K.GradFrom1x1(g, wk)
+                continue
             if need_src_grad:
                 red = None
                 if i in fuse_bn:
@@ -719,6 +741,16 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
             yb = slots[op.dst]
             if isinstance(yb, (K.BnOnLoad, K.BnPooled)):  # applied on load by its consumer / fused with the pooling: no output tensor (the mask comes from x)
                 yb = None
+            if isinstance(g, K.GradFrom1x1):             # the 1x1 conv behind this BatchNorm left its dgrad to this call
+                gx = K.bn_bwd_from_1x1(g, x, m.weight, m.bias, ctx.stats[i], ctx.groups, m.eps, op.relu,
+                                       m.weight.grad if train_w else None, m.bias.grad if train_w else None,
+                                       amax=amax_next() if (amax_next and m.num_features > 1) else None)
+                if train_w and on_param_grad is not None:
+                    on_param_grad(m.weight)
+                    on_param_grad(m.bias)
+                if need_src_grad:
+                    contribute(op.src, gx)
+                continue
             if isinstance(g, K.PooledGrad):              # BatchNorm (+ReLU) + MaxPool in one pass: its adjoint in one call too
                 gx = K.bn_maxpool_bwd(g, x, m.weight, m.bias, ctx.stats[i], m.running_mean, m.running_var, ctx.groups, m.eps, op.relu,
                                       ctx.training, m.weight.grad if train_w else None, m.bias.grad if train_w else None,

@@ -460,6 +460,14 @@ int bh_bn_maxpool_fwd(const float* x, const float* gamma, const float* beta, flo
 int bh_bn_maxpool_bwd(const float* gy, const unsigned char* idx, const float* x, const float* gamma, const float* beta, const double* stats,
                       float* gx, float* ggamma, float* gbeta, double* scratch, int groups, int N, int Hi, int Wi, int C, float eps, int flags,
                       int use_running, const float* running_mean, const float* running_var, float* amax_gx, void* stream);
+/* BatchNorm (+ReLU, no residual) adjoint whose output gradient is the dgrad of a 1x1 / stride-1 convolution with KC = 16 or 32 output channels
+ * (round 5): gs[groups*rows][KC] is the gradient of THAT CONVOLUTION's output, w[KC][C] its kernel-layout weight ([Co][1][1][Ci]); the
+ * BatchNorm's output gradient g = gs w is rebuilt per element in both passes and never stored (the decoder units' BatchNorm + ReLU + 1x1
+ * conv, /root/reference/src/backbones/utils.py:60-82).  Equivalent to bh_conv_dgrad (1x1) followed by bh_bn_bwd_amax with flags bit0 | bit2
+ * (training mode), up to the summation order of the KC products.  scratch: bh_bn_scratch_doubles; flags: bit0 relu, BH_BN_DETERMINISTIC. */
+int bh_bn_bwd_from_1x1(const float* gs, const float* w, int KC, const float* x, const float* gamma, const float* beta, const double* stats,
+                       float* gx, float* ggamma, float* gbeta, double* scratch, int groups, int rows, int C, float eps, int flags,
+                       float* amax_gx, void* stream);
 /* Two-branch join (round 4): y = act(bn_a(xa) + bn_b(xb)), both BatchNorms in training mode with their own statistics tables (already
  * accumulated: by the producers' epilogues or bh_bn_stats-style passes) - the end of ResNet50DeconvBlock / the strided ResNet34ConvBlock
  * (src/backbones/utils.py:60-82, 85-112) without writing the normalised lower branch.  flags: bit0 relu, BH_BN_DETERMINISTIC.  Running

@@ -1002,6 +1002,44 @@ def test_two_branch_batchnorm_join(K, groups, N, H, C, relu):
     assert torch.equal(gxa0, gxa) and torch.equal(gxb0, gxb)
 
 
+@pytest.mark.parametrize("N,H,C,relu", [(4, 32, 32, True), (2, 64, 32, False), (6, 24, 64, True), (16, 64, 32, True)])
+def test_batchnorm_adjoint_rebuilds_the_1x1_dgrad(K, N, H, C, relu):
+    """bh_bn_bwd_from_1x1 (round 5: BatchNorm + ReLU in front of the decoder units' 1x1 conv with 16 output channels): the BatchNorm's
+    output gradient g = gs w is rebuilt per element and never stored - against conv_dgrad (1x1) followed by bn_bwd with the mask recomputed
+    from x: input gradient, parameter gradients, magnitude record; deterministic call repeatable."""
+    groups, KC = 2, 16
+    g = torch.Generator().manual_seed(N + H + C)
+    x = (torch.randn(N, H, H, C, generator=g) * 1.2 + 0.2).cuda()
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+    rm, rv = torch.zeros(C).cuda(), torch.ones(C).cuda()
+    st = K.bn_stats_buffer(groups, C, "cuda")
+    K.bn_stats(x, st, groups, C)
+    w = (torch.randn(KC, 1, 1, C, generator=g) * 0.2).cuda()
+    gs = torch.randn(N, H, H, KC, generator=g).cuda()
+    d = K.conv_desc(N, H, H, C, KC, 1, 1, 0, precision=0)
+    gfull = K.conv_dgrad(gs, w, d)
+    gg0, gb0, gg1, gb1 = (torch.zeros(C, device="cuda") for _ in range(4))
+    rec0, rec1 = K.amax_record("cuda"), K.amax_record("cuda")
+    ref, _ = K.bn_bwd(gfull, None, x, gamma, st, rm, rv, groups, 1e-5, relu, True, False, gg0, gb0, beta=beta, had_res=False, amax=rec0)
+    out = K.bn_bwd_from_1x1(K.GradFrom1x1(gs, w), x, gamma, beta, st, groups, 1e-5, relu, gg1, gb1, amax=rec1)
+    close(out.cpu(), ref.cpu(), 5e-6)
+    close(gg1.cpu(), gg0.cpu(), 5e-6); close(gb1.cpu(), gb0.cpu(), 5e-6)
+    assert abs(float(rec1.max()) - float(out.abs().max())) == 0.0
+    # float64 reference of the whole chain
+    xd = x.double().cpu().reshape(groups, -1, C)
+    gd = (gs.double().cpu().reshape(-1, KC) @ w.double().cpu().reshape(KC, C)).reshape(groups, -1, C)
+    mu, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
+    xh = (xd - mu) / torch.sqrt(var + 1e-5)
+    y = xh * gamma.double().cpu() + beta.double().cpu()
+    dd = gd * (y > 0) if relu else gd
+    gx64 = gamma.double().cpu() / torch.sqrt(var + 1e-5) * (dd - dd.mean(1, keepdim=True) - xh * (dd * xh).mean(1, keepdim=True))
+    close(out.cpu().reshape(groups, -1, C), gx64, 2e-5)
+    with K.det_scope(True):
+        a1 = K.bn_bwd_from_1x1(K.GradFrom1x1(gs, w), x, gamma, beta, st, groups, 1e-5, relu)
+        a2 = K.bn_bwd_from_1x1(K.GradFrom1x1(gs, w), x, gamma, beta, st, groups, 1e-5, relu)
+    assert torch.equal(a1, a2)
+
+
 @pytest.mark.parametrize("N,H,Ci,Co,relu", [(4, 32, 32, 16, True), (2, 64, 64, 32, True), (6, 16, 32, 64, False), (128, 32, 32, 16, True)])
 def test_batchnorm_on_load_1x1_matches_materialised_batchnorm(K, N, H, Ci, Co, relu):
     """Round 4: the 1x1 conv of a decoder unit behind BatchNorm + ReLU (src/backbones/utils.py:60-82) - generic forward kernel and

@@ -38,7 +38,18 @@ def test_n_rank_step_matches_single_process_shard_sum(tmp_path, world, B, overla
     env = dict(os.environ, BIHOME_DIST_BACKEND="gloo", BIHOME_OVERLAP=overlap, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ddp_worker.py"), out, str(B)]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    # (the ranks normally finish in 10-20 s; twice in round 5 a run of the whole suite sat in this launch until the timeout on boxes where the
+    #  same build passed before and after - a stuck multi-process start on the shared GPU is retried once on a fresh port, and the ranks'
+    #  output is shown if that does not help)
+    r = None
+    for attempt in range(2):
+        cmd[cmd.index("--master-port") + 1] = str(_free_port())
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=int(os.environ.get("BIHOME_TEST_DDP_TIMEOUT", "300")))
+            break
+        except subprocess.TimeoutExpired as e:
+            if attempt == 1:
+                pytest.fail("the ranks did not finish: stdout ...%s\nstderr ...%s" % ((e.stdout or b"")[-1500:], (e.stderr or b"")[-3000:]))
     assert r.returncode == 0, r.stderr[-3000:]
     got, others = dict(np.load(out)), [dict(np.load(out + ".rank%d.npz" % k)) for k in range(1, world)]
     log = os.path.join(ROOT, "gpurun_out", "ddp_%d_rank_overlap%s.log" % (world, overlap))
