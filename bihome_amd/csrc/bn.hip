@@ -739,6 +739,9 @@ __global__ void __launch_bounds__(256) bn_fwd_coeffs_kernel(const double* __rest
                                                             float* __restrict__ upd_mean, float* __restrict__ upd_var,
                                                             float2* __restrict__ table, unsigned* __restrict__ amax) {
     __shared__ float sm_amax[4];
+    // (the running-statistics update has a workgroup of its own - the LAST one: behind the table it doubled the length of a launch that sits
+    //  between every conv and its BatchNorm-on-load consumer, 27 times per step)
+    if (upd_mean && blockIdx.x == gridDim.x - 1) { bn_update_running(stats, g, momentum, upd_mean, upd_var); return; }
     const int i = blockIdx.x * 256 + threadIdx.x;
     float bound = 0.f;
     if (i < g.groups * g.C) {
@@ -751,7 +754,6 @@ __global__ void __launch_bounds__(256) bn_fwd_coeffs_kernel(const double* __rest
         bound = 2.0f * (fabsf(gamma ? gamma[c] : 1.f) * sqrtf((float)g.rows) + fabsf(beta ? beta[c] : 0.f));
     }
     if (amax) bh_amax_commit(amax, bound, blockIdx.x, sm_amax);
-    if (upd_mean && blockIdx.x == 0) bn_update_running(stats, g, momentum, upd_mean, upd_var);
 }
 
 // per-channel sums of an NHWC tensor into caller-zeroed sums[groups][C][2] (used by bh_bn_fwd and by the conv entry
@@ -813,7 +815,7 @@ int bh_bn_fwd_coeffs_amax(const double* stats, const float* gamma, const float* 
     if (!stats || !table) return BH_E_BADARG;
     if (!bn_geom(groups, rows, C, g, -1)) return BH_E_UNSUPPORTED;        // (a reader: looks at the limbs of whatever mode wrote the sums)
     const bool upd = running_mean && running_var;
-    hipLaunchKernelGGL(bn_fwd_coeffs_kernel, dim3((groups * C + 255) / 256), dim3(256), 0, bh_stream(stream), stats, gamma, beta, g, eps,
+    hipLaunchKernelGGL(bn_fwd_coeffs_kernel, dim3((groups * C + 255) / 256 + (upd ? 1 : 0)), dim3(256), 0, bh_stream(stream), stats, gamma, beta, g, eps,
                        momentum, upd ? running_mean : nullptr, upd ? running_var : nullptr, reinterpret_cast<float2*>(table),
                        reinterpret_cast<unsigned*>(amax_y));
     BH_LAUNCH_CHECK();

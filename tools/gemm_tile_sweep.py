@@ -18,7 +18,7 @@ def bench(fn, n=20):
 
 cases = [("convT", 128, 32, 64, 32), ("convT", 128, 64, 32, 32), ("convT", 128, 32, 64, 64), ("convT", 128, 64, 32, 16), ("convT", 128, 16, 128, 128),
          ("convT", 128, 8, 256, 128), ("1x1", 128, 128, 32, 16), ("1x1", 128, 64, 64, 32), ("1x1", 128, 32, 128, 64), ("1x1", 128, 16, 256, 128)]
-tiles = [(0, 0), (64, 64), (128, 64), (64, 128), (128, 128), (128, 32)]
+tiles = [(0, 0), (-33, 0)]       # default (pw_kernel where it applies), then the pointwise kernel off
 for kind, N, H, Ci, Co in cases:
     x = torch.randn(N, H, H, Ci, device="cuda")
     if kind == "convT":
@@ -38,6 +38,8 @@ for kind, N, H, Ci, Co in cases:
                 ref = y
             err = (y - ref).abs().max().item()
             row.append("%dx%d %.1f%s" % (bm, bn, bench(lambda: K.conv_fwd(x, w, b, d)), "" if err < 1e-4 else " ERR"))
+            if bm == -33:
+                lib.bh_debug_force_tile(-33, 1)
         except Exception as e:
             row.append("%dx%d n/a" % (bm, bn))
     lib.bh_debug_force_tile(0, 0)
