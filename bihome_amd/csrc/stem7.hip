@@ -69,6 +69,27 @@ __global__ void __launch_bounds__(256) stem7_fwd_kernel(Stem7Args a) {
         }
         s1 = 0; s2 = 0;
     };
+    // The input patch of the NEXT tile is requested into registers before this tile's MFMAs and written to LDS behind them (round 5: the
+    // global-load latency of the staging sat between two barriers of every tile; with it in flight under the MFMAs: one plane 60 -> 58 us,
+    // two planes 108 -> 97 us - tools/stem_time.py)
+    constexpr int NPF = (CIN * PCH + 255) / 256;         // staged elements per thread
+    float pf[NPF];
+    auto fetch = [&](int tile_) {
+        const int img_ = tile_ / a.tiles_per_img, t_ = tile_ - img_ * a.tiles_per_img;
+        const int ty_ = t_ / a.tiles_x, tx_ = t_ - ty_ * a.tiles_x;
+        const int iy0 = ty_ * 16 - 3, ix0 = tx_ * 16 - 3;
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+            const int i = tid + j * 256;
+            const int c = i / PCH, r = i - c * PCH, yy = r / PW, xx = r - yy * PW;
+            const int iy = iy0 + yy, ix = ix0 + xx;
+            float v = 0.f;
+            if (tile_ < a.ntiles && i < CIN * PCH && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi)
+                v = a.x[(((size_t)img_ * CIN + c) * a.Hi + iy) * a.Wi + ix];
+            pf[j] = v;
+        }
+    };
+    fetch(blockIdx.x);
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const int img = tile / a.tiles_per_img, t = tile - img * a.tiles_per_img;
         if (a.bn_sums) {
@@ -76,17 +97,12 @@ __global__ void __launch_bounds__(256) stem7_fwd_kernel(Stem7Args a) {
             if (grp != cur_grp) { if (cur_grp >= 0) flush_stats(); cur_grp = grp; }
         }
         const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
-        const int iy0 = ty * 16 - 3, ix0 = tx * 16 - 3;
         __syncthreads();                                 // previous tile's fragment reads are done (and Wt is complete)
-        for (int i = tid; i < CIN * PCH; i += 256) {
-            const int c = i / PCH, r = i - c * PCH, yy = r / PW, xx = r - yy * PW;
-            const int iy = iy0 + yy, ix = ix0 + xx;
-            float v = 0.f;
-            if ((unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi)
-                v = a.x[(((size_t)img * CIN + c) * a.Hi + iy) * a.Wi + ix];
-            patch[i] = v;
-        }
+#pragma unroll
+        for (int j = 0; j < NPF; ++j)
+            if (tid + j * 256 < CIN * PCH) patch[tid + j * 256] = pf[j];
         __syncthreads();
+        fetch(tile + (int)gridDim.x);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
