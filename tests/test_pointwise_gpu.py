@@ -64,6 +64,37 @@ def test_pointwise_forward_against_float64(K, kind, N, H, W, Ci, Co, groups):
     assert torch.equal(y3, y) and float(rec.max()) == float(y.abs().max())
 
 
+@pytest.mark.parametrize("kind,N,H,W,Ci,Co", [CASES[0], CASES[3], CASES[5]])
+def test_pointwise_deterministic_call_repeats_bitwise(K, kind, N, H, W, Ci, Co):
+    """BH_ROUTE_DETERMINISTIC: the statistics leave through the integer limbs - two calls give bitwise the same sums buffer (and values)."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, H, W, Ci, generator=g).cuda()
+    b = torch.randn(Co, generator=g).cuda()
+    with K.det_scope(True):
+        if kind == "convT":
+            d = K.conv_desc(N, H, W, Ci, Co, 2, 2, 0, transposed=True, precision=4)
+            w = (torch.randn(Ci, 2, 2, Co, generator=g) * 0.1).cuda()
+        else:
+            d = K.conv_desc(N, H, W, Ci, Co, 1, 1, 0, precision=4)
+            w = (torch.randn(Co, 1, 1, Ci, generator=g) * 0.1).cuda()
+        outs = []
+        for _ in range(2):
+            s = K.bn_stats_buffer(2, Co, "cuda")
+            y = K.conv_fwd(x, w, b, d, bn_sums=s, groups=2)
+            outs.append((y, s))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1].view(torch.int64), outs[1][1].view(torch.int64))
+    # and the limbs hold the same totals as the default call's doubles
+    s0 = K.bn_stats_buffer(2, Co, "cuda")
+    K.conv_fwd(x, w, b, K.conv_desc(N, H, W, Ci, Co, 2 if kind == "convT" else 1, 2 if kind == "convT" else 1, 0, transposed=kind == "convT", precision=4),
+               bn_sums=s0, groups=2)
+    st = K.bn_stats_buffer(2, Co, "cuda")
+    yb = outs[0][0]
+    K.bn_stats(yb, st, 2, Co)
+    tab0 = s0.reshape(2, Co, 2, -1)[..., 0].cpu()
+    tab1 = st.reshape(2, Co, 2, -1)[..., 0].cpu()
+    assert (tab0 - tab1).abs().max().item() <= 1e-9 * tab1.abs().max().item() + 1e-6
+
+
 @pytest.mark.parametrize("N,H,Ci,Co", [(16, 64, 32, 16), (16, 64, 64, 32), (4, 128, 32, 16)])
 @pytest.mark.parametrize("relu", [True, False])
 def test_pointwise_batchnorm_on_load(K, N, H, Ci, Co, relu):
