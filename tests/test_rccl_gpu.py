@@ -86,6 +86,14 @@ def test_bench_eight_ranks_over_gloo_prints_the_eight_gpu_line():
     assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["global_batch"] == 512 and d["config"]["parallelism"] == "dp8"
     assert d["value"] > 0 and abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert "world_size=8" in r.stderr and "counted 8 ranks" in r.stderr
+    # round-4 VERDICT item 8: the line proves itself - backend, ranks counted by an all-reduce, buckets, the exchange timed alone, the same
+    # ranks stepping without it in the same run
+    dd = d["distributed"]
+    for k in ("backend", "rccl_version", "world_size", "ranks_counted", "buckets", "payload_bytes_per_step", "allreduce_ms_per_step",
+              "same_run_ms_per_step_without_exchange", "scaling_efficiency"):
+        assert k in dd, k
+    assert dd["backend"] == "gloo" and dd["world_size"] == dd["ranks_counted"] == 8 and dd["buckets"] >= 1
+    assert dd["allreduce_ms_per_step"] > 0 and 0 < dd["scaling_efficiency"] <= 1.05
     log = os.path.join(ROOT, "gpurun_out", "bench_8_rank_gloo.log")
     os.makedirs(os.path.dirname(log), exist_ok=True)
     with open(log, "w") as f:
@@ -116,8 +124,13 @@ def test_bench_json_line_contract():
     assert rf["bound"] in ("mfma", "hbm") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     # the library's own name of the dominant kernel, with every template argument as rocprofv3 prints the symbol
     assert rf["kernel"].startswith(("conv3x3_pc_kernel<", "conv3x3_halo_kernel<", "wgrad_x3_kernel<")) and rf["kernel"].endswith(">")
-    assert rf["kernel"].count(",") == {"conv3x3_pc_kernel": 2, "conv3x3_halo_kernel": 9, "wgrad_x3_kernel": 3}[rf["kernel"].split("<")[0]]
-    assert 0.2 < rf["frac"] < 1.0 and rf["frac"] < rf["frac_of_measured_peak"] < 1.2
+    first = rf["kernel"].split("+")[0]
+    assert first.count(",") in {"conv3x3_pc_kernel": (2,), "conv3x3_halo_kernel": (9,), "wgrad_x3_kernel": (3, 4)}[first.split("<")[0]]
+    assert 0.18 < rf["frac"] < 1.0 and rf["frac"] < rf["frac_of_measured_peak"] < 1.2
+    # round 5: both roofs next to each other, and the bit-exact arithmetic's step time from the same run
+    assert abs(rf["frac"] - max(rf["mfma_frac"], rf["hbm_frac"])) < 1e-9
+    alt = d["alt_arithmetic"]
+    assert alt["arithmetic"].startswith("f32x3") and alt["unit"] == "image-pairs/s" and alt["ms_per_step"] > d["ms_per_step"]
     assert rf["measured_peaks"]["bf16_mfma_random_operands_TFLOPs"] < rf["measured_peaks"]["bf16_mfma_constant_operands_TFLOPs"] <= 2600
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
