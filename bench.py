@@ -51,7 +51,9 @@ def x3_is_f16(kernel):
     if kernel.startswith("conv3x3_pc_kernel<"):
         return True
     args = kernel.split(">")[0].split(",")
-    return bool(x3_pieces(kernel)) and len(args) in (4, 10) and args[-1] == "true"
+    if kernel.startswith("wgrad_x3_kernel<"):                     # CB, BNI, NP, F16[, PC, MAP4]
+        return len(args) >= 4 and args[3] == "true"
+    return bool(x3_pieces(kernel)) and len(args) == 10 and args[-1] == "true"
 
 
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec

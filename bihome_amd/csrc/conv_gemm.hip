@@ -1009,6 +1009,7 @@ int bh_debug_force_tile(int bm, int bn) {
     if (bm == -31) { bh_wgrad_x3_tune(1, bn); return BH_OK; }            // (-31, 1): ablation - that kernel without its atomic flush
     if (bm == -33) { bh_pointwise_tune(0, bn); return BH_OK; }           // (-33, 0 / 1): the pointwise streaming kernel off / on
     if (bm == -34) { bh_pointwise_tune(1, bn); return BH_OK; }           // (-34, n): its workgroups per launch
+    if (bm == -36) { bh_wgrad_x3_tune(3, bn); return BH_OK; }            // (-36, 0 / 1): the 4 x 4-map form of the fp16-piece weight gradient off / on
     if (bm == -32) { bh_wgrad_x3_tune(2, bn); return BH_OK; }            // (-32, 0 / 1): the fp16-piece kernel's four-wave / eight-wave (producer + consumer) form
     if (bm == -20) { bh_bn_tune(bn); return BH_OK; }                     // (-20, n): workgroups per BatchNorm apply launch
     if (bm == -14) { bh_warp_tune(0, bn); return BH_OK; }               // (-14, 1|2): warp forward rows per thread

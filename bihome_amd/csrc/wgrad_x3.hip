@@ -58,19 +58,22 @@ struct WX3Args {
     const unsigned* amax_gy;
 };
 
-template <int CB, int NP = 3>
+// MAP4 (round 5, CB = 64): 4 x 4 feature maps (layer4 of the ResNet-34 regressor) - a tile is FOUR IMAGES laid out 2 x 2 as an 8 x 8 pixel block,
+// each with its own zero border: the halo image is 12 x 12 (sub-map (a, b) at rows 6a .. 6a + 5, columns 6b .. 6b + 5)
+template <int CB, int NP = 3, bool MAP4 = false>
 struct WXGeom {
+    static constexpr int XW = MAP4 ? 12 : 10;                  // halo rows / columns
     static constexpr int PIX = CB * 2;                        // bytes of a pixel record: CB bf16 channels
     // row skew: the four 64-byte segments of a transposing read (2x2 pixels) must start 16 banks apart
     static constexpr int GROW = 8 * PIX + (CB == 64 ? 64 : 128);      // gy tile row:  1088 / 640 B  (= 16 / 32 banks mod 64)
-    static constexpr int XROW = 10 * PIX + (CB == 64 ? 64 : 0);       // halo row:     1344 / 640 B
+    static constexpr int XROW = XW * PIX + (CB == 64 ? 64 : 0);       // halo row:     1344 / 640 B (MAP4: 1600)
     static constexpr int GP = 8 * GROW;                        // one piece image of the gy tile
-    static constexpr int XP = 10 * XROW;                       // one piece image of the halo
+    static constexpr int XP = XW * XROW;                       // one piece image of the halo
     static constexpr int XBASE = NP * GP;
     static constexpr int LDS = NP * (GP + XP);                 // one image of a tile: 66,432 / 34,560 B (three pieces)
     static constexpr int NG = CB / 8;                          // 8-channel groups per pixel
     static constexpr int GS = 64 * NG / 256;                   // gy staging slots per thread (2 / 1)
-    static constexpr int HS = (100 * NG + 255) / 256;          // halo staging slots per thread (4 / 2)
+    static constexpr int HS = (XW * XW * NG + 255) / 256;      // halo staging slots per thread (4 / 2; MAP4: 5)
 };
 
 // NP: bf16 pieces per operand - 3: the exact cut, six products (precision 2); 2: two rounded pieces, three products ("f32x2",
@@ -83,11 +86,12 @@ struct WXGeom {
 // blocks as the four-wave form: the results are bitwise the same; what changes is that the cut's VALU work and the LDS writes no longer
 // sit in the instruction stream of the wave that feeds the matrix pipe (which is alone on its SIMD and stalls for every one of them).
 // Two waves per SIMD leave 256 registers per wave: 144 accumulators + <= 112 for fragments and addresses.
-template <int CB, bool BNI = false, int NP = 3, bool F16 = false, bool PC = false>
+template <int CB, bool BNI = false, int NP = 3, bool F16 = false, bool PC = false, bool MAP4 = false>
 __global__ void __launch_bounds__(PC ? 512 : 256, 1) wgrad_x3_kernel(WX3Args a) {
     static_assert(!F16 || NP == 2, "fp16 pieces: two");
     static_assert(!PC || (CB == 64 && F16), "producer / consumer form: 64-channel blocks of fp16 pieces");
-    using G = WXGeom<CB, NP>;
+    static_assert(!MAP4 || (CB == 64 && F16), "4 x 4 maps: 64-channel blocks of fp16 pieces");
+    using G = WXGeom<CB, NP, MAP4>;
     constexpr int GS = G::GS, HS = G::HS, NG = G::NG;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const bool producer = PC && threadIdx.x >= 256;
@@ -114,17 +118,23 @@ __global__ void __launch_bounds__(PC ? 512 : 256, 1) wgrad_x3_kernel(WX3Args a) 
 #pragma unroll
     for (int j = 0; j < GS; ++j) {
         const int q = j * 256 + tid, p = q / NG, cg = q % NG;     // p = 0..63
-        g_pix[j] = (p >> 3) * a.W + (p & 7);
+        if constexpr (MAP4) g_pix[j] = (((p >> 5) * 2 + ((p >> 2) & 1)) << 4) + (((p >> 3) & 3) << 2) + (p & 3);      // image (py / 4, px / 4), its pixel (py % 4, px % 4)
+        else g_pix[j] = (p >> 3) * a.W + (p & 7);
         g_lds[j] = (p >> 3) * G::GROW + (p & 7) * G::PIX + cg * 16;
         g_cg[j] = cg * 8;
     }
     int h_y[HS], h_x[HS], h_lds[HS], h_cg[HS];
 #pragma unroll
     for (int j = 0; j < HS; ++j) {
-        const int q = min(j * 256 + tid, 100 * NG - 1);
-        const int hp = q / NG, cg = q % NG;                       // hp = 0..99
-        const int hy = (hp * 205) >> 11, hx = hp - hy * 10;
-        h_y[j] = hy - 1; h_x[j] = hx - 1;
+        const int q = min(j * 256 + tid, G::XW * G::XW * NG - 1);
+        const int hp = q / NG, cg = q % NG;                       // hp = 0..99 (MAP4: 0..143)
+        const int hy = MAP4 ? hp / 12 : (hp * 205) >> 11, hx = hp - hy * G::XW;
+        if constexpr (MAP4) {
+            // h_x: the image of the slot (0..3); h_y: its pixel offset from the tile's first image, or -1 on a border
+            const int sy = hy / 6, iy = hy - sy * 6 - 1, sx = hx / 6, ix = hx - sx * 6 - 1;
+            h_x[j] = sy * 2 + sx;
+            h_y[j] = ((unsigned)iy < 4u && (unsigned)ix < 4u) ? ((sy * 2 + sx) << 4) + (iy << 2) + ix : -1;
+        } else { h_y[j] = hy - 1; h_x[j] = hx - 1; }
         h_lds[j] = G::XBASE + hy * G::XROW + hx * G::PIX + cg * 16;
         h_cg[j] = cg * 8;
     }
@@ -152,7 +162,7 @@ __global__ void __launch_bounds__(PC ? 512 : 256, 1) wgrad_x3_kernel(WX3Args a) 
         // (multiply-high division with host-made reciprocals: exact for t * divisor < 2^32; no branch in the tile step)
         const int img = a.tiles_per_img == 1 ? t : (int)__umulhi((unsigned)t, a.m_tpi), r = t - img * a.tiles_per_img;
         const int ty = a.tiles_x == 1 ? r : (int)__umulhi((unsigned)r, a.m_tx), tx = r - ty * a.tiles_x;
-        const int org = (img * a.H + ty * 8) * a.W + tx * 8;     // pixel index of the tile's (0, 0)
+        const int org = MAP4 ? t * 64 : (img * a.H + ty * 8) * a.W + tx * 8;     // pixel index of the tile's (0, 0) (MAP4: of its first image)
         if constexpr (part <= 0) {
 #pragma unroll
             for (int j = 0; j < GS; ++j) {
@@ -163,12 +173,13 @@ __global__ void __launch_bounds__(PC ? 512 : 256, 1) wgrad_x3_kernel(WX3Args a) 
         }
 #pragma unroll
         for (int j = 0; j < HS; ++j) {
-            if (part >= 0 && (part == 0 || j / (HS / 2) != part - 1)) continue;
+            if (part >= 0 && (part == 0 || (j < HS / 2 ? 1 : 2) != part)) continue;      // (part 1: the first HS / 2 halo slots, part 2: the rest)
             const int y = ty * 8 + h_y[j], x = tx * 8 + h_x[j];
-            const unsigned in = ((unsigned)(org + h_y[j] * a.W + h_x[j]) * (unsigned)a.Ci + (unsigned)(ci0 + h_cg[j])) * 4u;
-            const bool ok = (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+            const unsigned in = MAP4 ? ((unsigned)(org + h_y[j]) * (unsigned)a.Ci + (unsigned)(ci0 + h_cg[j])) * 4u
+                                     : ((unsigned)(org + h_y[j] * a.W + h_x[j]) * (unsigned)a.Ci + (unsigned)(ci0 + h_cg[j])) * 4u;
+            const bool ok = MAP4 ? h_y[j] >= 0 : ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W);
             const unsigned off = ok ? in : OOB;                   // outside the image: zeros
-            if constexpr (BNI) { h_ok[j] = ok; h_tb[j] = TB0 + ((img / a.bni_ipg) * CB + h_cg[j]) * 8; }
+            if constexpr (BNI) { h_ok[j] = ok; h_tb[j] = TB0 + (((MAP4 ? 4 * t + h_x[j] : img) / a.bni_ipg) * CB + h_cg[j]) * 8; }
             rx[j][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0));
             rx[j][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsX, off + 16u, 0, 0));
         }
@@ -210,14 +221,14 @@ __global__ void __launch_bounds__(PC ? 512 : 256, 1) wgrad_x3_kernel(WX3Args a) 
             __builtin_amdgcn_s_setprio(2);
             if (nt > 0) {
                 WX_PART(-1, split);
-                WX_SLOT(0, smem); WX_SLOT(1, smem); WX_SLOT(2, smem); WX_SLOT(3, smem); WX_SLOT(4, smem); WX_SLOT(5, smem);
+                WX_SLOT(0, smem); WX_SLOT(1, smem); WX_SLOT(2, smem); WX_SLOT(3, smem); WX_SLOT(4, smem); WX_SLOT(5, smem); WX_SLOT(6, smem);
                 if (nt > 1) WX_PART(-1, split + a.nsplit);
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             for (int k = 0; k < nt; ++k) {
                 if (k + 1 < nt) {
                     char* const nimg = smem + ((k + 1) & 1) * G::LDS;
-                    WX_SLOT(0, nimg); WX_SLOT(1, nimg); WX_SLOT(2, nimg); WX_SLOT(3, nimg); WX_SLOT(4, nimg); WX_SLOT(5, nimg);
+                    WX_SLOT(0, nimg); WX_SLOT(1, nimg); WX_SLOT(2, nimg); WX_SLOT(3, nimg); WX_SLOT(4, nimg); WX_SLOT(5, nimg); WX_SLOT(6, nimg);
                     if (k + 2 < nt) WX_PART(-1, split + (k + 2) * a.nsplit);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -234,7 +245,7 @@ __global__ void __launch_bounds__(PC ? 512 : 256, 1) wgrad_x3_kernel(WX3Args a) 
     const int chan_b = (16 * gsel + 4 * gq) * 2;
     const int ksw = CB == 64 ? 0 : 2 * wave;
     const int laneA = ((jj >> 1) + ksw) * G::GROW + (4 * kh2 + (jj & 1)) * G::PIX + chan_b + wm * 64;
-    const int laneB = G::XBASE + ((jj >> 1) + ksw) * G::XROW + (4 * kh2 + (jj & 1)) * G::PIX + chan_b + wn * 64;
+    const int laneB = G::XBASE + ((jj >> 1) + ksw) * G::XROW + ((MAP4 ? 6 : 4) * kh2 + (jj & 1)) * G::PIX + chan_b + wn * 64;
 
     f32x16 acc[9];
 #pragma unroll
@@ -248,15 +259,17 @@ __global__ void __launch_bounds__(PC ? 512 : 256, 1) wgrad_x3_kernel(WX3Args a) 
         const i16x4 v0_ = WX_TR(la, pc * G::GP + 2 * (ks) * G::GROW);                                                   \
         const i16x4 v1_ = WX_TR(la, pc * G::GP + 2 * (ks) * G::GROW + 2 * G::PIX);                                      \
         dst[pc] = WX_OPER(v0_, v1_); }
+// (halo row of tile row 2 ks at kernel row 0: 2 ks - MAP4: rows 0..3 of the tile are sub-map rows 0..3 behind their border, rows 4..7 start at 6)
+#define WX_BROW(ks) (MAP4 ? 6 * ((ks) >> 1) + 2 * ((ks) & 1) : 2 * (ks))
 #define WX_LOAD_B(dst, ks, tap) _Pragma("unroll") for (int pc = 0; pc < NP; ++pc) {                                     \
-        const i16x4 v0_ = WX_TR(lb, pc * G::XP + (2 * (ks) + (tap) / 3) * G::XROW + ((tap) % 3) * G::PIX);              \
-        const i16x4 v1_ = WX_TR(lb, pc * G::XP + (2 * (ks) + (tap) / 3) * G::XROW + ((tap) % 3 + 2) * G::PIX);          \
+        const i16x4 v0_ = WX_TR(lb, pc * G::XP + (WX_BROW(ks) + (tap) / 3) * G::XROW + ((tap) % 3) * G::PIX);            \
+        const i16x4 v1_ = WX_TR(lb, pc * G::XP + (WX_BROW(ks) + (tap) / 3) * G::XROW + ((tap) % 3 + 2) * G::PIX);        \
         dst[pc] = WX_OPER(v0_, v1_); }
 
     if constexpr (!PC) {
         if (nt > 0) {
             WX_PART(-1, split);
-            WX_SLOT(0, smem); WX_SLOT(1, smem); WX_SLOT(2, smem); WX_SLOT(3, smem); WX_SLOT(4, smem); WX_SLOT(5, smem);   // (slots past GS + HS: nothing)
+            WX_SLOT(0, smem); WX_SLOT(1, smem); WX_SLOT(2, smem); WX_SLOT(3, smem); WX_SLOT(4, smem); WX_SLOT(5, smem); WX_SLOT(6, smem);   // (slots past GS + HS: nothing)
         }
     }
     if constexpr (PC) asm volatile("s_barrier" ::: "memory"); else __syncthreads();
@@ -290,7 +303,7 @@ __global__ void __launch_bounds__(PC ? 512 : 256, 1) wgrad_x3_kernel(WX3Args a) 
             } else if (CB == 64) {
                 if (pi == 3) { WX_SLOT(0, nimg); WX_SLOT(1, nimg); WX_PART(0, tnext); }
                 if (pi == 8) { WX_SLOT(2, nimg); WX_SLOT(3, nimg); WX_PART(1, tnext); }
-                if (pi == 13) { WX_SLOT(4, nimg); WX_SLOT(5, nimg); WX_PART(2, tnext); }
+                if (pi == 13) { WX_SLOT(4, nimg); WX_SLOT(5, nimg); WX_SLOT(6, nimg); WX_PART(2, tnext); }
             } else {
                 if (pi == 1) { WX_SLOT(0, nimg); WX_PART(0, tnext); }
                 if (pi == 2) { WX_SLOT(1, nimg); WX_PART(1, tnext); }
@@ -318,6 +331,7 @@ __global__ void __launch_bounds__(PC ? 512 : 256, 1) wgrad_x3_kernel(WX3Args a) 
     }
 #undef WX_LOAD_A
 #undef WX_LOAD_B
+#undef WX_BROW
 #undef WX_SLOT
 #undef WX_PART
 #undef WX_TR
@@ -393,9 +407,9 @@ __global__ void __launch_bounds__(256) wgrad_x3_reduce_kernel(const float* __res
     }
 }
 
-BH_KNOB(g_wx3_target, 256); BH_KNOB(g_wx3_noflush, 0); BH_KNOB(g_wx3_pc, 1);
+BH_KNOB(g_wx3_target, 256); BH_KNOB(g_wx3_noflush, 0); BH_KNOB(g_wx3_pc, 1); BH_KNOB(g_wx3_map4, 1);
 #ifdef BH_TUNING
-void bh_wgrad_x3_tune(int what, int v) { if (what == 0) g_wx3_target = v; else if (what == 1) g_wx3_noflush = v; else if (what == 2) g_wx3_pc = v; }
+void bh_wgrad_x3_tune(int what, int v) { if (what == 0) g_wx3_target = v; else if (what == 1) g_wx3_noflush = v; else if (what == 2) g_wx3_pc = v; else if (what == 3) g_wx3_map4 = v; }
 #endif
 
 // *taken = 1 when the shape is eligible (3x3 / stride 1 / pad 1, NHWC, H and W multiples of 8, channels multiples of 32).
@@ -404,7 +418,10 @@ int bh_wgrad_x3_try(const float* x, const float* gy, float* gw, const bh_conv_de
                     long long ws_bytes, long long* ws_need, const bh_bn_in* bni) {
     *taken = 0;
     if (d->transposed || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->in_nchw || d->out_nchw) return BH_OK;
-    if (d->Hi % 8 || d->Wi % 8 || d->Ho != d->Hi || d->Wo != d->Wi || d->Ci % 32 || d->Co % 32) return BH_OK;
+    // 4 x 4 maps (round 5: layer4 of the ResNet-34 regressor): fp16 pieces, 64-channel blocks, four images per tile
+    const bool map4 = d->Hi == 4 && d->Wi == 4 && d->Ho == 4 && d->Wo == 4 && d->N % 4 == 0 && d->Ci % 64 == 0 && d->Co % 64 == 0 &&
+                      d->precision == 4 && d->a_bound && d->b_bound && g_wx3_map4;
+    if (!map4 && (d->Hi % 8 || d->Wi % 8 || d->Ho != d->Hi || d->Wo != d->Wi || d->Ci % 32 || d->Co % 32)) return BH_OK;
     const long long xe = (long long)d->N * d->Hi * d->Wi * d->Ci, ge = (long long)d->N * d->Hi * d->Wi * d->Co;
     if (xe >= (1ll << 29) || ge >= (1ll << 29)) return BH_OK;
     const int cb = (d->Ci % 64 == 0 && d->Co % 64 == 0) ? 64 : 32;
@@ -412,6 +429,7 @@ int bh_wgrad_x3_try(const float* x, const float* gy, float* gw, const bh_conv_de
     a.X = x; a.GY = gy; a.Out = gw;
     a.N = d->N; a.H = d->Hi; a.W = d->Wi; a.Ci = d->Ci; a.Co = d->Co;
     a.tiles_x = d->Wi / 8; a.tiles_per_img = (d->Hi / 8) * a.tiles_x; a.ntiles = d->N * a.tiles_per_img;
+    if (map4) { a.tiles_x = 1; a.tiles_per_img = 1; a.ntiles = d->N / 4; }
     if ((long long)a.ntiles * a.tiles_per_img >= (1ll << 32)) return BH_OK;
     a.m_tx = (unsigned)((1ull << 32) / (unsigned)a.tiles_x + 1ull);
     a.m_tpi = (unsigned)((1ull << 32) / (unsigned)a.tiles_per_img + 1ull);
@@ -440,29 +458,33 @@ int bh_wgrad_x3_try(const float* x, const float* gy, float* gw, const bh_conv_de
     const bool f16 = d->precision == 4 && d->a_bound && d->b_bound;
     a.amax_x = reinterpret_cast<const unsigned*>(d->a_bound); a.amax_gy = reinterpret_cast<const unsigned*>(d->b_bound);
     // fp16 pieces, 64-channel blocks: the eight-wave producer / consumer form (same partial blocks, bitwise the same sums)
-    const bool pc = f16 && cb == 64 && g_wx3_pc;
-    // (the template arguments as rocprofv3 prints the symbol: CB, BNI, NP, F16 and - when set - PC)
+    // (the eight-wave form: a per-call route bit - include/bihome.h BH_ROUTE_WX3_PC; the tuning build's knob can switch it off)
+    const bool pc = f16 && cb == 64 && (d->route & BH_ROUTE_WX3_PC) && g_wx3_pc;
+    // (all six template arguments, as rocprofv3 prints the symbol: CB, BNI, NP, F16, PC, MAP4)
     if (bh_query(ws ? "wgrad_x3_kernel<%d,%s,%d,%s%s>+wgrad_x3_reduce_kernel<%d>" : "wgrad_x3_kernel<%d,%s,%d,%s%s>", cb, bni ? "true" : "false",
-                 (d->precision == 4 && !f16) ? 3 : np, f16 ? "true" : "false", pc ? ",true" : "", cb)) { *taken = 1; return BH_OK; }
+                 (d->precision == 4 && !f16) ? 3 : np, f16 ? "true" : "false", map4 ? (pc ? ",true,true" : ",false,true") : (pc ? ",true,false" : ",false,false"), cb)) { *taken = 1; return BH_OK; }
     typedef void (*kern_t)(WX3Args);
-    static const kern_t fns[14] = {wgrad_x3_kernel<64, false, 3>, wgrad_x3_kernel<32, false, 3>, wgrad_x3_kernel<64, true, 3>, wgrad_x3_kernel<32, true, 3>,
+    static const kern_t fns[18] = {wgrad_x3_kernel<64, false, 3>, wgrad_x3_kernel<32, false, 3>, wgrad_x3_kernel<64, true, 3>, wgrad_x3_kernel<32, true, 3>,
                                    wgrad_x3_kernel<64, false, 2>, wgrad_x3_kernel<32, false, 2>, wgrad_x3_kernel<64, true, 2>, wgrad_x3_kernel<32, true, 2>,
                                    wgrad_x3_kernel<64, false, 2, true>, wgrad_x3_kernel<32, false, 2, true>, wgrad_x3_kernel<64, true, 2, true>, wgrad_x3_kernel<32, true, 2, true>,
-                                   wgrad_x3_kernel<64, false, 2, true, true>, wgrad_x3_kernel<64, true, 2, true, true>};
-    static const int lds_of[14] = {2 * WXGeom<64, 3>::LDS, 2 * WXGeom<32, 3>::LDS, 2 * WXGeom<64, 3>::LDS, 2 * WXGeom<32, 3>::LDS,
+                                   wgrad_x3_kernel<64, false, 2, true, true>, wgrad_x3_kernel<64, true, 2, true, true>,
+                                   wgrad_x3_kernel<64, false, 2, true, true, true>, wgrad_x3_kernel<64, true, 2, true, true, true>,
+                                   wgrad_x3_kernel<64, false, 2, true, false, true>, wgrad_x3_kernel<64, true, 2, true, false, true>};
+    static const int lds_of[18] = {2 * WXGeom<64, 3>::LDS, 2 * WXGeom<32, 3>::LDS, 2 * WXGeom<64, 3>::LDS, 2 * WXGeom<32, 3>::LDS,
                                    2 * WXGeom<64, 2>::LDS, 2 * WXGeom<32, 2>::LDS, 2 * WXGeom<64, 2>::LDS, 2 * WXGeom<32, 2>::LDS,
                                    2 * WXGeom<64, 2>::LDS, 2 * WXGeom<32, 2>::LDS, 2 * WXGeom<64, 2>::LDS, 2 * WXGeom<32, 2>::LDS,
-                                   2 * WXGeom<64, 2>::LDS, 2 * WXGeom<64, 2>::LDS};
+                                   2 * WXGeom<64, 2>::LDS, 2 * WXGeom<64, 2>::LDS, 2 * WXGeom<64, 2, true>::LDS, 2 * WXGeom<64, 2, true>::LDS,
+                                   2 * WXGeom<64, 2, true>::LDS, 2 * WXGeom<64, 2, true>::LDS};
     static unsigned long long attr_devs = 0;
     if (bh_device_once(attr_devs)) {
-        for (int i = 0; i < 14; ++i) {
-            const bool tb = i < 12 ? (i & 2) != 0 : i == 13;
+        for (int i = 0; i < 18; ++i) {
+            const bool tb = i < 12 ? (i & 2) != 0 : (i & 1) != 0;
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[i]), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                      lds_of[i] + (tb ? 4 * ((i < 12 && (i & 1)) ? 32 : 64) * 8 : 0));
             if (e != hipSuccess) return (int)e;
         }
     }
-    const int ki = pc ? 12 + (bni ? 1 : 0) : (f16 ? 8 : (np == 2 && d->precision != 4) ? 4 : 0) + (bni ? 2 : 0) + (cb == 64 ? 0 : 1);
+    const int ki = map4 ? (pc ? 14 : 16) + (bni ? 1 : 0) : pc ? 12 + (bni ? 1 : 0) : (f16 ? 8 : (np == 2 && d->precision != 4) ? 4 : 0) + (bni ? 2 : 0) + (cb == 64 ? 0 : 1);
     hipLaunchKernelGGL(fns[ki], dim3(pairs * ns), dim3(pc ? 512 : 256), lds_of[ki] + tb_bytes, stream, a);
     BH_LAUNCH_CHECK();
     if (ws) {

@@ -5,7 +5,7 @@ import os
 
 import torch
 
-from ._lib import (AMAX_FLOATS, BN_DETERMINISTIC, F_DETERMINISTIC, GEOMETRY_FIELDS, ROUTE_DETERMINISTIC, BhBnIn, BhBnReduce, BhConvDesc,
+from ._lib import (AMAX_FLOATS, BN_DETERMINISTIC, F_DETERMINISTIC, GEOMETRY_FIELDS, ROUTE_DETERMINISTIC, ROUTE_WX3_PC, BhBnIn, BhBnReduce, BhConvDesc,
                    BhPack3x3Job, check, lib)
 
 
@@ -844,7 +844,13 @@ def conv_dgrad(gy, w, d, out=None, bn_reduce=None, wkey=None, wpacked=None, cols
 
 def wgrad_det_bytes(d):
     """Workspace bytes of the deterministic weight-gradient form for this conv (0: not available for the shape)."""
-    return int(lib.bh_conv_wgrad_det_bytes(ctypes.byref(_route_det(d))))
+    _route_det(d)
+    if d.precision == 4 and not d.a_bound:
+        # (a precision-4 launch is described WITH magnitude records - conv_wgrad attaches them -, and the fp16-piece forms size their
+        #  workspace differently from what a description without them falls back to: ask with placeholders, as conv_variant does)
+        d = _with_layout(d, d.w_layout)
+        d.a_bound = d.b_bound = 256
+    return int(lib.bh_conv_wgrad_det_bytes(ctypes.byref(d)))
 
 
 _STEM_WGRAD_WS = {}      # (device, bytes, stream) -> the stem weight gradient's partial-sum workspace: launches of ONE stream serialise on it;

@@ -678,6 +678,13 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
                     K.bias_grad_from_sums(red_arena[bias_off[i]:bias_off[i] + K.bn_stats_doubles(1, d.Co)], gb, 1, d.Co)
                     gb = None
                 ws = det_ws if det_ws is not None else (x3_ws if getattr(d, "bh_wx3", False) else None)
+                # the fp16-piece weight gradient's eight-wave form is the faster launch alone, the four-wave form the better neighbour: it
+                # leaves ~200 registers per SIMD lane, so the main stream's BatchNorm kernels run ON the same CUs (same-box A/B, round 5:
+                # two streams 13.30 ms with the four-wave form against 13.49; one stream 14.13 against 14.02)
+                if wgrad_stream is None:
+                    d.route |= K.ROUTE_WX3_PC
+                else:
+                    d.route &= ~K.ROUTE_WX3_PC
                 if wgrad_stream is None:
                     K.conv_wgrad(x, g, gw, gb, d, det_ws=ws)
                 else:

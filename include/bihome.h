@@ -270,6 +270,9 @@ int bh_absmax(const float* x, long long n, float* record, void* stream);
                                      * (default: only where it is the faster one) */
 #define BH_ROUTE_C3_TILE_WG 256     /* fwd / dgrad, precision 4: the one-workgroup-per-tile halo kernel instead of the persistent producer /
                                      * consumer kernel (round 5) - same convolution results bit for bit */
+#define BH_ROUTE_WX3_PC 1024        /* wgrad, precision 4, 64-channel blocks: the EIGHT-wave producer / consumer form of wgrad_x3_kernel (bitwise the
+                                     * four-wave result).  Faster alone (-2 us per launch); the default four-wave form leaves 200 registers per
+                                     * SIMD lane to co-resident kernels of a second stream, which is worth more in a two-stream step (round 5) */
 
 /* One 3x3 layer's weights for bh_conv3x3_pack: w[Co][3][3][Ci] (Co, Ci multiples of 32) -> pf (forward operand order) and
  * pd (dgrad operand order: transposed, taps flipped), Co*9*Ci floats each (split: 1.5x that); either may be NULL. */

@@ -118,19 +118,19 @@ def test_conv_variant_query_reports_the_dispatch():
     assert dx.precision == 2
     assert K.conv_variant(K._with_layout(dx, 2), "fwd") == "conv3x3_halo_kernel<false,64,false,2,true,true,false,3,false,false>"
     assert K.conv_variant(K._with_layout(dx, 2), "dgrad") == "conv3x3_halo_kernel<true,64,false,2,true,true,false,3,false,false>"
-    assert K.conv_variant(dx, "fwd") == "conv3x3_halo_kernel<false,64,false,2,false,false,false,3,false,false>" and K.conv_variant(dx, "wgrad") == "wgrad_x3_kernel<64,false,3,false>"
+    assert K.conv_variant(dx, "fwd") == "conv3x3_halo_kernel<false,64,false,2,false,false,false,3,false,false>" and K.conv_variant(dx, "wgrad") == "wgrad_x3_kernel<64,false,3,false,false,false>"
     assert K.wgrad_det_bytes(dx) == 256 * 36864 * 4                       # 256 partial blocks of 64 x 9 x 64
     # 'f32x2' (precision 3, w_layout 3: two rounded bf16 pieces, three products) - the same kernels with NP = 2
     d2 = K.conv_desc(128, 32, 32, 64, 64, 3, 1, 1, precision=K.PRECISION["f32x2"])
     assert d2.precision == 3 and K.packed_layout(3) == 3 and K.SPLIT_PIECES[3] == 2
     assert K.conv_variant(K._with_layout(d2, 3), "fwd") == "conv3x3_halo_kernel<false,64,false,2,true,true,false,2,false,false>"
     assert K.conv_variant(K._with_layout(d2, 3), "dgrad") == "conv3x3_halo_kernel<true,64,false,2,true,true,false,2,false,false>"
-    assert K.conv_variant(d2, "wgrad_det") == "wgrad_x3_kernel<64,false,2,false>+wgrad_x3_reduce_kernel<64>"
+    assert K.conv_variant(d2, "wgrad_det") == "wgrad_x3_kernel<64,false,2,false,false,false>+wgrad_x3_reduce_kernel<64>"
     for lay, prec in ((2, 3), (3, 2), (3, 0)):
         with pytest.raises(RuntimeError):
             K.conv_variant(K._with_layout(K.conv_desc(128, 32, 32, 64, 64, 3, 1, 1, precision=prec), lay), "fwd")   # layout <-> precision
     d32 = K.conv_desc(128, 64, 64, 32, 32, 3, 1, 1, precision=2)
-    assert K.conv_variant(d32, "wgrad") == "wgrad_x3_kernel<32,false,3,false>" and K.conv_variant(d32, "wgrad_det") == "wgrad_x3_kernel<32,false,3,false>+wgrad_x3_reduce_kernel<32>"
+    assert K.conv_variant(d32, "wgrad") == "wgrad_x3_kernel<32,false,3,false,false,false>" and K.conv_variant(d32, "wgrad_det") == "wgrad_x3_kernel<32,false,3,false,false,false>+wgrad_x3_reduce_kernel<32>"
     assert K.conv_variant(K.conv_desc(128, 128, 128, 16, 16, 3, 1, 1, precision=2), "wgrad").startswith("wgrad_small")           # channels % 32
     with pytest.raises(RuntimeError):
         K.conv_variant(K._with_layout(d, 2), "fwd")                  # split weights need precision 2

@@ -893,7 +893,7 @@ def test_conv3x3_f32x2_two_piece_mode(K, N, H, Ci, Co):
         gw = torch.zeros(Co, 3, 3, Ci, device="cuda")
         need = K.wgrad_det_bytes(d)
         if prec != 1 and need > 0:
-            assert K.conv_variant(d, "wgrad_det").startswith("wgrad_x3_kernel<%d,false,%d,false>" % (64 if (Ci % 64 == 0 and Co % 64 == 0) else 32, K.SPLIT_PIECES[prec]))
+            assert K.conv_variant(d, "wgrad_det").startswith("wgrad_x3_kernel<%d,false,%d,false,false,false>" % (64 if (Ci % 64 == 0 and Co % 64 == 0) else 32, K.SPLIT_PIECES[prec]))
             K.conv_wgrad(x, gy, gw, None, d, det_ws=torch.empty(need // 4, dtype=torch.float32, device="cuda"))
         else:
             K.conv_wgrad(x, gy, gw, None, d)

@@ -121,8 +121,16 @@ def test_wgrad_f16x2_kernel(K, N, H, Ci, Co):
         K.conv_wgrad(x, gy, gw, None, d, det_ws=ws)
         err[prec] = _rel(gw, ref)
         if prec == 4:
-            # (64-channel blocks: the eight-wave producer / consumer form, fifth template argument)
-            assert K.conv_variant(d, "wgrad_det").startswith("wgrad_x3_kernel<64,false,2,true,true>" if (Ci % 64 == 0 and Co % 64 == 0) else "wgrad_x3_kernel<32,false,2,true>")
+            assert K.conv_variant(d, "wgrad_det").startswith("wgrad_x3_kernel<%d,false,2,true,false,false>" % (64 if (Ci % 64 == 0 and Co % 64 == 0) else 32))
+            if Ci % 64 == 0 and Co % 64 == 0:
+                # round 5: the eight-wave producer / consumer form (route bit BH_ROUTE_WX3_PC; net.py asks for it in one-stream steps): same tiles,
+                # same MFMA order, same partial blocks - bitwise the four-wave gradient
+                from bihome_amd._lib import ROUTE_WX3_PC
+                dpc = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=4, route=ROUTE_WX3_PC)
+                assert K.conv_variant(dpc, "wgrad_det").startswith("wgrad_x3_kernel<64,false,2,true,true,false>")
+                gpc = torch.zeros(Co, 3, 3, Ci, device="cuda")
+                K.conv_wgrad(x, gy, gpc, None, dpc, det_ws=ws)
+                assert torch.equal(gpc, gw)
             g1 = torch.ones(Co, 3, 3, Ci, device="cuda")
             K.conv_wgrad(x, gy, g1, None, d, det_ws=ws)
             assert _rel(g1 - 1.0, gw.cpu().double()) < 1e-2 * 1.0 and torch.equal(gw, gw)       # lands on what gw holds (1 + 1e-5-sized entries)
@@ -134,6 +142,43 @@ def test_wgrad_f16x2_kernel(K, N, H, Ci, Co):
             assert _rel(gw3, gw.cpu().double()) < 2e-6
     print("\nf16x2 wgrad N%d H%d %d->%d: rel-L2 vs f64  fp32-mfma %.2e  f32x3 %.2e  f32x2 %.2e  f16x2 %.2e" % (N, H, Ci, Co, err[0], err[2], err[3], err[4]))
     assert err[4] <= 1.5 * err[0] + 1e-8 and err[4] < 0.25 * err[3], err       # (measured 0.75 x)
+
+
+@pytest.mark.parametrize("N,Ci,Co", [(128, 512, 512), (8, 128, 64), (12, 64, 128)])
+def test_wgrad_f16x2_on_4x4_maps(K, N, Ci, Co):
+    """Round 5 (round-4 VERDICT item 9): the fp16-piece weight gradient on 4 x 4 feature maps (layer4 of the ResNet-34 regressor,
+    /root/reference/src/backbones/ResNet34.py:6-50) - four images per 8 x 8 tile, each behind its own zero border - instead of the fp32-input
+    MFMA kernel: against torch float64 next to that kernel's error, workspace form bitwise repeatable, BatchNorm-on-load variant included."""
+    g = torch.Generator().manual_seed(N + Ci)
+    x = torch.randn(N, 4, 4, Ci, generator=g).cuda()
+    gy = (torch.randn(N, 4, 4, Co, generator=g) * 1e-3).cuda()
+    w = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x.double().cpu().permute(0, 3, 1, 2), w, None, 1, 1)
+    ref = torch.autograd.grad(y, w, gy.double().cpu().permute(0, 3, 1, 2))[0].permute(0, 2, 3, 1)
+    err = {}
+    for prec in (0, 4):
+        d = K.conv_desc(N, 4, 4, Ci, Co, 3, 1, 1, precision=prec)
+        need = K.wgrad_det_bytes(d)
+        ws = torch.empty(max(need, 4) // 4, dtype=torch.float32, device="cuda") if need else None
+        gw = torch.zeros(Co, 3, 3, Ci, device="cuda")
+        K.conv_wgrad(x, gy, gw, None, d, det_ws=ws)
+        err[prec] = _rel(gw, ref)
+        if prec == 4:
+            assert K.conv_variant(d, "wgrad_det").startswith("wgrad_x3_kernel<64,false,2,true,false,true>"), K.conv_variant(d, "wgrad_det")
+            from bihome_amd._lib import ROUTE_WX3_PC
+            dpc = K.conv_desc(N, 4, 4, Ci, Co, 3, 1, 1, precision=4, route=ROUTE_WX3_PC)
+            assert K.conv_variant(dpc, "wgrad_det").startswith("wgrad_x3_kernel<64,false,2,true,true,true>")
+            gpc = torch.zeros(Co, 3, 3, Ci, device="cuda")
+            K.conv_wgrad(x, gy, gpc, None, dpc, det_ws=ws)
+            assert torch.equal(gpc, gw)                                                          # the eight-wave form: bitwise the same
+            gw2 = torch.zeros(Co, 3, 3, Ci, device="cuda")
+            K.conv_wgrad(x, gy, gw2, None, d, det_ws=ws)
+            assert torch.equal(gw, gw2)
+            gw3 = torch.zeros(Co, 3, 3, Ci, device="cuda")
+            K.conv_wgrad(x, gy, gw3, None, d)                                                    # atomics form
+            assert _rel(gw3, gw.cpu().double()) < 2e-6
+    print("\nf16x2 wgrad on 4x4 maps N%d %d->%d: rel-L2 vs f64  fp32-mfma %.2e  f16x2 %.2e" % (N, Ci, Co, err[0], err[4]))
+    assert err[4] <= 1.5 * err[0] + 1e-8, err
 
 
 def test_conv3x3_f16x2_error_bound_under_cancellation(K):
