@@ -417,6 +417,12 @@ def main():
     else:
         def one_step():
             return train_step(model, batch(), opt, sched, reducer=reducer, loss_fn=loss_fn)
+    # (BIHOME_MAIN_PRIORITY: experiments - run the steps on a stream of this priority instead of the default stream; -1 = high)
+    _prio = os.environ.get("BIHOME_MAIN_PRIORITY")
+    if _prio:
+        sync()
+        _main = torch.cuda.Stream(priority=int(_prio))
+        torch.cuda.set_stream(_main)
     for _ in range(args.warmup):
         loss, dgt, dh = one_step()
     sync()

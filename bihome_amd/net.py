@@ -544,7 +544,8 @@ def side_stream(device):
     consumer inside the backward chain, so they run under the dgrad / BatchNorm kernels of the main stream."""
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+        # (BIHOME_SIDE_PRIORITY: experiments - the stream's priority; lower number = higher priority, out-of-range values are clamped)
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key, priority=int(os.environ.get("BIHOME_SIDE_PRIORITY", "0")))
     return _SIDE_STREAMS[key]
 
 
