@@ -435,7 +435,10 @@ int bh_wgrad_x3_try(const float* x, const float* gy, float* gw, const bh_conv_de
     a.m_tpi = (unsigned)((1ull << 32) / (unsigned)a.tiles_per_img + 1ull);
     a.cbi = d->Ci / cb;
     const int pairs = a.cbi * (d->Co / cb);
-    int ns = g_wx3_target / pairs;              // one workgroup per CU
+    // one workgroup per CU - or, when the caller says that another stream shares the GPU (BH_ROUTE_WX3_SHARED), 160: in-step sweep of
+    // round 5 (tools/ab_hook.sh "-30,n"): 128-192 all beat 256 by 0.15-0.19 ms per step on configs[1], 160 also on configs[3]
+    const int target = (d->route & BH_ROUTE_WX3_SHARED) && g_wx3_target == 256 ? 160 : g_wx3_target;
+    int ns = target / pairs;
     if (ns > a.ntiles) ns = a.ntiles;
     if (ns >= 8) ns = ns / 8 * 8;               // the workgroups of one split (same tiles, other channel blocks) land on one XCD
     if (ns < 1) ns = 1;

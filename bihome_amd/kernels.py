@@ -5,7 +5,7 @@ import os
 
 import torch
 
-from ._lib import (AMAX_FLOATS, BN_DETERMINISTIC, F_DETERMINISTIC, GEOMETRY_FIELDS, ROUTE_DETERMINISTIC, ROUTE_WX3_PC, BhBnIn, BhBnReduce, BhConvDesc,
+from ._lib import (AMAX_FLOATS, BN_DETERMINISTIC, F_DETERMINISTIC, GEOMETRY_FIELDS, ROUTE_DETERMINISTIC, ROUTE_WX3_PC, ROUTE_WX3_SHARED, BhBnIn, BhBnReduce, BhConvDesc,
                    BhPack3x3Job, check, lib)
 
 

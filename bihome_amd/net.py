@@ -682,10 +682,12 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
                 # the fp16-piece weight gradient's eight-wave form is the faster launch alone, the four-wave form the better neighbour: it
                 # leaves ~200 registers per SIMD lane, so the main stream's BatchNorm kernels run ON the same CUs (same-box A/B, round 5:
                 # two streams 13.30 ms with the four-wave form against 13.49; one stream 14.13 against 14.02)
+                # and with 160 instead of 256 workgroups the side stream leaves CUs to the main stream's next launch (and writes fewer partial
+                # blocks): two streams 12.60 against 12.79 ms (ROUTE_WX3_SHARED)
                 if wgrad_stream is None:
-                    d.route |= K.ROUTE_WX3_PC
+                    d.route = (d.route | K.ROUTE_WX3_PC) & ~K.ROUTE_WX3_SHARED
                 else:
-                    d.route &= ~K.ROUTE_WX3_PC
+                    d.route = (d.route & ~K.ROUTE_WX3_PC) | K.ROUTE_WX3_SHARED
                 if wgrad_stream is None:
                     K.conv_wgrad(x, g, gw, gb, d, det_ws=ws)
                 else:

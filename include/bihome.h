@@ -273,6 +273,9 @@ int bh_absmax(const float* x, long long n, float* record, void* stream);
 #define BH_ROUTE_WX3_PC 1024        /* wgrad, precision 4, 64-channel blocks: the EIGHT-wave producer / consumer form of wgrad_x3_kernel (bitwise the
                                      * four-wave result).  Faster alone (-2 us per launch); the default four-wave form leaves 200 registers per
                                      * SIMD lane to co-resident kernels of a second stream, which is worth more in a two-stream step (round 5) */
+#define BH_ROUTE_WX3_SHARED 2048    /* wgrad, split-operand 3x3 kernels: the launch shares the GPU with another stream - 160 workgroups instead of one
+                                     * per CU (fewer, longer workgroups: the other stream's launches start at once on the free CUs, and the split-K
+                                     * partial blocks shrink with the workgroup count).  Same-box in-step A/B, round 5: -0.19 ms per two-stream step */
 
 /* One 3x3 layer's weights for bh_conv3x3_pack: w[Co][3][3][Ci] (Co, Ci multiples of 32) -> pf (forward operand order) and
  * pd (dgrad operand order: transposed, taps flipped), Co*9*Ci floats each (split: 1.5x that); either may be NULL. */
