@@ -564,8 +564,16 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
         wgrad_stream.wait_stream(main)          # activations, zeroed gradient buffer
     grads = {prog.ops[-1].dst: gout}
     slots = ctx.slots
+    # (the fusion plan below is a pure function of the program, the mode and the shapes: made once and kept on the program - three
+    #  backward walks per step used to rebuild it, ~0.4 ms of a host that has ~9 ms of enqueueing to do per 12 ms step)
+    # (key: everything the plan reads that can differ between two walks of one program - mode, batch / map geometry via the output
+    #  gradient's shape, the joins made by this forward, the precision, the switches)
+    plan_key = (bool(ctx.training), bool(want_wgrad), int(ctx.groups), tuple(gout.shape), len(ctx.joined), len(ctx.descs), getattr(ctx, "precision", 0),
+                os.environ.get("BIHOME_FUSE_BN_REDUCE", "1"), os.environ.get("BIHOME_FUSE_BIAS_GRAD", "1"), os.environ.get("BIHOME_BN_FROM_1X1", "1"))
+    plans = prog.__dict__.setdefault("_bw_plans", {})
+    cached = plans.get(plan_key) if os.environ.get("BIHOME_PLAN_CACHE", "1") != "0" else None
     consumed_by = {}
-    for op in prog.ops:
+    for op in (prog.ops if cached is None else ()):
         consumed_by.setdefault(op.src, 0)
         consumed_by[op.src] += 1
         if op.res is not None:
@@ -581,7 +589,7 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
     # slot in backward order) also accumulates that BatchNorm's backward sums in its epilogue (bh_conv_dgrad_bnreduce),
     # so the BatchNorm adjoint is one apply launch instead of reduce + finalize + apply.
     fuse_bn = {}                                          # conv op index -> bn op index
-    if ctx.training and os.environ.get("BIHOME_FUSE_BN_REDUCE", "1") != "0":
+    if cached is None and ctx.training and os.environ.get("BIHOME_FUSE_BN_REDUCE", "1") != "0":
         producer = {op.dst: j for j, op in enumerate(prog.ops)}
         last_consumer = {}
         for j, op in enumerate(prog.ops):                 # the lowest-index consumer is processed last
@@ -596,7 +604,7 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
     # A 3x3 conv that is the ONLY consumer of a biased (transposed) conv's output: the column sums of its input gradient
     # are that layer's bias gradient - accumulated in the dgrad epilogue instead of a streaming pass over the gradient
     fuse_bias = {}                                        # conv op index -> producer op index
-    if want_wgrad and os.environ.get("BIHOME_FUSE_BIAS_GRAD", "1") != "0":
+    if cached is None and want_wgrad and os.environ.get("BIHOME_FUSE_BIAS_GRAD", "1") != "0":
         producer = {op.dst: j for j, op in enumerate(prog.ops)}
         for j, op in enumerate(prog.ops):
             p = producer.get(op.src)
@@ -632,7 +640,7 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
     # its dgrad is rebuilt inside that BatchNorm's adjoint (bh_bn_bwd_from_1x1) - the full-resolution decoder unit's 268 MB gradient is
     # never written
     from_1x1 = set()
-    if ctx.training and os.environ.get("BIHOME_BN_FROM_1X1", "1") != "0":
+    if cached is None and ctx.training and os.environ.get("BIHOME_BN_FROM_1X1", "1") != "0":
         producer_ = {op.dst: j for j, op in enumerate(prog.ops)}
         for j, op in enumerate(prog.ops):
             b = producer_.get(op.src)
@@ -645,12 +653,16 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
                 from_1x1.add(j)
     red_off, total = {}, 0
     bias_off = {}
-    for j, p in fuse_bias.items():
-        bias_off[p] = total
-        total += K.bn_stats_doubles(1, ctx.descs[j].Ci)
-    for b in fuse_bn.values():
-        red_off[b] = total
-        total += K.bn_stats_doubles(ctx.groups, prog.ops[b].mod.num_features)
+    if cached is None:
+        for j, p in fuse_bias.items():
+            bias_off[p] = total
+            total += K.bn_stats_doubles(1, ctx.descs[j].Ci)
+        for b in fuse_bn.values():
+            red_off[b] = total
+            total += K.bn_stats_doubles(ctx.groups, prog.ops[b].mod.num_features)
+        plans[plan_key] = (consumed_by, fuse_bn, fuse_bias, from_1x1, red_off, bias_off, total)
+    else:
+        consumed_by, fuse_bn, fuse_bias, from_1x1, red_off, bias_off, total = cached
     red_arena = torch.zeros(total, dtype=torch.float64, device=gout.device) if total else None
     bn_reduced = {}
     # precision 4: magnitude records of the BatchNorm input gradients (the gy operand of the fp16-piece dgrad / weight-gradient kernels)
