@@ -108,8 +108,13 @@ def _route_det(d):
     return d
 
 
+_raw_stream, _cur_device = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # (the raw handle of torch's current stream: two C calls - torch.cuda.current_stream() builds a Stream object through four Python
+    #  frames, ~140 times per training step)
+    return ctypes.c_void_p(_raw_stream(_cur_device()))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -177,7 +177,8 @@ def build_loss(solver):
 
 
 def train_step(model, data, opt, sched, clip=-1.0, reducer=None, loss_fn="biHomE"):
-    model.train()                                                   # train.py:296
+    if not model.training:                                          # train.py:296 (once per epoch upstream: a 420-module walk per step
+        model.train()                                               #  is 0.5 ms of host time, so only after an eval() phase)
     opt.zero_grad()                                                 # train.py:305
     if isinstance(loss_fn, torch.nn.Module):                        # train.py:318-322 (ground truth first, as upstream)
         ground_truth, network_output, delta_gt, delta_hat = model(data)

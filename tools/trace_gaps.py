@@ -45,3 +45,13 @@ print("gap histogram:", dict(hist))
 print("idle in front of (top 25):")
 for name, (t, n) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:25]:
     print("  %8.3f ms  %5d x  %6.2f us  %s" % (t / 1e6, n, t / n / 1e3, name))
+# launches per step that are not this library's kernels (torch-native elementwise / fills / cats, runtime blit copies)
+nst = max(hi - lo, 1) if len(marks) > hi else 1
+other = defaultdict(lambda: [0, 0])
+for s, e, name in rows:
+    if "at::" in name or "rocclr" in name:
+        k = name.split("<")[0] + ("<" + name.split("<")[-1][:60] if "<" in name else "")
+        other[k[:110]][0] += 1; other[k[:110]][1] += e - s
+print("torch / runtime launches per step (count, us per step):")
+for k, (n, t) in sorted(other.items(), key=lambda kv: -kv[1][1])[:30]:
+    print("  %6.1f x  %7.1f us  %s" % (n / nst, t / 1e3 / nst, k))
