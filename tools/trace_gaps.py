@@ -55,3 +55,22 @@ for s, e, name in rows:
 print("torch / runtime launches per step (count, us per step):")
 for k, (n, t) in sorted(other.items(), key=lambda kv: -kv[1][1])[:30]:
     print("  %6.1f x  %7.1f us  %s" % (n / nst, t / 1e3 / nst, k))
+# per HIP stream: busy time and launch count per step (which stream is the critical path, and how full it is)
+try:
+    per = defaultdict(lambda: [0, 0, None, 0])
+    with open(sys.argv[1]) as f:
+        for r in csv.DictReader(f):
+            s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            if s < rows[0][0] or e > rows[-1][1] + 1:
+                continue
+            q = r.get("Stream_Id") or r.get("Queue_Id")
+            p = per[q]
+            p[0] += e - s; p[1] += 1
+            if p[2] is not None and s > p[2]:
+                p[3] += s - p[2]
+            p[2] = e if p[2] is None else max(p[2], e)
+    print("per stream (busy ms / step, launches / step, gaps between consecutive launches of the stream ms / step):")
+    for q, (b, n, _, g) in sorted(per.items(), key=lambda kv: -kv[1][0]):
+        print("  stream %s: %.3f ms  %.1f launches  gaps %.3f ms" % (q, b / 1e6 / nst, n / nst, g / 1e6 / nst))
+except Exception as ex:
+    print("per-stream split unavailable:", ex)
