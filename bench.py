@@ -74,6 +74,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the exact-arithmetic (f32x3) timing leg that rides along with the f32 headline")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--autograd-single-thread", action="store_true",
+                    help="experiments: run autograd's backward on the calling thread (torch.autograd.set_multithreading_enabled(False)) - "
+                         "with --host-profile cProfile then sees the backward functions")
     ap.add_argument("--overlap", action="store_true", help="(default since round 4; kept for old command lines)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="one HIP stream: no weight-gradient side stream, no extractor prefetch under the backbone (the roofline leg "
@@ -370,6 +373,8 @@ def main():
         for h in args.hook:
             a_, b_ = (int(v) for v in h.split(","))
             lib.bh_debug_force_tile(a_, b_)
+    if args.autograd_single_thread:
+        torch.autograd.set_multithreading_enabled(False)
     cfg = configs.get(args.config)
     cfg["MODEL"]["BACKBONE"]["PRECISION"] = args.precision
     cfg["MODEL"]["HEAD"]["PRECISION"] = args.precision

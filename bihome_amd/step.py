@@ -188,7 +188,10 @@ def train_step(model, data, opt, sched, clip=-1.0, reducer=None, loss_fn="biHomE
         loss = torch.sum(1 - torch.cosine_similarity(ground_truth, network_output, dim=1))
     else:
         loss, delta_gt, delta_hat = model(data)                     # train.py:357
-    loss.backward()                                                 # train.py:379
+    # train.py:379.  On the calling thread: torch hands a CUDA graph's backward to a device thread, and the hand-over plus the two threads'
+    # turns at the interpreter lock cost 1.4 ms of host time per step (bench.py --host-profile) - a fifth of what a 7 ms step leaves the host
+    with torch.autograd.set_multithreading_enabled(os.environ.get("BIHOME_AUTOGRAD_THREAD", "0") == "1"):
+        loss.backward()
     if reducer is not None:
         reducer.allreduce()                                         # RCCL SUM over ranks
     if clip > 0:
