@@ -69,6 +69,22 @@ try:
             if p[2] is not None and s > p[2]:
                 p[3] += s - p[2]
             p[2] = e if p[2] is None else max(p[2], e)
+    # the busiest stream's own gaps: which launch did it wait in front of (host behind, or a wait on the other stream)?
+    main_q = max(per.items(), key=lambda kv: kv[1][0])[0]
+    mg, prev = defaultdict(lambda: [0, 0]), None
+    with open(sys.argv[1]) as f:
+        rr = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(f)
+                    if (r.get("Stream_Id") or r.get("Queue_Id")) == main_q)
+    for s_, e_, n_ in rr:
+        if s_ < rows[0][0] or e_ > rows[-1][1] + 1:
+            continue
+        if prev is not None and s_ > prev:
+            k = n_.replace("(anonymous namespace)::", "").split("(")[0][-70:]
+            mg[k][0] += s_ - prev; mg[k][1] += 1
+        prev = e_ if prev is None else max(prev, e_)
+    print("stream %s waited in front of (top 12, ms / step):" % main_q)
+    for k, (t, n) in sorted(mg.items(), key=lambda kv: -kv[1][0])[:12]:
+        print("  %7.3f ms  %5.1f x  %6.2f us  %s" % (t / 1e6 / nst, n / nst, t / n / 1e3, k))
     print("per stream (busy ms / step, launches / step, gaps between consecutive launches of the stream ms / step):")
     for q, (b, n, _, g) in sorted(per.items(), key=lambda kv: -kv[1][0]):
         print("  stream %s: %.3f ms  %.1f launches  gaps %.3f ms" % (q, b / 1e6 / nst, n / nst, g / 1e6 / nst))
