@@ -671,11 +671,16 @@ __global__ void __launch_bounds__(256) bn_join_bwd_apply_kernel(const float* __r
             const int rr = rbase + u * stride;
             const size_t off = gbase + (size_t)rr * g.C;
             const bool ok = rr < g.rows;
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            dv[u] = ok ? *reinterpret_cast<const float4*>(gy + off) : z;
-            yv[u] = (ok && relu && !remask) ? *reinterpret_cast<const float4*>(y + off) : make_float4(1.f, 1.f, 1.f, 1.f);
-            av[u] = ok ? *reinterpret_cast<const float4*>(xa + off) : z;
-            bv[u] = ok ? *reinterpret_cast<const float4*>(xb + off) : z;
+            // (loads under an `if`, not `ok ? *p : z` with a NAMED zero: the compiler made that a select between the global address and
+            //  the address of z in scratch memory, i.e. flat loads and a scratch store per operand - 32 bytes of private segment)
+            dv[u] = make_float4(0.f, 0.f, 0.f, 0.f); av[u] = dv[u]; bv[u] = dv[u];
+            yv[u] = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (ok) {
+                dv[u] = *reinterpret_cast<const float4*>(gy + off);
+                if (relu && !remask) yv[u] = *reinterpret_cast<const float4*>(y + off);
+                av[u] = *reinterpret_cast<const float4*>(xa + off);
+                bv[u] = *reinterpret_cast<const float4*>(xb + off);
+            }
         }
     };
     issue(r);
@@ -694,15 +699,16 @@ __global__ void __launch_bounds__(256) bn_join_bwd_apply_kernel(const float* __r
             const int rr = r + u * stride;
             if (rr >= g.rows) break;
             const size_t off = gbase + (size_t)rr * g.C;
-            float d[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
-            float yy[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
+            const float d0[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
+            const float y0[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
             const float a[4] = {av[u].x, av[u].y, av[u].z, av[u].w}, b[4] = {bv[u].x, bv[u].y, bv[u].z, bv[u].w};
             float oa[4], ob[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (remask) yy[i] = __builtin_fmaf(a[i], sca[i], __builtin_fmaf(b[i], scb[i], shm[i]));
-                if (relu && !(yy[i] > 0.f)) d[i] = 0.f;
-                const float e = d[i] - cf[i].x;
+                // (scalars, not arrays written under a condition: those ended up in scratch memory - 32 bytes of private segment)
+                const float yi = remask ? __builtin_fmaf(a[i], sca[i], __builtin_fmaf(b[i], scb[i], shm[i])) : y0[i];
+                const float di = (relu && !(yi > 0.f)) ? 0.f : d0[i];
+                const float e = di - cf[i].x;
                 oa[i] = sca[i] * (e - (a[i] - ma[i]) * ia[i] * cf[i].y);
                 ob[i] = scb[i] * (e - (b[i] - mb[i]) * ib[i] * cf[i].z);
                 vmax_a = fmaxf(vmax_a, fabsf(oa[i])); vmax_b = fmaxf(vmax_b, fabsf(ob[i]));

@@ -59,10 +59,6 @@ struct GemmArgs {
     const float* bni;
     int bni_relu, bni_rpg;
     unsigned* amax_out;      // optional magnitude record of the output (common.h F16X2): max |value stored|, one atomic max per workgroup
-    // round 5: up to four launches that differ only in their weights and tap grid as ONE launch, blockIdx.z = class (the parity classes of a
-    // stride-2 dgrad: four ~10 us launches of 256 workgroups each fill the chip once instead of four times a quarter)
-    int nclass;              // 0: a plain launch
-    struct Cls { long long bw_off, sBn; int T, kw, etap0; unsigned bw_bytes; } cls[4];
 };
 
 
@@ -87,10 +83,6 @@ __device__ __forceinline__ bool src_coord(const GemmArgs& a, int oy, int ox, int
 // does not also carry the pointer-based loader's prologue (VALU work is paid at MFMA price on this chip)
 template <int BM, int BN, int BK, bool VEC, bool BF16 = false, bool BUF = false>
 __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
-    if (a.nclass) {
-        const GemmArgs::Cls c = a.cls[blockIdx.z];
-        a.Bw += c.bw_off; a.sBn = c.sBn; a.T = c.T; a.kw = c.kw; a.etap0 = c.etap0; a.bw_bytes = c.bw_bytes;
-    }
     constexpr int WN = (BN >= 64) ? 2 : 1;         // waves along N
     constexpr int WM = 4 / WN;                     // waves along M
     static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "tile/wave mismatch");
@@ -746,7 +738,7 @@ static int launch(const GemmArgs& a, hipStream_t s) {
     if (bh_query("conv_gemm_kernel<%d,%d,%d,%s,%s,%s>", BM, BN, BK, VEC ? "true" : "false", BF16 ? "true" : "false",
                  (VEC && a.use_buf) ? "true" : "false"))
         return BH_OK;
-    dim3 grid((a.M + BM - 1) / BM, (a.Nn + BN - 1) / BN, a.nclass > 0 ? a.nclass : 1);
+    dim3 grid((a.M + BM - 1) / BM, (a.Nn + BN - 1) / BN);
     if constexpr (VEC) {
         if (a.use_buf) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, VEC, BF16, true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, VEC, BF16, false>), grid, dim3(256), 0, s, a);
@@ -765,7 +757,6 @@ static int g_force_bm = 0, g_force_bn = 0, g_prio = 0, g_no_buf = 0;     // tuni
 #else
 static constexpr int g_force_bm = 0, g_force_bn = 0, g_prio = 0, g_no_buf = 0;
 #endif
-BH_KNOB(g_s2_multi, 1);      // stride-2 3x3 dgrad: the four parity classes in one launch (tuning: bh_debug_force_tile(-37, 0|1))
 
 static int dispatch(const GemmArgs& a_in, hipStream_t s) {
     GemmArgs a = a_in;
@@ -1018,7 +1009,6 @@ int bh_debug_force_tile(int bm, int bn) {
     if (bm == -31) { bh_wgrad_x3_tune(1, bn); return BH_OK; }            // (-31, 1): ablation - that kernel without its atomic flush
     if (bm == -33) { bh_pointwise_tune(0, bn); return BH_OK; }           // (-33, 0 / 1): the pointwise streaming kernel off / on
     if (bm == -34) { bh_pointwise_tune(1, bn); return BH_OK; }           // (-34, n): its workgroups per launch
-    if (bm == -37) { g_s2_multi = bn; return BH_OK; }                    // (-37, 0 / 1): stride-2 3x3 dgrad classes as four launches / one
     if (bm == -36) { bh_wgrad_x3_tune(3, bn); return BH_OK; }            // (-36, 0 / 1): the 4 x 4-map form of the fp16-piece weight gradient off / on
     if (bm == -32) { bh_wgrad_x3_tune(2, bn); return BH_OK; }            // (-32, 0 / 1): the fp16-piece kernel's four-wave / eight-wave (producer + consumer) form
     if (bm == -20) { bh_bn_tune(bn); return BH_OK; }                     // (-20, n): workgroups per BatchNorm apply launch
@@ -1206,8 +1196,6 @@ int bh_conv_dgrad_s2(const float* gy, const float* w, float* gx, const bh_conv_d
         if (e != hipSuccess) return (int)e;
     }
     long long base = 0;
-    GemmArgs multi = {};
-    int nmulti = 0;
     for (int c = 0; c < 4; ++c) {
         const int py = c >> 1, px = c & 1;
         const int ky0 = (py + pad) % 2, kx0 = (px + pad) % 2;
@@ -1229,23 +1217,10 @@ int bh_conv_dgrad_s2(const float* gy, const float* w, float* gx, const bh_conv_d
             // B[t][k = co][n = ci] = Wc[ci][t][co]
             a.sBt = d->Co; a.sBc = 1; a.sBn = (long long)a.T * d->Co; a.b_kcontig = 1;
             a.epi = 1; a.ek = 2; a.eC = d->Ci; a.etap0 = py * 2 + px;
-            if (k3 && g_s2_multi) {
-                // the four classes as one launch: class 0's description (the one with the most taps decides nothing - tile choice and
-                // loader depend on M, Nn, Kc only) + what differs per class
-                if (nmulti == 0) { multi = a; multi.Bw = wpack; multi.bw_elems = (long long)d->Co * k * k * d->Ci; }
-                GemmArgs::Cls& q = multi.cls[nmulti++];
-                q.bw_off = base; q.sBn = a.sBn; q.T = a.T; q.kw = a.kw; q.etap0 = a.etap0; q.bw_bytes = (unsigned)(a.bw_elems * 4);
-                if (a.T > multi.T) multi.T = a.T;        // (host-side checks of dispatch see the largest tap count)
-            } else {
-                rc = dispatch(a, s);
-                if (rc) return rc;
-            }
+            rc = dispatch(a, s);
+            if (rc) return rc;
         }
         base += (long long)d->Ci * nty * ntx * d->Co;
-    }
-    if (nmulti) {
-        multi.nclass = nmulti;
-        return dispatch(multi, s);
     }
     return BH_OK;
 }
