@@ -288,6 +288,17 @@ def _momentum(bn):
     return bn.momentum
 
 
+def _zero_arenas(n_doubles, n_floats, device):
+    """The two zeroed scratch arenas of a pass - float64 sums and float32 magnitude records - out of ONE zero-filled byte buffer (one fill
+    launch instead of two, five times per training step).  Either may be empty (None)."""
+    if not (n_doubles or n_floats):
+        return None, None
+    buf = torch.zeros(n_doubles * 8 + n_floats * 4, dtype=torch.uint8, device=device)
+    a = buf[:n_doubles * 8].view(torch.float64) if n_doubles else None
+    b = buf[n_doubles * 8:].view(torch.float32) if n_floats else None
+    return a, b
+
+
 def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, packer=None):
     """packer: kernels.WeightPacker holding fragment-ordered copies of the 3x3 weights (refreshed here, one launch, when
     a parameter changed): the halo-tiled 3x3 kernel then streams its B operand straight into registers.
@@ -308,11 +319,9 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, p
         ctx.groups, ctx.training, ctx.precision = groups, training, int(precision)
     # precision 4: one zeroed arena of magnitude records, one per BatchNorm output (the operands of the fp16-piece 3x3 kernels)
     amax_next = None
+    nrec = 0
     if int(precision) == K.F16X2:
-        nrec = sum(1 for op in prog.ops if op.kind == "bn" or (op.kind == "conv" and isinstance(op.mod, nn.ConvTranspose2d)))
-        amax_arena = torch.zeros(max(nrec, 1) * K.AMAX_FLOATS, dtype=torch.float32, device=x.device)
-        amax_iter = iter(amax_arena.split(K.AMAX_FLOATS))
-        amax_next = lambda: next(amax_iter)
+        nrec = max(1, sum(1 for op in prog.ops if op.kind == "bn" or (op.kind == "conv" and isinstance(op.mod, nn.ConvTranspose2d))))
     # BatchNorm sums: one zeroed float64 arena for the whole pass (the kernels accumulate with atomics); a conv whose
     # only consumer is a training-mode BatchNorm accumulates that layer's statistics in its own epilogue
     bn_off, total = {}, 0
@@ -320,7 +329,10 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, p
         if op.kind == "bn":
             bn_off[i] = total
             total += K.bn_stats_doubles(groups, op.mod.num_features)
-    arena = torch.zeros(total, dtype=torch.float64, device=x.device) if total else None
+    arena, amax_arena = _zero_arenas(total, nrec * K.AMAX_FLOATS, x.device)          # (one fill launch for both)
+    if nrec:
+        amax_iter = iter(amax_arena.split(K.AMAX_FLOATS))
+        amax_next = lambda: next(amax_iter)
     fused_stats = {}                                      # conv op index -> bn op index
     if training:
         users = {}
@@ -663,13 +675,12 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
         plans[plan_key] = (consumed_by, fuse_bn, fuse_bias, from_1x1, red_off, bias_off, total)
     else:
         consumed_by, fuse_bn, fuse_bias, from_1x1, red_off, bias_off, total = cached
-    red_arena = torch.zeros(total, dtype=torch.float64, device=gout.device) if total else None
     bn_reduced = {}
     # precision 4: magnitude records of the BatchNorm input gradients (the gy operand of the fp16-piece dgrad / weight-gradient kernels)
     amax_next = None
-    if getattr(ctx, "precision", 0) == K.F16X2:
-        nrec = sum(1 for op in prog.ops if op.kind == "bn")
-        amax_arena = torch.zeros(max(nrec, 1) * K.AMAX_FLOATS, dtype=torch.float32, device=gout.device)
+    nrec = max(1, sum(1 for op in prog.ops if op.kind == "bn")) if getattr(ctx, "precision", 0) == K.F16X2 else 0
+    red_arena, amax_arena = _zero_arenas(total, nrec * K.AMAX_FLOATS, gout.device)    # (one fill launch for both)
+    if nrec:
         amax_iter = iter(amax_arena.split(K.AMAX_FLOATS))
         amax_next = lambda: next(amax_iter)
 
