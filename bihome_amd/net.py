@@ -333,67 +333,82 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, p
     if nrec:
         amax_iter = iter(amax_arena.split(K.AMAX_FLOATS))
         amax_next = lambda: next(amax_iter)
-    fused_stats = {}                                      # conv op index -> bn op index
-    if training:
-        users = {}
-        for op in prog.ops:
-            users[op.src] = users.get(op.src, 0) + 1
-            if op.res is not None:
-                users[op.res] = users.get(op.res, 0) + 1
-        producer = {op.dst: j for j, op in enumerate(prog.ops)}
-        for i, op in enumerate(prog.ops):
-            j = producer.get(op.src)
-            if (op.kind == "bn" and j is not None and prog.ops[j].kind == "conv" and users.get(op.src, 0) == 1
-                    and not prog.ops[j].extra["out_nchw"] and prog.ops[j].mod.weight.dim() == 4):
-                fused_stats[j] = i
-    # BatchNorm-on-load: a training-mode BatchNorm(+ReLU) without residual whose ONLY consumer is a 3x3 conv that runs the packed
-    # f32x3 forward and the f32x3 weight gradient is not applied at all - the consumer transforms the BatchNorm's INPUT while
-    # staging it (kernels.BnOnLoad): one launch and two tensor passes per such layer gone (the inner BatchNorm of every
-    # residual unit).  Needs the sums from the producer's epilogue (fused_stats) and a table of <= 4 KB.
-    bn_on_load = set()
-    bn_on_load_1x1 = set()
-    if training and os.environ.get("BIHOME_BN_ON_LOAD_1X1", "1") != "0" and groups <= 2 and int(precision) != 1:      # (not the bf16-operand mode)
-        # round 4: the same for a 1x1 / stride-1 conv consumer with <= 32 channels on one side (the 1x1 conv of the decoder units behind
-        # BatchNorm + ReLU at 64 x 64 and 128 x 128): generic forward kernel and small-channel weight-gradient kernel transform on load
-        consumer_ = {}
-        for j, op in enumerate(prog.ops):
-            consumer_.setdefault(op.src, j)
-        fused_bn_ = set(fused_stats.values())
-        for i, op in enumerate(prog.ops):
-            j = consumer_.get(op.dst)
-            if (op.kind == "bn" and op.res is None and i in fused_bn_ and users.get(op.dst, 0) == 1 and j is not None
-                    and prog.ops[j].kind == "conv" and prog.ops[j].src == op.dst and prog.ops[j].extra["weight_fn"] is None
-                    and not prog.ops[j].extra["in_nchw"] and not prog.ops[j].extra["out_nchw"] and isinstance(prog.ops[j].mod, nn.Conv2d)
-                    and prog.ops[j].mod.kernel_size == (1, 1) and prog.ops[j].mod.stride == (1, 1) and prog.ops[j].mod.padding == (0, 0)
-                    and prog.ops[j].mod.in_channels % 32 == 0 and prog.ops[j].mod.out_channels % 4 == 0
-                    and min(prog.ops[j].mod.in_channels, prog.ops[j].mod.out_channels) <= 32 and prog.ops[j].mod.weight.requires_grad):
-                bn_on_load_1x1.add(i)
-    if training and packer is not None and int(precision) in K.SPLIT_PIECES and os.environ.get("BIHOME_BN_ON_LOAD", "1") != "0":
-        consumer = {}
-        for j, op in enumerate(prog.ops):
-            consumer.setdefault(op.src, j)
-        fused_bn = set(fused_stats.values())
-        for i, op in enumerate(prog.ops):
-            j = consumer.get(op.dst)
-            if (op.kind == "bn" and op.res is None and i in fused_bn and users.get(op.dst, 0) == 1 and j is not None
-                    and prog.ops[j].kind == "conv" and prog.ops[j].src == op.dst and prog.ops[j].extra["weight_fn"] is None
-                    and not prog.ops[j].extra["in_nchw"] and id(prog.ops[j].mod.weight) in packer.entries
-                    and groups * op.mod.num_features * 8 <= 4096):
-                bn_on_load.add(i)
-    # Two-branch join (round 4): a training-mode BatchNorm whose residual input is itself the output of a training-mode BatchNorm that
-    # nobody else reads (the lower branch of ResNet50DeconvBlock / the strided ResNet34ConvBlock): the lower BatchNorm is not applied
-    # on its own - both are applied, added and rectified in ONE pass (kernels.bn_join_fwd), the adjoint is one reduce + one apply
-    joins = {}                                            # join bn op index -> lower bn op index
-    if training and os.environ.get("BIHOME_BN_JOIN", "1") != "0":
-        producer_ = {op.dst: j for j, op in enumerate(prog.ops)}
-        for i, op in enumerate(prog.ops):
-            j = producer_.get(op.res) if (op.kind == "bn" and op.res is not None) else None
-            if (j is not None and prog.ops[j].kind == "bn" and prog.ops[j].res is None and not prog.ops[j].relu
-                    and users.get(op.res, 0) == 1 and j not in bn_on_load and i not in bn_on_load
-                    and op.mod.num_features == prog.ops[j].mod.num_features and op.mod.num_features % 4 == 0
-                    and op.mod.weight is not None and prog.ops[j].mod.weight is not None):
-                joins[i] = j
-    join_lower = set(joins.values())
+    # the fusion plan below (which conv feeds which BatchNorm's sums, which BatchNorms are applied on load or joined) depends on the program, the
+    # mode and the weight packer only: computed once per (mode, groups, arithmetic, packer) and kept on the program, as run_backward's
+    fw_key = (bool(training), int(groups), int(precision), id(packer) if packer is not None else 0,
+              len(packer.entries) if packer is not None else 0, bool(packer.f16) if packer is not None else False,
+              os.environ.get("BIHOME_BN_ON_LOAD_1X1", "1"), os.environ.get("BIHOME_BN_ON_LOAD", "1"), os.environ.get("BIHOME_BN_JOIN", "1"),
+              tuple(op.mod.weight.requires_grad for op in prog.ops if op.kind == "conv"))
+    fw_plans = prog.__dict__.setdefault("_fw_plans", {})
+    fw_cached = fw_plans.get(fw_key) if os.environ.get("BIHOME_PLAN_CACHE", "1") != "0" else None
+    consumer = None
+    if fw_cached is None:
+        fused_stats = {}                                      # conv op index -> bn op index
+        if training:
+            users = {}
+            for op in prog.ops:
+                users[op.src] = users.get(op.src, 0) + 1
+                if op.res is not None:
+                    users[op.res] = users.get(op.res, 0) + 1
+            producer = {op.dst: j for j, op in enumerate(prog.ops)}
+            for i, op in enumerate(prog.ops):
+                j = producer.get(op.src)
+                if (op.kind == "bn" and j is not None and prog.ops[j].kind == "conv" and users.get(op.src, 0) == 1
+                        and not prog.ops[j].extra["out_nchw"] and prog.ops[j].mod.weight.dim() == 4):
+                    fused_stats[j] = i
+        # BatchNorm-on-load: a training-mode BatchNorm(+ReLU) without residual whose ONLY consumer is a 3x3 conv that runs the packed
+        # f32x3 forward and the f32x3 weight gradient is not applied at all - the consumer transforms the BatchNorm's INPUT while
+        # staging it (kernels.BnOnLoad): one launch and two tensor passes per such layer gone (the inner BatchNorm of every
+        # residual unit).  Needs the sums from the producer's epilogue (fused_stats) and a table of <= 4 KB.
+        bn_on_load = set()
+        bn_on_load_1x1 = set()
+        if training and os.environ.get("BIHOME_BN_ON_LOAD_1X1", "1") != "0" and groups <= 2 and int(precision) != 1:      # (not the bf16-operand mode)
+            # round 4: the same for a 1x1 / stride-1 conv consumer with <= 32 channels on one side (the 1x1 conv of the decoder units behind
+            # BatchNorm + ReLU at 64 x 64 and 128 x 128): generic forward kernel and small-channel weight-gradient kernel transform on load
+            consumer_ = {}
+            for j, op in enumerate(prog.ops):
+                consumer_.setdefault(op.src, j)
+            fused_bn_ = set(fused_stats.values())
+            for i, op in enumerate(prog.ops):
+                j = consumer_.get(op.dst)
+                if (op.kind == "bn" and op.res is None and i in fused_bn_ and users.get(op.dst, 0) == 1 and j is not None
+                        and prog.ops[j].kind == "conv" and prog.ops[j].src == op.dst and prog.ops[j].extra["weight_fn"] is None
+                        and not prog.ops[j].extra["in_nchw"] and not prog.ops[j].extra["out_nchw"] and isinstance(prog.ops[j].mod, nn.Conv2d)
+                        and prog.ops[j].mod.kernel_size == (1, 1) and prog.ops[j].mod.stride == (1, 1) and prog.ops[j].mod.padding == (0, 0)
+                        and prog.ops[j].mod.in_channels % 32 == 0 and prog.ops[j].mod.out_channels % 4 == 0
+                        and min(prog.ops[j].mod.in_channels, prog.ops[j].mod.out_channels) <= 32 and prog.ops[j].mod.weight.requires_grad):
+                    bn_on_load_1x1.add(i)
+        if training and packer is not None and int(precision) in K.SPLIT_PIECES and os.environ.get("BIHOME_BN_ON_LOAD", "1") != "0":
+            consumer = {}
+            for j, op in enumerate(prog.ops):
+                consumer.setdefault(op.src, j)
+            fused_bn = set(fused_stats.values())
+            for i, op in enumerate(prog.ops):
+                j = consumer.get(op.dst)
+                if (op.kind == "bn" and op.res is None and i in fused_bn and users.get(op.dst, 0) == 1 and j is not None
+                        and prog.ops[j].kind == "conv" and prog.ops[j].src == op.dst and prog.ops[j].extra["weight_fn"] is None
+                        and not prog.ops[j].extra["in_nchw"] and id(prog.ops[j].mod.weight) in packer.entries
+                        and groups * op.mod.num_features * 8 <= 4096):
+                    bn_on_load.add(i)
+        # Two-branch join (round 4): a training-mode BatchNorm whose residual input is itself the output of a training-mode BatchNorm that
+        # nobody else reads (the lower branch of ResNet50DeconvBlock / the strided ResNet34ConvBlock): the lower BatchNorm is not applied
+        # on its own - both are applied, added and rectified in ONE pass (kernels.bn_join_fwd), the adjoint is one reduce + one apply
+        joins = {}                                            # join bn op index -> lower bn op index
+        if training and os.environ.get("BIHOME_BN_JOIN", "1") != "0":
+            producer_ = {op.dst: j for j, op in enumerate(prog.ops)}
+            for i, op in enumerate(prog.ops):
+                j = producer_.get(op.res) if (op.kind == "bn" and op.res is not None) else None
+                if (j is not None and prog.ops[j].kind == "bn" and prog.ops[j].res is None and not prog.ops[j].relu
+                        and users.get(op.res, 0) == 1 and j not in bn_on_load and i not in bn_on_load
+                        and op.mod.num_features == prog.ops[j].mod.num_features and op.mod.num_features % 4 == 0
+                        and op.mod.weight is not None and prog.ops[j].mod.weight is not None):
+                    joins[i] = j
+        join_lower = set(joins.values())
+        if len(fw_plans) > 16:
+            fw_plans.clear()
+        fw_plans[fw_key] = (fused_stats, bn_on_load, bn_on_load_1x1, joins, join_lower, consumer)
+    else:
+        fused_stats, bn_on_load, bn_on_load_1x1, joins, join_lower, consumer = fw_cached
     folded = {}                                           # bn op index -> conv op index (conv deferred to the bn's position)
     if fold_cache is not None and not training and not save:
         users = {}
