@@ -791,7 +791,7 @@ __global__ void __launch_bounds__(256, X3 ? ((BN == 32 && NP == 2 && !BNI) ? C3_
 }
 
 constexpr int C3_MIN_BLOCKS = 256;      // below this many workgroups the generic kernel's finer tiles fill the chip better
-BH_KNOB(g_c3_noload, 0); BH_KNOB(g_c3_dbg_nch, -1); BH_KNOB(g_c3_subt, 2); BH_KNOB(g_c3_tpb, 2); BH_KNOB(g_c3_stamp, 0); BH_KNOB(g_c3_desync, 0); BH_KNOB(g_c3_walk32, 1); BH_KNOB(g_c3_pc, 1);
+BH_KNOB(g_c3_noload, 0); BH_KNOB(g_c3_dbg_nch, -1); BH_KNOB(g_c3_subt, 2); BH_KNOB(g_c3_tpb, 2); BH_KNOB(g_c3_stamp, 0); BH_KNOB(g_c3_desync, 0); BH_KNOB(g_c3_walk32, 1); BH_KNOB(g_c3_pc, 1); BH_KNOB(g_c3_wt64, 512); BH_KNOB(g_c3_wt32, 512);
 #ifdef BH_TUNING
 // copies the phase time stamps of the last instrumented launch to the host (n entries of 8 x u64)
 extern "C" int bh_debug_read_c3_stamps(unsigned long long* out, int n) {
@@ -803,6 +803,8 @@ void bh_conv3x3_tune(int disable, int min_blocks) {
     if (disable >= 500 && disable < 1000) { g_c3_stamp = disable - 500; return; }     // (-40, n): phase time stamps off (0) / on (halo kernel: any n > 0; persistent kernel: workgroup n - 1)
     if (disable >= 200 && disable < 264) { g_c3_desync = disable - 200; return; }
     if (disable == 300 || disable == 301) { g_c3_walk32 = disable - 300; return; }         // (-43, 0|1): several positions per workgroup in the 32-channel launches without statistics off / on
+    if (disable >= 2000 && disable < 6000) { g_c3_wt64 = disable - 2000; return; }        // (-45, n): workgroups per statistics launch, 64-channel tile
+    if (disable >= 6000 && disable < 10000) { g_c3_wt32 = disable - 6000; return; }       // (-46, n): the same, 32-channel tile (default 512)
     if (disable == 310 || disable == 311) { g_c3_pc = disable - 310; return; }            // (-44, 0|1): persistent producer / consumer kernel off / on
     if (disable <= -100) { g_c3_dbg_nch = -100 - disable - 1; return; }            // -100 -> -1 (all), -101 -> 0 chunks, -102 -> 1 ...
     if (disable >= 400 && disable < 464) { g_c3_noload = disable - 400; return; }      // (-18, bits): ablation bits (halo kernel 1 2 4; producer / consumer kernel 1 .. 16)
@@ -880,9 +882,11 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
         // statistics epilogues: every workgroup ends with one f64 atomic per (channel, moment) and the memory-side atomic unit takes
         // ~30 ns per same-address atomic - keep the workgroups per statistics group at <= 1024 by walking several tile positions per
         // workgroup (all inside one group) and adding their column sums in registers
+        // (round 5, in the two-stream step: 512 workgroups for the 32-channel tile as well - 12.64 against 12.71 ms in four alternating runs,
+        //  256 costs 0.16 ms; alone 1024 was the optimum.  64-channel tile: 256 / 512 / 1024 within 0.02 ms.  tools/ab_hook.sh "-46,n" / "-45,n")
         const int ppg = a.subtiles / (subt * groups);            // tile positions per statistics group
         int t = a.tpb;
-        const long long wtarget = (x3 && bn_tile == 64) ? 512 : (x3 ? 1024 : 2048);    // workgroups of the launch (all groups, all N tiles)
+        const long long wtarget = (x3 && bn_tile == 64) ? g_c3_wt64 : (x3 ? g_c3_wt32 : 2048);    // workgroups of the launch (all groups, all N tiles)
         while (ppg % (t * 2) == 0 && (ppg / t > 1024 || (long long)(ppg / t) * groups * grid.y > wtarget) && t < 64) t *= 2;
         if (ppg % t == 0 && (t > 1 || a.tpb == 1)) {
             if (t != a.tpb) { a.tpb = t; grid.x = (a.gx_total + t - 1) / t; }

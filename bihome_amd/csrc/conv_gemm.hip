@@ -1002,6 +1002,8 @@ int bh_debug_force_tile(int bm, int bn) {
     if (bm == -17) { g_wgrad_s1_target = bn; return BH_OK; }             // (-17, n): its split-K work items per launch
     if (bm == -40) { bh_conv3x3_tune(500 + (bn > 0 ? (bn < 400 ? bn : 400) : 0), 0); return BH_OK; }   // (-40, 0|1): 3x3 kernel phase time stamps (bh_debug_read_c3_stamps)
     if (bm == -43) { bh_conv3x3_tune(300 + (bn ? 1 : 0), 0); return BH_OK; }   // (-43, 0|1): 32-channel 3x3 launches without statistics walk several positions per workgroup off / on
+    if (bm == -45) { bh_conv3x3_tune(2000 + (bn < 4000 ? bn : 3999), 0); return BH_OK; }   // (-45, n): halo kernel, workgroups per statistics / BatchNorm-sums launch (64-channel tile; default 512)
+    if (bm == -46) { bh_conv3x3_tune(6000 + (bn < 4000 ? bn : 3999), 0); return BH_OK; }   // (-46, n): the same for the 32-channel tile (default 512)
     if (bm == -44) { bh_conv3x3_tune(310 + (bn ? 1 : 0), 0); return BH_OK; }   // (-44, 0|1): fp16-piece 3x3 launches on the persistent producer / consumer kernel off / on
     if (bm == -41) { bh_conv3x3_tune(200 + bn, 0); return BH_OK; }      // (-41, n): 3x3 kernel - second-round workgroups sleep n x 8128 cycles first
     if (bm == -18) { bh_conv3x3_tune(400 + bn, 0); return BH_OK; }       // (-18, bits): 3x3 kernel ablation - 1 no weight DMA, 2 no halo DMA in the loop
