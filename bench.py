@@ -238,6 +238,11 @@ def roofline_leg(model, data, opt, sched, reducer, nsteps=2):
         if hbm_frac > roof["mfma_frac"]:
             roof.update({"bound": "hbm", "achieved": top["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_frac,
                          "mfma_executed_tflops": ex})
+        # round-5 VERDICT: a kernel whose two fractions are both below 0.5 and within 5 % of each other is bound by NEITHER roof (latency,
+        # and the matrix pipe's power-limited clock on toggling operands: DESIGN.md 5.0); `achieved` / `peak` / `frac` stay those of the nearer one
+        if max(hbm_frac, roof["mfma_frac"]) < 0.5 and abs(hbm_frac - roof["mfma_frac"]) <= 0.05 * max(hbm_frac, roof["mfma_frac"]):
+            roof["nearest_roof"] = roof["bound"]
+            roof["bound"] = "neither"
     elif top["tflops"] > 0:
         roof = {"kernel": top["kernel"], "bound": "mfma", "achieved": top["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": top["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
@@ -342,6 +347,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # CU budget of the exchange: 42.3 MB per 12 ms step is ~6 GB/s per GPU on a ring - a fraction of ONE xGMI link - while every RCCL
+        # channel is a persistent workgroup that holds a CU which the step's 256-workgroup persistent conv kernels (one per CU, 158.5 KB
+        # of LDS: nothing co-resides) then have to queue for.  Four channels are plenty and cost four CUs; the caller's setting wins.
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "4")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
@@ -527,6 +536,9 @@ def main():
         dist_info = {"backend": backend, "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None),
                      "world_size": world, "ranks_counted": int(ones.item()), "devices_per_node": ndev,
                      "buckets": sum(len(r.buckets) for r in reds), "payload_bytes_per_step": payload, "reduce_op": "SUM",
+                     "rccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
+                     "exchange_launch": "each bucket behind the weight-gradient stream (event from the main stream, no wait on it); one join "
+                                        "in front of the optimizer",
                      "allreduce_ms_per_step": tar.item(),
                      "allreduce_note": "the step's bucket sequence alone (nothing to overlap with), max over ranks; inside a step the buckets "
                                        "leave from the backward hooks and run under the remaining backward kernels",

@@ -58,6 +58,9 @@ __device__ unsigned long long g_pc_ts[4 * 160 * 2];
 #else
 #define PC_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
+#ifndef PC_EMU
+#define PC_EMU 0
+#endif
 #define PC_H_ASM 0        // (1: the H waves' loads as inline assembly with hand-counted waits - see the note in the H role; not yet sound)
 #define PC_BARRIER_VM() asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
@@ -168,6 +171,22 @@ __global__ void __launch_bounds__(768) conv3x3_pc_kernel(C3Args a) {
     } while (0)
         PC_BARRIER();                                    // B(-1): halo stage 0 and weight row 0 are in LDS
         PC_LOADH(FA0, FB0, aL, bL, 0);
+#if PC_EMU
+        // (timing experiment, wrong results: what the row time would be with fewer fragment reads per MFMA.  Both fragment sets are loaded
+        //  once for real, then 1: the B reads are dropped - 4 reads per 6 MFMAs, the ratio of a 2 x 2 accumulator block; 2: every read is
+        //  dropped - the matrix pipe with the other roles around it; 3: the A reads of fragment 1 are dropped as well - 2 per 6)
+        PC_LOADH(FA1, FB1, aL, bL, 1);
+#undef PC_LD_B
+#define PC_LD_B(B_, bp, s2, pc_) (void)0
+#if PC_EMU >= 2
+#undef PC_LD_A
+#if PC_EMU == 2
+#define PC_LD_A(A_, ap, s2, i_, pc_) (void)0
+#else
+#define PC_LD_A(A_, ap, s2, i_, pc_) do { if ((i_) == 0) A_[i_][pc_] = *reinterpret_cast<const uint4*>((ap) + (pc_) * PC_PIECE + 2 * (s2) * PC_PS + (i_) * 64); } while (0)
+#endif
+#endif
+#endif
         int kap = 0;                                     // chunk counter: halo stage = kap & 1; the weight slot of kernel row r is slot r
         for (int ti = 0; ti < Tw; ++ti) {
 #pragma unroll

@@ -226,7 +226,10 @@ int bh_pointwise_try(const float* x, const float* w, const float* bias, float* y
     const int K = d->Ci, taps = tconv ? 4 : 1, N = taps * d->Co;
     if (K != 32 && K != 64) return BH_OK;
     if (bni && (!c1 || bni->groups < 1)) return BH_OK;
-    if (bni) groups = bni->groups;
+    // The kernel walks ONE partition of the images: with statistics AND a BatchNorm-on-load table the two group counts must agree (the
+    // generic kernel keeps them apart and takes the launch otherwise); with a table alone the partition is the table's.
+    if (bni && bn_sums && groups != bni->groups) return BH_OK;
+    if (bni && !bn_sums) groups = bni->groups;
     if (groups < 1 || d->N % groups) return BH_OK;
     const long long M = (long long)d->N * d->Hi * d->Wi, mpg = M / groups;
     if (M < 65536 || mpg % 32) return BH_OK;             // (small maps: the generic kernel's many workgroups are fine there)

@@ -10,6 +10,7 @@
 // large stream: 64 channels x 4 B per pixel) is written as 128-byte rows.  fp32 MFMA (v_mfma_f32_32x32x2_f32) in
 // every precision mode.
 #include "common.h"
+#include "warp_tap.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -193,8 +194,26 @@ int bh_stem7_try(const float* x, const float* w, const float* bias, float* y, co
 // its time in 3.6 M device-scope atomics: 182 us), 1.9x the GEMM work of the two-pass form and none of its 218 MB.  The same sums in another order
 // than the two-pass form; deterministic by construction.  gy [N][Ho][Wo][64] NHWC, w [64][7][7][1], gx [N][1][2 Ho][2 Wo].
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) stem7_dgrad_c1_kernel(const float* __restrict__ gy, const float* __restrict__ w, float* __restrict__ gx,
-                                                             int Ho, int Wo, int tiles_x, int tiles_per_img, int ntiles) {
+// WARP (round 6; round-3/4/5 VERDICT: "the warp folded into the extractor stem's dgrad epilogue"): the image whose gradient this is was
+// the homography warp of a source patch (src/data/utils.py:54-59 via PerceptualHead.py:371-401), and that gradient has ONE consumer - the
+// warp's adjoint with respect to H.  The thread that has just summed the gradient of image pixel (iy, ix) applies it on the spot: the
+// pixel's tap (warp_tap.h, the arithmetic of warp_bwd4_kernel), four gathered source pixels, the coverage term of the pooled all-ones
+// mask, the nine sums of dL/dH in double - kept in registers while the workgroup's tiles stay in one image (the tiles are walked in image
+// order here), reduced over the workgroup and added with nine f64 atomics when the image changes.  The 8.4 MB gradient is neither written
+// nor read back, warp_bwd4_kernel's launch (~19 us for 17 MB: VALU- and latency-bound) disappears into the shadow of this kernel's MFMAs.
+// gx may be NULL (the fused path), or is written as before (tests).
+struct Stem7WarpArgs {
+    const float* src;      // [N][1][Hi][Wi] source patches
+    const double* H64;     // [N][9]
+    const float* g_cov;    // [N][Hi / pool][Wi / pool] gradient of the pooled coverage, or NULL
+    double* gH;            // [N][9], accumulated (+=)
+    int pool_shift;        // log2(pool)
+    float cov_scale;       // 1 / pool^2
+};
+
+template <bool WARP>
+__global__ void __launch_bounds__(256, 3) stem7_dgrad_c1_kernel(const float* __restrict__ gy, const float* __restrict__ w, float* __restrict__ gx,
+                                                             int Ho, int Wo, int tiles_x, int tiles_per_img, int ntiles, Stem7WarpArgs wa) {
     constexpr int GP = 68;                               // row pitch of the gy tile in LDS (floats): 16-byte rows for the staging stores
     constexpr int TP = 53;                               // row pitch of the tap table (49 used)
     __shared__ float Wt[64 * 64];                        // [k = channel][n = tap, 49 used]
@@ -207,10 +226,39 @@ __global__ void __launch_bounds__(256) stem7_dgrad_c1_kernel(const float* __rest
     }
     const int Hi = 2 * Ho, Wi = 2 * Wo;
     const int py = tid >> 4, px = tid & 15;              // this thread's image pixel inside the tile
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // WARP: a contiguous range of tiles per workgroup (image order: the nine sums live in registers across the tiles of one image)
+    const int t_lo = WARP ? (int)(((long long)blockIdx.x * ntiles) / gridDim.x) : (int)blockIdx.x;
+    const int t_hi = WARP ? (int)(((long long)(blockIdx.x + 1) * ntiles) / gridDim.x) : ntiles;
+    const int t_step = WARP ? 1 : (int)gridDim.x;
+    __shared__ double wpart[4][9];
+    double ws[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) ws[k] = 0.0;
+    int cur_img = -1;
+    Hf Hc = {};
+    // the workgroup's sums for image `im` leave: wave sums -> LDS -> nine f64 atomics (uniform call: every thread of the workgroup)
+    auto warp_flush = [&](int im) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) ws[k] = wave_sum(ws[k]);
+        if (lane == 0)
+            for (int k = 0; k < 9; ++k) wpart[wave][k] = ws[k];
+        __syncthreads();
+        if (tid < 9) atomicAdd(wa.gH + (size_t)im * 9 + tid, ((wpart[0][tid] + wpart[1][tid]) + wpart[2][tid]) + wpart[3][tid]);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 9; ++k) ws[k] = 0.0;
+    };
+    for (int tile = t_lo; tile < t_hi; tile += t_step) {
         const int img = tile / tiles_per_img, t = tile - img * tiles_per_img;
         const int ty = t / tiles_x, tx = t - ty * tiles_x;
         const int oy0 = ty * 8 - 1, ox0 = tx * 8 - 1;    // first gy pixel of the window: image rows 16 ty .. 16 ty + 15 see oy0 .. oy0 + 10
+        if constexpr (WARP) {
+            if (img != cur_img) {
+                if (cur_img >= 0) warp_flush(cur_img);
+                cur_img = img;
+                Hc = load_h(wa.H64 + (size_t)img * 9);
+            }
+        }
         __syncthreads();                                 // the previous tile's tap table has been read (and Wt is complete)
         // 128 window slots x 16 float4: thread -> (slot, 4 channels); slots past 121 and pixels outside gy are zero
 #pragma unroll
@@ -259,7 +307,30 @@ __global__ void __launch_bounds__(256) stem7_dgrad_c1_kernel(const float* __rest
                 if (ky < 7 && kx < 7) sum += gt[(wy * 11 + wx) * TP + ky * 7 + kx];
             }
         }
-        gx[((size_t)img * Hi + iy) * Wi + ix] = sum;
+        if (!WARP || gx) gx[((size_t)img * Hi + iy) * Wi + ix] = sum;
+        if constexpr (WARP) {
+            // warp_bwd4_kernel's per-pixel arithmetic (csrc/warp.hip): float products, double sums
+            const Tap4 tp = make_tap4(Hc, ix, iy, Wi, Hi);
+            const unsigned plane = (unsigned)Hi * (unsigned)Wi;
+            const float gc = wa.g_cov ? wa.g_cov[((size_t)img * (Hi >> wa.pool_shift) + (iy >> wa.pool_shift)) * (Wi >> wa.pool_shift) + (ix >> wa.pool_shift)] * wa.cov_scale
+                                      : 0.0f;
+            const float sy = tp.wy0 + tp.wy1, sx = tp.wx0 + tp.wx1;
+            float gu = gc * ((tp.vx1 ? sy : 0.0f) - (tp.vx0 ? sy : 0.0f));
+            float gv = gc * ((tp.vy1 ? sx : 0.0f) - (tp.vy0 ? sx : 0.0f));
+            const __amdgpu_buffer_rsrc_t rs = plane_rsrc(wa.src + (size_t)img * plane, plane * 4u);
+            const float p00 = ldtap(rs, tp.o00), p01 = ldtap(rs, tp.o01), p10 = ldtap(rs, tp.o10), p11 = ldtap(rs, tp.o11);
+            gu += sum * ((p01 - p00) * tp.wy0 + (p11 - p10) * tp.wy1);
+            gv += sum * ((p10 - p00) * tp.wx0 + (p11 - p01) * tp.wx1);
+            const float a = gu * tp.iz, bq = gv * tp.iz;
+            const float gz = tp.guard ? 0.0f : -(gu * tp.u + gv * tp.v) * tp.iz;
+            const double fx = (double)ix, fy = (double)iy;
+            ws[0] += (double)a * fx; ws[1] += (double)a * fy; ws[2] += (double)a;
+            ws[3] += (double)bq * fx; ws[4] += (double)bq * fy; ws[5] += (double)bq;
+            ws[6] += (double)gz * fx; ws[7] += (double)gz * fy; ws[8] += (double)gz;
+        }
+    }
+    if constexpr (WARP) {
+        if (cur_img >= 0) warp_flush(cur_img);
     }
 }
 
@@ -274,7 +345,33 @@ extern "C" int bh_stem7_dgrad_c1(const float* gy, const float* w, float* gx, con
     const int tiles_x = d->Wo / 8, tpi = (d->Ho / 8) * tiles_x, ntiles = d->N * tpi;
     int blocks = 256 * 3;
     if (blocks > ntiles) blocks = ntiles;
-    hipLaunchKernelGGL(stem7_dgrad_c1_kernel, dim3(blocks), dim3(256), 0, s, gy, w, gx, d->Ho, d->Wo, tiles_x, tpi, ntiles);
+    hipLaunchKernelGGL(stem7_dgrad_c1_kernel<false>, dim3(blocks), dim3(256), 0, s, gy, w, gx, d->Ho, d->Wo, tiles_x, tpi, ntiles, Stem7WarpArgs{});
+    BH_LAUNCH_CHECK();
+    return BH_OK;
+}
+
+// The same dgrad with the warp's adjoint applied to the gradient it makes (stem7_dgrad_c1_kernel<true>): gH[N][9] += dL/dH of
+//   warped = warp(src, H)  (bh_warp_fwd, pool-averaged coverage included when g_cov is given)
+// for the gradient gx = dgrad(gy) of `warped` - what bh_stem7_dgrad_c1 followed by bh_warp_bwd(src, H64, gx, g_cov, ...) computes, without
+// the gradient image.  gx: NULL, or [N][Hi][Wi] written as by bh_stem7_dgrad_c1.  The f64 atomics make the last bits of gH depend on the
+// order of the workgroups: deterministic callers use the two separate calls (bh_warp_bwd_f with BH_F_DETERMINISTIC).
+extern "C" int bh_stem7_dgrad_c1_warp(const float* gy, const float* w, float* gx, const bh_conv_desc* d, const float* src, const double* H64,
+                                      const float* g_cov, int pool, double* gH, void* stream) {
+    if (!gy || !w || !d || !src || !H64 || !gH) return BH_E_BADARG;
+    if (d->transposed || d->Ci != 1 || d->Co != 64 || d->kh != 7 || d->kw != 7 || d->stride != 2 || d->pad != 3 || d->out_nchw ||
+        d->Ho % 8 || d->Wo % 8 || d->Ho * 2 != d->Hi || d->Wo * 2 != d->Wi)
+        return BH_E_UNSUPPORTED;
+    int shift = -1;
+    for (int b = 0; b < 6; ++b) if (pool == (1 << b)) shift = b;
+    if (shift < 0 || d->Hi % pool || d->Wi % pool || (long long)d->Hi * d->Wi * 4 >= (1ll << 31)) return BH_E_UNSUPPORTED;
+    if (d->N == 0) return BH_OK;
+    if (bh_query("stem7_dgrad_c1_kernel<true>")) return BH_OK;
+    hipStream_t s = bh_stream(stream);
+    const int tiles_x = d->Wo / 8, tpi = (d->Ho / 8) * tiles_x, ntiles = d->N * tpi;
+    int blocks = 256 * 3;
+    if (blocks > ntiles) blocks = ntiles;
+    Stem7WarpArgs wa = {src, H64, g_cov, gH, shift, 1.0f / (float)(pool * pool)};
+    hipLaunchKernelGGL(stem7_dgrad_c1_kernel<true>, dim3(blocks), dim3(256), 0, s, gy, w, gx, d->Ho, d->Wo, tiles_x, tpi, ntiles, wa);
     BH_LAUNCH_CHECK();
     return BH_OK;
 }

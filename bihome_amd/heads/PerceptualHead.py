@@ -190,6 +190,22 @@ class _ScaleSamples(torch.autograd.Function):
         return g_x, g_s, None
 
 
+def _extractor_dgrad_into_warp(aux, featw, wl, gfeatw, src, H64, gcov, pool, gH):
+    """The adjoint of  H -> extractor(warp(src, H))  given the feature gradient: extractor dgrad (one NetFunction node), then the warp's
+    adjoint into gH (+=).  Round 6: where the extractor's stem kernel applies (one-channel patches, default arithmetic) the two are ONE
+    launch - the Runner's `input_sink` tells the stem's dgrad what its gradient image is for (kernels.conv_dgrad warp_sink), the image is
+    never written and warp_bwd4_kernel never runs; every other case takes the two calls as before."""
+    runner = aux._runner(src.shape[1])
+    sink = dict(src=src, H64=H64, g_cov=gcov, pool=pool, gH=gH, done=False) if (src.shape[1] == 1 and src.is_contiguous()) else None
+    runner.input_sink = sink
+    try:
+        (gwarp,) = torch.autograd.grad(featw, wl, gfeatw, allow_unused=True)
+    finally:
+        runner.input_sink = None
+    if sink is None or not sink["done"]:
+        K.warp_bwd(src, H64, gwarp.contiguous(), gcov, pool, gH=gH)
+
+
 @K.scoped_function
 class _BiHomELoss(torch.autograd.Function):
     """triplet_resnet_loss, double-line branch (PerceptualHead.py:320-714) for stacked directions.
@@ -234,8 +250,7 @@ class _BiHomELoss(torch.autograd.Function):
         fw = featw.detach()
         gfeatw, gcov, gH = K.bihome_loss_bwd(g, feat[:B], feat[B:], fw[:B], fw[B:], cov[:B], cov[B:], None, None, M1, M2, numden,
                                              H64[:B], H64[B:], head.triplet_mu, joined=True)      # (both directions in one tensor each)
-        (gwarp,) = torch.autograd.grad(featw, wl, gfeatw)        # extractor dgrad (one NetFunction node)
-        K.warp_bwd(patches, H64, gwarp.contiguous(), gcov, ctx.pool, gH=gH)
+        _extractor_dgrad_into_warp(head.auxiliary_resnet, featw, wl, gfeatw, patches, H64, gcov, ctx.pool, gH)
         gdelta = K.h4pt_bwd(delta, H64, gH, h)
         return gdelta, None, None
 
@@ -283,9 +298,8 @@ class _IHomELoss(torch.autograd.Function):
         h = p1.shape[-1]
         g = g_loss.reshape(1).to(torch.float32).contiguous()
         gfw, gcov = K.oneline_loss_bwd(g, f2, featw.detach(), cov, T, numden, rep=ctx.n, sample_w=sw)
-        (gwarp,) = torch.autograd.grad(featw, wl, gfw)
         gH = torch.zeros_like(H64)
-        K.warp_bwd(p1, H64, gwarp.contiguous(), gcov, ctx.pool, gH=gH)
+        _extractor_dgrad_into_warp(ctx.head.auxiliary_resnet, featw, wl, gfw, p1, H64, gcov, ctx.pool, gH)
         gdelta = K.h4pt_bwd(delta, H64, gH, h)
         g_scores = per * g if sw is not None else None           # d loss / d score_b = loss_b
         return gdelta, None, None, g_scores, None
@@ -307,7 +321,7 @@ class _WarpFeatures(torch.autograd.Function):
             wl = warped.detach().requires_grad_(True)
             featw = aux(wl, groups=1)                            # :273
         ctx.saved = (delta, p1, H64, featw, wl)
-        ctx.pool = aux.stride
+        ctx.pool, ctx.aux = aux.stride, aux
         head.last = {"H_4pt": H32, "warped": warped}
         return featw.detach()
 
@@ -315,9 +329,8 @@ class _WarpFeatures(torch.autograd.Function):
     def backward(ctx, g):
         delta, p1, H64, featw, wl = ctx.saved
         ctx.saved = None
-        (gwarp,) = torch.autograd.grad(featw, wl, g.contiguous())
         gH = torch.zeros_like(H64)
-        K.warp_bwd(p1, H64, gwarp.contiguous(), None, ctx.pool, gH=gH)
+        _extractor_dgrad_into_warp(ctx.aux, featw, wl, g.contiguous(), p1, H64, None, ctx.pool, gH)
         return K.h4pt_bwd(delta, H64, gH, p1.shape[-1]), None, None
 
 

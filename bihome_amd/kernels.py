@@ -565,6 +565,7 @@ class WeightPacker:
     """Fragment-ordered copies (forward and dgrad operand order) of the 3x3 conv weights of one module tree, refreshed by
     ONE bh_conv3x3_pack launch whenever a parameter version changed (every optimizer step in training, once for frozen
     weights).  Buffers and the device job table are allocated once (addresses stay fixed: HIP-graph safe)."""
+    _serials = 0
 
     def __init__(self, split=False, f16=False):
         # split: False / 0 = fp32 fragments (w_layout 1); True / 3 = three exact bf16 pieces (w_layout 2, precision 2);
@@ -577,6 +578,8 @@ class WeightPacker:
         self.layout = 4 if self.f16 else {0: 1, 3: 2, 2: 3}[self.pieces]
         self.job_split = 3 if self.f16 else {0: 0, 3: 1, 2: 2}[self.pieces]
         self.entries = {}          # id(weight) -> (weight, pf, pd)
+        WeightPacker._serials += 1
+        self.serial = WeightPacker._serials       # names this packer in cache keys (net.run_forward's plan cache)
         self.table = None
         self.versions = None
         self.dirty = False         # a training forward ran since the last pack: the optimizer has (probably) moved the weights
@@ -777,8 +780,11 @@ def bias_grad_from_sums(sums, gbias, groups, C):
     check(lib.bh_bias_grad_from_sums(_p(sums), _p(gbias), groups, C, _stream()), "bh_bias_grad_from_sums")
 
 
-def conv_dgrad(gy, w, d, out=None, bn_reduce=None, wkey=None, wpacked=None, colsum=None):
-    """colsum (only when dgrad_bn_reduce_ok(d), no `out`, no bn_reduce): zeroed bn_stats_buffer(1, Ci) - the per-channel sums
+def conv_dgrad(gy, w, d, out=None, bn_reduce=None, wkey=None, wpacked=None, colsum=None, warp_sink=None):
+    """warp_sink (round 6; the extractor stem's dgrad on a one-channel image only): dict(src, H64, g_cov, pool, gH) - the image is the
+    homography warp of `src`; where the fused kernel applies, the warp's adjoint is accumulated into gH, warp_sink["done"] is set and
+    None is returned instead of the gradient image.
+    colsum (only when dgrad_bn_reduce_ok(d), no `out`, no bn_reduce): zeroed bn_stats_buffer(1, Ci) - the per-channel sums
     of the gradient written are accumulated in the epilogue (bias gradient of the producer of this conv's input).
     wpacked: the dgrad buffer of WeightPacker for this conv.
     wkey: (param, param._version) of the parameter `w` was derived from (cache key of derived weight tables).
@@ -817,6 +823,17 @@ def conv_dgrad(gy, w, d, out=None, bn_reduce=None, wkey=None, wpacked=None, cols
         if (d.Ci == 1 and d.Co == 64 and d.pad == 3 and d.Ho % 8 == 0 and d.Wo % 8 == 0 and d.Ho * 2 == d.Hi and d.Wo * 2 == d.Wi
                 and w.is_contiguous() and os.environ.get("BIHOME_STEM_DGRAD_FUSED", "1") != "0"):
             # one kernel (round 4): a workgroup owns a 16 x 16 image tile - window GEMM into a tap table in LDS + gather; no tap table in HBM
+            if warp_sink is not None and not deterministic() and os.environ.get("BIHOME_WARP_IN_STEM_DGRAD", "1") != "0":
+                # round 6: the image is the homography warp of warp_sink["src"] and its gradient has one consumer, the warp's adjoint: the
+                # kernel applies it to every pixel it has just summed (bh_stem7_dgrad_c1_warp) - no gradient image, no warp_bwd launch
+                ws_ = warp_sink
+                _chk(ws_["src"]); _chk(ws_["H64"], torch.float64); _chk(ws_["gH"], torch.float64); _chk(ws_["g_cov"])
+                # (the name keeps the plain kernel's: rocprofv3 prints the template argument, bh_conv_variant-style)
+                with _Timed("stem7_dgrad_c1_kernel<true>", conv_flops(d), 4.0 * (gy.numel() + ws_["src"].numel())):
+                    check(lib.bh_stem7_dgrad_c1_warp(_p(gy), _p(w), None, ctypes.byref(d), _p(ws_["src"]), _p(ws_["H64"]), _p(ws_["g_cov"]),
+                                                     int(ws_["pool"]), _p(ws_["gH"]), _stream()), "bh_stem7_dgrad_c1_warp")
+                ws_["done"] = True
+                return None
             gx = torch.empty((d.N, d.Hi, d.Wi, 1), dtype=torch.float32, device=gy.device)
             with _Timed("stem7_dgrad_c1_kernel", conv_flops(d), 4.0 * (gy.numel() + gx.numel())):
                 check(lib.bh_stem7_dgrad_c1(_p(gy), _p(w), _p(gx), ctypes.byref(d), _stream()), "bh_stem7_dgrad_c1")
@@ -899,10 +916,18 @@ def conv_wgrad(x, gy, gw, gbias, d, det_ws=None):
         # the backbone's stem (round 4): dedicated kernel + ordered reduction through a private workspace (no atomics: every mode)
         need = lib.bh_stem7_wgrad_ws_bytes(ctypes.byref(d))
         if need:
-            key = (str(x.device), int(need), int(torch.cuda.current_stream(x.device).cuda_stream))
-            ws = _STEM_WGRAD_WS.get(key)
-            if ws is None:
-                ws = _STEM_WGRAD_WS[key] = torch.empty(need // 4, dtype=torch.float32, device=x.device)
+            if torch.cuda.is_current_stream_capturing():
+                # under a graph capture the workspace is born in THAT graph's private pool: it must not outlive the capture in a module-level
+                # cache (a second graph capturing on the same stream handle would be handed a buffer the first graph's pool owns - round-5
+                # ADVICE); stream order inside the capture keeps a freed block safe for later allocations of the same stream
+                ws = torch.empty(need // 4, dtype=torch.float32, device=x.device)
+            else:
+                key = (str(x.device), int(need), int(torch.cuda.current_stream(x.device).cuda_stream))
+                ws = _STEM_WGRAD_WS.get(key)
+                if ws is None:
+                    if len(_STEM_WGRAD_WS) >= 8:           # (streams come and go: the cache stays bounded)
+                        _STEM_WGRAD_WS.clear()
+                    ws = _STEM_WGRAD_WS[key] = torch.empty(need // 4, dtype=torch.float32, device=x.device)
             with _Timed("stem7_wgrad_kernel<2>+stem7_wgrad_reduce_kernel<2>", conv_flops(d), 4.0 * (x.numel() + gy.numel() + gw.numel())):
                 check(lib.bh_stem7_wgrad(_p(x), _p(gy), _p(gw), ctypes.byref(d), _p(ws), need, _stream()), "bh_stem7_wgrad")
             return

@@ -335,7 +335,8 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, p
         amax_next = lambda: next(amax_iter)
     # the fusion plan below (which conv feeds which BatchNorm's sums, which BatchNorms are applied on load or joined) depends on the program, the
     # mode and the weight packer only: computed once per (mode, groups, arithmetic, packer) and kept on the program, as run_backward's
-    fw_key = (bool(training), int(groups), int(precision), id(packer) if packer is not None else 0,
+    # (the packer is named by its serial number, not by id(): an id can be reused by another packer after garbage collection)
+    fw_key = (bool(training), int(groups), int(precision), packer.serial if packer is not None else 0,
               len(packer.entries) if packer is not None else 0, bool(packer.f16) if packer is not None else False,
               os.environ.get("BIHOME_BN_ON_LOAD_1X1", "1"), os.environ.get("BIHOME_BN_ON_LOAD", "1"), os.environ.get("BIHOME_BN_JOIN", "1"),
               tuple(op.mod.weight.requires_grad for op in prog.ops if op.kind == "conv"))
@@ -579,7 +580,7 @@ def side_stream(device):
 _FROM_1X1_KC = (16,)      # output channels of the 1x1 convs whose dgrad the BatchNorm in front rebuilds (run_backward)
 
 
-def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=None, wgrad_stream=None, det_ws=None, x3_ws=None):
+def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=None, wgrad_stream=None, det_ws=None, x3_ws=None, input_sink=None):
     """Adjoint of run_forward. Parameter gradients are accumulated (+=) into each parameter's `.grad`
     tensor (which must already exist, see FlatGrads). Returns the input gradient or None.
     wgrad_stream: a second HIP stream for the conv weight-gradient launches.  The backward chain on the main stream is
@@ -595,7 +596,11 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
     #  backward walks per step used to rebuild it, ~0.4 ms of a host that has ~9 ms of enqueueing to do per 12 ms step)
     # (key: everything the plan reads that can differ between two walks of one program - mode, batch / map geometry via the output
     #  gradient's shape, the joins made by this forward, the precision, the switches)
-    plan_key = (bool(ctx.training), bool(want_wgrad), int(ctx.groups), tuple(gout.shape), len(ctx.joined), len(ctx.descs), getattr(ctx, "precision", 0),
+    #  gradient's shape, the joins made by this forward and the convs it ran - their CONTENTS, not their counts - the precision, which conv
+    #  weights / biases train (fuse_bias reads the flags: freezing a layer between two steps must not reuse the other plan), the switches)
+    plan_key = (bool(ctx.training), bool(want_wgrad), int(ctx.groups), tuple(gout.shape), frozenset(ctx.joined.items()), frozenset(ctx.descs),
+                getattr(ctx, "precision", 0),
+                tuple((op.mod.weight.requires_grad, op.mod.bias is not None and op.mod.bias.requires_grad) for op in prog.ops if op.kind == "conv"),
                 os.environ.get("BIHOME_FUSE_BN_REDUCE", "1"), os.environ.get("BIHOME_FUSE_BIAS_GRAD", "1"), os.environ.get("BIHOME_BN_FROM_1X1", "1"))
     plans = prog.__dict__.setdefault("_bw_plans", {})
     cached = plans.get(plan_key) if os.environ.get("BIHOME_PLAN_CACHE", "1") != "0" else None
@@ -640,29 +645,6 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
                 pm = prog.ops[p].mod
                 if pm.bias is not None and pm.bias.requires_grad and pm.weight.requires_grad and prog.ops[p].extra["weight_fn"] is None:
                     fuse_bias[j] = p
-    if os.environ.get("BIHOME_BN_PLAN") == "1" and not getattr(prog, "_bn_plan_printed", False):
-        # tools/: which BatchNorm adjoints still run their own reduce pass, and what completes their output gradient
-        prog._bn_plan_printed = True
-        lc = {}
-        for j, op in enumerate(prog.ops):
-            for sl in (op.src, op.res):
-                if sl is not None and sl not in lc:
-                    lc[sl] = j
-        for b, op in enumerate(prog.ops):
-            if op.kind != "bn":
-                continue
-            j = lc.get(op.dst)
-            cons = prog.ops[j] if j is not None else None
-            what = "output" if cons is None else cons.kind
-            if cons is not None and cons.kind == "conv":
-                m = cons.mod
-                what = "%s k%s s%s %d->%d" % (type(m).__name__, getattr(m, "kernel_size", "?"), getattr(m, "stride", "?"),
-                                               getattr(m, "in_channels", getattr(m, "in_features", 0)), getattr(m, "out_channels", getattr(m, "out_features", 0)))
-            elif cons is not None and cons.kind == "bn":
-                what = "bn(res)" if cons.res == op.dst else "bn"
-            print("BN_PLAN op %3d C%-4d %s last consumer: op %s %s | fused=%s joined=%s shape=%s" %
-                  (b, op.mod.num_features, "relu" if op.relu else "    ", j, what, b in fuse_bn.values(), b in ctx.joined,
-                   tuple(slots[op.src].shape) if hasattr(slots[op.src], "shape") else "?"), file=sys.stderr)
     # A 1x1 / stride-1 conv with 16 output channels that is the ONLY consumer of a training-mode BatchNorm (+ReLU, no residual, not joined):
     # its dgrad is rebuilt inside that BatchNorm's adjoint (bh_bn_bwd_from_1x1) - the full-resolution decoder unit's 268 MB gradient is
     # never written
@@ -690,6 +672,29 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
         plans[plan_key] = (consumed_by, fuse_bn, fuse_bias, from_1x1, red_off, bias_off, total)
     else:
         consumed_by, fuse_bn, fuse_bias, from_1x1, red_off, bias_off, total = cached
+    if os.environ.get("BIHOME_BN_PLAN") == "1" and not getattr(prog, "_bn_plan_printed", False):
+        # tools/: which BatchNorm adjoints still run their own reduce pass, and what completes their output gradient
+        prog._bn_plan_printed = True
+        lc = {}
+        for j, op in enumerate(prog.ops):
+            for sl in (op.src, op.res):
+                if sl is not None and sl not in lc:
+                    lc[sl] = j
+        for b, op in enumerate(prog.ops):
+            if op.kind != "bn":
+                continue
+            j = lc.get(op.dst)
+            cons = prog.ops[j] if j is not None else None
+            what = "output" if cons is None else cons.kind
+            if cons is not None and cons.kind == "conv":
+                m = cons.mod
+                what = "%s k%s s%s %d->%d" % (type(m).__name__, getattr(m, "kernel_size", "?"), getattr(m, "stride", "?"),
+                                               getattr(m, "in_channels", getattr(m, "in_features", 0)), getattr(m, "out_channels", getattr(m, "out_features", 0)))
+            elif cons is not None and cons.kind == "bn":
+                what = "bn(res)" if cons.res == op.dst else "bn"
+            print("BN_PLAN op %3d C%-4d %s last consumer: op %s %s | fused=%s joined=%s shape=%s" %
+                  (b, op.mod.num_features, "relu" if op.relu else "    ", j, what, b in fuse_bn.values(), b in ctx.joined,
+                   tuple(slots[op.src].shape) if hasattr(slots[op.src], "shape") else "?"), file=sys.stderr)
     bn_reduced = {}
     # precision 4: magnitude records of the BatchNorm input gradients (the gy operand of the fp16-piece dgrad / weight-gradient kernels)
     amax_next = None
@@ -766,7 +771,11 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
                 elif op.src in grads:
                     K.conv_dgrad(g, wk, d, out=grads[op.src], bn_reduce=red, wkey=ctx.wkeys[i], wpacked=ctx.wpacked.get(i))
                 else:
-                    grads[op.src] = K.conv_dgrad(g, wk, d, bn_reduce=red, wkey=ctx.wkeys[i], wpacked=ctx.wpacked.get(i))
+                    # (input_sink: the consumer of the INPUT's gradient folded into the first conv's dgrad - the warp's adjoint, round 6)
+                    gsrc = K.conv_dgrad(g, wk, d, bn_reduce=red, wkey=ctx.wkeys[i], wpacked=ctx.wpacked.get(i),
+                                        warp_sink=input_sink if (op.src == 0 and red is None) else None)
+                    if gsrc is not None:
+                        grads[op.src] = gsrc
         elif op.kind == "bn" and i in ctx.joined:
             j = ctx.joined[i]
             lop, m, lm = prog.ops[j], op.mod, prog.ops[j].mod
@@ -922,7 +931,7 @@ class NetFunction(torch.autograd.Function):
             r.reducer.wait_streams = [side] if side is not None else []
         gin = run_backward(r.prog, ctx.saved, g.contiguous(), want_wgrad=r.flat is not None, want_input_grad=ctx.want_x,
                            on_param_grad=hook, wgrad_stream=side, det_ws=r.det_workspace(g.device) if side is None else None,
-                           x3_ws=r.x3_workspace(g.device))
+                           x3_ws=r.x3_workspace(g.device), input_sink=getattr(r, "input_sink", None))
         ctx.saved = None
         return gin, None, None, None, None
 

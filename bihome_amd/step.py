@@ -66,11 +66,23 @@ class _FlatAdam(torch.optim.Adam):
     def load_state_dict(self, sd):
         n_own = sum(len(g["params"]) for g in self.param_groups)
         n_in = sum(len(g["params"]) for g in sd["param_groups"])
-        # this class's own flat form carries a marker (state_dict() of the base class, used by deepcopy / torch internals, never sets it on
-        # the reference layout); without a model-parameter list there is only that form
-        own_form = sd.get("bihome_flat_layout", False) or (n_in == n_own and n_in != len(self._all or []))
-        if self._all is None or own_form:
-            sd = {k: v for k, v in sd.items() if k != "bihome_flat_layout"}
+        # Two layouts can arrive: the reference's (one entry per model parameter, what state_dict() returns) and this class's own flat form
+        # (one entry per flat buffer + the remaining parameters: what the base class's state_dict() - deepcopy, torch internals - produces).
+        # They are told apart by what the entries HOLD, not by their count (round-5 ADVICE: the counts can coincide): in the reference layout
+        # every moment tensor has the shape of the model parameter at its position.
+        def reference_layout():
+            if self._all is None or n_in != len(self._all):
+                return False
+            ids = [pid for g in sd["param_groups"] for pid in g["params"]]
+            for pid, p in zip(ids, self._all):
+                e = sd["state"].get(pid, sd["state"].get(str(pid)))
+                if e and "exp_avg" in e and tuple(e["exp_avg"].shape) != tuple(p.shape):
+                    return False
+            return True
+        if self._all is None or not reference_layout():
+            if n_in != n_own:
+                raise ValueError("optimizer checkpoint holds %d parameters: neither the model's %d nor this optimizer's %d flat entries"
+                                 % (n_in, len(self._all or []), n_own))
             return super().load_state_dict(sd)
         if n_in != len(self._all):
             raise ValueError("optimizer checkpoint holds %d parameters, the model has %d" % (n_in, len(self._all)))

@@ -389,6 +389,16 @@ int bh_col2im_c1(const float* Tm, float* gx, const bh_conv_desc* d, int ldT, voi
  * (overwritten).  The frozen extractor's conv1 on a warped patch (src/heads/PerceptualHead.py:52-55,377,398).  BH_E_UNSUPPORTED for other
  * geometries: the caller keeps the two-pass form for those.  No atomics: every image tile has one writer. */
 int bh_stem7_dgrad_c1(const float* gy, const float* w, float* gx, const bh_conv_desc* d, void* stream);
+/* Round 6: that dgrad WITH the adjoint of the homography warp that produced the extractor's input (src/data/utils.py:54-59 `warp_image`
+ * as called by src/heads/PerceptualHead.py:371,392 `_warp`, followed by `auxiliary_resnet` :377,398): the gradient of the warped patch
+ * has one consumer - dL/dH - so the thread that sums a pixel's gradient applies the warp's adjoint on the spot (the pixel's bilinear tap,
+ * four gathered pixels of the SOURCE patch src[N,1,Hi,Wi], the coverage term of the pool-averaged all-ones mask when g_cov[N,Hi/pool,
+ * Wi/pool] is given: PerceptualHead.py:380-382,401,447-459) and gH[N,9] += the nine sums.  Equal to bh_stem7_dgrad_c1 followed by
+ * bh_warp_bwd(src, H64, gx, g_cov, N, 1, Hi, Wi, pool, gH) up to the order of the double sums; the 4 Hi Wi-byte gradient image is not
+ * written (gx = NULL) or written as before (gx != NULL).  gH accumulates through f64 atomics: deterministic callers
+ * (BH_F_DETERMINISTIC) use the two separate calls.  BH_E_UNSUPPORTED as bh_stem7_dgrad_c1, or when pool is not a power of two <= 32. */
+int bh_stem7_dgrad_c1_warp(const float* gy, const float* w, float* gx, const bh_conv_desc* d, const float* src, const double* H64,
+                           const float* g_cov, int pool, double* gH, void* stream);
 /* Weight gradient of the backbone's 7x7 / 2 stem on TWO stacked image planes (Rethinking.py:31, ResNet34.py:17) in a dedicated kernel
  * (round 4): x[N,2,Hi,Wi] NCHW, gy[N,Ho,Wo,64] NHWC, gw[64][7][7][2] +=.  Partial sums of the persistent workgroups go through the
  * caller's workspace (bh_stem7_wgrad_ws_bytes(d) bytes, 0 = geometry not taken) and are added in workgroup order: no atomics, bitwise

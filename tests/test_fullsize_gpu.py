@@ -49,13 +49,14 @@ def _oracle_step(cfg, d, dtype, choices=None, keys=("patch_1", "patch_2", "delta
 _ORACLE_CACHE = {}
 
 
-def _check_grads(model_params, g64, g32, max_bad=4, mult=1.0):
+def _check_grads(model_params, g64, g32, max_bad=1, mult=1.0):
     """Gradients against the float64 oracle, calibrated by the oracle's own float32 run.  At 64 pairs the reference
     arithmetic in float32 sits 0.5-1 % (relative L2, per tensor) from float64: a float32 SVD of the 9x9 normal matrix and
     ReLU / max-pool decisions within rounding of a tie move the whole backward pass (tools/grad_parity_report.py prints
     the table).  Required: whole-gradient relative L2 error <= 1.5x the float32 oracle's, and per tensor
     relL2(hip) <= max(2.5 x relL2(f32 oracle, same tensor), 2 x the float32 oracle's whole-gradient error), with at most
-    `max_bad` tensors up to 2x beyond that."""
+    `max_bad` tensors up to 2x beyond that.  (Rounds 1-5 allowed four such tensors; measured in round 6: none of 172 / 110 in seven of seven
+    runs - `pytest -s` prints the count, profiles/r06b_gpu_tests_measured.txt - so one is left for the run-to-run order of the fp32 atomics.)"""
     gscale = max(g.abs().max().item() for g in g64.values())
     num = num32 = den = 0.0
     rows = []
@@ -72,6 +73,7 @@ def _check_grads(model_params, g64, g32, max_bad=4, mult=1.0):
     print("whole-gradient relative L2 error %.3e (float32 oracle: %.3e)" % (e, e32))
     assert e <= mult * max(1.5 * e32, 1e-4), (e, e32)
     bad = [(n, a, b) for n, a, b in rows if a > mult * max(2.5 * b, 2 * e32, 1e-4)]
+    print("MEASURED tensors beyond the per-tensor band: %d of %d (allowed %d)%s" % (len(bad), len(rows), max_bad, "".join("\n   %s %.3e (f32 oracle %.3e)" % t for t in bad)))
     assert len(bad) <= max_bad and all(a <= 2 * mult * max(2.5 * b, 2 * e32, 1e-4) for _, a, b in bad), (bad[:10], e, e32)
     return e, e32
 

@@ -91,6 +91,11 @@ def test_dsac_argmin_bit_exact(K, golden):
     np.testing.assert_allclose(sel.cpu().numpy(), g["delta_hat"], atol=5e-2)   # f32 SVD noise at P=16, noise=2px
 
 
+# twice the largest error measured on the five cases (round 6, `pytest -s`, profiles/r06b_gpu_tests_measured.txt: 8.3e-6 of max |dL/dH|; rounds 1-5
+# allowed 2e-3): float32 coordinates and per-pixel products, double sums, against the float64 autograd of the oracle
+WARP_ADJOINT_BOUND = 2e-5
+
+
 @pytest.mark.parametrize("B,C,size,pool", [(5, 1, 128, 4), (2, 3, 64, 4), (3, 1, 32, 8), (2, 2, 48, 1), (1, 1, 256, 16)])
 def test_warp_fwd_bwd(K, B, C, size, pool):
     rng = np.random.Generator(np.random.PCG64(B * 100 + size))
@@ -104,18 +109,27 @@ def test_warp_fwd_bwd(K, B, C, size, pool):
     imt = torch.tensor(img, dtype=torch.float64)
     ref = O.warp_image(imt, Ht)
     refcov = F.avg_pool2d(O.warp_image(torch.ones(B, 1, size, size, dtype=torch.float64), Ht), pool).squeeze(1)
-    # the kernel evaluates the map in float32 (like grid_sample's float32 grid); coordinate rounding
-    # ~ size * 2^-24 * few -> value error ~ 1e-5 * local gradient
-    np.testing.assert_allclose(out.cpu().numpy(), ref.detach().numpy(), atol=2e-4)
-    np.testing.assert_allclose(cov.cpu().numpy(), refcov.detach().numpy(), atol=2e-5)
-    ref32 = O.warp_image(torch.tensor(img), H64.cpu().reshape(B, 3, 3).float())
-    np.testing.assert_allclose(out.cpu().numpy(), ref32.numpy(), atol=5e-4)     # reference's own float32 chain
+    # north_star: "fp32 warp ... within 1e-4 relative".  The kernel evaluates the map in float32 (like grid_sample's float32 grid):
+    # coordinate rounding ~ size * 2^-24 * few -> value error ~ 1e-5 * local gradient.  Bound: 1e-4 of the reference's range, or - where the
+    # reference's OWN float32 chain (torch.inverse twice, normalise, grid_sample) is further than that from float64 - 1.5 x that spread.
+    o, r64 = out.cpu().double().numpy(), ref.detach().numpy()
+    ref32 = O.warp_image(torch.tensor(img), H64.cpu().reshape(B, 3, 3).float()).double().numpy()
+    scale = np.abs(r64).max()
+    err, spread = np.abs(o - r64).max(), np.abs(ref32 - r64).max()
+    cerr = np.abs(cov.cpu().double().numpy() - refcov.detach().numpy()).max()
+    print("MEASURED warp B%d C%d %d pool%d: max|hip - f64| %.3e = %.2e of range; f32 oracle's own %.3e; coverage %.3e"
+          % (B, C, size, pool, err, err / scale, spread, cerr))
+    assert err <= max(1e-4 * scale, 1.5 * spread), (err, scale, spread)
+    assert np.abs(o - ref32).max() <= 1e-4 * scale + 1.5 * spread
+    assert cerr <= 2e-5
     go = rng.standard_normal(out.shape).astype(np.float32)
     gc = rng.standard_normal(cov.shape).astype(np.float32)
     ((ref * torch.tensor(go, dtype=torch.float64)).sum() + (refcov * torch.tensor(gc, dtype=torch.float64)).sum()).backward()
     gH = K.warp_bwd(dev(img), H64, dev(go), dev(gc), pool)
     r = Ht.grad.numpy().reshape(B, 9)
-    np.testing.assert_allclose(gH.cpu().numpy(), r, rtol=2e-3, atol=2e-4 * np.abs(r).max())
+    gerr = np.abs(gH.cpu().double().numpy() - r).max() / np.abs(r).max()
+    print("MEASURED warp adjoint B%d C%d %d pool%d: max error %.3e of max|dL/dH|" % (B, C, size, pool, gerr))
+    assert gerr <= WARP_ADJOINT_BOUND, gerr
     # coverage-only entry
     cov2 = K.mask_coverage_fwd(H64, size, size, pool)
     assert torch.equal(cov2, cov)
@@ -359,3 +373,47 @@ def test_scale_samples_and_scored_hinge_vs_torch64():
     gf, gm = K.oneline_loss_bwd(torch.ones(1, device="cuda"), f2.cuda(), f1w.cuda(), m1w.cuda(), T, numden, rep=n, sample_w=s.cuda())
     assert (gf.cpu().double() - c.grad).abs().max() <= 2e-5 * c.grad.abs().max() + 1e-8
     assert (gm.cpu().double() - m.grad).abs().max() <= 2e-4 * m.grad.abs().max() + 1e-7
+
+
+@pytest.mark.parametrize("B,size,pool,with_cov", [(6, 128, 4, True), (3, 64, 4, True), (5, 128, 8, True), (4, 32, 4, False), (2, 256, 16, True)])
+def test_stem_dgrad_with_the_warp_adjoint_folded_in(K, B, size, pool, with_cov):
+    """Round 6 (bh_stem7_dgrad_c1_warp, include/bihome.h): the extractor stem's dgrad that applies the warp's adjoint to the gradient it has
+    just made, against the two calls it replaces - bh_stem7_dgrad_c1, then bh_warp_bwd on its output: the gradient image (when asked for)
+    bit for bit, dL/dH to the rounding of a reordered double sum; and against the float64 autograd of the oracle's warp."""
+    import ctypes
+    from bihome_amd._lib import lib, check
+    rng = np.random.Generator(np.random.PCG64(B * 7 + size))
+    src = F.avg_pool2d(torch.tensor(rng.standard_normal((B, 1, size, size)).astype(np.float32)), 3, 1, 1).cuda().contiguous()
+    gy = torch.tensor(rng.standard_normal((B, size // 2, size // 2, 64)).astype(np.float32)).cuda()
+    w = torch.tensor((rng.standard_normal((64, 7, 7, 1)) * 0.05).astype(np.float32)).cuda()
+    gcov = torch.tensor(rng.standard_normal((B, size // pool, size // pool)).astype(np.float32)).cuda() if with_cov else None
+    H64, _ = K.h4pt_fwd(dev(rand_delta(B, size + 1, amp=size / 4.0)), size)
+    d = K.conv_desc(B, size, size, 1, 64, 7, 2, 3)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    gx0 = torch.empty(B, size, size, 1, device="cuda")
+    check(lib.bh_stem7_dgrad_c1(p(gy), p(w), p(gx0), ctypes.byref(d), stream), "bh_stem7_dgrad_c1")
+    base = torch.tensor(rng.standard_normal((B, 9))).cuda()          # gH accumulates: something is there already (ln3's gradient in the step)
+    gH0 = K.warp_bwd(src, H64, gx0.view(B, 1, size, size), gcov, pool, gH=base.clone())
+    for want_gx in (True, False):
+        gx1 = torch.full((B, size, size, 1), float("nan"), device="cuda") if want_gx else None
+        gH1 = base.clone()
+        check(lib.bh_stem7_dgrad_c1_warp(p(gy), p(w), p(gx1), ctypes.byref(d), p(src), p(H64), p(gcov), pool, p(gH1), stream), "bh_stem7_dgrad_c1_warp")
+        if want_gx:
+            assert torch.equal(gx1, gx0)
+        scale = (gH0 - base).abs().max().item()
+        err = (gH1 - gH0).abs().max().item()
+        print("MEASURED fused stem dgrad + warp adjoint B%d %d pool%d: max |gH - two calls| %.3e of %.3e" % (B, size, pool, err, scale))
+        assert err <= 1e-10 * scale, (err, scale)
+    # the float64 oracle: d/dH of <warp(src, H), gx> + <avgpool(warp(ones, H)), gcov>
+    Ht = H64.cpu().reshape(B, 3, 3).clone().requires_grad_(True)
+    ref = (O.warp_image(src.cpu().double(), Ht) * gx0.view(B, 1, size, size).cpu().double()).sum()
+    if with_cov:
+        ref = ref + (F.avg_pool2d(O.warp_image(torch.ones(B, 1, size, size, dtype=torch.float64), Ht), pool).squeeze(1) * gcov.cpu().double()).sum()
+    ref.backward()
+    r = Ht.grad.reshape(B, 9).numpy()
+    got = (gH1 - base).cpu().numpy()
+    assert np.abs(got - r).max() <= WARP_ADJOINT_BOUND * np.abs(r).max()
+    # geometries the kernel does not take are refused, not guessed
+    d2 = K.conv_desc(B, size, size, 1, 64, 7, 2, 3)
+    assert lib.bh_stem7_dgrad_c1_warp(p(gy), p(w), None, ctypes.byref(d2), p(src), p(H64), p(gcov), 3, p(gH1), stream) == -2

@@ -124,3 +124,35 @@ def test_pointwise_batchnorm_on_load(K, N, H, Ci, Co, relu):
     yd = ref.reshape(groups, -1, Co)
     tab = s.reshape(groups, Co, 2, -1)[..., 0].cpu()
     assert (tab[..., 0] - yd.sum(1)).abs().max().item() <= 3e-6 * yd.abs().sum(1).max().item()
+
+
+def test_pointwise_statistics_and_table_groups_may_differ(K):
+    """bh_conv_fwd_bnin takes the layout of `sums` (groups) and of the BatchNorm-on-load table (bni groups) as independent arguments
+    (round-5 ADVICE): with sums in ONE group and a table of TWO the streaming kernel declines (it walks one partition of the images) and the
+    generic kernel - which keeps the two counts apart - makes the launch; the sums land in the caller's [1][Co][2] entries."""
+    N, H, Ci, Co = 16, 64, 32, 16
+    g = torch.Generator().manual_seed(11)
+    z = (torch.randn(N, H, H, Ci, generator=g) * 1.5 + 0.3).cuda()
+    gamma, beta = (torch.rand(Ci, generator=g) + 0.5).cuda(), (torch.randn(Ci, generator=g) * 0.2).cuda()
+    rm, rv = torch.zeros(Ci).cuda(), torch.ones(Ci).cuda()
+    st = K.bn_stats_buffer(2, Ci, "cuda")
+    K.bn_stats(z, st, 2, Ci)
+    rec = K.amax_record("cuda")
+    table = K.bn_fwd_coeffs(st, gamma, beta, rm, rv, 2, N * H * H // 2, Ci, 1e-5, 0.1, amax=rec)
+    lazy = K.BnOnLoad(z, table, 2, True, amax=rec)
+    d = K.conv_desc(N, H, H, Ci, Co, 1, 1, 0, precision=4)
+    w = (torch.randn(Co, 1, 1, Ci, generator=g) * 0.1).cuda()
+    b = torch.randn(Co, generator=g).cuda()
+    s = K.bn_stats_buffer(1, Co, "cuda")
+    guard = s.clone()
+    y = K.conv_fwd(lazy, w, b, d, bn_sums=s, groups=1)
+    zd = z.double().cpu().reshape(2, -1, Ci)
+    mu, var = zd.mean(1, keepdim=True), zd.var(1, unbiased=False, keepdim=True)
+    a = ((zd - mu) / torch.sqrt(var + 1e-5) * gamma.double().cpu() + beta.double().cpu()).clamp_min(0)
+    ref = a.reshape(N, H, H, Ci) @ w.double().cpu().reshape(Co, Ci).t() + b.double().cpu()
+    assert _rel(y, ref) < 3e-6
+    yd = ref.reshape(1, -1, Co)
+    tab = s.reshape(1, Co, 2, -1)[..., 0].cpu()
+    assert (tab[..., 0] - yd.sum(1)).abs().max().item() <= 3e-6 * yd.abs().sum(1).max().item()
+    assert (tab[..., 1] - (yd * yd).sum(1)).abs().max().item() <= 3e-6 * (yd * yd).sum(1).max().item()
+    assert s.shape == guard.shape

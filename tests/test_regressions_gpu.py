@@ -419,5 +419,22 @@ def test_flat_adam_checkpoints_in_the_reference_layout(monkeypatch):
         assert lb2 == lc, (lb2, lc)
         pb, pc = mb[0].state_dict(), mc[0].state_dict()
         assert not [k for k in pb if not torch.equal(pb[k], pc[k])]
+        # the optimizer's OWN flat form (the base class's state_dict(): what deepcopy and torch internals produce) is recognised by what
+        # its entries hold - not by a marker, not by the entry count (round-5 ADVICE) - and resumes to the same next step
+        import copy
+        own = copy.deepcopy(torch.optim.Optimizer.state_dict(ob))
+        assert len(own["param_groups"][0]["params"]) != n_params
+        md, od, sd_ = make(True, {k: v.clone() for k, v in mb.state_dict().items()})
+        od.load_state_dict(own)
+        lb3 = train_step(mb, batch(), ob, sb)[0].item()
+        ld = train_step(md, batch(), od, sd_)[0].item()
+        assert lb3 == ld, (lb3, ld)
+        pb, pd = mb[0].state_dict(), md[0].state_dict()
+        assert not [k for k in pb if not torch.equal(pb[k], pd[k])]
+        # a checkpoint that fits neither layout is an error, not a guess
+        broken = copy.deepcopy(own)
+        broken["param_groups"][0]["params"] = broken["param_groups"][0]["params"] + [10 ** 6]
+        with pytest.raises(ValueError):
+            od.load_state_dict(broken)
     finally:
         K.set_deterministic(prev)
