@@ -252,12 +252,23 @@ __global__ void __launch_bounds__(256, 3) stem7_dgrad_c1_kernel(const float* __r
         const int img = tile / tiles_per_img, t = tile - img * tiles_per_img;
         const int ty = t / tiles_x, tx = t - ty * tiles_x;
         const int oy0 = ty * 8 - 1, ox0 = tx * 8 - 1;    // first gy pixel of the window: image rows 16 ty .. 16 ty + 15 see oy0 .. oy0 + 10
+        // WARP: this thread's pixel, its tap and the four source pixels are requested NOW - they depend on the homography only, so the
+        // gathers' latency (and the tap arithmetic) sits under the staging and the MFMAs below instead of behind the tile's last barrier
+        Tap4 tp = {};
+        float wp00 = 0.f, wp01 = 0.f, wp10 = 0.f, wp11 = 0.f, wgc = 0.f;
         if constexpr (WARP) {
             if (img != cur_img) {
                 if (cur_img >= 0) warp_flush(cur_img);
                 cur_img = img;
                 Hc = load_h(wa.H64 + (size_t)img * 9);
             }
+            const int iy_ = ty * 16 + py, ix_ = tx * 16 + px;
+            tp = make_tap4(Hc, ix_, iy_, 2 * Wo, 2 * Ho);
+            const unsigned plane = (unsigned)(4 * Ho) * (unsigned)Wo;
+            const __amdgpu_buffer_rsrc_t rs = plane_rsrc(wa.src + (size_t)img * plane, plane * 4u);
+            wp00 = ldtap(rs, tp.o00); wp01 = ldtap(rs, tp.o01); wp10 = ldtap(rs, tp.o10); wp11 = ldtap(rs, tp.o11);
+            if (wa.g_cov)
+                wgc = wa.g_cov[((size_t)img * ((2 * Ho) >> wa.pool_shift) + (iy_ >> wa.pool_shift)) * ((2 * Wo) >> wa.pool_shift) + (ix_ >> wa.pool_shift)] * wa.cov_scale;
         }
         __syncthreads();                                 // the previous tile's tap table has been read (and Wt is complete)
         // 128 window slots x 16 float4: thread -> (slot, 4 channels); slots past 121 and pixels outside gy are zero
@@ -310,17 +321,11 @@ __global__ void __launch_bounds__(256, 3) stem7_dgrad_c1_kernel(const float* __r
         if (!WARP || gx) gx[((size_t)img * Hi + iy) * Wi + ix] = sum;
         if constexpr (WARP) {
             // warp_bwd4_kernel's per-pixel arithmetic (csrc/warp.hip): float products, double sums
-            const Tap4 tp = make_tap4(Hc, ix, iy, Wi, Hi);
-            const unsigned plane = (unsigned)Hi * (unsigned)Wi;
-            const float gc = wa.g_cov ? wa.g_cov[((size_t)img * (Hi >> wa.pool_shift) + (iy >> wa.pool_shift)) * (Wi >> wa.pool_shift) + (ix >> wa.pool_shift)] * wa.cov_scale
-                                      : 0.0f;
             const float sy = tp.wy0 + tp.wy1, sx = tp.wx0 + tp.wx1;
-            float gu = gc * ((tp.vx1 ? sy : 0.0f) - (tp.vx0 ? sy : 0.0f));
-            float gv = gc * ((tp.vy1 ? sx : 0.0f) - (tp.vy0 ? sx : 0.0f));
-            const __amdgpu_buffer_rsrc_t rs = plane_rsrc(wa.src + (size_t)img * plane, plane * 4u);
-            const float p00 = ldtap(rs, tp.o00), p01 = ldtap(rs, tp.o01), p10 = ldtap(rs, tp.o10), p11 = ldtap(rs, tp.o11);
-            gu += sum * ((p01 - p00) * tp.wy0 + (p11 - p10) * tp.wy1);
-            gv += sum * ((p10 - p00) * tp.wx0 + (p11 - p01) * tp.wx1);
+            float gu = wgc * ((tp.vx1 ? sy : 0.0f) - (tp.vx0 ? sy : 0.0f));
+            float gv = wgc * ((tp.vy1 ? sx : 0.0f) - (tp.vy0 ? sx : 0.0f));
+            gu += sum * ((wp01 - wp00) * tp.wy0 + (wp11 - wp10) * tp.wy1);
+            gv += sum * ((wp10 - wp00) * tp.wx0 + (wp11 - wp01) * tp.wx1);
             const float a = gu * tp.iz, bq = gv * tp.iz;
             const float gz = tp.guard ? 0.0f : -(gu * tp.u + gv * tp.v) * tp.iz;
             const double fx = (double)ix, fy = (double)iy;

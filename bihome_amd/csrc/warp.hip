@@ -17,9 +17,14 @@ __device__ __forceinline__ void project(const double* __restrict__ Hm, int x, in
     float fx = (float)x, fy = (float)y;
     float h0 = (float)Hm[0], h1 = (float)Hm[1], h2 = (float)Hm[2], h3 = (float)Hm[3], h4 = (float)Hm[4],
           h5 = (float)Hm[5], h6 = (float)Hm[6], h7 = (float)Hm[7], h8 = (float)Hm[8];
-    float qx = h0 * fx + h1 * fy + h2, qy = h3 * fx + h4 * fy + h5, qz = h6 * fx + h7 * fy + h8;
+    // (the coordinate arithmetic of warp_tap.h make_tap4, spelled the same way: the kernels of every pooling size agree bitwise on where a
+    //  pixel lands - and so on which side of an integer coordinate, where the bilinear derivative jumps)
+    float qx = __builtin_fmaf(h0, fx, __builtin_fmaf(h1, fy, h2)), qy = __builtin_fmaf(h3, fx, __builtin_fmaf(h4, fy, h5)),
+          qz = __builtin_fmaf(h6, fx, __builtin_fmaf(h7, fy, h8));
     guard = !(fabsf(qz) > 1e-8f);
-    iz = guard ? 1.0f : 1.0f / qz;
+    float r = __builtin_amdgcn_rcpf(qz);
+    r = __builtin_fmaf(__builtin_fmaf(-qz, r, 1.0f), r, r);
+    iz = guard ? 1.0f : r;
     u = qx * iz;
     v = qy * iz;
 }

@@ -22,7 +22,11 @@ struct Tap4 {
 __device__ __forceinline__ Tap4 make_tap4(const Hf& H, int x, int y, int w, int h) {
     Tap4 t;
     const float fxp = (float)x, fyp = (float)y;
-    const float qx = H.h0 * fxp + H.h1 * fyp + H.h2, qy = H.h3 * fxp + H.h4 * fyp + H.h5, qz = H.h6 * fxp + H.h7 * fyp + H.h8;
+    // (spelled as fused multiply-adds in ONE order: every kernel that includes this header - forward, adjoint, the stem dgrad's folded
+    //  adjoint - gets bitwise the same coordinates, so they agree on which side of an integer coordinate a pixel falls: the bilinear
+    //  derivative jumps there, and with a coordinate left to the compiler's contraction one pixel in ~10^5 took the other branch)
+    const float qx = __builtin_fmaf(H.h0, fxp, __builtin_fmaf(H.h1, fyp, H.h2)), qy = __builtin_fmaf(H.h3, fxp, __builtin_fmaf(H.h4, fyp, H.h5)),
+                qz = __builtin_fmaf(H.h6, fxp, __builtin_fmaf(H.h7, fyp, H.h8));
     t.guard = !(fabsf(qz) > 1e-8f);
     float r = __builtin_amdgcn_rcpf(qz);
     r = __builtin_fmaf(__builtin_fmaf(-qz, r, 1.0f), r, r);     // one Newton step: within an ulp of 1/qz, exact for qz = 1
