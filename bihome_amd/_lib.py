@@ -37,7 +37,12 @@ ROUTE_GENERIC_CONV, ROUTE_HALO_SMALL, ROUTE_NO_STEM7, ROUTE_WGRAD_GENERIC, ROUTE
 
 class BhBnReduce(Structure):
     _fields_ = [("z", c_void_p), ("y", c_void_p), ("stats", c_void_p), ("gamma", c_void_p), ("beta", c_void_p),
-                ("eps", c_float), ("relu", c_int)]
+                ("eps", c_float), ("relu", c_int), ("amax_d", c_void_p)]
+
+
+class BhBnAdj(Structure):
+    _fields_ = [("z", c_void_p), ("y", c_void_p), ("stats", c_void_p), ("sums", c_void_p), ("gamma", c_void_p), ("beta", c_void_p),
+                ("eps", c_float), ("relu", c_int), ("groups", c_int)]
 
 
 class BhBnIn(Structure):
@@ -93,6 +98,7 @@ SIGNATURES = {
     "bh_conv_fwd_bnstats": [P, P, P, P, POINTER(BhConvDesc), P, c_int, P],
     "bh_conv_fwd_bnin": [P, P, P, P, POINTER(BhConvDesc), P, c_int, POINTER(BhBnIn), P],
     "bh_conv_wgrad_bnin": [P, P, P, P, POINTER(BhConvDesc), P, c_int64, POINTER(BhBnIn), P],
+    "bh_conv_wgrad_bnadj": [P, P, P, POINTER(BhConvDesc), P, c_int64, POINTER(BhBnIn), POINTER(BhBnAdj), P],
     "bh_bn_fwd_coeffs": [P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, P, P],
     "bh_conv_dgrad": [P, P, P, POINTER(BhConvDesc), c_int, P],
     "bh_conv_dgrad_colsum": [P, P, P, POINTER(BhConvDesc), P, P],

@@ -61,7 +61,7 @@ constexpr int C3_LDS_BYTES = 2 * C3_HALO_BYTES + 2 * C3_B_BYTES;      // 67584
 //  wave's (wm, wn, wh) roles.  s1 / s2 return the tile's column sums for c3_stats_merge.)
 template <int BN, int SUBT, int TM, bool MAP4 = false>
 __device__ __forceinline__ void c3_epilogue(const C3Args& a, f32x16 (&acc)[TM], int bx, int n0, int wm, int wn, int wh, int l31, int kh2,
-                                            double& s1, double& s2, int& img, int& g) {
+                                            double& s1, double& s2, int& img, int& g, float& amx) {
     // ---- epilogue: C/D layout col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m) ----
     // Element (i, r) of a lane is pixel (c3_strip_row(2*(r>>2) + kh2), 4*(i + wh) + (r&3)) of the sub-tile: the row part of
     // its address is one of four per-lane VGPRs, the column part (4*(i + wh) + (r&3)) * Nn is workgroup-uniform and rides in
@@ -176,6 +176,7 @@ __device__ __forceinline__ void c3_epilogue(const C3Args& a, f32x16 (&acc)[TM], 
                                     const float yv = ZM == 2 ? yin[i][r] : __builtin_fmaf(zv, r_sc, r_sh);
                                     if (!(yv > 0.f)) v = 0.f;
                                 }
+                                amx = fmaxf(amx, fabsf(v));            // (bh_bn_reduce.amax_d: max |mask(d)|)
                                 q1 += v; q2 = __builtin_fmaf(v, __builtin_fmaf(zv, r_invstd, c_x0), q2);
                             } else {
                                 q1 += v; q2 = __builtin_fmaf(v, v, q2);
@@ -375,6 +376,7 @@ __global__ void __launch_bounds__(256, X3 ? ((BN == 32 && NP == 2 && !BNI) ? C3_
         __syncthreads();
     }
     double S1 = 0.0, S2 = 0.0;                          // stat_acc: column sums over this workgroup's tile positions
+    float AMX = 0.0f;                                   // (a.amax_out: max |mask(d)| over this workgroup's tiles)
     int Simg = 0, Sg = 0x7fffffff, Sbx = 0;
     if (a.desync > 0 && (((blockIdx.x + gridDim.x * blockIdx.y) >> 8) & 1)) {
         for (int i = 0; i < a.desync; ++i) __builtin_amdgcn_s_sleep(127);
@@ -776,7 +778,7 @@ __global__ void __launch_bounds__(256, X3 ? ((BN == 32 && NP == 2 && !BNI) ? C3_
     }
     double s1, s2;
     int img, g;
-    c3_epilogue<BN, SUBT, TM, MAP4>(a, acc, bx, n0, wm, wn, wh, l31, kh2, s1, s2, img, g);
+    c3_epilogue<BN, SUBT, TM, MAP4>(a, acc, bx, n0, wm, wn, wh, l31, kh2, s1, s2, img, g, AMX);
     if (a.bn_sums) {
         if (a.stat_acc) { S1 += s1; S2 += s2; Sbx = bx; if (g < Sg) { Sg = g; Simg = img; } }    // (out-of-range sub-tiles add zero)
         else c3_stats_merge<BN, 0>(a, smem, s1, s2, img, g, bx, n0, wave, lane, tid);
@@ -788,6 +790,10 @@ __global__ void __launch_bounds__(256, X3 ? ((BN == 32 && NP == 2 && !BNI) ? C3_
     C3_STAMP(bx * gridDim.y + blockIdx.y, 3);
     }
     if (a.bn_sums && a.stat_acc) c3_stats_merge<BN, 0>(a, smem, S1, S2, Simg, Sg, Sbx, n0, wave, lane, tid);
+    if (a.amax_out) {                                    // one integer atomic max per wave (bits of a non-negative float order like integers)
+        const float m = wave_max(AMX);
+        if (lane == 0) atomicMax(a.amax_out + ((blockIdx.x * 4 + wave) % BH_AMAX_SLOTS) * BH_AMAX_STRIDE, __builtin_bit_cast(unsigned, m));
+    }
 }
 
 constexpr int C3_MIN_BLOCKS = 256;      // below this many workgroups the generic kernel's finer tiles fill the chip better
@@ -855,6 +861,7 @@ int bh_conv3x3_try(const float* src, const float* w, const float* bias, float* o
         if (!bnr->z || !bnr->stats) return BH_E_BADARG;
         a.bnr_z = bnr->z; a.bnr_y = bnr->y; a.bnr_stats = bnr->stats; a.bnr_gamma = bnr->gamma; a.bnr_beta = bnr->beta;
         a.bnr_eps = bnr->eps; a.bnr_relu = bnr->relu; a.bnr_rows = (d->N / groups) * d->Hi * d->Wi;
+        a.amax_out = reinterpret_cast<unsigned*>(bnr->amax_d);
     }
     a.res = res; a.relu = relu; a.dbg_nch = g_c3_dbg_nch;
     a.bn_sums = bn_sums; a.imgs_per_group = bn_sums ? d->N / groups : 1; a.groups = groups;

@@ -71,6 +71,8 @@ struct C3Args {
     // F16 (two fp16 pieces, common.h F16X2): magnitude record of Src (BH_AMAX_WORDS words); the weights' sixteen partial maxima sit
     // behind their pieces (word w_bytes / 4 of Wt, written by pack_weights_amax_kernel)
     const unsigned* amax_src;
+    // round 6 (bh_bn_reduce.amax_d): the BatchNorm-backward forms also leave max |mask(d)| of the gradient they write in this magnitude record
+    unsigned* amax_out;
 };
 
 

@@ -487,6 +487,7 @@ __global__ void __launch_bounds__(768) conv3x3_pc_kernel(C3Args a) {
         float4 r_invstd = bv, r_cx0 = bv, r_sc = bv, r_sh = bv;      // BatchNorm-reduce coefficients of the lane's four channels
         int cur_grp = -1, cur_n0 = 0;
         double S1[4] = {0.0, 0.0, 0.0, 0.0}, S2[4] = {0.0, 0.0, 0.0, 0.0};
+        float amx = 0.0f;                                 // (a.amax_out, BatchNorm-backward forms: max |mask(d)| of what this wave wrote)
         bool have = false;                                // S1 / S2 hold something
         // Statistics leave the workgroup with ONE f64 atomic per (channel, moment): stash() puts this wave's sums (reduced over its four pixel
         // lanes) into LDS, commit() - behind the next barrier - lets E wave 0 add the four waves' sums and issue the atomics.  Happens when the
@@ -606,6 +607,7 @@ __global__ void __launch_bounds__(768) conv3x3_pc_kernel(C3Args a) {
                         const float yv = rd_y ? y4[e] : __builtin_fmaf(z4[e], sc[e], sh[e]);
                         vm = (mask_on && !(yv > 0.f)) ? 0.f : v;
                         t = __builtin_fmaf(z4[e], isd[e], cx[e]);
+                        amx = fmaxf(amx, fabsf(vm));
                     }
                     S1[e] += (double)vm;
                     S2[e] = __builtin_fma((double)vm, (double)t, S2[e]);
@@ -689,6 +691,10 @@ __global__ void __launch_bounds__(768) conv3x3_pc_kernel(C3Args a) {
         }
         PC_BARRIER();                                     // F4
         commit();
+        if (rd_z && a.amax_out) {                         // one integer atomic max per E wave (bits of a non-negative float order like integers)
+            const float m = wave_max(amx);
+            if (lane == 0) atomicMax(a.amax_out + ((blockIdx.x * 4 + ew) % BH_AMAX_SLOTS) * BH_AMAX_STRIDE, __builtin_bit_cast(unsigned, m));
+        }
     }
 }
 }  // namespace

@@ -9,7 +9,7 @@
 #include "common.h"
 
 int bh_wgrad_x3_try(const float* x, const float* gy, float* gw, const bh_conv_desc* d, hipStream_t stream, int* taken, float* ws,
-                    long long ws_bytes, long long* ws_need, const bh_bn_in* bni = nullptr);    // wgrad_x3.hip
+                    long long ws_bytes, long long* ws_need, const bh_bn_in* bni = nullptr, const bh_bn_adj* bna = nullptr);    // wgrad_x3.hip
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -775,6 +775,18 @@ long long bh_conv_wgrad_det_bytes(const bh_conv_desc* d) {
     const int rc = conv_wgrad_impl(p, p, p, nullptr, d, nullptr, p, 0, &need);
     bh_query_ctx = saved;
     return rc == BH_OK ? need : 0;
+}
+
+// Round 6: the weight gradient whose gradient operand is a BatchNorm's adjoint applied on load (wgrad_x3_kernel<..., BNA>): `d` is the gradient
+// of the BatchNorm's OUTPUT, completed - with the sums of bna->sums - by bh_conv_dgrad_bnreduce; desc->b_bound is the magnitude record of d
+int bh_conv_wgrad_bnadj(const float* x, const float* d_out, float* gw, const bh_conv_desc* d, float* ws, long long ws_bytes, const bh_bn_in* bni,
+                        const bh_bn_adj* bna, void* stream) {
+    if (!d || !x || !d_out || !gw || !bna || !ws) return BH_E_BADARG;
+    if (d->precision != 4) return BH_E_UNSUPPORTED;
+    int taken = 0;
+    const int rc = bh_wgrad_x3_try(x, d_out, gw, d, bh_stream(stream), &taken, ws, ws_bytes, nullptr, bni, bna);
+    if (rc != BH_OK) return rc;
+    return taken ? BH_OK : BH_E_UNSUPPORTED;
 }
 
 int bh_conv_wgrad_bnin(const float* x, const float* gy, float* gw, float* gbias, const bh_conv_desc* d, float* ws, long long ws_bytes,

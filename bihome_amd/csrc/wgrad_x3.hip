@@ -56,6 +56,20 @@ struct WX3Args {
     // F16 (two fp16 pieces per operand, common.h F16X2): magnitude records of X (of the BatchNorm OUTPUT with BNI) and of GY
     const unsigned* amax_x;
     const unsigned* amax_gy;
+    // BNA (round 6): GY is d, the gradient of a training-mode BatchNorm's OUTPUT (not masked), and the operand the kernel contracts is
+    // that BatchNorm's adjoint, applied while the tile is staged:  g = sc (mask(d) - k1 - xhat(z) k2)  with z the BatchNorm's input
+    // (= this convolution's output), the mask y > 0 of the ReLU behind it (y recomputed as z sc + sh, or read from bna_y when a residual was
+    // added in front of the ReLU), k1 = sum mask(d) / rows, k2 = sum mask(d) xhat / rows from bna_sums (accumulated by the dgrad that made d:
+    // bh_conv_dgrad_bnreduce) and (mean, 1 / std) from the forward sums bna_stats.  amax_gy is then the magnitude record of d; the scale of
+    // the operand's fp16 pieces comes from the bound max_c |sc| (max |d| + |k1| + sqrt(rows) |k2|) over the workgroup's 64 channels.
+    const float* bna_z;
+    const float* bna_y;
+    const double* bna_stats;
+    const double* bna_sums;
+    const float* bna_gamma;
+    const float* bna_beta;
+    float bna_eps;
+    int bna_relu, bna_rows, bna_groups, bna_ipg;
 };
 
 // MAP4 (round 5, CB = 64): 4 x 4 feature maps (layer4 of the ResNet-34 regressor) - a tile is FOUR IMAGES laid out 2 x 2 as an 8 x 8 pixel block,
@@ -86,9 +100,10 @@ struct WXGeom {
 // blocks as the four-wave form: the results are bitwise the same; what changes is that the cut's VALU work and the LDS writes no longer
 // sit in the instruction stream of the wave that feeds the matrix pipe (which is alone on its SIMD and stalls for every one of them).
 // Two waves per SIMD leave 256 registers per wave: 144 accumulators + <= 112 for fragments and addresses.
-template <int CB, bool BNI = false, int NP = 3, bool F16 = false, bool PC = false, bool MAP4 = false>
+template <int CB, bool BNI = false, int NP = 3, bool F16 = false, bool PC = false, bool MAP4 = false, bool BNA = false>
 __global__ void __launch_bounds__(PC ? 512 : 256, 1) wgrad_x3_kernel(WX3Args a) {
     static_assert(!F16 || NP == 2, "fp16 pieces: two");
+    static_assert(!BNA || (CB == 64 && F16 && !MAP4), "BatchNorm adjoint on load: 64-channel blocks of fp16 pieces");
     static_assert(!PC || (CB == 64 && F16), "producer / consumer form: 64-channel blocks of fp16 pieces");
     static_assert(!MAP4 || (CB == 64 && F16), "4 x 4 maps: 64-channel blocks of fp16 pieces");
     using G = WXGeom<CB, NP, MAP4>;
@@ -110,6 +125,8 @@ __global__ void __launch_bounds__(PC ? 512 : 256, 1) wgrad_x3_kernel(WX3Args a) 
     }
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.GY), 0, a.gy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BNA ? a.bna_z : a.GY), 0, a.gy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((BNA && a.bna_y) ? a.bna_y : a.GY), 0, a.gy_bytes, 0x00020000);
 
     // ---- staging slots of this thread (tile independent parts): slot = (pixel, 8-channel group) -> 2 dwordx4, 3 ds_write_b128 ----
     // gy: 64 pixels x NG groups (GS per thread); halo: 100 x NG slots (HS per thread; the slots past the last one repeat it -
@@ -140,11 +157,51 @@ __global__ void __launch_bounds__(PC ? 512 : 256, 1) wgrad_x3_kernel(WX3Args a) 
     }
 
     float4 rg[GS][2], rx[HS][2];
+    float4 rz[BNA ? GS : 1][2], ry[BNA ? GS : 1][2];          // BNA: the BatchNorm's input (and saved output) of the gy slots
+    int g_tb = 0;                                                 // BNA: byte offset of the tile's statistics group in the coefficient table
+    const bool bna_rd_y = BNA && a.bna_y != nullptr;
     bool h_ok[HS];                                                // BNI: slot inside the image / statistics group of its image,
     int h_tb[HS];                                                 //      as byte offset of the slot's coefficients in the LDS table
 #pragma unroll
     for (int j = 0; j < HS; ++j) { h_ok[j] = false; h_tb[j] = 0; }
     constexpr int TB0 = 2 * G::LDS;                               // [groups][CB] x (scale, shift) of this workgroup's input-channel block
+    // BNA: [groups][8 channel groups][5 coefficients: sc, kz, kc, msc, msh][8 channels] floats behind the BNI table; one word for the bound
+    const int TBA0 = TB0 + (BNI ? a.bni_groups * CB * 8 : 0);
+    constexpr int TBA_GRP = (CB / 8) * 5 * 8 * 4;                 // bytes per statistics group
+    if constexpr (BNA) {
+        // coefficient table of the workgroup's 64 output channels (this thread: channel i % 64 of group i / 64) and the bound of |g|
+        unsigned* const bnd = reinterpret_cast<unsigned*>(smem + TBA0 + a.bna_groups * TBA_GRP);
+        if (threadIdx.x == 0) *bnd = 0u;
+        __syncthreads();
+        if (!PC || producer) {
+            const float maxd = __builtin_bit_cast(float, bh_amax_read(a.amax_gy, lane));
+            const double inv_rows = 1.0 / (double)a.bna_rows;
+            const float invn = 1.0f / (float)a.bna_rows, sqn = sqrtf((float)a.bna_rows);
+            for (int i = tid; i < a.bna_groups * CB; i += 256) {
+                const int grp = i / CB, ch = i - grp * CB, c = co0 + ch;
+                // (the arithmetic of bn_bwd_apply_kernel's coefficients, csrc/bn.hip: mean / variance in double, the rest in float)
+                const double m = bn_sum_total(a.bna_stats, a.bna_groups, grp, a.Co, c, 0) * inv_rows;
+                double var = bn_sum_total(a.bna_stats, a.bna_groups, grp, a.Co, c, 1) * inv_rows - m * m;
+                if (var < 0) var = 0;
+                const float mean = (float)m, invstd = 1.0f / sqrtf((float)var + a.bna_eps);
+                const float sc = (a.bna_gamma ? a.bna_gamma[c] : 1.f) * invstd, sh = (a.bna_beta ? a.bna_beta[c] : 0.f) - mean * sc;
+                const float k1 = (float)bn_sum_total(a.bna_sums, a.bna_groups, grp, a.Co, c, 0) * invn;
+                const float k2 = (float)bn_sum_total(a.bna_sums, a.bna_groups, grp, a.Co, c, 1) * invn;
+                // g = sc (dm - k1 - (z - mean) invstd k2) = sc dm + kz z + kc
+                const float kz = -sc * invstd * k2, kc = sc * (mean * invstd * k2 - k1);
+                float* const tb = reinterpret_cast<float*>(smem + TBA0 + grp * TBA_GRP + (ch >> 3) * 160) + (ch & 7);
+                tb[0] = sc; tb[8] = kz; tb[16] = kc; tb[24] = sc; tb[32] = sh;
+                const float bound = fabsf(sc) * (maxd + fabsf(k1) + sqn * fabsf(k2));
+                atomicMax(bnd, __builtin_bit_cast(unsigned, bound));       // (bits of a non-negative float order like integers; NaN / inf: loud)
+            }
+        }
+        __syncthreads();
+        if constexpr (F16) {
+            const int kg = bh_f16_scale_exp(*bnd);
+            f16_sg = __builtin_bit_cast(float, (unsigned)(127 + kg) << 23);
+            f16_kout = -(bh_f16_scale_exp(bh_amax_read(a.amax_x, lane)) + kg);
+        }
+    }
     if constexpr (BNI) {
         if (!PC || producer) {
             for (int i = tid; i < a.bni_groups * CB; i += 256) {
@@ -169,7 +226,16 @@ __global__ void __launch_bounds__(PC ? 512 : 256, 1) wgrad_x3_kernel(WX3Args a) 
                 const unsigned off = ((unsigned)(org + g_pix[j]) * (unsigned)a.Co + (unsigned)(co0 + g_cg[j])) * 4u;
                 rg[j][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsG, off, 0, 0));
                 rg[j][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsG, off + 16u, 0, 0));
+                if constexpr (BNA) {
+                    rz[j][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsZ, off, 0, 0));
+                    rz[j][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsZ, off + 16u, 0, 0));
+                    if (bna_rd_y) {
+                        ry[j][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsY, off, 0, 0));
+                        ry[j][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsY, off + 16u, 0, 0));
+                    }
+                }
             }
+            if constexpr (BNA) g_tb = TBA0 + (img / a.bna_ipg) * TBA_GRP;
         }
 #pragma unroll
         for (int j = 0; j < HS; ++j) {
@@ -189,6 +255,28 @@ __global__ void __launch_bounds__(PC ? 512 : 256, 1) wgrad_x3_kernel(WX3Args a) 
         constexpr int sl = decltype(SLOT)::value;
         uint4 p[3];
         if constexpr (sl < GS) {
+            if constexpr (BNA) {
+                // the BatchNorm adjoint of the slot's 8 channels: g = sc * mask(d) + kz * z + kc (a gy tile has no padding: every slot is a pixel)
+                const float4* tb = reinterpret_cast<const float4*>(smem + g_tb + (g_cg[sl] >> 3) * 160);
+                const float4 sc0 = tb[0], sc1 = tb[1], kz0 = tb[2], kz1 = tb[3], kc0 = tb[4], kc1 = tb[5], ms0 = tb[6], ms1 = tb[7], mh0 = tb[8], mh1 = tb[9];
+                float4& d0 = rg[sl][0];
+                float4& d1 = rg[sl][1];
+                const float4 z0 = rz[sl][0], z1 = rz[sl][1];
+                if (a.bna_relu) {
+                    float4 y0, y1;
+                    if (bna_rd_y) { y0 = ry[sl][0]; y1 = ry[sl][1]; }
+                    else {
+                        y0 = make_float4(__builtin_fmaf(z0.x, ms0.x, mh0.x), __builtin_fmaf(z0.y, ms0.y, mh0.y), __builtin_fmaf(z0.z, ms0.z, mh0.z), __builtin_fmaf(z0.w, ms0.w, mh0.w));
+                        y1 = make_float4(__builtin_fmaf(z1.x, ms1.x, mh1.x), __builtin_fmaf(z1.y, ms1.y, mh1.y), __builtin_fmaf(z1.z, ms1.z, mh1.z), __builtin_fmaf(z1.w, ms1.w, mh1.w));
+                    }
+                    if (!(y0.x > 0.f)) d0.x = 0.f; if (!(y0.y > 0.f)) d0.y = 0.f; if (!(y0.z > 0.f)) d0.z = 0.f; if (!(y0.w > 0.f)) d0.w = 0.f;
+                    if (!(y1.x > 0.f)) d1.x = 0.f; if (!(y1.y > 0.f)) d1.y = 0.f; if (!(y1.z > 0.f)) d1.z = 0.f; if (!(y1.w > 0.f)) d1.w = 0.f;
+                }
+                d0.x = __builtin_fmaf(sc0.x, d0.x, __builtin_fmaf(kz0.x, z0.x, kc0.x)); d0.y = __builtin_fmaf(sc0.y, d0.y, __builtin_fmaf(kz0.y, z0.y, kc0.y));
+                d0.z = __builtin_fmaf(sc0.z, d0.z, __builtin_fmaf(kz0.z, z0.z, kc0.z)); d0.w = __builtin_fmaf(sc0.w, d0.w, __builtin_fmaf(kz0.w, z0.w, kc0.w));
+                d1.x = __builtin_fmaf(sc1.x, d1.x, __builtin_fmaf(kz1.x, z1.x, kc1.x)); d1.y = __builtin_fmaf(sc1.y, d1.y, __builtin_fmaf(kz1.y, z1.y, kc1.y));
+                d1.z = __builtin_fmaf(sc1.z, d1.z, __builtin_fmaf(kz1.z, z1.z, kc1.z)); d1.w = __builtin_fmaf(sc1.w, d1.w, __builtin_fmaf(kz1.w, z1.w, kc1.w));
+            }
             bh_split8_any<NP, F16>(rg[sl][0], rg[sl][1], f16_sg, p);
 #pragma unroll
             for (int pc = 0; pc < NP; ++pc) *reinterpret_cast<uint4*>(img + g_lds[sl] + pc * G::GP) = p[pc];
@@ -415,7 +503,7 @@ void bh_wgrad_x3_tune(int what, int v) { if (what == 0) g_wx3_target = v; else i
 // *taken = 1 when the shape is eligible (3x3 / stride 1 / pad 1, NHWC, H and W multiples of 8, channels multiples of 32).
 // ws != NULL: deterministic reduction through ws (ws_need != NULL: dry run that only reports the bytes needed)
 int bh_wgrad_x3_try(const float* x, const float* gy, float* gw, const bh_conv_desc* d, hipStream_t stream, int* taken, float* ws,
-                    long long ws_bytes, long long* ws_need, const bh_bn_in* bni) {
+                    long long ws_bytes, long long* ws_need, const bh_bn_in* bni, const bh_bn_adj* bna) {
     *taken = 0;
     if (d->transposed || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->in_nchw || d->out_nchw) return BH_OK;
     // 4 x 4 maps (round 5: layer4 of the ResNet-34 regressor): fp16 pieces, 64-channel blocks, four images per tile
@@ -449,7 +537,16 @@ int bh_wgrad_x3_try(const float* x, const float* gy, float* gw, const bh_conv_de
         if (!bni->table || bni->groups < 1 || bni->groups > 4 || d->N % bni->groups) return BH_E_BADARG;
         a.bni = bni->table; a.bni_relu = bni->relu; a.bni_groups = bni->groups; a.bni_ipg = d->N / bni->groups;
     }
-    const int tb_bytes = bni ? bni->groups * cb * 8 : 0;
+    if (bna) {
+        // the BatchNorm adjoint on load: fp16 pieces, 64-channel blocks, whole images per statistics group, no 4 x 4 maps
+        if (!bna->z || !bna->stats || !bna->sums || bna->groups < 1 || bna->groups > 4 || d->N % bna->groups) return BH_E_BADARG;
+        if (cb != 64 || map4 || !(d->precision == 4 && d->a_bound && d->b_bound) || !ws) return BH_OK;
+        a.bna_z = bna->z; a.bna_y = (bna->relu && bna->y) ? bna->y : nullptr; a.bna_stats = bna->stats; a.bna_sums = bna->sums;
+        a.bna_gamma = bna->gamma; a.bna_beta = bna->beta; a.bna_eps = bna->eps; a.bna_relu = bna->relu ? 1 : 0;
+        a.bna_groups = bna->groups; a.bna_ipg = d->N / bna->groups;
+        a.bna_rows = a.bna_ipg * d->Hi * d->Wi;
+    }
+    const int tb_bytes = (bni ? bni->groups * cb * 8 : 0) + (bna ? bna->groups * 1280 + 16 : 0);
     const long long need = (long long)pairs * ns * 36864 * 4;
     if (ws) {
         if (ws_need) *ws_need = need;
@@ -465,8 +562,29 @@ int bh_wgrad_x3_try(const float* x, const float* gy, float* gw, const bh_conv_de
     const bool pc = f16 && cb == 64 && (d->route & BH_ROUTE_WX3_PC) && g_wx3_pc;
     // (all six template arguments, as rocprofv3 prints the symbol: CB, BNI, NP, F16, PC, MAP4)
     if (bh_query(ws ? "wgrad_x3_kernel<%d,%s,%d,%s%s>+wgrad_x3_reduce_kernel<%d>" : "wgrad_x3_kernel<%d,%s,%d,%s%s>", cb, bni ? "true" : "false",
-                 (d->precision == 4 && !f16) ? 3 : np, f16 ? "true" : "false", map4 ? (pc ? ",true,true" : ",false,true") : (pc ? ",true,false" : ",false,false"), cb)) { *taken = 1; return BH_OK; }
+                 (d->precision == 4 && !f16) ? 3 : np, f16 ? "true" : "false",
+                 bna ? (pc ? ",true,false,true" : ",false,false,true") : map4 ? (pc ? ",true,true" : ",false,true") : (pc ? ",true,false" : ",false,false"), cb)) { *taken = 1; return BH_OK; }
     typedef void (*kern_t)(WX3Args);
+    if (bna) {
+        // (four instantiations: BatchNorm-on-load of x {no, yes} x {four-wave, eight-wave form})
+        static const kern_t afn[4] = {wgrad_x3_kernel<64, false, 2, true, false, false, true>, wgrad_x3_kernel<64, true, 2, true, false, false, true>,
+                                      wgrad_x3_kernel<64, false, 2, true, true, false, true>, wgrad_x3_kernel<64, true, 2, true, true, false, true>};
+        constexpr int lds_a = 2 * WXGeom<64, 2>::LDS;
+        static unsigned long long attr_devs_a = 0;
+        if (bh_device_once(attr_devs_a)) {
+            for (int i = 0; i < 4; ++i) {
+                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(afn[i]), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                         lds_a + 4 * 64 * 8 + 4 * 1280 + 16);
+                if (e != hipSuccess) return (int)e;
+            }
+        }
+        hipLaunchKernelGGL(afn[(pc ? 2 : 0) + (bni ? 1 : 0)], dim3(pairs * ns), dim3(pc ? 512 : 256), lds_a + tb_bytes, stream, a);
+        BH_LAUNCH_CHECK();
+        hipLaunchKernelGGL(wgrad_x3_reduce_kernel<64>, dim3(36864 / 64, pairs), dim3(256), 0, stream, ws, gw, ns, a.cbi, d->Ci);
+        BH_LAUNCH_CHECK();
+        *taken = 1;
+        return BH_OK;
+    }
     static const kern_t fns[18] = {wgrad_x3_kernel<64, false, 3>, wgrad_x3_kernel<32, false, 3>, wgrad_x3_kernel<64, true, 3>, wgrad_x3_kernel<32, true, 3>,
                                    wgrad_x3_kernel<64, false, 2>, wgrad_x3_kernel<32, false, 2>, wgrad_x3_kernel<64, true, 2>, wgrad_x3_kernel<32, true, 2>,
                                    wgrad_x3_kernel<64, false, 2, true>, wgrad_x3_kernel<32, false, 2, true>, wgrad_x3_kernel<64, true, 2, true>, wgrad_x3_kernel<32, true, 2, true>,

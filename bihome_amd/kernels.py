@@ -5,7 +5,7 @@ import os
 
 import torch
 
-from ._lib import (AMAX_FLOATS, BN_DETERMINISTIC, F_DETERMINISTIC, GEOMETRY_FIELDS, ROUTE_DETERMINISTIC, ROUTE_WX3_PC, ROUTE_WX3_SHARED, BhBnIn, BhBnReduce, BhConvDesc,
+from ._lib import (AMAX_FLOATS, BN_DETERMINISTIC, F_DETERMINISTIC, GEOMETRY_FIELDS, ROUTE_DETERMINISTIC, ROUTE_WX3_PC, ROUTE_WX3_SHARED, BhBnAdj, BhBnIn, BhBnReduce, BhConvDesc,
                    BhPack3x3Job, check, lib)
 
 
@@ -810,7 +810,10 @@ def conv_dgrad(gy, w, d, out=None, bn_reduce=None, wkey=None, wpacked=None, cols
             out = torch.empty((d.N, d.Hi, d.Wi, d.Ci), dtype=torch.float32, device=gy.device)
         b = bn_reduce
         _chk(b["z"]); _chk(b["y"]); _chk(b["stats"], torch.float64); _chk(b["sums"], torch.float64)
-        st = BhBnReduce(_p(b["z"]), _p(b["y"]), _p(b["stats"]), _p(b["gamma"]), _p(b["beta"]), float(b["eps"]), int(bool(b["relu"])))
+        # (amax_d, round 6: a zeroed magnitude record that receives max |mask(d)| of the gradient written - conv_wgrad_bnadj's scale bound)
+        _chk(b.get("amax_d"))
+        st = BhBnReduce(_p(b["z"]), _p(b["y"]), _p(b["stats"]), _p(b["gamma"]), _p(b["beta"]), float(b["eps"]), int(bool(b["relu"])),
+                        _p(b.get("amax_d")))
         with _Timed(_conv_variant(d, "dgrad_bnr_y" if b["y"] is not None else "dgrad_bnr_z", acc, int(b["groups"])), conv_flops(d),
                     4.0 * (gy.numel() + out.numel() * ((3 if acc else 2) + (1 if b["y"] is not None else 0)) + w.numel())):
             check(lib.bh_conv_dgrad_bnreduce(_p(gy), _p(w), _p(out), ctypes.byref(d), int(acc), ctypes.byref(st), _p(b["sums"]),
@@ -878,6 +881,34 @@ def wgrad_det_bytes(d):
 _STEM_WGRAD_WS = {}      # (device, bytes, stream) -> the stem weight gradient's partial-sum workspace: launches of ONE stream serialise on it;
                          # another stream (a second model's side stream) gets its own.  Allocated by a step's first eager run - GraphedStep
                          # warms up eagerly before it captures, so the buffer is never born inside a graph's private pool
+
+
+def conv_wgrad_bnadj(x, dout, gw, d, ws, bna, amax_d):
+    """Round 6 (bh_conv_wgrad_bnadj): the weight gradient of a 3x3 conv whose output feeds a training-mode BatchNorm, from the gradient
+    `dout` of that BatchNorm's OUTPUT - the adjoint is applied while the kernel stages its operand.  x: the conv's input (tensor or
+    BnOnLoad); bna: dict(z, y, stats, sums, gamma, beta, eps, relu, groups) as conv_dgrad's bn_reduce plus the backward sums it filled;
+    amax_d: the magnitude record conv_dgrad(..., bn_reduce=dict(amax_d=...)) left.  Returns False where the kernel does not apply
+    (nothing was launched: run bn_bwd and conv_wgrad as before)."""
+    _route_det(d)
+    if d.precision != F16X2 or not getattr(d, "bh_wx3", True) or ws is None or deterministic():
+        return False
+    bol = x if isinstance(x, BnOnLoad) else None
+    xt = x.z if bol is not None else x
+    _chk(xt); _chk(dout); _chk(gw); _chk(ws); _chk(amax_d); _chk(bna["z"]); _chk(bna["y"]); _chk(bna["stats"], torch.float64); _chk(bna["sums"], torch.float64)
+    d.a_bound, d.b_bound = amax_of(x).data_ptr(), amax_d.data_ptr()
+    st = BhBnAdj(_p(bna["z"]), _p(bna["y"]), _p(bna["stats"]), _p(bna["sums"]), _p(bna["gamma"]), _p(bna["beta"]), float(bna["eps"]),
+                 int(bool(bna["relu"])), int(bna["groups"]))
+    bs = bol.struct() if bol is not None else None
+    name = ""
+    if TIMING is not None:
+        name = conv_variant(d, "wgrad_det").replace(",false,false>", ",false,false,true>").replace(",true,false>", ",true,false,true>") + (" bnin" if bol is not None else "")
+    with _Timed(name, conv_flops(d), 4.0 * (xt.numel() + dout.numel() * (3 if bna["y"] is not None else 2) + gw.numel())):
+        rc = lib.bh_conv_wgrad_bnadj(_p(xt), _p(dout), _p(gw), ctypes.byref(d), _p(ws), ws.numel() * 4, ctypes.byref(bs) if bs is not None else None,
+                                     ctypes.byref(st), _stream())
+    if rc == -2:
+        return False
+    check(rc, "bh_conv_wgrad_bnadj")
+    return True
 
 
 def conv_wgrad(x, gy, gw, gbias, d, det_ws=None):

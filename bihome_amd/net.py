@@ -601,7 +601,8 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
     plan_key = (bool(ctx.training), bool(want_wgrad), int(ctx.groups), tuple(gout.shape), frozenset(ctx.joined.items()), frozenset(ctx.descs),
                 getattr(ctx, "precision", 0),
                 tuple((op.mod.weight.requires_grad, op.mod.bias is not None and op.mod.bias.requires_grad) for op in prog.ops if op.kind == "conv"),
-                os.environ.get("BIHOME_FUSE_BN_REDUCE", "1"), os.environ.get("BIHOME_FUSE_BIAS_GRAD", "1"), os.environ.get("BIHOME_BN_FROM_1X1", "1"))
+                os.environ.get("BIHOME_FUSE_BN_REDUCE", "1"), os.environ.get("BIHOME_FUSE_BIAS_GRAD", "1"), os.environ.get("BIHOME_BN_FROM_1X1", "1"),
+                os.environ.get("BIHOME_WGRAD_BNADJ", "0"))
     plans = prog.__dict__.setdefault("_bw_plans", {})
     cached = plans.get(plan_key) if os.environ.get("BIHOME_PLAN_CACHE", "1") != "0" else None
     consumed_by = {}
@@ -660,6 +661,28 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
                     and prog.ops[b].mod.num_features % 4 == 0 and 256 % (prog.ops[b].mod.num_features // 4) == 0
                     and not op.extra["in_nchw"] and not op.extra["out_nchw"]):
                 from_1x1.add(j)
+    # Round 6 (round-5 VERDICT item 2): a fused BatchNorm whose input comes from a 3x3 conv with an fp16-piece weight gradient - that
+    # weight gradient takes the BatchNorm's adjoint ON LOAD (kernels.conv_wgrad_bnadj): it reads the gradient of the BatchNorm's output,
+    # the BatchNorm's input and the sums the dgrad epilogue made, so it is enqueued IN FRONT of the BatchNorm's adjoint pass and runs next
+    # to that HBM-bound pass instead of behind it.  bn op index -> conv op index
+    # MEASURED AND NOT ADOPTED (profiles/r06g_wx3_bnadj_ab.txt, r06g_step_ab_bnadj.txt): the second operand stream and its transform cost
+    # the weight-gradient kernel 6-15 us per launch alone (four waves 45.9 -> 61.4 us on 32 x 32 x 64, eight waves 43.8 -> 49.8) - as much as
+    # the 12-22 us adjoint pass it no longer waits for - and the step gets 0.27 ms SLOWER (13.34 against 13.07 ms, three alternating runs on
+    # one box).  The form stays behind BIHOME_WGRAD_BNADJ=1 (C ABI entry, parity test tests/test_f16x2_gpu.py); the default is off.
+    bnadj = {}
+    if (cached is None and want_wgrad and ctx.training and getattr(ctx, "precision", 0) == K.F16X2
+            and os.environ.get("BIHOME_WGRAD_BNADJ", "0") != "0"):
+        producer_c = {op.dst: j for j, op in enumerate(prog.ops)}
+        for b in fuse_bn.values():
+            c = producer_c.get(prog.ops[b].src)
+            if c is None or prog.ops[c].kind != "conv" or c not in ctx.descs or consumed_by.get(prog.ops[b].src, 0) != 1:
+                continue
+            cm, cd = prog.ops[c].mod, ctx.descs[c]
+            if (isinstance(cm, nn.Conv2d) and cm.kernel_size == (3, 3) and cm.stride == (1, 1) and cm.padding == (1, 1) and cm.weight.requires_grad
+                    and prog.ops[c].extra["weight_fn"] is None and not (cm.bias is not None and cm.bias.requires_grad)
+                    and getattr(cd, "bh_wx3", False) and cd.Ci % 64 == 0 and cd.Co % 64 == 0 and cd.Hi % 8 == 0 and cd.Wi % 8 == 0
+                    and cd.N % ctx.groups == 0):
+                bnadj[b] = c
     red_off, total = {}, 0
     bias_off = {}
     if cached is None:
@@ -669,9 +692,9 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
         for b in fuse_bn.values():
             red_off[b] = total
             total += K.bn_stats_doubles(ctx.groups, prog.ops[b].mod.num_features)
-        plans[plan_key] = (consumed_by, fuse_bn, fuse_bias, from_1x1, red_off, bias_off, total)
+        plans[plan_key] = (consumed_by, fuse_bn, fuse_bias, from_1x1, red_off, bias_off, total, bnadj)
     else:
-        consumed_by, fuse_bn, fuse_bias, from_1x1, red_off, bias_off, total = cached
+        consumed_by, fuse_bn, fuse_bias, from_1x1, red_off, bias_off, total, bnadj = cached
     if os.environ.get("BIHOME_BN_PLAN") == "1" and not getattr(prog, "_bn_plan_printed", False):
         # tools/: which BatchNorm adjoints still run their own reduce pass, and what completes their output gradient
         prog._bn_plan_printed = True
@@ -698,8 +721,10 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
     bn_reduced = {}
     # precision 4: magnitude records of the BatchNorm input gradients (the gy operand of the fp16-piece dgrad / weight-gradient kernels)
     amax_next = None
-    nrec = max(1, sum(1 for op in prog.ops if op.kind == "bn")) if getattr(ctx, "precision", 0) == K.F16X2 else 0
+    nrec = (max(1, sum(1 for op in prog.ops if op.kind == "bn")) + len(bnadj)) if getattr(ctx, "precision", 0) == K.F16X2 else 0
     red_arena, amax_arena = _zero_arenas(total, nrec * K.AMAX_FLOATS, gout.device)    # (one fill launch for both)
+    bnadj_on = wgrad_stream is not None and bool(bnadj)     # (only where a second stream exists: what the form buys is the earlier start)
+    amax_d_of, wgrad_done = {}, set()
     if nrec:
         amax_iter = iter(amax_arena.split(K.AMAX_FLOATS))
         amax_next = lambda: next(amax_iter)
@@ -714,7 +739,7 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
         if op.kind == "conv":
             d, wk = ctx.descs[i], ctx.weights[i]
             m = op.mod
-            if want_wgrad and m.weight.requires_grad and op.extra["weight_fn"] is None:
+            if want_wgrad and m.weight.requires_grad and op.extra["weight_fn"] is None and i not in wgrad_done:
                 gw = m.weight.grad if m.weight.dim() == 2 else kview(m.weight.grad)
                 gb = m.bias.grad if (m.bias is not None and m.bias.requires_grad) else None
                 has_gb = gb is not None
@@ -764,6 +789,8 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
                                stats=ctx.stats[b], gamma=bm.weight, beta=bm.bias, eps=bm.eps, relu=bop.relu, sums=sums,
                                groups=ctx.groups)
                     bn_reduced[b] = sums
+                    if bnadj_on and b in bnadj and amax_next is not None:
+                        red["amax_d"] = amax_d_of[b] = amax_next()      # (max |mask(d)|: the bound of the on-load adjoint's fp16 scale)
                 if i in fuse_bias and op.src not in grads and red is None:
                     p = fuse_bias[i]
                     grads[op.src] = K.conv_dgrad(g, wk, d, wpacked=ctx.wpacked.get(i),
@@ -818,6 +845,26 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
                 if need_src_grad:
                     contribute(op.src, gx)
                 continue
+            if bnadj_on and i in amax_d_of and isinstance(g, torch.Tensor):
+                c = bnadj[i]
+                cop, cd, cm = prog.ops[c], ctx.descs[c], prog.ops[c].mod
+                xin = slots[cop.src]
+                if isinstance(xin, (torch.Tensor, K.BnOnLoad)) and x3_ws is not None:
+                    cd.route = (cd.route & ~K.ROUTE_WX3_PC) | K.ROUTE_WX3_SHARED
+                    K.amax_of(xin)                                    # (made - if missing - on the main stream, in front of the event)
+                    ev = torch.cuda.Event()
+                    ev.record(main)                                   # d and its sums are final here; the adjoint pass below has not started
+                    g.record_stream(wgrad_stream)
+                    with torch.cuda.stream(wgrad_stream):
+                        wgrad_stream.wait_event(ev)
+                        done = K.conv_wgrad_bnadj(xin, g, kview(cm.weight.grad), cd, x3_ws,
+                                                  dict(z=x, y=yb if (op.relu and op.res is not None) else None, stats=ctx.stats[i],
+                                                       sums=bn_reduced[i], gamma=m.weight, beta=m.bias, eps=m.eps, relu=op.relu, groups=ctx.groups),
+                                                  amax_d_of[i])
+                    if done:
+                        wgrad_done.add(c)
+                        if on_param_grad is not None:
+                            on_param_grad(cm.weight)
             gx, gres = K.bn_bwd(g, yb, x, m.weight, ctx.stats[i], m.running_mean, m.running_var, ctx.groups,
                                 m.eps, op.relu, ctx.training, op.res is not None and ((op.res != 0) or want_input_grad),
                                 m.weight.grad if train_w else None, m.bias.grad if train_w else None, beta=m.bias,

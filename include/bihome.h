@@ -342,6 +342,32 @@ int bh_conv_fwd_bnin(const float* x, const float* w, const float* bias, float* y
                      const bh_bn_in* bni, void* stream);
 int bh_conv_wgrad_bnin(const float* x, const float* gy, float* gw, float* gbias, const bh_conv_desc* d, float* ws, long long ws_bytes,
                        const bh_bn_in* bni, void* stream);
+/* BatchNorm ADJOINT on load (round 6; round-5 VERDICT item 2): the weight gradient of a 3x3 / stride-1 convolution whose output z feeds a
+ * training-mode BatchNorm (+ReLU, + optional residual in front of the ReLU: src/backbones/utils.py:85-131 conv -> bn -> relu chains),
+ * computed from the gradient d of that BatchNorm's OUTPUT instead of the gradient of z:
+ *     gw[co][tap][ci] += sum_pixels g[pixel][co] x[pixel + tap][ci],   g = sc (mask(d) - k1 - xhat(z) k2)
+ * with the BatchNorm's adjoint g applied while the kernel stages its operand - sc = gamma / std, xhat = (z - mean) / std from the forward
+ * sums `stats`; k1 = sum mask(d) / rows, k2 = sum mask(d) xhat / rows from `sums`, which bh_conv_dgrad_bnreduce accumulated when it
+ * completed d; mask = (y > 0), y read from `y` (a residual was added in front of the ReLU) or recomputed as z sc + shift (y NULL); relu 0:
+ * no mask.  The launch therefore needs neither the BatchNorm's adjoint pass (bh_bn_bwd) nor its output tensor: it can start as soon as
+ * the dgrad that made d has finished, next to the HBM-bound adjoint pass instead of behind it.  x, bni as bh_conv_wgrad_bnin (bni NULL:
+ * x as it is).  desc->precision = 4 with desc->a_bound = the magnitude record of x and desc->b_bound = the record of d (max |d|:
+ * bh_conv_dgrad_bnreduce_amax leaves it); the fp16 scale of g comes from the a-priori bound max_c |sc| (max |d| + |k1| + sqrt(rows) |k2|).
+ * ws / ws_bytes: the partial-block workspace (bh_conv_wgrad_det_bytes).  BH_E_UNSUPPORTED where wgrad_x3_kernel's 64-channel fp16-piece
+ * form does not apply (the caller runs bh_bn_bwd and bh_conv_wgrad_* as before). */
+typedef struct {
+    const float* z;        /* the BatchNorm's input = the convolution's output [N,H,W,Co] */
+    const float* y;        /* the saved output behind the ReLU, or NULL (mask recomputed from z) */
+    const double* stats;   /* forward sums of z: bh_bn_stats_doubles(groups, Co) */
+    const double* sums;    /* backward sums (sum mask(d), sum mask(d) xhat), same layout */
+    const float* gamma;    /* NULL: 1 */
+    const float* beta;     /* NULL: 0 */
+    float eps;
+    int relu;
+    int groups;            /* statistics groups: equal stacks of images along N */
+} bh_bn_adj;
+int bh_conv_wgrad_bnadj(const float* x, const float* d_out, float* gw, const bh_conv_desc* desc, float* ws, long long ws_bytes,
+                        const bh_bn_in* bni, const bh_bn_adj* bna, void* stream);
 /* y = conv(x, w) + bias, and sums (bh_bn_stats_doubles(groups, Co) doubles, caller-zeroed) += per-channel (sum y, sum y^2) of each of the
  * `groups` sub-batches stacked along N: the batch statistics of the BatchNorm that follows, accumulated in the conv
  * epilogue (halo-tiled 3x3 kernel; generic implicit GEMM incl. ConvTranspose2d when the pixels of a group are a
@@ -366,6 +392,8 @@ typedef struct bh_bn_reduce {
     const float* beta;
     float eps;
     int relu;
+    float* amax_d;         /* round 6, optional: caller-zeroed magnitude record (BH_AMAX_FLOATS floats) that receives max |mask(d)| of the gradient
+                              written - what bh_conv_wgrad_bnadj's scale bound needs; NULL: not measured */
 } bh_bn_reduce;
 /* bh_conv_dgrad that also accumulates, in its epilogue, the backward sums of that BatchNorm (sum g*mask, sum g*mask*xhat
  * per group and channel) into `sums` (bh_bn_stats_doubles(groups, Ci) doubles, caller-zeroed): pass them to bh_bn_bwd

@@ -186,13 +186,17 @@ def test_pds_coco_three_steps_vs_golden(golden, precision):
     for it in (1, 2):
         sp_l, sp_m = abs(g32["loss"][it] - g64["loss"][it]), abs(g32["mace"][it] - g64["mace"][it])
         assert abs(losses[it] - g64["loss"][it]) <= max(5 * sp_l, 0.05 * abs(g64["loss"][it])), (it, losses, g64["loss"])
-        # (0.1 px of 24.7: training from random weights at B = 8 is chaotic after the first Adam step.  profiles/r04_pds_chaos.txt: at the
-        #  third step the fp32-input MFMA arithmetic itself lands 0.059 px from the float64 reference, f32x3 0.049, f16x2 0.055, f32x2 0.091 -
-        #  each repeatable to 0.001 from run to run; the 0.05 of rounds 2-3 was passed by f32x3 with 0.001 to spare)
-        # (round 5: the bit-exact 'f32x3' arithmetic runs the same three steps - it lands 0.086 px from the reference at the third step in this
-        #  build, 0.049 in round 3's, the default arithmetic 0.052: which side of 0.05 a build falls on is the chaos of the trajectory, not
-        #  its arithmetic, so both are held at 0.1)
-        assert abs(maces[it] - g64["mace"][it]) <= max(10 * sp_m, 0.1), (it, maces, g64["mace"])
+        # Training from random weights at B = 8 amplifies rounding-level differences ~20x per Adam step, and round 6 measured how far (round-5
+        # ADVICE asked for the cause of f32x3's 0.086 px): (1) tools/grad_arith_diff.py - the first step's gradient of ANY two arithmetics
+        # differs by 1-2 % in EVERY tensor incl. the last layer's bias, for forward passes that agree to 1e-6: the bilinear warp's derivative
+        # jumps where a sample coordinate crosses an integer, and dL/dH is a near-cancelling sum over 16 k pixels - one pixel on the other
+        # side of a kink moves it by ~1 % (the float32 reference sits the same 0.5-1 % from its float64 self, tests/test_fullsize_gpu.py);
+        # (2) profiles/r06f_pds_perturb.txt - multiplying the INPUTS by (1 + k 2^-22), k = 0..8, moves the third step's MACE of one and the
+        # same arithmetic over -0.062 ... +0.027 px (fp32-input MFMA) and -0.069 ... +0.037 px (fp16 pieces): standard deviation 0.03 px for
+        # both, no arithmetic stands out; (3) profiles/r06e_pds_variants.txt - the kernel-fusion switches (which do not touch the forward
+        # pass) move it by < 0.012 px.  The third step is therefore held at 0.15 px (5 sigma of that spread; f32x3 lands at -0.104 in this
+        # build, -0.049 in round 3's), the second at 0.03; the first step - before any update - stays at the north_star tolerances above.
+        assert abs(maces[it] - g64["mace"][it]) <= max(10 * sp_m, 0.03 if it == 1 else 0.15), (it, maces, g64["mace"])
 
 
 @pytest.mark.parametrize("base,loss_name", [("zeng-ihome", None), ("zeng-multihead", "L1Loss")])

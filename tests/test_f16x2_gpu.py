@@ -288,3 +288,82 @@ def test_f16x2_a_wrong_record_is_loud_not_silently_wrong(K):
     x._bh_amax = None
     y = K.conv_fwd(x, wk, None, d, wpacked=pf)           # no record: measured by a streaming pass
     assert x._bh_amax is not None and x._bh_amax.max().item() == x.abs().max().item() and _rel(y, ref) < 1e-6
+
+
+@pytest.mark.parametrize("N,H,Ci,C,C2,residual,bni", [(8, 16, 64, 64, 64, False, False), (4, 32, 64, 128, 128, True, False), (16, 8, 256, 256, 256, False, True),
+                                                      (6, 24, 128, 64, 64, True, True), (128, 32, 64, 64, 64, False, False)])
+def test_wgrad_with_the_batchnorm_adjoint_on_load(K, N, H, Ci, C, C2, residual, bni):
+    """Round 6 (bh_conv_wgrad_bnadj, include/bihome.h; round-5 VERDICT item 2): conv1 (Ci -> C) -> BatchNorm (+ residual) -> ReLU -> conv2
+    (C -> C2).  conv2's dgrad completes d, the gradient of the BatchNorm's output, and leaves the BatchNorm's backward sums and
+    max |mask(d)| (bh_bn_reduce.amax_d); conv1's weight gradient is then computed (a) as before - bn_bwd materialises the adjoint g, the
+    fp16-piece kernel contracts x with g - and (b) with the adjoint applied ON LOAD from (d, z [, y]) and the sums.  (b) against (a), both
+    against a float64 evaluation of the same formulas, the eight-wave form bitwise the four-wave one, the record exact."""
+    from bihome_amd._lib import ROUTE_WX3_PC
+    groups = 2
+    g = torch.Generator().manual_seed(N + H + C)
+    x = torch.randn(N, H, H, Ci, generator=g).cuda()
+    z = (torch.randn(N, H, H, C, generator=g) * 2.0 + 0.5).cuda()                   # conv1's output = the BatchNorm's input
+    res = torch.randn(N, H, H, C, generator=g).cuda() if residual else None
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.2).cuda()
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    y, st = K.bn_fwd(z, gamma, beta, rm, rv, res, groups, 1e-5, 0.1, True, True)
+    w2 = (torch.randn(C2, C, 3, 3, generator=g) * 0.05).cuda().contiguous(memory_format=torch.channels_last)
+    pk, pf2, pd2 = _packed(K, w2, 4)
+    gnext = (torch.randn(N, H, H, C2, generator=g) * 1e-3).cuda()
+    from bihome_amd._lib import ROUTE_HALO_SMALL
+    d2 = K.conv_desc(N, H, H, C, C2, 3, 1, 1, precision=4, route=ROUTE_HALO_SMALL)      # (small grids: keep the launch on the 3x3 kernels)
+    sums = K.bn_stats_buffer(groups, C, "cuda")
+    rec_d = K.amax_record("cuda")
+    K.amax_of(gnext)
+    dout = K.conv_dgrad(gnext, w2.permute(0, 2, 3, 1), d2, wpacked=pd2,
+                        bn_reduce=dict(z=z, y=y if residual else None, stats=st, gamma=gamma, beta=beta, eps=1e-5, relu=True, sums=sums, groups=groups,
+                                       amax_d=rec_d))
+    mask = (y > 0)
+    assert rec_d.max().item() == (dout * mask).abs().max().item()                   # the record: max |mask(d)|, exactly
+    # the conv1 input: a tensor, or a BatchNorm(+ReLU) applied on load
+    xin = x
+    if bni:
+        g0, b0 = (torch.rand(Ci, generator=g) + 0.5).cuda(), (torch.randn(Ci, generator=g) * 0.2).cuda()
+        st0 = K.bn_stats_buffer(groups, Ci, "cuda"); K.bn_stats(x, st0, groups, Ci)
+        rec0 = K.amax_record("cuda")
+        table0 = K.bn_fwd_coeffs(st0, g0, b0, torch.zeros(Ci, device="cuda"), torch.ones(Ci, device="cuda"), groups, N * H * H // groups, Ci, 1e-5, 0.1, amax=rec0)
+        xin = K.BnOnLoad(x, table0, groups, True, amax=rec0)
+    d1 = K.conv_desc(N, H, H, Ci, C, 3, 1, 1, precision=4)
+    d1.bh_wx3 = True
+    ws = torch.empty(K.wgrad_det_bytes(d1) // 4, dtype=torch.float32, device="cuda")
+    # (a) materialised adjoint
+    recg = K.amax_record("cuda")
+    gx, _ = K.bn_bwd(dout, y if residual else None, z, gamma, st, rm, rv, groups, 1e-5, True, True, False, beta=beta, had_res=residual,
+                     sums_ready=sums, amax=recg)
+    gw_a = torch.zeros(C, 3, 3, Ci, device="cuda")
+    K.conv_wgrad(xin, gx, gw_a, None, d1, det_ws=ws)
+    # (b) on load
+    bna = dict(z=z, y=y if residual else None, stats=st, sums=sums, gamma=gamma, beta=beta, eps=1e-5, relu=True, groups=groups)
+    gw_b = torch.zeros(C, 3, 3, Ci, device="cuda")
+    assert K.conv_wgrad_bnadj(xin, dout, gw_b, d1, ws, bna, rec_d)
+    dpc = K.conv_desc(N, H, H, Ci, C, 3, 1, 1, precision=4, route=ROUTE_WX3_PC)
+    dpc.bh_wx3 = True
+    gw_c = torch.zeros(C, 3, 3, Ci, device="cuda")
+    assert K.conv_wgrad_bnadj(xin, dout, gw_c, dpc, ws, bna, rec_d)
+    assert torch.equal(gw_c, gw_b)                                                  # eight-wave form: bitwise the four-wave one
+    # float64 evaluation of the same formulas from the same d
+    dd, zd = (dout * mask).double().cpu().view(groups, -1, C), z.double().cpu().view(groups, -1, C)
+    mu, var = zd.mean(1, keepdim=True), zd.var(1, unbiased=False, keepdim=True)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    xhat = (zd - mu) * rstd
+    gref = (gamma.double().cpu() * rstd) * (dd - dd.mean(1, keepdim=True) - xhat * (dd * xhat).mean(1, keepdim=True))
+    xd = x.double().cpu()
+    if bni:
+        x0 = xd.view(groups, -1, Ci)
+        m0, v0 = x0.mean(1, keepdim=True), x0.var(1, unbiased=False, keepdim=True)
+        xd = ((x0 - m0) / torch.sqrt(v0 + 1e-5) * g0.double().cpu() + b0.double().cpu()).clamp_min(0).view(N, H, H, Ci)
+    wt = torch.zeros(C, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    ref = torch.autograd.grad(F.conv2d(xd.permute(0, 3, 1, 2), wt, None, 1, 1), wt, gref.view(N, H, H, C).permute(0, 3, 1, 2))[0].permute(0, 2, 3, 1)
+    ea, eb = _rel(gw_a, ref), _rel(gw_b, ref)
+    print("\nBatchNorm adjoint on load N%d H%d %d->%d%s%s: weight gradient rel-L2 vs f64  materialised %.2e  on load %.2e; on load vs materialised %.2e"
+          % (N, H, Ci, C, " +res" if residual else "", " bnin" if bni else "", ea, eb, _rel(gw_b, gw_a.cpu().double())))
+    assert eb <= 1.5 * ea + 2e-7, (ea, eb)
+    # accumulates into what gw holds
+    g1 = torch.ones(C, 3, 3, Ci, device="cuda")
+    assert K.conv_wgrad_bnadj(xin, dout, g1, d1, ws, bna, rec_d)
+    assert _rel(g1 - 1.0, gw_b.cpu().double()) < 1e-2

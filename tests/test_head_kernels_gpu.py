@@ -91,9 +91,11 @@ def test_dsac_argmin_bit_exact(K, golden):
     np.testing.assert_allclose(sel.cpu().numpy(), g["delta_hat"], atol=5e-2)   # f32 SVD noise at P=16, noise=2px
 
 
-# twice the largest error measured on the five cases (round 6, `pytest -s`, profiles/r06b_gpu_tests_measured.txt: 8.3e-6 of max |dL/dH|; rounds 1-5
-# allowed 2e-3): float32 coordinates and per-pixel products, double sums, against the float64 autograd of the oracle
-WARP_ADJOINT_BOUND = 2e-5
+# ~twice the largest error measured on the five cases (round 6, `pytest -s`, profiles/r06b_gpu_tests_measured.txt: 8e-6 ... 3.8e-5 of max |dL/dH|
+# by build; rounds 1-5 allowed 2e-3): float32 coordinates and per-pixel products, double sums, against the float64 autograd of the oracle.
+# (Not tighter: the bilinear derivative jumps where a coordinate crosses an integer, and one pixel that float32 puts on the other side of
+# such a kink than float64 moves an entry by ~1e-5 of the maximum on these sizes.)
+WARP_ADJOINT_BOUND = 1e-4
 
 
 @pytest.mark.parametrize("B,C,size,pool", [(5, 1, 128, 4), (2, 3, 64, 4), (3, 1, 32, 8), (2, 2, 48, 1), (1, 1, 256, 16)])
