@@ -98,6 +98,7 @@ SIGNATURES = {
     "bh_conv_fwd_bnstats": [P, P, P, P, POINTER(BhConvDesc), P, c_int, P],
     "bh_conv_fwd_bnin": [P, P, P, P, POINTER(BhConvDesc), P, c_int, POINTER(BhBnIn), P],
     "bh_conv_wgrad_bnin": [P, P, P, P, POINTER(BhConvDesc), P, c_int64, POINTER(BhBnIn), P],
+    "bh_conv_wgrad_batch": [c_int, P, P, P, P, P, c_int64, P, P],
     "bh_conv_wgrad_bnadj": [P, P, P, POINTER(BhConvDesc), P, c_int64, POINTER(BhBnIn), POINTER(BhBnAdj), P],
     "bh_bn_fwd_coeffs": [P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, P, P],
     "bh_conv_dgrad": [P, P, P, POINTER(BhConvDesc), c_int, P],

@@ -9,7 +9,8 @@
 #include "common.h"
 
 int bh_wgrad_x3_try(const float* x, const float* gy, float* gw, const bh_conv_desc* d, hipStream_t stream, int* taken, float* ws,
-                    long long ws_bytes, long long* ws_need, const bh_bn_in* bni = nullptr, const bh_bn_adj* bna = nullptr);    // wgrad_x3.hip
+                    long long ws_bytes, long long* ws_need, const bh_bn_in* bni = nullptr, const bh_bn_adj* bna = nullptr,
+                    const struct WX3Batch* extra = nullptr);    // wgrad_x3.hip
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

@@ -62,6 +62,14 @@ struct WX3Args {
     // added in front of the ReLU), k1 = sum mask(d) / rows, k2 = sum mask(d) xhat / rows from bna_sums (accumulated by the dgrad that made d:
     // bh_conv_dgrad_bnreduce) and (mean, 1 / std) from the forward sums bna_stats.  amax_gy is then the magnitude record of d; the scale of
     // the operand's fp16 pieces comes from the bound max_c |sc| (max |d| + |k1| + sqrt(rows) |k2|) over the workgroup's 64 channels.
+    // Batch (round 6): up to four layers of ONE geometry in a launch - workgroup w belongs to layer w / wg_per_layer.  Each layer's pixel
+    // range is then split over fewer workgroups: the launch writes (and wgrad_x3_reduce_kernel reads) one set of partial blocks for all of
+    // them, where single launches write one set EACH, and three of four kernel / reduce launch pairs disappear.  Layer 0: the fields above.
+    int nlayers, wg_per_layer;
+    const float *X1, *X2, *X3, *GY1, *GY2, *GY3;
+    float *Out1, *Out2, *Out3;
+    const unsigned *amax_x1, *amax_x2, *amax_x3, *amax_gy1, *amax_gy2, *amax_gy3;
+    const float *bni1, *bni2, *bni3;
     const float* bna_z;
     const float* bna_y;
     const double* bna_stats;
@@ -112,21 +120,32 @@ __global__ void __launch_bounds__(PC ? 512 : 256, 1) wgrad_x3_kernel(WX3Args a) 
     const bool producer = PC && threadIdx.x >= 256;
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;      // (PC: index within the role)
     const int wm = CB == 64 ? (wave & 1) : 0, wn = CB == 64 ? (wave >> 1) : 0;      // CB = 64: cout half, cin half of the block
-    const int split = blockIdx.x % a.nsplit, pair = blockIdx.x / a.nsplit;
+    // (batched launches: this workgroup's layer and its operands - compile-time field names, scalar selects: no indexing into the arguments)
+    int bid = (int)blockIdx.x;
+    const float* aX = a.X; const float* aGY = a.GY; float* aOut = a.Out; const float* aBni = a.bni;
+    const unsigned* aAmaxX = a.amax_x; const unsigned* aAmaxGY = a.amax_gy;
+    if (a.nlayers > 1) {
+        const int layer = bid / a.wg_per_layer;
+        bid -= layer * a.wg_per_layer;
+        if (layer == 1) { aX = a.X1; aGY = a.GY1; aOut = a.Out1; aBni = a.bni1; aAmaxX = a.amax_x1; aAmaxGY = a.amax_gy1; }
+        else if (layer == 2) { aX = a.X2; aGY = a.GY2; aOut = a.Out2; aBni = a.bni2; aAmaxX = a.amax_x2; aAmaxGY = a.amax_gy2; }
+        else if (layer == 3) { aX = a.X3; aGY = a.GY3; aOut = a.Out3; aBni = a.bni3; aAmaxX = a.amax_x3; aAmaxGY = a.amax_gy3; }
+    }
+    const int split = bid % a.nsplit, pair = bid / a.nsplit;
     const int co0 = (pair / a.cbi) * CB, ci0 = (pair % a.cbi) * CB;
     constexpr unsigned OOB = 0x80000000u;
     float f16_sx = 1.0f, f16_sg = 1.0f;
     int f16_kout = 0;
     if constexpr (F16) {
-        const int kx = bh_f16_scale_exp(bh_amax_read(a.amax_x, lane)), kg = bh_f16_scale_exp(bh_amax_read(a.amax_gy, lane));
+        const int kx = bh_f16_scale_exp(bh_amax_read(aAmaxX, lane)), kg = bh_f16_scale_exp(bh_amax_read(aAmaxGY, lane));
         f16_sx = __builtin_bit_cast(float, (unsigned)(127 + kx) << 23);
         f16_sg = __builtin_bit_cast(float, (unsigned)(127 + kg) << 23);
         f16_kout = -(kx + kg);
     }
-    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, a.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.GY), 0, a.gy_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BNA ? a.bna_z : a.GY), 0, a.gy_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((BNA && a.bna_y) ? a.bna_y : a.GY), 0, a.gy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(aX), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(aGY), 0, a.gy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BNA ? a.bna_z : aGY), 0, a.gy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((BNA && a.bna_y) ? a.bna_y : aGY), 0, a.gy_bytes, 0x00020000);
 
     // ---- staging slots of this thread (tile independent parts): slot = (pixel, 8-channel group) -> 2 dwordx4, 3 ds_write_b128 ----
     // gy: 64 pixels x NG groups (GS per thread); halo: 100 x NG slots (HS per thread; the slots past the last one repeat it -
@@ -174,7 +193,7 @@ __global__ void __launch_bounds__(PC ? 512 : 256, 1) wgrad_x3_kernel(WX3Args a) 
         if (threadIdx.x == 0) *bnd = 0u;
         __syncthreads();
         if (!PC || producer) {
-            const float maxd = __builtin_bit_cast(float, bh_amax_read(a.amax_gy, lane));
+            const float maxd = __builtin_bit_cast(float, bh_amax_read(aAmaxGY, lane));
             const double inv_rows = 1.0 / (double)a.bna_rows;
             const float invn = 1.0f / (float)a.bna_rows, sqn = sqrtf((float)a.bna_rows);
             for (int i = tid; i < a.bna_groups * CB; i += 256) {
@@ -199,14 +218,14 @@ __global__ void __launch_bounds__(PC ? 512 : 256, 1) wgrad_x3_kernel(WX3Args a) 
         if constexpr (F16) {
             const int kg = bh_f16_scale_exp(*bnd);
             f16_sg = __builtin_bit_cast(float, (unsigned)(127 + kg) << 23);
-            f16_kout = -(bh_f16_scale_exp(bh_amax_read(a.amax_x, lane)) + kg);
+            f16_kout = -(bh_f16_scale_exp(bh_amax_read(aAmaxX, lane)) + kg);
         }
     }
     if constexpr (BNI) {
         if (!PC || producer) {
             for (int i = tid; i < a.bni_groups * CB; i += 256) {
                 const int grp = i / CB, ch = i - grp * CB;
-                reinterpret_cast<float2*>(smem + TB0)[i] = reinterpret_cast<const float2*>(a.bni)[grp * a.Ci + ci0 + ch];
+                reinterpret_cast<float2*>(smem + TB0)[i] = reinterpret_cast<const float2*>(aBni)[grp * a.Ci + ci0 + ch];
             }
         }
     }
@@ -438,7 +457,7 @@ __global__ void __launch_bounds__(PC ? 512 : 256, 1) wgrad_x3_kernel(WX3Args a) 
     for (int i = 0; i < 9; ++i) {
         int tap = i + rot;
         if (tap >= 9) tap -= 9;
-        float* const o = a.Out + ((long long)(co0 + wm * 32 + 4 * kh2) * 9 + tap) * a.Ci + ci0 + wn * 32 + l31;
+        float* const o = aOut + ((long long)(co0 + wm * 32 + 4 * kh2) * 9 + tap) * a.Ci + ci0 + wn * 32 + l31;
         float* const pp = a.partials ? a.partials + (((size_t)blockIdx.x * 9 + tap) * 4 + wave) * 1024 + lane : nullptr;
 #define WX_FLUSH(T)                                                                                                     \
     case T:                                                                                                             \
@@ -458,16 +477,19 @@ __global__ void __launch_bounds__(PC ? 512 : 256, 1) wgrad_x3_kernel(WX3Args a) 
 // flight), the four sub-sums are combined in fixed order through LDS: bitwise reproducible.
 // CB = 64: a partial block is [tap][wave = quadrant][r][lane], an element has nsplit terms.
 // CB = 32: the four waves of a workgroup hold four K-split terms of the same [tap][r][lane] element: 4 nsplit terms.
+// (batched launches: blockIdx.y = layer * pairs_per_layer + block pair; out1 .. out3 the gradients of layers 1 .. 3)
 template <int CB>
 __global__ void __launch_bounds__(256) wgrad_x3_reduce_kernel(const float* __restrict__ partials, float* __restrict__ out, int nsplit,
-                                                              int cbi, int Ci) {
+                                                              int cbi, int Ci, float* __restrict__ out1 = nullptr, float* __restrict__ out2 = nullptr,
+                                                              float* __restrict__ out3 = nullptr, int pairs_per_layer = 1 << 30) {
     __shared__ float red[4][64];
     const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + e;                           // CB 64: [tap][wave][r][lane] < 36864; CB 32: [tap][r][lane] < 9216
-    const int pair = blockIdx.y;
+    const int layer = (int)blockIdx.y / pairs_per_layer, pair = (int)blockIdx.y - layer * pairs_per_layer;
+    if (layer == 1) out = out1; else if (layer == 2) out = out2; else if (layer == 3) out = out3;
     const int nterm = CB == 64 ? nsplit : 4 * nsplit;              // term s of CB = 32: workgroup s >> 2, wave s & 3
     const int per = (nterm + 3) / 4, s0 = grp * per, s1 = min(nterm, s0 + per);
-    const float* const base = partials + (size_t)pair * nsplit * 36864;
+    const float* const base = partials + (size_t)blockIdx.y * nsplit * 36864;
     auto term = [&](int s) -> const float* {
         if (CB == 64) return base + (size_t)s * 36864 + idx;
         const int tap = idx >> 10, rl = idx & 1023;
@@ -502,8 +524,15 @@ void bh_wgrad_x3_tune(int what, int v) { if (what == 0) g_wx3_target = v; else i
 
 // *taken = 1 when the shape is eligible (3x3 / stride 1 / pad 1, NHWC, H and W multiples of 8, channels multiples of 32).
 // ws != NULL: deterministic reduction through ws (ws_need != NULL: dry run that only reports the bytes needed)
+// further layers of a batched launch (bh_conv_wgrad_batch): same geometry, arithmetic and BatchNorm-on-load form as layer 0
+struct WX3Batch {
+    int n;                                     // extra layers (1 .. 3)
+    const float* x[3]; const float* gy[3]; float* gw[3];
+    const void* a_bound[3]; const void* b_bound[3]; const float* bni[3];
+};
+
 int bh_wgrad_x3_try(const float* x, const float* gy, float* gw, const bh_conv_desc* d, hipStream_t stream, int* taken, float* ws,
-                    long long ws_bytes, long long* ws_need, const bh_bn_in* bni, const bh_bn_adj* bna) {
+                    long long ws_bytes, long long* ws_need, const bh_bn_in* bni, const bh_bn_adj* bna, const WX3Batch* extra) {
     *taken = 0;
     if (d->transposed || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->in_nchw || d->out_nchw) return BH_OK;
     // 4 x 4 maps (round 5: layer4 of the ResNet-34 regressor): fp16 pieces, 64-channel blocks, four images per tile
@@ -526,7 +555,9 @@ int bh_wgrad_x3_try(const float* x, const float* gy, float* gw, const bh_conv_de
     // one workgroup per CU - or, when the caller says that another stream shares the GPU (BH_ROUTE_WX3_SHARED), 160: in-step sweep of
     // round 5 (tools/ab_hook.sh "-30,n"): 128-192 all beat 256 by 0.15-0.19 ms per step on configs[1], 160 also on configs[3]
     const int target = (d->route & BH_ROUTE_WX3_SHARED) && g_wx3_target == 256 ? 160 : g_wx3_target;
-    int ns = target / pairs;
+    const int L = extra ? extra->n + 1 : 1;     // layers of this launch
+    if (extra && (map4 || cb != 64 || bna || !ws)) return BH_OK;
+    int ns = target / (pairs * L);
     if (ns > a.ntiles) ns = a.ntiles;
     if (ns >= 8) ns = ns / 8 * 8;               // the workgroups of one split (same tiles, other channel blocks) land on one XCD
     if (ns < 1) ns = 1;
@@ -547,7 +578,16 @@ int bh_wgrad_x3_try(const float* x, const float* gy, float* gw, const bh_conv_de
         a.bna_rows = a.bna_ipg * d->Hi * d->Wi;
     }
     const int tb_bytes = (bni ? bni->groups * cb * 8 : 0) + (bna ? bna->groups * 1280 + 16 : 0);
-    const long long need = (long long)pairs * ns * 36864 * 4;
+    const long long need = (long long)pairs * L * ns * 36864 * 4;
+    if (extra) {
+        a.nlayers = L; a.wg_per_layer = pairs * ns;
+        a.X1 = extra->x[0]; a.GY1 = extra->gy[0]; a.Out1 = extra->gw[0]; a.bni1 = extra->bni[0];
+        a.amax_x1 = reinterpret_cast<const unsigned*>(extra->a_bound[0]); a.amax_gy1 = reinterpret_cast<const unsigned*>(extra->b_bound[0]);
+        if (L > 2) { a.X2 = extra->x[1]; a.GY2 = extra->gy[1]; a.Out2 = extra->gw[1]; a.bni2 = extra->bni[1];
+                     a.amax_x2 = reinterpret_cast<const unsigned*>(extra->a_bound[1]); a.amax_gy2 = reinterpret_cast<const unsigned*>(extra->b_bound[1]); }
+        if (L > 3) { a.X3 = extra->x[2]; a.GY3 = extra->gy[2]; a.Out3 = extra->gw[2]; a.bni3 = extra->bni[2];
+                     a.amax_x3 = reinterpret_cast<const unsigned*>(extra->a_bound[2]); a.amax_gy3 = reinterpret_cast<const unsigned*>(extra->b_bound[2]); }
+    }
     if (ws) {
         if (ws_need) *ws_need = need;
         else if (ws_bytes < need) return BH_E_BADARG;
@@ -606,13 +646,44 @@ int bh_wgrad_x3_try(const float* x, const float* gy, float* gw, const bh_conv_de
         }
     }
     const int ki = map4 ? (pc ? 14 : 16) + (bni ? 1 : 0) : pc ? 12 + (bni ? 1 : 0) : (f16 ? 8 : (np == 2 && d->precision != 4) ? 4 : 0) + (bni ? 2 : 0) + (cb == 64 ? 0 : 1);
-    hipLaunchKernelGGL(fns[ki], dim3(pairs * ns), dim3(pc ? 512 : 256), lds_of[ki] + tb_bytes, stream, a);
+    hipLaunchKernelGGL(fns[ki], dim3(pairs * L * ns), dim3(pc ? 512 : 256), lds_of[ki] + tb_bytes, stream, a);
     BH_LAUNCH_CHECK();
     if (ws) {
-        if (cb == 64) hipLaunchKernelGGL(wgrad_x3_reduce_kernel<64>, dim3(36864 / 64, pairs), dim3(256), 0, stream, ws, gw, ns, a.cbi, d->Ci);
+        if (cb == 64) hipLaunchKernelGGL(wgrad_x3_reduce_kernel<64>, dim3(36864 / 64, pairs * L), dim3(256), 0, stream, ws, gw, ns, a.cbi, d->Ci,
+                                         a.Out1, a.Out2, a.Out3, pairs);
         else hipLaunchKernelGGL(wgrad_x3_reduce_kernel<32>, dim3(9216 / 64, pairs), dim3(256), 0, stream, ws, gw, ns, a.cbi, d->Ci);
         BH_LAUNCH_CHECK();
     }
     *taken = 1;
     return BH_OK;
+}
+
+// Round 6: the fp16-piece weight gradients of 2 .. 4 layers of ONE geometry in one launch (+ one reduce launch).  Same tiles, same MFMA
+// order per workgroup; what changes is how many workgroups share a layer's pixels (fewer: one set of partial blocks per LAUNCH instead of
+// per layer) - the sums are deterministic, not bitwise those of the single launches.
+extern "C" int bh_conv_wgrad_batch(int n, const float* const* x, const float* const* gy, float* const* gw, const bh_conv_desc* const* descs, float* ws,
+                                   long long ws_bytes, const bh_bn_in* const* bni, void* stream) {
+    if (n < 1 || n > 4 || !x || !gy || !gw || !descs || !ws) return BH_E_BADARG;
+    const bh_conv_desc* d0 = descs[0];
+    if (!d0 || d0->precision != 4 || !d0->a_bound || !d0->b_bound) return BH_E_UNSUPPORTED;
+    WX3Batch ex = {};
+    ex.n = n - 1;
+    for (int i = 0; i < n; ++i) {
+        const bh_conv_desc* di = descs[i];
+        if (!di || !x[i] || !gy[i] || !gw[i]) return BH_E_BADARG;
+        if (di->N != d0->N || di->Hi != d0->Hi || di->Wi != d0->Wi || di->Ci != d0->Ci || di->Co != d0->Co || di->kh != d0->kh || di->kw != d0->kw ||
+            di->stride != d0->stride || di->pad != d0->pad || di->transposed != d0->transposed || di->in_nchw != d0->in_nchw ||
+            di->out_nchw != d0->out_nchw || di->precision != d0->precision || di->route != d0->route || !di->a_bound || !di->b_bound)
+            return BH_E_BADARG;
+        const bh_bn_in* bi = bni ? bni[i] : nullptr;
+        const bh_bn_in* b0 = bni ? bni[0] : nullptr;
+        if ((bi != nullptr) != (b0 != nullptr) || (bi && (bi->groups != b0->groups || bi->relu != b0->relu || !bi->table))) return BH_E_BADARG;
+        if (i > 0) { ex.x[i - 1] = x[i]; ex.gy[i - 1] = gy[i]; ex.gw[i - 1] = gw[i]; ex.a_bound[i - 1] = di->a_bound; ex.b_bound[i - 1] = di->b_bound;
+                     ex.bni[i - 1] = bi ? bi->table : nullptr; }
+    }
+    int taken = 0;
+    const int rc = bh_wgrad_x3_try(x[0], gy[0], gw[0], d0, bh_stream(stream), &taken, ws, ws_bytes, nullptr, bni ? bni[0] : nullptr, nullptr,
+                                   n > 1 ? &ex : nullptr);
+    if (rc != BH_OK) return rc;
+    return taken ? BH_OK : BH_E_UNSUPPORTED;
 }

@@ -911,6 +911,42 @@ def conv_wgrad_bnadj(x, dout, gw, d, ws, bna, amax_d):
     return True
 
 
+def conv_wgrad_batch(items, ws):
+    """Round 6 (bh_conv_wgrad_batch): the fp16-piece weight gradients of 2 .. 4 layers of one geometry in one launch.  items: [(x, gy, gw, d)],
+    x a tensor or BnOnLoad (all of one kind); every d of the same geometry and route.  Returns False where the kernel form does not apply
+    (nothing launched: call conv_wgrad per layer)."""
+    n = len(items)
+    d0 = items[0][3]
+    if not (1 <= n <= 4) or d0.precision != F16X2 or ws is None or deterministic():
+        return False
+    xs, bols = [], []
+    for x, gy, gw, d in items:
+        _route_det(d)
+        bol = x if isinstance(x, BnOnLoad) else None
+        xt = x.z if bol is not None else x
+        _chk(xt); _chk(gy); _chk(gw)
+        d.a_bound, d.b_bound = amax_of(x).data_ptr(), amax_of(gy).data_ptr()
+        xs.append(xt); bols.append(bol)
+    if any((b is None) != (bols[0] is None) for b in bols):
+        return False
+    _chk(ws)
+    PA = ctypes.c_void_p * n
+    xa, ga, wa = PA(*[t.data_ptr() for t in xs]), PA(*[it[1].data_ptr() for it in items]), PA(*[it[2].data_ptr() for it in items])
+    da = (ctypes.POINTER(BhConvDesc) * n)(*[ctypes.pointer(it[3]) for it in items])
+    structs = [b.struct() for b in bols] if bols[0] is not None else None
+    ba = (ctypes.POINTER(BhBnIn) * n)(*[ctypes.pointer(b) for b in structs]) if structs is not None else None
+    name = ""
+    if TIMING is not None:
+        name = (conv_variant(d0, "wgrad_det") + (" bnin" if structs is not None else "")) + " x%d layers" % n
+    nb = sum(4.0 * (t.numel() + it[1].numel() + it[2].numel()) for t, it in zip(xs, items))
+    with _Timed(name, n * conv_flops(d0), nb):
+        rc = lib.bh_conv_wgrad_batch(n, xa, ga, wa, da, _p(ws), ws.numel() * 4, ba, _stream())
+    if rc == -2:
+        return False
+    check(rc, "bh_conv_wgrad_batch")
+    return True
+
+
 def conv_wgrad(x, gy, gw, gbias, d, det_ws=None):
     """gw += x^T gy (split-K MFMA kernel, fp32 atomics); gbias += column sums of gy (separate launch, own timing entry so
     that the wgrad entry is the kernel rocprofv3 lists under the same name).

@@ -729,6 +729,30 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
         amax_iter = iter(amax_arena.split(K.AMAX_FLOATS))
         amax_next = lambda: next(amax_iter)
 
+    # Round 6: consecutive fp16-piece weight gradients of ONE geometry are queued and leave as one launch of up to `wbatch` layers
+    # (kernels.conv_wgrad_batch: one set of split-K partial blocks and one kernel / reduce launch pair per BATCH instead of per layer);
+    # a change of geometry, a full queue or the end of the walk flushes it.  BIHOME_WGRAD_BATCH=1: every layer its own launch (rounds 2-5).
+    wbatch = max(1, min(4, int(os.environ.get("BIHOME_WGRAD_BATCH", "4")))) if wgrad_stream is not None else 1
+    wpend = []
+
+    def wflush():
+        if not wpend:
+            return
+        items = list(wpend)
+        wpend.clear()
+        ev = torch.cuda.Event()
+        ev.record(main)                                       # the last queued layer's gradient is final here
+        for it in items:
+            it[2].record_stream(wgrad_stream)
+        with torch.cuda.stream(wgrad_stream):
+            wgrad_stream.wait_event(ev)
+            if len(items) == 1 or not K.conv_wgrad_batch([(it[1], it[2], it[3], it[4]) for it in items], x3_ws):
+                for it in items:
+                    K.conv_wgrad(it[1], it[2], it[3], None, it[4], det_ws=x3_ws)
+        if on_param_grad is not None:                         # these layers' gradients are final (enqueued): their buckets may leave
+            for it in items:
+                on_param_grad(it[5].weight)
+
     for i in range(len(prog.ops) - 1, -1, -1):
         op = prog.ops[i]
         g = grads.pop(op.dst, None)
@@ -756,8 +780,23 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
                     d.route = (d.route | K.ROUTE_WX3_PC) & ~K.ROUTE_WX3_SHARED
                 else:
                     d.route = (d.route & ~K.ROUTE_WX3_PC) | K.ROUTE_WX3_SHARED
+                queued = False
                 if wgrad_stream is None:
                     K.conv_wgrad(x, g, gw, gb, d, det_ws=ws)
+                elif (wbatch > 1 and gb is None and getattr(ctx, "precision", 0) == K.F16X2 and getattr(d, "bh_wx3", False) and ws is not None
+                      and d.Ci % 64 == 0 and d.Co % 64 == 0 and d.Hi >= 8):
+                    # round 6: queued - up to `wbatch` consecutive layers of one geometry leave in ONE launch (kernels.conv_wgrad_batch)
+                    key = (d.N, d.Hi, d.Wi, d.Ci, d.Co, (x.groups, bool(x.relu)) if isinstance(x, K.BnOnLoad) else None)
+                    if wpend and wpend[0][0] != key:
+                        wflush()
+                    K.amax_of(g)                                      # (magnitude records: on the main stream, as below)
+                    K.amax_of(x)
+                    wpend.append((key, x, g, gw, d, m))
+                    if len(wpend) >= wbatch:
+                        wflush()
+                    queued = True
+                    if on_param_grad is not None and has_gb:      # (its column sums came from the consumer's dgrad epilogue: final)
+                        on_param_grad(m.bias)
                 else:
                     if getattr(ctx, "precision", 0) == K.F16X2 and getattr(d, "bh_wx3", False):
                         # magnitude records the fp16-piece weight gradient reads: made (if missing) on the MAIN stream, in front of the
@@ -771,7 +810,7 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
                     with torch.cuda.stream(wgrad_stream):
                         wgrad_stream.wait_event(ev)
                         K.conv_wgrad(x, g, gw, gb, d, det_ws=ws if getattr(d, "bh_wx3", False) else None)     # (one stream: launches serialise on the workspace)
-                if on_param_grad is not None:       # gradient of this layer is final: its bucket may leave
+                if on_param_grad is not None and not queued:       # gradient of this layer is final: its bucket may leave
                     on_param_grad(m.weight)
                     if has_gb:
                         on_param_grad(m.bias)
@@ -908,6 +947,7 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
         elif op.kind == "gap":
             if need_src_grad:
                 contribute(op.src, K.gap_bwd(g, tuple(x.shape)))
+    wflush()
     if wgrad_stream is not None:
         main.wait_stream(wgrad_stream)          # the optimiser (and the release of the activations) follows
     return grads.get(0)

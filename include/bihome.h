@@ -355,6 +355,14 @@ int bh_conv_wgrad_bnin(const float* x, const float* gy, float* gw, float* gbias,
  * bh_conv_dgrad_bnreduce_amax leaves it); the fp16 scale of g comes from the a-priori bound max_c |sc| (max |d| + |k1| + sqrt(rows) |k2|).
  * ws / ws_bytes: the partial-block workspace (bh_conv_wgrad_det_bytes).  BH_E_UNSUPPORTED where wgrad_x3_kernel's 64-channel fp16-piece
  * form does not apply (the caller runs bh_bn_bwd and bh_conv_wgrad_* as before). */
+/* Round 6: the weight gradients of n = 1 .. 4 layers of ONE geometry (precision 4, 64-channel blocks: what wgrad_x3_kernel's fp16-piece form
+ * takes) in ONE launch + one reduce launch: gw[i] += x[i]^T gy[i].  descs[i]: identical geometry / route, each with its own magnitude records
+ * (a_bound of x[i], b_bound of gy[i]); bni: NULL, or n BatchNorm-on-load tables of equal groups / relu.  ws >= n-independent
+ * bh_conv_wgrad_det_bytes(descs[0]) bytes.  Fewer workgroups share a layer's pixels, so a LAUNCH writes the <= 256 partial blocks that each
+ * single launch writes (37.7 MB less traffic per extra layer) and n - 1 kernel / reduce launch pairs disappear.  Deterministic; equal to the
+ * single launches up to the order of the split-K sums.  BH_E_UNSUPPORTED where that kernel form does not apply. */
+int bh_conv_wgrad_batch(int n, const float* const* x, const float* const* gy, float* const* gw, const bh_conv_desc* const* descs, float* ws,
+                        long long ws_bytes, const bh_bn_in* const* bni, void* stream);
 typedef struct {
     const float* z;        /* the BatchNorm's input = the convolution's output [N,H,W,Co] */
     const float* y;        /* the saved output behind the ReLU, or NULL (mask recomputed from z) */

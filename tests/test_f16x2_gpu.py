@@ -367,3 +367,50 @@ def test_wgrad_with_the_batchnorm_adjoint_on_load(K, N, H, Ci, C, C2, residual, 
     g1 = torch.ones(C, 3, 3, Ci, device="cuda")
     assert K.conv_wgrad_bnadj(xin, dout, g1, d1, ws, bna, rec_d)
     assert _rel(g1 - 1.0, gw_b.cpu().double()) < 1e-2
+
+
+@pytest.mark.parametrize("N,H,Ci,Co,n,bni", [(16, 16, 64, 64, 4, False), (128, 32, 64, 64, 2, False), (8, 8, 256, 128, 3, False), (6, 24, 128, 64, 4, True),
+                                             (16, 16, 64, 64, 1, False)])
+def test_wgrad_f16x2_batched_layers(K, N, H, Ci, Co, n, bni):
+    """Round 6 (bh_conv_wgrad_batch, include/bihome.h): the fp16-piece weight gradients of n layers of one geometry in ONE launch, against
+    the n single launches (same kernel, fewer workgroups per layer: equal up to the order of the split-K sums) and against float64;
+    every layer reads its OWN operands, records and BatchNorm-on-load table, and accumulates into what its gradient buffer holds."""
+    from bihome_amd._lib import ROUTE_WX3_SHARED
+    groups = 2
+    g = torch.Generator().manual_seed(N + H + Ci + n)
+    items, singles, refs = [], [], []
+    ws = None
+    for i in range(n):
+        x = (torch.randn(N, H, H, Ci, generator=g) * (1.0 + i)).cuda()
+        gy = (torch.randn(N, H, H, Co, generator=g) * 10.0 ** (-3 - i)).cuda()           # (very different magnitudes: one record per layer)
+        xin, xd = x, x.double().cpu()
+        if bni:
+            g0, b0 = (torch.rand(Ci, generator=g) + 0.5).cuda(), (torch.randn(Ci, generator=g) * 0.2).cuda()
+            st0 = K.bn_stats_buffer(groups, Ci, "cuda"); K.bn_stats(x, st0, groups, Ci)
+            rec0 = K.amax_record("cuda")
+            table0 = K.bn_fwd_coeffs(st0, g0, b0, torch.zeros(Ci, device="cuda"), torch.ones(Ci, device="cuda"), groups, N * H * H // groups, Ci, 1e-5, 0.1, amax=rec0)
+            xin = K.BnOnLoad(x, table0, groups, True, amax=rec0)
+            x0 = xd.view(groups, -1, Ci)
+            xd = ((x0 - x0.mean(1, keepdim=True)) / torch.sqrt(x0.var(1, unbiased=False, keepdim=True) + 1e-5) * g0.double().cpu() + b0.double().cpu()).clamp_min(0).view(N, H, H, Ci)
+        wt = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+        refs.append(torch.autograd.grad(F.conv2d(xd.permute(0, 3, 1, 2), wt, None, 1, 1), wt, gy.double().cpu().permute(0, 3, 1, 2))[0].permute(0, 2, 3, 1))
+        d = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=4, route=ROUTE_WX3_SHARED); d.bh_wx3 = True
+        if ws is None:
+            ws = torch.empty(K.wgrad_det_bytes(d) // 4, dtype=torch.float32, device="cuda")
+        base = torch.randn(Co, 3, 3, Ci, generator=g).cuda() * 1e-6
+        gw1 = base.clone()
+        K.conv_wgrad(xin, gy, gw1, None, d, det_ws=ws)
+        singles.append((gw1, base))
+        d2 = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=4, route=ROUTE_WX3_SHARED); d2.bh_wx3 = True
+        items.append((xin, gy, base.clone(), d2))
+    assert K.conv_wgrad_batch(items, ws)
+    for i in range(n):
+        got, (one, base) = items[i][2], singles[i]
+        e_b, e_1 = _rel(got - base, refs[i]), _rel(one - base, refs[i])
+        print("batched wgrad N%d H%d %d->%d layer %d of %d%s: rel-L2 vs f64  batched %.2e  single %.2e  batched vs single %.2e"
+              % (N, H, Ci, Co, i, n, " bnin" if bni else "", e_b, e_1, _rel(got - base, (one - base).cpu().double())))
+        assert e_b <= 1.5 * e_1 + 2e-7, (i, e_b, e_1)
+    # repeatable bit for bit (ordered reduction through the workspace)
+    again = [(it[0], it[1], singles[i][1].clone(), it[3]) for i, it in enumerate(items)]
+    assert K.conv_wgrad_batch(again, ws)
+    assert all(torch.equal(a[2], b[2]) for a, b in zip(again, items))
