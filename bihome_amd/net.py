@@ -731,8 +731,12 @@ def run_backward(prog, ctx, gout, want_wgrad, want_input_grad, on_param_grad=Non
 
     # Round 6: consecutive fp16-piece weight gradients of ONE geometry are queued and leave as one launch of up to `wbatch` layers
     # (kernels.conv_wgrad_batch: one set of split-K partial blocks and one kernel / reduce launch pair per BATCH instead of per layer);
-    # a change of geometry, a full queue or the end of the walk flushes it.  BIHOME_WGRAD_BATCH=1: every layer its own launch (rounds 2-5).
-    wbatch = max(1, min(4, int(os.environ.get("BIHOME_WGRAD_BATCH", "4")))) if wgrad_stream is not None else 1
+    # a change of geometry, a full queue or the end of the walk flushes it.
+    # MEASURED AND NOT ADOPTED (profiles/r06i_step_ab_wgrad_batch.txt, three alternating runs on one box): 12.43 ms per step with every
+    # layer its own launch, 12.49 with pairs, 12.51 with batches of four - a batch starts when its LAST layer's gradient exists, and what
+    # the later start costs the two-stream schedule exceeds the launches and the 12 MB of partial blocks per layer it saves.  The default
+    # is 1 (every layer its own launch, as in rounds 2-5); BIHOME_WGRAD_BATCH=2..4 enables the queue.
+    wbatch = max(1, min(4, int(os.environ.get("BIHOME_WGRAD_BATCH", "1")))) if wgrad_stream is not None else 1
     wpend = []
 
     def wflush():

@@ -395,8 +395,8 @@ def test_wgrad_f16x2_batched_layers(K, N, H, Ci, Co, n, bni):
         wt = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
         refs.append(torch.autograd.grad(F.conv2d(xd.permute(0, 3, 1, 2), wt, None, 1, 1), wt, gy.double().cpu().permute(0, 3, 1, 2))[0].permute(0, 2, 3, 1))
         d = K.conv_desc(N, H, H, Ci, Co, 3, 1, 1, precision=4, route=ROUTE_WX3_SHARED); d.bh_wx3 = True
-        if ws is None:
-            ws = torch.empty(K.wgrad_det_bytes(d) // 4, dtype=torch.float32, device="cuda")
+        if ws is None:      # (a batch's partial blocks: <= 256 x 147 KB whatever the layer count - the models' 40 MB workspace)
+            ws = torch.empty(max(K.wgrad_det_bytes(d), 40 << 20) // 4, dtype=torch.float32, device="cuda")
         base = torch.randn(Co, 3, 3, Ci, generator=g).cuda() * 1e-6
         gw1 = base.clone()
         K.conv_wgrad(xin, gy, gw1, None, d, det_ws=ws)
