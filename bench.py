@@ -402,8 +402,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # CU budget of the exchange: 42.3 MB per 12 ms step is ~6 GB/s per GPU on a ring - a fraction of ONE xGMI link - while every RCCL
         # channel is a persistent workgroup that holds a CU which the step's 256-workgroup persistent conv kernels (one per CU, 158.5 KB
-        # of LDS: nothing co-resides) then have to queue for.  Four channels are plenty and cost four CUs; the caller's setting wins.
-        os.environ.setdefault("NCCL_MAX_NCHANNELS", "4")
+        # of LDS: nothing co-resides) then have to queue for.  Eight channels are plenty and cost eight CUs (a guess without a node to measure on); the caller's setting wins.
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "8")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:

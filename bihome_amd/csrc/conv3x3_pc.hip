@@ -44,15 +44,15 @@ constexpr int PC_LDS = PC_OFF_RED + PC_RED_BYTES;    // 162,304 B of 163,840
 constexpr unsigned PC_XOOB = 0x80000000u;            // out-of-range buffer offset (tensor sizes are below 2^31): the load returns zeros
 
 #ifdef BH_TUNING
-// barrier time stamps of workgroup 0 (shader clock): [role C / H / D / E][barrier number][arrival, release]
-__device__ unsigned long long g_pc_ts[4 * 160 * 2];
+// barrier time stamps of one workgroup (shader clock): [wave 0 .. 11][barrier number][arrival, release] (round 6: every wave, not one per role -
+// tools/pc_timeline.py names the wave the others wait for)
+__device__ unsigned long long g_pc_ts[12 * 160 * 2];
 #define PC_BARRIER()                                                                                                    \
     do {                                                                                                                \
-        const bool st_ = a.dbg_ts && blockIdx.x == (unsigned)(a.dbg_ts - 1) && (tid & 63) == 0 && (wave == 0 || wave == 4 || wave == 7 || wave == 8);        \
-        const int role_ = wave == 0 ? 0 : (wave == 4 ? 1 : (wave == 7 ? 2 : 3));                                        \
-        if (st_ && pc_nb < 160) g_pc_ts[(role_ * 160 + pc_nb) * 2] = __builtin_readcyclecounter();                      \
+        const bool st_ = a.dbg_ts && blockIdx.x == (unsigned)(a.dbg_ts - 1) && (tid & 63) == 0;                        \
+        if (st_ && pc_nb < 160) g_pc_ts[(wave * 160 + pc_nb) * 2] = __builtin_readcyclecounter();                       \
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                                \
-        if (st_ && pc_nb < 160) g_pc_ts[(role_ * 160 + pc_nb) * 2 + 1] = __builtin_readcyclecounter();                  \
+        if (st_ && pc_nb < 160) g_pc_ts[(wave * 160 + pc_nb) * 2 + 1] = __builtin_readcyclecounter();                   \
         ++pc_nb;                                                                                                        \
     } while (0)
 #else
@@ -701,7 +701,7 @@ __global__ void __launch_bounds__(768) conv3x3_pc_kernel(C3Args a) {
 
 #ifdef BH_TUNING
 extern "C" int bh_debug_read_pc_stamps(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pc_ts), sizeof(unsigned long long) * 4 * 160 * 2, 0, hipMemcpyDeviceToHost);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pc_ts), sizeof(unsigned long long) * 12 * 160 * 2, 0, hipMemcpyDeviceToHost);
 }
 #endif
 

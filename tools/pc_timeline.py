@@ -27,18 +27,27 @@ lib.bh_debug_force_tile(-40, 1 + 37)          # stamps of workgroup 37
 for _ in range(3): fn()
 torch.cuda.synchronize()
 lib.bh_debug_force_tile(-40, 0)
-buf = (ctypes.c_ulonglong * (4 * 160 * 2))()
+buf = (ctypes.c_ulonglong * (12 * 160 * 2))()
 lib.bh_debug_read_pc_stamps.argtypes = [ctypes.c_void_p]
 lib.bh_debug_read_pc_stamps(buf)
-t = np.array(buf, dtype=np.float64).reshape(4, 160, 2)
-nb = int((t[0, :, 0] > 0).sum())
-t0 = t[:, 0, 0].min()
-t = (t - t0) / 1000.0          # kilo-cycles
-print(shape, mode, "barriers", nb, " (kilo-cycles of the shader clock; arrival -> release per role)")
-print(" b#    C arr   rel |   H arr   rel |   D arr   rel |   E arr   rel |  last")
+tw = np.array(buf, dtype=np.float64).reshape(12, 160, 2)          # round 6: every wave (0-3 C, 4-6 H, 7 D, 8-11 E)
+nb = int((tw[0, :, 0] > 0).sum())
+t0 = tw[:, 0, 0].min()
+tw = (tw - t0) / 1000.0          # kilo-cycles
+ROLE = "CCCCHHHDEEEE"
+rep = [0, 4, 7, 8]               # one wave per role for the table (as in round 5)
+t = tw[rep]
+print(shape, mode, "barriers", nb, " (kilo-cycles of the shader clock; arrival -> release per role; last = the wave the others waited for, its lag behind the second-last)")
+print(" b#    C arr   rel |   H arr   rel |   D arr   rel |   E arr   rel |  last wave")
 for b in range(nb):
     arr = t[:, b, 0]; rel = t[:, b, 1]
-    print("%3d  " % b + " | ".join("%7.2f %6.2f" % (arr[r], rel[r] - arr[r]) for r in range(4)) + " |  " + "CHDE"[int(arr.argmax())])
-print("total %.1f kilo-cycles; waiting at barriers: C %.1f  H %.1f  D %.1f  E %.1f" % ((t[:, nb - 1, 1].max(),) + tuple((t[r, :nb, 1] - t[r, :nb, 0]).sum() for r in range(4))))
-last = [int(t[:, b, 0].argmax()) for b in range(nb)]
-print("last to arrive: " + "  ".join("%s %d" % ("CHDE"[r], last.count(r)) for r in range(4)))
+    a12 = tw[:, b, 0]; order = np.argsort(a12); w = int(order[-1])
+    print("%3d  " % b + " | ".join("%7.2f %6.2f" % (arr[r], rel[r] - arr[r]) for r in range(4)) + " |  %s%d +%.2f" % (ROLE[w], w, a12[order[-1]] - a12[order[-2]]))
+print("total %.1f kilo-cycles; waiting at barriers: C %.1f  H %.1f  D %.1f  E %.1f" % ((tw[:, nb - 1, 1].max(),) + tuple((t[r, :nb, 1] - t[r, :nb, 0]).sum() for r in range(4))))
+last = [ROLE[int(tw[:, b, 0].argmax())] for b in range(nb)]
+print("last to arrive: " + "  ".join("%s %d" % (r, last.count(r)) for r in "CHDE"))
+lagw = {}
+for b in range(nb):
+    a12 = tw[:, b, 0]; order = np.argsort(a12); w = int(order[-1])
+    lagw[w] = lagw.get(w, 0.0) + (a12[order[-1]] - a12[order[-2]])
+print("kilo-cycles the workgroup waited for its last wave, by wave: " + "  ".join("%s%d %.1f" % (ROLE[w], w, v) for w, v in sorted(lagw.items())))
