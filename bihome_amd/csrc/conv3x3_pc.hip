@@ -646,6 +646,10 @@ __global__ void __launch_bounds__(768) conv3x3_pc_kernel(C3Args a) {
             epi_fetch(Q0{}, i0 + 0); epi_fetch(Q1{}, i0 + 1); epi_fetch(Q2{}, i0 + 2); epi_fetch(Q3{}, i0 + 3);
         };
         // batch b of the run tile, then the request of the batch after it: b + 1 of the same tile, or batch 0 of tile `nxt` (-1: none)
+        // (Round 6 tried refilling a unit's registers right after that unit has been consumed, so that the requests leave a batch's run
+        //  time earlier: the compiler then waits vmcnt(0) in front of EVERY unit - a register loaded in an earlier loop iteration counts as
+        //  pending whatever has been waited for since - i.e. for the refill just issued: dgrad + BatchNorm sums + accumulate 57.4 us
+        //  against 48.8 on the 32 x 32 shape, barrier time line 123 against 103 kilo-cycles.  The whole-batch order stays.)
         auto step_batch = [&](int b, int nxt) {
             run_batch(b);
             if (nld == 0) return;
