@@ -156,7 +156,7 @@ def warp_adjoint_fold_cost(B2, size, pool=4, rounds=4, n=40):
     w = torch.randn(64, 7, 7, 1, device="cuda") * 0.05
     gx = torch.empty(B2, size, size, 1, device="cuda")
     gH = torch.zeros(B2, 9, dtype=torch.float64, device="cuda")
-    d = K.conv_desc(B2, size, size, 1, 64, 7, 2, 3)
+    d = K.conv_desc(B2, size, size, 1, 64, 7, 2, 3, precision=4)      # (the step's arithmetic: the fp16-piece window GEMM)
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 

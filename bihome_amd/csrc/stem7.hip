@@ -13,6 +13,10 @@
 #include "warp_tap.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+BH_KNOB(g_stem_f16, 1);            // (tuning build: the stems' fp16-piece forms on / off - bh_debug_force_tile)
+#ifdef BH_TUNING
+void bh_stem7_tune(int v) { g_stem_f16 = v; }
+#endif
 
 struct Stem7Args {
     const float* x;        // [N][CIN][Hi][Wi]
@@ -137,6 +141,186 @@ __global__ void __launch_bounds__(256) stem7_fwd_kernel(Stem7Args a) {
     if (a.bn_sums && cur_grp >= 0) flush_stats();
 }
 
+// Round 6 (round-5 VERDICT item 9 / weak #15: "stems still run the fp32-input MFMA at <= 0.5 of a measured 145 TFLOP/s"): the same forward
+// in the fp16-piece arithmetic of the 3x3 layers (common.h F16X2; bh_conv_desc.precision = 4) - every operand as TWO fp16 numbers of
+// (value x 2^k), three v_mfma_f32_32x32x16_f16 products per product, fp32 accumulate, the result rescaled by 2^-(kx + kw) (exact).
+//   * K order: a k-step of 16 is TWO tap rows (c, ky), (c, ky + 1) of 8 taps each - seven real kx and one pad tap with a zero weight -
+//     so the eight consecutive k a lane supplies are eight consecutive patch pixels of one row: four ds_read_b32 per piece (the patch is
+//     kept as two fp16 planes, row pitch 22 halfs, pad column zero).  One plane: 4 k-steps = 12 MFMAs of 32 cycles per 32 x 32 block
+//     where the fp32-input form issues 26 of 64.
+//   * scales: the filter bank's k from its maximum (every workgroup derives it from the 3136 CIN weights while it cuts them into LDS);
+//     the patch's k PER TILE from the maximum of the 21 x 21 pixels the workgroup has just fetched (wave maxima through LDS behind the
+//     barrier the staging needs anyway) - no magnitude record of the input images is needed, and a dark tile keeps its bits.
+// Same tiles, same epilogue (bias, ReLU, BatchNorm sums) as stem7_fwd_kernel.
+typedef _Float16 st_f16x8 __attribute__((ext_vector_type(8)));
+template <int CIN>
+__global__ void __launch_bounds__(256) stem7_fwd_f16_kernel(Stem7Args a) {
+    constexpr int ROWS = 7 * CIN;                       // tap rows (c, ky)
+    constexpr int KS = (ROWS + 1) / 2;                  // k-steps of two tap rows
+    constexpr int PW = 21, PP = 22;                     // patch width, row pitch in halfs (a row starts 4-byte aligned)
+    constexpr int PLANE = CIN * PW * PP;                // halfs per fp16 plane
+    constexpr int WB = KS * 4096;                       // bytes of one piece of the filter bank: [k-step][g 2][n 64] x 8 halfs
+    extern __shared__ __attribute__((aligned(16))) char smc[];
+    char* const Wp = smc;                               // [piece 2][KS][2][64] x 16 B
+    _Float16* const ph = reinterpret_cast<_Float16*>(smc + 2 * WB);      // patch planes: hi, then lo
+    float* const smx = reinterpret_cast<float*>(smc + 2 * WB + ((2 * PLANE * 2 + 15) & ~15));      // 4 wave maxima (+ 2 KB: statistics merge)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh2 = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+
+    // ---- filter bank: maximum -> scale -> two fp16 pieces in fragment order ----
+    float wmax = 0.f;
+    for (int i = tid; i < 64 * 49 * CIN; i += 256) wmax = fmaxf(wmax, fabsf(a.w[i]));
+    wmax = wave_max(wmax);
+    if (lane == 0) smx[wave] = wmax;
+    for (int i = tid; i < 2 * PLANE / 2; i += 256) reinterpret_cast<unsigned*>(ph)[i] = 0u;      // (pad column / unused slots stay zero)
+    __syncthreads();
+    wmax = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+    const int kw = bh_f16_scale_exp(__builtin_bit_cast(unsigned, wmax));
+    const float sw = __builtin_bit_cast(float, (unsigned)(127 + kw) << 23);
+    for (int i = tid; i < KS * 2 * 64; i += 256) {       // slot (s, g, n): eight taps of row r = 2 s + g for output channel n
+        const int n = i & 63, g = (i >> 6) & 1, s_ = i >> 7;
+        const int r = 2 * s_ + g, c = r / 7, ky = r - c * 7;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (r < ROWS && j < 7) ? a.w[(n * 49 + ky * 7 + j) * CIN + c] : 0.f;
+        uint4 hi, lo;
+        bh_split8_f16(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), sw, hi, lo);
+        *reinterpret_cast<uint4*>(Wp + i * 16) = hi;
+        *reinterpret_cast<uint4*>(Wp + WB + i * 16) = lo;
+    }
+    // lane's pixel inside the tile and its fragment addresses
+    const int py = wm * 4 + (l31 >> 3), px = l31 & 7;
+    const char* const abase = reinterpret_cast<const char*>(ph) + ((2 * py) * PP + 2 * px) * 2;
+    const char* const bbase = Wp + (kh2 * 64 + wn * 32 + l31) * 16;
+    const float bv = a.bias ? a.bias[wn * 32 + l31] : 0.f;
+
+    double s1 = 0, s2 = 0;
+    int cur_grp = -1;
+    double* const red = reinterpret_cast<double*>(smx + 4);      // [2 wm][64 n][2] doubles: 2 KB behind the maxima (16-byte aligned)
+    auto flush_stats = [&]() {
+        __syncthreads();
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (kh2 == 0) { red[(wm * 64 + wn * 32 + l31) * 2] = s1; red[(wm * 64 + wn * 32 + l31) * 2 + 1] = s2; }
+        __syncthreads();
+        if (tid < 128 && cur_grp >= 0) {
+            const int n = tid >> 1, mom = tid & 1;
+            bh_acc_add(&a.bn_sums[bn_sum_index(0, a.groups, cur_grp, 64, n, mom)], red[n * 2 + mom] + red[(64 + n) * 2 + mom], a.det);
+        }
+        s1 = 0; s2 = 0;
+    };
+    constexpr int PCH = PW * PW;
+    constexpr int NPF = (CIN * PCH + 255) / 256;
+    float pf[NPF];
+    auto fetch = [&](int tile_) {
+        const int img_ = tile_ / a.tiles_per_img, t_ = tile_ - img_ * a.tiles_per_img;
+        const int ty_ = t_ / a.tiles_x, tx_ = t_ - ty_ * a.tiles_x;
+        const int iy0 = ty_ * 16 - 3, ix0 = tx_ * 16 - 3;
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+            const int i = tid + j * 256;
+            const int c = i / PCH, r = i - c * PCH, yy = r / PW, xx = r - yy * PW;
+            const int iy = iy0 + yy, ix = ix0 + xx;
+            float v = 0.f;
+            if (tile_ < a.ntiles && i < CIN * PCH && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi)
+                v = a.x[(((size_t)img_ * CIN + c) * a.Hi + iy) * a.Wi + ix];
+            pf[j] = v;
+        }
+    };
+    fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int img = tile / a.tiles_per_img, t = tile - img * a.tiles_per_img;
+        if (a.bn_sums) {
+            const int grp = img / a.imgs_per_group;
+            if (grp != cur_grp) { if (cur_grp >= 0) flush_stats(); cur_grp = grp; }
+        }
+        const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+        // the tile's maximum: wave maxima through LDS behind the barrier that also ends the previous tile's fragment reads
+        float m = 0.f;
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) m = fmaxf(m, fabsf(pf[j]));
+        m = wave_max(m);
+        __syncthreads();                                 // previous tile's fragment reads (and its maxima reads) are done; Wp is complete
+        if (lane == 0) smx[wave] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+        const int kx = bh_f16_scale_exp(__builtin_bit_cast(unsigned, m));
+        const float sx = __builtin_bit_cast(float, (unsigned)(127 + kx) << 23);
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+            const int i = tid + j * 256;
+            if (i < CIN * PCH) {
+                const int c = i / PCH, r = i - c * PCH, yy = r / PW, xx = r - yy * PW;
+                const _Float16 h = (_Float16)(pf[j] * sx);
+                const _Float16 l = (_Float16)__builtin_fmaf(pf[j], sx, -(float)h);
+                ph[(c * PW + yy) * PP + xx] = h;
+                ph[PLANE + (c * PW + yy) * PP + xx] = l;
+            }
+        }
+        __syncthreads();
+        fetch(tile + (int)gridDim.x);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) {
+            // tap rows of the two half-waves (compile-time): r -> (c, ky) -> patch row; a row past the last one reads row 0 (its weights are 0)
+            const int r0 = 2 * s_, r1 = 2 * s_ + 1;
+            const int o0 = ((r0 / 7) * PW + r0 % 7) * PP * 2;
+            const int o1 = r1 < ROWS ? ((r1 / 7) * PW + r1 % 7) * PP * 2 : 0;
+            const char* const ap = abase + (kh2 ? o1 : o0);
+            uint4 ah, al;
+            ah.x = *reinterpret_cast<const unsigned*>(ap);      ah.y = *reinterpret_cast<const unsigned*>(ap + 4);
+            ah.z = *reinterpret_cast<const unsigned*>(ap + 8);  ah.w = *reinterpret_cast<const unsigned*>(ap + 12);
+            al.x = *reinterpret_cast<const unsigned*>(ap + PLANE * 2);      al.y = *reinterpret_cast<const unsigned*>(ap + PLANE * 2 + 4);
+            al.z = *reinterpret_cast<const unsigned*>(ap + PLANE * 2 + 8);  al.w = *reinterpret_cast<const unsigned*>(ap + PLANE * 2 + 12);
+            const uint4 bh = *reinterpret_cast<const uint4*>(bbase + s_ * 2048);
+            const uint4 bl = *reinterpret_cast<const uint4*>(bbase + WB + s_ * 2048);
+            // small products first: lo*hi, hi*lo, hi*hi
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(st_f16x8, al), __builtin_bit_cast(st_f16x8, bh), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(st_f16x8, ah), __builtin_bit_cast(st_f16x8, bl), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(st_f16x8, ah), __builtin_bit_cast(st_f16x8, bh), acc, 0, 0, 0);
+        }
+        const int kout = -(kx + kw);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mrow = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh2;
+            const int oy = ty * 8 + (mrow >> 3), ox = tx * 8 + (mrow & 7);
+            float v = __builtin_ldexpf(acc[r], kout) + bv;
+            if (a.relu) v = fmaxf(v, 0.f);
+            a.y[(((size_t)img * a.Ho + oy) * a.Wo + ox) * 64 + wn * 32 + l31] = v;
+            acc[r] = v;
+        }
+        if (a.bn_sums) {
+            float q1 = 0.f, q2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { q1 += acc[r]; q2 = __builtin_fmaf(acc[r], acc[r], q2); }
+            s1 += (double)q1; s2 += (double)q2;
+        }
+    }
+    if (a.bn_sums && cur_grp >= 0) flush_stats();
+}
+
+template <int CIN>
+static int stem7_f16_launch(const Stem7Args& a, hipStream_t s) {
+    constexpr int KS = (7 * CIN + 1) / 2;
+    const size_t lds = (size_t)2 * KS * 4096 + ((2 * CIN * 21 * 22 * 2 + 15) & ~15) + 16 + 2048;
+    if (bh_query("stem7_fwd_f16_kernel<%d>", CIN)) return BH_OK;
+    static unsigned long long attr_devs = 0;
+    if (bh_device_once(attr_devs)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem7_fwd_f16_kernel<CIN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    const int per_cu = lds > 40 * 1024 ? (lds > 80 * 1024 ? 1 : 2) : 4;
+    int blocks = 256 * per_cu;
+    if (blocks > a.ntiles) blocks = a.ntiles;
+    hipLaunchKernelGGL((stem7_fwd_f16_kernel<CIN>), dim3(blocks), dim3(256), lds, s, a);
+    BH_LAUNCH_CHECK();
+    return BH_OK;
+}
+
 template <int CIN>
 static int stem7_launch(const Stem7Args& a, hipStream_t s) {
     constexpr int KP = (49 * CIN + 3) / 4 * 4;
@@ -173,9 +357,12 @@ int bh_stem7_try(const float* x, const float* w, const float* bias, float* y, co
     a.tiles_x = d->Wo / 8; a.tiles_per_img = (d->Ho / 8) * a.tiles_x; a.ntiles = d->N * a.tiles_per_img;
     if (a.ntiles < 256) return BH_OK;
     int rc;
+    // precision 4 (the fp16-piece arithmetic of the 3x3 layers; round 6): the same tiles on v_mfma_f32_32x32x16_f16 - one and two planes
+    // (the extractor's and the backbone's stems; the RGB stems keep the fp32-input form: their filter bank in pieces would take one workgroup per CU)
+    const bool f16 = d->precision == 4 && d->Ci <= 2 && !(d->route & BH_ROUTE_DETERMINISTIC) && g_stem_f16;
     switch (d->Ci) {
-        case 1: rc = stem7_launch<1>(a, stream); break;
-        case 2: rc = stem7_launch<2>(a, stream); break;
+        case 1: rc = f16 ? stem7_f16_launch<1>(a, stream) : stem7_launch<1>(a, stream); break;
+        case 2: rc = f16 ? stem7_f16_launch<2>(a, stream) : stem7_launch<2>(a, stream); break;
         case 3: rc = stem7_launch<3>(a, stream); break;
         default: rc = stem7_launch<6>(a, stream); break;
     }
@@ -211,18 +398,48 @@ struct Stem7WarpArgs {
     float cov_scale;       // 1 / pool^2
 };
 
-template <bool WARP>
+// F16 (round 6; bh_conv_desc.precision = 4): the window GEMM in the fp16-piece arithmetic of the 3x3 layers - gy tile and filter bank as two
+// fp16 pieces each (the tile's scale from ITS maximum, the bank's from the bank's: no magnitude record needed), three
+// v_mfma_f32_32x32x16_f16 products per product: 24 MFMAs of 32 cycles per wave and tile where the fp32-input form issues 64 of 64.  The
+// staged pieces are [pixel][64 channels + 8] halfs (a lane's eight consecutive k are one ds_read_b128), the bank [k-step][k half][tap] x 8 halfs.
+template <bool WARP, bool F16 = false>
 __global__ void __launch_bounds__(256, 3) stem7_dgrad_c1_kernel(const float* __restrict__ gy, const float* __restrict__ w, float* __restrict__ gx,
                                                              int Ho, int Wo, int tiles_x, int tiles_per_img, int ntiles, Stem7WarpArgs wa) {
     constexpr int GP = 68;                               // row pitch of the gy tile in LDS (floats): 16-byte rows for the staging stores
     constexpr int TP = 53;                               // row pitch of the tap table (49 used)
-    __shared__ float Wt[64 * 64];                        // [k = channel][n = tap, 49 used]
-    __shared__ __attribute__((aligned(16))) float gt[128 * GP];   // [gy pixel of the 11 x 11 window, 121 used][channel]; then the tap table [121][TP]
+    constexpr int HP = 72;                               // F16: row pitch of a piece of the gy tile (halfs)
+    __shared__ float Wt[64 * 64];                        // [k = channel][n = tap, 49 used]; F16: two pieces x [4 k-steps][2][64 taps] x 16 B
+    // [gy pixel of the 11 x 11 window, 121 used][channel] (F16: two pieces of [128][HP] halfs = 36,864 B); then the tap table [121][TP]
+    __shared__ __attribute__((aligned(16))) float gt[F16 ? (2 * 128 * HP * 2) / 4 : 128 * GP];
+    __shared__ float smx[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kh2 = lane >> 5;
-    for (int i = tid; i < 64 * 64; i += 256) {
-        const int k = i >> 6, n = i & 63;
-        Wt[i] = n < 49 ? w[k * 49 + n] : 0.f;
+    int kw = 0;
+    if constexpr (!F16) {
+        for (int i = tid; i < 64 * 64; i += 256) {
+            const int k = i >> 6, n = i & 63;
+            Wt[i] = n < 49 ? w[k * 49 + n] : 0.f;
+        }
+    } else {
+        float wmax = 0.f;
+        for (int i = tid; i < 64 * 49; i += 256) wmax = fmaxf(wmax, fabsf(w[i]));
+        wmax = wave_max(wmax);
+        if (lane == 0) smx[wave] = wmax;
+        __syncthreads();
+        wmax = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+        kw = bh_f16_scale_exp(__builtin_bit_cast(unsigned, wmax));
+        const float sw = __builtin_bit_cast(float, (unsigned)(127 + kw) << 23);
+        // slot (s, g, n): channels k = 16 s + 8 g .. + 7 of tap n (w[k][7][7][1]: w[k * 49 + n]); taps 49 .. 63: zeros
+        for (int i = tid; i < 4 * 2 * 64; i += 256) {
+            const int n = i & 63, g = (i >> 6) & 1, s_ = i >> 7;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = n < 49 ? w[(16 * s_ + 8 * g + j) * 49 + n] : 0.f;
+            uint4 hi, lo;
+            bh_split8_f16(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), sw, hi, lo);
+            reinterpret_cast<uint4*>(Wt)[i] = hi;
+            reinterpret_cast<uint4*>(Wt)[512 + i] = lo;
+        }
     }
     const int Hi = 2 * Ho, Wi = 2 * Wo;
     const int py = tid >> 4, px = tid & 15;              // this thread's image pixel inside the tile
@@ -270,6 +487,10 @@ __global__ void __launch_bounds__(256, 3) stem7_dgrad_c1_kernel(const float* __r
             if (wa.g_cov)
                 wgc = wa.g_cov[((size_t)img * ((2 * Ho) >> wa.pool_shift) + (iy_ >> wa.pool_shift)) * ((2 * Wo) >> wa.pool_shift) + (ix_ >> wa.pool_shift)] * wa.cov_scale;
         }
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        if constexpr (!F16) {
         __syncthreads();                                 // the previous tile's tap table has been read (and Wt is complete)
         // 128 window slots x 16 float4: thread -> (slot, 4 channels); slots past 121 and pixels outside gy are zero
 #pragma unroll
@@ -283,9 +504,6 @@ __global__ void __launch_bounds__(256, 3) stem7_dgrad_c1_kernel(const float* __r
             *reinterpret_cast<float4*>(gt + slot * GP + c4) = v;
         }
         __syncthreads();
-        f32x16 acc0, acc1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
         const float* ap = gt + (wave * 32 + l31) * GP + kh2;
         const float* bp = Wt + kh2 * 64 + l31;
 #pragma unroll
@@ -293,6 +511,56 @@ __global__ void __launch_bounds__(256, 3) stem7_dgrad_c1_kernel(const float* __r
             const float av = ap[2 * kk];
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[2 * kk * 64], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[2 * kk * 64 + 32], acc1, 0, 0, 0);
+        }
+        } else {
+        // the window into registers, its maximum over the workgroup, then the two fp16 pieces of (value x 2^kg) into LDS
+        float4 sv[8];
+        float m = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int q = j * 256 + tid, slot = q >> 4, c4 = (q & 15) * 4;
+            const int wy = slot / 11, wx = slot - wy * 11;
+            const int oy = oy0 + wy, ox = ox0 + wx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (slot < 121 && (unsigned)oy < (unsigned)Ho && (unsigned)ox < (unsigned)Wo)
+                v = *reinterpret_cast<const float4*>(gy + (((size_t)img * Ho + oy) * Wo + ox) * 64 + c4);
+            sv[j] = v;
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+        m = wave_max(m);
+        __syncthreads();                                 // the previous tile's tap table (and its maxima) have been read; the bank is complete
+        if (lane == 0) smx[wave] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+        const int kg = bh_f16_scale_exp(__builtin_bit_cast(unsigned, m));
+        const float sg = __builtin_bit_cast(float, (unsigned)(127 + kg) << 23);
+        char* const gh = reinterpret_cast<char*>(gt);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int q = j * 256 + tid, slot = q >> 4, c4 = (q & 15) * 4;
+            uint2 hi, lo;
+            bh_split2_pair_f16(sv[j].x, sv[j].y, sg, hi.x, lo.x);
+            bh_split2_pair_f16(sv[j].z, sv[j].w, sg, hi.y, lo.y);
+            *reinterpret_cast<uint2*>(gh + (slot * HP + c4) * 2) = hi;
+            *reinterpret_cast<uint2*>(gh + 128 * HP * 2 + (slot * HP + c4) * 2) = lo;
+        }
+        __syncthreads();
+        const char* const ap = gh + ((wave * 32 + l31) * HP + 8 * kh2) * 2;
+        const char* const bp = reinterpret_cast<const char*>(Wt) + (kh2 * 64 + l31) * 16;
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+            const uint4 ah = *reinterpret_cast<const uint4*>(ap + s_ * 32), al = *reinterpret_cast<const uint4*>(ap + 128 * HP * 2 + s_ * 32);
+            const uint4 b0h = *reinterpret_cast<const uint4*>(bp + s_ * 2048), b0l = *reinterpret_cast<const uint4*>(bp + 8192 + s_ * 2048);
+            const uint4 b1h = *reinterpret_cast<const uint4*>(bp + s_ * 2048 + 512), b1l = *reinterpret_cast<const uint4*>(bp + 8192 + s_ * 2048 + 512);
+#define ST_MF(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(st_f16x8, A_), __builtin_bit_cast(st_f16x8, B_), C_, 0, 0, 0)
+            ST_MF(al, b0h, acc0); ST_MF(al, b1h, acc1);          // small products first, the two accumulators alternating
+            ST_MF(ah, b0l, acc0); ST_MF(ah, b1l, acc1);
+            ST_MF(ah, b0h, acc0); ST_MF(ah, b1h, acc1);
+#undef ST_MF
+        }
+        const int kout = -(kg + kw);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = __builtin_ldexpf(acc0[r], kout); acc1[r] = __builtin_ldexpf(acc1[r], kout); }
         }
         __syncthreads();                                 // every wave has read its gy rows: the table may overwrite them
         // C/D layout: col = lane&31 (tap), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (slot of the wave's 32)
@@ -345,12 +613,15 @@ extern "C" int bh_stem7_dgrad_c1(const float* gy, const float* w, float* gx, con
         d->Ho % 8 || d->Wo % 8 || d->Ho * 2 != d->Hi || d->Wo * 2 != d->Wi)
         return BH_E_UNSUPPORTED;
     if (d->N == 0) return BH_OK;
-    if (bh_query("stem7_dgrad_c1_kernel")) return BH_OK;
+    if (bh_query((d->precision == 4 && g_stem_f16) ? "stem7_dgrad_c1_kernel<false,true>" : "stem7_dgrad_c1_kernel")) return BH_OK;
     hipStream_t s = bh_stream(stream);
     const int tiles_x = d->Wo / 8, tpi = (d->Ho / 8) * tiles_x, ntiles = d->N * tpi;
     int blocks = 256 * 3;
     if (blocks > ntiles) blocks = ntiles;
-    hipLaunchKernelGGL(stem7_dgrad_c1_kernel<false>, dim3(blocks), dim3(256), 0, s, gy, w, gx, d->Ho, d->Wo, tiles_x, tpi, ntiles, Stem7WarpArgs{});
+    if (d->precision == 4 && g_stem_f16)       // (round 6: the fp16-piece arithmetic of the 3x3 layers)
+        hipLaunchKernelGGL((stem7_dgrad_c1_kernel<false, true>), dim3(blocks), dim3(256), 0, s, gy, w, gx, d->Ho, d->Wo, tiles_x, tpi, ntiles, Stem7WarpArgs{});
+    else
+        hipLaunchKernelGGL((stem7_dgrad_c1_kernel<false, false>), dim3(blocks), dim3(256), 0, s, gy, w, gx, d->Ho, d->Wo, tiles_x, tpi, ntiles, Stem7WarpArgs{});
     BH_LAUNCH_CHECK();
     return BH_OK;
 }
@@ -370,13 +641,16 @@ extern "C" int bh_stem7_dgrad_c1_warp(const float* gy, const float* w, float* gx
     for (int b = 0; b < 6; ++b) if (pool == (1 << b)) shift = b;
     if (shift < 0 || d->Hi % pool || d->Wi % pool || (long long)d->Hi * d->Wi * 4 >= (1ll << 31)) return BH_E_UNSUPPORTED;
     if (d->N == 0) return BH_OK;
-    if (bh_query("stem7_dgrad_c1_kernel<true>")) return BH_OK;
+    if (bh_query((d->precision == 4 && g_stem_f16) ? "stem7_dgrad_c1_kernel<true,true>" : "stem7_dgrad_c1_kernel<true>")) return BH_OK;
     hipStream_t s = bh_stream(stream);
     const int tiles_x = d->Wo / 8, tpi = (d->Ho / 8) * tiles_x, ntiles = d->N * tpi;
     int blocks = 256 * 3;
     if (blocks > ntiles) blocks = ntiles;
     Stem7WarpArgs wa = {src, H64, g_cov, gH, shift, 1.0f / (float)(pool * pool)};
-    hipLaunchKernelGGL(stem7_dgrad_c1_kernel<true>, dim3(blocks), dim3(256), 0, s, gy, w, gx, d->Ho, d->Wo, tiles_x, tpi, ntiles, wa);
+    if (d->precision == 4 && g_stem_f16)
+        hipLaunchKernelGGL((stem7_dgrad_c1_kernel<true, true>), dim3(blocks), dim3(256), 0, s, gy, w, gx, d->Ho, d->Wo, tiles_x, tpi, ntiles, wa);
+    else
+        hipLaunchKernelGGL((stem7_dgrad_c1_kernel<true, false>), dim3(blocks), dim3(256), 0, s, gy, w, gx, d->Ho, d->Wo, tiles_x, tpi, ntiles, wa);
     BH_LAUNCH_CHECK();
     return BH_OK;
 }

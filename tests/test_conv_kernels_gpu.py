@@ -144,6 +144,32 @@ def test_gray_stem_conv_and_its_dgrad(K, N, Hi, det):
     close(gx.cpu().reshape(N, 1, Hi, Hi), xt.grad)
 
 
+@pytest.mark.parametrize("N,Hi,scale", [(8, 64, 1.0), (4, 128, 1e-4), (3, 128, 30.0)])
+def test_gray_stem_dgrad_in_fp16_pieces(K, N, Hi, scale):
+    """Round 6 (stem7_dgrad_c1_kernel<.., F16>; bh_conv_desc.precision = 4): the one-channel stem's dgrad with the window GEMM in the fp16-piece
+    arithmetic - against torch float64 next to the fp32-input MFMA form on the same data (error <= 1.5x), gradients of very different
+    magnitudes incl. a tile that is all zeros and one 1e-5 of the rest (the tile's scale comes from its own maximum)."""
+    g = torch.Generator().manual_seed(21 + Hi)
+    w = torch.randn(64, 1, 7, 7, generator=g, dtype=torch.float64) / 7
+    gy = torch.randn(N, 64, Hi // 2, Hi // 2, generator=g, dtype=torch.float64) * scale
+    gy[0, :, :8, :8] = 0.0
+    gy[-1, :, 8:24, 8:24] *= 1e-5
+    xt = torch.zeros(N, 1, Hi, Hi, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xt, w, None, stride=2, padding=3).backward(gy)
+    ref = xt.grad
+    wg = w.float().permute(0, 2, 3, 1).contiguous().cuda()
+    gyk = gy.float().permute(0, 2, 3, 1).contiguous().cuda()
+    err = {}
+    for prec in (0, 4):
+        d = K.conv_desc(N, Hi, Hi, 1, 64, 7, 2, 3, precision=prec)
+        gx = K.conv_dgrad(gyk, wg, d).cpu().double().reshape(N, 1, Hi, Hi)
+        err[prec] = ((gx - ref).norm() / ref.norm()).item()
+        err[(prec, "dim")] = ((gx[-1, :, 20:44, 20:44] - ref[-1, :, 20:44, 20:44]).norm() / ref[-1, :, 20:44, 20:44].norm()).item()
+    print("\nstem dgrad N%d H%d scale %g: rel-L2 vs f64  fp32-input MFMA %.2e  fp16 pieces %.2e;  dim region %.2e / %.2e"
+          % (N, Hi, scale, err[0], err[4], err[(0, "dim")], err[(4, "dim")]))
+    assert err[4] <= 1.5 * err[0] + 1e-8 and err[(4, "dim")] <= 1.5 * err[(0, "dim")] + 1e-7, err
+
+
 def test_last_conv_nchw_output(K):
     """1x1 128->2 with bias writing the NCHW perspective field (Rethinking.py:147) and adjoints fed by an
     NCHW gradient."""
@@ -474,6 +500,49 @@ def test_stem7_forward_kernel(K, N, H, Ci, relu):
     assert K.conv_variant(d0, "fwd").startswith("conv_gemm_kernel")
     y0 = K.conv_fwd(xk, wk, b.float().cuda(), d0, relu=relu)
     close(y.cpu(), y0.cpu(), 2e-5)
+
+
+@pytest.mark.parametrize("N,H,Ci,relu,scale", [(4, 128, 1, False, 1.0), (4, 128, 2, True, 1.0), (16, 64, 1, False, 300.0), (8, 128, 2, False, 1e-3)])
+def test_stem7_forward_in_fp16_pieces(K, N, H, Ci, relu, scale):
+    """Round 6 (stem7_fwd_f16_kernel, csrc/stem7.hip; bh_conv_desc.precision = 4): the one- and two-plane stems in the fp16-piece
+    arithmetic of the 3x3 layers - against torch float64, next to the fp32-input MFMA kernel on the same data (error <= 1.5x its error),
+    with inputs of very different magnitudes (the patch's scale is taken per tile, the filter bank's per launch: no magnitude record), dark
+    tiles in a bright image, and the BatchNorm sums of the epilogue."""
+    g = torch.Generator().manual_seed(7 + Ci)
+    x = torch.randn(N, Ci, H, H, generator=g, dtype=torch.float64) * scale
+    x[0, :, : H // 2] *= 1e-4                                 # a dark half image: its tiles get their own scale
+    x[-1, :, 16:32, 16:32] = 0.0                              # an all-zero tile
+    w = torch.randn(64, Ci, 7, 7, generator=g, dtype=torch.float64) * 0.1
+    b = torch.randn(64, generator=g, dtype=torch.float64) * scale
+    ref = F.conv2d(x, w, b, 2, 3)
+    if relu:
+        ref = F.relu(ref)
+    xk = x.float().cuda().contiguous()
+    if Ci == 1:
+        xk = xk.view(N, H, H, 1)
+    wk = w.float().cuda().permute(0, 2, 3, 1).contiguous()
+    err = {}
+    for prec in (0, 4):
+        d = K.conv_desc(N, H, H, Ci, 64, 7, 2, 3, in_nchw=Ci != 1, precision=prec)
+        assert K.conv_variant(d, "fwd") == ("stem7_fwd_f16_kernel<%d>" if prec == 4 else "stem7_fwd_kernel<%d>") % Ci
+        y = K.conv_fwd(xk, wk, b.float().cuda(), d, relu=relu)
+        yd = y.permute(0, 3, 1, 2).cpu().double()
+        err[prec] = ((yd - ref).norm() / ref.norm()).item()
+        # per dark region as well: the dark half image must keep its relative accuracy
+        dark = ((yd[0, :, : H // 4 - 2] - ref[0, :, : H // 4 - 2]).norm() / ref[0, :, : H // 4 - 2].norm()).item()
+        err[(prec, "dark")] = dark
+    print("\nstem forward N%d H%d Ci%d scale %g: rel-L2 vs f64  fp32-input MFMA %.2e  fp16 pieces %.2e;  dark half image %.2e / %.2e"
+          % (N, H, Ci, scale, err[0], err[4], err[(0, "dark")], err[(4, "dark")]))
+    assert err[4] <= 1.5 * err[0] + 1e-8 and err[(4, "dark")] <= 1.5 * err[(0, "dark")] + 1e-7, err
+    # BatchNorm statistics of the output from the epilogue (what the model asks for), in two groups
+    if not relu:
+        d = K.conv_desc(N, H, H, Ci, 64, 7, 2, 3, in_nchw=Ci != 1, precision=4)
+        sums = K.bn_stats_buffer(2, 64, "cuda")
+        y2 = K.conv_fwd(xk, wk, None, d, bn_sums=sums, groups=2)
+        yd = y2.double().reshape(2, -1, 64)
+        tab = sums.reshape(K.BN_SUM_SLOTS, 2, 64, 2, K.BN_SUM_STRIDE)[..., 0].sum(0).cpu()
+        refs = torch.stack([yd.sum(1), (yd * yd).sum(1)], -1).cpu()
+        assert ((tab - refs).abs() <= 1e-6 * refs.abs().max()).all()
 
 
 @pytest.mark.parametrize("N,H,Ci,Co,groups", [(4, 8, 32, 32, 2), (8, 8, 64, 32, 2)])

@@ -377,8 +377,9 @@ def test_scale_samples_and_scored_hinge_vs_torch64():
     assert (gm.cpu().double() - m.grad).abs().max() <= 2e-4 * m.grad.abs().max() + 1e-7
 
 
+@pytest.mark.parametrize("prec", [0, 4])
 @pytest.mark.parametrize("B,size,pool,with_cov", [(6, 128, 4, True), (3, 64, 4, True), (5, 128, 8, True), (4, 32, 4, False), (2, 256, 16, True)])
-def test_stem_dgrad_with_the_warp_adjoint_folded_in(K, B, size, pool, with_cov):
+def test_stem_dgrad_with_the_warp_adjoint_folded_in(K, B, size, pool, with_cov, prec):
     """Round 6 (bh_stem7_dgrad_c1_warp, include/bihome.h): the extractor stem's dgrad that applies the warp's adjoint to the gradient it has
     just made, against the two calls it replaces - bh_stem7_dgrad_c1, then bh_warp_bwd on its output: the gradient image (when asked for)
     bit for bit, dL/dH to float rounding of the per-pixel products (same taps bitwise: warp_tap.h)."""
@@ -390,7 +391,7 @@ def test_stem_dgrad_with_the_warp_adjoint_folded_in(K, B, size, pool, with_cov):
     w = torch.tensor((rng.standard_normal((64, 7, 7, 1)) * 0.05).astype(np.float32)).cuda()
     gcov = torch.tensor(rng.standard_normal((B, size // pool, size // pool)).astype(np.float32)).cuda() if with_cov else None
     H64, _ = K.h4pt_fwd(dev(rand_delta(B, size + 1, amp=size / 4.0)), size)
-    d = K.conv_desc(B, size, size, 1, 64, 7, 2, 3)
+    d = K.conv_desc(B, size, size, 1, 64, 7, 2, 3, precision=prec)     # (4: the window GEMM in fp16 pieces - both entry points, the same tiles)
     p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     gx0 = torch.empty(B, size, size, 1, device="cuda")
@@ -413,5 +414,5 @@ def test_stem_dgrad_with_the_warp_adjoint_folded_in(K, B, size, pool, with_cov):
     # (the two calls are held against the float64 oracle by test_warp_fwd_bwd; a direct comparison on THESE inputs would measure how many
     #  pixels float32 coordinates put on the other side of an integer - the bilinear derivative jumps there - not the kernel)
     # geometries the kernel does not take are refused, not guessed
-    d2 = K.conv_desc(B, size, size, 1, 64, 7, 2, 3)
+    d2 = K.conv_desc(B, size, size, 1, 64, 7, 2, 3, precision=prec)
     assert lib.bh_stem7_dgrad_c1_warp(p(gy), p(w), None, ctypes.byref(d2), p(src), p(H64), p(gcov), 3, p(gH1), stream) == -2

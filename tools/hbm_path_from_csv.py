@@ -20,8 +20,8 @@ if wb == wb:
     print("%-46s %7.2f us (%s calls)" % ("warp_bwd4_kernel", wb, calls))
     tot += wb
 else:
-    fused, c1 = avg(rows, "stem7_dgrad_c1_kernel<true>")
-    plain, c2 = avg(rows2, "stem7_dgrad_c1_kernel<false>")
+    fused, c1 = avg(rows, "stem7_dgrad_c1_kernel<true")
+    plain, c2 = avg(rows2, "stem7_dgrad_c1_kernel<false")
     sep, c3 = avg(rows2, "warp_bwd4_kernel")
     print("%-46s %7.2f us (%s calls)" % ("stem7_dgrad_c1_kernel<true> (warp adjoint inside)", fused, c1))
     print("%-46s %7.2f us (%s calls; second csv)" % ("stem7_dgrad_c1_kernel<false>", plain, c2))

@@ -14,7 +14,7 @@ gcov = [torch.randn(B, size // pool, size // pool, device='cuda') for _ in range
 w = torch.randn(64, 7, 7, 1, device='cuda') * 0.05
 gx = torch.empty(B, size, size, 1, device='cuda')
 gH = torch.zeros(B, 9, dtype=torch.float64, device='cuda')
-d = K.conv_desc(B, size, size, 1, 64, 7, 2, 3)
+d = K.conv_desc(B, size, size, 1, 64, 7, 2, 3, precision=int(os.environ.get("STEM_PREC", "4")))
 p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 def plain(i): check(lib.bh_stem7_dgrad_c1(p(gy[i]), p(w), p(gx), ctypes.byref(d), st()), "plain")
