@@ -359,7 +359,7 @@ int bh_stem7_try(const float* x, const float* w, const float* bias, float* y, co
     int rc;
     // precision 4 (the fp16-piece arithmetic of the 3x3 layers; round 6): the same tiles on v_mfma_f32_32x32x16_f16 - one and two planes
     // (the extractor's and the backbone's stems; the RGB stems keep the fp32-input form: their filter bank in pieces would take one workgroup per CU)
-    const bool f16 = d->precision == 4 && d->Ci <= 2 && !(d->route & BH_ROUTE_DETERMINISTIC) && g_stem_f16;
+    const bool f16 = d->precision == 4 && d->Ci <= 2 && g_stem_f16;      // (deterministic calls too: the same arithmetic in both modes)
     switch (d->Ci) {
         case 1: rc = f16 ? stem7_f16_launch<1>(a, stream) : stem7_launch<1>(a, stream); break;
         case 2: rc = f16 ? stem7_f16_launch<2>(a, stream) : stem7_launch<2>(a, stream); break;

@@ -197,7 +197,11 @@ def test_two_models_of_one_process_run_in_different_modes():
         assert not bad, bad[:10]
         # the default model: same arithmetic, atomics order differs (after one Adam step from random weights the near-cancelling loss
         # moves by a few 1e-5 between two default runs as well: a sanity band, the bitwise assertions above are the claim)
-        assert abs(lb[0] - la[0]) <= 1e-4 * abs(la[0]) + 1e-5
+        # (round 6: the default model folds the warp's adjoint into the extractor stem's dgrad, the deterministic one runs the two calls - the
+        #  same taps bit for bit, gradients equal to 2.6e-6 in every tensor (tools/grad_arith_diff.py "f16x2@BIHOME_WARP_IN_STEM_DGRAD=1"
+        #  against "...=0"), and one Adam step from random weights turns a relative gradient difference d into ~100 d of this loss: the
+        #  atomics' 1e-7 into the "few 1e-5" above, 2.6e-6 into 3e-4 - measured 2.9e-4.  A sanity band, hence 2e-3.)
+        assert abs(lb[0] - la[0]) <= 2e-3 * abs(la[0]) + 1e-5
     finally:
         K.set_deterministic(prev)
 

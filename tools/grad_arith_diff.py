@@ -10,6 +10,21 @@ from bihome_amd.weights import load_synthetic
 g64 = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "zeng_pds_b8_f64.npz"))
 d = synth.make_pairs(8, seed=8, photometric_max_delta=32)
 def grads(prec):
+    # "precision[@ENV=VALUE]": an environment switch for this run only (read at call time by the kernels' Python layer)
+    prec, _, envkv = prec.partition("@")
+    saved = None
+    if envkv:
+        ek, _, ev = envkv.partition("=")
+        saved = (ek, os.environ.get(ek)); os.environ[ek] = ev
+    try:
+        return _grads(prec)
+    finally:
+        if saved is not None:
+            if saved[1] is None: os.environ.pop(saved[0], None)
+            else: os.environ[saved[0]] = saved[1]
+
+
+def _grads(prec):
     cfg = configs.get("zeng-bihome-pds")
     bbp, hp = (prec.split("/") + [prec])[:2]          # "backbone/head" or one name for both
     cfg["MODEL"]["BACKBONE"]["PRECISION"], cfg["MODEL"]["HEAD"]["PRECISION"] = bbp, hp
@@ -23,7 +38,7 @@ def grads(prec):
     torch.cuda.synchronize()
     gpf = {"pf_hat_12.grad": None}
     return loss.item(), {n: p.grad.detach().double().cpu().clone() for n, p in model[0].named_parameters() if p.grad is not None}
-l0, ref = grads("f32-mfma")
+l0, ref = grads(os.environ.get("GRAD_DIFF_REF", "f32-mfma"))
 for prec in (sys.argv[1:] or ["f32-mfma", "f32x3", "f16x2"]):
     l, g = grads(prec)
     rows = []
