@@ -1014,6 +1014,7 @@ int bh_debug_force_tile(int bm, int bn) {
     if (bm == -36) { bh_wgrad_x3_tune(3, bn); return BH_OK; }            // (-36, 0 / 1): the 4 x 4-map form of the fp16-piece weight gradient off / on
     if (bm == -32) { bh_wgrad_x3_tune(2, bn); return BH_OK; }            // (-32, 0 / 1): the fp16-piece kernel's four-wave / eight-wave (producer + consumer) form
     if (bm == -20) { bh_bn_tune(bn); return BH_OK; }                     // (-20, n): workgroups per BatchNorm apply launch
+    if (bm == -47) { bh_stem7_tune(bn); return BH_OK; }                  // (-47, 0 / 1): the stems' fp16-piece forms (forward, one-channel dgrad) off / on
     if (bm == -14) { bh_warp_tune(0, bn); return BH_OK; }               // (-14, 1|2): warp forward rows per thread
     if (bm == -15) { bh_warp_tune(1, bn); return BH_OK; }               // (-15, 1|2|4): warp adjoint rows per thread
     if (bm == -12) { bh_conv3x3_tune(20 + bn, 0); return BH_OK; }      // (-12, 1|2): 3x3 kernel tile positions per workgroup on two-round launches

@@ -282,6 +282,9 @@ __global__ void __launch_bounds__(256) stem7_fwd_f16_kernel(Stem7Args a) {
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(st_f16x8, ah), __builtin_bit_cast(st_f16x8, bl), acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(st_f16x8, ah), __builtin_bit_cast(st_f16x8, bh), acc, 0, 0, 0);
         }
+        // (the last products must have left the matrix pipe before their registers are read: spelled out, as in conv3x3_pc_kernel - this
+        //  compiler's own padding did not survive every loop structure there)
+        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc));
         const int kout = -(kx + kw);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -396,6 +399,7 @@ struct Stem7WarpArgs {
     double* gH;            // [N][9], accumulated (+=)
     int pool_shift;        // log2(pool)
     float cov_scale;       // 1 / pool^2
+    int wpi;               // workgroups per image (the grid is N * wpi)
 };
 
 // F16 (round 6; bh_conv_desc.precision = 4): the window GEMM in the fp16-piece arithmetic of the 3x3 layers - gy tile and filter bank as two
@@ -444,10 +448,17 @@ __global__ void __launch_bounds__(256, 3) stem7_dgrad_c1_kernel(const float* __r
     const int Hi = 2 * Ho, Wi = 2 * Wo;
     const int py = tid >> 4, px = tid & 15;              // this thread's image pixel inside the tile
     // WARP: a contiguous range of tiles per workgroup (image order: the nine sums live in registers across the tiles of one image)
-    const int t_lo = WARP ? (int)(((long long)blockIdx.x * ntiles) / gridDim.x) : (int)blockIdx.x;
-    const int t_hi = WARP ? (int)(((long long)(blockIdx.x + 1) * ntiles) / gridDim.x) : ntiles;
-    const int t_step = WARP ? 1 : (int)gridDim.x;
+    // WARP: wa.wpi workgroups per image, workgroup j of an image takes its tiles j, j + wpi, ... - the nine sums stay in registers for the
+    // workgroup's whole life (ONE reduction and nine atomics per workgroup), and the workgroups that run together work on neighbouring
+    // tiles of the same images, so the 11 x 11 windows' overlap is served by the L2 as in the plain kernel's strided walk
+    const int w_img = WARP ? (int)blockIdx.x / wa.wpi : 0, w_j = WARP ? (int)blockIdx.x - w_img * wa.wpi : 0;
+    const int t_lo = WARP ? w_img * tiles_per_img + w_j : (int)blockIdx.x;
+    const int t_hi = WARP ? (w_img + 1) * tiles_per_img : ntiles;
+    const int t_step = WARP ? wa.wpi : (int)gridDim.x;
     __shared__ double wpart[4][9];
+    // (Round 6 also tried the nine per-thread sums in float - a thread sees <= ~11 pixels - with the double starting at the wave reduction:
+    //  no faster, and with the fp16-piece window GEMM in the same kernel the sums came out wrong in a few images per launch, differently
+    //  from run to run (tests/test_head_kernels_gpu.py's multi-tile cases; not root-caused - the double form below is bit-stable).)
     double ws[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) ws[k] = 0.0;
@@ -558,6 +569,7 @@ __global__ void __launch_bounds__(256, 3) stem7_dgrad_c1_kernel(const float* __r
             ST_MF(ah, b0h, acc0); ST_MF(ah, b1h, acc1);
 #undef ST_MF
         }
+        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc0), "+v"(acc1));      // (as above: the products have left the matrix pipe)
         const int kout = -(kg + kw);
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = __builtin_ldexpf(acc0[r], kout); acc1[r] = __builtin_ldexpf(acc1[r], kout); }
@@ -644,9 +656,12 @@ extern "C" int bh_stem7_dgrad_c1_warp(const float* gy, const float* w, float* gx
     if (bh_query((d->precision == 4 && g_stem_f16) ? "stem7_dgrad_c1_kernel<true,true>" : "stem7_dgrad_c1_kernel<true>")) return BH_OK;
     hipStream_t s = bh_stream(stream);
     const int tiles_x = d->Wo / 8, tpi = (d->Ho / 8) * tiles_x, ntiles = d->N * tpi;
-    int blocks = 256 * 3;
-    if (blocks > ntiles) blocks = ntiles;
-    Stem7WarpArgs wa = {src, H64, g_cov, gH, shift, 1.0f / (float)(pool * pool)};
+    // three workgroups per CU as the plain kernel, as whole workgroups per image (>= 1, <= one per tile)
+    int wpi = (256 * 3) / d->N;
+    if (wpi < 1) wpi = 1;
+    if (wpi > tpi) wpi = tpi;
+    const int blocks = d->N * wpi;
+    Stem7WarpArgs wa = {src, H64, g_cov, gH, shift, 1.0f / (float)(pool * pool), wpi};
     if (d->precision == 4 && g_stem_f16)
         hipLaunchKernelGGL((stem7_dgrad_c1_kernel<true, true>), dim3(blocks), dim3(256), 0, s, gy, w, gx, d->Ho, d->Wo, tiles_x, tpi, ntiles, wa);
     else

@@ -378,7 +378,8 @@ def test_scale_samples_and_scored_hinge_vs_torch64():
 
 
 @pytest.mark.parametrize("prec", [0, 4])
-@pytest.mark.parametrize("B,size,pool,with_cov", [(6, 128, 4, True), (3, 64, 4, True), (5, 128, 8, True), (4, 32, 4, False), (2, 256, 16, True)])
+@pytest.mark.parametrize("B,size,pool,with_cov", [(6, 128, 4, True), (3, 64, 4, True), (5, 128, 8, True), (4, 32, 4, False), (2, 256, 16, True),
+                                                 (16, 128, 4, True), (40, 128, 4, True), (130, 64, 4, True)])     # (the last three: several tiles per workgroup)
 def test_stem_dgrad_with_the_warp_adjoint_folded_in(K, B, size, pool, with_cov, prec):
     """Round 6 (bh_stem7_dgrad_c1_warp, include/bihome.h): the extractor stem's dgrad that applies the warp's adjoint to the gradient it has
     just made, against the two calls it replaces - bh_stem7_dgrad_c1, then bh_warp_bwd on its output: the gradient image (when asked for)
