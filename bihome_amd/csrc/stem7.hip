@@ -480,11 +480,12 @@ __global__ void __launch_bounds__(256, 3) stem7_dgrad_c1_kernel(const float* __r
         const int img = tile / tiles_per_img, t = tile - img * tiles_per_img;
         const int ty = t / tiles_x, tx = t - ty * tiles_x;
         const int oy0 = ty * 8 - 1, ox0 = tx * 8 - 1;    // first gy pixel of the window: image rows 16 ty .. 16 ty + 15 see oy0 .. oy0 + 10
-        // WARP: this thread's pixel, its tap and the four source pixels are requested NOW - they depend on the homography only, so the
-        // gathers' latency (and the tap arithmetic) sits under the staging and the MFMAs below instead of behind the tile's last barrier
+        // WARP: this thread's pixel, its tap and the four source pixels are requested early - they depend on the homography only, so the gathers'
+        // latency (and the tap arithmetic) sits under the staging and the MFMAs below instead of behind the tile's last barrier - but BEHIND the
+        // window's own loads (F16): the vector-memory counter is in order, and gathers requested first made every tile wait for them
         Tap4 tp = {};
         float wp00 = 0.f, wp01 = 0.f, wp10 = 0.f, wp11 = 0.f, wgc = 0.f;
-        if constexpr (WARP) {
+        auto warp_top = [&]() {
             if (img != cur_img) {
                 if (cur_img >= 0) warp_flush(cur_img);
                 cur_img = img;
@@ -497,10 +498,11 @@ __global__ void __launch_bounds__(256, 3) stem7_dgrad_c1_kernel(const float* __r
             wp00 = ldtap(rs, tp.o00); wp01 = ldtap(rs, tp.o01); wp10 = ldtap(rs, tp.o10); wp11 = ldtap(rs, tp.o11);
             if (wa.g_cov)
                 wgc = wa.g_cov[((size_t)img * ((2 * Ho) >> wa.pool_shift) + (iy_ >> wa.pool_shift)) * ((2 * Wo) >> wa.pool_shift) + (ix_ >> wa.pool_shift)] * wa.cov_scale;
-        }
+        };
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        if constexpr (WARP && !F16) warp_top();
         if constexpr (!F16) {
         __syncthreads();                                 // the previous tile's tap table has been read (and Wt is complete)
         // 128 window slots x 16 float4: thread -> (slot, 4 channels); slots past 121 and pixels outside gy are zero
@@ -536,8 +538,11 @@ __global__ void __launch_bounds__(256, 3) stem7_dgrad_c1_kernel(const float* __r
             if (slot < 121 && (unsigned)oy < (unsigned)Ho && (unsigned)ox < (unsigned)Wo)
                 v = *reinterpret_cast<const float4*>(gy + (((size_t)img * Ho + oy) * Wo + ox) * 64 + c4);
             sv[j] = v;
-            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         }
+        if constexpr (WARP) warp_top();                   // (behind the window's loads in the in-order vector-memory queue)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(sv[j].x), fabsf(sv[j].y))), fmaxf(fabsf(sv[j].z), fabsf(sv[j].w)));
         m = wave_max(m);
         __syncthreads();                                 // the previous tile's tap table (and its maxima) have been read; the bank is complete
         if (lane == 0) smx[wave] = m;

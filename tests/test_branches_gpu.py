@@ -141,7 +141,11 @@ def test_detone_three_steps_vs_golden(golden, precision, head_precision):
     if precision in ("f32", "f32x2"):      # 'f32x2' (two rounded bf16 pieces, three products) is held to the float32 tolerances
         assert abs(losses[0] - g64["loss"][0]) <= max(3 * abs(g32["loss"][0] - g64["loss"][0]), 1e-4 * abs(g64["loss"][0]))
         assert abs(maces[0] - g64["mace"][0]) < 1e-3
-        mult, lrel, mfloor = 5.0, 0.05, 0.05
+        # (mfloor, round 6: profiles/r06p_detone_perturb.txt - inputs x (1 + k 2^-22), k = 0..8, move the SECOND step's MACE of one and the same
+        #  arithmetic over -0.020 ... +0.065 px (fp32-input MFMA) / -0.009 ... +0.068 px (fp16 pieces), the third step's by +-0.5 px: which side
+        #  of the earlier 0.05 a build lands on is rounding (this build +0.067 with the stems in fp16 pieces, +0.019 ... +0.065 without);
+        #  DESIGN.md 0.1 finding 3 has the mechanism.  0.15 px = ~5 sigma of that spread.)
+        mult, lrel, mfloor = 5.0, 0.05, 0.15
     else:
         assert abs(losses[0] - g64["loss"][0]) <= 5e-2 * abs(g64["loss"][0])
         assert abs(maces[0] - g64["mace"][0]) < 2e-2

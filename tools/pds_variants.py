@@ -12,20 +12,22 @@ import numpy as np, torch
 from bihome_amd import configs, synth
 from bihome_amd.step import build_model, build_optimizer, mace, train_step
 from bihome_amd.weights import load_synthetic
-g64 = np.load(os.path.join(%r, "tests", "golden", "zeng_pds_b8_f64.npz"))
-d = synth.make_pairs(8, seed=8, photometric_max_delta=32)
+CASE = os.environ.get("PDS_CASE", "zeng-pds")      # "detone": configs[3]'s three-step test (tests/test_branches_gpu.py::test_detone_three_steps_vs_golden)
+g64 = np.load(os.path.join(%r, "tests", "golden", "detone_b8_f64.npz" if CASE == "detone" else "zeng_pds_b8_f64.npz"))
+d = synth.make_pairs(8, seed=5) if CASE == "detone" else synth.make_pairs(8, seed=8, photometric_max_delta=32)
 _k = int(os.environ.get("PDS_PERTURB", "0"))
 if _k:        # rounding-level perturbation of the inputs: every pixel times (1 + k 2^-22) - what a different summation order does to a forward pass
     for key in ("patch_1", "patch_2"):
         d[key] = (d[key].astype(np.float64) * (1.0 + _k * 2.0 ** -22)).astype(np.float32)
-cfg = configs.get("zeng-bihome-pds")
+cfg = configs.get("detone-bihome" if CASE == "detone" else "zeng-bihome-pds")
 cfg["MODEL"]["BACKBONE"]["PRECISION"] = cfg["MODEL"]["HEAD"]["PRECISION"] = sys.argv[1]
 model = build_model(cfg); load_synthetic(model[0], 0); load_synthetic(model[1].auxiliary_resnet, 0); model.train()
 opt, sched = build_optimizer(model, cfg["SOLVER"])
 M = []
 for it in range(3):
     data = {k: torch.tensor(d[k]).cuda() for k in ("patch_1", "patch_2", "delta")}
-    data["choice_12"] = torch.tensor(g64["choice_12"][it]).long().cuda(); data["choice_21"] = torch.tensor(g64["choice_21"][it]).long().cuda()
+    if CASE != "detone":
+        data["choice_12"] = torch.tensor(g64["choice_12"][it]).long().cuda(); data["choice_21"] = torch.tensor(g64["choice_21"][it]).long().cuda()
     loss, dgt, dh = train_step(model, data, opt, sched)
     M.append(mace(dgt, dh) - float(g64["mace"][it]))
 print("RESULT %%+.4f %%+.4f %%+.4f" %% tuple(M))
