@@ -183,6 +183,47 @@ def warp_adjoint_fold_cost(B2, size, pool=4, rounds=4, n=40):
             "rounds": rounds, "launches_per_round": n}
 
 
+def warp_forward_fold_cost(B2, size, rounds=4, n=40):
+    """Per-launch time of the one-plane fp16-piece stem forward on a resident image (bh_conv_fwd_bnstats) and of bh_stem7_fwd_warp (the same
+    stem making the warped pixels and the pooled coverage on the way, as the step calls it: the warped image is not written) on B2 images of size x size, buffer sets rotating
+    beyond the Infinity Cache; returns the best round of each and the difference."""
+    import ctypes
+    from bihome_amd import kernels as K
+    from bihome_amd._lib import check, lib
+    nset = 6
+    H64, _ = K.h4pt_fwd((torch.rand(B2, 4, 2, device="cuda") - 0.5) * (size / 4.0), size)
+    src = [torch.randn(B2, 1, size, size, device="cuda") for _ in range(nset)]
+    y = [torch.empty(B2, size // 2, size // 2, 64, device="cuda") for _ in range(nset)]
+    cov = torch.empty(B2, size // 4, size // 4, device="cuda")
+    sums = K.bn_stats_buffer(2, 64, "cuda")
+    w = torch.randn(64, 7, 7, 1, device="cuda") * 0.05
+    d = K.conv_desc(B2, size, size, 1, 64, 7, 2, 3, precision=4)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def plain(i):
+        check(lib.bh_conv_fwd_bnstats(p(src[i]), p(w), None, p(y[i]), ctypes.byref(d), p(sums), 2, st), "bh_conv_fwd_bnstats")
+
+    def fused(i):
+        check(lib.bh_stem7_fwd_warp(p(src[i]), p(H64), 4, p(w), None, p(y[i]), ctypes.byref(d), None, p(cov), p(sums), 2, st), "bh_stem7_fwd_warp")
+
+    def run(fn):
+        for i in range(nset):
+            fn(i)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for i in range(n):
+            fn(i % nset)
+        b.record()
+        torch.cuda.synchronize()
+        return 1e3 * a.elapsed_time(b) / n
+    tp, tf = [], []
+    for _ in range(rounds):
+        tp.append(run(plain)); tf.append(run(fused))
+    return {"plain_stem_fwd_us": round(min(tp), 2), "with_warp_us": round(min(tf), 2), "added_us": round(max(min(tf) - min(tp), 0.0), 2),
+            "rounds": rounds, "launches_per_round": n}
+
+
 def roofline_leg(model, data, opt, sched, reducer, nsteps=2):
     """Per-launch HIP-event timing (events recorded on the launch stream) of every conv/BN launch for a few
     extra steps; returns the roofline object of the kernel with the largest total time plus a breakdown."""
@@ -224,17 +265,25 @@ def roofline_leg(model, data, opt, sched, reducer, nsteps=2):
     # BASELINE.json's HBM-bound part: homography warp + perceptual-feature L1 / triplet reduction (SURVEY.md 8(d) bytes)
     hp = [r for r in rows if r["kernel"] in ("warp_fwd_kernel", "warp_bwd_kernel", "triplet_fwd_kernel", "triplet_bwd_kernel")]
     hbm_path = None
-    fold = None
-    if hp and any(r["kernel"] == "stem7_dgrad_c1_kernel<true>" for r in rows) and not any(r["kernel"] == "warp_bwd_kernel" for r in rows):
+    fold = ffold = None
+    names = {r["kernel"] for r in rows}
+    B2_, size_ = data["patch_1"].shape[0] * 2, data["patch_1"].shape[-1]
+    warp_bytes = 4.0 * (2 * B2_ * size_ * size_ + B2_ * (size_ // 4) ** 2)      # 8 B / pixel + the pooled coverage, each direction
+    if hp and "stem7_fwd_f16_kernel<1,true>" in names and "warp_fwd_kernel" not in names:
+        # round 6: the warp runs INSIDE the extractor stem's forward (bh_stem7_fwd_warp) - there is no warp_fwd launch to time.  Its cost is
+        # what it adds to that launch: the fused and the plain stem forward timed back to back on buffers of the step's shape
+        ffold = warp_forward_fold_cost(B2_, size_)
+        hp = hp + [{"kernel": "warp_fwd (folded into stem7_fwd_f16_kernel<1,true>: its launch time over the plain stem forward's)",
+                    "launches_per_step": 0, "ms_per_step": 1e-3 * ffold["added_us"], "avg_us": ffold["added_us"],
+                    "gbs": warp_bytes / (max(ffold["added_us"], 1e-3) * 1e-6) / 1e9, "bytes_per_launch": warp_bytes, "bytes_total": warp_bytes}]
+    if hp and "stem7_dgrad_c1_kernel<true>" in names and "warp_bwd_kernel" not in names:
         # round 6: the warp's adjoint runs INSIDE the extractor stem's dgrad (bh_stem7_dgrad_c1_warp) - there is no warp_bwd launch to time.
         # Its cost is what it adds to that launch: the fused and the plain stem dgrad timed back to back on buffers of the step's shape
         # (alternating rounds, per-launch time from one event pair around each round); its bytes stay SURVEY 8(d)'s (image + gradient read).
-        fold = warp_adjoint_fold_cost(data["patch_1"].shape[0] * 2, data["patch_1"].shape[-1])
-        wf = next(r for r in hp if r["kernel"] == "warp_fwd_kernel")
+        fold = warp_adjoint_fold_cost(B2_, size_)
         hp = hp + [{"kernel": "warp_bwd (folded into stem7_dgrad_c1_kernel<true>: its launch time over the plain stem dgrad's)",
                     "launches_per_step": 0, "ms_per_step": 1e-3 * fold["added_us"], "avg_us": fold["added_us"],
-                    "gbs": wf["bytes_per_launch"] / (max(fold["added_us"], 1e-3) * 1e-6) / 1e9, "bytes_per_launch": wf["bytes_per_launch"],
-                    "bytes_total": wf["bytes_per_launch"]}]
+                    "gbs": warp_bytes / (max(fold["added_us"], 1e-3) * 1e-6) / 1e9, "bytes_per_launch": warp_bytes, "bytes_total": warp_bytes}]
     if hp:
         # these launches take 12-20 us, so the cost of the event pair itself matters: time empty pairs on the same stream
         # (median) and report the path both as recorded and net of that; profiles/*kernel_stats.csv holds rocprofv3's
@@ -252,7 +301,7 @@ def roofline_leg(model, data, opt, sched, reducer, nsteps=2):
         hbm_path = {"kernels": {r["kernel"]: {"us": round(r["avg_us"], 1), "GB/s": round(r["gbs"], 1)} for r in hp},
                     "algorithmic_bytes_per_step": by_, "ms_per_step": round(ms_, 4), "achieved_GBs": round(by_ / (ms_ * 1e-3) / 1e9, 1),
                     "frac_of_hbm_peak": round(by_ / (ms_ * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                    "warp_adjoint_fold": fold,
+                    "warp_adjoint_fold": fold, "warp_forward_fold": ffold,
                     "empty_event_pair_us": round(ovh_us, 2), "ms_per_step_net_of_event_pairs": round(net_, 4),
                     "frac_of_hbm_peak_net_of_event_pairs": round(by_ / (net_ * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
     # the same launches grouped by kernel template (all instantiations of one __global__ function)

@@ -109,6 +109,7 @@ SIGNATURES = {
     "bh_col2im_c1": [P, P, POINTER(BhConvDesc), c_int, P],
     "bh_stem7_dgrad_c1": [P, P, P, POINTER(BhConvDesc), P],
     "bh_stem7_dgrad_c1_warp": [P, P, P, POINTER(BhConvDesc), P, P, P, c_int, P, P],
+    "bh_stem7_fwd_warp": [P, P, c_int, P, P, P, POINTER(BhConvDesc), P, P, P, c_int, P],
     "bh_stem7_wgrad": [P, P, P, POINTER(BhConvDesc), P, ctypes.c_size_t, P],
     "bh_conv_wgrad": [P, P, P, P, POINTER(BhConvDesc), P],
     "bh_conv_wgrad_det": [P, P, P, P, POINTER(BhConvDesc), P, c_int64, P],

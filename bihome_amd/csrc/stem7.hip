@@ -32,6 +32,11 @@ struct Stem7Args {
     // separate bn_stats pass over the 134 MB output is gone)
     double* bn_sums;
     int groups, imgs_per_group, det;
+    // stem7_fwd_f16_kernel<1, true> (round 6): x is not read - the input image is the homography warp of wsrc, made while the patch is fetched
+    const float* wsrc;     // [N][1][Hi][Wi] source patches
+    const double* H64;     // [N][9]
+    float* warped;         // [N][1][Hi][Wi] the warped image (every pixel written once, by the workgroup that owns its tile) or NULL
+    float* cov;            // [N][Hi/4][Wi/4] 4 x 4 average of the warped all-ones mask, or NULL
 };
 
 template <int CIN>
@@ -152,9 +157,19 @@ __global__ void __launch_bounds__(256) stem7_fwd_kernel(Stem7Args a) {
 //     the patch's k PER TILE from the maximum of the 21 x 21 pixels the workgroup has just fetched (wave maxima through LDS behind the
 //     barrier the staging needs anyway) - no magnitude record of the input images is needed, and a dark tile keeps its bits.
 // Same tiles, same epilogue (bias, ReLU, BatchNorm sums) as stem7_fwd_kernel.
+//
+// WARP (one plane; round 6): the image is the homography warp of a source patch (src/data/utils.py:54-59 via PerceptualHead.py:371-401)
+// and this stem is its consumer (:377,398).  The fetch of a tile's 21 x 21 patch - which runs one tile ahead, behind the MFMAs of the
+// current one - makes the warped pixels instead of loading them: the pixel's tap (warp_tap.h: the arithmetic of warp_fwd4_kernel, bitwise),
+// four gathered source pixels, the blend.  The 16 x 16 pixels a tile owns are written to `warped` by their workgroup (the image stays
+// available to the caller; nobody reads it back on this path) and their bilinear weight sums go through 1 KB of LDS into the 4 x 4
+// averages of the pooled all-ones mask (PerceptualHead.py:380-382,447-459), summed in warp_fwd4_kernel's order: the coverage is bitwise
+// what that kernel writes.  The 5-pixel rim of the patch is warped again by the neighbouring tiles (441 / 256 of the taps) - VALU and L2
+// gathers in the shadow of the matrix pipe; warp_fwd4_kernel's launch (~12 us for 17 MB: latency-bound) is gone.
 typedef _Float16 st_f16x8 __attribute__((ext_vector_type(8)));
-template <int CIN>
-__global__ void __launch_bounds__(256) stem7_fwd_f16_kernel(Stem7Args a) {
+template <int CIN, bool WARP = false>
+__global__ void __launch_bounds__(256) stem7_fwd_f16_kernel(Stem7Args a, const double* __restrict__ Hp /* = a.H64 (WARP) */) {
+    static_assert(!WARP || CIN == 1, "the warp is folded into the one-plane stem only");
     constexpr int ROWS = 7 * CIN;                       // tap rows (c, ky)
     constexpr int KS = (ROWS + 1) / 2;                  // k-steps of two tap rows
     constexpr int PW = 21, PP = 22;                     // patch width, row pitch in halfs (a row starts 4-byte aligned)
@@ -213,19 +228,51 @@ __global__ void __launch_bounds__(256) stem7_fwd_f16_kernel(Stem7Args a) {
     constexpr int PCH = PW * PW;
     constexpr int NPF = (CIN * PCH + 255) / 256;
     float pf[NPF];
+    // WARP: the four gathered source pixels and their weights stay in registers until the top of the next tile (the gathers fly behind the
+    // MFMAs and the epilogue of the current one, like the plain loads; no branch around them - a pixel outside the image or past the patch
+    // gathers at an out-of-range offset, which a buffer load answers with 0, and carries zero weights)
+    float pt[WARP ? NPF : 1][4], pwt[WARP ? NPF : 1][4];
+    float pw[WARP ? NPF : 1];                           // the pixel's bilinear weight sum (the warped all-ones mask)
+    float* const cw = reinterpret_cast<float*>(red + 256);      // WARP: [16][16] weight sums of the tile's own pixels (1 KB behind `red`)
+    const unsigned plane = (unsigned)a.Hi * (unsigned)a.Wi;
+    Hf Hnext = {};
+    if constexpr (WARP) Hnext = load_h(Hp + (size_t)((int)blockIdx.x < a.ntiles ? (int)blockIdx.x / a.tiles_per_img : 0) * 9);
     auto fetch = [&](int tile_) {
         const int img_ = tile_ / a.tiles_per_img, t_ = tile_ - img_ * a.tiles_per_img;
         const int ty_ = t_ / a.tiles_x, tx_ = t_ - ty_ * a.tiles_x;
         const int iy0 = ty_ * 16 - 3, ix0 = tx_ * 16 - 3;
+        if constexpr (WARP) {
+            const bool live = tile_ < a.ntiles;
+            const int im = live ? img_ : 0;
+            const Hf Hm = Hnext;                        // (loaded one tile ahead: below)
+            const __amdgpu_buffer_rsrc_t rs = plane_rsrc(a.wsrc + (size_t)im * plane, plane * 4u);
 #pragma unroll
-        for (int j = 0; j < NPF; ++j) {
-            const int i = tid + j * 256;
-            const int c = i / PCH, r = i - c * PCH, yy = r / PW, xx = r - yy * PW;
-            const int iy = iy0 + yy, ix = ix0 + xx;
-            float v = 0.f;
-            if (tile_ < a.ntiles && i < CIN * PCH && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi)
-                v = a.x[(((size_t)img_ * CIN + c) * a.Hi + iy) * a.Wi + ix];
-            pf[j] = v;
+            for (int j = 0; j < NPF; ++j) {
+                const int i = tid + j * 256;
+                const int yy = i / PW, xx = i - yy * PW;
+                const int iy = iy0 + yy, ix = ix0 + xx;
+                const bool ok = live && i < PCH && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+                const Tap4 tp = make_tap4(Hm, ix, iy, a.Wi, a.Hi);
+                float w00, w01, w10, w11, ws_;
+                tap_weights(tp, w00, w01, w10, w11, ws_);
+                pwt[j][0] = ok ? w00 : 0.f; pwt[j][1] = ok ? w01 : 0.f; pwt[j][2] = ok ? w10 : 0.f; pwt[j][3] = ok ? w11 : 0.f;
+                pt[j][0] = ldtap(rs, ok ? tp.o00 : 0xFFFFFFFFu); pt[j][1] = ldtap(rs, ok ? tp.o01 : 0xFFFFFFFFu);
+                pt[j][2] = ldtap(rs, ok ? tp.o10 : 0xFFFFFFFFu); pt[j][3] = ldtap(rs, ok ? tp.o11 : 0xFFFFFFFFu);
+            }
+            // the homography of the tile after this one: nine (wave-uniform) loads whose latency would otherwise sit in front of the taps
+            const int nx = tile_ + (int)gridDim.x;
+            Hnext = load_h(Hp + (size_t)(nx < a.ntiles ? nx / a.tiles_per_img : 0) * 9);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NPF; ++j) {
+                const int i = tid + j * 256;
+                const int c = i / PCH, r = i - c * PCH, yy = r / PW, xx = r - yy * PW;
+                const int iy = iy0 + yy, ix = ix0 + xx;
+                float v = 0.f;
+                if (tile_ < a.ntiles && i < CIN * PCH && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi)
+                    v = a.x[(((size_t)img_ * CIN + c) * a.Hi + iy) * a.Wi + ix];
+                pf[j] = v;
+            }
         }
     };
     fetch(blockIdx.x);
@@ -236,6 +283,13 @@ __global__ void __launch_bounds__(256) stem7_fwd_f16_kernel(Stem7Args a) {
             if (grp != cur_grp) { if (cur_grp >= 0) flush_stats(); cur_grp = grp; }
         }
         const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+        if constexpr (WARP) {
+#pragma unroll
+            for (int j = 0; j < NPF; ++j) {
+                pf[j] = tap_blend(pt[j][0], pt[j][1], pt[j][2], pt[j][3], pwt[j][0], pwt[j][1], pwt[j][2], pwt[j][3]);
+                pw[j] = tap_wsum(pwt[j][0], pwt[j][1], pwt[j][2], pwt[j][3]);
+            }
+        }
         // the tile's maximum: wave maxima through LDS behind the barrier that also ends the previous tile's fragment reads
         float m = 0.f;
 #pragma unroll
@@ -256,9 +310,31 @@ __global__ void __launch_bounds__(256) stem7_fwd_f16_kernel(Stem7Args a) {
                 const _Float16 l = (_Float16)__builtin_fmaf(pf[j], sx, -(float)h);
                 ph[(c * PW + yy) * PP + xx] = h;
                 ph[PLANE + (c * PW + yy) * PP + xx] = l;
+                if constexpr (WARP) {
+                    if ((unsigned)(yy - 3) < 16u && (unsigned)(xx - 3) < 16u) {      // the 16 x 16 pixels this tile owns
+                        cw[(yy - 3) * 16 + (xx - 3)] = pw[j];
+                        if (a.warped) a.warped[(size_t)img * plane + (unsigned)(ty * 16 + yy - 3) * (unsigned)a.Wi + (tx * 16 + xx - 3)] = pf[j];
+                    }
+                }
             }
         }
         __syncthreads();
+        if constexpr (WARP) {
+            if (a.cov && tid < 16) {
+                // a 4 x 4 cell in warp_fwd4_kernel's order: rows left to right, then (r0 + r1) + (r2 + r3)
+                const int cy = tid >> 2, cx = tid & 3;
+                float rr[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float* q = cw + (4 * cy + r) * 16 + 4 * cx;
+                    float cv = 0.0f;
+                    cv += q[0]; cv += q[1]; cv += q[2]; cv += q[3];
+                    rr[r] = cv;
+                }
+                a.cov[(size_t)img * (a.Hi / 4) * (a.Wi / 4) + (size_t)(ty * 4 + cy) * (a.Wi / 4) + tx * 4 + cx] =
+                    ((rr[0] + rr[1]) + (rr[2] + rr[3])) * (1.0f / 16.0f);
+            }
+        }
         fetch(tile + (int)gridDim.x);
         f32x16 acc;
 #pragma unroll
@@ -305,21 +381,21 @@ __global__ void __launch_bounds__(256) stem7_fwd_f16_kernel(Stem7Args a) {
     if (a.bn_sums && cur_grp >= 0) flush_stats();
 }
 
-template <int CIN>
+template <int CIN, bool WARP = false>
 static int stem7_f16_launch(const Stem7Args& a, hipStream_t s) {
     constexpr int KS = (7 * CIN + 1) / 2;
-    const size_t lds = (size_t)2 * KS * 4096 + ((2 * CIN * 21 * 22 * 2 + 15) & ~15) + 16 + 2048;
-    if (bh_query("stem7_fwd_f16_kernel<%d>", CIN)) return BH_OK;
+    const size_t lds = (size_t)2 * KS * 4096 + ((2 * CIN * 21 * 22 * 2 + 15) & ~15) + 16 + 2048 + (WARP ? 1024 : 0);
+    if (bh_query(WARP ? "stem7_fwd_f16_kernel<%d,true>" : "stem7_fwd_f16_kernel<%d>", CIN)) return BH_OK;
     static unsigned long long attr_devs = 0;
     if (bh_device_once(attr_devs)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem7_fwd_f16_kernel<CIN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem7_fwd_f16_kernel<CIN, WARP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
     const int per_cu = lds > 40 * 1024 ? (lds > 80 * 1024 ? 1 : 2) : 4;
     int blocks = 256 * per_cu;
     if (blocks > a.ntiles) blocks = a.ntiles;
-    hipLaunchKernelGGL((stem7_fwd_f16_kernel<CIN>), dim3(blocks), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((stem7_fwd_f16_kernel<CIN, WARP>), dim3(blocks), dim3(256), lds, s, a, a.H64);
     BH_LAUNCH_CHECK();
     return BH_OK;
 }
@@ -372,6 +448,26 @@ int bh_stem7_try(const float* x, const float* w, const float* bias, float* y, co
     if (rc) return rc;
     *taken = 1;
     return BH_OK;
+}
+
+// The one-plane stem on the homography warp of src (stem7_fwd_f16_kernel<1, true> above): y = conv(warp(src, H)), the warped image and the
+// pooled coverage written on the way (either may be NULL).  BH_E_UNSUPPORTED unless the fp16-piece stem applies and pool == 4.
+extern "C" int bh_stem7_fwd_warp(const float* src, const double* H64, int pool, const float* w, const float* bias, float* y,
+                                 const bh_conv_desc* d, float* warped, float* cov, double* bn_sums, int groups, void* stream) {
+    if (!src || !H64 || !w || !y || !d) return BH_E_BADARG;
+    if ((d->route & BH_ROUTE_NO_STEM7) || d->transposed || d->kh != 7 || d->kw != 7 || d->stride != 2 || d->pad != 3 || d->Co != 64 ||
+        d->out_nchw || d->Ci != 1 || d->Ho % 8 || d->Wo % 8 || d->Ho * 2 != d->Hi || d->Wo * 2 != d->Wi)
+        return BH_E_UNSUPPORTED;
+    if (d->precision != 4 || !g_stem_f16 || pool != 4 || (long long)d->Hi * d->Wi * 4 >= (1ll << 31)) return BH_E_UNSUPPORTED;
+    if (bn_sums && (groups < 1 || d->N % groups)) return BH_E_BADARG;
+    Stem7Args a = {};
+    a.x = nullptr; a.w = w; a.bias = bias; a.y = y; a.relu = 0;
+    a.bn_sums = bn_sums; a.groups = groups > 0 ? groups : 1; a.imgs_per_group = d->N / a.groups; a.det = (d->route & BH_ROUTE_DETERMINISTIC) ? 1 : 0;
+    a.N = d->N; a.Hi = d->Hi; a.Wi = d->Wi; a.Ho = d->Ho; a.Wo = d->Wo;
+    a.tiles_x = d->Wo / 8; a.tiles_per_img = (d->Ho / 8) * a.tiles_x; a.ntiles = d->N * a.tiles_per_img;
+    a.wsrc = src; a.H64 = H64; a.warped = warped; a.cov = cov;
+    if (a.ntiles < 256) return BH_E_UNSUPPORTED;
+    return stem7_f16_launch<1, true>(a, bh_stream(stream));
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -227,8 +227,9 @@ __global__ void __launch_bounds__(256) warp_fwd4_kernel(const float* __restrict_
         for (int i = 0; i < 4; ++i) {
             const Tap4 t = make_tap4(H, xq + i, y, w, h);
             o00[i] = t.o00; o01[i] = t.o01; o10[i] = t.o10; o11[i] = t.o11;
-            w00[i] = t.wx0 * t.wy0; w01[i] = t.wx1 * t.wy0; w10[i] = t.wx0 * t.wy1; w11[i] = t.wx1 * t.wy1;
-            cv += w00[i] + w01[i] + w10[i] + w11[i];
+            float ws_;
+            tap_weights(t, w00[i], w01[i], w10[i], w11[i], ws_);
+            cv += ws_;
         }
         if (img) {
             for (int c = 0; c < C; ++c) {
@@ -237,11 +238,7 @@ __global__ void __launch_bounds__(256) warp_fwd4_kernel(const float* __restrict_
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float p00 = ldtap(rs, o00[i]), p01 = ldtap(rs, o01[i]), p10 = ldtap(rs, o10[i]), p11 = ldtap(rs, o11[i]);
-                    float acc = p00 * w00[i];
-                    acc += p01 * w01[i];
-                    acc += p10 * w10[i];
-                    acc += p11 * w11[i];
-                    o[i] = acc;
+                    o[i] = tap_blend(p00, p01, p10, p11, w00[i], w01[i], w10[i], w11[i]);
                 }
                 *reinterpret_cast<float4*>(out + ((size_t)b * C + c) * plane + (unsigned)y * (unsigned)w + xq) = make_float4(o[0], o[1], o[2], o[3]);
             }

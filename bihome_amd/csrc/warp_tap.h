@@ -20,6 +20,7 @@ struct Tap4 {
 };
 
 __device__ __forceinline__ Tap4 make_tap4(const Hf& H, int x, int y, int w, int h) {
+#pragma clang fp contract(off)      // (only the fused multiply-adds that are written out: u - floor(u) after u = qx * iz is one the compiler would make)
     Tap4 t;
     const float fxp = (float)x, fyp = (float)y;
     // (spelled as fused multiply-adds in ONE order: every kernel that includes this header - forward, adjoint, the stem dgrad's folded
@@ -49,6 +50,26 @@ __device__ __forceinline__ Tap4 make_tap4(const Hf& H, int x, int y, int w, int 
     t.o10 = (t.vx0 && t.vy1) ? (unsigned)(o + w4) : 0xFFFFFFFFu;
     t.o11 = (t.vx1 && t.vy1) ? (unsigned)(o + w4 + 4) : 0xFFFFFFFFu;
     return t;
+}
+
+// the blend of the four taps, spelled out for the same reason: warp_fwd4_kernel and the stem forward that makes its own warped pixels
+// (stem7_fwd_f16_kernel<1, true>) produce bitwise the same image
+__device__ __forceinline__ void tap_weights(const Tap4& t, float& w00, float& w01, float& w10, float& w11, float& wsum) {
+#pragma clang fp contract(off)
+    w00 = t.wx0 * t.wy0; w01 = t.wx1 * t.wy0; w10 = t.wx0 * t.wy1; w11 = t.wx1 * t.wy1;
+    wsum = ((w00 + w01) + w10) + w11;      // the warped all-ones mask at this pixel
+}
+__device__ __forceinline__ float tap_wsum(float w00, float w01, float w10, float w11) {
+#pragma clang fp contract(off)
+    return ((w00 + w01) + w10) + w11;
+}
+__device__ __forceinline__ float tap_blend(float p00, float p01, float p10, float p11, float w00, float w01, float w10, float w11) {
+#pragma clang fp contract(off)
+    float acc = p00 * w00;
+    acc = __builtin_fmaf(p01, w01, acc);
+    acc = __builtin_fmaf(p10, w10, acc);
+    acc = __builtin_fmaf(p11, w11, acc);
+    return acc;
 }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const float* p, unsigned bytes) {

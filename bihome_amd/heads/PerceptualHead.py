@@ -64,6 +64,7 @@ class AuxiliaryResnet(nn.Module):
     """PerceptualHead.py:15-76 for AUXILIARY_RESNET='resnet34', AUXILIARY_RESNET_OUTPUT_LAYER 1..4 (:24-33,:62-67).
     Output is NHWC [N, h/s, w/s, C] with (s, C) = (4, 64), (8, 128), (16, 256), (32, 512) - the layout the triplet
     kernel reads."""
+    keep_warped = False        # True: the loss nodes also write the warped patches (head.last["warped"]) when the stem makes them itself
 
     def __init__(self, **kwargs):
         super().__init__()
@@ -206,6 +207,36 @@ def _extractor_dgrad_into_warp(aux, featw, wl, gfeatw, src, H64, gcov, pool, gH)
         K.warp_bwd(src, H64, gwarp.contiguous(), gcov, pool, gH=gH)
 
 
+def _extractor_of_warp(aux, src, H64, pool, groups, want_cov=True):
+    """warped, cov, wl, featw = the homography warp of src (PerceptualHead.py:371,392 `_warp` -> src/data/utils.py:54-59), the pooled
+    coverage of the warped all-ones mask (:380-382,447-459), and the extractor's features of the warped image as a differentiable function
+    of it (:377,398).  Round 6: where the extractor's stem kernel applies (one-channel patches, default arithmetic, pool 4) the warp is made
+    INSIDE the stem's forward launch (the Runner's `input_source` -> kernels.conv_fwd warp_src -> bh_stem7_fwd_warp): warp_fwd4_kernel
+    never runs, `cov` (and `warped`, when somebody wants to look at it) are written on the way, bitwise what the separate launch writes."""
+    B, C, h, w = src.shape
+    if C != 1 or not src.is_contiguous():
+        warped, cov = K.warp_fwd(src, H64, pool, want_cov=want_cov)
+        with torch.enable_grad():
+            wl = warped.detach().requires_grad_(True)
+            featw = aux(wl, groups=groups)
+        return warped, cov, wl, featw
+    warped = torch.empty_like(src)
+    cov = torch.empty(B, h // pool, w // pool, dtype=torch.float32, device=src.device) if want_cov else None
+    runner = aux._runner(1)
+    # the warped image itself has no reader on this path (the frozen extractor's stem has no weight gradient; the stem's dgrad does not
+    # need its input): the fused kernel writes it only on request (aux.keep_warped, for inspection) - `warped` is then None
+    want_image = bool(getattr(aux, "keep_warped", False)) or runner.flat is not None
+    source = dict(src=src, H64=H64, pool=pool, cov=cov, want_image=want_image, done=False, filled=False)
+    runner.input_source = source
+    try:
+        with torch.enable_grad():
+            wl = warped.detach().requires_grad_(True)
+            featw = aux(wl, groups=groups)
+    finally:
+        runner.input_source = None
+    return (warped if (want_image or not source["done"]) else None), cov, wl, featw
+
+
 @K.scoped_function
 class _BiHomELoss(torch.autograd.Function):
     """triplet_resnet_loss, double-line branch (PerceptualHead.py:320-714) for stacked directions.
@@ -226,10 +257,7 @@ class _BiHomELoss(torch.autograd.Function):
                 feat = aux(patches, groups=2)                   # :358,:367  (patch_1 then patch_2 statistics)
         H64, H32 = K.h4pt_fwd(delta, h)                          # _warp -> four_point_to_homography :237-243
         pool = aux.stride                                        # :450 downsample_factor = mask size // feature size
-        warped, cov = K.warp_fwd(patches, H64, pool)             # :371,:382,:392,:401,:447-459
-        with torch.enable_grad():
-            wl = warped.detach().requires_grad_(True)
-            featw = aux(wl, groups=2)                            # :377,:398
+        warped, cov, wl, featw = _extractor_of_warp(aux, patches, H64, pool, groups=2)      # :371-382,:392-401,:447-459
         f1, f2, f1w, f2w = feat[:B], feat[B:], featw.detach()[:B], featw.detach()[B:]
         m1w, m2w = cov[:B], cov[B:]
         M1, M2, numden = K.triplet_l1_fwd(f1, f2, f1w, f2w, m1w, m2w)      # :559-561,:609-653
@@ -278,10 +306,7 @@ class _IHomELoss(torch.autograd.Function):
         H64, H32 = K.h4pt_fwd(delta, h)                          # :371 -> four_point_to_homography
         pool = aux.stride
         p1 = patches[:B].contiguous() if n == 1 else patches[:B].repeat_interleave(n, 0)   # :352 one copy per hypothesis
-        warped, cov = K.warp_fwd(p1, H64, pool)                  # :371,:382 + downsample (:447-451)
-        with torch.enable_grad():
-            wl = warped.detach().requires_grad_(True)
-            featw = aux(wl, groups=1)                            # :377
+        warped, cov, wl, featw = _extractor_of_warp(aux, p1, H64, pool, groups=1)           # :371-382 + downsample (:447-451)
         sw = scores.contiguous() if scores is not None else None
         loss, T, numden, per = K.oneline_loss_fwd(feat[:B], feat[B:], featw.detach(), cov, head.triplet_margin, rep=n,
                                                   sample_w=sw)    # :474-533
@@ -316,10 +341,7 @@ class _WarpFeatures(torch.autograd.Function):
         delta = delta.contiguous()
         h = p1.shape[-1]
         H64, H32 = K.h4pt_fwd(delta, h)                          # _warp :237-243
-        warped, _ = K.warp_fwd(p1, H64, aux.stride, want_cov=False)   # :272
-        with torch.enable_grad():
-            wl = warped.detach().requires_grad_(True)
-            featw = aux(wl, groups=1)                            # :273
+        warped, _, wl, featw = _extractor_of_warp(aux, p1, H64, aux.stride, groups=1, want_cov=False)      # :272-273
         ctx.saved = (delta, p1, H64, featw, wl)
         ctx.pool, ctx.aux = aux.stride, aux
         head.last = {"H_4pt": H32, "warped": warped}

@@ -667,12 +667,37 @@ def bn_fwd_coeffs(stats, gamma, beta, rmean, rvar, groups, rows, C, eps, momentu
     return table
 
 
-def conv_fwd(x, w, bias, d, bn_sums=None, groups=1, res=None, relu=False, wpacked=None, amax=None):
+def conv_fwd(x, w, bias, d, bn_sums=None, groups=1, res=None, relu=False, wpacked=None, amax=None, warp_src=None):
     """wpacked: the forward buffer of WeightPacker for this conv (then `w` is only used for the byte count).
     bn_sums: zeroed float64 sums buffer - the conv also accumulates the batch statistics of its output for the
     BatchNorm that follows (bn_fwd(..., stats=bn_sums, stats_ready=True)).  res / relu: inference epilogue
-    y = act(conv + bias + res) (BatchNorm folded into w, bias by the caller)."""
+    y = act(conv + bias + res) (BatchNorm folded into w, bias by the caller).
+    warp_src (round 6; the extractor's one-plane stem only): dict(src, H64, pool, cov[, want_image]) - x is an UNFILLED buffer for the
+    homography warp of `src`; where the fused kernel applies, the stem makes the warped pixels itself (bh_stem7_fwd_warp: warp_src["cov"]
+    and - unless want_image is False - x are written on the way; warp_src["done"] is set), else bh_warp_fwd fills them here and the conv
+    runs as always."""
     _mark(d)
+    if warp_src is not None:
+        ws_ = warp_src
+        _chk(ws_["src"]); _chk(ws_["H64"], torch.float64); _chk(ws_["cov"]); _chk(x); _chk(w); _chk(bias); _chk(bn_sums, torch.float64)
+        B_, h_, w_ = ws_["src"].shape[0], ws_["src"].shape[-2], ws_["src"].shape[-1]
+        if (res is None and not relu and wpacked is None and amax is None and d.Ci == 1 and d.precision == F16X2 and ws_["pool"] == 4
+                and not d.transposed and d.kh == 7 and d.kw == 7 and d.stride == 2 and d.pad == 3 and d.Co == 64 and not d.out_nchw
+                and d.Ho % 8 == 0 and d.Wo % 8 == 0 and d.Ho * 2 == d.Hi and d.Wo * 2 == d.Wi and d.N * (d.Ho // 8) * (d.Wo // 8) >= 256
+                and w.is_contiguous() and os.environ.get("BIHOME_WARP_IN_STEM_FWD", "1") != "0"):
+            y = torch.empty(conv_out_shape(d), dtype=torch.float32, device=x.device)
+            with _Timed("stem7_fwd_f16_kernel<1,true>", conv_flops(d), 4.0 * (2 * x.numel() + y.numel() + w.numel())):
+                # (want_image False: nobody reads the warped image - the kernel keeps it to itself, x stays unfilled)
+                rc = lib.bh_stem7_fwd_warp(_p(ws_["src"]), _p(ws_["H64"]), 4, _p(w), _p(bias), _p(y), ctypes.byref(d),
+                                           _p(x) if ws_.get("want_image", True) else None, _p(ws_["cov"]), _p(bn_sums), groups, _stream())
+            if rc != -2:                                 # (BH_E_UNSUPPORTED: the geometry is not the fp16-piece stem's - the two calls)
+                check(rc, "bh_stem7_fwd_warp")
+                ws_["done"] = ws_["filled"] = True
+                return y
+        with _Timed("warp_fwd_kernel", 0.0, 4.0 * (2 * x.numel() + (ws_["cov"].numel() if ws_["cov"] is not None else 0))):
+            check(lib.bh_warp_fwd_f(_p(ws_["src"]), _p(ws_["H64"]), B_, 1, h_, w_, int(ws_["pool"]), _p(x), _p(ws_["cov"]), _fdet(), _stream()),
+                  "bh_warp_fwd")
+        ws_["filled"] = True
     if isinstance(x, BnOnLoad):
         # the BatchNorm in front of this conv is applied on load (packed f32x3 forward only)
         bol, x = x, x.z

@@ -299,12 +299,14 @@ def _zero_arenas(n_doubles, n_floats, device):
     return a, b
 
 
-def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, packer=None):
+def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, packer=None, input_source=None):
     """packer: kernels.WeightPacker holding fragment-ordered copies of the 3x3 weights (refreshed here, one launch, when
     a parameter changed): the halo-tiled 3x3 kernel then streams its B operand straight into registers.
     x: NHWC (or NCHW when the first conv is flagged in_nchw). Returns (out, ctx|None).
     fold_cache (inference only: not training, nothing saved): a dict - every conv whose only consumer is a BatchNorm
-    runs with that BatchNorm folded into its weights and the ReLU / residual add fused into its epilogue."""
+    runs with that BatchNorm folded into its weights and the ReLU / residual add fused into its epilogue.
+    input_source (round 6): x is an unfilled buffer - the homography warp of input_source["src"], which the conv that reads the input
+    makes on the way (kernels.conv_fwd warp_src) or has made in front of it."""
     ctx = Ctx() if save else None
     if int(precision) == K.F16X2 and (packer is None or not packer.f16):
         # the fp16-piece kernels exist for packed weights with magnitude records of their operands (the BatchNorm kernels of a
@@ -446,7 +448,8 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, p
                     fold_cache[(id(cop.mod), id(op.mod))] = (ent[0], ent[1], ent[2], pf)
                 else:
                     pf = ent[3]
-            out = K.conv_fwd(csrc, kview(wf), bf, d, res=slots[op.res] if op.res is not None else None, relu=op.relu, wpacked=pf)
+            out = K.conv_fwd(csrc, kview(wf), bf, d, res=slots[op.res] if op.res is not None else None, relu=op.relu, wpacked=pf,
+                             warp_src=input_source if cop.src == 0 else None)
         elif op.kind == "conv":
             e = op.extra
             d = _conv_geometry(op.mod, src.shape, e["in_nchw"], e["out_nchw"], precision)
@@ -455,18 +458,19 @@ def run_forward(prog, x, groups, training, save, precision=0, fold_cache=None, p
             pk = None
             if packer is not None and e["weight_fn"] is None and d.bh_packs and id(op.mod.weight) in packer.entries:
                 pk = packer.entries[id(op.mod.weight)]
+            wsrc = input_source if op.src == 0 else None
             if i in fused_stats and d.N % groups == 0:
                 b = fused_stats[i]
                 out = K.conv_fwd(src, wk, op.mod.bias, d,
                                  bn_sums=arena[bn_off[b]:bn_off[b] + K.bn_stats_doubles(groups, d.Co)], groups=groups,
-                                 wpacked=pk[1] if pk else None)
+                                 wpacked=pk[1] if pk else None, warp_src=wsrc)
                 ready.add(b)
             elif amax_next and pk is None and isinstance(op.mod, nn.ConvTranspose2d) and not e["out_nchw"]:
                 # a transposed conv in front of a packed fp16-piece 3x3 conv (the decoder units): the magnitude record of its output from
                 # its own epilogue instead of a bh_absmax pass over the (up to 268 MB) tensor
-                out = K.conv_fwd(src, wk, op.mod.bias, d, amax=amax_next())
+                out = K.conv_fwd(src, wk, op.mod.bias, d, amax=amax_next(), warp_src=wsrc)
             else:
-                out = K.conv_fwd(src, wk, op.mod.bias, d, wpacked=pk[1] if pk else None)
+                out = K.conv_fwd(src, wk, op.mod.bias, d, wpacked=pk[1] if pk else None, warp_src=wsrc)
             if save:
                 ctx.descs[i], ctx.weights[i] = d, wk
                 ctx.wpacked[i] = pk[2] if pk else None
@@ -1005,8 +1009,11 @@ class NetFunction(torch.autograd.Function):
             # about to change under the folded copies
             runner._fold.clear()
         fold = runner._fold if (runner.fold_bn and not training and not need) else None
+        source = getattr(runner, "input_source", None)
         out, saved = run_forward(runner.prog, x, groups, training, save=need, precision=runner.precision, fold_cache=fold,
-                                 packer=runner.packer_for(x.device) if fold is None else None)
+                                 packer=runner.packer_for(x.device) if fold is None else None, input_source=source)
+        if source is not None and not source.get("filled"):
+            raise RuntimeError("input_source: no conv reads the network's input directly - nobody made the warped image")
         ctx.runner, ctx.saved, ctx.want_x = runner, saved, ctx.needs_input_grad[0]
         return out
 

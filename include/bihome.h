@@ -435,6 +435,15 @@ int bh_stem7_dgrad_c1(const float* gy, const float* w, float* gx, const bh_conv_
  * (BH_F_DETERMINISTIC) use the two separate calls.  BH_E_UNSUPPORTED as bh_stem7_dgrad_c1, or when pool is not a power of two <= 32. */
 int bh_stem7_dgrad_c1_warp(const float* gy, const float* w, float* gx, const bh_conv_desc* d, const float* src, const double* H64,
                            const float* g_cov, int pool, double* gH, void* stream);
+/* Round 6: the one-plane 7x7 / 2 stem ON the homography warp of a source patch - `auxiliary_resnet(_warp(patch, H))` of
+ * src/heads/PerceptualHead.py:371-377,392-398 (warp_image: src/data/utils.py:54-59) in one launch: y[N,Ho,Wo,64] = conv(warp(src[N,1,Hi,Wi],
+ * H64[N,9])) with the fp16-piece stem kernel (d->precision = 4) making the warped pixels while it fetches its patches; warped[N,1,Hi,Wi]
+ * (the image, as bh_warp_fwd writes it - bitwise) and cov[N,Hi/4,Wi/4] (the pool-averaged warped all-ones mask, :380-382,447-459 - bitwise
+ * bh_warp_fwd's) are written on the way, either may be NULL; bn_sums / groups as bh_conv_fwd_bnstats (NULL: no statistics).  Equal to
+ * bh_warp_fwd(src, H64, N, 1, Hi, Wi, 4, warped, cov) followed by bh_conv_fwd_bnstats(warped, ...) - bitwise in y as well (the same
+ * pixels into the same arithmetic).  BH_E_UNSUPPORTED where the fp16-piece stem does not apply, or pool != 4: the caller makes the two calls. */
+int bh_stem7_fwd_warp(const float* src, const double* H64, int pool, const float* w, const float* bias, float* y, const bh_conv_desc* d,
+                      float* warped, float* cov, double* bn_sums, int groups, void* stream);
 /* Weight gradient of the backbone's 7x7 / 2 stem on TWO stacked image planes (Rethinking.py:31, ResNet34.py:17) in a dedicated kernel
  * (round 4): x[N,2,Hi,Wi] NCHW, gy[N,Ho,Wo,64] NHWC, gw[64][7][7][2] +=.  Partial sums of the persistent workgroups go through the
  * caller's workspace (bh_stem7_wgrad_ws_bytes(d) bytes, 0 = geometry not taken) and are added in workgroup order: no atomics, bitwise

@@ -417,3 +417,64 @@ def test_stem_dgrad_with_the_warp_adjoint_folded_in(K, B, size, pool, with_cov, 
     # geometries the kernel does not take are refused, not guessed
     d2 = K.conv_desc(B, size, size, 1, 64, 7, 2, 3, precision=prec)
     assert lib.bh_stem7_dgrad_c1_warp(p(gy), p(w), None, ctypes.byref(d2), p(src), p(H64), p(gcov), 3, p(gH1), stream) == -2
+
+
+@pytest.mark.parametrize("det", [False, True])
+@pytest.mark.parametrize("B,size,groups,with_cov,with_img", [(4, 128, 2, True, True), (16, 64, 1, True, True), (40, 128, 2, True, False),
+                                                             (130, 64, 2, False, True), (6, 256, 1, True, True)])
+def test_stem_forward_with_the_warp_folded_in(K, B, size, groups, with_cov, with_img, det):
+    """Round 6 (bh_stem7_fwd_warp, include/bihome.h): the extractor's one-plane stem that makes the warped pixels while it fetches its
+    patches, against the two calls it replaces - bh_warp_fwd, then bh_conv_fwd_bnstats on its output.  Same taps, same blend, the same
+    pixels into the same arithmetic: the warped image, the pooled coverage and the stem's output bit for bit; the BatchNorm sums to the
+    order of the f64 atomics (bitwise in deterministic calls)."""
+    import ctypes
+    from bihome_amd._lib import lib, check
+    rng = np.random.Generator(np.random.PCG64(B * 11 + size))
+    src = F.avg_pool2d(torch.tensor(rng.standard_normal((B, 1, size, size)).astype(np.float32)), 3, 1, 1).cuda().contiguous()
+    w = torch.tensor((rng.standard_normal((64, 7, 7, 1)) * 0.05).astype(np.float32)).cuda()
+    H64, _ = K.h4pt_fwd(dev(rand_delta(B, size + 1, amp=size / 4.0)), size)
+    H64[B // 2] = torch.tensor([1., 0, 3 * size, 0, 1, 0, 0, 0, 1], dtype=torch.float64)      # one image warped entirely out of its source
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    with K.det_scope(det):
+        d = K.conv_desc(B, size, size, 1, 64, 7, 2, 3, precision=4)
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        warped0, cov0 = K.warp_fwd(src, H64, 4)
+        s0 = K.bn_stats_buffer(groups, 64, "cuda")
+        y0 = K.conv_fwd(warped0.view(B, size, size, 1), w, None, d, bn_sums=s0, groups=groups)
+        assert K.conv_variant(d, "fwd", bn_groups=groups) == "stem7_fwd_f16_kernel<1>"
+        s1 = K.bn_stats_buffer(groups, 64, "cuda")
+        y1 = torch.full_like(y0, float("nan"))
+        warped1 = torch.full_like(warped0, float("nan")) if with_img else None
+        cov1 = torch.full_like(cov0, float("nan")) if with_cov else None
+        check(lib.bh_stem7_fwd_warp(p(src), p(H64), 4, p(w), None, p(y1), ctypes.byref(d), p(warped1), p(cov1), p(s1), groups, stream),
+              "bh_stem7_fwd_warp")
+        if with_img:
+            assert torch.equal(warped1, warped0)
+        if with_cov:
+            assert torch.equal(cov1, cov0)
+        assert torch.equal(y1, y0)
+        assert warped0[B // 2].abs().max().item() == 0.0 and (y1[B // 2] == 0).all()
+        if det:
+            assert torch.equal(s1.view(torch.int64), s0.view(torch.int64))      # (integer limbs: compared as bit patterns)
+        else:
+            assert (s1 - s0).abs().max().item() <= 1e-9 * s0.abs().max().item()
+        # through kernels.conv_fwd (what the Runner calls): the input buffer is filled on the way
+        x2 = torch.full((B, size, size, 1), float("nan"), device="cuda")
+        cov2 = torch.full_like(cov0, float("nan"))
+        source = dict(src=src, H64=H64, pool=4, cov=cov2, done=False, filled=False)
+        y2 = K.conv_fwd(x2, w, None, d, bn_sums=K.bn_stats_buffer(groups, 64, "cuda"), groups=groups, warp_src=source)
+        assert source["done"] and source["filled"]
+        assert torch.equal(y2, y0) and torch.equal(x2.view_as(warped0), warped0) and torch.equal(cov2, cov0)
+        # ... and where the fused kernel does not apply (fp32-input MFMA stem; pool 8) the two calls are made inside
+        for prec, pool in ((0, 4), (4, 8)):
+            dd = K.conv_desc(B, size, size, 1, 64, 7, 2, 3, precision=prec)
+            x3 = torch.full((B, size, size, 1), float("nan"), device="cuda")
+            cov3 = torch.full((B, size // pool, size // pool), float("nan"), device="cuda")
+            source = dict(src=src, H64=H64, pool=pool, cov=cov3, done=False, filled=False)
+            y3 = K.conv_fwd(x3, w, None, dd, bn_sums=K.bn_stats_buffer(groups, 64, "cuda"), groups=groups, warp_src=source)
+            assert source["filled"] and not source["done"]
+            wref, cref = K.warp_fwd(src, H64, pool)
+            assert torch.equal(x3.view_as(wref), wref) and torch.equal(cov3, cref)
+            yref = K.conv_fwd(wref.view(B, size, size, 1), w, None, dd, bn_sums=K.bn_stats_buffer(groups, 64, "cuda"), groups=groups)
+            assert torch.equal(y3, yref)
+        assert lib.bh_stem7_fwd_warp(p(src), p(H64), 8, p(w), None, p(y1), ctypes.byref(d), None, None, None, 1, stream) == -2

@@ -29,8 +29,8 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d 
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${T}_fetch -o ${T} -- python3 bench.py --no-alt --steps 6 --warmup 2 --no-cpu-baseline --no-overlap > $O/tmp.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${T}_write -o ${T} -- python3 bench.py --no-alt --steps 6 --warmup 2 --no-cpu-baseline --no-overlap > $O/tmp.log 2>&1
 cp $(find $O/${T}_kt -name "*kernel_stats.csv" | head -1) $O/${T}_kernel_stats.csv
-# (round 6) the same trace with the warp's adjoint as its own launch again: the plain stem dgrad's duration, for tools/hbm_path_from_csv.py
-BIHOME_WARP_IN_STEM_DGRAD=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_kt2 -o ${T} -- python3 bench.py --no-alt --steps 20 --warmup 5 --no-cpu-baseline --no-overlap --no-roofline > $O/${T}_kt2.log 2>&1
+# (round 6) the same trace with the warp and its adjoint as their own launches again: the plain stem dgrad's duration, for tools/hbm_path_from_csv.py
+BIHOME_WARP_IN_STEM_DGRAD=0 BIHOME_WARP_IN_STEM_FWD=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_kt2 -o ${T} -- python3 bench.py --no-alt --steps 20 --warmup 5 --no-cpu-baseline --no-overlap --no-roofline > $O/${T}_kt2.log 2>&1
 cp $(find $O/${T}_kt2 -name "*kernel_stats.csv" | head -1) $O/${T}_kernel_stats_unfolded.csv
 python3 tools/hbm_path_from_csv.py $O/${T}_kernel_stats.csv $O/${T}_kernel_stats_unfolded.csv > $O/${T}_hbm_path.txt 2>&1
 python3 tools/mfma_busy_summary.py $(find $O/${T}_mfma -name "*counter_collection.csv" | head -1) $O/${T}_mfma_busy.json

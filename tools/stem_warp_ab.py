@@ -30,3 +30,18 @@ def bench(fn, n=60):
     return 1e3 * a.elapsed_time(b) / n
 for rnd in range(3):
     print("round %d: plain stem dgrad %.1f us | with the warp adjoint folded in %.1f us | plain + warp_bwd %.1f us" % (rnd, bench(plain), bench(fused), bench(two)), flush=True)
+# the forward side (bh_stem7_fwd_warp; fp16-piece stem only): plain stem forward on a resident image | the stem making the warped pixels |
+# warp_fwd + plain stem forward
+if d.precision == 4:
+    y = [torch.empty(B, size // 2, size // 2, 64, device='cuda') for _ in range(NSET)]
+    warped = torch.empty(B, 1, size, size, device='cuda'); cov = torch.empty(B, size // 4, size // 4, device='cuda')
+    sums = K.bn_stats_buffer(2, 64, 'cuda')
+    def fplain(i): check(lib.bh_conv_fwd_bnstats(p(src[i]), p(w), None, p(y[i]), ctypes.byref(d), p(sums), 2, st()), "fwd plain")
+    def ffused(i): check(lib.bh_stem7_fwd_warp(p(src[i]), p(H64), 4, p(w), None, p(y[i]), ctypes.byref(d), p(warped), p(cov), p(sums), 2, st()), "fwd fused")
+    def ffused_noimg(i): check(lib.bh_stem7_fwd_warp(p(src[i]), p(H64), 4, p(w), None, p(y[i]), ctypes.byref(d), None, p(cov), p(sums), 2, st()), "fwd fused")
+    def ftwo(i):
+        check(lib.bh_warp_fwd_f(p(src[i]), p(H64), B, 1, size, size, 4, p(warped), p(cov), 0, st()), "warp_fwd")
+        check(lib.bh_conv_fwd_bnstats(p(warped), p(w), None, p(y[i]), ctypes.byref(d), p(sums), 2, st()), "fwd plain")
+    for rnd in range(3):
+        print("round %d: plain stem fwd %.1f us | with the warp folded in %.1f us (without the image write %.1f) | warp_fwd + plain %.1f us"
+              % (rnd, bench(fplain), bench(ffused), bench(ffused_noimg), bench(ftwo)), flush=True)
