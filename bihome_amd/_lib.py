@@ -179,6 +179,7 @@ ROUTE_DETERMINISTIC, BN_DETERMINISTIC, F_DETERMINISTIC = 128, 32, 1
 ROUTE_C3_PC = 512
 ROUTE_WX3_PC = 1024       # include/bihome.h BH_ROUTE_WX3_PC
 ROUTE_WX3_SHARED = 2048   # include/bihome.h BH_ROUTE_WX3_SHARED             # ... the persistent kernel for every launch it supports (default: where it is the faster one)
+ROUTE_GEMM_X3 = 4096         # include/bihome.h BH_ROUTE_GEMM_X3: the generic kernel in three bf16 pieces (precision 2 / 4), opt-in
 ROUTE_C3_TILE_WG = 256        # precision-4 3x3 fwd / dgrad on the one-workgroup-per-tile halo kernel instead of the persistent one
 
 

@@ -168,6 +168,31 @@ __device__ __forceinline__ void bh_split8(const float4& u, const float4& v, uint
 #endif
 }
 
+// four floats -> the four bf16 of each piece (the generic implicit-GEMM kernel stages float4s), and one float (its transposed B path)
+__device__ __forceinline__ void bh_split4(const float4& u, uint2& hi, uint2& mid, uint2& lo) {
+    const float x[4] = {u.x, u.y, u.z, u.w};
+    unsigned h[2], m[2], l[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const unsigned b0 = __builtin_bit_cast(unsigned, x[2 * e]), b1 = __builtin_bit_cast(unsigned, x[2 * e + 1]);
+        h[e] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+        const bh_f32x2 r = {x[2 * e] - __builtin_bit_cast(float, b0 & 0xFFFF0000u), x[2 * e + 1] - __builtin_bit_cast(float, b1 & 0xFFFF0000u)};
+        m[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bh_bf16x2));
+        const bh_f32x2 t = {r[0] - __builtin_bit_cast(float, m[e] << 16), r[1] - __builtin_bit_cast(float, m[e] & 0xFFFF0000u)};
+        l[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bh_bf16x2));
+    }
+    hi = make_uint2(h[0], h[1]); mid = make_uint2(m[0], m[1]); lo = make_uint2(l[0], l[1]);
+}
+__device__ __forceinline__ void bh_split1(float x, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
+    const unsigned b = __builtin_bit_cast(unsigned, x);
+    hi = (unsigned short)(b >> 16);
+    const float r = x - __builtin_bit_cast(float, b & 0xFFFF0000u);
+    const __bf16 m = (__bf16)r;
+    mid = __builtin_bit_cast(unsigned short, m);
+    const float t = r - (float)m;
+    lo = __builtin_bit_cast(unsigned short, (__bf16)t);
+}
+
 // X2 ("f32x2": bh_conv_desc.precision = 3): two bf16 pieces per operand, both ROUNDED to nearest even (v_cvt_pk_bf16_f32):
 // x = hi + mid + e with |e| <= 2^-18 |x| and zero mean, and a product a*b is evaluated as hi*hi + hi*mid + mid*hi (three MFMAs;
 // the dropped mid*mid is <= 2^-18 |a*b| as well).  Error ~4e-6 per product: ~13x the fp32 rounding, ~500x below the bf16-operand

@@ -42,6 +42,7 @@ struct GemmArgs {
     long long src_elems, bw_elems;   // tensor sizes (host side: buffer descriptors)
     int prio;              // experiment: s_setprio(1) around the MFMA block
     int bf16;              // operands rounded to bf16 (fp32 accumulate) where the vectorised path applies
+    int x3;                // operands cut exactly into three bf16 pieces, six products (fp32 accuracy; X3 template form) where that path applies
     int ek, eC;            // scatter: kernel (== stride) and real channel count (Nn = ek*ek*eC)
     int ewshift, ehwshift; // log2(Wo), log2(Ho*Wo) when both are powers of two (epilogue pixel decode by shifts), else -1
     int etap0;             // scatter: tap index of column 0 (a parity class of a strided dgrad writes ONE tap position)
@@ -59,11 +60,18 @@ struct GemmArgs {
     const float* bni;
     int bni_relu, bni_rpg;
     unsigned* amax_out;      // optional magnitude record of the output (common.h F16X2): max |value stored|, one atomic max per workgroup
+    // round 6: nz > 0 - ONE launch for nz problems that differ only in their B operand and tap set (the parity classes of a stride-2
+    // dgrad, bh_conv_dgrad_s2): workgroup z = blockIdx.z takes (Bw, T, kw, etap0, bw_bytes) from these tables
+    int nz;
+    const float* Bw_z[4];
+    long long sBn_z[4];
+    int T_z[4], kw_z[4], etap0_z[4];
+    unsigned bw_bytes_z[4];
 };
 
 
-__device__ __forceinline__ bool src_coord(const GemmArgs& a, int oy, int ox, int t, int& iy, int& ix) {
-    const int ky = t / a.kw, kx = t - ky * a.kw;
+__device__ __forceinline__ bool src_coord(const GemmArgs& a, int kw, int oy, int ox, int t, int& iy, int& ix) {
+    const int ky = t / kw, kx = t - ky * kw;
     if (!a.adjoint) {
         iy = oy * a.stride - a.pad + ky;
         ix = ox * a.stride - a.pad + kx;
@@ -81,8 +89,21 @@ __device__ __forceinline__ bool src_coord(const GemmArgs& a, int oy, int ox, int
 
 // BUF: the buffer-descriptor loader (GemmArgs::use_buf) as a compile-time switch, so that the instantiation that runs
 // does not also carry the pointer-based loader's prologue (VALU work is paid at MFMA price on this chip)
-template <int BM, int BN, int BK, bool VEC, bool BF16 = false, bool BUF = false>
-__global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
+template <int BM, int BN, int BK, bool VEC, bool BF16 = false, bool BUF = false, bool X3 = false>
+__global__ void __launch_bounds__(256) conv_gemm_kernel(const GemmArgs a) {
+    // the B operand and tap set of THIS workgroup's problem (a.nz > 0: one of nz problems in the launch, chosen by blockIdx.z).  Scalars
+    // picked with constant indices: writing to the by-value argument struct, or indexing its tables with blockIdx.z, puts the whole
+    // struct into scratch memory - every later a.field a scratch load (measured: every instantiation of this kernel 1.5-3x slower)
+    const float* zBw = a.Bw;
+    int zT = a.T, zkw = a.kw, zetap0 = a.etap0;
+    unsigned zbw_bytes = a.bw_bytes;
+    long long zsBn = a.sBn;
+    if (a.nz) {
+        const int z = blockIdx.z;
+#define BH_ZSEL(f) (z == 0 ? a.f[0] : z == 1 ? a.f[1] : z == 2 ? a.f[2] : a.f[3])
+        zBw = BH_ZSEL(Bw_z); zT = BH_ZSEL(T_z); zkw = BH_ZSEL(kw_z); zetap0 = BH_ZSEL(etap0_z); zbw_bytes = BH_ZSEL(bw_bytes_z); zsBn = BH_ZSEL(sBn_z);
+#undef BH_ZSEL
+    }
     constexpr int WN = (BN >= 64) ? 2 : 1;         // waves along N
     constexpr int WM = 4 / WN;                     // waves along M
     static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "tile/wave mismatch");
@@ -98,14 +119,22 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
     // accumulate on v_mfma_f32_32x32x16_bf16): tiles are row-major [row][BK + 8] bf16 - the 80-byte row stride makes
     // the ds_read_b128 fragment reads bank-conflict free and the float4 -> bf16x4 staging writes need no transpose.
     static_assert(!BF16 || (VEC && BK == 32), "bf16 operand mode needs the vectorised loader and BK = 32");
+    // X3 (round 6; with BF16): fp32 accuracy on that pipe - every operand is cut EXACTLY into three bf16 pieces while staging (common.h X3,
+    // the arithmetic of the 3x3 layers' f32x3 mode), three LDS planes per operand, six products per product (total order <= 2, small
+    // ones first): 2.67x less matrix-pipe time than v_mfma_f32_32x32x2_f32.  The layers that run here in the fp32-accurate modes - strided
+    // 3x3 convs and their parity-class dgrads, 128-channel transposed convs, 1x1 convs off the streaming kernel - were bound by the fp32 pipe.
+    static_assert(!X3 || BF16, "the three-piece mode is a form of the bf16 operand mode");
+    constexpr int NPL = X3 ? 3 : 1;
     constexpr int LDH = BK + 8;
+    constexpr int PA = BM * LDH, PB = BN * LDH;    // bf16 elements per plane
     // C4 layout (vectorised fp32 path): tiles are stored as float4 k-chunks, [BK/4][rows + 1] x float4.  One
     // ds_write_b128 stages a loaded float4 (the +1 row of padding spreads the 8 chunk-lanes of a row over all 32
     // banks), one ds_read_b128 feeds FOUR MFMAs (the two half-waves take chunks 2c and 2c+1, so MFMA step j
     // multiplies k = 8c + j and 8c + 4 + j; any pairing of k is valid for a sum over k).
     constexpr bool C4 = VEC && !BF16;
-    constexpr int A_FLOATS = BF16 ? (BM * LDH / 2) : (C4 ? CH * (BM + 1) * 4 : BK * LDA);
-    constexpr int B_FLOATS = BF16 ? (BN * LDH / 2) : (C4 ? CH * (BN + 1) * 4 : BK * LDB_N);
+    constexpr bool B4 = C4 || X3;                  // N-contiguous B: the lanes-along-k thread mapping (conflict-free transposing LDS writes)
+    constexpr int A_FLOATS = BF16 ? NPL * (BM * LDH / 2) : (C4 ? CH * (BM + 1) * 4 : BK * LDA);
+    constexpr int B_FLOATS = BF16 ? NPL * (BN * LDH / 2) : (C4 ? CH * (BN + 1) * 4 : BK * LDB_N);
     __shared__ __attribute__((aligned(16))) float As[A_FLOATS];
     __shared__ __attribute__((aligned(16))) float Bs[B_FLOATS];
     __bf16* Ah = reinterpret_cast<__bf16*>(As);
@@ -159,7 +188,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int kchunks = (a.Kc + BK - 1) / BK;
-    const int ktiles = VEC ? a.T * kchunks : (a.T * a.Kc + BK - 1) / BK;   // scalar path: K linear over (t, c)
+    const int ktiles = VEC ? zT * kchunks : (zT * a.Kc + BK - 1) / BK;   // scalar path: K linear over (t, c)
 
     float4 ra[AIT], rb[BIT];
     float4 bt0 = make_float4(1.f, 0.f, 1.f, 0.f), bt1 = bt0;      // a.bni: (scale, shift) of the four channels of this thread's A chunk
@@ -179,7 +208,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
 #pragma unroll
     for (int i = 0; i < BIT_K; ++i) {
         int n = n0 + bk_row0 + i * AROWS;
-        b_rowptr[i] = ((bk_row0 + i * AROWS) < BN && n < a.Nn) ? a.Bw + (long long)n * a.sBn + bk_chunk * 4 : nullptr;
+        b_rowptr[i] = ((bk_row0 + i * AROWS) < BN && n < a.Nn) ? zBw + (long long)n * zsBn + bk_chunk * 4 : nullptr;
     }
 
     // ---- buffer-load fast path (use_buf): every A row keeps ONE 32-bit byte offset (its anchor pixel) and a bit
@@ -193,15 +222,15 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
     __amdgpu_buffer_rsrc_t rsA, rsB;
     if constexpr (VEC && BUF) {
         rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Src), 0, a.src_bytes, 0x00020000);
-        rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Bw), 0, a.bw_bytes, 0x00020000);
+        rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(zBw), 0, zbw_bytes, 0x00020000);
 #pragma unroll
         for (int i = 0; i < AIT; ++i) {
             const int pix = (int)a_base[i] + a_ay[i] * a.Ws + a_ax[i];
             a_voff[i] = ((unsigned)pix * (unsigned)a.Cs + (unsigned)(a_chunk * 4)) * 4u;
             unsigned long long mk = 0;
             int t = 0;
-            for (int ky = 0; ky * a.kw < a.T; ++ky)
-                for (int kx = 0; kx < a.kw; ++kx, ++t) {
+            for (int ky = 0; ky * zkw < zT; ++ky)
+                for (int kx = 0; kx < zkw; ++kx, ++t) {
                     const int iy = a.adjoint ? a_ay[i] - ky : a_ay[i] + ky, ix = a.adjoint ? a_ax[i] - kx : a_ax[i] + kx;
                     if (a_ok[i] && (unsigned)iy < (unsigned)a.Hs && (unsigned)ix < (unsigned)a.Ws) mk |= 1ull << t;
                 }
@@ -210,12 +239,12 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
 #pragma unroll
         for (int i = 0; i < BIT_K; ++i) {
             const int n = n0 + bk_row0 + i * AROWS;
-            bK_voff[i] = ((bk_row0 + i * AROWS) < BN && n < a.Nn) ? (unsigned)((long long)n * a.sBn + bk_chunk * 4) * 4u : OOB;
+            bK_voff[i] = ((bk_row0 + i * AROWS) < BN && n < a.Nn) ? (unsigned)((long long)n * zsBn + bk_chunk * 4) * 4u : OOB;
         }
         if constexpr (C4 || BF16) {
 #pragma unroll
             for (int i = 0; i < BIT; ++i) {
-                if (C4) {
+                if (B4) {
                     const int chn = b4_c0 + i * C4_CPP, n = n0 + chn * 4;
                     bN_voff[i] = (i < BIT_N4 && chn < NCH && n < a.Nn) ? (unsigned)((long long)b4_k * a.sBc + n) * 4u : OOB;
                 } else {
@@ -253,12 +282,12 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
                 }
             } else {
                 const unsigned toffB = (unsigned)((long long)t * a.sBt + (long long)c0 * a.sBc) * 4u;
-                constexpr int NB = C4 ? BIT_N4 : BIT_N;
-                const bool cokB = c0 + (C4 ? b4_k : 0) < a.Kc;
+                constexpr int NB = B4 ? BIT_N4 : BIT_N;
+                const bool cokB = c0 + (B4 ? b4_k : 0) < a.Kc;
 #pragma unroll
                 for (int i = 0; i < NB; ++i) {
                     bool ok = cokB && bN_voff[i] != OOB;
-                    if (!C4) ok = ok && (c0 + bn_row0 + i * BROWS_N < a.Kc);
+                    if (!B4) ok = ok && (c0 + bn_row0 + i * BROWS_N < a.Kc);
                     const v4i32 v = __builtin_amdgcn_raw_buffer_load_b128(rsB, ok ? bN_voff[i] + toffB : OOB, 0, 0);
                     rb[i] = __builtin_bit_cast(float4, v);
                 }
@@ -266,7 +295,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
             nx_c0 += BK;
             if (nx_c0 >= a.Kc) {
                 nx_c0 = 0; ++nx_t;
-                if (++nx_kx == a.kw) { nx_kx = 0; ++nx_ky; }
+                if (++nx_kx == zkw) { nx_kx = 0; ++nx_ky; }
             }
             }
         } else if (VEC) {
@@ -308,14 +337,14 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
                     if (b_rowptr[i] && cok) v = *reinterpret_cast<const float4*>(b_rowptr[i] + toff);
                     rb[i] = v;
                 }
-            } else if constexpr (C4) {
+            } else if constexpr (B4) {
                 const int c2 = c0 + b4_k;
 #pragma unroll
                 for (int i = 0; i < BIT_N4; ++i) {
                     const int chn = b4_c0 + i * C4_CPP, n = n0 + chn * 4;
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (chn < NCH && c2 < a.Kc) {
-                        const float* p = a.Bw + t * a.sBt + (long long)c2 * a.sBc + n;
+                        const float* p = zBw + t * a.sBt + (long long)c2 * a.sBc + n;
                         if (n + 3 < a.Nn) v = *reinterpret_cast<const float4*>(p);
                         else {
                             if (n < a.Nn) v.x = p[0];
@@ -333,7 +362,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
                     int c2 = c0 + kr;
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (kr < BK && c2 < a.Kc) {
-                        const float* p = a.Bw + t * a.sBt + (long long)c2 * a.sBc + n;
+                        const float* p = zBw + t * a.sBt + (long long)c2 * a.sBc + n;
                         if (n + 3 < a.Nn) v = *reinterpret_cast<const float4*>(p);
                         else {
                             if (n < a.Nn) v.x = p[0];
@@ -348,11 +377,11 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
             nx_c0 += BK;
             if (nx_c0 >= a.Kc) {
                 nx_c0 = 0; ++nx_t;
-                if (++nx_kx == a.kw) { nx_kx = 0; ++nx_ky; }
+                if (++nx_kx == zkw) { nx_kx = 0; ++nx_ky; }
             }
         } else {
             // scalar path (tiny channel counts / NCHW network input): k = t*Kc + c decoded per element
-            const int Ktot = a.T * a.Kc;
+            const int Ktot = zT * a.Kc;
             const int k0 = kt * BK + a_chunk * 4;
 #pragma unroll
             for (int i = 0; i < AIT; ++i) {
@@ -362,7 +391,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
                     int k = k0 + j;
                     if (a_ok[i] && k < Ktot) {
                         int t = k / a.Kc, c = k - t * a.Kc, iy, ix;
-                        if (src_coord(a, a_oy[i], a_ox[i], t, iy, ix)) {
+                        if (src_coord(a, zkw, a_oy[i], a_ox[i], t, iy, ix)) {
                             size_t off = a.src_nchw ? ((((size_t)a_n[i] * a.Cs + c) * a.Hs + iy) * a.Ws + ix)
                                                     : ((((size_t)a_n[i] * a.Hs + iy) * a.Ws + ix) * a.Cs + c);
                             e[j] = a.Src[off];
@@ -382,7 +411,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
                         int k = kb0 + j;
                         if (k < Ktot) {
                             int t = k / a.Kc, c = k - t * a.Kc;
-                            e[j] = a.Bw[t * a.sBt + (long long)c * a.sBc + (long long)n * a.sBn];
+                            e[j] = zBw[t * a.sBt + (long long)c * a.sBc + (long long)n * zsBn];
                         }
                     }
                 }
@@ -392,7 +421,49 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
     };
 
     auto store_tile = [&]() {
-        if constexpr (BF16) {
+        if constexpr (BF16 && X3) {
+#pragma unroll
+            for (int i = 0; i < AIT; ++i) {
+                const int row = a_row0 + i * AROWS;
+                uint2 h, m, l;
+                bh_split4(ra[i], h, m, l);
+                *reinterpret_cast<uint2*>(&Ah[row * LDH + a_chunk * 4]) = h;
+                *reinterpret_cast<uint2*>(&Ah[PA + row * LDH + a_chunk * 4]) = m;
+                *reinterpret_cast<uint2*>(&Ah[2 * PA + row * LDH + a_chunk * 4]) = l;
+            }
+            if (a.b_kcontig) {
+#pragma unroll
+                for (int i = 0; i < BIT_K; ++i) {
+                    const int row = bk_row0 + i * AROWS;
+                    if (row < BN) {
+                        uint2 h, m, l;
+                        bh_split4(rb[i], h, m, l);
+                        *reinterpret_cast<uint2*>(&Bh[row * LDH + bk_chunk * 4]) = h;
+                        *reinterpret_cast<uint2*>(&Bh[PB + row * LDH + bk_chunk * 4]) = m;
+                        *reinterpret_cast<uint2*>(&Bh[2 * PB + row * LDH + bk_chunk * 4]) = l;
+                    }
+                }
+            } else {
+                // (lanes along k, as the fp32 C4 layout stages this orientation: consecutive lanes write consecutive halfs of one row)
+                unsigned short* const Bu = reinterpret_cast<unsigned short*>(Bh);
+#pragma unroll
+                for (int i = 0; i < BIT_N4; ++i) {
+                    const int chn = b4_c0 + i * C4_CPP;
+                    if (chn < NCH) {
+                        const float e[4] = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            unsigned short h, m, l;
+                            bh_split1(e[q], h, m, l);
+                            Bu[(chn * 4 + q) * LDH + b4_k] = h;
+                            Bu[PB + (chn * 4 + q) * LDH + b4_k] = m;
+                            Bu[2 * PB + (chn * 4 + q) * LDH + b4_k] = l;
+                        }
+                    }
+                }
+            }
+            return;
+        } else if constexpr (BF16) {
 #pragma unroll
             for (int i = 0; i < AIT; ++i) {
                 const int row = a_row0 + i * AROWS;
@@ -494,7 +565,34 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
         if (!(a.prio & 4) || kt == 0) store_tile();           // (ablation bits, bh_debug_force_tile(-1, x): 2 = no reloads, 4 = no restaging)
         __syncthreads();
         if (kt + 1 < ktiles && !(a.prio & 2)) load_tile(kt + 1);
-        if constexpr (BF16) {
+        if constexpr (BF16 && X3) {
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc)
+                        af[i][pc] = *reinterpret_cast<const bf16x8*>(&Ah[pc * PA + ((wm * TM + i) * 32 + l31) * LDH + ks * 16 + kh2 * 8]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc)
+                        bf[j][pc] = *reinterpret_cast<const bf16x8*>(&Bh[pc * PB + ((wn * TN + j) * 32 + l31) * LDH + ks * 16 + kh2 * 8]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        // the six products of total order <= 2, small ones first (0 = hi, 1 = mid, 2 = lo)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else if constexpr (BF16) {
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
                 bf16x8 af[TM], bf[TN];
@@ -574,7 +672,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
         const int n = n0 + (wn * TN + j) * 32 + l31;
         nok[j] = n < a.Nn;
         int co = n, tap = 0;
-        if (a.epi == 1) { tap = n / a.eC; co = n - tap * a.eC; tap += a.etap0; }
+        if (a.epi == 1) { tap = n / a.eC; co = n - tap * a.eC; tap += zetap0; }
         cco[j] = co; ctap[j] = tap;
         bvj[j] = (a.bias && nok[j]) ? a.bias[co] : 0.0f;
     }
@@ -733,17 +831,17 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmArgs a) {
     }
 }
 
-template <int BM, int BN, int BK, bool VEC, bool BF16 = false>
+template <int BM, int BN, int BK, bool VEC, bool BF16 = false, bool X3 = false>
 static int launch(const GemmArgs& a, hipStream_t s) {
-    if (bh_query("conv_gemm_kernel<%d,%d,%d,%s,%s,%s>", BM, BN, BK, VEC ? "true" : "false", BF16 ? "true" : "false",
-                 (VEC && a.use_buf) ? "true" : "false"))
+    if (bh_query(X3 ? "conv_gemm_kernel<%d,%d,%d,%s,%s,%s,true>" : "conv_gemm_kernel<%d,%d,%d,%s,%s,%s>", BM, BN, BK, VEC ? "true" : "false",
+                 BF16 ? "true" : "false", (VEC && a.use_buf) ? "true" : "false"))
         return BH_OK;
-    dim3 grid((a.M + BM - 1) / BM, (a.Nn + BN - 1) / BN);
+    dim3 grid((a.M + BM - 1) / BM, (a.Nn + BN - 1) / BN, a.nz ? a.nz : 1);
     if constexpr (VEC) {
-        if (a.use_buf) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, VEC, BF16, true>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, VEC, BF16, false>), grid, dim3(256), 0, s, a);
+        if (a.use_buf) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, VEC, BF16, true, X3>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, VEC, BF16, false, X3>), grid, dim3(256), 0, s, a);
     } else {
-        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, VEC, BF16, false>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, VEC, BF16, false, X3>), grid, dim3(256), 0, s, a);
     }
     BH_LAUNCH_CHECK();
     return BH_OK;
@@ -751,6 +849,8 @@ static int launch(const GemmArgs& a, hipStream_t s) {
 
 // Tile choice: the largest tile that still gives the 256 CUs about two workgroups each; the small-spatial
 // layers (8x8x256ch, 16x16x128ch at 2B = 128) otherwise launch only 128-256 workgroups.
+BH_KNOB(g_s2_merge, 1);            // (tuning build, hook -49: the parity classes of a stride-2 dgrad in one launch / one launch each)
+BH_KNOB(g_gemm_x3, 1);             // (tuning build, hook -48: the three-piece form of this kernel in the fp32-accurate modes off / on)
 #ifdef BH_TUNING
 extern int g_wgrad_target, g_wgrad_noflush, g_wgrad_xcd_map, g_wgrad_s1, g_wgrad_s1_target, g_wgrad_s3_target;
 static int g_force_bm = 0, g_force_bn = 0, g_prio = 0, g_no_buf = 0;     // tuning hook (bh_debug_force_tile), 0 = automatic
@@ -778,6 +878,7 @@ static int dispatch(const GemmArgs& a_in, hipStream_t s) {
     if (a.bni && !a.use_buf) return BH_E_UNSUPPORTED;
     a.src_bytes = (unsigned)(a.src_elems * 4);
     a.bw_bytes = (unsigned)(a.bw_elems * 4);
+    for (int z = 0; z < a.nz; ++z) a.bw_bytes_z[z] = (unsigned)((long long)a.Nn * a.T_z[z] * a.Kc * 4);      // (class-packed [Nn][T][Kc])
     {
         const long long oe = a.epi == 1 ? (long long)a.M * a.ek * a.ek * a.eC : (long long)a.M * a.Nn;
         a.out_bytes = (oe > 0 && oe < (1ll << 29)) ? (unsigned)(oe * 4) : 0u;
@@ -795,6 +896,17 @@ static int dispatch(const GemmArgs& a_in, hipStream_t s) {
         if (bm == 128 && bn == 64) return launch<128, 64, 32, true, true>(a, s);
         if (bm == 128 && bn == 32) return launch<128, 32, 32, true, true>(a, s);
         return BH_E_UNSUPPORTED;
+    }
+    if (vec && a.x3 && !a.bf16 && !a.bni && (a.Kc % 32) == 0 && g_gemm_x3) {
+        // fp32-accurate modes (bh_conv_desc.precision 2 / 4), round 6: three exact bf16 pieces per operand, six products - the tiles of the
+        // fp32 path (64-row tiles: latency hiding over reuse)
+        if (a.Nn > 64) {
+            const long long nt = (a.Nn + 127) / 128, mt64 = (a.M + 63) / 64;
+            if (a.Nn >= 256 && mt64 * nt >= 512) return launch<64, 128, 32, true, true, true>(a, s);
+            return launch<64, 64, 32, true, true, true>(a, s);
+        }
+        if (a.Nn > 32) return launch<64, 64, 32, true, true, true>(a, s);
+        return launch<128, 32, 32, true, true, true>(a, s);
     }
     if (vec && g_force_bm && (a.Kc % 32) == 0) {
         const int bm = g_force_bm, bn = g_force_bn;
@@ -1014,6 +1126,8 @@ int bh_debug_force_tile(int bm, int bn) {
     if (bm == -36) { bh_wgrad_x3_tune(3, bn); return BH_OK; }            // (-36, 0 / 1): the 4 x 4-map form of the fp16-piece weight gradient off / on
     if (bm == -32) { bh_wgrad_x3_tune(2, bn); return BH_OK; }            // (-32, 0 / 1): the fp16-piece kernel's four-wave / eight-wave (producer + consumer) form
     if (bm == -20) { bh_bn_tune(bn); return BH_OK; }                     // (-20, n): workgroups per BatchNorm apply launch
+    if (bm == -49) { g_s2_merge = bn; return BH_OK; }                    // (-49, 0 / 1): stride-2 dgrad - one launch per parity class / one launch
+    if (bm == -48) { g_gemm_x3 = bn; return BH_OK; }                     // (-48, 0 / 1): the generic kernel's three-bf16-piece form in the fp32-accurate modes off / on
     if (bm == -47) { bh_stem7_tune(bn); return BH_OK; }                  // (-47, 0 / 1): the stems' fp16-piece forms (forward, one-channel dgrad) off / on
     if (bm == -14) { bh_warp_tune(0, bn); return BH_OK; }               // (-14, 1|2): warp forward rows per thread
     if (bm == -15) { bh_warp_tune(1, bn); return BH_OK; }               // (-15, 1|2|4): warp adjoint rows per thread
@@ -1067,7 +1181,7 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, cons
         if (d->out_nchw || rpg % 128 || rpg * groups > 2048ll * 64) return BH_E_UNSUPPORTED;
         a.bn_sums = bn_sums; a.bn_rpg = (int)rpg; a.bn_groups = groups; a.bn_C = d->Co; a.bn_det = (d->route & BH_ROUTE_DETERMINISTIC) ? 1 : 0;
     }
-    a.Src = x; a.Bw = w; a.bias = bias; a.Out = y; a.bf16 = d->precision == 1;
+    a.Src = x; a.Bw = w; a.bias = bias; a.Out = y; a.bf16 = d->precision == 1; a.x3 = (d->route & BH_ROUTE_GEMM_X3) && (d->precision == 2 || d->precision == 4);
     a.Hs = d->Hi; a.Ws = d->Wi; a.Cs = d->Ci; a.Kc = d->Ci;
     a.src_elems = (long long)d->N * d->Hi * d->Wi * d->Ci;
     a.bw_elems = (long long)d->Co * d->kh * d->kw * d->Ci;
@@ -1198,7 +1312,18 @@ int bh_conv_dgrad_s2(const float* gy, const float* w, float* gx, const bh_conv_d
         hipError_t e = hipMemsetAsync(gx, 0, sizeof(float) * (size_t)d->N * d->Hi * d->Wi * d->Ci, s);
         if (e != hipSuccess) return (int)e;
     }
+    // the classes are ONE launch (round 6; they were four - each a few k-tiles on 512 workgroups, latency-bound): gridDim.z = classes with
+    // at least one tap, the workgroup takes its class's packed weights and tap set from the argument tables
+    GemmArgs a = {};
+    a.Src = gy; a.bias = nullptr; a.Out = gx; a.accumulate = accumulate; a.bf16 = d->precision == 1; a.x3 = (d->route & BH_ROUTE_GEMM_X3) && (d->precision == 2 || d->precision == 4);
+    a.M = d->N * d->Ho * d->Wo; a.Nn = d->Ci; a.Kc = d->Co;
+    a.Ho = d->Ho; a.Wo = d->Wo;                 // class grid (Hi/2 x Wi/2) == gy grid
+    a.Hs = d->Ho; a.Ws = d->Wo; a.Cs = d->Co;
+    a.src_elems = (long long)d->N * d->Ho * d->Wo * d->Co;
+    a.adjoint = 0; a.stride = 1; a.pad = 0;
+    a.epi = 1; a.ek = 2; a.eC = d->Ci;
     long long base = 0;
+    int tmax = 0;
     for (int c = 0; c < 4; ++c) {
         const int py = c >> 1, px = c & 1;
         const int ky0 = (py + pad) % 2, kx0 = (px + pad) % 2;
@@ -1209,23 +1334,31 @@ int bh_conv_dgrad_s2(const float* gy, const float* w, float* gx, const bh_conv_d
             const int cy = (py + pad - ky0) / 2, cx = (px + pad - kx0) / 2;
             const int padv_y = (nty - 1) - cy, padv_x = (ntx - 1) - cx;
             if (padv_y != 0 || padv_x != 0) return BH_E_UNSUPPORTED;      // (0 for the two supported geometries)
-            GemmArgs a = {};
-            a.Src = gy; a.Bw = wpack + base; a.bias = nullptr; a.Out = gx; a.accumulate = accumulate; a.bf16 = d->precision == 1;
-            a.M = d->N * d->Ho * d->Wo; a.Nn = d->Ci; a.Kc = d->Co; a.T = nty * ntx; a.kw = ntx;
-            a.Ho = d->Ho; a.Wo = d->Wo;                 // class grid (Hi/2 x Wi/2) == gy grid
-            a.Hs = d->Ho; a.Ws = d->Wo; a.Cs = d->Co;
-            a.src_elems = (long long)d->N * d->Ho * d->Wo * d->Co;
-            a.bw_elems = (long long)d->Ci * nty * ntx * d->Co;
-            a.adjoint = 0; a.stride = 1; a.pad = 0;
-            // B[t][k = co][n = ci] = Wc[ci][t][co]
-            a.sBt = d->Co; a.sBc = 1; a.sBn = (long long)a.T * d->Co; a.b_kcontig = 1;
-            a.epi = 1; a.ek = 2; a.eC = d->Ci; a.etap0 = py * 2 + px;
-            rc = dispatch(a, s);
-            if (rc) return rc;
+            const int z = a.nz++;
+            a.Bw_z[z] = wpack + base; a.T_z[z] = nty * ntx; a.kw_z[z] = ntx; a.etap0_z[z] = py * 2 + px;
+            a.sBn_z[z] = (long long)nty * ntx * d->Co;      // B[t][k = co][n = ci] = Wc[ci][t][co]
+            if (nty * ntx > tmax) tmax = nty * ntx;
         }
         base += (long long)d->Ci * nty * ntx * d->Co;
     }
-    return BH_OK;
+    if (!a.nz) return BH_OK;
+    // (the fields the dispatcher looks at: the largest class; the kernel replaces them per workgroup)
+    a.Bw = a.Bw_z[0]; a.T = tmax; a.kw = a.kw_z[0]; a.etap0 = a.etap0_z[0];
+    a.bw_elems = (long long)d->Ci * tmax * d->Co;
+    a.sBt = d->Co; a.sBc = 1; a.sBn = a.sBn_z[0]; a.b_kcontig = 1;
+    if (!g_s2_merge) {                           // (tuning build: one launch per class, as before)
+        const int nz = a.nz;
+        GemmArgs b = a;
+        b.nz = 0;
+        for (int z = 0; z < nz; ++z) {
+            b.Bw = a.Bw_z[z]; b.T = a.T_z[z]; b.kw = a.kw_z[z]; b.etap0 = a.etap0_z[z]; b.sBn = a.sBn_z[z];
+            b.bw_elems = (long long)d->Ci * b.T * d->Co;
+            rc = dispatch(b, s);
+            if (rc) return rc;
+        }
+        return BH_OK;
+    }
+    return dispatch(a, s);
 }
 
 int bh_conv_dgrad_bnreduce(const float* gy, const float* w, float* gx, const bh_conv_desc* d, int accumulate,
@@ -1286,7 +1419,7 @@ int bh_conv_dgrad(const float* gy, const float* w, float* gx, const bh_conv_desc
     }
     GemmArgs a = {};
     a.src_nchw = d->out_nchw;                         // gradient of the NCHW network output
-    a.Src = gy; a.Bw = w; a.bias = nullptr; a.Out = gx; a.accumulate = accumulate; a.bf16 = d->precision == 1;
+    a.Src = gy; a.Bw = w; a.bias = nullptr; a.Out = gx; a.accumulate = accumulate; a.bf16 = d->precision == 1; a.x3 = (d->route & BH_ROUTE_GEMM_X3) && (d->precision == 2 || d->precision == 4);
     a.M = d->N * d->Hi * d->Wi; a.Nn = d->Ci; a.Kc = d->Co; a.T = d->kh * d->kw;
     a.Ho = d->Hi; a.Wo = d->Wi;               // output-side grid of this GEMM = conv input grid
     a.Hs = d->Ho; a.Ws = d->Wo; a.Cs = d->Co;  // gathered source = gy grid

@@ -875,7 +875,7 @@ def conv_dgrad(gy, w, d, out=None, bn_reduce=None, wkey=None, wpacked=None, cols
         if out is None:
             out = torch.empty((d.N, d.Hi, d.Wi, d.Ci), dtype=torch.float32, device=gy.device)
         wpack = torch.empty(w.numel(), dtype=torch.float32, device=gy.device)
-        nlaunch = 5 if d.kh == 3 else (2 + (0 if acc else 1))
+        nlaunch = 2 if d.kh == 3 else (2 + (0 if acc else 1))         # (weight pack + ONE launch for the parity classes: round 6)
         with _Timed("conv_dgrad_s2(%d kernels)" % nlaunch + (" N%d %dx%d C%d->%d k%d" % (d.N, d.Hi, d.Wi, d.Ci, d.Co, d.kh) if TIMING_DETAIL else ""),
                     conv_flops(d) / 4.0 * (1.0 if d.kh == 1 else 1.0), 4.0 * (gy.numel() + out.numel() * (2 if acc else 1) + 2 * w.numel())):
             check(lib.bh_conv_dgrad_s2(_p(gy), _p(w), _p(out), ctypes.byref(d), int(acc), _p(wpack), _stream()), "bh_conv_dgrad_s2")

@@ -276,6 +276,11 @@ int bh_absmax(const float* x, long long n, float* record, void* stream);
 #define BH_ROUTE_WX3_SHARED 2048    /* wgrad, split-operand 3x3 kernels: the launch shares the GPU with another stream - 160 workgroups instead of one
                                      * per CU (fewer, longer workgroups: the other stream's launches start at once on the free CUs, and the split-K
                                      * partial blocks shrink with the workgroup count).  Same-box in-step A/B, round 5: -0.19 ms per two-stream step */
+#define BH_ROUTE_GEMM_X3 4096       /* fwd / dgrad, precision 2 / 4, round 6: layers that run on the generic implicit-GEMM kernel (strided and 1x1 convs,
+                                     * 128- / 256-channel transposed convs, their dgrads) cut their operands exactly into three bf16 pieces and make six
+                                     * products per product (the arithmetic of the f32x3 3x3 kernels) instead of running the fp32-input MFMA: error against
+                                     * float64 <= the fp32-input MFMA's (tests/test_conv_kernels_gpu.py), those launches ~10 % shorter, the step 0.05 ms.
+                                     * Opt-in: without it these layers are bit-identical to precision 0. */
 
 /* One 3x3 layer's weights for bh_conv3x3_pack: w[Co][3][3][Ci] (Co, Ci multiples of 32) -> pf (forward operand order) and
  * pd (dgrad operand order: transposed, taps flipped), Co*9*Ci floats each (split: 1.5x that); either may be NULL. */

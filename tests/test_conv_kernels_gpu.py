@@ -340,6 +340,57 @@ def test_fused_tail_fwd_bwd(K, groups, N, H, Ci, Cm, Co, training, sparse):
     close(gb2.cpu(), b2t.grad, 1e-5)
 
 
+def _err(a, ref):
+    a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    return np.abs(a - ref).max() / (np.abs(ref).max() + 1e-30)
+
+
+@pytest.mark.parametrize("prec", [2, 4])
+@pytest.mark.parametrize("N,Hi,Ci,Co,k,s,p,T,scale", [
+    (4, 32, 64, 128, 3, 2, 1, False, 1.0), (4, 16, 128, 256, 3, 2, 1, False, 1.0), (2, 32, 64, 128, 1, 2, 0, False, 1.0),
+    (3, 16, 256, 128, 1, 1, 0, False, 1.0), (4, 16, 128, 128, 2, 2, 0, True, 1.0), (4, 16, 128, 64, 2, 2, 0, True, 1.0),
+    (2, 8, 256, 256, 2, 2, 0, True, 1.0), (4, 32, 64, 128, 3, 2, 1, False, 1e-6), (4, 16, 128, 64, 2, 2, 0, True, 3e4)])
+def test_generic_kernel_in_three_bf16_pieces(K, N, Hi, Ci, Co, k, s, p, T, scale, prec):
+    """Round 6 (BH_ROUTE_GEMM_X3, opt-in): in the fp32-accurate modes (bh_conv_desc.precision 2 / 4) the generic implicit-GEMM kernel -
+    strided and 1x1 convs, 128- and 256-channel transposed convs, their dgrads - cuts its operands exactly into three bf16 pieces and makes
+    six products per product (conv_gemm_kernel<...,true,true,true>) instead of running the fp32-input MFMA.  Error against float64 no worse than the fp32-input
+    MFMA's on the same data (both ~1e-7 of the largest output: the fp32 accumulate), at ordinary, tiny and large magnitudes."""
+    x = rnd((N, Ci, Hi, Hi), 150) * scale
+    if T:
+        w = (rnd((Ci, Co, k, k), 151) / np.sqrt(Ci)).astype(np.float32)
+    else:
+        w = (rnd((Co, Ci, k, k), 151) / np.sqrt(Ci * k * k)).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    ref = F.conv_transpose2d(xt, wt, None, stride=2) if T else F.conv2d(xt, wt, None, stride=s, padding=p)
+    gy = rnd(tuple(ref.shape), 152)
+    ref.backward(torch.tensor(gy, dtype=torch.float64))
+    xg = torch.tensor(x).permute(0, 2, 3, 1).contiguous().cuda()
+    wg = torch.tensor(w).permute(0, 2, 3, 1).contiguous().cuda()
+    gyg = torch.tensor(gy).permute(0, 2, 3, 1).contiguous().cuda()
+    errs = {}
+    from bihome_amd._lib import ROUTE_GEMM_X3
+    for pr in (0, prec):
+        d = K.conv_desc(N, Hi, Hi, Ci, Co, k, s, p, transposed=T, precision=pr, route=ROUTE_GEMM_X3)
+        if pr:       # (without the route bit these layers stay on the fp32-input MFMA, bit for bit precision 0)
+            assert K.conv_variant(K.conv_desc(N, Hi, Hi, Ci, Co, k, s, p, transposed=T, precision=pr), "fwd") == \
+                K.conv_variant(K.conv_desc(N, Hi, Hi, Ci, Co, k, s, p, transposed=T, precision=0), "fwd")
+        y = K.conv_fwd(xg, wg, None, d)
+        gx = K.conv_dgrad(gyg, wg, d)
+        errs[pr] = (_err(y.cpu().permute(0, 3, 1, 2), ref.detach()), _err(gx.cpu().permute(0, 3, 1, 2), xt.grad))
+        if pr:
+            for which in ("fwd", "dgrad"):
+                v = K.conv_variant(d, which)
+                # conv_gemm_kernel<BM,BN,BK,VEC,BF16,BUF,X3>
+                assert all(part.startswith("conv_gemm_kernel<") and len(part.split(",")) == 7 and part.endswith(",true>")
+                           for part in v.split("+") if "pack" not in part), v
+    print("MEASURED generic kernel N%d %dx%d C%d->%d k%d s%d%s x%g: fp32-input MFMA fwd %.2e dgrad %.2e | three bf16 pieces (precision %d) fwd %.2e dgrad %.2e"
+          % (N, Hi, Hi, Ci, Co, k, s, " T" if T else "", scale, errs[0][0], errs[0][1], prec, errs[prec][0], errs[prec][1]))
+    for i in range(2):
+        assert errs[prec][i] <= 1.5 * errs[0][i] + 2e-8, errs
+        assert errs[prec][i] < 2e-6
+
+
 @pytest.mark.parametrize("N,Hi,Ci,Co,k,s,p", [(2, 32, 64, 64, 3, 1, 1), (2, 16, 128, 256, 3, 2, 1), (3, 8, 256, 256, 3, 1, 1),
                                               (2, 16, 256, 128, 1, 1, 0)])
 def test_bf16_operand_mode(K, N, Hi, Ci, Co, k, s, p):
