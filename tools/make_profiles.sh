@@ -37,4 +37,4 @@ python3 tools/mfma_busy_summary.py $(find $O/${T}_mfma -name "*counter_collectio
 python3 tools/pmc_summary.py $(find $O/${T}_fetch -name "*counter_collection.csv" | head -1) $(find $O/${T}_write -name "*counter_collection.csv" | head -1) $O/${T}_pmc_traffic.json
 rm -rf $O/${T}_kt $O/${T}_kt2 $O/${T}_mfma $O/${T}_fetch $O/${T}_write $O/tmp.log
 ls -la $O | grep ${T}_
-for f in $O/${T}_bench*.json; do python3 -c "import json,sys; j=json.load(open(sys.argv[1])); print(sys.argv[1], j['ms_per_step'], round(j['value'],1), j['roofline']['kernel'], round(j['roofline']['frac'],3))" $f; done
+for f in $O/${T}_bench*.json; do python3 -c "import json,sys; j=json.load(open(sys.argv[1])); r=j.get('roofline') or {}; print(sys.argv[1], j['ms_per_step'], round(j['value'],1), r.get('kernel'), round(r.get('frac') or 0,3))" $f; done
