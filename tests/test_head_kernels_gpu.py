@@ -478,3 +478,33 @@ def test_stem_forward_with_the_warp_folded_in(K, B, size, groups, with_cov, with
             yref = K.conv_fwd(wref.view(B, size, size, 1), w, None, dd, bn_sums=K.bn_stats_buffer(groups, 64, "cuda"), groups=groups)
             assert torch.equal(y3, yref)
         assert lib.bh_stem7_fwd_warp(p(src), p(H64), 8, p(w), None, p(y1), ctypes.byref(d), None, None, None, 1, stream) == -2
+
+
+def test_extractor_of_warp_keeps_the_image_only_on_request(K):
+    """heads/PerceptualHead._extractor_of_warp (round 6): with the warp made inside the extractor stem's forward nobody reads the warped
+    patches - they are written only when `AuxiliaryResnet.keep_warped` asks for them; coverage and features are the same either way and
+    equal those of the two separate calls (BIHOME_WARP_IN_STEM_FWD=0 at the kernel level: kernels.conv_fwd without warp_src)."""
+    from bihome_amd.heads import PerceptualHead as PH
+    torch.manual_seed(3)
+    aux = PH.AuxiliaryResnet(AUXILIARY_RESNET_OUTPUT_LAYER=1).cuda().train()
+    B, size = 8, 128
+    src = torch.rand(B, 1, size, size, device="cuda")
+    H64, _ = K.h4pt_fwd(dev(rand_delta(B, size + 1, amp=size / 4.0)), size)
+    warped0, cov0 = K.warp_fwd(src, H64, aux.stride)
+    with torch.no_grad():
+        feat0 = aux(warped0, groups=2)
+    for keep in (False, True):
+        aux.keep_warped = keep
+        warped, cov, wl, featw = PH._extractor_of_warp(aux, src, H64, aux.stride, groups=2)
+        assert torch.equal(cov, cov0) and torch.equal(featw.detach(), feat0)
+        assert featw.requires_grad and wl.requires_grad
+        if keep:
+            assert torch.equal(warped, warped0)
+        else:
+            assert warped is None
+    # three-channel patches take the two calls
+    src3 = torch.rand(4, 3, size, size, device="cuda")
+    H3, _ = K.h4pt_fwd(dev(rand_delta(4, size + 1, amp=size / 4.0)), size)
+    warped, cov, wl, featw = PH._extractor_of_warp(aux, src3, H3, aux.stride, groups=1)
+    w3, c3 = K.warp_fwd(src3, H3, aux.stride)
+    assert torch.equal(warped, w3) and torch.equal(cov, c3)
